@@ -1,0 +1,157 @@
+"""Generate tests/golden/*.npz from an implementation that is INDEPENDENT of the oracle.
+
+Run in the build container only:  python oracle/make_golden.py
+
+The reference (/root/reference/src/nomad_audio/nomad.py) cannot be imported here (fairseq,
+torchaudio and the network download of its weights are all unavailable).  What is importable is
+HuggingFace ``transformers``' ``Wav2Vec2Model`` - a separate implementation of the same upstream
+wav2vec 2.0 BASE architecture that fairseq implements.  This script loads the SAME seeded
+parameter set (``nomad_amd.weights.seeded_state_dict``) into that model through the published
+fairseq->HF key map, runs the reference's head (nomad.py:228-230) and SciPy's ``cdist`` /
+``np.mean`` (nomad.py:108-111) on top, and stores inputs/outputs as small fixtures.  Neither
+``transformers`` nor anything under /root/reference travels with the fixtures.
+
+Fixtures written (data only):
+  tests/golden/wavs/*.wav          the reference's six example clips (data/nmr-data, data/test-data)
+  tests/golden/hf_example_wavs.npz embeddings (6,256), 2x4 distance matrix + means, per-layer checksums
+  tests/golden/hf_tiny.npz         batch of 3 synthetic clips of 6000 samples: full 12 layer outputs + embeddings
+  tests/golden/hf_loss.npz         nomad.forward() oracle pins: two (2,1,16384) inputs -> loss (HF layers + torch L1)
+"""
+import os
+import shutil
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from nomad_amd.weights import seeded_state_dict  # noqa: E402
+
+REF = "/root/reference"
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def hf_model_from_state_dict(sd):
+    from transformers import Wav2Vec2Config, Wav2Vec2Model
+    cfg = Wav2Vec2Config()  # defaults == wav2vec2-base
+    cfg.apply_spec_augment = False
+    m = Wav2Vec2Model(cfg).eval()
+    hf = {}
+    p = "ssl_model."
+    for i in range(7):
+        hf[f"feature_extractor.conv_layers.{i}.conv.weight"] = sd[p + f"feature_extractor.conv_layers.{i}.0.weight"]
+    hf["feature_extractor.conv_layers.0.layer_norm.weight"] = sd[p + "feature_extractor.conv_layers.0.2.weight"]
+    hf["feature_extractor.conv_layers.0.layer_norm.bias"] = sd[p + "feature_extractor.conv_layers.0.2.bias"]
+    hf["feature_projection.layer_norm.weight"] = sd[p + "layer_norm.weight"]
+    hf["feature_projection.layer_norm.bias"] = sd[p + "layer_norm.bias"]
+    hf["feature_projection.projection.weight"] = sd[p + "post_extract_proj.weight"]
+    hf["feature_projection.projection.bias"] = sd[p + "post_extract_proj.bias"]
+    hf["encoder.pos_conv_embed.conv.bias"] = sd[p + "encoder.pos_conv.0.bias"]
+    hf["encoder.pos_conv_embed.conv.parametrizations.weight.original0"] = sd[p + "encoder.pos_conv.0.weight_g"]
+    hf["encoder.pos_conv_embed.conv.parametrizations.weight.original1"] = sd[p + "encoder.pos_conv.0.weight_v"]
+    hf["encoder.layer_norm.weight"] = sd[p + "encoder.layer_norm.weight"]
+    hf["encoder.layer_norm.bias"] = sd[p + "encoder.layer_norm.bias"]
+    for l in range(12):
+        a, b = p + f"encoder.layers.{l}.", f"encoder.layers.{l}."
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            for wb in ("weight", "bias"):
+                hf[b + f"attention.{n}.{wb}"] = sd[a + f"self_attn.{n}.{wb}"]
+        for wb in ("weight", "bias"):
+            hf[b + f"layer_norm.{wb}"] = sd[a + f"self_attn_layer_norm.{wb}"]
+            hf[b + f"feed_forward.intermediate_dense.{wb}"] = sd[a + f"fc1.{wb}"]
+            hf[b + f"feed_forward.output_dense.{wb}"] = sd[a + f"fc2.{wb}"]
+            hf[b + f"final_layer_norm.{wb}"] = sd[a + f"final_layer_norm.{wb}"]
+    hf["masked_spec_embed"] = sd[p + "mask_emb"]
+    missing, unexpected = m.load_state_dict(hf, strict=False)
+    assert not unexpected, unexpected
+    assert all("masked_spec_embed" in k for k in missing), missing
+    return m
+
+
+@torch.no_grad()
+def hf_forward(m, wav):
+    out = m(wav, output_hidden_states=True)
+    # hidden_states[0] is the encoder input (after pos-conv + LN); [1..12] are the layer outputs
+    return out.last_hidden_state, list(out.hidden_states[1:])
+
+
+def hf_head(x, w, b):
+    e = torch.nn.functional.linear(torch.relu(x.mean(1)), w, b)
+    return torch.nn.functional.normalize(e, dim=1)
+
+
+def read_wav(path):
+    from scipy.io import wavfile
+    sr, x = wavfile.read(path)
+    assert sr == 16000 and x.dtype == np.int16 and x.ndim == 1
+    return torch.from_numpy(x.astype(np.float32) / 32768.0)[None, :]
+
+
+def main():
+    from scipy.spatial.distance import cdist
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    os.makedirs(os.path.join(GOLD, "wavs", "nmr-data"), exist_ok=True)
+    os.makedirs(os.path.join(GOLD, "wavs", "test-data"), exist_ok=True)
+    names = {"nmr-data": ["FI53_04", "FL67_01", "MJ57_01", "MJ60_10"],
+             "test-data": ["445-123860-0012_NOISE_15", "6563-285357-0042_OPUS_64k"]}
+    for d, ns in names.items():
+        for n in ns:
+            shutil.copyfile(os.path.join(REF, "data", d, n + ".wav"), os.path.join(GOLD, "wavs", d, n + ".wav"))
+
+    sd = seeded_state_dict(0)
+    m = hf_model_from_state_dict(sd)
+    we, be = sd["embedding_layer.1.weight"], sd["embedding_layer.1.bias"]
+
+    # 1. the reference's own example: 2 deg x 4 ref
+    embs, checks = {}, {}
+    for d, ns in names.items():
+        for n in ns:
+            wav = read_wav(os.path.join(GOLD, "wavs", d, n + ".wav"))
+            x, layers = hf_forward(m, wav)
+            embs[n] = hf_head(x, we, be)[0].numpy()
+            checks[n] = np.array([[float(l.double().sum()), float(l.double().abs().sum())] for l in layers])
+    nmr = np.stack([embs[n] for n in names["nmr-data"]])
+    deg = np.stack([embs[n] for n in names["test-data"]])
+    dm = cdist(deg, nmr)
+    np.savez(os.path.join(GOLD, "hf_example_wavs.npz"),
+             nmr_names=np.array(names["nmr-data"]), deg_names=np.array(names["test-data"]),
+             nmr_emb=nmr, deg_emb=deg, dist=dm, mean=dm.mean(axis=1),
+             layer_checks=np.stack([checks[n] for n in names["nmr-data"] + names["test-data"]]))
+    print("example wavs: dist\n", dm, "\nmean", dm.mean(axis=1))
+
+    # 2. tiny synthetic batch with full layer outputs
+    g = torch.Generator().manual_seed(123)
+    wav = (0.1 * torch.randn(3, 6000, generator=g)).clamp(-1, 1)
+    x, layers = hf_forward(m, wav)
+    np.savez(os.path.join(GOLD, "hf_tiny.npz"), wav=wav.numpy(),
+             layers=torch.stack(layers).numpy(), emb=hf_head(x, we, be).numpy())
+
+    # 3. peaky-attention variant (qk_gain 6) on the same tiny batch
+    sd2 = seeded_state_dict(1, qk_gain=6.0)
+    m2 = hf_model_from_state_dict(sd2)
+    x, layers = hf_forward(m2, wav)
+    np.savez(os.path.join(GOLD, "hf_tiny_peaky.npz"), wav=wav.numpy(),
+             last=x.numpy(), layer0=layers[0].numpy(),
+             emb=hf_head(x, sd2["embedding_layer.1.weight"], sd2["embedding_layer.1.bias"]).numpy())
+
+    # 4. nomad.forward() pins (LossNetLayers' own embedding layer is seeded explicitly)
+    g = torch.Generator().manual_seed(7)
+    clean = (0.1 * torch.randn(2, 1, 16384, generator=g)).clamp(-1, 1)
+    est = (clean + 0.02 * torch.randn(2, 1, 16384, generator=g)).clamp(-1, 1)
+    lw = (torch.rand(256, 768, generator=g) * 2 - 1) / 768 ** 0.5
+    lb = (torch.rand(256, generator=g) * 2 - 1) / 768 ** 0.5
+    outs = []
+    for w_ in (est, clean):
+        x, layers = hf_forward(m, w_.squeeze(1))
+        outs.append(layers + [hf_head(x, lw, lb)])
+    loss = sum(torch.nn.functional.l1_loss(a, b) for a, b in zip(outs[0], outs[1]))
+    np.savez(os.path.join(GOLD, "hf_loss.npz"), estimate=est.numpy(), clean=clean.numpy(),
+             emb_w=lw.numpy(), emb_b=lb.numpy(), loss=np.float64(loss),
+             terms=np.array([float(torch.nn.functional.l1_loss(a, b)) for a, b in zip(outs[0], outs[1])]))
+    print("loss", float(loss))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,199 @@
+"""CPU oracle for the NOMAD scoring hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module.  The product (``nomad_amd``) never imports it and has no CPU fallback.
+
+What it restates (plain PyTorch fp32 on CPU; numpy float64 for the distance stage):
+
+* ``backbone``      - fairseq ``Wav2Vec2Model.forward(wav, mask=False, features_only=True)`` as
+  called at /root/reference/src/nomad_audio/nomad.py:226 and :245.  fairseq (``>=0.12.2``,
+  un-pinned above, /root/reference/requirements.txt:4) is a third-party dependency that is absent
+  from /root/reference and from the build image; the algorithm restated here is the published
+  wav2vec 2.0 BASE architecture (``wav2vec_small.pt`` config: conv_feature_layers
+  [(512,10,5)]+[(512,3,2)]*4+[(512,2,2)]*2, conv_bias=False, extractor_mode=default (GroupNorm on
+  layer 0), 768-d / 12 layers / 12 heads / FFN 3072, post-LN (layer_norm_first=False),
+  conv_pos=128, conv_pos_groups=16, GELU).  SURVEY.md section 3.2 is the op-by-op spec.
+* ``triplet_forward`` - ``TripletModel.forward`` (nomad.py:224-231).
+* ``lossnet_forward`` - ``LossNetLayers.forward`` (nomad.py:243-258).
+* ``nomad_loss``      - ``NomadLoss.forward`` (nomad.py:267-282).
+* ``pairwise``        - ``scipy.spatial.distance.cdist`` + ``np.mean(axis=1)`` (nomad.py:108-111).
+* ``load_wav``        - ``Nomad.load_processing`` for PCM wav at 16 kHz (nomad.py:192-212).
+
+PINNING STATUS.  The reference holds no programmatic golden vectors for this path; its only
+pinned values are the 3-decimal README tables (README.md:69-81), which need the real
+``nomad_best_model.pt`` (downloaded at import time by the reference; not available offline).
+The reference itself cannot be imported here (fairseq + torchaudio + network are all missing).
+The oracle is therefore pinned against an independent implementation of the same upstream
+architecture that IS importable in the build container - HuggingFace ``transformers``
+``Wav2Vec2Model`` - with identical seeded weights (``oracle/make_golden.py`` generated
+``tests/golden/*.npz`` from that model; ``tests/test_oracle.py`` re-checks it live when
+``transformers`` is importable).  Parity against the reference's own README table is
+**unpinned** until real weights are available (slot: ``tests/test_readme_table.py``).
+"""
+from __future__ import annotations
+
+import struct
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+CONV_STRIDES = (5, 2, 2, 2, 2, 2, 2)
+NUM_LAYERS = 12
+NUM_HEADS = 12
+P = "ssl_model."
+
+
+def fold_pos_conv_weight(sd: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """weight_norm(dim=2) of fairseq's pos_conv: w = v * (g / ||v||_(0,1)), g of shape (1,1,K)."""
+    v = sd[P + "encoder.pos_conv.0.weight_v"]
+    g = sd[P + "encoder.pos_conv.0.weight_g"]
+    norm = v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()
+    return v * (g / norm)
+
+
+def feature_extractor(sd: Dict[str, torch.Tensor], wav: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
+    """7-layer conv feature extractor -> (B, T, 512) (before layer_norm).  wav: (B, N) raw amplitude."""
+    x = wav[:, None, :]
+    for i, stride in enumerate(CONV_STRIDES):
+        w = sd[P + f"feature_extractor.conv_layers.{i}.0.weight"]
+        x = F.conv1d(x, w, stride=stride)
+        if i == 0:  # Fp32GroupNorm(512 groups, 512 channels), affine, eps 1e-5
+            x = F.group_norm(x, 512, sd[P + "feature_extractor.conv_layers.0.2.weight"],
+                             sd[P + "feature_extractor.conv_layers.0.2.bias"], eps=1e-5)
+        x = F.gelu(x)
+        if taps is not None:
+            taps[f"conv{i}"] = x.transpose(1, 2).contiguous()
+    return x.transpose(1, 2)
+
+
+def encoder_layer(sd: Dict[str, torch.Tensor], l: int, x: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
+    """One post-LN TransformerSentenceEncoderLayer (layer_norm_first=False), eval mode. x: (B,T,768)."""
+    q_ = P + f"encoder.layers.{l}."
+    B, T, C = x.shape
+    hd = C // NUM_HEADS
+    q = F.linear(x, sd[q_ + "self_attn.q_proj.weight"], sd[q_ + "self_attn.q_proj.bias"]) * (hd ** -0.5)
+    k = F.linear(x, sd[q_ + "self_attn.k_proj.weight"], sd[q_ + "self_attn.k_proj.bias"])
+    v = F.linear(x, sd[q_ + "self_attn.v_proj.weight"], sd[q_ + "self_attn.v_proj.bias"])
+    q = q.view(B, T, NUM_HEADS, hd).transpose(1, 2)
+    k = k.view(B, T, NUM_HEADS, hd).transpose(1, 2)
+    v = v.view(B, T, NUM_HEADS, hd).transpose(1, 2)
+    a = torch.softmax(q @ k.transpose(-1, -2), dim=-1) @ v
+    a = a.transpose(1, 2).reshape(B, T, C)
+    if taps is not None and l == 0:
+        taps["attn0"] = a
+    a = F.linear(a, sd[q_ + "self_attn.out_proj.weight"], sd[q_ + "self_attn.out_proj.bias"])
+    x = F.layer_norm(x + a, (C,), sd[q_ + "self_attn_layer_norm.weight"], sd[q_ + "self_attn_layer_norm.bias"], 1e-5)
+    h = F.gelu(F.linear(x, sd[q_ + "fc1.weight"], sd[q_ + "fc1.bias"]))
+    h = F.linear(h, sd[q_ + "fc2.weight"], sd[q_ + "fc2.bias"])
+    x = F.layer_norm(x + h, (C,), sd[q_ + "final_layer_norm.weight"], sd[q_ + "final_layer_norm.bias"], 1e-5)
+    return x
+
+
+def backbone(sd: Dict[str, torch.Tensor], wav: torch.Tensor, taps: Optional[dict] = None
+             ) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+    """wav (B,N) -> (x (B,T,768), [12 layer outputs (B,T,768)]).
+
+    The reference gets ``layer_results`` as (T,B,768) tuples and permutes them to (B,T,768)
+    (nomad.py:248); the list returned here is already in that (B,T,768) form.
+    """
+    x = feature_extractor(sd, wav, taps)
+    x = F.layer_norm(x, (512,), sd[P + "layer_norm.weight"], sd[P + "layer_norm.bias"], 1e-5)
+    x = F.linear(x, sd[P + "post_extract_proj.weight"], sd[P + "post_extract_proj.bias"])
+    if taps is not None:
+        taps["proj"] = x
+    w = fold_pos_conv_weight(sd)
+    pc = F.conv1d(x.transpose(1, 2), w, sd[P + "encoder.pos_conv.0.bias"], padding=64, groups=16)
+    pc = pc[:, :, :-1]  # SamePad: even kernel drops the last frame
+    x = x + F.gelu(pc).transpose(1, 2)
+    x = F.layer_norm(x, (768,), sd[P + "encoder.layer_norm.weight"], sd[P + "encoder.layer_norm.bias"], 1e-5)
+    if taps is not None:
+        taps["enc_in"] = x
+    layers = []
+    for l in range(NUM_LAYERS):
+        x = encoder_layer(sd, l, x, taps)
+        layers.append(x)
+    return x, layers
+
+
+def head(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """mean over time -> ReLU -> Linear(768,256) -> L2 normalise (nomad.py:228-230)."""
+    e = F.linear(F.relu(torch.mean(x, 1)), w, b)
+    return F.normalize(e, dim=1)
+
+
+def triplet_forward(sd: Dict[str, torch.Tensor], wav: torch.Tensor) -> torch.Tensor:
+    """``TripletModel.forward`` (nomad.py:224-231): wav (B,1,N) or (B,N) -> (B,256) unit-norm."""
+    if wav.dim() == 3:
+        wav = wav.squeeze(1)
+    x, _ = backbone(sd, wav)
+    return head(x, sd["embedding_layer.1.weight"], sd["embedding_layer.1.bias"])
+
+
+def lossnet_forward(sd: Dict[str, torch.Tensor], wav: torch.Tensor,
+                    emb_w: torch.Tensor, emb_b: torch.Tensor) -> List[torch.Tensor]:
+    """``LossNetLayers.forward`` (nomad.py:243-258): 12 layer outputs (B,T,768) + embedding (B,256).
+
+    ``emb_w/emb_b`` are LossNetLayers' OWN embedding layer (nomad.py:238-241), which the reference
+    never loads from the checkpoint (it stays randomly initialised) - callers inject it.
+    """
+    if wav.dim() == 3:
+        wav = wav.squeeze(1)
+    x, layers = backbone(sd, wav)
+    return list(layers) + [head(x, emb_w, emb_b)]
+
+
+def nomad_loss(nomad_ref: Sequence[torch.Tensor], nomad_test: Sequence[torch.Tensor]) -> torch.Tensor:
+    """``NomadLoss.forward`` (nomad.py:267-282): sum over 13 entries of mean |test - ref|."""
+    loss = 0.0
+    for i in range(13):
+        loss = loss + F.l1_loss(nomad_test[i], nomad_ref[i])
+    return loss
+
+
+def pairwise(test_emb: np.ndarray, nmr_emb: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """cdist (Euclidean, float64, difference form) + row mean, as nomad.py:108-111."""
+    a = np.asarray(test_emb, dtype=np.float64)
+    b = np.asarray(nmr_emb, dtype=np.float64)
+    d = np.sqrt(((a[:, None, :] - b[None, :, :]) ** 2).sum(-1))
+    return d, d.mean(axis=1)
+
+
+def load_wav(path: str) -> Tuple[np.ndarray, int]:
+    """Minimal RIFF/WAVE reader: (channels, N) float32 in [-1,1) (int16/32768 like torchaudio.load), sr."""
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:4] != b"RIFF" or data[8:12] != b"WAVE":
+        raise ValueError(f"{path}: not a RIFF/WAVE file")
+    pos = 12
+    fmt = None
+    while pos + 8 <= len(data):
+        cid = data[pos:pos + 4]
+        size = struct.unpack("<I", data[pos + 4:pos + 8])[0]
+        body = data[pos + 8:pos + 8 + size]
+        if cid == b"fmt ":
+            fmt = struct.unpack("<HHIIHH", body[:16])
+        elif cid == b"data":
+            tag, ch, sr, _, _, bits = fmt
+            if tag == 1 and bits == 16:
+                x = np.frombuffer(body, dtype="<i2").astype(np.float32) / 32768.0
+            elif tag == 1 and bits == 32:
+                x = np.frombuffer(body, dtype="<i4").astype(np.float32) / 2147483648.0
+            elif tag == 3 and bits == 32:
+                x = np.frombuffer(body, dtype="<f4").astype(np.float32)
+            else:
+                raise ValueError(f"{path}: unsupported wav format tag={tag} bits={bits}")
+            return x.reshape(-1, ch).T.copy(), sr
+        pos += 8 + size + (size & 1)
+    raise ValueError(f"{path}: no data chunk")
+
+
+def load_processing(path: str) -> torch.Tensor:
+    """``Nomad.load_processing`` (nomad.py:192-212) for 16 kHz input: (1,N) fp32 mono."""
+    x, sr = load_wav(path)
+    if x.shape[0] > 1:
+        x = ((x[0] + x[1]) / 2)[None, :]
+    if sr != 16000:
+        raise NotImplementedError("oracle covers 16 kHz input only (all reference fixtures are 16 kHz)")
+    return torch.from_numpy(np.ascontiguousarray(x))
