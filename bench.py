@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""NOMAD scoring throughput on MI355X: clips/s embedded + N x M NOMAD distances.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" (per rank) = one pass of the hot path over one batch of synthetic input (BASELINE.json
+configs[1]): 256 clips of 16 kHz x 4 s (224 degraded + 32 non-matching references) through the
+wav2vec 2.0 BASE backbone + 768->256 head in fp32, one all-gather (RCCL) of the reference
+embeddings, then this rank's (224 x 32*N) float64 distance slab + row means (the NOMAD scores).
+Per-GPU work is fixed as N grows (weak scaling); value = all ranks' clips / max-over-ranks time.
+Inputs are resident in HBM before the timed region.  Weights: real nomad_best_model.pt when present,
+otherwise a seeded random parameter set of the same architecture (no network for checkpoints).
+
+Also on the JSON line:
+  roofline      the dominant kernel (fp32 MFMA GEMM, all launches): algorithmic FLOPs / summed
+                hipEvent durations of those launches inside the timed region, vs the 157.3 TF fp32 MFMA peak
+  cpu_baseline  the CPU oracle (PyTorch fp32 restatement of the reference path, batch-1 loop like
+                nomad.py:171-183 + float64 cdist) timed on this box's host cores over a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_CLIP_4S = 56.925e9      # BASELINE.md section 2 (2*MAC, no recompute)
+FLOP_LAYERS_4S = 35.264e9        # the 12 encoder layers ("attention-GEMM" subset)
+PEAK_FP32_MFMA = 157.3e12        # MI355X_MICROARCH.md chip table
+
+
+def cpu_baseline(sd, n_samples, budget_s=15.0, max_clips=64):
+    import numpy as np
+    import torch
+    from oracle import nomad_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(0)
+    wav = (0.1 * torch.randn(max_clips, n_samples, generator=g)).clamp(-1, 1)
+    embs = []
+    with torch.no_grad():
+        O.triplet_forward(sd, wav[:1])  # warm-up
+        t0 = time.perf_counter()
+        n = 0
+        while n < max_clips and (time.perf_counter() - t0 < budget_s or n < 4):
+            embs.append(O.triplet_forward(sd, wav[n:n + 1])[0].numpy())  # batch-1 loop, like the reference
+            n += 1
+        e = np.stack(embs)
+        half = max(1, n // 8)
+        O.pairwise(e[half:], e[:half])
+        dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 3), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} clips of {n_samples} samples, batch-1 loop (as nomad.py:171-183) + float64 cdist "
+                      f"{n - half}x{half}, {dt:.1f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="clips per GPU per step")
+    ap.add_argument("--refs", type=int, default=32, help="of which non-matching references")
+    ap.add_argument("--seconds", type=float, default=4.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with hipEvents")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from nomad_amd import build
+    from nomad_amd.dist import ShardedScorer
+    from nomad_amd.engine import Engine
+    from nomad_amd.weights import find_checkpoint, load_checkpoint, num_frames, seeded_state_dict
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                         f"--nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: nomad_amd has no CPU path")
+    if rank == 0:
+        build.build_library()
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        dist.barrier()
+
+    ckpt = find_checkpoint()
+    sd = load_checkpoint(ckpt) if ckpt else seeded_state_dict(0)
+    eng = Engine(sd, local_rank)
+    scorer = ShardedScorer(eng.embed, eng.pairwise)
+
+    n_samples = int(round(args.seconds * 16000))
+    B, n_ref = args.batch, args.refs
+    g = torch.Generator().manual_seed(1000 + rank)
+    wav = (0.1 * torch.randn(B, n_samples, generator=g)).clamp(-1, 1).cuda()  # resident in HBM
+    deg_wav, ref_wav = wav[:B - n_ref], wav[B - n_ref:]
+
+    def step():
+        return scorer.score(deg_wav, ref_wav, want_matrix=True)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    profile = not args.no_profile
+    if profile:
+        eng.profile_enable(True)
+        eng.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        mean, d, _ = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = eng.profile_read() if profile else None
+    if profile:
+        eng.profile_enable(False)
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    assert torch.isfinite(mean).all()
+
+    if rank == 0:
+        clips = world * B * args.steps
+        value = clips / elapsed
+        T = num_frames(n_samples)
+        flop_clip = FLOP_PER_CLIP_4S if n_samples == 64000 else None
+        out = {
+            "metric": "clips/sec embedded + NxM NOMAD distances, 16kHz x 4s batches",
+            "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (0.1*randn waveforms, seed 1000+rank; " +
+                    ("real nomad_best_model.pt" if ckpt else "seeded random-init wav2vec2-base + head weights") + ")",
+            "config": {"workload": f"configs[1]: batch={B} x {n_samples} samples (T={T}) per GPU, wav2vec2-base + "
+                                   f"projection head fp32, {B - n_ref} deg x {n_ref}*N ref float64 distances + means",
+                       "clips_per_gpu_per_step": B, "deg_per_gpu": B - n_ref, "ref_total": n_ref * world,
+                       "parallelism": f"clip-sharded x{world}, all-gather of ref embeddings"},
+        }
+        if flop_clip:
+            out["model_tflops_per_gpu"] = round(value * flop_clip / world / 1e12, 2)
+            out["model_frac_of_fp32_mfma_peak"] = round(value * flop_clip / world / PEAK_FP32_MFMA, 4)
+            out["encoder_layers_frac_of_fp32_mfma_peak"] = round(value * FLOP_LAYERS_4S / world / PEAK_FP32_MFMA, 4)
+        if prof:
+            gm = prof["gemm_f32_mfma"]
+            ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32), all launches",
+                               "achieved": round(ach, 2), "peak": round(PEAK_FP32_MFMA / 1e12, 1), "unit": "TFLOP/s",
+                               "frac": round(ach * 1e12 / PEAK_FP32_MFMA, 4), "traffic": None,
+                               "launches": gm["launches"], "avg_launch_ms": round(gm["ms"] / max(gm["launches"], 1), 4),
+                               "algorithmic_gflop_per_launch": round(gm["flops"] / max(gm["launches"], 1) / 1e9, 3)}
+            out["kernel_time_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in prof.items()}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd, n_samples)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,154 @@
+/*
+ * nomad_hip.h - C ABI of libnomad_hip.so, the MI355X (gfx950) NOMAD scoring engine.
+ *
+ * The reference (alessandroragano/nomad) has no FFI boundary of its own: its hot path is Python
+ * calling into fairseq/PyTorch/SciPy.  Each entry point below replaces one such call site
+ * (paths relative to /root/reference):
+ *
+ *   nomad_create / nomad_destroy   Nomad.__init__ model construction + load_state_dict
+ *                                  (src/nomad_audio/nomad.py:57-71)
+ *   nomad_embed                    TripletModel.forward (nomad.py:224-231) and
+ *                                  LossNetLayers.forward (nomad.py:243-258): wav2vec 2.0 BASE
+ *                                  backbone (fairseq Wav2Vec2Model, call sites nomad.py:226,245)
+ *                                  + mean/ReLU/Linear/L2-normalise head
+ *   nomad_pairwise                 scipy cdist + np.mean(axis=1) (nomad.py:108-111)
+ *   nomad_l1_loss                  NomadLoss.forward (nomad.py:267-282)
+ *
+ * Conventions: every function returns 0 on success or a negative nomad_status; nothing throws.
+ * All `dev` pointers are device (HBM) pointers owned by the caller; `host` pointers are host
+ * memory.  Compute entry points are asynchronous on the caller's hipStream_t and never allocate:
+ * scratch comes from the caller-provided workspace (size from nomad_workspace_bytes).  A context
+ * is bound to one device and is not re-entrant.  The library has no CPU fallback: without a
+ * gfx950 device nomad_create fails with NOMAD_ERR_NO_DEVICE.
+ */
+#ifndef NOMAD_HIP_H
+#define NOMAD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NOMAD_NUM_LAYERS 12
+#define NOMAD_EMBED_DIM 768
+#define NOMAD_EMB_DIM 256
+
+typedef enum nomad_status {
+    NOMAD_OK = 0,
+    NOMAD_ERR_INVALID = -1,   /* bad argument */
+    NOMAD_ERR_NO_DEVICE = -2, /* no usable gfx950 device */
+    NOMAD_ERR_HIP = -3,       /* a HIP runtime call failed; see nomad_last_error() */
+    NOMAD_ERR_WORKSPACE = -4  /* workspace too small */
+} nomad_status;
+
+typedef struct nomad_ctx nomad_ctx;
+typedef void* nomad_stream_t; /* hipStream_t */
+
+/* One transformer encoder layer, fairseq TransformerSentenceEncoderLayer parameter names.
+ * All matrices are row-major [out][in] exactly as torch.nn.Linear stores them. */
+typedef struct nomad_layer_weights {
+    const float *q_w, *q_b, *k_w, *k_b, *v_w, *v_b, *o_w, *o_b; /* self_attn.{q,k,v,out}_proj */
+    const float *ln1_w, *ln1_b;                                 /* self_attn_layer_norm */
+    const float *fc1_w, *fc1_b, *fc2_w, *fc2_b;                 /* fc1 [3072][768], fc2 [768][3072] */
+    const float *ln2_w, *ln2_b;                                 /* final_layer_norm */
+} nomad_layer_weights;
+
+/* HOST pointers, fp32, in the layout of the reference checkpoint nomad_best_model.pt
+ * (keys ssl_model.* / embedding_layer.1.*; nomad.py:63-65).  nomad_create copies and repacks
+ * them; the caller may free them afterwards. */
+typedef struct nomad_weights {
+    const float* conv_w[7];          /* feature_extractor.conv_layers.i.0.weight: [512][1][10], 4x[512][512][3], 2x[512][512][2] */
+    const float *gn_w, *gn_b;        /* feature_extractor.conv_layers.0.2 (GroupNorm 512) */
+    const float *feat_ln_w, *feat_ln_b; /* layer_norm (512) */
+    const float *proj_w, *proj_b;    /* post_extract_proj [768][512] */
+    const float *pos_v, *pos_g, *pos_b; /* encoder.pos_conv.0 weight_v [768][48][128], weight_g [128], bias */
+    const float *enc_ln_w, *enc_ln_b;   /* encoder.layer_norm */
+    nomad_layer_weights layers[NOMAD_NUM_LAYERS];
+    const float *emb_w, *emb_b;      /* embedding_layer.1 [256][768], [256] */
+} nomad_weights;
+
+/* ---- lifetime ---------------------------------------------------------------------------- */
+int nomad_create(nomad_ctx** out, int device, const nomad_weights* host_weights);
+void nomad_destroy(nomad_ctx* ctx);
+const char* nomad_last_error(void);
+const char* nomad_version(void);
+
+/* ---- shapes ------------------------------------------------------------------------------ */
+/* Encoder frames T for a clip of n_samples (conv stack (10,5),(3,2)x4,(2,2)x2); <=0 if too short. */
+int nomad_num_frames(int n_samples);
+/* Scratch bytes nomad_embed needs for a (B, n_samples) batch. */
+int nomad_workspace_bytes(const nomad_ctx* ctx, int B, int n_samples, size_t* bytes);
+
+/* ---- hot path ---------------------------------------------------------------------------- */
+/*
+ * Embed B clips of n_samples each.
+ *   wav_dev     [B][n_samples] fp32 raw amplitude (nomad.py:225 squeezes (B,1,N) to this)
+ *   head_w_dev/head_b_dev  optional override of the 768->256 head ([256][768],[256], device);
+ *               NULL = the checkpoint's embedding_layer (TripletModel).  LossNetLayers has its own
+ *               never-loaded embedding layer (nomad.py:238-241), which callers pass here.
+ *   emb_dev     [B][256] fp32 unit-norm embeddings (out)
+ *   layers_dev  optional [12][B][T][768] fp32 transformer layer outputs (out; nomad.py:248), or NULL
+ */
+int nomad_embed(nomad_ctx* ctx, const float* wav_dev, int B, int n_samples,
+                const float* head_w_dev, const float* head_b_dev,
+                float* emb_dev, float* layers_dev,
+                void* workspace_dev, size_t workspace_bytes, nomad_stream_t stream);
+
+/*
+ * Euclidean distance matrix + row means, computed in float64 in the difference form
+ * sqrt(sum_k (a_k - b_k)^2) like scipy's cdist on float32 inputs promoted to double.
+ *   deg_dev [Nd][256] fp32, ref_dev [Nr][256] fp32
+ *   dist_dev  optional [Nd][Nr] float64 (out) or NULL;  mean_dev [Nd] float64 (out)
+ */
+int nomad_pairwise(nomad_ctx* ctx, const float* deg_dev, int Nd, const float* ref_dev, int Nr,
+                   double* dist_dev, double* mean_dev, nomad_stream_t stream);
+
+/*
+ * NomadLoss: sum_{i<12} mean|a_layers[i]-b_layers[i]| + mean|a_emb-b_emb|.
+ *   a_layers_dev/b_layers_dev [12][B][T][768]; a_emb_dev/b_emb_dev [B][256]; loss_dev [1] fp32 (out)
+ *   scratch_dev: >= nomad_l1_scratch_bytes() bytes of device scratch.
+ */
+size_t nomad_l1_scratch_bytes(void);
+int nomad_l1_loss(nomad_ctx* ctx, const float* a_layers_dev, const float* b_layers_dev,
+                  const float* a_emb_dev, const float* b_emb_dev, int B, int T,
+                  float* loss_dev, void* scratch_dev, nomad_stream_t stream);
+
+/* ---- measurement ------------------------------------------------------------------------- */
+/* Kernel classes for the in-library HIP-event timers. */
+enum { NOMAD_K_GEMM = 0, NOMAD_K_ATTN = 1, NOMAD_K_FRONT = 2, NOMAD_K_ROW = 3, NOMAD_K_PAIR = 4, NOMAD_K_COUNT = 5 };
+/* When enabled every kernel launch of nomad_embed/nomad_pairwise is bracketed by hipEvents on the
+ * launch stream.  nomad_profile_read synchronises those events and returns, per class, the summed
+ * device time (ms), launch count and algorithmic FLOPs (2*M*N*K of the true problem, no padding)
+ * since the last nomad_profile_reset. */
+int nomad_profile_enable(nomad_ctx* ctx, int on);
+int nomad_profile_reset(nomad_ctx* ctx);
+int nomad_profile_read(nomad_ctx* ctx, double ms[NOMAD_K_COUNT], long long launches[NOMAD_K_COUNT],
+                       double flops[NOMAD_K_COUNT]);
+
+/* ---- kernel-level diagnostics (used by tests/ to localise a parity failure) --------------- */
+/* C[M][N] = epilogue(A[M][K] * W[N][K]^T): + bias[N] (nullable), GELU if gelu!=0, + R[M][N] (nullable).
+ * tile selects the kernel instantiation: 0 = 128x128x32, 1 = 128x64x16, 2 = 64x64x32. */
+int nomad_diag_gemm(nomad_ctx* ctx, const float* A_dev, const float* W_dev, const float* bias_dev,
+                    const float* R_dev, float* C_dev, int M, int N, int K, int gelu, int tile,
+                    nomad_stream_t stream);
+/* out[M][N] = LayerNorm(in[M][N]) * gamma + beta, N in {512, 768}, eps 1e-5. */
+int nomad_diag_layernorm(nomad_ctx* ctx, const float* in_dev, const float* gamma_dev, const float* beta_dev,
+                         float* out_dev, int M, int N, nomad_stream_t stream);
+/* ctx_out[B*T][768] = softmax(q k^T) v per head, from qkv[B*T][2304] (q pre-scaled). */
+int nomad_diag_attention(nomad_ctx* ctx, const float* qkv_dev, float* out_dev, int B, int T, nomad_stream_t stream);
+/* With on!=0 every conv layer output gets its own workspace region (no ping-pong aliasing), so
+ * nomad_diag_workspace_region can read all of them back after nomad_embed.  Changes
+ * nomad_workspace_bytes. */
+int nomad_diag_keep_intermediates(nomad_ctx* ctx, int on);
+/* Byte offset and size of a named intermediate inside the nomad_embed workspace for (B, n_samples):
+ * "conv0".."conv6" (time-major [B][L_i][512]), "featln" [B*T][512], "xpad" [B][T+128][768]
+ * (post_extract_proj output at rows 64..64+T of each clip). */
+int nomad_diag_workspace_region(const nomad_ctx* ctx, int B, int n_samples, const char* name,
+                                size_t* offset, size_t* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NOMAD_HIP_H */

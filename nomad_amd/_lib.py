@@ -1,0 +1,78 @@
+"""ctypes binding of libnomad_hip.so (include/nomad_hip.h).  No torch types cross this boundary:
+only raw device/host addresses, sizes and the hipStream_t handle."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+NUM_LAYERS = 12
+K_GEMM, K_ATTN, K_FRONT, K_ROW, K_PAIR, K_COUNT = 0, 1, 2, 3, 4, 5
+KERNEL_CLASS_NAMES = ("gemm_f32_mfma", "attention_f32_mfma", "frontend", "rowwise", "pairwise_f64")
+
+_fp = C.c_void_p  # every pointer is passed as an address
+
+
+class LayerWeights(C.Structure):
+    _fields_ = [(n, _fp) for n in ("q_w", "q_b", "k_w", "k_b", "v_w", "v_b", "o_w", "o_b", "ln1_w", "ln1_b",
+                                   "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ln2_w", "ln2_b")]
+
+
+class Weights(C.Structure):
+    _fields_ = ([("conv_w", _fp * 7)] +
+                [(n, _fp) for n in ("gn_w", "gn_b", "feat_ln_w", "feat_ln_b", "proj_w", "proj_b",
+                                    "pos_v", "pos_g", "pos_b", "enc_ln_w", "enc_ln_b")] +
+                [("layers", LayerWeights * NUM_LAYERS), ("emb_w", _fp), ("emb_b", _fp)])
+
+
+# name -> (restype, argtypes): the complete export list of include/nomad_hip.h
+SIGNATURES = {
+    "nomad_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(Weights)]),
+    "nomad_destroy": (None, [C.c_void_p]),
+    "nomad_last_error": (C.c_char_p, []),
+    "nomad_version": (C.c_char_p, []),
+    "nomad_num_frames": (C.c_int, [C.c_int]),
+    "nomad_workspace_bytes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
+    "nomad_embed": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_size_t, _fp]),
+    "nomad_pairwise": (C.c_int, [C.c_void_p, _fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp]),
+    "nomad_l1_scratch_bytes": (C.c_size_t, []),
+    "nomad_l1_loss": (C.c_int, [C.c_void_p, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp]),
+    "nomad_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "nomad_profile_reset": (C.c_int, [C.c_void_p]),
+    "nomad_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
+    "nomad_diag_gemm": (C.c_int, [C.c_void_p, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    "nomad_diag_layernorm": (C.c_int, [C.c_void_p, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp]),
+    "nomad_diag_attention": (C.c_int, [C.c_void_p, _fp, _fp, C.c_int, C.c_int, _fp]),
+    "nomad_diag_keep_intermediates": (C.c_int, [C.c_void_p, C.c_int]),
+    "nomad_diag_workspace_region": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p,
+                                              C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+}
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libnomad_hip.so")
+_lib = None
+
+
+def load():
+    """Load the in-tree shared library; raises if it has not been built (no fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -m nomad_amd.build` "
+                           "(hipcc --offload-arch=gfx950). nomad_amd has no CPU or PyTorch fallback path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class NomadHipError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().nomad_last_error()
+        raise NomadHipError(f"{what} failed (status {rc}): {msg.decode() if msg else ''}")

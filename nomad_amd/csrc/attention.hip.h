@@ -1,0 +1,140 @@
+// fp32 flash-style self-attention for wav2vec 2.0 BASE (12 heads x 64, no mask, eval mode):
+//   ctx[b,t,h*64:(h+1)*64] = softmax_j(q[b,t,h] . k[b,j,h]) v[b,j,h]          
+// Input is the fused QKV GEMM output qkv[B*T][2304] = [q*64^-0.5 | k | v] (the 1/8 scale of
+// fairseq MultiheadAttention is folded into Wq/bq at repack time).
+//
+// One workgroup = 64 query rows of one (clip, head); wave w owns 16 of them.  K/V are streamed
+// in 64-key tiles through LDS with an online softmax, so any T works (199 frames for 4 s,
+// 1499 for 30 s) without materialising the T x T score matrix.
+//
+// Matrix core: v_mfma_f32_16x16x4_f32.  Both products are computed TRANSPOSED so that the score
+// accumulator is directly the next MFMA's B operand (no LDS round trip, no lane shuffles):
+//   S^T[key][q] = sum_d K[key][d] Q[q][d]      A = K (LDS), B = Q (registers)
+//   O^T[d][q]  += sum_key V[key][d] P[key][q]  A = V (LDS), B = P (the S^T accumulator itself)
+// D layout: col = lane&15, row = 4*(lane>>4) + reg.  Lane (qi = lane&15, g = lane>>4) therefore
+// holds, for its ONE query row, keys {16*sub + 4g + r} - and an MFMA k-step wants lane group g to
+// supply contraction index g.  The contraction order is free, so k-step (sub, r) contracts keys
+// {16*sub + 4g + r : g = 0..3}: each lane's own register r.  The same trick orders d for S^T
+// (one ds_read_b128 of K feeds 4 MFMAs).  Softmax statistics are per lane (all 4 lane groups of
+// a query share them after two xor-shuffles).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "gemm_f32.hip.h"
+
+namespace nomad {
+
+constexpr int kAttnLD = 68;  // 64 + 4 floats: 272-B rows
+
+__global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                            int T) {
+    __shared__ __attribute__((aligned(16))) float Ks[64 * kAttnLD];
+    __shared__ __attribute__((aligned(16))) float Vs[64 * kAttnLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qi = lane & 15, g = lane >> 4;
+    const int bh = blockIdx.y, b = bh / 12, h = bh - b * 12;
+    const long long base = (long long)b * T * 2304 + h * 64;
+    const int q_row = blockIdx.x * 64 + wave * 16 + qi;
+    const int q_ld = q_row < T ? q_row : T - 1;
+
+    // Q fragment: Q[q][16*dd + 4g + j]
+    float4 qf[4];
+#pragma unroll
+    for (int dd = 0; dd < 4; ++dd)
+        qf[dd] = *reinterpret_cast<const float4*>(qkv + base + (long long)q_ld * 2304 + dd * 16 + g * 4);
+
+    f32x4 o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int ntiles = (T + 63) / 64;
+    for (int kt = 0; kt < ntiles; ++kt) {
+        __syncthreads();  // previous tile fully consumed
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = tid + i * 256, row = id >> 4, c4 = id & 15;
+            int key = kt * 64 + row;
+            key = key < T ? key : T - 1;
+            const float* src = qkv + base + (long long)key * 2304 + c4 * 4;
+            *reinterpret_cast<float4*>(Ks + row * kAttnLD + c4 * 4) = *reinterpret_cast<const float4*>(src + 768);
+            *reinterpret_cast<float4*>(Vs + row * kAttnLD + c4 * 4) = *reinterpret_cast<const float4*>(src + 1536);
+        }
+        __syncthreads();
+
+        // S^T tile: 4 sub-tiles of 16 keys
+        f32x4 s[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) {
+            float4 kf[4];
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub)
+                kf[sub] = *reinterpret_cast<const float4*>(Ks + (sub * 16 + qi) * kAttnLD + dd * 16 + g * 4);
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub) s[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[sub].x, qf[dd].x, s[sub], 0, 0, 0);
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub) s[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[sub].y, qf[dd].y, s[sub], 0, 0, 0);
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub) s[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[sub].z, qf[dd].z, s[sub], 0, 0, 0);
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub) s[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[sub].w, qf[dd].w, s[sub], 0, 0, 0);
+        }
+
+        // mask keys beyond T (last tile only), online softmax
+        float m_tile = -INFINITY;
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 64 + sub * 16 + g * 4 + r;
+                if (key >= T) s[sub][r] = -INFINITY;
+                m_tile = fmaxf(m_tile, s[sub][r]);
+            }
+        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 16));
+        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));
+        const float m_new = fmaxf(m_run, m_tile);  // finite: every tile holds at least one valid key
+        const float alpha = expf(m_run - m_new);   // first tile: exp(-inf) = 0
+        float psum = 0.f;
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = expf(s[sub][r] - m_new);
+                s[sub][r] = pv;
+                psum += pv;
+            }
+        l_run = l_run * alpha + psum;  // per-lane partial (this lane's keys); folded across g at the end
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] *= alpha;
+
+        // O^T += V^T P^T : k-step (sub, r) contracts keys 16*sub + 4g + r
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float* vrow = Vs + (sub * 16 + g * 4 + r) * kAttnLD + qi;
+                const float pv = s[sub][r];
+#pragma unroll
+                for (int ds = 0; ds < 4; ++ds)
+                    o[ds] = __builtin_amdgcn_mfma_f32_16x16x4f32(vrow[ds * 16], pv, o[ds], 0, 0, 0);
+            }
+    }
+
+    float l_tot = l_run + __shfl_xor(l_run, 16);
+    l_tot += __shfl_xor(l_tot, 32);
+    const float inv = 1.0f / l_tot;
+    if (q_row < T) {
+        float* dst = out + ((long long)b * T + q_row) * 768 + h * 64 + g * 4;
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds) {
+            float4 r;
+            r.x = o[ds][0] * inv; r.y = o[ds][1] * inv; r.z = o[ds][2] * inv; r.w = o[ds][3] * inv;
+            *reinterpret_cast<float4*>(dst + ds * 16) = r;
+        }
+    }
+}
+
+}  // namespace nomad

@@ -1,0 +1,137 @@
+// Waveform front end: Conv1d(1->512, k=10, s=5, no bias) -> GroupNorm(512 groups) -> GELU
+// (fairseq ConvFeatureExtractionModel layer 0, extractor_mode=default).
+//
+// GroupNorm needs per-(clip, channel) statistics over all L0 = (N-10)/5+1 frames before any
+// output element can be normalised.  Because the layer has a single input channel, those
+// statistics are quadratic forms of the waveform's 10x10 frame autocorrelation:
+//     y[c,t] = sum_j w[c,j] x[5t+j]
+//     sum_t y      = sum_j   w[c,j]        S[j],      S[j]   = sum_t x[5t+j]
+//     sum_t y^2    = sum_jk  w[c,j] w[c,k] R[j][k],   R[j][k] = sum_t x[5t+j] x[5t+k]
+// so one fp64 pass over the 256 KB waveform (not the 26 MB conv output) yields mean and variance
+// of all 512 channels; the conv itself is then evaluated once, with normalise+affine folded into
+// a per-(clip,channel) scale/shift, GELU applied in registers, and written time-major.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "gemm_f32.hip.h"
+
+namespace nomad {
+
+constexpr int kStatsPerClip = 65;  // 10 sums + 55 upper-triangular products
+
+// grid: B blocks of 256 threads.  stats[b][0..9] = S, stats[b][10..64] = R (j<=k, row-major).
+__global__ __launch_bounds__(256) void wav_stats_kernel(const float* __restrict__ wav, int n_samples, int L0,
+                                                        double* __restrict__ stats) {
+    const int b = blockIdx.x;
+    const float* x = wav + (long long)b * n_samples;
+    double acc[kStatsPerClip];
+#pragma unroll
+    for (int i = 0; i < kStatsPerClip; ++i) acc[i] = 0.0;
+    for (int t = threadIdx.x; t < L0; t += 256) {
+        double v[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) v[j] = (double)x[5 * t + j];
+        int idx = 10;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            acc[j] += v[j];
+#pragma unroll
+            for (int k = j; k < 10; ++k) acc[idx++] += v[j] * v[k];
+        }
+    }
+    __shared__ double red[4][kStatsPerClip];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < kStatsPerClip; ++i) {
+        double s = acc[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) red[wave][i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < kStatsPerClip)
+        stats[(long long)b * kStatsPerClip + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// grid: B blocks of 512 threads (one per channel).  scale = rstd*gamma, shift = beta - mean*rstd*gamma.
+__global__ __launch_bounds__(512) void gn_fold_kernel(const double* __restrict__ stats, const float* __restrict__ w0,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      int L0, float* __restrict__ scale, float* __restrict__ shift) {
+    const int b = blockIdx.x, c = threadIdx.x;
+    const double* st = stats + (long long)b * kStatsPerClip;
+    double w[10];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) w[j] = (double)w0[c * 10 + j];
+    double s1 = 0.0, s2 = 0.0;
+    int idx = 10;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+        s1 += w[j] * st[j];
+#pragma unroll
+        for (int k = j; k < 10; ++k) {
+            const double r = st[idx++];
+            s2 += (k == j ? 1.0 : 2.0) * w[j] * w[k] * r;
+        }
+    }
+    const double mean = s1 / L0;
+    double var = s2 / L0 - mean * mean;  // biased variance, as torch group_norm
+    var = var > 0.0 ? var : 0.0;
+    const double rstd = 1.0 / sqrt(var + 1e-5);
+    const double g = (double)gamma[c];
+    scale[b * 512 + c] = (float)(rstd * g);
+    shift[b * 512 + c] = (float)((double)beta[c] - mean * rstd * g);
+}
+
+// grid: (ceil(L0/FR), B), 256 threads.  Thread = (4 channels) x (frame parity); samples staged in LDS.
+// out[b][t][c] time-major, c contiguous: each frame is one 2 KB coalesced row.
+constexpr int kConv0Frames = 64;
+__global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restrict__ wav, int n_samples, int L0,
+                                                            const float* __restrict__ w0, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, float* __restrict__ out) {
+    __shared__ float xs[kConv0Frames * 5 + 8];
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * kConv0Frames;
+    const int nfr = min(kConv0Frames, L0 - t0);
+    const float* x = wav + (long long)b * n_samples + 5 * t0;
+    const int nx = 5 * nfr + 5;
+    for (int i = threadIdx.x; i < nx; i += 256) xs[i] = x[i];
+    const int cq = threadIdx.x & 127, par = threadIdx.x >> 7;
+    float w[4][10], sc[4], sh[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = cq * 4 + q;
+        sc[q] = scale[b * 512 + c];
+        sh[q] = shift[b * 512 + c];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) w[q][j] = w0[c * 10 + j];
+    }
+    __syncthreads();
+    float* o = out + ((long long)b * L0 + t0) * 512 + cq * 4;
+    for (int t = par; t < nfr; t += 2) {
+        float xv[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) xv[j] = xs[5 * t + j];
+        float4 r;
+        float* rp = reinterpret_cast<float*>(&r);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float y = 0.f;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) y = fmaf(w[q][j], xv[j], y);
+            rp[q] = gelu_erf(fmaf(y, sc[q], sh[q]));
+        }
+        *reinterpret_cast<float4*>(o + (long long)t * 512) = r;
+    }
+}
+
+// Zero the 64 leading and 64 trailing pad frames of every clip in the pos-conv input buffer
+// xpad[B][T+128][768].  grid: (128, B), 192 threads (one float4 each).
+__global__ __launch_bounds__(192) void zero_pad_rows_kernel(float* __restrict__ xpad, int T) {
+    const int b = blockIdx.y;
+    const int r = blockIdx.x < 64 ? blockIdx.x : T + blockIdx.x;
+    float4* p = reinterpret_cast<float4*>(xpad + ((long long)b * (T + 128) + r) * 768);
+    p[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+}  // namespace nomad

@@ -1,0 +1,231 @@
+// fp32 MFMA GEMM / implicit-GEMM for gfx950 (CDNA4):  C = epilogue(A * W^T)
+//
+// One kernel template serves every dense contraction of the wav2vec 2.0 BASE forward
+// (K3/K4 strided Conv1d, K6 post_extract_proj, K7 grouped pos-conv,
+// K9 fused QKV, K11 out_proj, K12 FFN).  Activations are kept time-major ([clip][frame][channel]),
+// so a k=3/stride=2 Conv1d output row is a dot product over 3*512 CONTIGUOUS floats starting at
+// input frame 2t: the convolution is a plain GEMM whose A-row stride (1024) is smaller than K
+// (1536).  The only extra machinery is the RowMap (rows restart per clip) and a chunked K map
+// (pos-conv: 128 taps x 48 channels, taps 768 floats apart).
+//
+// Matrix core: v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD = the fp32 peak).
+// Operand maps (cdna_hip_programming.md section 3): lane l supplies A[i=l&31][k=l>>5] and
+// B[k=l>>5][j=l&31]; D[i][j] lands at col j = lane&31, row i = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+// The contraction index may be visited in any order, so one ds_read_b128 per lane feeds four
+// consecutive MFMAs: lane half h reads k = 8q+4h .. 8q+4h+3 and MFMA j contracts {8q+j, 8q+4+j}.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace nomad {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Address of logical row m: rows are grouped in clips of `clip_rows` rows.
+struct RowMap {
+    long long off;          // element offset of (clip 0, row 0)
+    long long clip_stride;  // elements between clips
+    int clip_rows;          // rows per clip in the logical M index
+    int ld;                 // elements between consecutive rows of one clip
+};
+
+__device__ __forceinline__ long long row_addr(const RowMap& r, int m) {
+    const int c = m / r.clip_rows;
+    const int t = m - c * r.clip_rows;
+    return r.off + (long long)c * r.clip_stride + (long long)t * r.ld;
+}
+
+struct GemmParams {
+    const float* A;
+    RowMap amap;
+    int kchunk, kstride;  // logical k -> (k / kchunk) * kstride + k % kchunk   (BK divides kchunk)
+    const float* W;       // [N_padded][ldw], k contiguous
+    int ldw;
+    float* C;
+    RowMap cmap;
+    const float* bias;    // [N] or nullptr
+    const float* R;       // residual or nullptr, added AFTER the activation
+    RowMap rmap;
+    int M, N, K;          // N = padded N covered by the grid (multiple of BN)
+    int n_valid;          // columns >= n_valid are not stored
+    int gelu;
+    // per-group (blockIdx.y) element offsets: grouped pos-conv
+    long long a_goff, w_goff, c_goff, r_goff;
+    int bias_goff;
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ float gelu_erf(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+// XCD-aware bijective remap of a 1-D grid: blocks b and b+8 share an XCD (round-robin dispatch),
+// so give each XCD a contiguous run of tiles; consecutive tiles share the A row panel (n fastest).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int xcd = bid & 7, local = bid >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + local;
+}
+
+template <int BM, int BN, int BK>
+struct GemmCfg {
+    static constexpr int LD = BK + 4;  // +16 B row pad: conflict-free ds_read_b128 (144 B / 80 B rows)
+    static constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 MFMA tiles per wave (2x2 waves)
+    static constexpr int A_CHUNKS = BM * BK / 4 / 256, B_CHUNKS = BN * BK / 4 / 256;
+    static constexpr int LDS_BYTES = 2 * (BM + BN) * LD * 4;
+};
+
+template <int BM, int BN, int BK>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
+    using Cfg = GemmCfg<BM, BN, BK>;
+    constexpr int LD = Cfg::LD, TM = Cfg::TM, TN = Cfg::TN;
+    constexpr int KC = BK / 4;  // float4 chunks per tile row
+    static_assert(Cfg::A_CHUNKS >= 1 && Cfg::B_CHUNKS >= 1, "tile too small for 256 threads");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                 // [2][BM][LD]
+    float* Bs = smem + 2 * BM * LD;   // [2][BN][LD]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int wg = xcd_remap(blockIdx.x, nwg);
+    const int tile_m = wg / p.tiles_n, tile_n = wg - tile_m * p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int grp = blockIdx.y;
+
+    const float* Ag = p.A + grp * p.a_goff;
+    const float* Wg = p.W + grp * p.w_goff;
+
+    // per-thread staging sources (rows fixed for the whole K loop)
+    const float* a_src[Cfg::A_CHUNKS];
+    const float* b_src[Cfg::B_CHUNKS];
+    int a_dst[Cfg::A_CHUNKS], b_dst[Cfg::B_CHUNKS];
+#pragma unroll
+    for (int i = 0; i < Cfg::A_CHUNKS; ++i) {
+        const int id = tid + i * 256, row = id / KC, kc = id - row * KC;
+        int m = m0 + row;
+        m = m < p.M ? m : p.M - 1;
+        a_src[i] = Ag + row_addr(p.amap, m) + kc * 4;
+        a_dst[i] = row * LD + kc * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < Cfg::B_CHUNKS; ++i) {
+        const int id = tid + i * 256, row = id / KC, kc = id - row * KC;
+        b_src[i] = Wg + (long long)(n0 + row) * p.ldw + kc * 4;
+        b_dst[i] = row * LD + kc * 4;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 a_reg[Cfg::A_CHUNKS], b_reg[Cfg::B_CHUNKS];
+    const int nk = p.K / BK;
+
+// Staging is written as macros (not lambdas): by-reference captures of the register arrays kept
+// them in scratch memory.
+#define NOMAD_LOAD_TILE(KT)                                                                          \
+    {                                                                                                \
+        const int k0_ = (KT)*BK;                                                                     \
+        const int kq_ = k0_ / p.kchunk;                                                              \
+        const long long a_koff_ = (long long)kq_ * p.kstride + (k0_ - kq_ * p.kchunk);               \
+        _Pragma("unroll") for (int i = 0; i < Cfg::A_CHUNKS; ++i) a_reg[i] =                         \
+            *reinterpret_cast<const f32x4*>(a_src[i] + a_koff_);                                    \
+        _Pragma("unroll") for (int i = 0; i < Cfg::B_CHUNKS; ++i) b_reg[i] =                         \
+            *reinterpret_cast<const f32x4*>(b_src[i] + k0_);                                        \
+    }
+#define NOMAD_STORE_TILE(BUF)                                                                        \
+    {                                                                                                \
+        float* as_ = As + (BUF)*BM * LD;                                                             \
+        float* bs_ = Bs + (BUF)*BN * LD;                                                             \
+        _Pragma("unroll") for (int i = 0; i < Cfg::A_CHUNKS; ++i)                                    \
+            *reinterpret_cast<f32x4*>(as_ + a_dst[i]) = a_reg[i];                                   \
+        _Pragma("unroll") for (int i = 0; i < Cfg::B_CHUNKS; ++i)                                    \
+            *reinterpret_cast<f32x4*>(bs_ + b_dst[i]) = b_reg[i];                                   \
+    }
+
+    NOMAD_LOAD_TILE(0)
+    NOMAD_STORE_TILE(0)
+    __syncthreads();
+
+    const int frag_row = lane & 31, frag_k = (lane >> 5) * 4;
+    const int a_frag_off = (wm * (BM / 2) + frag_row) * LD + frag_k;
+    const int b_frag_off = (wn * (BN / 2) + frag_row) * LD + frag_k;
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) NOMAD_LOAD_TILE(kt + 1)  // global loads in flight under the MFMAs
+        const float* as = As + cur * BM * LD + a_frag_off;
+        const float* bs = Bs + cur * BN * LD + b_frag_off;
+#pragma unroll
+        for (int kq = 0; kq < BK / 8; ++kq) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LD + kq * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * LD + kq * 8);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (kt + 1 < nk) NOMAD_STORE_TILE(cur ^ 1)
+        __syncthreads();
+    }
+
+#undef NOMAD_LOAD_TILE
+#undef NOMAD_STORE_TILE
+    // epilogue: lane owns column n, 16 rows per 32x32 tile
+    float* Cg = p.C + grp * p.c_goff;
+    const float* Rg = p.R ? p.R + grp * p.r_goff : nullptr;
+    const float* biasg = p.bias ? p.bias + grp * p.bias_goff : nullptr;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+        const bool n_ok = n < p.n_valid;
+        const float bv = (biasg && n_ok) ? biasg[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < p.M && n_ok) {
+                    float v = acc[i][j][r] + bv;
+                    if (p.gelu) v = gelu_erf(v);
+                    if (Rg) v += Rg[row_addr(p.rmap, m) + n];
+                    Cg[row_addr(p.cmap, m) + n] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int BK>
+inline hipError_t launch_gemm(GemmParams p, int groups, hipStream_t s) {
+    using Cfg = GemmCfg<BM, BN, BK>;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = p.N / BN;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<BM, BN, BK>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    dim3 grid(p.tiles_m * p.tiles_n, groups);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK>), grid, dim3(256), Cfg::LDS_BYTES, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace nomad

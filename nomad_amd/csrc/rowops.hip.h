@@ -1,0 +1,148 @@
+// Row-wise kernels: LayerNorm (SURVEY.md K5/K8 and the two post-LN norms of every encoder layer),
+// the embedding head (K13: mean_t -> ReLU -> Linear(768,256) -> L2 normalise, nomad.py:228-230)
+// and the NomadLoss L1 reduction (K15, nomad.py:267-282).  All are HBM-bound: one wave per row,
+// 16-byte loads, statistics by wavefront (64-lane) shuffles.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace nomad {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// out[m][:] = (in[m][:] - mean) * rstd * gamma + beta; optional second copy out2 (layer_results).
+// VPT float4 per lane: N = 256 * VPT (512 -> 2, 768 -> 3).  grid: ceil(M/4) blocks of 256 threads.
+template <int VPT>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ in, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ out,
+                                                        float* __restrict__ out2, int M) {
+    constexpr int N = 256 * VPT;
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const float4* row = reinterpret_cast<const float4*>(in + (long long)m * N);
+    float4 v[VPT];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        v[i] = row[lane + 64 * i];
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) * (1.0f / N);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+        q += (a * a + b * b) + (c * c + d * d);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / N) + 1e-5f);
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    const float4* b4 = reinterpret_cast<const float4*>(beta);
+    float4* o = reinterpret_cast<float4*>(out + (long long)m * N);
+    float4* o2 = out2 ? reinterpret_cast<float4*>(out2 + (long long)m * N) : nullptr;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const float4 g = g4[lane + 64 * i], bb = b4[lane + 64 * i];
+        float4 r;
+        r.x = (v[i].x - mean) * rstd * g.x + bb.x;
+        r.y = (v[i].y - mean) * rstd * g.y + bb.y;
+        r.z = (v[i].z - mean) * rstd * g.z + bb.z;
+        r.w = (v[i].w - mean) * rstd * g.w + bb.w;
+        o[lane + 64 * i] = r;
+        if (o2) o2[lane + 64 * i] = r;
+    }
+}
+
+// grid: B blocks of 256 threads.  x [B][T][768] -> emb [B][256].
+__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, int T, const float* __restrict__ w,
+                                                   const float* __restrict__ bias, float* __restrict__ emb) {
+    __shared__ float pooled[768];
+    __shared__ float e[256];
+    __shared__ float wsum[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* xb = x + (long long)b * T * 768;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int t = 0; t < T; ++t) {
+        const float* r = xb + (long long)t * 768;
+        s0 += r[tid];
+        s1 += r[tid + 256];
+        s2 += r[tid + 512];
+    }
+    const float inv = 1.0f / (float)T;
+    pooled[tid] = fmaxf(s0 * inv, 0.f);
+    pooled[tid + 256] = fmaxf(s1 * inv, 0.f);
+    pooled[tid + 512] = fmaxf(s2 * inv, 0.f);
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    float p[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) p[i] = pooled[lane + 64 * i];
+    for (int o = wave * 64; o < wave * 64 + 64; ++o) {
+        const float* wr = w + (long long)o * 768;
+        float d = 0.f;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) d = fmaf(wr[lane + 64 * i], p[i], d);
+        d = wave_sum(d);
+        if (lane == 0) e[o] = d + bias[o];
+    }
+    __syncthreads();
+    const float v = e[tid];
+    const float ss = wave_sum(v * v);
+    if (lane == 0) wsum[wave] = ss;
+    __syncthreads();
+    const float nrm = sqrtf((wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
+    emb[(long long)b * 256 + tid] = v / fmaxf(nrm, 1e-12f);  // F.normalize eps
+}
+
+// NomadLoss.  Stage 1: per-block fp64 partial sums of |a-b| over the 12 layer tensors (n_layer
+// float4s in total) and over the embeddings; stage 2: one block folds the partials in fixed order.
+constexpr int kL1Blocks = 1024;
+__global__ __launch_bounds__(256) void l1_partial_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
+                                                         long long n4, const float* __restrict__ ea,
+                                                         const float* __restrict__ eb, int ne,
+                                                         double* __restrict__ partial) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)kL1Blocks * 256) {
+        const float4 x = a[i], y = b[i];
+        s += (double)((fabsf(x.x - y.x) + fabsf(x.y - y.y)) + (fabsf(x.z - y.z) + fabsf(x.w - y.w)));
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (blockIdx.x == 0) {  // embedding term, one block
+        __syncthreads();
+        double se = 0.0;
+        for (int i = threadIdx.x; i < ne; i += 256) se += (double)fabsf(ea[i] - eb[i]);
+        se = wave_sum(se);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = se;
+        __syncthreads();
+        if (threadIdx.x == 0) partial[kL1Blocks] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void l1_final_kernel(const double* __restrict__ partial, double layer_elems,
+                                                       double emb_elems, float* __restrict__ loss) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < kL1Blocks; i += 256) s += partial[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double layers = (red[0] + red[1]) + (red[2] + red[3]);
+        // 12 terms each a mean over layer_elems elements, plus the embedding term
+        loss[0] = (float)(layers / layer_elems + partial[kL1Blocks] / emb_elems);
+    }
+}
+
+}  // namespace nomad

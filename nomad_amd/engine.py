@@ -1,0 +1,200 @@
+"""Host-side handle on the HIP engine: owns a nomad_ctx, hands it device buffers that PyTorch-ROCm
+allocates, and launches on torch's current HIP stream.  PyTorch is plumbing here (memory, streams,
+torch.distributed); every FLOP of the NOMAD path runs in libnomad_hip.so."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib
+from .weights import check_state_dict, num_frames
+
+P = "ssl_model."
+
+
+def _weights_struct(sd: Dict[str, torch.Tensor]):
+    """Build the nomad_weights struct of HOST pointers; returns (struct, keepalive list)."""
+    keep = []
+
+    def ptr(key):
+        t = sd[key].detach().to(device="cpu", dtype=torch.float32).contiguous()
+        keep.append(t)
+        return t.data_ptr()
+
+    w = _lib.Weights()
+    for i in range(7):
+        w.conv_w[i] = ptr(P + f"feature_extractor.conv_layers.{i}.0.weight")
+    w.gn_w = ptr(P + "feature_extractor.conv_layers.0.2.weight")
+    w.gn_b = ptr(P + "feature_extractor.conv_layers.0.2.bias")
+    w.feat_ln_w = ptr(P + "layer_norm.weight")
+    w.feat_ln_b = ptr(P + "layer_norm.bias")
+    w.proj_w = ptr(P + "post_extract_proj.weight")
+    w.proj_b = ptr(P + "post_extract_proj.bias")
+    w.pos_v = ptr(P + "encoder.pos_conv.0.weight_v")
+    w.pos_g = ptr(P + "encoder.pos_conv.0.weight_g")
+    w.pos_b = ptr(P + "encoder.pos_conv.0.bias")
+    w.enc_ln_w = ptr(P + "encoder.layer_norm.weight")
+    w.enc_ln_b = ptr(P + "encoder.layer_norm.bias")
+    for l in range(_lib.NUM_LAYERS):
+        q = P + f"encoder.layers.{l}."
+        lw = w.layers[l]
+        for short, name in (("q", "self_attn.q_proj"), ("k", "self_attn.k_proj"), ("v", "self_attn.v_proj"),
+                            ("o", "self_attn.out_proj"), ("ln1", "self_attn_layer_norm"), ("fc1", "fc1"),
+                            ("fc2", "fc2"), ("ln2", "final_layer_norm")):
+            setattr(lw, short + "_w", ptr(q + name + ".weight"))
+            setattr(lw, short + "_b", ptr(q + name + ".bias"))
+    w.emb_w = ptr("embedding_layer.1.weight")
+    w.emb_b = ptr("embedding_layer.1.bias")
+    return w, keep
+
+
+class Engine:
+    """One engine per (process, GPU).  Not thread-safe; asynchronous on torch's current stream."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device: int = 0):
+        self.lib = _lib.load()
+        check_state_dict(state_dict)
+        self.device_index = int(device)
+        self.device = torch.device("cuda", self.device_index)
+        w, keep = _weights_struct(state_dict)
+        handle = C.c_void_p()
+        _lib.check(self.lib.nomad_create(C.byref(handle), self.device_index, C.byref(w)), "nomad_create")
+        del keep
+        self.ctx = handle
+        self._ws: Optional[torch.Tensor] = None
+        self._l1_scratch: Optional[torch.Tensor] = None
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.nomad_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- helpers -----------------------------------------------------------------------------
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def workspace_bytes(self, B: int, n_samples: int) -> int:
+        n = C.c_size_t()
+        _lib.check(self.lib.nomad_workspace_bytes(self.ctx, B, n_samples, C.byref(n)), "nomad_workspace_bytes")
+        return n.value
+
+    def _workspace(self, nbytes: int) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def _check_dev(self, t: torch.Tensor, name: str):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise ValueError(f"{name} must be a contiguous fp32 tensor on {self.device}")
+
+    # ---- hot path ------------------------------------------------------------------------------
+    def embed(self, wav: torch.Tensor, head: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+              want_layers: bool = False):
+        """wav (B,N) or (B,1,N) fp32 on the GPU -> emb (B,256) [, layers (12,B,T,768)]."""
+        if wav.dim() == 3:
+            wav = wav.squeeze(1)
+        self._check_dev(wav, "wav")
+        B, N = wav.shape
+        T = num_frames(N)
+        if T < 1:
+            raise ValueError(f"clip of {N} samples is shorter than the conv stack's receptive field")
+        emb = torch.empty(B, 256, dtype=torch.float32, device=self.device)
+        layers = torch.empty(12, B, T, 768, dtype=torch.float32, device=self.device) if want_layers else None
+        hw = hb = None
+        if head is not None:
+            hw, hb = head
+            self._check_dev(hw, "head weight")
+            self._check_dev(hb, "head bias")
+        nbytes = self.workspace_bytes(B, N)
+        ws = self._workspace(nbytes)
+        _lib.check(self.lib.nomad_embed(self.ctx, wav.data_ptr(), B, N,
+                                        hw.data_ptr() if hw is not None else None,
+                                        hb.data_ptr() if hb is not None else None,
+                                        emb.data_ptr(), layers.data_ptr() if layers is not None else None,
+                                        ws.data_ptr(), ws.numel(), self._stream()), "nomad_embed")
+        return (emb, layers) if want_layers else emb
+
+    def pairwise(self, deg: torch.Tensor, ref: torch.Tensor, want_matrix: bool = True):
+        """deg (Nd,256), ref (Nr,256) fp32 on GPU -> (dist (Nd,Nr) float64 or None, mean (Nd,) float64)."""
+        self._check_dev(deg, "deg")
+        self._check_dev(ref, "ref")
+        if deg.shape[1] != 256 or ref.shape[1] != 256:
+            raise ValueError("embeddings must be 256-dimensional")
+        Nd, Nr = deg.shape[0], ref.shape[0]
+        dist = torch.empty(Nd, Nr, dtype=torch.float64, device=self.device) if want_matrix else None
+        mean = torch.empty(Nd, dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.nomad_pairwise(self.ctx, deg.data_ptr(), Nd, ref.data_ptr(), Nr,
+                                           dist.data_ptr() if dist is not None else None, mean.data_ptr(),
+                                           self._stream()), "nomad_pairwise")
+        return dist, mean
+
+    def l1_loss(self, a_layers, b_layers, a_emb, b_emb) -> torch.Tensor:
+        for t, n in ((a_layers, "a_layers"), (b_layers, "b_layers"), (a_emb, "a_emb"), (b_emb, "b_emb")):
+            self._check_dev(t, n)
+        _, B, T, _ = a_layers.shape
+        if self._l1_scratch is None:
+            self._l1_scratch = torch.empty(self.lib.nomad_l1_scratch_bytes(), dtype=torch.uint8, device=self.device)
+        loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.nomad_l1_loss(self.ctx, a_layers.data_ptr(), b_layers.data_ptr(), a_emb.data_ptr(),
+                                          b_emb.data_ptr(), B, T, loss.data_ptr(), self._l1_scratch.data_ptr(),
+                                          self._stream()), "nomad_l1_loss")
+        return loss[0]
+
+    # ---- measurement -----------------------------------------------------------------------------
+    def profile_enable(self, on: bool = True):
+        _lib.check(self.lib.nomad_profile_enable(self.ctx, int(on)), "nomad_profile_enable")
+
+    def profile_reset(self):
+        _lib.check(self.lib.nomad_profile_reset(self.ctx), "nomad_profile_reset")
+
+    def profile_read(self):
+        ms = (C.c_double * _lib.K_COUNT)()
+        n = (C.c_longlong * _lib.K_COUNT)()
+        fl = (C.c_double * _lib.K_COUNT)()
+        _lib.check(self.lib.nomad_profile_read(self.ctx, ms, n, fl), "nomad_profile_read")
+        return {name: {"ms": ms[i], "launches": n[i], "flops": fl[i]}
+                for i, name in enumerate(_lib.KERNEL_CLASS_NAMES)}
+
+    # ---- diagnostics (tests) ---------------------------------------------------------------------
+    def diag_gemm(self, A, W, bias=None, R=None, gelu=False, tile=0):
+        M, K = A.shape
+        N = W.shape[0]
+        out = torch.empty(M, N, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.nomad_diag_gemm(self.ctx, A.data_ptr(), W.data_ptr(),
+                                            bias.data_ptr() if bias is not None else None,
+                                            R.data_ptr() if R is not None else None, out.data_ptr(),
+                                            M, N, K, int(gelu), tile, self._stream()), "nomad_diag_gemm")
+        return out
+
+    def diag_layernorm(self, x, gamma, beta):
+        M, N = x.shape
+        out = torch.empty_like(x)
+        _lib.check(self.lib.nomad_diag_layernorm(self.ctx, x.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                 out.data_ptr(), M, N, self._stream()), "nomad_diag_layernorm")
+        return out
+
+    def diag_attention(self, qkv, B, T):
+        out = torch.empty(B * T, 768, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.nomad_diag_attention(self.ctx, qkv.data_ptr(), out.data_ptr(), B, T, self._stream()),
+                   "nomad_diag_attention")
+        return out
+
+    def diag_keep_intermediates(self, on: bool):
+        _lib.check(self.lib.nomad_diag_keep_intermediates(self.ctx, int(on)), "nomad_diag_keep_intermediates")
+        self._ws = None
+
+    def diag_region(self, B: int, n_samples: int, name: str) -> torch.Tensor:
+        """View (fp32, flat) of a named intermediate of the LAST embed() call with this (B, n_samples)."""
+        off, nb = C.c_size_t(), C.c_size_t()
+        _lib.check(self.lib.nomad_diag_workspace_region(self.ctx, B, n_samples, name.encode(), C.byref(off), C.byref(nb)),
+                   "nomad_diag_workspace_region")
+        return self._ws[off.value:off.value + nb.value].view(torch.float32)

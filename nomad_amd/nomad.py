@@ -1,0 +1,249 @@
+"""Drop-in ``Nomad`` surface over the MI355X HIP engine.
+
+Mirrors /root/reference/src/nomad_audio/nomad.py: same class and method names, argument meaning,
+return values, CSV side effects and exception messages -
+
+* ``Nomad(device=None)``                 nomad.py:36-80
+* ``predict(mode, nmr, deg, results_path) -> (df_avg_nomad, df_dm)``   nomad.py:82-140
+* ``forward(estimate, clean) -> loss``   nomad.py:142-146
+* ``get_embeddings(path)`` / ``get_embeddings_csv(model, file_names)``  nomad.py:148-189
+* ``load_processing(filepath, target_sr, trim)``                       nomad.py:192-212
+* ``TripletModel`` / ``LossNetLayers`` / ``NomadLoss``                 nomad.py:214-282
+
+What differs, deliberately:
+
+* all arithmetic (wav2vec 2.0 BASE backbone, head, distances, L1 loss) runs in libnomad_hip.so on
+  a gfx950 GPU; there is NO CPU path - ``device='cpu'`` raises.
+* nothing is downloaded at import time (no network in production clusters); the checkpoint is read
+  from ``pt-models/nomad_best_model.pt`` (the reference's location, nomad.py:28) or from
+  ``$NOMAD_CHECKPOINT``; ``Nomad(weights=...)`` accepts a state dict or ``'seeded'``.
+* ``get_embeddings_csv`` batches clips of equal length into one launch instead of the
+  reference's batch-1 loop with a device sync per clip (nomad.py:171-183); clips are never
+  zero-padded, so every clip sees exactly the arithmetic it sees at batch 1.
+* the distance matrix is computed on the GPU (float64, difference form) instead of SciPy.
+"""
+from __future__ import annotations
+
+import os
+from collections import OrderedDict
+from datetime import datetime
+from typing import Dict, List, Optional, Union
+
+import numpy as np
+import pandas as pd
+import torch
+
+from . import wavio
+from .engine import Engine
+from .weights import find_checkpoint, load_checkpoint, seeded_state_dict
+
+SSL_OUT_DIM = 768
+EMB_DIM = 256
+
+
+def _resolve_device(device) -> int:
+    if device is None:
+        device = "cuda"
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError(f"NOMAD (MI355X build) runs on a HIP GPU only; device={device!r} is not supported "
+                           "(there is no CPU path)")
+    return dev.index if dev.index is not None else (torch.cuda.current_device() if torch.cuda.is_available() else 0)
+
+
+class TripletModel:
+    """``TripletModel.forward(wav, lengths=None)`` (nomad.py:224-231) on the engine."""
+
+    def __init__(self, engine: Engine):
+        self.engine = engine
+
+    def eval(self):
+        return self
+
+    def __call__(self, wav: torch.Tensor, lengths=None) -> torch.Tensor:
+        return self.forward(wav, lengths)
+
+    def forward(self, wav: torch.Tensor, lengths=None) -> torch.Tensor:
+        return self.engine.embed(wav.to(self.engine.device, torch.float32).contiguous())
+
+
+class LossNetLayers:
+    """``LossNetLayers.forward(wav)`` (nomad.py:243-258): 12 layer outputs (B,T,768) + embedding.
+
+    Owns its own ``Linear(768,256)`` like the reference (nomad.py:238-241) - freshly initialised and
+    never loaded from the checkpoint - exposed as ``embedding_weight`` / ``embedding_bias`` so callers
+    that need reproducibility can set it.
+    """
+
+    def __init__(self, engine: Engine, ssl_out_dim: int = SSL_OUT_DIM, emb_dim: int = EMB_DIM):
+        self.engine = engine
+        lin = torch.nn.Linear(ssl_out_dim, emb_dim)
+        self.embedding_weight = lin.weight.detach().to(engine.device).contiguous()
+        self.embedding_bias = lin.bias.detach().to(engine.device).contiguous()
+
+    def __call__(self, wav):
+        return self.forward(wav)
+
+    def forward(self, wav: torch.Tensor) -> List[torch.Tensor]:
+        wav = wav.to(self.engine.device, torch.float32).contiguous()
+        emb, layers = self.engine.embed(wav, head=(self.embedding_weight, self.embedding_bias), want_layers=True)
+        return [layers[i] for i in range(12)] + [emb]
+
+
+class NomadLoss:
+    """``NomadLoss.forward(nomad_ref, nomad_test)`` (nomad.py:267-282): sum of 13 L1 means."""
+
+    def __init__(self, engine: Engine):
+        self.engine = engine
+        self.L = 13
+        self.only_embedding = False
+
+    def eval(self):
+        return self
+
+    def __call__(self, nomad_ref, nomad_test):
+        return self.forward(nomad_ref, nomad_test)
+
+    def forward(self, nomad_ref, nomad_test) -> torch.Tensor:
+        ref_layers = _stack_layers(nomad_ref[:12])
+        test_layers = _stack_layers(nomad_test[:12])
+        return self.engine.l1_loss(test_layers, ref_layers, nomad_test[12].contiguous(), nomad_ref[12].contiguous())
+
+
+def _stack_layers(layers) -> torch.Tensor:
+    """The 12 tensors LossNetLayers returns are views of one (12,B,T,768) buffer: reuse it."""
+    base = layers[0]._base if layers[0]._base is not None else None
+    if base is not None and base.dim() == 4 and base.shape[0] == 12 and all(
+            l._base is base and l.data_ptr() == base[i].data_ptr() for i, l in enumerate(layers)):
+        return base
+    return torch.stack([l.contiguous() for l in layers])
+
+
+class Nomad:
+    def __init__(self, device=None, weights: Union[None, str, Dict[str, torch.Tensor]] = None):
+        dev_index = _resolve_device(device)
+        self.DEVICE = f"cuda:{dev_index}"
+        print(f"NOMAD running on: {self.DEVICE}")
+        if weights is None:
+            path = find_checkpoint()
+            if path is None:
+                raise FileNotFoundError(
+                    "NOMAD weights not found: place nomad_best_model.pt under ./pt-models/ (the reference "
+                    "downloads it there, nomad.py:27-33) or set $NOMAD_CHECKPOINT; for synthetic benchmarks "
+                    "pass weights='seeded'")
+            sd = load_checkpoint(path)
+        elif isinstance(weights, str) and weights == "seeded":
+            sd = seeded_state_dict(0)
+        elif isinstance(weights, str):
+            sd = load_checkpoint(weights)
+        else:
+            sd = weights
+        self.engine = Engine(sd, dev_index)
+        self.model = TripletModel(self.engine)
+        self.lossnet_layers = LossNetLayers(self.engine, SSL_OUT_DIM, EMB_DIM)
+        self.nomad_loss = NomadLoss(self.engine)
+
+    # ------------------------------------------------------------------------------------------
+    def predict(self, mode="dir", nmr="data/nmr-data", deg="data/test-data", results_path=None):
+        if nmr is None:
+            raise Exception("nmr_path not specified, you need to pass a valid value to nmr_path")
+        if deg is None:
+            raise Exception("test_path not specified, you need to pass a valide value to test_path")
+
+        if mode == "dir":
+            if os.path.isdir(nmr) == False:  # noqa: E712 (message parity with the reference)
+                raise Exception(f"Path to the non-matching reference files {nmr} does not exist")
+            if os.path.isdir(deg) == False:  # noqa: E712
+                raise Exception(f"Path to the test files {deg} does not exist")
+        elif mode == "csv":
+            if os.path.isfile(nmr) == False:  # noqa: E712
+                raise Exception(f"File {nmr} does not exist")
+            if os.path.isfile(deg) == False:  # noqa: E712
+                raise Exception(f"File {deg} does not exist")
+        else:
+            raise Exception(f"Mode value {mode} is not valid. Valid values are dir and csv")
+
+        print(f"Compute non-matching reference embeddings from {nmr}")
+        nmr_embeddings = self.get_embeddings(nmr).set_index("filename")
+
+        print(f"Compute degraded embeddings from {deg}")
+        test_embeddings = self.get_embeddings(deg).set_index("filename")
+
+        # Pairwise distance matrix + average NOMAD score, on the GPU (cdist + np.mean, nomad.py:108-111)
+        deg_t = torch.from_numpy(np.ascontiguousarray(test_embeddings.to_numpy(dtype=np.float32))).to(self.engine.device)
+        ref_t = torch.from_numpy(np.ascontiguousarray(nmr_embeddings.to_numpy(dtype=np.float32))).to(self.engine.device)
+        dist, mean = self.engine.pairwise(deg_t, ref_t, want_matrix=True)
+        distance_matrix = dist.cpu().numpy()
+        avg_nomad = mean.cpu().numpy()
+
+        test_files = [x.split("/")[-1].split(".")[0] for x in test_embeddings.index]
+        df_avg_nomad = pd.DataFrame({"Test File": test_files, "NOMAD": avg_nomad}).set_index("Test File").round(3)
+
+        df_dm = pd.DataFrame(distance_matrix).round(3)
+        df_dm["Test File"] = test_files
+        df_dm.set_index("Test File", inplace=True)
+        df_dm.columns = [x.split("/")[-1].split(".")[0] for x in nmr_embeddings.index]
+
+        if results_path is None:
+            dt_string = datetime.now().strftime("%d-%m-%Y_%H-%M-%S")
+            out_dir = os.path.join("results-csv", dt_string)
+            os.makedirs(out_dir, exist_ok=True)
+            results_avg_path = os.path.join(out_dir, f"{dt_string}_nomad_avg.csv")
+            results_scores_path = os.path.join(out_dir, f"{dt_string}_nomad_scores.csv")
+        else:
+            results_avg_path = os.path.join(results_path, "nomad_avg.csv")
+            results_scores_path = os.path.join(results_path, "nomad_scores.csv")
+
+        df_avg_nomad.reset_index().to_csv(results_avg_path, index=False)
+        df_dm.reset_index().to_csv(results_scores_path, index=False)
+        return df_avg_nomad, df_dm
+
+    def forward(self, estimate, clean):
+        """NOMAD loss value (nomad.py:142-146).  The backward pass through the HIP engine is not built
+        yet: a tensor that requires grad is rejected instead of silently returning a constant."""
+        if torch.is_tensor(estimate) and estimate.requires_grad:
+            raise NotImplementedError("nomad.forward(): d loss / d estimate is not implemented in the HIP engine "
+                                      "yet; call with estimate.detach() for the loss value")
+        estimate_embeddings = self.lossnet_layers(estimate)
+        clean_embeddings = self.lossnet_layers(clean)
+        loss = self.nomad_loss(clean_embeddings, estimate_embeddings)
+        return loss
+
+    def get_embeddings(self, path):
+        if os.path.isdir(path):
+            data = pd.DataFrame(os.listdir(path))
+            data.columns = ["filename"]
+            data["filename"] = [os.path.join(path, x) for x in data["filename"]]
+        elif os.path.isfile(path):
+            data = pd.read_csv(path)
+            if "filename" not in data.columns:
+                raise Exception("File {path} not including a column called filename. Please pass a csv file with a "
+                                "column called filename that includes the absolute filpaths of the waveforms.")
+        else:
+            raise Exception(f"Path {path} does not exist")
+        return self.get_embeddings_csv(self.model, data)
+
+    def get_embeddings_csv(self, model, file_names, root=False, max_batch: int = 256):
+        """Embeddings for every row of ``file_names`` (a DataFrame with the path in column 0)."""
+        file_names_arr = np.array(file_names)
+        paths = []
+        for row in file_names_arr:
+            name = row[0] if isinstance(row, np.ndarray) else row
+            paths.append(os.path.join(root, name) if root else name)
+        waves = [self.load_processing(p, trim=False) for p in paths]
+        embeddings = np.zeros((len(waves), EMB_DIM), dtype=np.float32)
+        by_len: "OrderedDict[int, list]" = OrderedDict()
+        for i, w in enumerate(waves):
+            by_len.setdefault(w.shape[1], []).append(i)
+        for n, idxs in by_len.items():
+            for s in range(0, len(idxs), max_batch):
+                chunk = idxs[s:s + max_batch]
+                batch = torch.from_numpy(np.concatenate([waves[i] for i in chunk], axis=0))
+                emb = model(batch.to(self.engine.device), None)
+                embeddings[chunk] = emb.cpu().numpy()
+        emb_df = pd.DataFrame(embeddings)
+        df_emb = pd.concat([file_names.reset_index(), emb_df], axis=1).drop("index", axis=1)
+        return df_emb
+
+    def load_processing(self, filepath, target_sr=16000, trim=False):
+        return wavio.load_processing(filepath, target_sr, trim)

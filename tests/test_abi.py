@@ -1,0 +1,60 @@
+"""CPU: the C-ABI library builds, loads, and exports exactly what include/nomad_hip.h declares.
+No compute entry point is called here (there is no GPU in the build container)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "nomad_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nomad_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree(built_lib):
+    from nomad_amd import _lib
+    names = header_functions()
+    assert len(names) >= 15
+    assert sorted(_lib.SIGNATURES) == names
+    lib = C.CDLL(built_lib)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/nomad_hip.h but not exported"
+
+
+def test_shape_helpers(built_lib):
+    from nomad_amd import _lib
+    from nomad_amd.weights import num_frames
+    lib = _lib.load()
+    assert lib.nomad_version().startswith(b"nomad_hip")
+    for n in (9, 400, 16384, 27225, 64000, 223840, 480000):
+        assert lib.nomad_num_frames(n) == max(num_frames(n), 0)
+    assert lib.nomad_l1_scratch_bytes() > 0
+
+
+def test_create_fails_loudly_without_gpu(built_lib, sd0):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from nomad_amd.engine import Engine
+    from nomad_amd._lib import NomadHipError
+    with pytest.raises(NomadHipError, match="no HIP device|no CPU path|device"):
+        Engine(sd0, 0)
+
+
+def test_cpu_device_is_rejected():
+    from nomad_amd.nomad import Nomad
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        Nomad(device="cpu", weights="seeded")
+
+
+def test_no_oracle_import_in_product():
+    """The product must not route through the oracle."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "nomad_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f

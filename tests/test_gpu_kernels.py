@@ -1,0 +1,119 @@
+"""GPU: each HIP kernel, called through the C ABI (libnomad_hip.so), against a CPU reference."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TILES = {0: (128, 128, 32), 1: (128, 64, 16), 2: (64, 64, 32)}
+
+
+def _dev(x):
+    return x.to("cuda").contiguous()
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2])
+@pytest.mark.parametrize("M", [1, 63, 200, 257, 1000])
+def test_gemm_exact_integer_asymmetric(engine, tile, M):
+    """Exact small-integer operands with an asymmetric W: any MFMA operand/output layout slip
+    (row<->col swap, wrong k pairing) shows up as a hard mismatch."""
+    bm, bn, bk = TILES[tile]
+    N, K = 2 * bn, 3 * bk * 2
+    g = torch.Generator().manual_seed(M * 7 + tile)
+    A = torch.randint(-3, 4, (M, K), generator=g).float()
+    W = torch.randint(-3, 4, (N, K), generator=g).float()
+    W += (torch.arange(N)[:, None] % 5).float() - (torch.arange(K)[None, :] % 3).float()  # break symmetry
+    ref = (A.double() @ W.double().T).float()
+    out = engine.diag_gemm(_dev(A), _dev(W), tile=tile).cpu()
+    assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("tile,M,N,K", [(0, 500, 256, 768), (0, 130, 768, 3072), (2, 84, 768, 512),
+                                        (2, 300, 512, 1536), (1, 260, 64, 96)])
+@pytest.mark.parametrize("epi", ["none", "bias", "bias_gelu", "bias_res", "bias_gelu_res"])
+def test_gemm_epilogues(engine, tile, M, N, K, epi):
+    g = torch.Generator().manual_seed(11)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) * K ** -0.5
+    bias = torch.randn(N, generator=g) if "bias" in epi else None
+    R = torch.randn(M, N, generator=g) if "res" in epi else None
+    ref = A.double() @ W.double().T
+    if bias is not None:
+        ref = ref + bias.double()
+    if "gelu" in epi:
+        ref = F.gelu(ref)
+    if R is not None:
+        ref = ref + R.double()
+    out = engine.diag_gemm(_dev(A), _dev(W), _dev(bias) if bias is not None else None,
+                           _dev(R) if R is not None else None, gelu="gelu" in epi, tile=tile).cpu()
+    err = (out.double() - ref).abs().max().item()
+    assert err < 1e-5 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("N", [512, 768])
+@pytest.mark.parametrize("M", [1, 5, 199, 1030])
+def test_layernorm(engine, M, N):
+    g = torch.Generator().manual_seed(N + M)
+    x = torch.randn(M, N, generator=g) * 3 + 0.7
+    gamma, beta = 1 + 0.1 * torch.randn(N, generator=g), 0.1 * torch.randn(N, generator=g)
+    ref = F.layer_norm(x.double(), (N,), gamma.double(), beta.double(), 1e-5)
+    out = engine.diag_layernorm(_dev(x), _dev(gamma), _dev(beta)).cpu()
+    assert (out.double() - ref).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("B,T", [(2, 50), (1, 64), (2, 65), (1, 199), (1, 330)])
+@pytest.mark.parametrize("gain", [1.0, 8.0])
+def test_attention(engine, B, T, gain):
+    """softmax(q k^T) v per head vs float64; gain 8 makes the softmax peaky (online-softmax rescale path)."""
+    g = torch.Generator().manual_seed(T)
+    qkv = torch.randn(B * T, 2304, generator=g)
+    qkv[:, :1536] *= gain ** 0.5
+    q, k, v = (qkv[:, i * 768:(i + 1) * 768].double().view(B, T, 12, 64).transpose(1, 2) for i in range(3))
+    ref = (torch.softmax(q @ k.transpose(-1, -2), -1) @ v).transpose(1, 2).reshape(B * T, 768)
+    out = engine.diag_attention(_dev(qkv), B, T).cpu()
+    assert (out.double() - ref).abs().max().item() < 5e-6
+
+
+def test_attention_forced_rescale(engine):
+    """A key in a LATER tile dominates one query row: the running max must jump and rescale O, l."""
+    B, T = 1, 199
+    g = torch.Generator().manual_seed(3)
+    qkv = torch.randn(T, 2304, generator=g) * 0.3
+    qkv[7, 0:64] = 2.0           # query row 7, head 0
+    qkv[150, 768:832] = 2.0      # key 150 (third tile) aligned with it -> score 256
+    q, k, v = (qkv[:, i * 768:(i + 1) * 768].double().view(B, T, 12, 64).transpose(1, 2) for i in range(3))
+    ref = (torch.softmax(q @ k.transpose(-1, -2), -1) @ v).transpose(1, 2).reshape(T, 768)
+    out = engine.diag_attention(_dev(qkv), B, T).cpu()
+    assert torch.isfinite(out).all()
+    assert (out.double() - ref).abs().max().item() < 5e-6
+
+
+@pytest.mark.parametrize("Nd,Nr", [(2, 4), (70, 130), (33, 64), (300, 1000)])
+def test_pairwise_matches_scipy(engine, Nd, Nr):
+    from scipy.spatial.distance import cdist
+    rng = np.random.default_rng(Nd)
+    a = rng.standard_normal((Nd, 256)).astype(np.float32)
+    b = rng.standard_normal((Nr, 256)).astype(np.float32)
+    a /= np.linalg.norm(a, axis=1, keepdims=True)
+    b /= np.linalg.norm(b, axis=1, keepdims=True)
+    b[1] = a[0]                                                            # exact duplicate -> 0
+    b[2] = a[1] + 1e-4 * rng.standard_normal(256).astype(np.float32)       # small-distance regime
+    d, m = engine.pairwise(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda())
+    ref = cdist(a, b)
+    assert d.dtype == torch.float64
+    assert np.abs(d.cpu().numpy() - ref).max() < 1e-13
+    assert d[0, 1].item() == 0.0
+    assert np.abs(m.cpu().numpy() - ref.mean(axis=1)).max() < 1e-13
+    _, m2 = engine.pairwise(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), want_matrix=False)
+    assert torch.equal(m, m2)  # deterministic, matrix optional
+
+
+def test_l1_loss(engine):
+    g = torch.Generator().manual_seed(0)
+    B, T = 3, 50
+    a, b = torch.randn(12, B, T, 768, generator=g), torch.randn(12, B, T, 768, generator=g)
+    ea, eb = torch.randn(B, 256, generator=g), torch.randn(B, 256, generator=g)
+    ref = sum(F.l1_loss(a[i].double(), b[i].double()) for i in range(12)) + F.l1_loss(ea.double(), eb.double())
+    out = engine.l1_loss(_dev(a), _dev(b), _dev(ea), _dev(eb))
+    assert abs(out.item() - ref.item()) < 1e-5

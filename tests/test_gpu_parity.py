@@ -1,0 +1,141 @@
+"""GPU: the whole hot path through the C ABI vs the oracle and the committed golden vectors.
+
+Tolerances (fp32; BASELINE.json north star: per-pair NOMAD scores within 1e-4 of the reference):
+  intermediate activations / layer outputs  <= 1e-4 abs (values reach ~5)
+  embeddings (unit norm)                    <= 1e-5 abs
+  distances / NOMAD scores                  <= 1e-4 abs
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLD
+from oracle import nomad_oracle as O
+
+pytestmark = pytest.mark.gpu
+LAYER_TOL, EMB_TOL, SCORE_TOL = 1e-4, 1e-5, 1e-4
+
+
+def test_tiny_batch_vs_hf_golden(engine):
+    g = np.load(os.path.join(GOLD, "hf_tiny.npz"))
+    wav = torch.from_numpy(g["wav"]).cuda()
+    emb, layers = engine.embed(wav, want_layers=True)
+    torch.cuda.synchronize()
+    assert layers.shape == (12, 3, 18, 768)
+    for l in range(12):
+        err = (layers[l].cpu() - torch.from_numpy(g["layers"][l])).abs().max().item()
+        assert err < LAYER_TOL, (l, err)
+    assert (emb.cpu() - torch.from_numpy(g["emb"])).abs().max().item() < EMB_TOL
+
+
+def test_peaky_attention_vs_hf_golden(engine_peaky):
+    g = np.load(os.path.join(GOLD, "hf_tiny_peaky.npz"))
+    emb, layers = engine_peaky.embed(torch.from_numpy(g["wav"]).cuda(), want_layers=True)
+    assert (layers[0].cpu() - torch.from_numpy(g["layer0"])).abs().max().item() < LAYER_TOL
+    assert (layers[11].cpu() - torch.from_numpy(g["last"])).abs().max().item() < 5e-4
+    assert (emb.cpu() - torch.from_numpy(g["emb"])).abs().max().item() < 5e-5
+
+
+def test_every_stage_vs_oracle(engine, sd0):
+    """Intermediates of one small ragged batch: localises a failure to a kernel."""
+    gen = torch.Generator().manual_seed(42)
+    B, N = 2, 9000
+    wav = (0.1 * torch.randn(B, N, generator=gen)).clamp(-1, 1)
+    taps = {}
+    with torch.no_grad():
+        O.backbone(sd0, wav, taps)
+    engine.diag_keep_intermediates(True)
+    try:
+        engine.embed(wav.cuda())
+        torch.cuda.synchronize()
+        T = taps["conv6"].shape[1]
+        for i in range(7):
+            got = engine.diag_region(B, N, f"conv{i}").cpu().view(B, -1, 512)
+            err = (got - taps[f"conv{i}"]).abs().max().item()
+            assert err < 2e-5, (f"conv{i}", err)
+        xpad = engine.diag_region(B, N, "xpad").cpu().view(B, T + 128, 768)
+        assert xpad[:, :64].abs().max().item() == 0.0 and xpad[:, 64 + T:].abs().max().item() == 0.0
+        assert (xpad[:, 64:64 + T] - taps["proj"]).abs().max().item() < 2e-5
+    finally:
+        engine.diag_keep_intermediates(False)
+
+
+def test_batch_invariance_is_bit_exact(engine):
+    """A clip's embedding must not depend on what else is in the batch (no padding, no cross-clip math)."""
+    gen = torch.Generator().manual_seed(9)
+    wav = (0.1 * torch.randn(5, 16384, generator=gen)).clamp(-1, 1).cuda()
+    full = engine.embed(wav).clone()
+    for i in (0, 3):
+        one = engine.embed(wav[i:i + 1].contiguous())
+        assert torch.equal(one[0], full[i])
+
+
+def test_c2_shape_small_batch_vs_oracle(engine, sd0):
+    """Config C2's clip shape (16 kHz x 4 s -> T=199) at B=6 against the CPU oracle."""
+    gen = torch.Generator().manual_seed(0)
+    wav = (0.1 * torch.randn(6, 64000, generator=gen)).clamp(-1, 1)
+    with torch.no_grad():
+        ref = O.triplet_forward(sd0, wav)
+    emb = engine.embed(wav.cuda()).cpu()
+    assert (emb - ref).abs().max().item() < EMB_TOL
+    d, m = engine.pairwise(emb[:4].cuda().contiguous(), emb[4:].cuda().contiguous())
+    dref, mref = O.pairwise(ref[:4].numpy(), ref[4:].numpy())
+    assert np.abs(d.cpu().numpy() - dref).max() < SCORE_TOL
+    assert np.abs(m.cpu().numpy() - mref).max() < SCORE_TOL
+
+
+def test_predict_example_2x4(built_lib, sd0, tmp_path):
+    """The reference's own example (config C1) through the drop-in Nomad.predict surface."""
+    from nomad_amd.nomad import Nomad
+    g = np.load(os.path.join(GOLD, "hf_example_wavs.npz"))
+    nmd = Nomad(weights=sd0)
+    df_avg, df_dm = nmd.predict("dir", os.path.join(GOLD, "wavs", "nmr-data"), os.path.join(GOLD, "wavs", "test-data"),
+                                results_path=str(tmp_path))
+    assert df_avg.index.name == "Test File" and list(df_avg.columns) == ["NOMAD"]
+    assert sorted(df_dm.columns) == sorted(str(n) for n in g["nmr_names"])
+    for i, dn in enumerate(g["deg_names"]):
+        assert abs(df_avg.loc[str(dn), "NOMAD"] - round(float(g["mean"][i]), 3)) <= 1.01e-3
+        for j, rn in enumerate(g["nmr_names"]):
+            assert abs(df_dm.loc[str(dn), str(rn)] - round(float(g["dist"][i, j]), 3)) <= 1.01e-3
+    assert os.path.isfile(tmp_path / "nomad_avg.csv") and os.path.isfile(tmp_path / "nomad_scores.csv")
+    # unrounded parity: embeddings + distances at the north-star tolerance
+    emb = nmd.get_embeddings(os.path.join(GOLD, "wavs", "test-data")).set_index("filename")
+    for i, dn in enumerate(g["deg_names"]):
+        row = emb.loc[os.path.join(GOLD, "wavs", "test-data", f"{dn}.wav")].to_numpy(dtype=np.float32)
+        assert np.abs(row - g["deg_emb"][i]).max() < EMB_TOL
+    with pytest.raises(Exception, match="is not valid. Valid values are dir and csv"):
+        nmd.predict("zip", "a", "b")
+    with pytest.raises(Exception, match="does not exist"):
+        nmd.predict("dir", "/nonexistent/nmr", "/nonexistent/deg")
+
+
+def test_forward_loss_vs_hf_golden(built_lib, sd0):
+    from nomad_amd.nomad import Nomad
+    g = np.load(os.path.join(GOLD, "hf_loss.npz"))
+    nmd = Nomad(weights=sd0)
+    nmd.lossnet_layers.embedding_weight = torch.from_numpy(g["emb_w"]).cuda()
+    nmd.lossnet_layers.embedding_bias = torch.from_numpy(g["emb_b"]).cuda()
+    outs = nmd.lossnet_layers(torch.from_numpy(g["estimate"]).cuda())
+    assert len(outs) == 13 and outs[0].shape == (2, 50, 768) and outs[12].shape == (2, 256)
+    loss = nmd.forward(torch.from_numpy(g["estimate"]).cuda(), torch.from_numpy(g["clean"]).cuda())
+    assert loss.dim() == 0
+    assert abs(loss.item() - float(g["loss"])) < 1e-4
+
+
+def test_full_c2_batch_properties(engine):
+    """BASELINE config C2 at full size (256 x 64000): size-independent properties."""
+    gen = torch.Generator().manual_seed(0)
+    wav = (0.1 * torch.randn(256, 64000, generator=gen)).clamp(-1, 1).cuda()
+    emb = engine.embed(wav)
+    torch.cuda.synchronize()
+    assert torch.isfinite(emb).all()
+    assert (emb.norm(dim=1) - 1).abs().max().item() < 1e-5
+    one = engine.embed(wav[200:201].contiguous())
+    assert torch.equal(one[0], emb[200])            # batch-invariant, bit-exact
+    d, m = engine.pairwise(emb, emb)
+    assert d.diagonal().abs().max().item() == 0.0   # d(a,a) = 0 exactly (difference form)
+    assert (d - d.T).abs().max().item() == 0.0
+    assert d.max().item() <= 2.0 + 1e-6
+    assert (m - d.mean(dim=1)).abs().max().item() < 1e-12

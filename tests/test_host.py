@@ -1,0 +1,100 @@
+"""CPU: host-side logic - checkpoint layout, WAV front end, partitioning."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLD
+from nomad_amd import wavio
+from nomad_amd.weights import check_state_dict, expected_shapes, load_checkpoint, seeded_state_dict
+
+
+def test_state_dict_layout(sd0, tmp_path):
+    shapes = expected_shapes()
+    assert len(shapes) == 1 + 7 + 2 + 2 + 2 + 3 + 12 * 16 + 2 + 2
+    n_params = sum(int(np.prod(s)) for k, s in shapes.items())
+    assert 94.3e6 < n_params < 94.8e6  # wav2vec2-base + head (~94.6 M)
+    check_state_dict(sd0)
+    bad = dict(sd0)
+    del bad["embedding_layer.1.bias"]
+    with pytest.raises(KeyError):
+        check_state_dict(bad)
+    # round trip through the on-disk format the reference uses (torch.save of a state dict)
+    p = tmp_path / "nomad_best_model.pt"
+    small = {k: v for k, v in sd0.items()}
+    torch.save(small, p)
+    back = load_checkpoint(str(p))
+    assert all(torch.equal(back[k], sd0[k]) for k in shapes if not k.endswith("mask_emb"))
+
+
+def test_seeded_weights_are_deterministic():
+    a, b = seeded_state_dict(3), seeded_state_dict(3)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    c = seeded_state_dict(4)
+    assert not torch.equal(a["embedding_layer.1.weight"], c["embedding_layer.1.weight"])
+
+
+def test_wav_reader_formats(tmp_path):
+    from scipy.io import wavfile
+    rng = np.random.default_rng(0)
+    x16 = (rng.standard_normal((800, 2)) * 8000).astype(np.int16)
+    wavfile.write(tmp_path / "s16.wav", 22050, x16)
+    y, sr = wavio.read_wav(str(tmp_path / "s16.wav"))
+    assert sr == 22050 and y.shape == (2, 800)
+    assert np.array_equal(y, x16.T.astype(np.float32) / 32768.0)
+    xf = rng.standard_normal(500).astype(np.float32) * 0.1
+    wavfile.write(tmp_path / "f32.wav", 16000, xf)
+    y, sr = wavio.read_wav(str(tmp_path / "f32.wav"))
+    assert np.array_equal(y[0], xf)
+    x32 = (rng.standard_normal(300) * 1e8).astype(np.int32)
+    wavfile.write(tmp_path / "s32.wav", 8000, x32)
+    y, _ = wavio.read_wav(str(tmp_path / "s32.wav"))
+    assert np.allclose(y[0], x32 / 2147483648.0, atol=1e-7)
+    with pytest.raises(ValueError):
+        (tmp_path / "bad.wav").write_bytes(b"not a wav file at all")
+        wavio.read_wav(str(tmp_path / "bad.wav"))
+
+
+def test_load_processing_matches_reference_semantics(tmp_path):
+    from scipy.io import wavfile
+    # shipped fixture: 16 kHz mono PCM16 -> (1, N) fp32, untouched
+    w = wavio.load_processing(os.path.join(GOLD, "wavs", "nmr-data", "FI53_04.wav"))
+    assert w.shape == (1, 30671) and w.dtype == np.float32 and np.abs(w).max() <= 1.0
+    # stereo: (ch0 + ch1) / 2 (nomad.py:199-200); trim to 10 s (nomad.py:208-210)
+    rng = np.random.default_rng(1)
+    st = (rng.standard_normal((16000 * 11, 2)) * 3000).astype(np.int16)
+    wavfile.write(tmp_path / "st.wav", 16000, st)
+    w = wavio.load_processing(str(tmp_path / "st.wav"), trim=True)
+    assert w.shape == (1, 160000)
+    ref = (st[:160000, 0].astype(np.float32) / 32768.0 + st[:160000, 1].astype(np.float32) / 32768.0) / 2
+    assert np.allclose(w[0], ref, atol=1e-7)
+
+
+@pytest.mark.parametrize("sr", [8000, 22050, 44100, 48000])
+def test_resampler_properties(sr):
+    """torchaudio is not installable here, so the sinc resampler is pinned by its defining properties:
+    output length ceil(N*16000/sr), a band-limited tone is reproduced, DC gain is 1."""
+    n = sr  # one second
+    t = np.arange(n) / sr
+    tone = (0.5 * np.sin(2 * np.pi * 440.0 * t)).astype(np.float32)[None, :]
+    y = wavio.resample(tone, sr, 16000)
+    assert y.shape == (1, math.ceil(n * 16000 / sr))
+    t2 = np.arange(y.shape[1]) / 16000
+    want = 0.5 * np.sin(2 * np.pi * 440.0 * t2)
+    mid = slice(200, -200)
+    assert np.abs(y[0, mid] - want[mid]).max() < 2e-3
+    dc = wavio.resample(np.ones((1, n), dtype=np.float32), sr, 16000)
+    assert np.abs(dc[0, mid] - 1.0).max() < 2e-3
+
+
+def test_partition_covers_everything():
+    from nomad_amd.dist import partition
+    for n in (0, 1, 7, 1000, 10000):
+        for w in (1, 2, 4, 8):
+            spans = [partition(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
