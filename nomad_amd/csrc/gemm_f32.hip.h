@@ -68,27 +68,31 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + local;
 }
 
-template <int BM, int BN, int BK>
+template <int BM, int BN, int BK, int WM, int WN>
 struct GemmCfg {
+    static constexpr int THREADS = WM * WN * 64;
     static constexpr int LD = BK + 4;  // +16 B row pad: conflict-free ds_read_b128 (144 B / 80 B rows)
-    static constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 MFMA tiles per wave (2x2 waves)
-    static constexpr int A_CHUNKS = BM * BK / 4 / 256, B_CHUNKS = BN * BK / 4 / 256;
+    static constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile
+    static constexpr int TM = WTM / 32, TN = WTN / 32;  // 32x32 MFMA tiles per wave
+    static constexpr int A_CHUNKS = BM * BK / 4 / THREADS, B_CHUNKS = BN * BK / 4 / THREADS;
     static constexpr int LDS_BYTES = 2 * (BM + BN) * LD * 4;
 };
 
-template <int BM, int BN, int BK>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
-    using Cfg = GemmCfg<BM, BN, BK>;
-    constexpr int LD = Cfg::LD, TM = Cfg::TM, TN = Cfg::TN;
+// WM x WN waves per workgroup, each owning a (BM/WM) x (BN/WN) output tile.
+template <int BM, int BN, int BK, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_f32_kernel(const GemmParams p) {
+    using Cfg = GemmCfg<BM, BN, BK, WM, WN>;
+    constexpr int LD = Cfg::LD, TM = Cfg::TM, TN = Cfg::TN, NT = Cfg::THREADS;
     constexpr int KC = BK / 4;  // float4 chunks per tile row
-    static_assert(Cfg::A_CHUNKS >= 1 && Cfg::B_CHUNKS >= 1, "tile too small for 256 threads");
+    static_assert(Cfg::A_CHUNKS >= 1 && Cfg::B_CHUNKS >= 1 && TM >= 1 && TN >= 1, "bad tile");
+    static_assert(BM * BK / 4 % NT == 0 && BN * BK / 4 % NT == 0, "staging must divide evenly");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                 // [2][BM][LD]
     float* Bs = smem + 2 * BM * LD;   // [2][BN][LD]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave - wm * WN;
     const int nwg = p.tiles_m * p.tiles_n;
     const int wg = xcd_remap(blockIdx.x, nwg);
     const int tile_m = wg / p.tiles_n, tile_n = wg - tile_m * p.tiles_n;
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
     int a_dst[Cfg::A_CHUNKS], b_dst[Cfg::B_CHUNKS];
 #pragma unroll
     for (int i = 0; i < Cfg::A_CHUNKS; ++i) {
-        const int id = tid + i * 256, row = id / KC, kc = id - row * KC;
+        const int id = tid + i * NT, row = id / KC, kc = id - row * KC;
         int m = m0 + row;
         m = m < p.M ? m : p.M - 1;
         a_src[i] = Ag + row_addr(p.amap, m) + kc * 4;
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
     }
 #pragma unroll
     for (int i = 0; i < Cfg::B_CHUNKS; ++i) {
-        const int id = tid + i * 256, row = id / KC, kc = id - row * KC;
+        const int id = tid + i * NT, row = id / KC, kc = id - row * KC;
         b_src[i] = Wg + (long long)(n0 + row) * p.ldw + kc * 4;
         b_dst[i] = row * LD + kc * 4;
     }
@@ -125,29 +129,28 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // register staging uses native vector types: HIP's float4 class kept these arrays in scratch
     f32x4 a_reg[Cfg::A_CHUNKS], b_reg[Cfg::B_CHUNKS];
     const int nk = p.K / BK;
 
-// Staging is written as macros (not lambdas): by-reference captures of the register arrays kept
-// them in scratch memory.
 #define NOMAD_LOAD_TILE(KT)                                                                          \
     {                                                                                                \
         const int k0_ = (KT)*BK;                                                                     \
         const int kq_ = k0_ / p.kchunk;                                                              \
         const long long a_koff_ = (long long)kq_ * p.kstride + (k0_ - kq_ * p.kchunk);               \
         _Pragma("unroll") for (int i = 0; i < Cfg::A_CHUNKS; ++i) a_reg[i] =                         \
-            *reinterpret_cast<const f32x4*>(a_src[i] + a_koff_);                                    \
+            *reinterpret_cast<const f32x4*>(a_src[i] + a_koff_);                                     \
         _Pragma("unroll") for (int i = 0; i < Cfg::B_CHUNKS; ++i) b_reg[i] =                         \
-            *reinterpret_cast<const f32x4*>(b_src[i] + k0_);                                        \
+            *reinterpret_cast<const f32x4*>(b_src[i] + k0_);                                         \
     }
 #define NOMAD_STORE_TILE(BUF)                                                                        \
     {                                                                                                \
         float* as_ = As + (BUF)*BM * LD;                                                             \
         float* bs_ = Bs + (BUF)*BN * LD;                                                             \
         _Pragma("unroll") for (int i = 0; i < Cfg::A_CHUNKS; ++i)                                    \
-            *reinterpret_cast<f32x4*>(as_ + a_dst[i]) = a_reg[i];                                   \
+            *reinterpret_cast<f32x4*>(as_ + a_dst[i]) = a_reg[i];                                    \
         _Pragma("unroll") for (int i = 0; i < Cfg::B_CHUNKS; ++i)                                    \
-            *reinterpret_cast<f32x4*>(bs_ + b_dst[i]) = b_reg[i];                                   \
+            *reinterpret_cast<f32x4*>(bs_ + b_dst[i]) = b_reg[i];                                    \
     }
 
     NOMAD_LOAD_TILE(0)
@@ -155,8 +158,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
     __syncthreads();
 
     const int frag_row = lane & 31, frag_k = (lane >> 5) * 4;
-    const int a_frag_off = (wm * (BM / 2) + frag_row) * LD + frag_k;
-    const int b_frag_off = (wn * (BN / 2) + frag_row) * LD + frag_k;
+    const int a_frag_off = (wm * Cfg::WTM + frag_row) * LD + frag_k;
+    const int b_frag_off = (wn * Cfg::WTN + frag_row) * LD + frag_k;
 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
@@ -170,15 +173,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
             for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LD + kq * 8);
 #pragma unroll
             for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * LD + kq * 8);
+            // consecutive MFMAs go to different accumulators (no back-to-back dependent issue)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-                }
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][c], bf[j][c], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < nk) NOMAD_STORE_TILE(cur ^ 1)
         __syncthreads();
@@ -186,45 +188,47 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
 
 #undef NOMAD_LOAD_TILE
 #undef NOMAD_STORE_TILE
-    // epilogue: lane owns column n, 16 rows per 32x32 tile
+    // epilogue: lane owns column n, 16 rows per 32x32 tile.  Plain (single-clip) maps avoid the
+    // per-row integer division of row_addr().
     float* Cg = p.C + grp * p.c_goff;
     const float* Rg = p.R ? p.R + grp * p.r_goff : nullptr;
     const float* biasg = p.bias ? p.bias + grp * p.bias_goff : nullptr;
+    const bool c_plain = p.cmap.clip_rows >= p.M, r_plain = p.rmap.clip_rows >= p.M;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+        const int n = n0 + wn * Cfg::WTN + j * 32 + (lane & 31);
         const bool n_ok = n < p.n_valid;
         const float bv = (biasg && n_ok) ? biasg[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int m = m0 + wm * Cfg::WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m < p.M && n_ok) {
                     float v = acc[i][j][r] + bv;
                     if (p.gelu) v = gelu_erf(v);
-                    if (Rg) v += Rg[row_addr(p.rmap, m) + n];
-                    Cg[row_addr(p.cmap, m) + n] = v;
+                    if (Rg) v += Rg[(r_plain ? p.rmap.off + (long long)m * p.rmap.ld : row_addr(p.rmap, m)) + n];
+                    Cg[(c_plain ? p.cmap.off + (long long)m * p.cmap.ld : row_addr(p.cmap, m)) + n] = v;
                 }
             }
         }
     }
 }
 
-template <int BM, int BN, int BK>
+template <int BM, int BN, int BK, int WM = 2, int WN = 2>
 inline hipError_t launch_gemm(GemmParams p, int groups, hipStream_t s) {
-    using Cfg = GemmCfg<BM, BN, BK>;
+    using Cfg = GemmCfg<BM, BN, BK, WM, WN>;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = p.N / BN;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<BM, BN, BK>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<BM, BN, BK, WM, WN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     dim3 grid(p.tiles_m * p.tiles_n, groups);
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK>), grid, dim3(256), Cfg::LDS_BYTES, s, p);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN>), grid, dim3(Cfg::THREADS), Cfg::LDS_BYTES, s, p);
     return hipGetLastError();
 }
 

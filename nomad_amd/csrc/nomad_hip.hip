@@ -174,9 +174,19 @@ int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s) {
     const double flops = 2.0 * p.M * (double)p.n_valid * p.K * groups;
     Scope sc(c, s, NOMAD_K_GEMM, flops);
     hipError_t e;
-    if (tile == 0) e = launch_gemm<128, 128, 32>(p, groups, s);
-    else if (tile == 1) e = launch_gemm<128, 64, 16>(p, groups, s);
-    else e = launch_gemm<64, 64, 32>(p, groups, s);
+    switch (tile) {
+        case 0: e = launch_gemm<128, 128, 32, 2, 2>(p, groups, s); break;
+        case 1: e = launch_gemm<128, 64, 16, 2, 2>(p, groups, s); break;
+        case 2: e = launch_gemm<64, 64, 32, 2, 2>(p, groups, s); break;
+        // experimental instantiations (tools/gemm_sweep.py)
+        case 3: e = launch_gemm<128, 128, 16, 2, 2>(p, groups, s); break;
+        case 4: e = launch_gemm<256, 128, 32, 4, 2>(p, groups, s); break;
+        case 5: e = launch_gemm<256, 256, 32, 4, 2>(p, groups, s); break;
+        case 6: e = launch_gemm<256, 128, 16, 4, 2>(p, groups, s); break;
+        case 7: e = launch_gemm<128, 256, 32, 2, 2>(p, groups, s); break;
+        case 8: e = launch_gemm<256, 256, 16, 4, 2>(p, groups, s); break;
+        default: return fail(NOMAD_ERR_INVALID, "unknown gemm tile id %d", tile);
+    }
     if (e != hipSuccess) return fail(NOMAD_ERR_HIP, "gemm launch: %s", hipGetErrorString(e));
     return 0;
 }
@@ -580,7 +590,9 @@ int nomad_profile_read(nomad_ctx* c, double ms[NOMAD_K_COUNT], long long launche
 int nomad_diag_gemm(nomad_ctx* c, const float* A, const float* W, const float* bias, const float* R, float* C, int M,
                     int N, int K, int gelu, int tile, nomad_stream_t stream) {
     if (!c || !A || !W || !C || M <= 0) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: bad argument");
-    const int bn = tile == 0 ? 128 : 64, bk = tile == 1 ? 16 : 32;
+    static const int kBN[] = {128, 64, 64, 128, 128, 256, 128, 256, 256}, kBK[] = {32, 16, 32, 16, 32, 32, 16, 32, 16};
+    if (tile < 0 || tile > 8) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile id %d", tile);
+    const int bn = kBN[tile], bk = kBK[tile];
     if (N % bn || K % bk) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: N %% %d or K %% %d != 0", bn, bk);
     return run_gemm(c, dense(A, K, W, bias, R, C, M, N, K, gelu), 1, tile, static_cast<hipStream_t>(stream));
 }

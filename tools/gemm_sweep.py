@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Time the fp32 MFMA GEMM instantiations (nomad_diag_gemm tile ids) on the hot shapes of config C2.
+Usage on the GPU box:  python3 tools/gemm_sweep.py [--tiles 0,3,4] [--shapes fc1,qkv] [--iters 5]"""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from nomad_amd.engine import Engine  # noqa: E402
+from nomad_amd.weights import seeded_state_dict  # noqa: E402
+
+SHAPES = {  # name: (M, N, K, bias, gelu, residual)
+    "out": (50944, 768, 768, True, False, True),
+    "qkv": (50944, 2304, 768, True, False, False),
+    "fc1": (50944, 3072, 768, True, True, False),
+    "fc2": (50944, 768, 3072, True, False, True),
+    "conv3": (409344, 512, 1536, False, True, False),
+    "conv5": (102144, 512, 1024, False, True, False),
+    "fc1_nogelu": (50944, 3072, 768, True, False, False),
+}
+TILE_NAMES = {0: "128x128x32 w2x2", 1: "128x64x16 w2x2", 2: "64x64x32 w2x2", 3: "128x128x16 w2x2",
+              4: "256x128x32 w4x2", 5: "256x256x32 w4x2", 6: "256x128x16 w4x2", 7: "128x256x32 w2x2",
+              8: "256x256x16 w4x2"}
+BN = {0: 128, 1: 64, 2: 64, 3: 128, 4: 128, 5: 256, 6: 128, 7: 256, 8: 256}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tiles", default="0,3,4,5,6,7,8")
+    ap.add_argument("--shapes", default="out,qkv,fc1,fc2,conv3,fc1_nogelu")
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--json", default=None)
+    a = ap.parse_args()
+    eng = Engine(seeded_state_dict(0), 0)
+    g = torch.Generator().manual_seed(0)
+    res = []
+    for sname in a.shapes.split(","):
+        M, N, K, has_b, gelu, has_r = SHAPES[sname]
+        A = torch.randn(M, K, generator=g).cuda()
+        W = (torch.randn(N, K, generator=g) * K ** -0.5).cuda()
+        b = torch.randn(N, generator=g).cuda() if has_b else None
+        R = torch.randn(M, N, generator=g).cuda() if has_r else None
+        base = None
+        for t in (int(x) for x in a.tiles.split(",")):
+            if N % BN[t]:
+                continue
+            out = eng.diag_gemm(A, W, b, R, gelu=gelu, tile=t)  # warm-up
+            if base is None:
+                base = out.clone()
+            ok = bool(torch.equal(out, base))  # same k order in every instantiation -> bit-identical
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.iters + 1)]
+            ev[0].record()
+            for i in range(a.iters):
+                eng.diag_gemm(A, W, b, R, gelu=gelu, tile=t)
+                ev[i + 1].record()
+            torch.cuda.synchronize()
+            ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(a.iters))
+            tf = 2.0 * M * N * K / (ms[len(ms) // 2] * 1e-3) / 1e12
+            row = {"shape": sname, "tile": t, "cfg": TILE_NAMES[t], "ms_med": round(ms[len(ms) // 2], 4),
+                   "ms_min": round(ms[0], 4), "tflops": round(tf, 1), "bit_identical": ok}
+            res.append(row)
+            print(json.dumps(row), flush=True)
+        del A, W, b, R
+    if a.json:
+        json.dump(res, open(a.json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
