@@ -53,6 +53,7 @@ struct GemmParams {
     long long a_goff, w_goff, c_goff, r_goff;
     int bias_goff;
     int tiles_m, tiles_n;
+    int group_m;          // >0: walk tiles down M in groups of group_m row-tiles (L2 reuse of W), 0: n fastest
 };
 
 __device__ __forceinline__ float gelu_erf(float x) {
@@ -68,6 +69,22 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + local;
 }
 
+// Linear tile id -> (tile_m, tile_n).  group_m > 0: groups of group_m row-tiles are walked m-fastest, so
+// the ~64 workgroups that are resident on one XCD together cover a group_m x (64/group_m) block of tiles
+// and each A / W panel fetched into that XCD's L2 is shared by several of them.
+__device__ __forceinline__ void tile_coords(int wg, int tiles_m, int tiles_n, int group_m, int& tm, int& tn) {
+    if (group_m <= 0) {
+        tm = wg / tiles_n;
+        tn = wg - tm * tiles_n;
+        return;
+    }
+    const int per_group = group_m * tiles_n;
+    const int g = wg / per_group, in = wg - g * per_group;
+    const int rows = min(group_m, tiles_m - g * group_m);
+    tn = in / rows;
+    tm = g * group_m + (in - tn * rows);
+}
+
 template <int BM, int BN, int BK, int WM, int WN>
 struct GemmCfg {
     static constexpr int THREADS = WM * WN * 64;
@@ -79,7 +96,9 @@ struct GemmCfg {
 };
 
 // WM x WN waves per workgroup, each owning a (BM/WM) x (BN/WN) output tile.
-template <int BM, int BN, int BK, int WM, int WN>
+// ABL != 0 are timing-only ablations (wrong results): 1 = no global loads / LDS stores in the K loop,
+// 2 = additionally no barrier, 3 = loads and stores kept but no barrier.
+template <int BM, int BN, int BK, int WM, int WN, int ABL = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_kernel(const GemmParams p) {
     using Cfg = GemmCfg<BM, BN, BK, WM, WN>;
     constexpr int LD = Cfg::LD, TM = Cfg::TM, TN = Cfg::TN, NT = Cfg::THREADS;
@@ -95,7 +114,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_kernel(const GemmParams 
     const int wm = wave / WN, wn = wave - wm * WN;
     const int nwg = p.tiles_m * p.tiles_n;
     const int wg = xcd_remap(blockIdx.x, nwg);
-    const int tile_m = wg / p.tiles_n, tile_n = wg - tile_m * p.tiles_n;
+    int tile_m, tile_n;
+    tile_coords(wg, p.tiles_m, p.tiles_n, p.group_m, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int grp = blockIdx.y;
 
@@ -155,6 +175,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_kernel(const GemmParams 
 
     NOMAD_LOAD_TILE(0)
     NOMAD_STORE_TILE(0)
+    if (ABL != 0) NOMAD_STORE_TILE(1)
     __syncthreads();
 
     const int frag_row = lane & 31, frag_k = (lane >> 5) * 4;
@@ -163,7 +184,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_kernel(const GemmParams 
 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) NOMAD_LOAD_TILE(kt + 1)  // global loads in flight under the MFMAs
+        if (kt + 1 < nk && ABL != 1 && ABL != 2) NOMAD_LOAD_TILE(kt + 1)  // global loads in flight under the MFMAs
         const float* as = As + cur * BM * LD + a_frag_off;
         const float* bs = Bs + cur * BN * LD + b_frag_off;
 #pragma unroll
@@ -182,8 +203,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_kernel(const GemmParams 
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][c], bf[j][c], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) NOMAD_STORE_TILE(cur ^ 1)
-        __syncthreads();
+        if (kt + 1 < nk && ABL != 1 && ABL != 2) NOMAD_STORE_TILE(cur ^ 1)
+        if (ABL < 2) __syncthreads();
     }
 
 #undef NOMAD_LOAD_TILE
@@ -215,20 +236,179 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_kernel(const GemmParams 
     }
 }
 
-template <int BM, int BN, int BK, int WM = 2, int WN = 2>
-inline hipError_t launch_gemm(GemmParams p, int groups, hipStream_t s) {
+// ---------------------------------------------------------------------------------------------------
+// LDS-DMA variant: tiles go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR round trip, no ds_write).
+// One wave-instruction fills 1 KiB of LDS linearly (wave-uniform base + lane*16 B), so the LDS image is
+// unpadded [rows][BK]; the bank-conflict fix is an XOR swizzle applied on the per-lane SOURCE address and
+// again on the fragment read (cdna_hip_programming.md rule 21): 16-B chunk c of row r lives at chunk
+// c ^ ((r / RB) % KC), RB = rows per 256-B bank row.  A 16-lane ds_read_b128 group touches 16 rows that
+// are distinct mod 16 at one logical chunk, which that map spreads over all 16 slots of the bank row.
+template <int BM, int BN, int BK, int WM, int WN>
+struct GldsCfg {
+    static constexpr int THREADS = WM * WN * 64;
+    static constexpr int KC = BK / 4, RB = 16 / KC;
+    static constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+    static constexpr int A_CHUNKS = BM * KC / THREADS, B_CHUNKS = BN * KC / THREADS;
+    static constexpr int LDS_BYTES = 2 * (BM + BN) * BK * 4;
+};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int BM, int BN, int BK, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_f32_glds_kernel(const GemmParams p) {
+    using Cfg = GldsCfg<BM, BN, BK, WM, WN>;
+    constexpr int TM = Cfg::TM, TN = Cfg::TN, NT = Cfg::THREADS, KC = Cfg::KC, RB = Cfg::RB;
+    static_assert(BK == 16 || BK == 32, "swizzle is written for 64-B and 128-B rows");
+    static_assert(BM * KC % NT == 0 && BN * KC % NT == 0 && TM >= 1 && TN >= 1, "bad tile");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                 // [2][BM][BK]
+    float* Bs = smem + 2 * BM * BK;   // [2][BN][BK]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int wg = xcd_remap(blockIdx.x, nwg);
+    int tile_m, tile_n;
+    tile_coords(wg, p.tiles_m, p.tiles_n, p.group_m, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int grp = blockIdx.y;
+    const float* Ag = p.A + grp * p.a_goff;
+    const float* Wg = p.W + grp * p.w_goff;
+
+    // Per-lane source pointers; LDS chunk id = tid + i*NT is linear in the lane within each wave-instruction.
+    const float* a_src[Cfg::A_CHUNKS];
+    const float* b_src[Cfg::B_CHUNKS];
+#pragma unroll
+    for (int i = 0; i < Cfg::A_CHUNKS; ++i) {
+        const int id = tid + i * NT, row = id / KC, pc = id - row * KC;
+        int m = m0 + row;
+        m = m < p.M ? m : p.M - 1;
+        a_src[i] = Ag + row_addr(p.amap, m) + ((pc ^ ((row / RB) % KC)) * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < Cfg::B_CHUNKS; ++i) {
+        const int id = tid + i * NT, row = id / KC, pc = id - row * KC;
+        b_src[i] = Wg + (long long)(n0 + row) * p.ldw + ((pc ^ ((row / RB) % KC)) * 4);
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = p.K / BK;
+#define NOMAD_GLDS_TILE(KT, BUF)                                                                         \
+    {                                                                                                    \
+        const int k0_ = (KT)*BK;                                                                         \
+        const int kq_ = k0_ / p.kchunk;                                                                  \
+        const long long a_koff_ = (long long)kq_ * p.kstride + (k0_ - kq_ * p.kchunk);                   \
+        float* as_ = As + (BUF)*BM * BK + wave * 256;                                                    \
+        float* bs_ = Bs + (BUF)*BN * BK + wave * 256;                                                    \
+        _Pragma("unroll") for (int i = 0; i < Cfg::A_CHUNKS; ++i)                                        \
+            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + a_koff_), (lptr_t)(as_ + i * NT * 4), 16, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < Cfg::B_CHUNKS; ++i)                                        \
+            __builtin_amdgcn_global_load_lds((gptr_t)(b_src[i] + k0_), (lptr_t)(bs_ + i * NT * 4), 16, 0, 0);     \
+    }
+
+    NOMAD_GLDS_TILE(0, 0)
+
+    // fragment read offsets (floats): row R, logical chunk 2*kq + h -> physical chunk ^ swz(R)
+    const int frag_row = lane & 31, h = lane >> 5;
+    const int swz = (frag_row / RB) % KC;  // WTM, 32 are multiples of RB*KC: independent of the tile offsets
+    int koff[BK / 8];
+#pragma unroll
+    for (int kq = 0; kq < BK / 8; ++kq) koff[kq] = ((kq * 2 + h) ^ swz) * 4;
+    const int a_row_off = (wm * Cfg::WTM + frag_row) * BK;
+    const int b_row_off = (wn * Cfg::WTN + frag_row) * BK;
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        __syncthreads();  // tile kt has landed (vmcnt(0)) and every wave is done with buffer cur^1
+        if (kt + 1 < nk) NOMAD_GLDS_TILE(kt + 1, cur ^ 1)
+        const float* as = As + cur * BM * BK + a_row_off;
+        const float* bs = Bs + cur * BN * BK + b_row_off;
+#pragma unroll
+        for (int kq = 0; kq < BK / 8; ++kq) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * BK + koff[kq]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * BK + koff[kq]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][c], bf[j][c], acc[i][j], 0, 0, 0);
+        }
+    }
+#undef NOMAD_GLDS_TILE
+
+    float* Cg = p.C + grp * p.c_goff;
+    const float* Rg = p.R ? p.R + grp * p.r_goff : nullptr;
+    const float* biasg = p.bias ? p.bias + grp * p.bias_goff : nullptr;
+    const bool c_plain = p.cmap.clip_rows >= p.M, r_plain = p.rmap.clip_rows >= p.M;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * Cfg::WTN + j * 32 + (lane & 31);
+        const bool n_ok = n < p.n_valid;
+        const float bv = (biasg && n_ok) ? biasg[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * Cfg::WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < p.M && n_ok) {
+                    float v = acc[i][j][r] + bv;
+                    if (p.gelu) v = gelu_erf(v);
+                    if (Rg) v += Rg[(r_plain ? p.rmap.off + (long long)m * p.rmap.ld : row_addr(p.rmap, m)) + n];
+                    Cg[(c_plain ? p.cmap.off + (long long)m * p.cmap.ld : row_addr(p.cmap, m)) + n] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int BK, int WM, int WN>
+inline hipError_t launch_gemm_glds(GemmParams p, int groups, hipStream_t s, int extra_lds = 0) {
+    using Cfg = GldsCfg<BM, BN, BK, WM, WN>;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = p.N / BN;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_glds_kernel<BM, BN, BK, WM, WN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    dim3 grid(p.tiles_m * p.tiles_n, groups);
+    hipLaunchKernelGGL((gemm_f32_glds_kernel<BM, BN, BK, WM, WN>), grid, dim3(Cfg::THREADS), Cfg::LDS_BYTES + extra_lds,
+                       s, p);
+    return hipGetLastError();
+}
+
+template <int BM, int BN, int BK, int WM = 2, int WN = 2, int ABL = 0>
+inline hipError_t launch_gemm(GemmParams p, int groups, hipStream_t s, int extra_lds = 0) {
     using Cfg = GemmCfg<BM, BN, BK, WM, WN>;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = p.N / BN;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<BM, BN, BK, WM, WN>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<BM, BN, BK, WM, WN, ABL>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     dim3 grid(p.tiles_m * p.tiles_n, groups);
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN>), grid, dim3(Cfg::THREADS), Cfg::LDS_BYTES, s, p);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN, ABL>), grid, dim3(Cfg::THREADS), Cfg::LDS_BYTES + extra_lds, s,
+                       p);
     return hipGetLastError();
 }
 

@@ -170,7 +170,14 @@ struct Scope {
 
 RowMap plain_map(int M, int ld) { return RowMap{0, 0, M > 0 ? M : 1, ld}; }
 
-int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s) {
+// LDS padding that limits residency to `occ` workgroups per CU (0 = no limit) for a kernel using `lds` bytes.
+int occ_pad(int occ, int lds) {
+    if (occ <= 0) return 0;
+    const int budget = (160 * 1024 / occ) & ~255;
+    return budget > lds ? budget - lds : 0;
+}
+
+int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, int occ = 0) {
     const double flops = 2.0 * p.M * (double)p.n_valid * p.K * groups;
     Scope sc(c, s, NOMAD_K_GEMM, flops);
     hipError_t e;
@@ -185,6 +192,29 @@ int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s) {
         case 6: e = launch_gemm<256, 128, 16, 4, 2>(p, groups, s); break;
         case 7: e = launch_gemm<128, 256, 32, 2, 2>(p, groups, s); break;
         case 8: e = launch_gemm<256, 256, 16, 4, 2>(p, groups, s); break;
+        case 9: e = launch_gemm<128, 128, 16, 4, 2>(p, groups, s, 16 * 1024); break;   // 8 waves, forced 2 WG/CU
+        case 10: e = launch_gemm<128, 128, 16, 2, 4>(p, groups, s, 16 * 1024); break;
+        case 11: e = launch_gemm<128, 128, 32, 4, 2>(p, groups, s); break;
+        case 12: e = launch_gemm<128, 128, 32, 2, 4>(p, groups, s); break;
+        case 13: e = launch_gemm<128, 128, 16, 4, 2>(p, groups, s); break;               // 3 WG/CU if registers allow
+        case 20: e = launch_gemm_glds<128, 128, 32, 2, 2>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 2, 2>::LDS_BYTES)); break;
+        case 21: e = launch_gemm_glds<256, 128, 16, 4, 2>(p, groups, s, occ_pad(occ, GldsCfg<256, 128, 16, 4, 2>::LDS_BYTES)); break;
+        case 22: e = launch_gemm_glds<128, 128, 16, 4, 2>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 16, 4, 2>::LDS_BYTES)); break;
+        case 23: e = launch_gemm_glds<256, 128, 32, 4, 2>(p, groups, s, occ_pad(occ, GldsCfg<256, 128, 32, 4, 2>::LDS_BYTES)); break;
+        case 24: e = launch_gemm_glds<256, 256, 16, 4, 2>(p, groups, s, occ_pad(occ, GldsCfg<256, 256, 16, 4, 2>::LDS_BYTES)); break;
+        case 25: e = launch_gemm_glds<256, 256, 32, 4, 2>(p, groups, s, occ_pad(occ, GldsCfg<256, 256, 32, 4, 2>::LDS_BYTES)); break;
+        case 26: e = launch_gemm_glds<128, 128, 16, 2, 2>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 16, 2, 2>::LDS_BYTES)); break;
+        case 27: e = launch_gemm_glds<256, 256, 16, 4, 4>(p, groups, s, occ_pad(occ, GldsCfg<256, 256, 16, 4, 4>::LDS_BYTES)); break;
+        case 28: e = launch_gemm_glds<128, 64, 16, 2, 2>(p, groups, s, occ_pad(occ, GldsCfg<128, 64, 16, 2, 2>::LDS_BYTES)); break;
+        case 29: e = launch_gemm_glds<128, 64, 32, 4, 2>(p, groups, s, occ_pad(occ, GldsCfg<128, 64, 32, 4, 2>::LDS_BYTES)); break;
+        case 30: e = launch_gemm_glds<128, 64, 32, 2, 2>(p, groups, s, occ_pad(occ, GldsCfg<128, 64, 32, 2, 2>::LDS_BYTES)); break;
+        case 31: e = launch_gemm_glds<128, 128, 32, 4, 2>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 4, 2>::LDS_BYTES)); break;
+        case 14: e = launch_gemm<128, 128, 32, 2, 2, 1>(p, groups, s); break;            // ablations of tile 0
+        case 15: e = launch_gemm<128, 128, 32, 2, 2, 2>(p, groups, s); break;
+        case 16: e = launch_gemm<128, 128, 32, 2, 2, 3>(p, groups, s); break;
+        case 17: e = launch_gemm<256, 128, 16, 4, 2, 1>(p, groups, s); break;            // ablations of tile 6
+        case 18: e = launch_gemm<256, 128, 16, 4, 2, 2>(p, groups, s); break;
+        case 19: e = launch_gemm<256, 128, 16, 4, 2, 3>(p, groups, s); break;
         default: return fail(NOMAD_ERR_INVALID, "unknown gemm tile id %d", tile);
     }
     if (e != hipSuccess) return fail(NOMAD_ERR_HIP, "gemm launch: %s", hipGetErrorString(e));
@@ -213,9 +243,17 @@ GemmParams dense(const float* A, int lda, const float* W, const float* bias, con
     return p;
 }
 
-int pick_tile(int M, int N) {
-    if (N % 128 == 0 && M >= 1024) return 0;
-    return 2;  // 64x64x32 for small problems (all N here are multiples of 64)
+// Kernel instantiation for a dense problem (measured on MI355X, tools/gemm_sweep.py, profiles/):
+//   21 = LDS-DMA 256x128x16, 8 waves: best when the grid is many rounds deep (QKV, fc1, conv1-4)
+//   29 = LDS-DMA 128x64x32, 8 waves: finer tiles for N = 768 / 512 problems where a 256x128 grid is only
+//        2-3 rounds deep and the last partial round would idle a third of the CUs
+//    2 = register-staged 64x64x32 for tiny batches
+int pick_tile(int M, int N, int K) {
+    (void)K;
+    if (M < 1024) return 2;
+    const long long tiles256 = (long long)((M + 255) / 256) * (N / 128);
+    if (N % 128 == 0 && tiles256 >= 2048) return 21;
+    return 29;
 }
 
 int run_layernorm(nomad_ctx* c, const float* in, const float* g, const float* b, float* out, float* out2, int M, int N,
@@ -434,7 +472,7 @@ int nomad_embed(nomad_ctx* c, const float* wav, int B, int n_samples, const floa
         p.cmap = plain_map(p.M, 512);
         p.rmap = p.cmap;
         p.gelu = 1;
-        if ((rc = run_gemm(c, p, 1, pick_tile(p.M, 512), s))) return rc;
+        if ((rc = run_gemm(c, p, 1, pick_tile(p.M, 512, p.K), s))) return rc;
     }
 
     // ---- LayerNorm(512) + post_extract_proj into the padded pos-conv buffer ------------------
@@ -448,7 +486,7 @@ int nomad_embed(nomad_ctx* c, const float* wav, int B, int n_samples, const floa
     {
         GemmParams p = dense(F(lay.featln), 512, c->proj_w, c->proj_b, nullptr, xpad, M, 768, 512, 0);
         p.cmap = pad_map;
-        if ((rc = run_gemm(c, p, 1, pick_tile(M, 768), s))) return rc;
+        if ((rc = run_gemm(c, p, 1, pick_tile(M, 768, 512), s))) return rc;
     }
     // ---- pos-conv: 16 groups x (M x 48 x 6144), x + gelu(conv + bias) -------------------------
     {
@@ -474,7 +512,7 @@ int nomad_embed(nomad_ctx* c, const float* wav, int B, int n_samples, const floa
         p.N = 64;
         p.n_valid = 48;
         p.gelu = 1;
-        if ((rc = run_gemm(c, p, 16, 1, s))) return rc;
+        if ((rc = run_gemm(c, p, 16, M >= 1024 ? 28 : 1, s))) return rc;
     }
     float* x = F(lay.x);
     float* x2 = F(lay.x2);
@@ -485,16 +523,16 @@ int nomad_embed(nomad_ctx* c, const float* wav, int B, int n_samples, const floa
     for (int l = 0; l < NOMAD_NUM_LAYERS; ++l) {
         const LayerDev& d = c->layers[l];
         if ((rc = run_gemm(c, dense(x, 768, d.qkv_w, d.qkv_b, nullptr, F(lay.qkv), M, 2304, 768, 0), 1,
-                           pick_tile(M, 2304), s)))
+                           pick_tile(M, 2304, 768), s)))
             return rc;
         if ((rc = run_attention(c, F(lay.qkv), F(lay.ctxb), B, T, s))) return rc;
-        if ((rc = run_gemm(c, dense(F(lay.ctxb), 768, d.o_w, d.o_b, x, y, M, 768, 768, 0), 1, pick_tile(M, 768), s)))
+        if ((rc = run_gemm(c, dense(F(lay.ctxb), 768, d.o_w, d.o_b, x, y, M, 768, 768, 0), 1, pick_tile(M, 768, 768), s)))
             return rc;
         if ((rc = run_layernorm(c, y, d.ln1_w, d.ln1_b, x2, nullptr, M, 768, s))) return rc;
         if ((rc = run_gemm(c, dense(x2, 768, d.fc1_w, d.fc1_b, nullptr, F(lay.h), M, 3072, 768, 1), 1,
-                           pick_tile(M, 3072), s)))
+                           pick_tile(M, 3072, 768), s)))
             return rc;
-        if ((rc = run_gemm(c, dense(F(lay.h), 3072, d.fc2_w, d.fc2_b, x2, y, M, 768, 3072, 0), 1, pick_tile(M, 768), s)))
+        if ((rc = run_gemm(c, dense(F(lay.h), 3072, d.fc2_w, d.fc2_b, x2, y, M, 768, 3072, 0), 1, pick_tile(M, 768, 3072), s)))
             return rc;
         float* lo = layers_out ? layers_out + (size_t)l * M * 768 : nullptr;
         if ((rc = run_layernorm(c, y, d.ln2_w, d.ln2_b, x, lo, M, 768, s))) return rc;
@@ -590,11 +628,20 @@ int nomad_profile_read(nomad_ctx* c, double ms[NOMAD_K_COUNT], long long launche
 int nomad_diag_gemm(nomad_ctx* c, const float* A, const float* W, const float* bias, const float* R, float* C, int M,
                     int N, int K, int gelu, int tile, nomad_stream_t stream) {
     if (!c || !A || !W || !C || M <= 0) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: bad argument");
-    static const int kBN[] = {128, 64, 64, 128, 128, 256, 128, 256, 256}, kBK[] = {32, 16, 32, 16, 32, 32, 16, 32, 16};
-    if (tile < 0 || tile > 8) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile id %d", tile);
+    // diagnostics: tile id + 100 * group_m (grouped tile order) + 10000 * occ (workgroups per CU limit)
+    const int occ = tile / 10000;
+    const int group_m = (tile % 10000) / 100;
+    tile %= 100;
+    static const int kBN[] = {128, 64, 64, 128, 128, 256, 128, 256, 256, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128,
+                              128, 128, 128, 128, 256, 256, 128, 256, 64, 64, 64, 128};
+    static const int kBK[] = {32, 16, 32, 16, 32, 32, 16, 32, 16, 16, 16, 32, 32, 16, 32, 32, 32, 16, 16, 16,
+                              32, 16, 16, 32, 16, 32, 16, 16, 16, 32, 32, 32};
+    if (tile < 0 || tile > 31) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile id %d", tile);
     const int bn = kBN[tile], bk = kBK[tile];
     if (N % bn || K % bk) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: N %% %d or K %% %d != 0", bn, bk);
-    return run_gemm(c, dense(A, K, W, bias, R, C, M, N, K, gelu), 1, tile, static_cast<hipStream_t>(stream));
+    GemmParams p = dense(A, K, W, bias, R, C, M, N, K, gelu);
+    p.group_m = group_m;
+    return run_gemm(c, p, 1, tile, static_cast<hipStream_t>(stream), occ);
 }
 
 int nomad_diag_layernorm(nomad_ctx* c, const float* in, const float* g, const float* b, float* out, int M, int N,

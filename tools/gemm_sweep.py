@@ -20,11 +20,20 @@ SHAPES = {  # name: (M, N, K, bias, gelu, residual)
     "conv3": (409344, 512, 1536, False, True, False),
     "conv5": (102144, 512, 1024, False, True, False),
     "fc1_nogelu": (50944, 3072, 768, True, False, False),
+    "proj": (50944, 768, 512, True, False, False),
 }
 TILE_NAMES = {0: "128x128x32 w2x2", 1: "128x64x16 w2x2", 2: "64x64x32 w2x2", 3: "128x128x16 w2x2",
               4: "256x128x32 w4x2", 5: "256x256x32 w4x2", 6: "256x128x16 w4x2", 7: "128x256x32 w2x2",
-              8: "256x256x16 w4x2"}
+              8: "256x256x16 w4x2", 9: "128x128x16 w4x2 2wg/cu", 10: "128x128x16 w2x4 2wg/cu", 11: "128x128x32 w4x2",
+              12: "128x128x32 w2x4", 13: "128x128x16 w4x2", 14: "t0 ABL1 no-loads", 15: "t0 ABL2 no-loads,no-barrier",
+              16: "t0 ABL3 no-barrier", 17: "t6 ABL1 no-loads", 18: "t6 ABL2 no-loads,no-barrier", 19: "t6 ABL3 no-barrier"}
 BN = {0: 128, 1: 64, 2: 64, 3: 128, 4: 128, 5: 256, 6: 128, 7: 256, 8: 256}
+BN.update({t: 128 for t in range(9, 20)})
+TILE_NAMES.update({20: "glds 128x128x32 w2x2", 21: "glds 256x128x16 w4x2", 22: "glds 128x128x16 w4x2",
+                   23: "glds 256x128x32 w4x2", 24: "glds 256x256x16 w4x2", 25: "glds 256x256x32 w4x2",
+                   26: "glds 128x128x16 w2x2", 27: "glds 256x256x16 w4x4"})
+BN.update({20: 128, 21: 128, 22: 128, 23: 128, 24: 256, 25: 256, 26: 128, 27: 256, 28: 64, 29: 64, 30: 64, 31: 128})
+TILE_NAMES.update({28: "glds 128x64x16 w2x2", 29: "glds 128x64x32 w4x2", 30: "glds 128x64x32 w2x2", 31: "glds 128x128x32 w4x2"})
 
 
 def main():
@@ -45,7 +54,7 @@ def main():
         R = torch.randn(M, N, generator=g).cuda() if has_r else None
         base = None
         for t in (int(x) for x in a.tiles.split(",")):
-            if N % BN[t]:
+            if N % BN[t % 100]:
                 continue
             out = eng.diag_gemm(A, W, b, R, gelu=gelu, tile=t)  # warm-up
             if base is None:
@@ -59,7 +68,7 @@ def main():
             torch.cuda.synchronize()
             ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(a.iters))
             tf = 2.0 * M * N * K / (ms[len(ms) // 2] * 1e-3) / 1e12
-            row = {"shape": sname, "tile": t, "cfg": TILE_NAMES[t], "ms_med": round(ms[len(ms) // 2], 4),
+            row = {"shape": sname, "tile": t, "cfg": TILE_NAMES[t % 100] + (f" gm{t % 10000 // 100}" if t % 10000 >= 100 else "") + (f" occ{t // 10000}" if t >= 10000 else ""), "ms_med": round(ms[len(ms) // 2], 4),
                    "ms_min": round(ms[0], 4), "tflops": round(tf, 1), "bit_identical": ok}
             res.append(row)
             print(json.dumps(row), flush=True)
