@@ -143,8 +143,8 @@ int nomad_diag_attention(nomad_ctx* ctx, const float* qkv_dev, float* out_dev, i
  * nomad_workspace_bytes. */
 int nomad_diag_keep_intermediates(nomad_ctx* ctx, int on);
 /* Byte offset and size of a named intermediate inside the nomad_embed workspace for (B, n_samples):
- * "conv0".."conv6" (time-major [B][L_i][512]), "featln" [B*T][512], "xpad" [B][T+128][768]
- * (post_extract_proj output at rows 64..64+T of each clip). */
+ * "conv0".."conv6" (time-major [B][L_i][512]), "featln" [B*T][512], "xpad" [16 groups][B][T+128][48]
+ * (post_extract_proj output, group-major, at frames 64..64+T of each clip; zero frames around). */
 int nomad_diag_workspace_region(const nomad_ctx* ctx, int B, int n_samples, const char* name,
                                 size_t* offset, size_t* bytes);
 

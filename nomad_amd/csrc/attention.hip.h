@@ -26,6 +26,67 @@ namespace nomad {
 
 constexpr int kAttnLD = 68;  // 64 + 4 floats: 272-B rows
 
+// One 64-key tile for one wave: NSUB = number of 16-key sub-tiles that hold at least one valid key,
+// `valid` = number of valid keys in the tile (keys >= valid are masked to -inf).
+template <int NSUB>
+__device__ __forceinline__ void attn_tile(const float* __restrict__ Ks, const float* __restrict__ Vs,
+                                          const float4 (&qf)[4], f32x4 (&o)[4], float& m_run, float& l_run, int qi,
+                                          int g, int valid) {
+    f32x4 s[NSUB];
+#pragma unroll
+    for (int i = 0; i < NSUB; ++i) s[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dd = 0; dd < 4; ++dd) {
+        float4 kf[NSUB];
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub)
+            kf[sub] = *reinterpret_cast<const float4*>(Ks + (sub * 16 + qi) * kAttnLD + dd * 16 + g * 4);
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) s[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[sub].x, qf[dd].x, s[sub], 0, 0, 0);
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) s[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[sub].y, qf[dd].y, s[sub], 0, 0, 0);
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) s[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[sub].z, qf[dd].z, s[sub], 0, 0, 0);
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) s[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[sub].w, qf[dd].w, s[sub], 0, 0, 0);
+    }
+    float m_tile = -INFINITY;
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (sub * 16 + g * 4 + r >= valid) s[sub][r] = -INFINITY;
+            m_tile = fmaxf(m_tile, s[sub][r]);
+        }
+    m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 16));
+    m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));
+    const float m_new = fmaxf(m_run, m_tile);  // finite: every tile holds at least one valid key
+    const float alpha = expf(m_run - m_new);   // first tile: exp(-inf) = 0
+    float psum = 0.f;
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float pv = expf(s[sub][r] - m_new);
+            s[sub][r] = pv;
+            psum += pv;
+        }
+    l_run = l_run * alpha + psum;  // per-lane partial (this lane's keys); folded across g at the end
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] *= alpha;
+    // O^T += V^T P^T : k-step (sub, r) contracts keys 16*sub + 4g + r
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float* vrow = Vs + (sub * 16 + g * 4 + r) * kAttnLD + qi;
+            const float pv = s[sub][r];
+#pragma unroll
+            for (int ds = 0; ds < 4; ++ds) o[ds] = __builtin_amdgcn_mfma_f32_16x16x4f32(vrow[ds * 16], pv, o[ds], 0, 0, 0);
+        }
+}
+
 __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                             int T) {
     __shared__ __attribute__((aligned(16))) float Ks[64 * kAttnLD];
@@ -48,6 +109,10 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
     for (int i = 0; i < 4; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
 
+    // Work is skipped at 16-row granularity in both dimensions (T = 199 is 12.4 sub-tiles of 16): a wave
+    // whose 16 query rows are all past T only helps with the K/V loads, and the last key tile multiplies only
+    // its NSUB sub-tiles that hold a valid key (straight-line code per NSUB, no branches among the MFMAs).
+    const bool wave_active = blockIdx.x * 64 + wave * 16 < T;  // wave-uniform
     const int ntiles = (T + 63) / 64;
     for (int kt = 0; kt < ntiles; ++kt) {
         __syncthreads();  // previous tile fully consumed
@@ -61,66 +126,13 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
             *reinterpret_cast<float4*>(Vs + row * kAttnLD + c4 * 4) = *reinterpret_cast<const float4*>(src + 1536);
         }
         __syncthreads();
-
-        // S^T tile: 4 sub-tiles of 16 keys
-        f32x4 s[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) s[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int dd = 0; dd < 4; ++dd) {
-            float4 kf[4];
-#pragma unroll
-            for (int sub = 0; sub < 4; ++sub)
-                kf[sub] = *reinterpret_cast<const float4*>(Ks + (sub * 16 + qi) * kAttnLD + dd * 16 + g * 4);
-#pragma unroll
-            for (int sub = 0; sub < 4; ++sub) s[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[sub].x, qf[dd].x, s[sub], 0, 0, 0);
-#pragma unroll
-            for (int sub = 0; sub < 4; ++sub) s[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[sub].y, qf[dd].y, s[sub], 0, 0, 0);
-#pragma unroll
-            for (int sub = 0; sub < 4; ++sub) s[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[sub].z, qf[dd].z, s[sub], 0, 0, 0);
-#pragma unroll
-            for (int sub = 0; sub < 4; ++sub) s[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[sub].w, qf[dd].w, s[sub], 0, 0, 0);
-        }
-
-        // mask keys beyond T (last tile only), online softmax
-        float m_tile = -INFINITY;
-#pragma unroll
-        for (int sub = 0; sub < 4; ++sub)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt * 64 + sub * 16 + g * 4 + r;
-                if (key >= T) s[sub][r] = -INFINITY;
-                m_tile = fmaxf(m_tile, s[sub][r]);
-            }
-        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 16));
-        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));
-        const float m_new = fmaxf(m_run, m_tile);  // finite: every tile holds at least one valid key
-        const float alpha = expf(m_run - m_new);   // first tile: exp(-inf) = 0
-        float psum = 0.f;
-#pragma unroll
-        for (int sub = 0; sub < 4; ++sub)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float pv = expf(s[sub][r] - m_new);
-                s[sub][r] = pv;
-                psum += pv;
-            }
-        l_run = l_run * alpha + psum;  // per-lane partial (this lane's keys); folded across g at the end
-        m_run = m_new;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] *= alpha;
-
-        // O^T += V^T P^T : k-step (sub, r) contracts keys 16*sub + 4g + r
-#pragma unroll
-        for (int sub = 0; sub < 4; ++sub)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float* vrow = Vs + (sub * 16 + g * 4 + r) * kAttnLD + qi;
-                const float pv = s[sub][r];
-#pragma unroll
-                for (int ds = 0; ds < 4; ++ds)
-                    o[ds] = __builtin_amdgcn_mfma_f32_16x16x4f32(vrow[ds * 16], pv, o[ds], 0, 0, 0);
-            }
+        if (!wave_active) continue;
+        const int valid = T - kt * 64;  // valid keys in this tile (>= 1)
+        if (valid >= 64) attn_tile<4>(Ks, Vs, qf, o, m_run, l_run, qi, g, 64);
+        else if (valid > 48) attn_tile<4>(Ks, Vs, qf, o, m_run, l_run, qi, g, valid);
+        else if (valid > 32) attn_tile<3>(Ks, Vs, qf, o, m_run, l_run, qi, g, valid);
+        else if (valid > 16) attn_tile<2>(Ks, Vs, qf, o, m_run, l_run, qi, g, valid);
+        else attn_tile<1>(Ks, Vs, qf, o, m_run, l_run, qi, g, valid);
     }
 
     float l_tot = l_run + __shfl_xor(l_run, 16);

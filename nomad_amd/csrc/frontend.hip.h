@@ -125,13 +125,19 @@ __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restr
     }
 }
 
-// Zero the 64 leading and 64 trailing pad frames of every clip in the pos-conv input buffer
-// xpad[B][T+128][768].  grid: (128, B), 192 threads (one float4 each).
-__global__ __launch_bounds__(192) void zero_pad_rows_kernel(float* __restrict__ xpad, int T) {
-    const int b = blockIdx.y;
-    const int r = blockIdx.x < 64 ? blockIdx.x : T + blockIdx.x;
-    float4* p = reinterpret_cast<float4*>(xpad + ((long long)b * (T + 128) + r) * 768);
-    p[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+// Pos-conv input buffer, GROUP-MAJOR: xg[16 groups][B clips][T+128 frames][48 channels], 64 zero frames on
+// each side of every clip (SamePad of the k=128 grouped conv).  With 192-B rows a group's K vector
+// (128 taps x 48 channels) for output frame t is 6144 CONTIGUOUS floats starting at frame t, so the
+// grouped conv is a plain GEMM with lda = 48 < K and every byte of every fetched line is used.
+// grid: 16*B blocks of 256 threads; zeroes the two 64-frame pads of one (group, clip).
+__global__ __launch_bounds__(256) void zero_pad_rows_kernel(float* __restrict__ xg, int T) {
+    float4* base = reinterpret_cast<float4*>(xg + (long long)blockIdx.x * (T + 128) * 48);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4* tail = base + (long long)(T + 64) * 12;
+    for (int i = threadIdx.x; i < 64 * 12; i += 256) {
+        base[i] = z;
+        tail[i] = z;
+    }
 }
 
 }  // namespace nomad

@@ -54,6 +54,10 @@ struct GemmParams {
     int bias_goff;
     int tiles_m, tiles_n;
     int group_m;          // >0: walk tiles down M in groups of group_m row-tiles (L2 reuse of W), 0: n fastest
+    // Optional column-block split of C: column n goes to block n / c_colblk (c_colblk_stride elements apart)
+    // at column n % c_colblk.  post_extract_proj uses it to write the pos-conv input group-major.
+    int c_colblk;
+    long long c_colblk_stride;
 };
 
 __device__ __forceinline__ float gelu_erf(float x) {
@@ -220,6 +224,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_kernel(const GemmParams 
         const int n = n0 + wn * Cfg::WTN + j * 32 + (lane & 31);
         const bool n_ok = n < p.n_valid;
         const float bv = (biasg && n_ok) ? biasg[n] : 0.f;
+        long long c_col = n;
+        if (p.c_colblk > 0) {
+            const int blk = n / p.c_colblk;
+            c_col = (long long)blk * p.c_colblk_stride + (n - blk * p.c_colblk);
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -229,7 +238,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_kernel(const GemmParams 
                     float v = acc[i][j][r] + bv;
                     if (p.gelu) v = gelu_erf(v);
                     if (Rg) v += Rg[(r_plain ? p.rmap.off + (long long)m * p.rmap.ld : row_addr(p.rmap, m)) + n];
-                    Cg[(c_plain ? p.cmap.off + (long long)m * p.cmap.ld : row_addr(p.cmap, m)) + n] = v;
+                    Cg[(c_plain ? p.cmap.off + (long long)m * p.cmap.ld : row_addr(p.cmap, m)) + c_col] = v;
                 }
             }
         }
@@ -360,6 +369,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_glds_kernel(const GemmPa
         const int n = n0 + wn * Cfg::WTN + j * 32 + (lane & 31);
         const bool n_ok = n < p.n_valid;
         const float bv = (biasg && n_ok) ? biasg[n] : 0.f;
+        long long c_col = n;
+        if (p.c_colblk > 0) {
+            const int blk = n / p.c_colblk;
+            c_col = (long long)blk * p.c_colblk_stride + (n - blk * p.c_colblk);
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -369,7 +383,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_glds_kernel(const GemmPa
                     float v = acc[i][j][r] + bv;
                     if (p.gelu) v = gelu_erf(v);
                     if (Rg) v += Rg[(r_plain ? p.rmap.off + (long long)m * p.rmap.ld : row_addr(p.rmap, m)) + n];
-                    Cg[(c_plain ? p.cmap.off + (long long)m * p.cmap.ld : row_addr(p.cmap, m)) + n] = v;
+                    Cg[(c_plain ? p.cmap.off + (long long)m * p.cmap.ld : row_addr(p.cmap, m)) + c_col] = v;
                 }
             }
         }

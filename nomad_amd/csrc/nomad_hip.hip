@@ -178,6 +178,7 @@ int occ_pad(int occ, int lds) {
 }
 
 int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, int occ = 0) {
+    if (tile == 29 && occ == 0) occ = 4;  // measured: 4 workgroups/CU is the best residency for the 128x64x32 kernel
     const double flops = 2.0 * p.M * (double)p.n_valid * p.K * groups;
     Scope sc(c, s, NOMAD_K_GEMM, flops);
     hipError_t e;
@@ -249,10 +250,9 @@ GemmParams dense(const float* A, int lda, const float* W, const float* bias, con
 //        2-3 rounds deep and the last partial round would idle a third of the CUs
 //    2 = register-staged 64x64x32 for tiny batches
 int pick_tile(int M, int N, int K) {
-    (void)K;
     if (M < 1024) return 2;
     const long long tiles256 = (long long)((M + 255) / 256) * (N / 128);
-    if (N % 128 == 0 && tiles256 >= 2048) return 21;
+    if (N % 128 == 0 && (tiles256 >= 2048 || K >= 2048 || K <= 512)) return 21;
     return 29;
 }
 
@@ -417,7 +417,7 @@ int nomad_diag_workspace_region(const nomad_ctx* c, int B, int n_samples, const 
     } else if (strcmp(name, "encin") == 0) {
         *offset = l.x;
         *bytes = sizeof(float) * 768 * (size_t)s.M;
-    } else if (strcmp(name, "xpad") == 0) {
+    } else if (strcmp(name, "xpad") == 0) {  // group-major [16][B][T+128][48]
         *offset = l.xpad;
         *bytes = sizeof(float) * 768 * (size_t)B * (s.T + 128);
     } else {
@@ -477,26 +477,29 @@ int nomad_embed(nomad_ctx* c, const float* wav, int B, int n_samples, const floa
 
     // ---- LayerNorm(512) + post_extract_proj into the padded pos-conv buffer ------------------
     if ((rc = run_layernorm(c, F(lay.conv[6]), c->fln_w, c->fln_b, F(lay.featln), nullptr, M, 512, s))) return rc;
+    // group-major pos-conv buffer xg[16][B][T+128][48]; x (post_extract_proj output) sits at frames 64..64+T
     float* xpad = F(lay.xpad);
-    const RowMap pad_map{64LL * 768, (long long)(T + 128) * 768, T, 768};
+    const long long grp_stride = (long long)B * (T + 128) * 48;
+    const RowMap pad_map{64LL * 48, (long long)(T + 128) * 48, T, 48};
     {
         Scope sc(c, s, NOMAD_K_ROW, 0.0);
-        hipLaunchKernelGGL(zero_pad_rows_kernel, dim3(128, B), dim3(192), 0, s, xpad, T);
+        hipLaunchKernelGGL(zero_pad_rows_kernel, dim3(16 * B), dim3(256), 0, s, xpad, T);
     }
     {
         GemmParams p = dense(F(lay.featln), 512, c->proj_w, c->proj_b, nullptr, xpad, M, 768, 512, 0);
         p.cmap = pad_map;
+        p.c_colblk = 48;
+        p.c_colblk_stride = grp_stride;
         if ((rc = run_gemm(c, p, 1, pick_tile(M, 768, 512), s))) return rc;
     }
     // ---- pos-conv: 16 groups x (M x 48 x 6144), x + gelu(conv + bias) -------------------------
     {
         GemmParams p{};
         p.A = xpad;
-        p.amap = RowMap{0, (long long)(T + 128) * 768, T, 768};
-        p.a_goff = 48;
-        p.kchunk = 48;
-        p.kstride = 768;
+        p.amap = RowMap{0, (long long)(T + 128) * 48, T, 48};  // row (clip, t) starts at frame t: taps are contiguous
+        p.a_goff = grp_stride;
         p.K = 6144;
+        p.kchunk = 6144;
         p.W = c->pos_w;
         p.ldw = 6144;
         p.w_goff = 64LL * 6144;
@@ -507,12 +510,12 @@ int nomad_embed(nomad_ctx* c, const float* wav, int B, int n_samples, const floa
         p.c_goff = 48;
         p.R = xpad;
         p.rmap = pad_map;
-        p.r_goff = 48;
+        p.r_goff = grp_stride;
         p.M = M;
         p.N = 64;
         p.n_valid = 48;
         p.gelu = 1;
-        if ((rc = run_gemm(c, p, 16, M >= 1024 ? 28 : 1, s))) return rc;
+        if ((rc = run_gemm(c, p, 16, M >= 1024 ? 29 : 2, s))) return rc;
     }
     float* x = F(lay.x);
     float* x2 = F(lay.x2);

@@ -55,9 +55,10 @@ def test_every_stage_vs_oracle(engine, sd0):
             got = engine.diag_region(B, N, f"conv{i}").cpu().view(B, -1, 512)
             err = (got - taps[f"conv{i}"]).abs().max().item()
             assert err < 2e-5, (f"conv{i}", err)
-        xpad = engine.diag_region(B, N, "xpad").cpu().view(B, T + 128, 768)
-        assert xpad[:, :64].abs().max().item() == 0.0 and xpad[:, 64 + T:].abs().max().item() == 0.0
-        assert (xpad[:, 64:64 + T] - taps["proj"]).abs().max().item() < 2e-5
+        xg = engine.diag_region(B, N, "xpad").cpu().view(16, B, T + 128, 48)   # group-major pos-conv input
+        assert xg[:, :, :64].abs().max().item() == 0.0 and xg[:, :, 64 + T:].abs().max().item() == 0.0
+        proj = xg[:, :, 64:64 + T].permute(1, 2, 0, 3).reshape(B, T, 768)
+        assert (proj - taps["proj"]).abs().max().item() < 2e-5
     finally:
         engine.diag_keep_intermediates(False)
 
