@@ -115,6 +115,34 @@ int nomad_l1_loss(nomad_ctx* ctx, const float* a_layers_dev, const float* b_laye
                   const float* a_emb_dev, const float* b_emb_dev, int B, int T,
                   float* loss_dev, void* scratch_dev, nomad_stream_t stream);
 
+/* ---- training: Nomad.forward() as a differentiable loss (nomad.py:142-146 + autograd) ------ */
+/*
+ * The reference back-propagates through the whole backbone to `estimate` (and, wastefully, into the
+ * backbone parameters, which nobody uses: the freeze is commented out at nomad.py:74-76).  Here the
+ * weights are frozen and only d loss / d waveform is computed.
+ *
+ *   nomad_enable_backward    builds the transposed weight copies once (allocates; call before training)
+ *   nomad_embed_train        = nomad_embed with layers_dev mandatory; additionally fills `saved_dev`
+ *                              (nomad_saved_bytes) with what the backward needs
+ *   nomad_l1_loss_backward   d NomadLoss / d a_layers, d a_emb  (sign(a-b)/numel, times *upstream_dev)
+ *   nomad_embed_backward     given d loss / d layers [12][B][T][768] (nullable) and d loss / d emb [B][256]
+ *                            writes d loss / d wav [B][n_samples]; scratch: nomad_backward_workspace_bytes
+ */
+int nomad_enable_backward(nomad_ctx* ctx);
+int nomad_saved_bytes(const nomad_ctx* ctx, int B, int n_samples, size_t* bytes);
+int nomad_backward_workspace_bytes(const nomad_ctx* ctx, int B, int n_samples, size_t* bytes);
+int nomad_embed_train(nomad_ctx* ctx, const float* wav_dev, int B, int n_samples,
+                      const float* head_w_dev, const float* head_b_dev, float* emb_dev, float* layers_dev,
+                      void* saved_dev, size_t saved_bytes, void* workspace_dev, size_t workspace_bytes,
+                      nomad_stream_t stream);
+int nomad_l1_loss_backward(nomad_ctx* ctx, const float* a_layers_dev, const float* b_layers_dev,
+                           const float* a_emb_dev, const float* b_emb_dev, int B, int T,
+                           const float* upstream_dev, float* dlayers_dev, float* demb_dev, nomad_stream_t stream);
+int nomad_embed_backward(nomad_ctx* ctx, const float* wav_dev, int B, int n_samples,
+                         const float* head_w_dev, const float* head_b_dev, const float* layers_dev,
+                         const void* saved_dev, size_t saved_bytes, const float* dlayers_dev, const float* demb_dev,
+                         float* dwav_dev, void* workspace_dev, size_t workspace_bytes, nomad_stream_t stream);
+
 /* ---- measurement ------------------------------------------------------------------------- */
 /* Kernel classes for the in-library HIP-event timers. */
 enum { NOMAD_K_GEMM = 0, NOMAD_K_ATTN = 1, NOMAD_K_FRONT = 2, NOMAD_K_ROW = 3, NOMAD_K_PAIR = 4, NOMAD_K_COUNT = 5 };
@@ -138,6 +166,12 @@ int nomad_diag_layernorm(nomad_ctx* ctx, const float* in_dev, const float* gamma
                          float* out_dev, int M, int N, nomad_stream_t stream);
 /* ctx_out[B*T][768] = softmax(q k^T) v per head, from qkv[B*T][2304] (q pre-scaled). */
 int nomad_diag_attention(nomad_ctx* ctx, const float* qkv_dev, float* out_dev, int B, int T, nomad_stream_t stream);
+/* dx[M][N] = LayerNorm backward of g w.r.t. the LN input x (weights frozen). */
+int nomad_diag_layernorm_bwd(nomad_ctx* ctx, const float* x_dev, const float* g_dev, const float* gamma_dev,
+                             float* dx_dev, int M, int N, nomad_stream_t stream);
+/* Runs the attention forward (ctx_out [B*T][768], lse [B*12][T]) then its backward: dqkv [B*T][2304]. */
+int nomad_diag_attention_bwd(nomad_ctx* ctx, const float* qkv_dev, const float* dctx_dev, float* ctx_out_dev,
+                             float* lse_dev, float* dqkv_dev, int B, int T, nomad_stream_t stream);
 /* With on!=0 every conv layer output gets its own workspace region (no ping-pong aliasing), so
  * nomad_diag_workspace_region can read all of them back after nomad_embed.  Changes
  * nomad_workspace_bytes. */

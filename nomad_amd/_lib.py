@@ -36,12 +36,22 @@ SIGNATURES = {
     "nomad_pairwise": (C.c_int, [C.c_void_p, _fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp]),
     "nomad_l1_scratch_bytes": (C.c_size_t, []),
     "nomad_l1_loss": (C.c_int, [C.c_void_p, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp]),
+    "nomad_enable_backward": (C.c_int, [C.c_void_p]),
+    "nomad_saved_bytes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
+    "nomad_backward_workspace_bytes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
+    "nomad_embed_train": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_size_t, _fp,
+                                    C.c_size_t, _fp]),
+    "nomad_l1_loss_backward": (C.c_int, [C.c_void_p, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp]),
+    "nomad_embed_backward": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, C.c_size_t, _fp, _fp,
+                                       _fp, _fp, C.c_size_t, _fp]),
     "nomad_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "nomad_profile_reset": (C.c_int, [C.c_void_p]),
     "nomad_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
     "nomad_diag_gemm": (C.c_int, [C.c_void_p, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "nomad_diag_layernorm": (C.c_int, [C.c_void_p, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp]),
     "nomad_diag_attention": (C.c_int, [C.c_void_p, _fp, _fp, C.c_int, C.c_int, _fp]),
+    "nomad_diag_layernorm_bwd": (C.c_int, [C.c_void_p, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp]),
+    "nomad_diag_attention_bwd": (C.c_int, [C.c_void_p, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp]),
     "nomad_diag_keep_intermediates": (C.c_int, [C.c_void_p, C.c_int]),
     "nomad_diag_workspace_region": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p,
                                               C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),

@@ -87,8 +87,9 @@ __device__ __forceinline__ void attn_tile(const float* __restrict__ Ks, const fl
         }
 }
 
+// lse (nullable): [B*12][T] log-sum-exp of every score row, saved for the backward pass.
 __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                            int T) {
+                                                            float* __restrict__ lse, int T) {
     __shared__ __attribute__((aligned(16))) float Ks[64 * kAttnLD];
     __shared__ __attribute__((aligned(16))) float Vs[64 * kAttnLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -138,6 +139,7 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
     float l_tot = l_run + __shfl_xor(l_run, 16);
     l_tot += __shfl_xor(l_tot, 32);
     const float inv = 1.0f / l_tot;
+    if (lse && q_row < T && g == 0) lse[(long long)bh * T + q_row] = m_run + logf(l_tot);
     if (q_row < T) {
         float* dst = out + ((long long)b * T + q_row) * 768 + h * 64 + g * 4;
 #pragma unroll

@@ -1,0 +1,479 @@
+// Backward (d loss / d waveform) kernels for Nomad.forward() used as a training loss
+// (/root/reference/src/nomad_audio/nomad.py:142-146 + autograd).
+// Weights are frozen (the user's purpose is the gradient w.r.t. `estimate`), so only dX is propagated:
+// every dense contraction of the backward is the SAME fp32 MFMA GEMM kernel as the forward, fed with
+// transposed weight copies; this file holds what is not a GEMM:
+//   LayerNorm backward, GELU' multiplies (fused into GEMM epilogues or as row kernels), attention backward
+//   (recompute P from the saved log-sum-exp, flash style, deterministic: no atomics), head / L1-loss
+//   backward, GroupNorm + conv0 backward, and the one-time weight transposes.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "gemm_f32.hip.h"
+#include "rowops.hip.h"
+
+namespace nomad {
+
+// d/du gelu_erf(u) = Phi(u) + u * phi(u)
+__device__ __forceinline__ float dgelu_erf(float u) {
+    const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * u * u);
+    return cdf + u * pdf;
+}
+
+// ---- one-time weight transposes (nomad_enable_backward) ---------------------------------------------
+// out[c * ld_out + r] = in[r * ld_in + c], r < R, c < C.  grid: (ceil(C/32), ceil(R/32)), block (32, 8).
+__global__ void transpose_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ out, int ld_out, int R,
+                                 int C) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + threadIdx.x;
+        tile[i][threadIdx.x] = (r < R && c < C) ? in[(long long)r * ld_in + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + threadIdx.x;
+        if (r < R && c < C) out[(long long)c * ld_out + r] = tile[threadIdx.x][i];
+    }
+}
+
+// Pos-conv backward weights: wb[g][ci (64 rows, 48 valid)][tp*48 + n] = w[g][n][(127 - tp)*48 + ci]
+// (w = forward repack [16][64][6144]).  grid: 16*64 blocks of 256 threads.
+__global__ void posconv_bwd_weight_kernel(const float* __restrict__ w, float* __restrict__ wb) {
+    const int g = blockIdx.x >> 6, ci = blockIdx.x & 63;
+    float* dst = wb + ((long long)g * 64 + ci) * 6144;
+    for (int k = threadIdx.x; k < 6144; k += 256) {
+        const int tp = k / 48, n = k - tp * 48;
+        dst[k] = ci < 48 ? w[((long long)g * 64 + n) * 6144 + (127 - tp) * 48 + ci] : 0.f;
+    }
+}
+
+// ---- LayerNorm backward -----------------------------------------------------------------------------
+// x = LN input, g (+ g2) = d loss / d LN output; dx = rstd * (gg - mean(gg) - xhat * mean(gg * xhat)),
+// gg = (g + g2) * gamma.  One wave per row; N = 256 * VPT.
+template <int VPT>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                            const float* __restrict__ g2,
+                                                            const float* __restrict__ gamma, float* __restrict__ dx,
+                                                            int M) {
+    constexpr int N = 256 * VPT;
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const float4* xr = reinterpret_cast<const float4*>(x + (long long)m * N);
+    const float4* gr = reinterpret_cast<const float4*>(g + (long long)m * N);
+    const float4* g2r = g2 ? reinterpret_cast<const float4*>(g2 + (long long)m * N) : nullptr;
+    const float4* gm4 = reinterpret_cast<const float4*>(gamma);
+    float xv[VPT][4], gv[VPT][4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const float4 a = xr[lane + 64 * i];
+        float4 b = gr[lane + 64 * i];
+        if (g2r) {
+            const float4 c = g2r[lane + 64 * i];
+            b.x += c.x; b.y += c.y; b.z += c.z; b.w += c.w;
+        }
+        const float4 gm = gm4[lane + 64 * i];
+        xv[i][0] = a.x; xv[i][1] = a.y; xv[i][2] = a.z; xv[i][3] = a.w;
+        gv[i][0] = b.x * gm.x; gv[i][1] = b.y * gm.y; gv[i][2] = b.z * gm.z; gv[i][3] = b.w * gm.w;
+        s += (a.x + a.y) + (a.z + a.w);
+    }
+    const float mean = wave_sum(s) * (1.0f / N);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            xv[i][j] -= mean;
+            q += xv[i][j] * xv[i][j];
+        }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / N) + 1e-5f);
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            xv[i][j] *= rstd;  // xhat
+            sg += gv[i][j];
+            sgx += gv[i][j] * xv[i][j];
+        }
+    const float mg = wave_sum(sg) * (1.0f / N), mgx = wave_sum(sgx) * (1.0f / N);
+    float4* o = reinterpret_cast<float4*>(dx + (long long)m * N);
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        float4 r;
+        r.x = rstd * (gv[i][0] - mg - xv[i][0] * mgx);
+        r.y = rstd * (gv[i][1] - mg - xv[i][1] * mgx);
+        r.z = rstd * (gv[i][2] - mg - xv[i][2] * mgx);
+        r.w = rstd * (gv[i][3] - mg - xv[i][3] * mgx);
+        o[lane + 64 * i] = r;
+    }
+}
+
+// out[map(m)][c] = g[m][c] * gelu'(u[m][c]) for rows of 512 floats: conv6 gradient into the padded dU layout.
+__global__ __launch_bounds__(128) void dgelu_rows512_kernel(const float* __restrict__ g, const float* __restrict__ u,
+                                                            float* __restrict__ out, RowMap omap, int M) {
+    const int m = blockIdx.x;
+    if (m >= M) return;
+    const float4 a = reinterpret_cast<const float4*>(g + (long long)m * 512)[threadIdx.x];
+    const float4 b = reinterpret_cast<const float4*>(u + (long long)m * 512)[threadIdx.x];
+    float4 r;
+    r.x = a.x * dgelu_erf(b.x); r.y = a.y * dgelu_erf(b.y); r.z = a.z * dgelu_erf(b.z); r.w = a.w * dgelu_erf(b.w);
+    reinterpret_cast<float4*>(out + row_addr(omap, m))[threadIdx.x] = r;
+}
+
+// Pos-conv: dug[grp][clip][64 + t][48] = dy0[m][grp*48 + c] * gelu'(upc[m][grp*48 + c])   (group-major, padded)
+// grid: M blocks of 192 threads (one float4 each).
+__global__ __launch_bounds__(192) void dgelu_to_groups_kernel(const float* __restrict__ g, const float* __restrict__ u,
+                                                              float* __restrict__ dug, int T, long long grp_stride) {
+    const int m = blockIdx.x, b = m / T, t = m - b * T;
+    const float4 a = reinterpret_cast<const float4*>(g + (long long)m * 768)[threadIdx.x];
+    const float4 c = reinterpret_cast<const float4*>(u + (long long)m * 768)[threadIdx.x];
+    float4 r;
+    r.x = a.x * dgelu_erf(c.x); r.y = a.y * dgelu_erf(c.y); r.z = a.z * dgelu_erf(c.z); r.w = a.w * dgelu_erf(c.w);
+    const int col = threadIdx.x * 4, grp = col / 48, cc = col - grp * 48;
+    float* dst = dug + grp * grp_stride + ((long long)b * (T + 128) + 64 + t) * 48 + cc;
+    *reinterpret_cast<float4*>(dst) = r;
+}
+
+// ---- head backward ----------------------------------------------------------------------------------
+// e = normalize(W relu(mean_t x) + b).  Given de -> gx[b][t][:] = relu'(mean) * (W^T dz) / T for every t.
+// grid: B blocks of 256 threads.
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ x, int T, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, const float* __restrict__ de,
+                                                       float* __restrict__ gx) {
+    __shared__ float pooled[768], mask[768], z[256], dz[256], red[4], red2[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* xb = x + (long long)b * T * 768;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int t = 0; t < T; ++t) {
+        const float* r = xb + (long long)t * 768;
+        s0 += r[tid]; s1 += r[tid + 256]; s2 += r[tid + 512];
+    }
+    const float inv = 1.0f / (float)T;
+    const float m0 = s0 * inv, m1 = s1 * inv, m2 = s2 * inv;
+    pooled[tid] = fmaxf(m0, 0.f); pooled[tid + 256] = fmaxf(m1, 0.f); pooled[tid + 512] = fmaxf(m2, 0.f);
+    mask[tid] = m0 > 0.f ? inv : 0.f; mask[tid + 256] = m1 > 0.f ? inv : 0.f; mask[tid + 512] = m2 > 0.f ? inv : 0.f;
+    __syncthreads();
+    float p[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) p[i] = pooled[lane + 64 * i];
+    for (int o = wave * 64; o < wave * 64 + 64; ++o) {
+        const float* wr = w + (long long)o * 768;
+        float d = 0.f;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) d = fmaf(wr[lane + 64 * i], p[i], d);
+        d = wave_sum(d);
+        if (lane == 0) z[o] = d + bias[o];
+    }
+    __syncthreads();
+    const float zv = z[tid], dev = de[(long long)b * 256 + tid];
+    const float ss = wave_sum(zv * zv);
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    const float nrm = fmaxf(sqrtf((red[0] + red[1]) + (red[2] + red[3])), 1e-12f);
+    const float ev = zv / nrm;
+    const float dot = wave_sum(ev * dev);
+    if (lane == 0) red2[wave] = dot;
+    __syncthreads();
+    const float edot = (red2[0] + red2[1]) + (red2[2] + red2[3]);
+    dz[tid] = (dev - ev * edot) / nrm;
+    __syncthreads();
+    // dp[c] = sum_o W[o][c] dz[o]; thread handles c = tid, tid+256, tid+512 (coalesced over c)
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+    for (int o = 0; o < 256; ++o) {
+        const float* wr = w + (long long)o * 768;
+        const float dzo = dz[o];
+        d0 = fmaf(wr[tid], dzo, d0); d1 = fmaf(wr[tid + 256], dzo, d1); d2 = fmaf(wr[tid + 512], dzo, d2);
+    }
+    d0 *= mask[tid]; d1 *= mask[tid + 256]; d2 *= mask[tid + 512];
+    float* gb = gx + (long long)b * T * 768;
+    for (int t = 0; t < T; ++t) {
+        float* r = gb + (long long)t * 768;
+        r[tid] = d0; r[tid + 256] = d1; r[tid + 512] = d2;
+    }
+}
+
+// ---- L1 loss backward: d/da sum_i mean|a_i - b_i| = sign(a - b) / numel_i, times the upstream scalar ------
+__global__ __launch_bounds__(256) void l1_bwd_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
+                                                     long long n4, float inv_numel, const float* __restrict__ upstream,
+                                                     float4* __restrict__ out) {
+    const float sc = inv_numel * upstream[0];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 x = a[i], y = b[i];
+        float4 r;
+        r.x = x.x > y.x ? sc : (x.x < y.x ? -sc : 0.f);
+        r.y = x.y > y.y ? sc : (x.y < y.y ? -sc : 0.f);
+        r.z = x.z > y.z ? sc : (x.z < y.z ? -sc : 0.f);
+        r.w = x.w > y.w ? sc : (x.w < y.w ? -sc : 0.f);
+        out[i] = r;
+    }
+}
+
+// ---- attention backward -----------------------------------------------------------------------------
+// Per (clip, head): S = q k^T (q pre-scaled), P = exp(S - lse), dP = dO v^T, D = rowsum(dO * O),
+// dS = P * (dP - D); dV = P^T dO, dK = dS^T q, dQ = dS k.  Tiles of 32 x 32 through LDS, fp32 VALU
+// (the backward's FLOPs are in the GEMMs; T x T work is 0.3 % at T = 50).  Two kernels, no atomics:
+//   attn_bwd_dkv_kernel: one workgroup per 32-key tile, loops over query tiles  -> dk, dv
+//   attn_bwd_dq_kernel : one workgroup per 32-query tile, loops over key tiles  -> dq
+// qkv/dqkv: [B*T][2304] = [q | k | v]; o, dO: [B*T][768]; lse: [B*12][T].
+constexpr int kAB = 32;        // tile edge
+constexpr int kABLD = 65;      // 64 + 1 floats per LDS row
+
+__device__ __forceinline__ void ab_load_tile(float* dst, const float* src, long long row_stride, int row0, int T,
+                                             int tid) {
+    // 32 rows x 64 floats; rows past T are zero-filled
+    for (int i = tid; i < kAB * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        dst[r * kABLD + c] = (row0 + r < T) ? src[(long long)(row0 + r) * row_stride + c] : 0.f;
+    }
+}
+
+// Computes P and dS for the (q tile, k tile) pair held in LDS; thread -> 4 entries (qi = tid>>3, kj = (tid&7)*4..+3)
+__device__ __forceinline__ void ab_scores(const float* Qs, const float* Ks, const float* Vs, const float* dOs,
+                                          const float* lse_s, const float* D_s, float* Ps, float* dSs, int q0, int k0,
+                                          int T, int tid) {
+    const int qi = tid >> 3, kj0 = (tid & 7) * 4;
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, dp[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int d = 0; d < 64; ++d) {
+        const float qv = Qs[qi * kABLD + d], dov = dOs[qi * kABLD + d];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s[j] = fmaf(qv, Ks[(kj0 + j) * kABLD + d], s[j]);
+            dp[j] = fmaf(dov, Vs[(kj0 + j) * kABLD + d], dp[j]);
+        }
+    }
+    const bool q_ok = q0 + qi < T;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool ok = q_ok && (k0 + kj0 + j < T);
+        const float pv = ok ? expf(s[j] - lse_s[qi]) : 0.f;
+        Ps[qi * 33 + kj0 + j] = pv;
+        dSs[qi * 33 + kj0 + j] = pv * (dp[j] - D_s[qi]);
+    }
+}
+
+__device__ __forceinline__ void ab_row_stats(const float* dOs, const float* Os, const float* lse, float* lse_s,
+                                             float* D_s, int q0, int T, int tid) {
+    // D[q] = sum_d dO[q][d] * O[q][d]; 8 threads per row
+    const int qi = tid >> 3, part = tid & 7;
+    float acc = 0.f;
+    for (int d = part * 8; d < part * 8 + 8; ++d) acc = fmaf(dOs[qi * kABLD + d], Os[qi * kABLD + d], acc);
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    acc += __shfl_xor(acc, 4);
+    if (part == 0) {
+        D_s[qi] = acc;
+        lse_s[qi] = (q0 + qi < T) ? lse[q0 + qi] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
+                                                           const float* __restrict__ dO, const float* __restrict__ lse,
+                                                           float* __restrict__ dqkv, int T) {
+    __shared__ float Qs[kAB * kABLD], Ks[kAB * kABLD], Vs[kAB * kABLD], dOs[kAB * kABLD], Os[kAB * kABLD];
+    __shared__ float Ps[kAB * 33], dSs[kAB * 33], lse_s[kAB], D_s[kAB];
+    const int tid = threadIdx.x, bh = blockIdx.y, b = bh / 12, h = bh - b * 12;
+    const int k0 = blockIdx.x * kAB;
+    const float* qb = qkv + (long long)b * T * 2304 + h * 64;
+    const float* ob = o + (long long)b * T * 768 + h * 64;
+    const float* dob = dO + (long long)b * T * 768 + h * 64;
+    const float* lb = lse + (long long)bh * T;
+    ab_load_tile(Ks, qb + 768, 2304, k0, T, tid);
+    ab_load_tile(Vs, qb + 1536, 2304, k0, T, tid);
+    // outputs: thread -> key kj = tid >> 3, d = (tid & 7) * 8 .. +7
+    const int kj = tid >> 3, d0 = (tid & 7) * 8;
+    float dk[8], dv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dk[i] = dv[i] = 0.f;
+    for (int q0 = 0; q0 < T; q0 += kAB) {
+        __syncthreads();
+        ab_load_tile(Qs, qb, 2304, q0, T, tid);
+        ab_load_tile(dOs, dob, 768, q0, T, tid);
+        ab_load_tile(Os, ob, 768, q0, T, tid);
+        __syncthreads();
+        ab_row_stats(dOs, Os, lb, lse_s, D_s, q0, T, tid);
+        __syncthreads();
+        ab_scores(Qs, Ks, Vs, dOs, lse_s, D_s, Ps, dSs, q0, k0, T, tid);
+        __syncthreads();
+        for (int qi = 0; qi < kAB; ++qi) {
+            const float pv = Ps[qi * 33 + kj], ds = dSs[qi * 33 + kj];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                dv[i] = fmaf(pv, dOs[qi * kABLD + d0 + i], dv[i]);
+                dk[i] = fmaf(ds, Qs[qi * kABLD + d0 + i], dk[i]);
+            }
+        }
+    }
+    if (k0 + kj < T) {
+        float* dst = dqkv + ((long long)b * T + k0 + kj) * 2304 + h * 64 + d0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            dst[768 + i] = dk[i];
+            dst[1536 + i] = dv[i];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
+                                                          const float* __restrict__ dO, const float* __restrict__ lse,
+                                                          float* __restrict__ dqkv, int T) {
+    __shared__ float Qs[kAB * kABLD], Ks[kAB * kABLD], Vs[kAB * kABLD], dOs[kAB * kABLD], Os[kAB * kABLD];
+    __shared__ float Ps[kAB * 33], dSs[kAB * 33], lse_s[kAB], D_s[kAB];
+    const int tid = threadIdx.x, bh = blockIdx.y, b = bh / 12, h = bh - b * 12;
+    const int q0 = blockIdx.x * kAB;
+    const float* qb = qkv + (long long)b * T * 2304 + h * 64;
+    const float* ob = o + (long long)b * T * 768 + h * 64;
+    const float* dob = dO + (long long)b * T * 768 + h * 64;
+    const float* lb = lse + (long long)bh * T;
+    ab_load_tile(Qs, qb, 2304, q0, T, tid);
+    ab_load_tile(dOs, dob, 768, q0, T, tid);
+    ab_load_tile(Os, ob, 768, q0, T, tid);
+    __syncthreads();
+    ab_row_stats(dOs, Os, lb, lse_s, D_s, q0, T, tid);
+    const int qi = tid >> 3, d0 = (tid & 7) * 8;
+    float dq[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dq[i] = 0.f;
+    for (int k0 = 0; k0 < T; k0 += kAB) {
+        __syncthreads();
+        ab_load_tile(Ks, qb + 768, 2304, k0, T, tid);
+        ab_load_tile(Vs, qb + 1536, 2304, k0, T, tid);
+        __syncthreads();
+        ab_scores(Qs, Ks, Vs, dOs, lse_s, D_s, Ps, dSs, q0, k0, T, tid);
+        __syncthreads();
+        for (int kj = 0; kj < kAB; ++kj) {
+            const float ds = dSs[qi * 33 + kj];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dq[i] = fmaf(ds, Ks[kj * kABLD + d0 + i], dq[i]);
+        }
+    }
+    if (q0 + qi < T) {
+        float* dst = dqkv + ((long long)b * T + q0 + qi) * 2304 + h * 64 + d0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dst[i] = dq[i];
+    }
+}
+
+// ---- conv0 + GroupNorm backward ---------------------------------------------------------------------
+// Forward: y[t,c] = sum_j w[c,j] x[5t+j];  z = (y - mean_c) * rstd_c * gamma_c + beta_c;  out = gelu(z).
+// Given G = d loss / d out (time-major [B][L0][512]):
+//   dz = G * gelu'(z);  s1[c] = sum_t dz,  s2[c] = sum_t dz * yhat,  yhat = (y - mean) * rstd
+//   dy = gamma * rstd * (dz - s1/L0 - yhat * s2/L0);  dx[5t+j] += sum_c dy[t,c] w[c,j]
+// Pass 1 (gn_bwd_stats_kernel): per-(clip, frame chunk) partial s1, s2 -> fixed-order fold in pass 2's prologue.
+// Pass 2 (conv0_bwd_kernel): dy, then the 512-channel contraction per frame by wave reductions.
+constexpr int kGnChunk = 256;  // frames per block in both passes
+
+__device__ __forceinline__ void conv0_frame(const float* xs, int t, const float (&w)[2][10], const float (&sc)[2],
+                                            const float (&sh)[2], const float (&mean)[2], const float (&rstd)[2],
+                                            float (&z)[2], float (&yhat)[2]) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        float y = 0.f;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) y = fmaf(w[q][j], xs[5 * t + j], y);
+        z[q] = fmaf(y, sc[q], sh[q]);
+        yhat[q] = (y - mean[q]) * rstd[q];
+    }
+}
+
+// grid: (chunks, B), 256 threads: thread owns channels c = tid and tid + 256.  partial[b][chunk][2][512]
+__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restrict__ wav, int n_samples, int L0,
+                                                           const float* __restrict__ w0, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, const float* __restrict__ gmean,
+                                                           const float* __restrict__ grstd, const float* __restrict__ G,
+                                                           float* __restrict__ partial) {
+    __shared__ float xs[kGnChunk * 5 + 8];
+    const int b = blockIdx.y, t0 = blockIdx.x * kGnChunk, nfr = min(kGnChunk, L0 - t0), tid = threadIdx.x;
+    const float* x = wav + (long long)b * n_samples + 5 * t0;
+    for (int i = tid; i < 5 * nfr + 5; i += 256) xs[i] = x[i];
+    float w[2][10], sc[2], sh[2], mean[2], rstd[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int c = tid + 256 * q;
+        sc[q] = scale[b * 512 + c]; sh[q] = shift[b * 512 + c];
+        mean[q] = gmean[b * 512 + c]; rstd[q] = grstd[b * 512 + c];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) w[q][j] = w0[c * 10 + j];
+    }
+    __syncthreads();
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    const float* g = G + ((long long)b * L0 + t0) * 512;
+    for (int t = 0; t < nfr; ++t) {
+        float z[2], yh[2];
+        conv0_frame(xs, t, w, sc, sh, mean, rstd, z, yh);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float dz = g[(long long)t * 512 + tid + 256 * q] * dgelu_erf(z[q]);
+            s1[q] += dz;
+            s2[q] = fmaf(dz, yh[q], s2[q]);
+        }
+    }
+    float* p = partial + ((long long)b * gridDim.x + blockIdx.x) * 1024;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        p[tid + 256 * q] = s1[q];
+        p[512 + tid + 256 * q] = s2[q];
+    }
+}
+
+// grid: (chunks, B), 256 threads.  dwav must be zero-initialised; each sample receives at most two
+// contributions (frames t and t+1), so the float atomics are order-independent (a + b == b + a).
+__global__ __launch_bounds__(256) void conv0_bwd_kernel(const float* __restrict__ wav, int n_samples, int L0,
+                                                        const float* __restrict__ w0, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, const float* __restrict__ gmean,
+                                                        const float* __restrict__ grstd, const float* __restrict__ G,
+                                                        const float* __restrict__ partial, int nchunks,
+                                                        float* __restrict__ dwav) {
+    __shared__ float xs[kGnChunk * 5 + 8];
+    __shared__ float red[4][10];
+    const int b = blockIdx.y, t0 = blockIdx.x * kGnChunk, nfr = min(kGnChunk, L0 - t0), tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const float* x = wav + (long long)b * n_samples + 5 * t0;
+    for (int i = tid; i < 5 * nfr + 5; i += 256) xs[i] = x[i];
+    float w[2][10], sc[2], sh[2], mean[2], rstd[2], m1[2], m2[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int c = tid + 256 * q;
+        sc[q] = scale[b * 512 + c]; sh[q] = shift[b * 512 + c];
+        mean[q] = gmean[b * 512 + c]; rstd[q] = grstd[b * 512 + c];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) w[q][j] = w0[c * 10 + j];
+        float a1 = 0.f, a2 = 0.f;  // fold the chunk partials in chunk order (deterministic)
+        for (int k = 0; k < nchunks; ++k) {
+            const float* p = partial + ((long long)b * nchunks + k) * 1024;
+            a1 += p[c];
+            a2 += p[512 + c];
+        }
+        m1[q] = a1 / (float)L0;
+        m2[q] = a2 / (float)L0;
+    }
+    __syncthreads();
+    const float* g = G + ((long long)b * L0 + t0) * 512;
+    float* dx = dwav + (long long)b * n_samples + 5 * t0;
+    for (int t = 0; t < nfr; ++t) {
+        float z[2], yh[2], contrib[10];
+        conv0_frame(xs, t, w, sc, sh, mean, rstd, z, yh);
+#pragma unroll
+        for (int j = 0; j < 10; ++j) contrib[j] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float dz = g[(long long)t * 512 + tid + 256 * q] * dgelu_erf(z[q]);
+            const float dy = sc[q] * (dz - m1[q] - yh[q] * m2[q]);  // sc = gamma * rstd
+#pragma unroll
+            for (int j = 0; j < 10; ++j) contrib[j] = fmaf(dy, w[q][j], contrib[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            const float v = wave_sum(contrib[j]);
+            if (lane == 0) red[wave][j] = v;
+        }
+        __syncthreads();
+        if (tid < 10) atomicAdd(&dx[5 * t + tid], (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]));
+        __syncthreads();
+    }
+}
+
+}  // namespace nomad

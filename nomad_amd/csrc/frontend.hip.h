@@ -57,7 +57,8 @@ __global__ __launch_bounds__(256) void wav_stats_kernel(const float* __restrict_
 // grid: B blocks of 512 threads (one per channel).  scale = rstd*gamma, shift = beta - mean*rstd*gamma.
 __global__ __launch_bounds__(512) void gn_fold_kernel(const double* __restrict__ stats, const float* __restrict__ w0,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      int L0, float* __restrict__ scale, float* __restrict__ shift) {
+                                                      int L0, float* __restrict__ scale, float* __restrict__ shift,
+                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out) {
     const int b = blockIdx.x, c = threadIdx.x;
     const double* st = stats + (long long)b * kStatsPerClip;
     double w[10];
@@ -81,6 +82,10 @@ __global__ __launch_bounds__(512) void gn_fold_kernel(const double* __restrict__
     const double g = (double)gamma[c];
     scale[b * 512 + c] = (float)(rstd * g);
     shift[b * 512 + c] = (float)((double)beta[c] - mean * rstd * g);
+    if (mean_out) {  // saved for the GroupNorm backward
+        mean_out[b * 512 + c] = (float)mean;
+        rstd_out[b * 512 + c] = (float)rstd;
+    }
 }
 
 // grid: (ceil(L0/FR), B), 256 threads.  Thread = (4 channels) x (frame parity); samples staged in LDS.

@@ -58,7 +58,20 @@ struct GemmParams {
     // at column n % c_colblk.  post_extract_proj uses it to write the pos-conv input group-major.
     int c_colblk;
     long long c_colblk_stride;
+    // Training support.  Upre (nullable): the pre-activation acc + bias is ALSO stored there, at the same
+    // index as C (saved for the backward's GELU').  DG (nullable): the result is multiplied by
+    // gelu'(DG[dgmap(m) + n]) after the optional GELU and before the residual: backward GEMMs whose output
+    // feeds a GELU's input gradient.
+    float* Upre;
+    const float* DG;
+    RowMap dgmap;
+    long long dg_goff;
 };
+
+__device__ __forceinline__ float dgelu_erf_(float u) {
+    const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752440f));
+    return cdf + u * 0.39894228040143267794f * expf(-0.5f * u * u);
+}
 
 __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
@@ -236,9 +249,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_kernel(const GemmParams 
                 const int m = m0 + wm * Cfg::WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m < p.M && n_ok) {
                     float v = acc[i][j][r] + bv;
+                    const long long c_idx = (c_plain ? p.cmap.off + (long long)m * p.cmap.ld : row_addr(p.cmap, m)) + c_col;
+                    if (p.Upre) p.Upre[grp * p.c_goff + c_idx] = v;
                     if (p.gelu) v = gelu_erf(v);
+                    if (p.DG) v *= dgelu_erf_(p.DG[grp * p.dg_goff + row_addr(p.dgmap, m) + n]);
                     if (Rg) v += Rg[(r_plain ? p.rmap.off + (long long)m * p.rmap.ld : row_addr(p.rmap, m)) + n];
-                    Cg[(c_plain ? p.cmap.off + (long long)m * p.cmap.ld : row_addr(p.cmap, m)) + c_col] = v;
+                    Cg[c_idx] = v;
                 }
             }
         }
@@ -381,9 +397,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_glds_kernel(const GemmPa
                 const int m = m0 + wm * Cfg::WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m < p.M && n_ok) {
                     float v = acc[i][j][r] + bv;
+                    const long long c_idx = (c_plain ? p.cmap.off + (long long)m * p.cmap.ld : row_addr(p.cmap, m)) + c_col;
+                    if (p.Upre) p.Upre[grp * p.c_goff + c_idx] = v;
                     if (p.gelu) v = gelu_erf(v);
+                    if (p.DG) v *= dgelu_erf_(p.DG[grp * p.dg_goff + row_addr(p.dgmap, m) + n]);
                     if (Rg) v += Rg[(r_plain ? p.rmap.off + (long long)m * p.rmap.ld : row_addr(p.rmap, m)) + n];
-                    Cg[(c_plain ? p.cmap.off + (long long)m * p.cmap.ld : row_addr(p.cmap, m)) + c_col] = v;
+                    Cg[c_idx] = v;
                 }
             }
         }

@@ -21,6 +21,7 @@
 
 #include "../../include/nomad_hip.h"
 #include "attention.hip.h"
+#include "backward.hip.h"
 #include "frontend.hip.h"
 #include "gemm_f32.hip.h"
 #include "pairwise.hip.h"
@@ -111,6 +112,80 @@ Layout make_layout(const Shapes& s, bool keep) {
     return l;
 }
 
+// What a training-mode forward keeps for the backward pass (all fp32, carved from the caller's `saved` block).
+struct SavedLayer {
+    float *qkv, *ctx, *lse, *y1, *u, *y2;
+};
+struct Saved {
+    float *gn_scale, *gn_shift, *gn_mean, *gn_rstd;
+    float* u[7];   // pre-GELU conv outputs, layers 1..6, compact [B][L_i][512]
+    float* c6;     // conv6 post-GELU output = LayerNorm(512) input
+    float *y0, *upc;  // encoder LayerNorm input, pos-conv pre-GELU
+    SavedLayer L[NOMAD_NUM_LAYERS];
+    size_t total;
+};
+
+Saved make_saved(const Shapes& s, void* base) {
+    Saved v{};
+    size_t off = 0;
+    char* b = static_cast<char*>(base);
+    auto take = [&](size_t floats) {
+        float* ptr = reinterpret_cast<float*>(b + off);
+        off += align_up(floats * sizeof(float));
+        return ptr;
+    };
+    const size_t M = s.M;
+    v.gn_scale = take(512 * (size_t)s.B);
+    v.gn_shift = take(512 * (size_t)s.B);
+    v.gn_mean = take(512 * (size_t)s.B);
+    v.gn_rstd = take(512 * (size_t)s.B);
+    for (int i = 1; i < 7; ++i) v.u[i] = take(512 * (size_t)s.B * s.L[i]);
+    v.c6 = take(512 * M);
+    v.y0 = take(768 * M);
+    v.upc = take(768 * M);
+    for (int l = 0; l < NOMAD_NUM_LAYERS; ++l) {
+        v.L[l].qkv = take(2304 * M);
+        v.L[l].ctx = take(768 * M);
+        v.L[l].lse = take(12 * M);
+        v.L[l].y1 = take(768 * M);
+        v.L[l].u = take(3072 * M);
+        v.L[l].y2 = take(768 * M);
+    }
+    v.total = off;
+    return v;
+}
+
+// Scratch of nomad_embed_backward.
+struct BwdLayout {
+    size_t gx, dya, dyb, dh, dqkv, dug, f1, f2, bufa, bufb, partial, total;
+    int nchunks;
+};
+
+BwdLayout make_bwd_layout(const Shapes& s) {
+    BwdLayout l{};
+    size_t off = 0;
+    auto take = [&](size_t floats) {
+        size_t o = off;
+        off += align_up(floats * sizeof(float));
+        return o;
+    };
+    const size_t M = s.M;
+    l.gx = take(768 * M);
+    l.dya = take(768 * M);
+    l.dyb = take(768 * M);
+    l.dh = take(3072 * M);
+    l.dqkv = take(2304 * M);
+    l.dug = take(768 * (size_t)s.B * (s.T + 128));
+    l.f1 = take(512 * M);
+    l.f2 = take(512 * M);
+    l.bufa = take(512 * (size_t)s.B * (s.L[0] + 2));
+    l.bufb = take(512 * (size_t)s.B * (s.L[1] + 2));
+    l.nchunks = (s.L[0] + kGnChunk - 1) / kGnChunk;
+    l.partial = take(1024 * (size_t)s.B * l.nchunks);
+    l.total = off;
+    return l;
+}
+
 }  // namespace
 
 struct nomad_ctx {
@@ -125,6 +200,15 @@ struct nomad_ctx {
     float *eln_w = nullptr, *eln_b = nullptr;
     LayerDev layers[NOMAD_NUM_LAYERS] = {};
     float *emb_w = nullptr, *emb_b = nullptr;
+    // transposed copies for the dX-only backward (built by nomad_enable_backward)
+    bool bwd_ready = false;
+    float* conv_bw_even[7] = {};  // k=3 layers 1..4: [512][1024] = [W_tap2^T | W_tap0^T]
+    float* conv_bw_odd[7] = {};   // k=3 layers 1..4: [512][512]  = W_tap1^T
+    float* conv_bw2[7] = {};      // k=2 layers 5,6: [1024][512]
+    float* proj_wT = nullptr;     // [512][768]
+    float* pos_wb = nullptr;      // [16][64][6144], taps flipped
+    float *qkv_wT[NOMAD_NUM_LAYERS] = {}, *o_wT[NOMAD_NUM_LAYERS] = {}, *fc1_wT[NOMAD_NUM_LAYERS] = {},
+          *fc2_wT[NOMAD_NUM_LAYERS] = {};
     std::vector<void*> allocs;
     // profiling
     bool prof = false;
@@ -267,10 +351,10 @@ int run_layernorm(nomad_ctx* c, const float* in, const float* g, const float* b,
     return 0;
 }
 
-int run_attention(nomad_ctx* c, const float* qkv, float* out, int B, int T, hipStream_t s) {
+int run_attention(nomad_ctx* c, const float* qkv, float* out, float* lse, int B, int T, hipStream_t s) {
     const double flops = 4.0 * B * 12.0 * (double)T * T * 64;
     Scope sc(c, s, NOMAD_K_ATTN, flops);
-    hipLaunchKernelGGL(attention_f32_kernel, dim3((T + 63) / 64, B * 12), dim3(256), 0, s, qkv, out, T);
+    hipLaunchKernelGGL(attention_f32_kernel, dim3((T + 63) / 64, B * 12), dim3(256), 0, s, qkv, out, lse, T);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -426,8 +510,13 @@ int nomad_diag_workspace_region(const nomad_ctx* c, int B, int n_samples, const 
     return 0;
 }
 
-int nomad_embed(nomad_ctx* c, const float* wav, int B, int n_samples, const float* head_w, const float* head_b,
-                float* emb, float* layers_out, void* workspace, size_t workspace_bytes, nomad_stream_t stream) {
+}  // extern "C"
+
+// The forward pass.  sv == nullptr: scoring mode (intermediates alias inside the workspace).  sv != nullptr:
+// training mode - every tensor the backward needs is written to its slot in `sv` instead.
+static int forward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, const float* head_w, const float* head_b,
+                        float* emb, float* layers_out, void* workspace, size_t workspace_bytes, nomad_stream_t stream,
+                        const Saved* sv) {
     Shapes sh;
     if (!c || !wav || !emb || !workspace || B <= 0 || !make_shapes(B, n_samples, &sh))
         return fail(NOMAD_ERR_INVALID, "nomad_embed: bad argument (B=%d, n_samples=%d)", B, n_samples);
@@ -442,16 +531,18 @@ int nomad_embed(nomad_ctx* c, const float* wav, int B, int n_samples, const floa
 
     // ---- front end: conv0 + GroupNorm + GELU ------------------------------------------------
     double* stats = reinterpret_cast<double*>(ws + lay.stats);
+    float* gn_scale = sv ? sv->gn_scale : F(lay.scale);
+    float* gn_shift = sv ? sv->gn_shift : F(lay.shift);
     {
         Scope sc(c, s, NOMAD_K_FRONT, 0.0);
         hipLaunchKernelGGL(wav_stats_kernel, dim3(B), dim3(256), 0, s, wav, n_samples, sh.L[0], stats);
         hipLaunchKernelGGL(gn_fold_kernel, dim3(B), dim3(512), 0, s, stats, c->conv0_w, c->gn_w, c->gn_b, sh.L[0],
-                           F(lay.scale), F(lay.shift));
+                           gn_scale, gn_shift, sv ? sv->gn_mean : nullptr, sv ? sv->gn_rstd : nullptr);
     }
     {
         Scope sc(c, s, NOMAD_K_FRONT, 2.0 * B * (double)sh.L[0] * 512 * 10);
         hipLaunchKernelGGL(conv0_gn_gelu_kernel, dim3((sh.L[0] + kConv0Frames - 1) / kConv0Frames, B), dim3(256), 0, s,
-                           wav, n_samples, sh.L[0], c->conv0_w, F(lay.scale), F(lay.shift), F(lay.conv[0]));
+                           wav, n_samples, sh.L[0], c->conv0_w, gn_scale, gn_shift, F(lay.conv[0]));
     }
     HIP_TRY(hipGetLastError());
 
@@ -465,7 +556,8 @@ int nomad_embed(nomad_ctx* c, const float* wav, int B, int n_samples, const floa
         p.kchunk = p.K;
         p.W = c->conv_w[i];
         p.ldw = p.K;
-        p.C = F(lay.conv[i]);
+        p.C = (sv && i == 6) ? sv->c6 : F(lay.conv[i]);
+        p.Upre = sv ? sv->u[i] : nullptr;
         p.M = B * sh.L[i];
         p.N = 512;
         p.n_valid = 512;
@@ -476,7 +568,8 @@ int nomad_embed(nomad_ctx* c, const float* wav, int B, int n_samples, const floa
     }
 
     // ---- LayerNorm(512) + post_extract_proj into the padded pos-conv buffer ------------------
-    if ((rc = run_layernorm(c, F(lay.conv[6]), c->fln_w, c->fln_b, F(lay.featln), nullptr, M, 512, s))) return rc;
+    if ((rc = run_layernorm(c, sv ? sv->c6 : F(lay.conv[6]), c->fln_w, c->fln_b, F(lay.featln), nullptr, M, 512, s)))
+        return rc;
     // group-major pos-conv buffer xg[16][B][T+128][48]; x (post_extract_proj output) sits at frames 64..64+T
     float* xpad = F(lay.xpad);
     const long long grp_stride = (long long)B * (T + 128) * 48;
@@ -505,7 +598,8 @@ int nomad_embed(nomad_ctx* c, const float* wav, int B, int n_samples, const floa
         p.w_goff = 64LL * 6144;
         p.bias = c->pos_b;
         p.bias_goff = 48;
-        p.C = F(lay.y);
+        p.C = sv ? sv->y0 : F(lay.y);
+        p.Upre = sv ? sv->upc : nullptr;
         p.cmap = plain_map(M, 768);
         p.c_goff = 48;
         p.R = xpad;
@@ -520,25 +614,30 @@ int nomad_embed(nomad_ctx* c, const float* wav, int B, int n_samples, const floa
     float* x = F(lay.x);
     float* x2 = F(lay.x2);
     float* y = F(lay.y);
-    if ((rc = run_layernorm(c, y, c->eln_w, c->eln_b, x, nullptr, M, 768, s))) return rc;
+    if ((rc = run_layernorm(c, sv ? sv->y0 : y, c->eln_w, c->eln_b, x, nullptr, M, 768, s))) return rc;
 
     // ---- 12 post-LN transformer layers --------------------------------------------------------
     for (int l = 0; l < NOMAD_NUM_LAYERS; ++l) {
         const LayerDev& d = c->layers[l];
-        if ((rc = run_gemm(c, dense(x, 768, d.qkv_w, d.qkv_b, nullptr, F(lay.qkv), M, 2304, 768, 0), 1,
-                           pick_tile(M, 2304, 768), s)))
+        float* qkv = sv ? sv->L[l].qkv : F(lay.qkv);
+        float* ctxb = sv ? sv->L[l].ctx : F(lay.ctxb);
+        float* y1 = sv ? sv->L[l].y1 : y;
+        float* y2 = sv ? sv->L[l].y2 : y;
+        if ((rc = run_gemm(c, dense(x, 768, d.qkv_w, d.qkv_b, nullptr, qkv, M, 2304, 768, 0), 1, pick_tile(M, 2304, 768), s)))
             return rc;
-        if ((rc = run_attention(c, F(lay.qkv), F(lay.ctxb), B, T, s))) return rc;
-        if ((rc = run_gemm(c, dense(F(lay.ctxb), 768, d.o_w, d.o_b, x, y, M, 768, 768, 0), 1, pick_tile(M, 768, 768), s)))
+        if ((rc = run_attention(c, qkv, ctxb, sv ? sv->L[l].lse : nullptr, B, T, s))) return rc;
+        if ((rc = run_gemm(c, dense(ctxb, 768, d.o_w, d.o_b, x, y1, M, 768, 768, 0), 1, pick_tile(M, 768, 768), s)))
             return rc;
-        if ((rc = run_layernorm(c, y, d.ln1_w, d.ln1_b, x2, nullptr, M, 768, s))) return rc;
-        if ((rc = run_gemm(c, dense(x2, 768, d.fc1_w, d.fc1_b, nullptr, F(lay.h), M, 3072, 768, 1), 1,
-                           pick_tile(M, 3072, 768), s)))
-            return rc;
-        if ((rc = run_gemm(c, dense(F(lay.h), 3072, d.fc2_w, d.fc2_b, x2, y, M, 768, 3072, 0), 1, pick_tile(M, 768, 3072), s)))
+        if ((rc = run_layernorm(c, y1, d.ln1_w, d.ln1_b, x2, nullptr, M, 768, s))) return rc;
+        {
+            GemmParams p = dense(x2, 768, d.fc1_w, d.fc1_b, nullptr, F(lay.h), M, 3072, 768, 1);
+            p.Upre = sv ? sv->L[l].u : nullptr;
+            if ((rc = run_gemm(c, p, 1, pick_tile(M, 3072, 768), s))) return rc;
+        }
+        if ((rc = run_gemm(c, dense(F(lay.h), 3072, d.fc2_w, d.fc2_b, x2, y2, M, 768, 3072, 0), 1, pick_tile(M, 768, 3072), s)))
             return rc;
         float* lo = layers_out ? layers_out + (size_t)l * M * 768 : nullptr;
-        if ((rc = run_layernorm(c, y, d.ln2_w, d.ln2_b, x, lo, M, 768, s))) return rc;
+        if ((rc = run_layernorm(c, y2, d.ln2_w, d.ln2_b, x, lo, M, 768, s))) return rc;
     }
 
     // ---- head -----------------------------------------------------------------------------------
@@ -546,6 +645,272 @@ int nomad_embed(nomad_ctx* c, const float* wav, int B, int n_samples, const floa
         Scope sc(c, s, NOMAD_K_ROW, 2.0 * B * 768 * 256);
         hipLaunchKernelGGL(head_kernel, dim3(B), dim3(256), 0, s, x, T, head_w ? head_w : c->emb_w,
                            head_b ? head_b : c->emb_b, emb);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// One backward GEMM: C[M][N] = A[M][K] * Wt[N][K]^T (Wt = transposed forward weight), optional GELU' and residual.
+static int bwd_gemm(nomad_ctx* c, const float* A, const float* Wt, float* C, int M, int N, int K, const float* DG,
+                    const float* R, hipStream_t s) {
+    GemmParams p = dense(A, K, Wt, nullptr, R, C, M, N, K, 0);
+    p.DG = DG;
+    p.dgmap = plain_map(M, N);
+    return run_gemm(c, p, 1, pick_tile(M, N, K), s);
+}
+
+static int run_ln_bwd(nomad_ctx* c, const float* x, const float* g, const float* g2, const float* gamma, float* dx, int M,
+                      int N, hipStream_t s) {
+    Scope sc(c, s, NOMAD_K_ROW, 0.0);
+    const int blocks = (M + 3) / 4;
+    if (N == 768) hipLaunchKernelGGL(layernorm_bwd_kernel<3>, dim3(blocks), dim3(256), 0, s, x, g, g2, gamma, dx, M);
+    else hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(blocks), dim3(256), 0, s, x, g, g2, gamma, dx, M);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" {
+
+int nomad_embed(nomad_ctx* c, const float* wav, int B, int n_samples, const float* head_w, const float* head_b,
+                float* emb, float* layers_out, void* workspace, size_t workspace_bytes, nomad_stream_t stream) {
+    return forward_impl(c, wav, B, n_samples, head_w, head_b, emb, layers_out, workspace, workspace_bytes, stream, nullptr);
+}
+
+int nomad_saved_bytes(const nomad_ctx* c, int B, int n_samples, size_t* bytes) {
+    Shapes sh;
+    if (!c || !bytes || B <= 0 || !make_shapes(B, n_samples, &sh))
+        return fail(NOMAD_ERR_INVALID, "nomad_saved_bytes: bad shape B=%d N=%d", B, n_samples);
+    *bytes = make_saved(sh, nullptr).total;
+    return 0;
+}
+
+int nomad_backward_workspace_bytes(const nomad_ctx* c, int B, int n_samples, size_t* bytes) {
+    Shapes sh;
+    if (!c || !bytes || B <= 0 || !make_shapes(B, n_samples, &sh))
+        return fail(NOMAD_ERR_INVALID, "nomad_backward_workspace_bytes: bad shape B=%d N=%d", B, n_samples);
+    *bytes = make_bwd_layout(sh).total;
+    return 0;
+}
+
+int nomad_embed_train(nomad_ctx* c, const float* wav, int B, int n_samples, const float* head_w, const float* head_b,
+                      float* emb, float* layers_out, void* saved, size_t saved_bytes, void* workspace,
+                      size_t workspace_bytes, nomad_stream_t stream) {
+    Shapes sh;
+    if (!c || !saved || !layers_out || B <= 0 || !make_shapes(B, n_samples, &sh))
+        return fail(NOMAD_ERR_INVALID, "nomad_embed_train: bad argument");
+    const Saved sv = make_saved(sh, saved);
+    if (saved_bytes < sv.total)
+        return fail(NOMAD_ERR_WORKSPACE, "nomad_embed_train: saved block %zu < required %zu", saved_bytes, sv.total);
+    return forward_impl(c, wav, B, n_samples, head_w, head_b, emb, layers_out, workspace, workspace_bytes, stream, &sv);
+}
+
+int nomad_enable_backward(nomad_ctx* c) {
+    if (!c) return fail(NOMAD_ERR_INVALID, "null ctx");
+    if (c->bwd_ready) return 0;
+    HIP_TRY(hipSetDevice(c->device));
+    auto alloc = [&](size_t floats, float** out) -> int {
+        void* d = nullptr;
+        HIP_TRY(hipMalloc(&d, floats * sizeof(float)));
+        c->allocs.push_back(d);
+        *out = static_cast<float*>(d);
+        return 0;
+    };
+    auto transpose = [&](const float* in, int ld_in, float* out, int ld_out, int R, int C) {
+        hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(32, 8), 0, 0, in, ld_in, out, ld_out, R, C);
+    };
+    int rc;
+    for (int i = 1; i <= 4; ++i) {  // k = 3: forward repack is [n][tap*512 + c]
+        if ((rc = alloc(512 * 1024, &c->conv_bw_even[i]))) return rc;
+        if ((rc = alloc(512 * 512, &c->conv_bw_odd[i]))) return rc;
+        transpose(c->conv_w[i] + 2 * 512, 1536, c->conv_bw_even[i], 1024, 512, 512);        // tap 2 pairs with dU[t'-1]
+        transpose(c->conv_w[i], 1536, c->conv_bw_even[i] + 512, 1024, 512, 512);            // tap 0 pairs with dU[t']
+        transpose(c->conv_w[i] + 512, 1536, c->conv_bw_odd[i], 512, 512, 512);              // tap 1
+    }
+    for (int i = 5; i <= 6; ++i) {  // k = 2: [n][tap*512 + c] -> [(tap*512 + c)][n]
+        if ((rc = alloc(1024 * 512, &c->conv_bw2[i]))) return rc;
+        transpose(c->conv_w[i], 1024, c->conv_bw2[i], 512, 512, 1024);
+    }
+    if ((rc = alloc(512 * 768, &c->proj_wT))) return rc;
+    transpose(c->proj_w, 512, c->proj_wT, 768, 768, 512);
+    if ((rc = alloc((size_t)16 * 64 * 6144, &c->pos_wb))) return rc;
+    hipLaunchKernelGGL(posconv_bwd_weight_kernel, dim3(16 * 64), dim3(256), 0, 0, c->pos_w, c->pos_wb);
+    for (int l = 0; l < NOMAD_NUM_LAYERS; ++l) {
+        const LayerDev& d = c->layers[l];
+        if ((rc = alloc((size_t)768 * 2304, &c->qkv_wT[l]))) return rc;
+        if ((rc = alloc((size_t)768 * 768, &c->o_wT[l]))) return rc;
+        if ((rc = alloc((size_t)768 * 3072, &c->fc1_wT[l]))) return rc;
+        if ((rc = alloc((size_t)3072 * 768, &c->fc2_wT[l]))) return rc;
+        transpose(d.qkv_w, 768, c->qkv_wT[l], 2304, 2304, 768);
+        transpose(d.o_w, 768, c->o_wT[l], 768, 768, 768);
+        transpose(d.fc1_w, 768, c->fc1_wT[l], 3072, 3072, 768);
+        transpose(d.fc2_w, 3072, c->fc2_wT[l], 768, 768, 3072);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    c->bwd_ready = true;
+    return 0;
+}
+
+int nomad_l1_loss_backward(nomad_ctx* c, const float* a_layers, const float* b_layers, const float* a_emb,
+                           const float* b_emb, int B, int T, const float* upstream, float* dlayers, float* demb,
+                           nomad_stream_t stream) {
+    if (!c || !a_layers || !b_layers || !a_emb || !b_emb || !upstream || !dlayers || !demb || B <= 0 || T <= 0)
+        return fail(NOMAD_ERR_INVALID, "nomad_l1_loss_backward: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long per_layer = (long long)B * T * 768;
+    Scope sc(c, s, NOMAD_K_ROW, 0.0);
+    hipLaunchKernelGGL(l1_bwd_kernel, dim3(2048), dim3(256), 0, s, reinterpret_cast<const float4*>(a_layers),
+                       reinterpret_cast<const float4*>(b_layers), per_layer * 12 / 4, 1.0f / (float)per_layer, upstream,
+                       reinterpret_cast<float4*>(dlayers));
+    hipLaunchKernelGGL(l1_bwd_kernel, dim3(64), dim3(256), 0, s, reinterpret_cast<const float4*>(a_emb),
+                       reinterpret_cast<const float4*>(b_emb), (long long)B * 64, 1.0f / (float)(B * 256), upstream,
+                       reinterpret_cast<float4*>(demb));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int nomad_embed_backward(nomad_ctx* c, const float* wav, int B, int n_samples, const float* head_w, const float* head_b,
+                         const float* layers_out, const void* saved, size_t saved_bytes, const float* dlayers,
+                         const float* demb, float* dwav, void* workspace, size_t workspace_bytes,
+                         nomad_stream_t stream) {
+    Shapes sh;
+    if (!c || !wav || !layers_out || !saved || !demb || !dwav || !workspace || B <= 0 || !make_shapes(B, n_samples, &sh))
+        return fail(NOMAD_ERR_INVALID, "nomad_embed_backward: bad argument");
+    if (!c->bwd_ready) return fail(NOMAD_ERR_INVALID, "nomad_embed_backward: call nomad_enable_backward first");
+    const Saved sv = make_saved(sh, const_cast<void*>(saved));
+    const BwdLayout lay = make_bwd_layout(sh);
+    if (saved_bytes < sv.total || workspace_bytes < lay.total)
+        return fail(NOMAD_ERR_WORKSPACE, "nomad_embed_backward: saved %zu/%zu, workspace %zu/%zu", saved_bytes, sv.total,
+                    workspace_bytes, lay.total);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    char* ws = static_cast<char*>(workspace);
+    auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    const int T = sh.T, M = sh.M;
+    float *gx = F(lay.gx), *dya = F(lay.dya), *dyb = F(lay.dyb), *dh = F(lay.dh), *dqkv = F(lay.dqkv);
+    int rc;
+
+    // ---- head -> d loss / d x_12 -------------------------------------------------------------------
+    {
+        Scope sc(c, s, NOMAD_K_ROW, 0.0);
+        hipLaunchKernelGGL(head_bwd_kernel, dim3(B), dim3(256), 0, s, layers_out + (size_t)11 * M * 768, T,
+                           head_w ? head_w : c->emb_w, head_b ? head_b : c->emb_b, demb, gx);
+    }
+    // ---- 12 transformer layers, last to first ---------------------------------------------------------
+    for (int l = NOMAD_NUM_LAYERS - 1; l >= 0; --l) {
+        const LayerDev& d = c->layers[l];
+        const SavedLayer& sl = sv.L[l];
+        const float* dl = dlayers ? dlayers + (size_t)l * M * 768 : nullptr;
+        if ((rc = run_ln_bwd(c, sl.y2, gx, dl, d.ln2_w, dya, M, 768, s))) return rc;                   // dy2
+        if ((rc = bwd_gemm(c, dya, c->fc2_wT[l], dh, M, 3072, 768, sl.u, nullptr, s))) return rc;      // du = (dy2 W2) * gelu'(u)
+        if ((rc = bwd_gemm(c, dh, c->fc1_wT[l], dyb, M, 768, 3072, nullptr, dya, s))) return rc;       // dx1 = du W1 + dy2
+        if ((rc = run_ln_bwd(c, sl.y1, dyb, nullptr, d.ln1_w, dya, M, 768, s))) return rc;             // dy1
+        if ((rc = bwd_gemm(c, dya, c->o_wT[l], dyb, M, 768, 768, nullptr, nullptr, s))) return rc;     // dctx
+        {
+            Scope sc(c, s, NOMAD_K_ATTN, 10.0 * B * 12.0 * (double)T * T * 64);
+            const dim3 grid((T + kAB - 1) / kAB, B * 12);
+            hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, s, sl.qkv, sl.ctx, dyb, sl.lse, dqkv, T);
+            hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, s, sl.qkv, sl.ctx, dyb, sl.lse, dqkv, T);
+        }
+        if ((rc = bwd_gemm(c, dqkv, c->qkv_wT[l], gx, M, 768, 2304, nullptr, dya, s))) return rc;      // dx_in = dqkv Wqkv + dy1
+    }
+    // ---- encoder input: LayerNorm, x + gelu(pos_conv(x)) --------------------------------------------
+    if ((rc = run_ln_bwd(c, sv.y0, gx, nullptr, c->eln_w, dya, M, 768, s))) return rc;                   // dy0
+    {
+        float* dug = F(lay.dug);
+        const long long grp_stride = (long long)B * (T + 128) * 48;
+        {
+            Scope sc(c, s, NOMAD_K_ROW, 0.0);
+            hipLaunchKernelGGL(zero_pad_rows_kernel, dim3(16 * B), dim3(256), 0, s, dug, T);
+            hipLaunchKernelGGL(dgelu_to_groups_kernel, dim3(M), dim3(192), 0, s, dya, sv.upc, dug, T, grp_stride);
+        }
+        GemmParams p{};
+        p.A = dug;
+        p.amap = RowMap{48, (long long)(T + 128) * 48, T, 48};  // row (clip, t) starts at buffer frame t + 1
+        p.a_goff = grp_stride;
+        p.K = 6144;
+        p.kchunk = 6144;
+        p.W = c->pos_wb;
+        p.ldw = 6144;
+        p.w_goff = 64LL * 6144;
+        p.C = dyb;
+        p.cmap = plain_map(M, 768);
+        p.c_goff = 48;
+        p.R = dya;
+        p.rmap = plain_map(M, 768);
+        p.r_goff = 48;
+        p.M = M;
+        p.N = 64;
+        p.n_valid = 48;
+        if ((rc = run_gemm(c, p, 16, M >= 1024 ? 29 : 2, s))) return rc;                                // dxp
+    }
+    // ---- post_extract_proj, LayerNorm(512), GELU of conv6 ----------------------------------------------
+    if ((rc = bwd_gemm(c, dyb, c->proj_wT, F(lay.f1), M, 512, 768, nullptr, nullptr, s))) return rc;
+    if ((rc = run_ln_bwd(c, sv.c6, F(lay.f1), nullptr, c->fln_w, F(lay.f2), M, 512, s))) return rc;
+    float* bufs[2] = {F(lay.bufa), F(lay.bufb)};  // dU6 -> a, dU5 -> b, ..., dU1 -> b, G0 -> a
+    {
+        HIP_TRY(hipMemsetAsync(bufs[0], 0, sizeof(float) * 512 * (size_t)B * (T + 2), s));
+        Scope sc(c, s, NOMAD_K_ROW, 0.0);
+        const RowMap om{512, (long long)(T + 2) * 512, T, 512};
+        hipLaunchKernelGGL(dgelu_rows512_kernel, dim3(M), dim3(128), 0, s, F(lay.f2), sv.u[6], bufs[0], om, M);
+    }
+    // ---- conv6..conv1: transposed strided convolutions as GEMMs over the padded dU buffers -------------
+    for (int i = 6; i >= 1; --i) {
+        const float* dU = bufs[i % 2];        // [B][L_i + 2][512], data at rows 1..L_i
+        float* out = bufs[(i + 1) % 2];
+        const int Lout = sh.L[i], Lin = sh.L[i - 1];
+        const bool to_g0 = (i == 1);          // conv0's output gradient is compact and gets no GELU' here
+        const long long out_clip = to_g0 ? (long long)Lin * 512 : (long long)(Lin + 2) * 512;
+        const long long out_off = to_g0 ? 0 : 512;
+        HIP_TRY(hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * out_clip, s));
+        GemmParams p{};
+        p.A = dU;
+        p.C = out;
+        p.DG = to_g0 ? nullptr : sv.u[i - 1];
+        p.rmap = plain_map(1, 1);
+        if (kConvK[i] == 2) {
+            p.amap = RowMap{512, (long long)(Lout + 2) * 512, Lout, 512};
+            p.K = 512;
+            p.W = c->conv_bw2[i];
+            p.N = 1024;
+            p.M = B * Lout;
+            p.cmap = RowMap{out_off, out_clip, Lout, 1024};
+            p.dgmap = RowMap{0, (long long)Lin * 512, Lout, 1024};
+            p.kchunk = p.K; p.ldw = p.K; p.n_valid = p.N;
+            if ((rc = run_gemm(c, p, 1, pick_tile(p.M, p.N, p.K), s))) return rc;
+        } else {
+            const int E = (Lin + 1) / 2, O = Lin / 2;
+            // even input frames 2t': dU[t'-1] W_tap2 + dU[t'] W_tap0
+            p.amap = RowMap{0, (long long)(Lout + 2) * 512, E, 512};
+            p.K = 1024;
+            p.W = c->conv_bw_even[i];
+            p.N = 512;
+            p.M = B * E;
+            p.cmap = RowMap{out_off, out_clip, E, 1024};
+            p.dgmap = RowMap{0, (long long)Lin * 512, E, 1024};
+            p.kchunk = p.K; p.ldw = p.K; p.n_valid = p.N;
+            if ((rc = run_gemm(c, p, 1, pick_tile(p.M, p.N, p.K), s))) return rc;
+            // odd input frames 2t'+1: dU[t'] W_tap1
+            p.amap = RowMap{512, (long long)(Lout + 2) * 512, O, 512};
+            p.K = 512;
+            p.W = c->conv_bw_odd[i];
+            p.M = B * O;
+            p.cmap = RowMap{out_off + 512, out_clip, O, 1024};
+            p.dgmap = RowMap{512, (long long)Lin * 512, O, 1024};
+            p.kchunk = p.K; p.ldw = p.K;
+            if (O > 0 && (rc = run_gemm(c, p, 1, pick_tile(p.M, p.N, p.K), s))) return rc;
+        }
+    }
+    // ---- conv0 + GroupNorm -> d loss / d waveform -------------------------------------------------------
+    {
+        const float* G0 = bufs[0];
+        float* partial = F(lay.partial);
+        HIP_TRY(hipMemsetAsync(dwav, 0, sizeof(float) * (size_t)B * n_samples, s));
+        Scope sc(c, s, NOMAD_K_FRONT, 0.0);
+        const dim3 grid(lay.nchunks, B);
+        hipLaunchKernelGGL(gn_bwd_stats_kernel, grid, dim3(256), 0, s, wav, n_samples, sh.L[0], c->conv0_w, sv.gn_scale,
+                           sv.gn_shift, sv.gn_mean, sv.gn_rstd, G0, partial);
+        hipLaunchKernelGGL(conv0_bwd_kernel, grid, dim3(256), 0, s, wav, n_samples, sh.L[0], c->conv0_w, sv.gn_scale,
+                           sv.gn_shift, sv.gn_mean, sv.gn_rstd, G0, partial, lay.nchunks, dwav);
     }
     HIP_TRY(hipGetLastError());
     return 0;
@@ -653,9 +1018,30 @@ int nomad_diag_layernorm(nomad_ctx* c, const float* in, const float* g, const fl
     return run_layernorm(c, in, g, b, out, nullptr, M, N, static_cast<hipStream_t>(stream));
 }
 
+int nomad_diag_layernorm_bwd(nomad_ctx* c, const float* x, const float* g, const float* gamma, float* dx, int M, int N,
+                             nomad_stream_t stream) {
+    if (!c || !x || !g || !gamma || !dx || M <= 0 || (N != 512 && N != 768))
+        return fail(NOMAD_ERR_INVALID, "nomad_diag_layernorm_bwd: bad argument");
+    return run_ln_bwd(c, x, g, nullptr, gamma, dx, M, N, static_cast<hipStream_t>(stream));
+}
+
+int nomad_diag_attention_bwd(nomad_ctx* c, const float* qkv, const float* dctx, float* ctx_out, float* lse, float* dqkv,
+                             int B, int T, nomad_stream_t stream) {
+    if (!c || !qkv || !dctx || !ctx_out || !lse || !dqkv || B <= 0 || T <= 0)
+        return fail(NOMAD_ERR_INVALID, "nomad_diag_attention_bwd: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int rc = run_attention(c, qkv, ctx_out, lse, B, T, s);
+    if (rc) return rc;
+    const dim3 grid((T + kAB - 1) / kAB, B * 12);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, s, qkv, ctx_out, dctx, lse, dqkv, T);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, s, qkv, ctx_out, dctx, lse, dqkv, T);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int nomad_diag_attention(nomad_ctx* c, const float* qkv, float* out, int B, int T, nomad_stream_t stream) {
     if (!c || !qkv || !out || B <= 0 || T <= 0) return fail(NOMAD_ERR_INVALID, "nomad_diag_attention: bad argument");
-    return run_attention(c, qkv, out, B, T, static_cast<hipStream_t>(stream));
+    return run_attention(c, qkv, out, nullptr, B, T, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

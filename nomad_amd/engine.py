@@ -149,6 +149,65 @@ class Engine:
                                           self._stream()), "nomad_l1_loss")
         return loss[0]
 
+    # ---- training (differentiable forward) ---------------------------------------------------------
+    def enable_backward(self):
+        _lib.check(self.lib.nomad_enable_backward(self.ctx), "nomad_enable_backward")
+
+    def _size(self, fn, B, n_samples, what):
+        n = C.c_size_t()
+        _lib.check(fn(self.ctx, B, n_samples, C.byref(n)), what)
+        return n.value
+
+    def embed_train(self, wav: torch.Tensor, head: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+        """Training-mode forward: -> (emb (B,256), layers (12,B,T,768), saved block for embed_backward)."""
+        if wav.dim() == 3:
+            wav = wav.squeeze(1)
+        self._check_dev(wav, "wav")
+        B, N = wav.shape
+        T = num_frames(N)
+        emb = torch.empty(B, 256, dtype=torch.float32, device=self.device)
+        layers = torch.empty(12, B, T, 768, dtype=torch.float32, device=self.device)
+        saved = torch.empty(self._size(self.lib.nomad_saved_bytes, B, N, "nomad_saved_bytes"), dtype=torch.uint8,
+                            device=self.device)
+        hw, hb = head if head is not None else (None, None)
+        ws = self._workspace(self.workspace_bytes(B, N))
+        _lib.check(self.lib.nomad_embed_train(self.ctx, wav.data_ptr(), B, N,
+                                              hw.data_ptr() if hw is not None else None,
+                                              hb.data_ptr() if hb is not None else None,
+                                              emb.data_ptr(), layers.data_ptr(), saved.data_ptr(), saved.numel(),
+                                              ws.data_ptr(), ws.numel(), self._stream()), "nomad_embed_train")
+        return emb, layers, saved
+
+    def embed_backward(self, wav, layers, saved, dlayers, demb, head=None) -> torch.Tensor:
+        """d loss / d wav (B,N) from d loss / d layers (12,B,T,768 or None) and d loss / d emb (B,256)."""
+        if wav.dim() == 3:
+            wav = wav.squeeze(1)
+        B, N = wav.shape
+        self.enable_backward()
+        nb = self._size(self.lib.nomad_backward_workspace_bytes, B, N, "nomad_backward_workspace_bytes")
+        ws = self._workspace(nb)
+        dwav = torch.empty(B, N, dtype=torch.float32, device=self.device)
+        hw, hb = head if head is not None else (None, None)
+        _lib.check(self.lib.nomad_embed_backward(self.ctx, wav.data_ptr(), B, N,
+                                                 hw.data_ptr() if hw is not None else None,
+                                                 hb.data_ptr() if hb is not None else None,
+                                                 layers.data_ptr(), saved.data_ptr(), saved.numel(),
+                                                 dlayers.data_ptr() if dlayers is not None else None, demb.data_ptr(),
+                                                 dwav.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()),
+                   "nomad_embed_backward")
+        return dwav
+
+    def l1_loss_backward(self, a_layers, b_layers, a_emb, b_emb, upstream: torch.Tensor):
+        """(d loss/d a_layers, d loss/d a_emb) for NomadLoss, scaled by the 0-dim device tensor `upstream`."""
+        _, B, T, _ = a_layers.shape
+        dl = torch.empty_like(a_layers)
+        de = torch.empty_like(a_emb)
+        up = upstream.to(self.device, torch.float32).reshape(1).contiguous()
+        _lib.check(self.lib.nomad_l1_loss_backward(self.ctx, a_layers.data_ptr(), b_layers.data_ptr(), a_emb.data_ptr(),
+                                                   b_emb.data_ptr(), B, T, up.data_ptr(), dl.data_ptr(), de.data_ptr(),
+                                                   self._stream()), "nomad_l1_loss_backward")
+        return dl, de
+
     # ---- measurement -----------------------------------------------------------------------------
     def profile_enable(self, on: bool = True):
         _lib.check(self.lib.nomad_profile_enable(self.ctx, int(on)), "nomad_profile_enable")
@@ -187,6 +246,22 @@ class Engine:
         _lib.check(self.lib.nomad_diag_attention(self.ctx, qkv.data_ptr(), out.data_ptr(), B, T, self._stream()),
                    "nomad_diag_attention")
         return out
+
+    def diag_layernorm_bwd(self, x, g, gamma):
+        M, N = x.shape
+        dx = torch.empty_like(x)
+        _lib.check(self.lib.nomad_diag_layernorm_bwd(self.ctx, x.data_ptr(), g.data_ptr(), gamma.data_ptr(),
+                                                     dx.data_ptr(), M, N, self._stream()), "nomad_diag_layernorm_bwd")
+        return dx
+
+    def diag_attention_bwd(self, qkv, dctx, B, T):
+        out = torch.empty(B * T, 768, dtype=torch.float32, device=self.device)
+        lse = torch.empty(B * 12, T, dtype=torch.float32, device=self.device)
+        dqkv = torch.empty(B * T, 2304, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.nomad_diag_attention_bwd(self.ctx, qkv.data_ptr(), dctx.data_ptr(), out.data_ptr(),
+                                                     lse.data_ptr(), dqkv.data_ptr(), B, T, self._stream()),
+                   "nomad_diag_attention_bwd")
+        return out, lse, dqkv
 
     def diag_keep_intermediates(self, on: bool):
         _lib.check(self.lib.nomad_diag_keep_intermediates(self.ctx, int(on)), "nomad_diag_keep_intermediates")

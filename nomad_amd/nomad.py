@@ -119,6 +119,39 @@ def _stack_layers(layers) -> torch.Tensor:
     return torch.stack([l.contiguous() for l in layers])
 
 
+class _NomadLossFn(torch.autograd.Function):
+    """loss = NomadLoss(LossNetLayers(clean), LossNetLayers(estimate)); backward = d loss / d estimate."""
+
+    @staticmethod
+    def forward(ctx, estimate, clean, nomad):
+        eng = nomad.engine
+        head = (nomad.lossnet_layers.embedding_weight, nomad.lossnet_layers.embedding_bias)
+        est = estimate.detach().to(eng.device, torch.float32).contiguous()
+        cln = clean.detach().to(eng.device, torch.float32).contiguous()
+        need_grad = estimate.requires_grad
+        if need_grad:
+            e_emb, e_layers, saved = eng.embed_train(est, head)
+        else:
+            e_emb, e_layers = eng.embed(est, head=head, want_layers=True)
+            saved = None
+        c_emb, c_layers = eng.embed(cln, head=head, want_layers=True)
+        loss = eng.l1_loss(e_layers, c_layers, e_emb, c_emb)
+        if need_grad:
+            ctx.nomad = nomad
+            ctx.shape = estimate.shape
+            ctx.save_for_backward(est, e_layers, e_emb, c_layers, c_emb, saved)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        est, e_layers, e_emb, c_layers, c_emb, saved = ctx.saved_tensors
+        eng = ctx.nomad.engine
+        head = (ctx.nomad.lossnet_layers.embedding_weight, ctx.nomad.lossnet_layers.embedding_bias)
+        dl, de = eng.l1_loss_backward(e_layers, c_layers, e_emb, c_emb, grad_out)
+        dwav = eng.embed_backward(est, e_layers, saved, dl, de, head)
+        return dwav.reshape(ctx.shape), None, None
+
+
 class Nomad:
     def __init__(self, device=None, weights: Union[None, str, Dict[str, torch.Tensor]] = None):
         dev_index = _resolve_device(device)
@@ -199,15 +232,12 @@ class Nomad:
         return df_avg_nomad, df_dm
 
     def forward(self, estimate, clean):
-        """NOMAD loss value (nomad.py:142-146).  The backward pass through the HIP engine is not built
-        yet: a tensor that requires grad is rejected instead of silently returning a constant."""
-        if torch.is_tensor(estimate) and estimate.requires_grad:
-            raise NotImplementedError("nomad.forward(): d loss / d estimate is not implemented in the HIP engine "
-                                      "yet; call with estimate.detach() for the loss value")
-        estimate_embeddings = self.lossnet_layers(estimate)
-        clean_embeddings = self.lossnet_layers(clean)
-        loss = self.nomad_loss(clean_embeddings, estimate_embeddings)
-        return loss
+        """NOMAD loss (nomad.py:142-146), differentiable w.r.t. ``estimate``.
+
+        The whole forward and backward run in the HIP engine (``torch.autograd.Function`` glue only).  The
+        backbone is frozen: the reference would also accumulate parameter gradients nobody reads
+        (the freeze is commented out at nomad.py:74-76); ``clean`` receives no gradient."""
+        return _NomadLossFn.apply(estimate, clean, self)
 
     def get_embeddings(self, path):
         if os.path.isdir(path):

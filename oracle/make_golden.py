@@ -15,7 +15,8 @@ Fixtures written (data only):
   tests/golden/wavs/*.wav          the reference's six example clips (data/nmr-data, data/test-data)
   tests/golden/hf_example_wavs.npz embeddings (6,256), 2x4 distance matrix + means, per-layer checksums
   tests/golden/hf_tiny.npz         batch of 3 synthetic clips of 6000 samples: full 12 layer outputs + embeddings
-  tests/golden/hf_loss.npz         nomad.forward() oracle pins: two (2,1,16384) inputs -> loss (HF layers + torch L1)
+  tests/golden/hf_loss.npz         nomad.forward() pins: two (2,1,16384) inputs -> loss and d loss/d estimate
+                                   (HF layers + torch L1 + torch autograd)
 """
 import os
 import shutil
@@ -142,13 +143,17 @@ def main():
     est = (clean + 0.02 * torch.randn(2, 1, 16384, generator=g)).clamp(-1, 1)
     lw = (torch.rand(256, 768, generator=g) * 2 - 1) / 768 ** 0.5
     lb = (torch.rand(256, generator=g) * 2 - 1) / 768 ** 0.5
+    est.requires_grad_(True)
     outs = []
-    for w_ in (est, clean):
-        x, layers = hf_forward(m, w_.squeeze(1))
-        outs.append(layers + [hf_head(x, lw, lb)])
-    loss = sum(torch.nn.functional.l1_loss(a, b) for a, b in zip(outs[0], outs[1]))
+    with torch.enable_grad():
+        for w_ in (est, clean):
+            o = m(w_.squeeze(1), output_hidden_states=True)
+            outs.append(list(o.hidden_states[1:]) + [hf_head(o.last_hidden_state, lw, lb)])
+        loss = sum(torch.nn.functional.l1_loss(a, b) for a, b in zip(outs[0], outs[1]))
+        (grad,) = torch.autograd.grad(loss, est)
+    est = est.detach()
     np.savez(os.path.join(GOLD, "hf_loss.npz"), estimate=est.numpy(), clean=clean.numpy(),
-             emb_w=lw.numpy(), emb_b=lb.numpy(), loss=np.float64(loss),
+             emb_w=lw.numpy(), emb_b=lb.numpy(), loss=np.float64(loss.detach()), grad=grad.numpy(),
              terms=np.array([float(torch.nn.functional.l1_loss(a, b)) for a, b in zip(outs[0], outs[1])]))
     print("loss", float(loss))
 
