@@ -140,3 +140,34 @@ def test_full_c2_batch_properties(engine):
     assert (d - d.T).abs().max().item() == 0.0
     assert d.max().item() <= 2.0 + 1e-6
     assert (m - d.mean(dim=1)).abs().max().item() < 1e-12
+
+
+def test_long_form_30s_fp32_vs_oracle(engine, sd0):
+    """Config C5's shape (30 s at 16 kHz -> T = 1499, 24 key tiles per attention row) in fp32 vs the CPU oracle."""
+    gen = torch.Generator().manual_seed(5)
+    wav = (0.1 * torch.randn(1, 480000, generator=gen)).clamp(-1, 1)
+    with torch.no_grad():
+        x, layers = O.backbone(sd0, wav)
+        ref = O.triplet_forward(sd0, wav)
+    emb, lay = engine.embed(wav.cuda(), want_layers=True)
+    assert lay.shape == (12, 1, 1499, 768)
+    assert (lay[0].cpu() - layers[0]).abs().max().item() < LAYER_TOL
+    assert (lay[11].cpu() - layers[11]).abs().max().item() < LAYER_TOL
+    assert (emb.cpu() - ref).abs().max().item() < EMB_TOL
+
+
+def test_c3_distance_stage_full_size(engine):
+    """Config C3's distance stage at full size: 10 000 degraded x 1 000 references (unit-norm embeddings)."""
+    gen = torch.Generator().manual_seed(3)
+    deg = torch.nn.functional.normalize(torch.randn(10000, 256, generator=gen), dim=1)
+    ref = torch.nn.functional.normalize(torch.randn(1000, 256, generator=gen), dim=1)
+    ref[7] = deg[123]
+    d, m = engine.pairwise(deg.cuda(), ref.cuda())
+    torch.cuda.synchronize()
+    assert d.shape == (10000, 1000) and d.dtype == torch.float64
+    assert d[123, 7].item() == 0.0
+    rows = [0, 123, 5000, 9999]
+    dref, mref = O.pairwise(deg[rows].numpy(), ref.numpy())
+    assert np.abs(d[rows].cpu().numpy() - dref).max() < 1e-13
+    assert np.abs(m[rows].cpu().numpy() - mref).max() < 1e-13
+    assert (m - d.mean(dim=1)).abs().max().item() < 1e-12   # mean of means identity over the whole matrix
