@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="clips per GPU per step")
     ap.add_argument("--refs", type=int, default=32, help="of which non-matching references")
     ap.add_argument("--seconds", type=float, default=4.0)
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+                    help="f32 = the BASELINE metric (configs[1]); bf16 = the long-form config C5 path "
+                         "(use with --seconds 30 --batch 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with hipEvents")
     args = ap.parse_args()
@@ -110,7 +113,7 @@ def main():
     ckpt = find_checkpoint()
     sd = load_checkpoint(ckpt) if ckpt else seeded_state_dict(0)
     eng = Engine(sd, local_rank)
-    scorer = ShardedScorer(eng.embed, eng.pairwise)
+    scorer = ShardedScorer(eng.embed_bf16 if args.dtype == "bf16" else eng.embed, eng.pairwise)
 
     n_samples = int(round(args.seconds * 16000))
     B, n_ref = args.batch, args.refs
@@ -152,12 +155,13 @@ def main():
         clips = world * B * args.steps
         value = clips / elapsed
         T = num_frames(n_samples)
-        flop_clip = FLOP_PER_CLIP_4S if n_samples == 64000 else None
+        flop_clip = {64000: FLOP_PER_CLIP_4S, 480000: 500.044e9}.get(n_samples)
+        peak = 2.5e15 if args.dtype == "bf16" else PEAK_FP32_MFMA
         out = {
             "metric": "clips/sec embedded + NxM NOMAD distances, 16kHz x 4s batches",
             "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic (0.1*randn waveforms, seed 1000+rank; " +
                     ("real nomad_best_model.pt" if ckpt else "seeded random-init wav2vec2-base + head weights") + ")",
             "config": {"workload": f"configs[1]: batch={B} x {n_samples} samples (T={T}) per GPU, wav2vec2-base + "
@@ -167,14 +171,23 @@ def main():
         }
         if flop_clip:
             out["model_tflops_per_gpu"] = round(value * flop_clip / world / 1e12, 2)
-            out["model_frac_of_fp32_mfma_peak"] = round(value * flop_clip / world / PEAK_FP32_MFMA, 4)
-            out["encoder_layers_frac_of_fp32_mfma_peak"] = round(value * FLOP_LAYERS_4S / world / PEAK_FP32_MFMA, 4)
+            out["model_frac_of_mfma_peak"] = round(value * flop_clip / world / peak, 4)
+            if n_samples == 64000:
+                out["encoder_layers_frac_of_mfma_peak"] = round(value * FLOP_LAYERS_4S / world / peak, 4)
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if args.dtype == "f32" and n_samples == 64000 and B == 256 and os.path.isfile(tfile):
+            # HBM-side bytes per GEMM launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
+            # same command (tools/gpu_round3.sh); fabric-side counters, Infinity-Cache hits included
+            traffic = round(json.load(open(tfile))["gemm_all_launches"]["hbm_bytes_per_launch"])
         if prof:
             gm = prof["gemm_f32_mfma"]
             ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
-            out["roofline"] = {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32), all launches",
-                               "achieved": round(ach, 2), "peak": round(PEAK_FP32_MFMA / 1e12, 1), "unit": "TFLOP/s",
-                               "frac": round(ach * 1e12 / PEAK_FP32_MFMA, 4), "traffic": None,
+            kname = ("gemm_bf16_glds_kernel (v_mfma_f32_32x32x16_bf16)" if args.dtype == "bf16"
+                     else "gemm_f32_glds_kernel (v_mfma_f32_32x32x2_f32)") + ", all launches"
+            out["roofline"] = {"bound": "mfma", "kernel": kname,
+                               "achieved": round(ach, 2), "peak": round(peak / 1e12, 1), "unit": "TFLOP/s",
+                               "frac": round(ach * 1e12 / peak, 4), "traffic": traffic,
                                "launches": gm["launches"], "avg_launch_ms": round(gm["ms"] / max(gm["launches"], 1), 4),
                                "algorithmic_gflop_per_launch": round(gm["flops"] / max(gm["launches"], 1) / 1e9, 3)}
             out["kernel_time_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in prof.items()}

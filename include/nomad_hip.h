@@ -143,6 +143,20 @@ int nomad_embed_backward(nomad_ctx* ctx, const float* wav_dev, int B, int n_samp
                          const void* saved_dev, size_t saved_bytes, const float* dlayers_dev, const float* demb_dev,
                          float* dwav_dev, void* workspace_dev, size_t workspace_bytes, nomad_stream_t stream);
 
+/* ---- bf16 path (BASELINE config C5: long-form clips) ---------------------------------------- */
+/*
+ * The reference is fp32 only (torch 1.12, no AMP); this path exists for throughput on long clips.
+ * Activations and weights are bf16 in HBM, every accumulation, bias/GELU/residual, GroupNorm/LayerNorm
+ * statistic and the attention softmax are fp32.  Accuracy is reported against this library's fp32 path.
+ *   nomad_enable_bf16          builds the bf16 weight copies once (allocates)
+ *   nomad_embed_bf16           scoring forward: wav [B][n_samples] fp32 -> emb [B][256] fp32
+ *   nomad_workspace_bytes_bf16 scratch size for it
+ */
+int nomad_enable_bf16(nomad_ctx* ctx);
+int nomad_workspace_bytes_bf16(const nomad_ctx* ctx, int B, int n_samples, size_t* bytes);
+int nomad_embed_bf16(nomad_ctx* ctx, const float* wav_dev, int B, int n_samples, float* emb_dev,
+                     void* workspace_dev, size_t workspace_bytes, nomad_stream_t stream);
+
 /* ---- measurement ------------------------------------------------------------------------- */
 /* Kernel classes for the in-library HIP-event timers. */
 enum { NOMAD_K_GEMM = 0, NOMAD_K_ATTN = 1, NOMAD_K_FRONT = 2, NOMAD_K_ROW = 3, NOMAD_K_PAIR = 4, NOMAD_K_COUNT = 5 };
@@ -161,6 +175,11 @@ int nomad_profile_read(nomad_ctx* ctx, double ms[NOMAD_K_COUNT], long long launc
 int nomad_diag_gemm(nomad_ctx* ctx, const float* A_dev, const float* W_dev, const float* bias_dev,
                     const float* R_dev, float* C_dev, int M, int N, int K, int gelu, int tile,
                     nomad_stream_t stream);
+/* The bf16 GEMM: A [M][K], W [N][K], R, C [M][N] are bf16; bias fp32.  tile: 0 = 256x128, 1 = 128x128,
+ * 2 = 128x64, 3 = 256x256, 4 = 64x64 (all BK = 64). */
+int nomad_diag_gemm_bf16(nomad_ctx* ctx, const void* A_dev, const void* W_dev, const float* bias_dev,
+                         const void* R_dev, void* C_dev, int M, int N, int K, int gelu, int tile,
+                         nomad_stream_t stream);
 /* out[M][N] = LayerNorm(in[M][N]) * gamma + beta, N in {512, 768}, eps 1e-5. */
 int nomad_diag_layernorm(nomad_ctx* ctx, const float* in_dev, const float* gamma_dev, const float* beta_dev,
                          float* out_dev, int M, int N, nomad_stream_t stream);

@@ -20,6 +20,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "dtypes.hip.h"
 #include "gemm_f32.hip.h"
 
 namespace nomad {
@@ -88,7 +89,9 @@ __device__ __forceinline__ void attn_tile(const float* __restrict__ Ks, const fl
 }
 
 // lse (nullable): [B*12][T] log-sum-exp of every score row, saved for the backward pass.
-__global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+// T_ = storage type of qkv / out (fp32 or bf16); the arithmetic is fp32 MFMA either way.
+template <typename T_ = float>
+__global__ __launch_bounds__(256) void attention_f32_kernel(const T_* __restrict__ qkv, T_* __restrict__ out,
                                                             float* __restrict__ lse, int T) {
     __shared__ __attribute__((aligned(16))) float Ks[64 * kAttnLD];
     __shared__ __attribute__((aligned(16))) float Vs[64 * kAttnLD];
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
     float4 qf[4];
 #pragma unroll
     for (int dd = 0; dd < 4; ++dd)
-        qf[dd] = *reinterpret_cast<const float4*>(qkv + base + (long long)q_ld * 2304 + dd * 16 + g * 4);
+        qf[dd] = load4<T_>(qkv + base + (long long)q_ld * 2304 + dd * 16 + g * 4);
 
     f32x4 o[4];
 #pragma unroll
@@ -122,9 +125,9 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
             const int id = tid + i * 256, row = id >> 4, c4 = id & 15;
             int key = kt * 64 + row;
             key = key < T ? key : T - 1;
-            const float* src = qkv + base + (long long)key * 2304 + c4 * 4;
-            *reinterpret_cast<float4*>(Ks + row * kAttnLD + c4 * 4) = *reinterpret_cast<const float4*>(src + 768);
-            *reinterpret_cast<float4*>(Vs + row * kAttnLD + c4 * 4) = *reinterpret_cast<const float4*>(src + 1536);
+            const T_* src = qkv + base + (long long)key * 2304 + c4 * 4;
+            *reinterpret_cast<float4*>(Ks + row * kAttnLD + c4 * 4) = load4<T_>(src + 768);
+            *reinterpret_cast<float4*>(Vs + row * kAttnLD + c4 * 4) = load4<T_>(src + 1536);
         }
         __syncthreads();
         if (!wave_active) continue;
@@ -141,12 +144,12 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
     const float inv = 1.0f / l_tot;
     if (lse && q_row < T && g == 0) lse[(long long)bh * T + q_row] = m_run + logf(l_tot);
     if (q_row < T) {
-        float* dst = out + ((long long)b * T + q_row) * 768 + h * 64 + g * 4;
+        T_* dst = out + ((long long)b * T + q_row) * 768 + h * 64 + g * 4;
 #pragma unroll
         for (int ds = 0; ds < 4; ++ds) {
             float4 r;
             r.x = o[ds][0] * inv; r.y = o[ds][1] * inv; r.z = o[ds][2] * inv; r.w = o[ds][3] * inv;
-            *reinterpret_cast<float4*>(dst + ds * 16) = r;
+            store4<T_>(dst + ds * 16, r);
         }
     }
 }

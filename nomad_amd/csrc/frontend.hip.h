@@ -13,6 +13,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "dtypes.hip.h"
 #include "gemm_f32.hip.h"
 
 namespace nomad {
@@ -91,9 +92,10 @@ __global__ __launch_bounds__(512) void gn_fold_kernel(const double* __restrict__
 // grid: (ceil(L0/FR), B), 256 threads.  Thread = (4 channels) x (frame parity); samples staged in LDS.
 // out[b][t][c] time-major, c contiguous: each frame is one 2 KB coalesced row.
 constexpr int kConv0Frames = 64;
+template <typename TOut>
 __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restrict__ wav, int n_samples, int L0,
                                                             const float* __restrict__ w0, const float* __restrict__ scale,
-                                                            const float* __restrict__ shift, float* __restrict__ out) {
+                                                            const float* __restrict__ shift, TOut* __restrict__ out) {
     __shared__ float xs[kConv0Frames * 5 + 8];
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * kConv0Frames;
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restr
         for (int j = 0; j < 10; ++j) w[q][j] = w0[c * 10 + j];
     }
     __syncthreads();
-    float* o = out + ((long long)b * L0 + t0) * 512 + cq * 4;
+    TOut* o = out + ((long long)b * L0 + t0) * 512 + cq * 4;
     for (int t = par; t < nfr; t += 2) {
         float xv[10];
 #pragma unroll
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restr
             for (int j = 0; j < 10; ++j) y = fmaf(w[q][j], xv[j], y);
             rp[q] = gelu_erf(fmaf(y, sc[q], sh[q]));
         }
-        *reinterpret_cast<float4*>(o + (long long)t * 512) = r;
+        store4<TOut>(o + (long long)t * 512, r);
     }
 }
 
@@ -135,11 +137,13 @@ __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restr
 // (128 taps x 48 channels) for output frame t is 6144 CONTIGUOUS floats starting at frame t, so the
 // grouped conv is a plain GEMM with lda = 48 < K and every byte of every fetched line is used.
 // grid: 16*B blocks of 256 threads; zeroes the two 64-frame pads of one (group, clip).
-__global__ __launch_bounds__(256) void zero_pad_rows_kernel(float* __restrict__ xg, int T) {
+template <typename T_>
+__global__ __launch_bounds__(256) void zero_pad_rows_kernel(T_* __restrict__ xg, int T) {
+    constexpr int V = 48 * sizeof(T_) / 16;  // 16-byte vectors per 48-channel frame
     float4* base = reinterpret_cast<float4*>(xg + (long long)blockIdx.x * (T + 128) * 48);
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4* tail = base + (long long)(T + 64) * 12;
-    for (int i = threadIdx.x; i < 64 * 12; i += 256) {
+    float4* tail = base + (long long)(T + 64) * V;
+    for (int i = threadIdx.x; i < 64 * V; i += 256) {
         base[i] = z;
         tail[i] = z;
     }

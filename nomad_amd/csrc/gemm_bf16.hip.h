@@ -1,0 +1,166 @@
+// bf16 MFMA GEMM / implicit-GEMM for gfx950 (config C5, long-form clips):  C = epilogue(A * W^T)
+// A, W, C, R are bf16 in HBM; accumulation, bias, GELU and the residual add are fp32.
+//
+// Same structure as gemm_f32_glds_kernel (gemm_f32.hip.h): LDS-DMA staging (global_load_lds_dwordx4),
+// unpadded [rows][128 B] LDS image with the XOR swizzle applied on the source address and again on the
+// fragment read, one barrier per K tile, XCD-aware tile order, fused epilogue.  A 128-byte LDS row now
+// holds 64 bf16 (BK = 64) and one 16-byte chunk is exactly one lane's operand of
+// v_mfma_f32_32x32x16_bf16 (lane l: row l&31, k = 8*(l>>5) + 0..7), so a ds_read_b128 per operand tile
+// feeds ONE MFMA of 32 cycles (fp32: four MFMAs of 64 cycles).  All GemmParams offsets are in elements.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "dtypes.hip.h"
+#include "gemm_f32.hip.h"
+
+namespace nomad {
+
+template <int BM, int BN, int WM, int WN>
+struct Bf16Cfg {
+    static constexpr int THREADS = WM * WN * 64;
+    static constexpr int BK = 64, KC = 8, RB = 2;  // 8 chunks of 16 B per row, 2 rows per 256-B bank row
+    static constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+    static constexpr int A_CHUNKS = BM * KC / THREADS, B_CHUNKS = BN * KC / THREADS;
+    static constexpr int LDS_BYTES = 2 * (BM + BN) * 128;
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_glds_kernel(const GemmParams p) {
+    using Cfg = Bf16Cfg<BM, BN, WM, WN>;
+    constexpr int TM = Cfg::TM, TN = Cfg::TN, NT = Cfg::THREADS, KC = Cfg::KC, RB = Cfg::RB, BK = Cfg::BK;
+    static_assert(BM * KC % NT == 0 && BN * KC % NT == 0 && TM >= 1 && TN >= 1, "bad tile");
+    extern __shared__ __attribute__((aligned(16))) char smem_b[];
+    char* As = smem_b;                   // [2][BM][128 B]
+    char* Bs = smem_b + 2 * BM * 128;    // [2][BN][128 B]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int wg = xcd_remap(blockIdx.x, nwg);
+    int tile_m, tile_n;
+    tile_coords(wg, p.tiles_m, p.tiles_n, p.group_m, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int grp = blockIdx.y;
+    const bf16_t* Ag = reinterpret_cast<const bf16_t*>(p.A) + grp * p.a_goff;
+    const bf16_t* Wg = reinterpret_cast<const bf16_t*>(p.W) + grp * p.w_goff;
+
+    const bf16_t* a_src[Cfg::A_CHUNKS];
+    const bf16_t* b_src[Cfg::B_CHUNKS];
+#pragma unroll
+    for (int i = 0; i < Cfg::A_CHUNKS; ++i) {
+        const int id = tid + i * NT, row = id / KC, pc = id - row * KC;
+        int m = m0 + row;
+        m = m < p.M ? m : p.M - 1;
+        a_src[i] = Ag + row_addr(p.amap, m) + ((pc ^ ((row / RB) % KC)) * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < Cfg::B_CHUNKS; ++i) {
+        const int id = tid + i * NT, row = id / KC, pc = id - row * KC;
+        b_src[i] = Wg + (long long)(n0 + row) * p.ldw + ((pc ^ ((row / RB) % KC)) * 8);
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = p.K / BK;
+#define NOMAD_GLDS_TILE(KT, BUF)                                                                         \
+    {                                                                                                    \
+        const int k0_ = (KT)*BK;                                                                         \
+        const int kq_ = k0_ / p.kchunk;                                                                  \
+        const long long a_koff_ = (long long)kq_ * p.kstride + (k0_ - kq_ * p.kchunk);                   \
+        char* as_ = As + (BUF)*BM * 128 + wave * 1024;                                                   \
+        char* bs_ = Bs + (BUF)*BN * 128 + wave * 1024;                                                   \
+        _Pragma("unroll") for (int i = 0; i < Cfg::A_CHUNKS; ++i)                                        \
+            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + a_koff_), (lptr_t)(as_ + i * NT * 16), 16, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < Cfg::B_CHUNKS; ++i)                                        \
+            __builtin_amdgcn_global_load_lds((gptr_t)(b_src[i] + k0_), (lptr_t)(bs_ + i * NT * 16), 16, 0, 0);     \
+    }
+
+    NOMAD_GLDS_TILE(0, 0)
+
+    const int frag_row = lane & 31, h = lane >> 5;
+    const int swz = (frag_row / RB) % KC;
+    int koff[BK / 16];  // byte offset of this lane's chunk for k-step kq
+#pragma unroll
+    for (int kq = 0; kq < BK / 16; ++kq) koff[kq] = ((kq * 2 + h) ^ swz) * 16;
+    const int a_row_off = (wm * Cfg::WTM + frag_row) * 128;
+    const int b_row_off = (wn * Cfg::WTN + frag_row) * 128;
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        __syncthreads();  // tile kt has landed (vmcnt(0)) and every wave is done with buffer cur^1
+        if (kt + 1 < nk) NOMAD_GLDS_TILE(kt + 1, cur ^ 1)
+        const char* as = As + cur * BM * 128 + a_row_off;
+        const char* bs = Bs + cur * BN * 128 + b_row_off;
+#pragma unroll
+        for (int kq = 0; kq < BK / 16; ++kq) {
+            bf16x8 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(as + i * 32 * 128 + koff[kq]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(bs + j * 32 * 128 + koff[kq]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+#undef NOMAD_GLDS_TILE
+
+    bf16_t* Cg = reinterpret_cast<bf16_t*>(p.C) + grp * p.c_goff;
+    const bf16_t* Rg = p.R ? reinterpret_cast<const bf16_t*>(p.R) + grp * p.r_goff : nullptr;
+    const float* biasg = p.bias ? p.bias + grp * p.bias_goff : nullptr;
+    const bool c_plain = p.cmap.clip_rows >= p.M, r_plain = p.rmap.clip_rows >= p.M;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * Cfg::WTN + j * 32 + (lane & 31);
+        const bool n_ok = n < p.n_valid;
+        const float bv = (biasg && n_ok) ? biasg[n] : 0.f;
+        long long c_col = n;
+        if (p.c_colblk > 0) {
+            const int blk = n / p.c_colblk;
+            c_col = (long long)blk * p.c_colblk_stride + (n - blk * p.c_colblk);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * Cfg::WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < p.M && n_ok) {
+                    float v = acc[i][j][r] + bv;
+                    if (p.gelu) v = gelu_erf(v);
+                    if (Rg) v += (float)Rg[(r_plain ? p.rmap.off + (long long)m * p.rmap.ld : row_addr(p.rmap, m)) + n];
+                    Cg[(c_plain ? p.cmap.off + (long long)m * p.cmap.ld : row_addr(p.cmap, m)) + c_col] = (bf16_t)v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+inline hipError_t launch_gemm_bf16(GemmParams p, int groups, hipStream_t s, int extra_lds = 0) {
+    using Cfg = Bf16Cfg<BM, BN, WM, WN>;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = p.N / BN;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_glds_kernel<BM, BN, WM, WN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    dim3 grid(p.tiles_m * p.tiles_n, groups);
+    hipLaunchKernelGGL((gemm_bf16_glds_kernel<BM, BN, WM, WN>), grid, dim3(Cfg::THREADS), Cfg::LDS_BYTES + extra_lds, s,
+                       p);
+    return hipGetLastError();
+}
+
+}  // namespace nomad

@@ -23,6 +23,7 @@
 #include "attention.hip.h"
 #include "backward.hip.h"
 #include "frontend.hip.h"
+#include "gemm_bf16.hip.h"
 #include "gemm_f32.hip.h"
 #include "pairwise.hip.h"
 #include "rowops.hip.h"
@@ -209,6 +210,12 @@ struct nomad_ctx {
     float* pos_wb = nullptr;      // [16][64][6144], taps flipped
     float *qkv_wT[NOMAD_NUM_LAYERS] = {}, *o_wT[NOMAD_NUM_LAYERS] = {}, *fc1_wT[NOMAD_NUM_LAYERS] = {},
           *fc2_wT[NOMAD_NUM_LAYERS] = {};
+    // bf16 weight copies for the bf16 path (built by nomad_enable_bf16); biases and norm parameters stay fp32
+    bool bf16_ready = false;
+    bf16_t* conv_w16[7] = {};
+    bf16_t *proj_w16 = nullptr, *pos_w16 = nullptr;
+    bf16_t *qkv_w16[NOMAD_NUM_LAYERS] = {}, *o_w16[NOMAD_NUM_LAYERS] = {}, *fc1_w16[NOMAD_NUM_LAYERS] = {},
+           *fc2_w16[NOMAD_NUM_LAYERS] = {};
     std::vector<void*> allocs;
     // profiling
     bool prof = false;
@@ -344,8 +351,8 @@ int run_layernorm(nomad_ctx* c, const float* in, const float* g, const float* b,
                   hipStream_t s) {
     Scope sc(c, s, NOMAD_K_ROW, 0.0);
     const int blocks = (M + 3) / 4;
-    if (N == 768) hipLaunchKernelGGL(layernorm_kernel<3>, dim3(blocks), dim3(256), 0, s, in, g, b, out, out2, M);
-    else if (N == 512) hipLaunchKernelGGL(layernorm_kernel<2>, dim3(blocks), dim3(256), 0, s, in, g, b, out, out2, M);
+    if (N == 768) hipLaunchKernelGGL((layernorm_kernel<3, float, float>), dim3(blocks), dim3(256), 0, s, in, g, b, out, out2, M);
+    else if (N == 512) hipLaunchKernelGGL((layernorm_kernel<2, float, float>), dim3(blocks), dim3(256), 0, s, in, g, b, out, out2, M);
     else return fail(NOMAD_ERR_INVALID, "layernorm: N=%d unsupported", N);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -354,7 +361,7 @@ int run_layernorm(nomad_ctx* c, const float* in, const float* g, const float* b,
 int run_attention(nomad_ctx* c, const float* qkv, float* out, float* lse, int B, int T, hipStream_t s) {
     const double flops = 4.0 * B * 12.0 * (double)T * T * 64;
     Scope sc(c, s, NOMAD_K_ATTN, flops);
-    hipLaunchKernelGGL(attention_f32_kernel, dim3((T + 63) / 64, B * 12), dim3(256), 0, s, qkv, out, lse, T);
+    hipLaunchKernelGGL(attention_f32_kernel<float>, dim3((T + 63) / 64, B * 12), dim3(256), 0, s, qkv, out, lse, T);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -541,7 +548,7 @@ static int forward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, co
     }
     {
         Scope sc(c, s, NOMAD_K_FRONT, 2.0 * B * (double)sh.L[0] * 512 * 10);
-        hipLaunchKernelGGL(conv0_gn_gelu_kernel, dim3((sh.L[0] + kConv0Frames - 1) / kConv0Frames, B), dim3(256), 0, s,
+        hipLaunchKernelGGL(conv0_gn_gelu_kernel<float>, dim3((sh.L[0] + kConv0Frames - 1) / kConv0Frames, B), dim3(256), 0, s,
                            wav, n_samples, sh.L[0], c->conv0_w, gn_scale, gn_shift, F(lay.conv[0]));
     }
     HIP_TRY(hipGetLastError());
@@ -576,7 +583,7 @@ static int forward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, co
     const RowMap pad_map{64LL * 48, (long long)(T + 128) * 48, T, 48};
     {
         Scope sc(c, s, NOMAD_K_ROW, 0.0);
-        hipLaunchKernelGGL(zero_pad_rows_kernel, dim3(16 * B), dim3(256), 0, s, xpad, T);
+        hipLaunchKernelGGL(zero_pad_rows_kernel<float>, dim3(16 * B), dim3(256), 0, s, xpad, T);
     }
     {
         GemmParams p = dense(F(lay.featln), 512, c->proj_w, c->proj_b, nullptr, xpad, M, 768, 512, 0);
@@ -643,7 +650,7 @@ static int forward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, co
     // ---- head -----------------------------------------------------------------------------------
     {
         Scope sc(c, s, NOMAD_K_ROW, 2.0 * B * 768 * 256);
-        hipLaunchKernelGGL(head_kernel, dim3(B), dim3(256), 0, s, x, T, head_w ? head_w : c->emb_w,
+        hipLaunchKernelGGL(head_kernel<float>, dim3(B), dim3(256), 0, s, x, T, head_w ? head_w : c->emb_w,
                            head_b ? head_b : c->emb_b, emb);
     }
     HIP_TRY(hipGetLastError());
@@ -669,7 +676,252 @@ static int run_ln_bwd(nomad_ctx* c, const float* x, const float* g, const float*
     return 0;
 }
 
+// ---- bf16 path (config C5) -----------------------------------------------------------------------------
+static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, int tile = -1) {
+    const double flops = 2.0 * p.M * (double)p.n_valid * p.K * groups;
+    Scope sc(c, s, NOMAD_K_GEMM, flops);
+    if (tile < 0) {
+        // measured (profiles/r01_gemm_sweep_bf16.json): 128x128 (8 waves) wins on the transformer shapes,
+        // 256x256 on the very tall conv problems
+        const long long tiles256sq = (long long)((p.M + 255) / 256) * (p.N / 256);
+        if (p.N % 128 != 0) tile = p.M < 512 ? 4 : 2;
+        else if (p.M < 512) tile = 4;
+        else tile = (p.N % 256 == 0 && tiles256sq >= 2048) ? 3 : 1;
+    }
+    hipError_t e;
+    switch (tile) {
+        case 0: e = launch_gemm_bf16<256, 128, 4, 2>(p, groups, s); break;
+        case 1: e = launch_gemm_bf16<128, 128, 4, 2>(p, groups, s); break;
+        case 2: e = launch_gemm_bf16<128, 64, 4, 2>(p, groups, s); break;
+        case 3: e = launch_gemm_bf16<256, 256, 4, 2>(p, groups, s); break;
+        case 4: e = launch_gemm_bf16<64, 64, 2, 2>(p, groups, s); break;
+        case 5: e = launch_gemm_bf16<128, 128, 2, 2>(p, groups, s); break;
+        case 6: e = launch_gemm_bf16<256, 128, 2, 2>(p, groups, s); break;
+        default: return fail(NOMAD_ERR_INVALID, "unknown bf16 gemm tile id %d", tile);
+    }
+    if (e != hipSuccess) return fail(NOMAD_ERR_HIP, "bf16 gemm launch: %s", hipGetErrorString(e));
+    return 0;
+}
+
+template <int VPT>
+static void launch_ln_bf16(const bf16_t* in, const float* g, const float* b, bf16_t* out, int M, hipStream_t s) {
+    hipLaunchKernelGGL((layernorm_kernel<VPT, bf16_t, bf16_t>), dim3((M + 3) / 4), dim3(256), 0, s, in, g, b, out,
+                       static_cast<float*>(nullptr), M);
+}
+
+struct Bf16Layout {
+    size_t stats, scale, shift, conva, convb, xpad, x, x2, y, qkv, ctxb, h, total;
+};
+
+static Bf16Layout make_bf16_layout(const Shapes& s) {
+    Bf16Layout l{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += align_up(bytes);
+        return o;
+    };
+    const size_t e = sizeof(bf16_t), M = s.M;
+    l.stats = take(sizeof(double) * kStatsPerClip * s.B);
+    l.scale = take(sizeof(float) * 512 * s.B);
+    l.shift = take(sizeof(float) * 512 * s.B);
+    l.conva = take(e * 512 * (size_t)s.B * s.L[0]);
+    l.convb = take(e * 512 * (size_t)s.B * s.L[1]);
+    l.xpad = take(e * 768 * (size_t)s.B * (s.T + 128));
+    l.x = take(e * 768 * M);
+    l.x2 = take(e * 768 * M);
+    l.y = take(e * 768 * M);
+    l.qkv = take(e * 2304 * M);
+    l.ctxb = take(e * 768 * M);
+    l.h = take(e * 3072 * M);
+    l.total = off;
+    return l;
+}
+
+// Scoring forward with bf16 activations / weights and fp32 accumulation, statistics and softmax.
+static int forward_bf16(nomad_ctx* c, const float* wav, int B, int n_samples, float* emb, void* workspace,
+                        size_t workspace_bytes, nomad_stream_t stream) {
+    Shapes sh;
+    if (!c || !wav || !emb || !workspace || B <= 0 || !make_shapes(B, n_samples, &sh))
+        return fail(NOMAD_ERR_INVALID, "nomad_embed_bf16: bad argument (B=%d, n_samples=%d)", B, n_samples);
+    if (!c->bf16_ready) return fail(NOMAD_ERR_INVALID, "nomad_embed_bf16: call nomad_enable_bf16 first");
+    const Bf16Layout lay = make_bf16_layout(sh);
+    if (workspace_bytes < lay.total)
+        return fail(NOMAD_ERR_WORKSPACE, "nomad_embed_bf16: workspace %zu < required %zu", workspace_bytes, lay.total);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    char* ws = static_cast<char*>(workspace);
+    auto H = [&](size_t off) { return reinterpret_cast<bf16_t*>(ws + off); };
+    auto asf = [](const bf16_t* p_) { return reinterpret_cast<const float*>(p_); };  // GemmParams carries typeless pointers
+    auto asfm = [](bf16_t* p_) { return reinterpret_cast<float*>(p_); };
+    const int T = sh.T, M = sh.M;
+    int rc;
+    double* stats = reinterpret_cast<double*>(ws + lay.stats);
+    float* scale = reinterpret_cast<float*>(ws + lay.scale);
+    float* shift = reinterpret_cast<float*>(ws + lay.shift);
+    bf16_t* cb[2] = {H(lay.conva), H(lay.convb)};
+    {
+        Scope sc(c, s, NOMAD_K_FRONT, 0.0);
+        hipLaunchKernelGGL(wav_stats_kernel, dim3(B), dim3(256), 0, s, wav, n_samples, sh.L[0], stats);
+        hipLaunchKernelGGL(gn_fold_kernel, dim3(B), dim3(512), 0, s, stats, c->conv0_w, c->gn_w, c->gn_b, sh.L[0], scale,
+                           shift, static_cast<float*>(nullptr), static_cast<float*>(nullptr));
+    }
+    {
+        Scope sc(c, s, NOMAD_K_FRONT, 2.0 * B * (double)sh.L[0] * 512 * 10);
+        hipLaunchKernelGGL(conv0_gn_gelu_kernel<bf16_t>, dim3((sh.L[0] + kConv0Frames - 1) / kConv0Frames, B), dim3(256), 0,
+                           s, wav, n_samples, sh.L[0], c->conv0_w, scale, shift, cb[0]);
+    }
+    for (int i = 1; i < 7; ++i) {
+        GemmParams p{};
+        p.A = asf(cb[(i - 1) % 2]);
+        p.amap = RowMap{0, (long long)sh.L[i - 1] * 512, sh.L[i], kConvS[i] * 512};
+        p.K = kConvK[i] * 512;
+        p.kchunk = p.K;
+        p.W = asf(c->conv_w16[i]);
+        p.ldw = p.K;
+        p.C = asfm(cb[i % 2]);
+        p.M = B * sh.L[i];
+        p.N = 512;
+        p.n_valid = 512;
+        p.cmap = plain_map(p.M, 512);
+        p.rmap = p.cmap;
+        p.gelu = 1;
+        if ((rc = run_gemm_bf16(c, p, 1, s))) return rc;
+    }
+    bf16_t* conv6 = cb[0];
+    bf16_t* featln = cb[1];
+    {
+        Scope sc(c, s, NOMAD_K_ROW, 0.0);
+        launch_ln_bf16<2>(conv6, c->fln_w, c->fln_b, featln, M, s);
+    }
+    bf16_t* xpad = H(lay.xpad);
+    const long long grp_stride = (long long)B * (T + 128) * 48;
+    const RowMap pad_map{64LL * 48, (long long)(T + 128) * 48, T, 48};
+    {
+        Scope sc(c, s, NOMAD_K_ROW, 0.0);
+        hipLaunchKernelGGL(zero_pad_rows_kernel<bf16_t>, dim3(16 * B), dim3(256), 0, s, xpad, T);
+    }
+    {
+        GemmParams p = dense(asf(featln), 512, asf(c->proj_w16), c->proj_b, nullptr, asfm(xpad), M, 768, 512, 0);
+        p.cmap = pad_map;
+        p.c_colblk = 48;
+        p.c_colblk_stride = grp_stride;
+        if ((rc = run_gemm_bf16(c, p, 1, s))) return rc;
+    }
+    bf16_t *x = H(lay.x), *x2 = H(lay.x2), *y = H(lay.y), *qkv = H(lay.qkv), *ctxb = H(lay.ctxb), *hb = H(lay.h);
+    {
+        GemmParams p{};
+        p.A = asf(xpad);
+        p.amap = RowMap{0, (long long)(T + 128) * 48, T, 48};
+        p.a_goff = grp_stride;
+        p.K = 6144;
+        p.kchunk = 6144;
+        p.W = asf(c->pos_w16);
+        p.ldw = 6144;
+        p.w_goff = 64LL * 6144;
+        p.bias = c->pos_b;
+        p.bias_goff = 48;
+        p.C = asfm(y);
+        p.cmap = plain_map(M, 768);
+        p.c_goff = 48;
+        p.R = asf(xpad);
+        p.rmap = pad_map;
+        p.r_goff = grp_stride;
+        p.M = M;
+        p.N = 64;
+        p.n_valid = 48;
+        p.gelu = 1;
+        if ((rc = run_gemm_bf16(c, p, 16, s))) return rc;
+    }
+    {
+        Scope sc(c, s, NOMAD_K_ROW, 0.0);
+        launch_ln_bf16<3>(y, c->eln_w, c->eln_b, x, M, s);
+    }
+    for (int l = 0; l < NOMAD_NUM_LAYERS; ++l) {
+        const LayerDev& d = c->layers[l];
+        if ((rc = run_gemm_bf16(c, dense(asf(x), 768, asf(c->qkv_w16[l]), d.qkv_b, nullptr, asfm(qkv), M, 2304, 768, 0), 1, s)))
+            return rc;
+        {
+            Scope sc(c, s, NOMAD_K_ATTN, 4.0 * B * 12.0 * (double)T * T * 64);
+            hipLaunchKernelGGL(attention_f32_kernel<bf16_t>, dim3((T + 63) / 64, B * 12), dim3(256), 0, s, qkv, ctxb,
+                               static_cast<float*>(nullptr), T);
+        }
+        if ((rc = run_gemm_bf16(c, dense(asf(ctxb), 768, asf(c->o_w16[l]), d.o_b, asf(x), asfm(y), M, 768, 768, 0), 1, s)))
+            return rc;
+        {
+            Scope sc(c, s, NOMAD_K_ROW, 0.0);
+            launch_ln_bf16<3>(y, d.ln1_w, d.ln1_b, x2, M, s);
+        }
+        if ((rc = run_gemm_bf16(c, dense(asf(x2), 768, asf(c->fc1_w16[l]), d.fc1_b, nullptr, asfm(hb), M, 3072, 768, 1), 1, s)))
+            return rc;
+        if ((rc = run_gemm_bf16(c, dense(asf(hb), 3072, asf(c->fc2_w16[l]), d.fc2_b, asf(x2), asfm(y), M, 768, 3072, 0), 1, s)))
+            return rc;
+        {
+            Scope sc(c, s, NOMAD_K_ROW, 0.0);
+            launch_ln_bf16<3>(y, d.ln2_w, d.ln2_b, x, M, s);
+        }
+    }
+    {
+        Scope sc(c, s, NOMAD_K_ROW, 2.0 * B * 768 * 256);
+        hipLaunchKernelGGL(head_kernel<bf16_t>, dim3(B), dim3(256), 0, s, x, T, c->emb_w, c->emb_b, emb);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 extern "C" {
+
+int nomad_enable_bf16(nomad_ctx* c) {
+    if (!c) return fail(NOMAD_ERR_INVALID, "null ctx");
+    if (c->bf16_ready) return 0;
+    HIP_TRY(hipSetDevice(c->device));
+    auto conv = [&](const float* src, size_t n, bf16_t** out) -> int {
+        void* d = nullptr;
+        HIP_TRY(hipMalloc(&d, n * sizeof(bf16_t)));
+        c->allocs.push_back(d);
+        *out = static_cast<bf16_t*>(d);
+        hipLaunchKernelGGL(to_bf16_kernel, dim3(1024), dim3(256), 0, 0, src, *out, (long long)(n / 4));
+        return 0;
+    };
+    int rc;
+    for (int i = 1; i < 7; ++i)
+        if ((rc = conv(c->conv_w[i], (size_t)512 * kConvK[i] * 512, &c->conv_w16[i]))) return rc;
+    if ((rc = conv(c->proj_w, (size_t)768 * 512, &c->proj_w16))) return rc;
+    if ((rc = conv(c->pos_w, (size_t)16 * 64 * 6144, &c->pos_w16))) return rc;
+    for (int l = 0; l < NOMAD_NUM_LAYERS; ++l) {
+        const LayerDev& d = c->layers[l];
+        if ((rc = conv(d.qkv_w, (size_t)2304 * 768, &c->qkv_w16[l]))) return rc;
+        if ((rc = conv(d.o_w, (size_t)768 * 768, &c->o_w16[l]))) return rc;
+        if ((rc = conv(d.fc1_w, (size_t)3072 * 768, &c->fc1_w16[l]))) return rc;
+        if ((rc = conv(d.fc2_w, (size_t)768 * 3072, &c->fc2_w16[l]))) return rc;
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    c->bf16_ready = true;
+    return 0;
+}
+
+int nomad_workspace_bytes_bf16(const nomad_ctx* c, int B, int n_samples, size_t* bytes) {
+    Shapes sh;
+    if (!c || !bytes || B <= 0 || !make_shapes(B, n_samples, &sh))
+        return fail(NOMAD_ERR_INVALID, "nomad_workspace_bytes_bf16: bad shape B=%d N=%d", B, n_samples);
+    *bytes = make_bf16_layout(sh).total;
+    return 0;
+}
+
+int nomad_embed_bf16(nomad_ctx* c, const float* wav, int B, int n_samples, float* emb, void* workspace,
+                     size_t workspace_bytes, nomad_stream_t stream) {
+    return forward_bf16(c, wav, B, n_samples, emb, workspace, workspace_bytes, stream);
+}
+
+int nomad_diag_gemm_bf16(nomad_ctx* c, const void* A, const void* W, const float* bias, const void* R, void* C, int M,
+                         int N, int K, int gelu, int tile, nomad_stream_t stream) {
+    static const int kBN[] = {128, 128, 64, 256, 64, 128, 128};
+    if (!c || !A || !W || !C || M <= 0 || tile < 0 || tile > 6) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: bad argument");
+    if (N % kBN[tile] || K % 64) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: N %% %d or K %% 64 != 0", kBN[tile]);
+    GemmParams p = dense(static_cast<const float*>(A), K, static_cast<const float*>(W), bias, static_cast<const float*>(R),
+                         static_cast<float*>(C), M, N, K, gelu);
+    return run_gemm_bf16(c, p, 1, static_cast<hipStream_t>(stream), tile);
+}
 
 int nomad_embed(nomad_ctx* c, const float* wav, int B, int n_samples, const float* head_w, const float* head_b,
                 float* emb, float* layers_out, void* workspace, size_t workspace_bytes, nomad_stream_t stream) {
@@ -820,7 +1072,7 @@ int nomad_embed_backward(nomad_ctx* c, const float* wav, int B, int n_samples, c
         const long long grp_stride = (long long)B * (T + 128) * 48;
         {
             Scope sc(c, s, NOMAD_K_ROW, 0.0);
-            hipLaunchKernelGGL(zero_pad_rows_kernel, dim3(16 * B), dim3(256), 0, s, dug, T);
+            hipLaunchKernelGGL(zero_pad_rows_kernel<float>, dim3(16 * B), dim3(256), 0, s, dug, T);
             hipLaunchKernelGGL(dgelu_to_groups_kernel, dim3(M), dim3(192), 0, s, dya, sv.upc, dug, T, grp_stride);
         }
         GemmParams p{};

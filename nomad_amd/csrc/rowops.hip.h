@@ -5,6 +5,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "dtypes.hip.h"
+
 namespace nomad {
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -20,20 +22,20 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // out[m][:] = (in[m][:] - mean) * rstd * gamma + beta; optional second copy out2 (layer_results).
 // VPT float4 per lane: N = 256 * VPT (512 -> 2, 768 -> 3).  grid: ceil(M/4) blocks of 256 threads.
-template <int VPT>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ in, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, float* __restrict__ out,
+template <int VPT, typename TIn = float, typename TOut = float>
+__global__ __launch_bounds__(256) void layernorm_kernel(const TIn* __restrict__ in, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, TOut* __restrict__ out,
                                                         float* __restrict__ out2, int M) {
     constexpr int N = 256 * VPT;
     const int lane = threadIdx.x & 63;
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
-    const float4* row = reinterpret_cast<const float4*>(in + (long long)m * N);
+    const TIn* row = in + (long long)m * N;
     float4 v[VPT];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
-        v[i] = row[lane + 64 * i];
+        v[i] = load4<TIn>(row + 4 * (lane + 64 * i));
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
     const float mean = wave_sum(s) * (1.0f / N);
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / N) + 1e-5f);
     const float4* g4 = reinterpret_cast<const float4*>(gamma);
     const float4* b4 = reinterpret_cast<const float4*>(beta);
-    float4* o = reinterpret_cast<float4*>(out + (long long)m * N);
+    TOut* o = out + (long long)m * N;
     float4* o2 = out2 ? reinterpret_cast<float4*>(out2 + (long long)m * N) : nullptr;
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
@@ -56,25 +58,26 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         r.y = (v[i].y - mean) * rstd * g.y + bb.y;
         r.z = (v[i].z - mean) * rstd * g.z + bb.z;
         r.w = (v[i].w - mean) * rstd * g.w + bb.w;
-        o[lane + 64 * i] = r;
+        store4<TOut>(o + 4 * (lane + 64 * i), r);
         if (o2) o2[lane + 64 * i] = r;
     }
 }
 
 // grid: B blocks of 256 threads.  x [B][T][768] -> emb [B][256].
-__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, int T, const float* __restrict__ w,
+template <typename TIn = float>
+__global__ __launch_bounds__(256) void head_kernel(const TIn* __restrict__ x, int T, const float* __restrict__ w,
                                                    const float* __restrict__ bias, float* __restrict__ emb) {
     __shared__ float pooled[768];
     __shared__ float e[256];
     __shared__ float wsum[4];
     const int b = blockIdx.x, tid = threadIdx.x;
-    const float* xb = x + (long long)b * T * 768;
+    const TIn* xb = x + (long long)b * T * 768;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
     for (int t = 0; t < T; ++t) {
-        const float* r = xb + (long long)t * 768;
-        s0 += r[tid];
-        s1 += r[tid + 256];
-        s2 += r[tid + 512];
+        const TIn* r = xb + (long long)t * 768;
+        s0 += (float)r[tid];
+        s1 += (float)r[tid + 256];
+        s2 += (float)r[tid + 512];
     }
     const float inv = 1.0f / (float)T;
     pooled[tid] = fmaxf(s0 * inv, 0.f);

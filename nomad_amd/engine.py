@@ -149,6 +149,30 @@ class Engine:
                                           self._stream()), "nomad_l1_loss")
         return loss[0]
 
+    # ---- bf16 path (long-form clips, config C5) -----------------------------------------------------
+    def embed_bf16(self, wav: torch.Tensor) -> torch.Tensor:
+        """Scoring forward with bf16 activations/weights (fp32 accumulation and statistics)."""
+        if wav.dim() == 3:
+            wav = wav.squeeze(1)
+        self._check_dev(wav, "wav")
+        B, N = wav.shape
+        _lib.check(self.lib.nomad_enable_bf16(self.ctx), "nomad_enable_bf16")
+        ws = self._workspace(self._size(self.lib.nomad_workspace_bytes_bf16, B, N, "nomad_workspace_bytes_bf16"))
+        emb = torch.empty(B, 256, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.nomad_embed_bf16(self.ctx, wav.data_ptr(), B, N, emb.data_ptr(), ws.data_ptr(), ws.numel(),
+                                             self._stream()), "nomad_embed_bf16")
+        return emb
+
+    def diag_gemm_bf16(self, A, W, bias=None, R=None, gelu=False, tile=0):
+        M, K = A.shape
+        N = W.shape[0]
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=self.device)
+        _lib.check(self.lib.nomad_diag_gemm_bf16(self.ctx, A.data_ptr(), W.data_ptr(),
+                                                 bias.data_ptr() if bias is not None else None,
+                                                 R.data_ptr() if R is not None else None, out.data_ptr(),
+                                                 M, N, K, int(gelu), tile, self._stream()), "nomad_diag_gemm_bf16")
+        return out
+
     # ---- training (differentiable forward) ---------------------------------------------------------
     def enable_backward(self):
         _lib.check(self.lib.nomad_enable_backward(self.ctx), "nomad_enable_backward")

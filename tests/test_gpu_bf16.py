@@ -1,0 +1,74 @@
+"""GPU: the bf16 path (BASELINE config C5) - bf16 MFMA GEMM kernel and the bf16 scoring forward, checked against
+exact integer data, a float64 reference, and this library's own fp32 path (the reference has no bf16)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF16_TILES = {0: (256, 128), 1: (128, 128), 2: (128, 64), 3: (256, 256), 4: (64, 64), 5: (128, 128), 6: (256, 128)}
+
+
+@pytest.mark.parametrize("tile", sorted(BF16_TILES))
+@pytest.mark.parametrize("M", [1, 200, 257, 1000])
+def test_gemm_bf16_exact_integer_asymmetric(engine, tile, M):
+    bm, bn = BF16_TILES[tile]
+    N, K = 2 * bn, 192
+    g = torch.Generator().manual_seed(M + tile)
+    A = torch.randint(-1, 2, (M, K), generator=g).float()
+    W = torch.randint(-1, 2, (N, K), generator=g).float()
+    W[:, ::7] = 1.0                      # break symmetry; |C| <= 192 stays exactly representable in bf16? no: use
+    ref = (A.double() @ W.double().T)    # values up to 192 need 8 bits: exact in bf16 (8-bit significand) up to 256
+    out = engine.diag_gemm_bf16(A.bfloat16().cuda(), W.bfloat16().cuda(), tile=tile).float().cpu()
+    assert torch.equal(out.double(), ref)
+
+
+@pytest.mark.parametrize("tile,M,N,K", [(0, 1500, 256, 768), (1, 700, 768, 3072), (2, 260, 64, 6144), (4, 84, 768, 512),
+                                        (3, 600, 512, 1536)])
+@pytest.mark.parametrize("epi", ["none", "bias_gelu", "bias_res"])
+def test_gemm_bf16_epilogues(engine, tile, M, N, K, epi):
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(M, K, generator=g).bfloat16()
+    W = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16()
+    bias = torch.randn(N, generator=g) if "bias" in epi else None
+    R = torch.randn(M, N, generator=g).bfloat16() if "res" in epi else None
+    ref = A.double() @ W.double().T
+    if bias is not None:
+        ref = ref + bias.double()
+    if "gelu" in epi:
+        ref = F.gelu(ref)
+    if R is not None:
+        ref = ref + R.double()
+    out = engine.diag_gemm_bf16(A.cuda(), W.cuda(), bias.cuda() if bias is not None else None,
+                                R.cuda() if R is not None else None, gelu="gelu" in epi, tile=tile).cpu()
+    err = (out.double() - ref).abs().max().item()
+    assert err < 2 ** -7 * max(1.0, ref.abs().max().item()), err      # one bf16 rounding of the output
+
+
+def test_embed_bf16_vs_fp32_path(engine):
+    gen = torch.Generator().manual_seed(0)
+    wav = (0.1 * torch.randn(8, 64000, generator=gen)).clamp(-1, 1).cuda()
+    e32 = engine.embed(wav)
+    e16 = engine.embed_bf16(wav)
+    torch.cuda.synchronize()
+    assert torch.isfinite(e16).all()
+    assert (e16.norm(dim=1) - 1).abs().max().item() < 1e-5
+    err = (e16 - e32).abs().max().item()
+    cos = F.cosine_similarity(e16, e32, dim=1).min().item()
+    d32, m32 = engine.pairwise(e32[:6].contiguous(), e32[6:].contiguous())
+    d16, m16 = engine.pairwise(e16[:6].contiguous(), e16[6:].contiguous())
+    serr = (d16 - d32).abs().max().item()
+    print(f"bf16 vs fp32: embedding max|err| {err:.3e}, min cosine {cos:.6f}, score max|err| {serr:.3e}")
+    assert err < 2e-2 and cos > 0.999 and serr < 5e-2
+
+
+def test_embed_bf16_long_form(engine):
+    """Config C5's shape: 30 s clips (T = 1499)."""
+    gen = torch.Generator().manual_seed(1)
+    wav = (0.1 * torch.randn(2, 480000, generator=gen)).clamp(-1, 1).cuda()
+    e32 = engine.embed(wav)
+    e16 = engine.embed_bf16(wav)
+    assert torch.isfinite(e16).all()
+    assert F.cosine_similarity(e16, e32, dim=1).min().item() > 0.999
+    one = engine.embed_bf16(wav[1:2].contiguous())
+    assert torch.equal(one[0], e16[1])      # batch invariance holds in bf16 too

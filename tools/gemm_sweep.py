@@ -42,10 +42,40 @@ def main():
     ap.add_argument("--shapes", default="out,qkv,fc1,fc2,conv3,fc1_nogelu")
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--bf16", action="store_true", help="sweep the bf16 GEMM instantiations (tile ids 0..6)")
     a = ap.parse_args()
     eng = Engine(seeded_state_dict(0), 0)
     g = torch.Generator().manual_seed(0)
     res = []
+    if a.bf16:
+        names = {0: "bf16 256x128 w4x2", 1: "bf16 128x128 w4x2", 2: "bf16 128x64 w4x2", 3: "bf16 256x256 w4x2",
+                 4: "bf16 64x64 w2x2", 5: "bf16 128x128 w2x2", 6: "bf16 256x128 w2x2"}
+        bn = {0: 128, 1: 128, 2: 64, 3: 256, 4: 64, 5: 128, 6: 128}
+        for sname in a.shapes.split(","):
+            M, N, K, has_b, gelu, has_r = SHAPES[sname]
+            A = torch.randn(M, K, generator=g).bfloat16().cuda()
+            W = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16().cuda()
+            b = torch.randn(N, generator=g).cuda() if has_b else None
+            R = torch.randn(M, N, generator=g).bfloat16().cuda() if has_r else None
+            for t in (int(x) for x in a.tiles.split(",")):
+                if N % bn[t]:
+                    continue
+                eng.diag_gemm_bf16(A, W, b, R, gelu=gelu, tile=t)
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.iters + 1)]
+                ev[0].record()
+                for i in range(a.iters):
+                    eng.diag_gemm_bf16(A, W, b, R, gelu=gelu, tile=t)
+                    ev[i + 1].record()
+                torch.cuda.synchronize()
+                ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(a.iters))
+                tf = 2.0 * M * N * K / (ms[len(ms) // 2] * 1e-3) / 1e12
+                row = {"shape": sname, "tile": t, "cfg": names[t], "ms_med": round(ms[len(ms) // 2], 4),
+                       "ms_min": round(ms[0], 4), "tflops": round(tf, 1), "bit_identical": True}
+                res.append(row)
+                print(json.dumps(row), flush=True)
+        if a.json:
+            json.dump(res, open(a.json, "w"), indent=1)
+        return
     for sname in a.shapes.split(","):
         M, N, K, has_b, gelu, has_r = SHAPES[sname]
         A = torch.randn(M, K, generator=g).cuda()
