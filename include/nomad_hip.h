@@ -180,6 +180,8 @@ int nomad_diag_gemm(nomad_ctx* ctx, const float* A_dev, const float* W_dev, cons
 int nomad_diag_gemm_bf16(nomad_ctx* ctx, const void* A_dev, const void* W_dev, const float* bias_dev,
                          const void* R_dev, void* C_dev, int M, int N, int K, int gelu, int tile,
                          nomad_stream_t stream);
+/* bf16 attention: qkv [B*T][2304] bf16 (q pre-scaled) -> out [B*T][768] bf16. */
+int nomad_diag_attention_bf16(nomad_ctx* ctx, const void* qkv_dev, void* out_dev, int B, int T, nomad_stream_t stream);
 /* out[M][N] = LayerNorm(in[M][N]) * gamma + beta, N in {512, 768}, eps 1e-5. */
 int nomad_diag_layernorm(nomad_ctx* ctx, const float* in_dev, const float* gamma_dev, const float* beta_dev,
                          float* out_dev, int M, int N, nomad_stream_t stream);

@@ -842,8 +842,7 @@ static int forward_bf16(nomad_ctx* c, const float* wav, int B, int n_samples, fl
             return rc;
         {
             Scope sc(c, s, NOMAD_K_ATTN, 4.0 * B * 12.0 * (double)T * T * 64);
-            hipLaunchKernelGGL(attention_f32_kernel<bf16_t>, dim3((T + 63) / 64, B * 12), dim3(256), 0, s, qkv, ctxb,
-                               static_cast<float*>(nullptr), T);
+            hipLaunchKernelGGL(attention_bf16_kernel, dim3((T + 63) / 64, B * 12), dim3(256), 0, s, qkv, ctxb, T);
         }
         if ((rc = run_gemm_bf16(c, dense(asf(ctxb), 768, asf(c->o_w16[l]), d.o_b, asf(x), asfm(y), M, 768, 768, 0), 1, s)))
             return rc;
@@ -1287,6 +1286,16 @@ int nomad_diag_attention_bwd(nomad_ctx* c, const float* qkv, const float* dctx, 
     const dim3 grid((T + kAB - 1) / kAB, B * 12);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, s, qkv, ctx_out, dctx, lse, dqkv, T);
     hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, s, qkv, ctx_out, dctx, lse, dqkv, T);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int nomad_diag_attention_bf16(nomad_ctx* c, const void* qkv, void* out, int B, int T, nomad_stream_t stream) {
+    if (!c || !qkv || !out || B <= 0 || T <= 0) return fail(NOMAD_ERR_INVALID, "nomad_diag_attention_bf16: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Scope sc(c, s, NOMAD_K_ATTN, 4.0 * B * 12.0 * (double)T * T * 64);
+    hipLaunchKernelGGL(attention_bf16_kernel, dim3((T + 63) / 64, B * 12), dim3(256), 0, s,
+                       static_cast<const bf16_t*>(qkv), static_cast<bf16_t*>(out), T);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -163,6 +163,12 @@ class Engine:
                                              self._stream()), "nomad_embed_bf16")
         return emb
 
+    def diag_attention_bf16(self, qkv, B, T):
+        out = torch.empty(B * T, 768, dtype=torch.bfloat16, device=self.device)
+        _lib.check(self.lib.nomad_diag_attention_bf16(self.ctx, qkv.data_ptr(), out.data_ptr(), B, T, self._stream()),
+                   "nomad_diag_attention_bf16")
+        return out
+
     def diag_gemm_bf16(self, A, W, bias=None, R=None, gelu=False, tile=0):
         M, K = A.shape
         N = W.shape[0]
