@@ -343,7 +343,11 @@ GemmParams dense(const float* A, int lda, const float* W, const float* bias, con
 int pick_tile(int M, int N, int K) {
     if (M < 1024) return 2;
     const long long tiles256 = (long long)((M + 255) / 256) * (N / 128);
-    if (N % 128 == 0 && (tiles256 >= 2048 || K >= 2048 || K <= 512)) return 21;
+    if (N % 128 == 0 && tiles256 >= 2048) return 21;
+    // N = 768 / 512 problems of the full batch (about 1200 tiles): the 256x128 kernel still wins for the long-K
+    // (fc2) and short-K (proj) cases; below one round of tiles (small batches, config C4) the finer 128x64
+    // tiles keep more CUs busy (profiles/r01_gemm_sweep_small_m.json).
+    if (N % 128 == 0 && tiles256 >= 512 && (K >= 2048 || K <= 512)) return 21;
     return 29;
 }
 

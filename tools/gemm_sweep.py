@@ -21,6 +21,13 @@ SHAPES = {  # name: (M, N, K, bias, gelu, residual)
     "conv5": (102144, 512, 1024, False, True, False),
     "fc1_nogelu": (50944, 3072, 768, True, False, False),
     "proj": (50944, 768, 512, True, False, False),
+    # quantisation probes for the 256x128 kernel at 2 workgroups/CU (512 slots): 9.0, 9.33 and 9.98 rounds
+    "fc1_9r": (49152, 3072, 768, True, True, False),
+    "fc1_10r": (54528, 3072, 768, True, True, False),
+    "c4_qkv": (1600, 2304, 768, True, False, False),
+    "c4_fc1": (1600, 3072, 768, True, True, False),
+    "c4_fc2": (1600, 768, 3072, True, False, True),
+    "c4_out": (1600, 768, 768, True, False, True),
 }
 TILE_NAMES = {0: "128x128x32 w2x2", 1: "128x64x16 w2x2", 2: "64x64x32 w2x2", 3: "128x128x16 w2x2",
               4: "256x128x32 w4x2", 5: "256x256x32 w4x2", 6: "256x128x16 w4x2", 7: "128x256x32 w2x2",
