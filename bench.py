@@ -103,11 +103,12 @@ def main():
                          f"--nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: nomad_amd has no CPU path")
-    if rank == 0:
-        build.build_library()
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if rank == 0:
+        build.build_library()  # no-op when the in-tree .so is up to date; other ranks wait before dlopen
+    if world > 1:
         dist.barrier()
 
     ckpt = find_checkpoint()

@@ -9,7 +9,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnomad_hip.so")
 SOURCES = ["nomad_hip.hip"]
-HEADERS = ["gemm_f32.hip.h", "frontend.hip.h", "rowops.hip.h", "attention.hip.h", "pairwise.hip.h",
+HEADERS = ["gemm_f32.hip.h", "gemm_bf16.hip.h", "dtypes.hip.h", "backward.hip.h", "frontend.hip.h", "rowops.hip.h",
+           "attention.hip.h", "pairwise.hip.h",
            os.path.join("..", "..", "include", "nomad_hip.h")]
 
 
@@ -31,13 +32,17 @@ def needs_build() -> bool:
 def build_library(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
+    tmp = LIB + f".tmp{os.getpid()}"
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Wall", "-Wno-unused-function", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-Wall", "-Wno-unused-function", "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
         raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    os.replace(tmp, LIB)  # atomic: a concurrent dlopen never sees a half-written library
     if verbose:
         print(res.stderr)
     return LIB
