@@ -295,11 +295,14 @@ struct GldsCfg {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int BM, int BN, int BK, int WM, int WN>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_f32_glds_kernel(const GemmParams p) {
+// MINW: second __launch_bounds__ argument (minimum waves per SIMD the register allocation must allow).
+// EARLY: issue the first fragment reads of a K tile before the LDS-DMA of the next tile (hides the DMA's
+// address arithmetic under the LDS read latency).
+template <int BM, int BN, int BK, int WM, int WN, int MINW = 1, bool EARLY = false>
+__global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_f32_glds_kernel(const GemmParams p) {
     using Cfg = GldsCfg<BM, BN, BK, WM, WN>;
     constexpr int TM = Cfg::TM, TN = Cfg::TN, NT = Cfg::THREADS, KC = Cfg::KC, RB = Cfg::RB;
-    static_assert(BK == 16 || BK == 32, "swizzle is written for 64-B and 128-B rows");
+    static_assert(BK == 8 || BK == 16 || BK == 32, "swizzle is written for 32-, 64- and 128-B rows");
     static_assert(BM * KC % NT == 0 && BN * KC % NT == 0 && TM >= 1 && TN >= 1, "bad tile");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                 // [2][BM][BK]
@@ -370,16 +373,31 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_glds_kernel(const GemmPa
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         __syncthreads();  // tile kt has landed (vmcnt(0)) and every wave is done with buffer cur^1
-        if (kt + 1 < nk) NOMAD_GLDS_TILE(kt + 1, cur ^ 1)
         const float* as = As + cur * BM * BK + a_row_off;
         const float* bs = Bs + cur * BN * BK + b_row_off;
+        f32x4 af0[TM], bf0[TN];
+        if (EARLY) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af0[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * BK + koff[0]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf0[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * BK + koff[0]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (kt + 1 < nk) NOMAD_GLDS_TILE(kt + 1, cur ^ 1)
 #pragma unroll
         for (int kq = 0; kq < BK / 8; ++kq) {
             f32x4 af[TM], bf[TN];
+            if (EARLY && kq == 0) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * BK + koff[kq]);
+                for (int i = 0; i < TM; ++i) af[i] = af0[i];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * BK + koff[kq]);
+                for (int j = 0; j < TN; ++j) bf[j] = bf0[j];
+            } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * BK + koff[kq]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * BK + koff[kq]);
+            }
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -424,21 +442,21 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_glds_kernel(const GemmPa
     }
 }
 
-template <int BM, int BN, int BK, int WM, int WN>
+template <int BM, int BN, int BK, int WM, int WN, int MINW = 1, bool EARLY = false>
 inline hipError_t launch_gemm_glds(GemmParams p, int groups, hipStream_t s, int extra_lds = 0) {
     using Cfg = GldsCfg<BM, BN, BK, WM, WN>;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = p.N / BN;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_glds_kernel<BM, BN, BK, WM, WN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_glds_kernel<BM, BN, BK, WM, WN, MINW, EARLY>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     dim3 grid(p.tiles_m * p.tiles_n, groups);
-    hipLaunchKernelGGL((gemm_f32_glds_kernel<BM, BN, BK, WM, WN>), grid, dim3(Cfg::THREADS), Cfg::LDS_BYTES + extra_lds,
-                       s, p);
+    hipLaunchKernelGGL((gemm_f32_glds_kernel<BM, BN, BK, WM, WN, MINW, EARLY>), grid, dim3(Cfg::THREADS),
+                       Cfg::LDS_BYTES + extra_lds, s, p);
     return hipGetLastError();
 }
 

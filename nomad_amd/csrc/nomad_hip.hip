@@ -301,6 +301,8 @@ int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, in
         case 29: e = launch_gemm_glds<128, 64, 32, 4, 2>(p, groups, s, occ_pad(occ, GldsCfg<128, 64, 32, 4, 2>::LDS_BYTES)); break;
         case 30: e = launch_gemm_glds<128, 64, 32, 2, 2>(p, groups, s, occ_pad(occ, GldsCfg<128, 64, 32, 2, 2>::LDS_BYTES)); break;
         case 31: e = launch_gemm_glds<128, 128, 32, 4, 2>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 4, 2>::LDS_BYTES)); break;
+        case 33: e = launch_gemm_glds<256, 128, 16, 4, 2, 1, true>(p, groups, s, occ_pad(occ, GldsCfg<256, 128, 16, 4, 2>::LDS_BYTES)); break;
+        case 35: e = launch_gemm_glds<128, 64, 32, 4, 2, 1, true>(p, groups, s, occ_pad(occ, GldsCfg<128, 64, 32, 4, 2>::LDS_BYTES)); break;
         case 14: e = launch_gemm<128, 128, 32, 2, 2, 1>(p, groups, s); break;            // ablations of tile 0
         case 15: e = launch_gemm<128, 128, 32, 2, 2, 2>(p, groups, s); break;
         case 16: e = launch_gemm<128, 128, 32, 2, 2, 3>(p, groups, s); break;
@@ -1256,10 +1258,10 @@ int nomad_diag_gemm(nomad_ctx* c, const float* A, const float* W, const float* b
     const int group_m = (tile % 10000) / 100;
     tile %= 100;
     static const int kBN[] = {128, 64, 64, 128, 128, 256, 128, 256, 256, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128,
-                              128, 128, 128, 128, 256, 256, 128, 256, 64, 64, 64, 128};
+                              128, 128, 128, 128, 256, 256, 128, 256, 64, 64, 64, 128, 128, 128, 128, 64, 128};
     static const int kBK[] = {32, 16, 32, 16, 32, 32, 16, 32, 16, 16, 16, 32, 32, 16, 32, 32, 32, 16, 16, 16,
-                              32, 16, 16, 32, 16, 32, 16, 16, 16, 32, 32, 32};
-    if (tile < 0 || tile > 31) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile id %d", tile);
+                              32, 16, 16, 32, 16, 32, 16, 16, 16, 32, 32, 32, 16, 16, 16, 32, 8};
+    if (tile < 0 || tile > 35) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile id %d", tile);
     const int bn = kBN[tile], bk = kBK[tile];
     if (N % bn || K % bk) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: N %% %d or K %% %d != 0", bn, bk);
     GemmParams p = dense(A, K, W, bias, R, C, M, N, K, gelu);
