@@ -64,6 +64,8 @@ class Engine:
         del keep
         self.ctx = handle
         self._ws: Optional[torch.Tensor] = None
+        self._ws_side: Optional[torch.Tensor] = None   # second workspace for a concurrent forward on a side stream
+        self._side_stream: Optional[torch.cuda.Stream] = None
         self._l1_scratch: Optional[torch.Tensor] = None
 
     def close(self):
@@ -86,11 +88,21 @@ class Engine:
         _lib.check(self.lib.nomad_workspace_bytes(self.ctx, B, n_samples, C.byref(n)), "nomad_workspace_bytes")
         return n.value
 
-    def _workspace(self, nbytes: int) -> torch.Tensor:
+    def _workspace(self, nbytes: int, side: bool = False) -> torch.Tensor:
+        if side:
+            if self._ws_side is None or self._ws_side.numel() < nbytes:
+                self._ws_side = None
+                self._ws_side = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            return self._ws_side
         if self._ws is None or self._ws.numel() < nbytes:
             self._ws = None
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         return self._ws
+
+    def side_stream(self) -> "torch.cuda.Stream":
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=self.device)
+        return self._side_stream
 
     def _check_dev(self, t: torch.Tensor, name: str):
         if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
@@ -98,8 +110,10 @@ class Engine:
 
     # ---- hot path ------------------------------------------------------------------------------
     def embed(self, wav: torch.Tensor, head: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
-              want_layers: bool = False):
-        """wav (B,N) or (B,1,N) fp32 on the GPU -> emb (B,256) [, layers (12,B,T,768)]."""
+              want_layers: bool = False, side: bool = False):
+        """wav (B,N) or (B,1,N) fp32 on the GPU -> emb (B,256) [, layers (12,B,T,768)].
+        side=True uses a second workspace so the call may run concurrently with another forward on a
+        different stream (the launch stream is always torch's current stream)."""
         if wav.dim() == 3:
             wav = wav.squeeze(1)
         self._check_dev(wav, "wav")
@@ -115,7 +129,7 @@ class Engine:
             self._check_dev(hw, "head weight")
             self._check_dev(hb, "head bias")
         nbytes = self.workspace_bytes(B, N)
-        ws = self._workspace(nbytes)
+        ws = self._workspace(nbytes, side)
         _lib.check(self.lib.nomad_embed(self.ctx, wav.data_ptr(), B, N,
                                         hw.data_ptr() if hw is not None else None,
                                         hb.data_ptr() if hb is not None else None,

@@ -129,12 +129,21 @@ class _NomadLossFn(torch.autograd.Function):
         est = estimate.detach().to(eng.device, torch.float32).contiguous()
         cln = clean.detach().to(eng.device, torch.float32).contiguous()
         need_grad = estimate.requires_grad
+        # the two forwards are independent: at training batch sizes (32 x 1 s) one of them fills less than half
+        # of the chip, so the clean branch runs concurrently on a side stream with its own workspace
+        cur = torch.cuda.current_stream(eng.device)
+        side = eng.side_stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            c_emb, c_layers = eng.embed(cln, head=head, want_layers=True, side=True)
         if need_grad:
             e_emb, e_layers, saved = eng.embed_train(est, head)
         else:
             e_emb, e_layers = eng.embed(est, head=head, want_layers=True)
             saved = None
-        c_emb, c_layers = eng.embed(cln, head=head, want_layers=True)
+        cur.wait_stream(side)
+        for t in (c_emb, c_layers, cln):
+            t.record_stream(cur)
         loss = eng.l1_loss(e_layers, c_layers, e_emb, c_emb)
         if need_grad:
             ctx.nomad = nomad
