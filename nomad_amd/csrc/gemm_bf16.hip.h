@@ -21,10 +21,13 @@ struct Bf16Cfg {
     static constexpr int BK = 64, KC = 8, RB = 2;  // 8 chunks of 16 B per row, 2 rows per 256-B bank row
     static constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
     static constexpr int A_CHUNKS = BM * KC / THREADS, B_CHUNKS = BN * KC / THREADS;
-    static constexpr int LDS_BYTES = 2 * (BM + BN) * 128;
+    static constexpr int STAGE_BYTES = 2 * (BM + BN) * 128;
+    static constexpr int EPI_BYTES = WM * WN * 32 * (WTN + 4) * 4;  // one 32-row fp32 slab per wave
+    static constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
 };
 
-template <int BM, int BN, int WM, int WN>
+// ABL (timing-only ablations, wrong results): 1 = no epilogue stores, 2 = no K loop (prologue + epilogue only).
+template <int BM, int BN, int WM, int WN, int ABL = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_glds_kernel(const GemmParams p) {
     using Cfg = Bf16Cfg<BM, BN, WM, WN>;
     constexpr int TM = Cfg::TM, TN = Cfg::TN, NT = Cfg::THREADS, KC = Cfg::KC, RB = Cfg::RB, BK = Cfg::BK;
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_glds_kernel(const GemmP
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = p.K / BK;
+    const int nk = ABL == 2 ? 1 : p.K / BK;
 #define NOMAD_GLDS_TILE(KT, BUF)                                                                         \
     {                                                                                                    \
         const int k0_ = (KT)*BK;                                                                         \
@@ -115,50 +118,81 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_glds_kernel(const GemmP
     }
 #undef NOMAD_GLDS_TILE
 
+    // Epilogue through LDS.  An MFMA accumulator holds one column per lane, so storing it directly means 2-byte
+    // scattered stores (measured: 45 % of the whole kernel).  Instead each wave parks a 32-row slab of its tile
+    // in LDS as fp32 (bias and GELU applied on the way), then every lane picks up 8 consecutive columns of one
+    // row, adds the residual from a 16-byte load and writes one 16-byte bf16 vector: full 128-byte segments.
     bf16_t* Cg = reinterpret_cast<bf16_t*>(p.C) + grp * p.c_goff;
     const bf16_t* Rg = p.R ? reinterpret_cast<const bf16_t*>(p.R) + grp * p.r_goff : nullptr;
     const float* biasg = p.bias ? p.bias + grp * p.bias_goff : nullptr;
     const bool c_plain = p.cmap.clip_rows >= p.M, r_plain = p.rmap.clip_rows >= p.M;
+    constexpr int ELD = Cfg::WTN + 4;            // floats per slab row (16-byte pad against bank conflicts)
+    constexpr int CG = Cfg::WTN / 8;             // 8-column groups per row
+    float* slab = reinterpret_cast<float*>(smem_b) + wave * (32 * ELD);
+    float bv[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * Cfg::WTN + j * 32 + (lane & 31);
-        const bool n_ok = n < p.n_valid;
-        const float bv = (biasg && n_ok) ? biasg[n] : 0.f;
-        long long c_col = n;
-        if (p.c_colblk > 0) {
-            const int blk = n / p.c_colblk;
-            c_col = (long long)blk * p.c_colblk_stride + (n - blk * p.c_colblk);
-        }
+        bv[j] = (biasg && n < p.n_valid) ? biasg[n] : 0.f;
+    }
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TM; ++i) {
+        __syncthreads();  // main loop (or the previous slab) is done with this LDS
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * Cfg::WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m < p.M && n_ok) {
-                    float v = acc[i][j][r] + bv;
-                    if (p.gelu) v = gelu_erf(v);
-                    if (Rg) v += (float)Rg[(r_plain ? p.rmap.off + (long long)m * p.rmap.ld : row_addr(p.rmap, m)) + n];
-                    Cg[(c_plain ? p.cmap.off + (long long)m * p.cmap.ld : row_addr(p.cmap, m)) + c_col] = (bf16_t)v;
+                float v = acc[i][j][r] + bv[j];
+                if (p.gelu) v = gelu_erf(v);
+                slab[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * ELD + j * 32 + (lane & 31)] = v;
+            }
+        __syncthreads();
+        if (ABL != 1) {
+#pragma unroll
+            for (int it = 0; it < 32 * CG / 64; ++it) {
+                const int id = lane + 64 * it, row = id / CG, cg = id - row * CG;
+                const int m = m0 + wm * Cfg::WTM + i * 32 + row;
+                const int n = n0 + wn * Cfg::WTN + cg * 8;
+                if (m < p.M && n < p.n_valid) {
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(slab + row * ELD + cg * 8);
+                    const f32x4 hi = *reinterpret_cast<const f32x4*>(slab + row * ELD + cg * 8 + 4);
+                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    if (Rg) {
+                        const bf16x8 rv = *reinterpret_cast<const bf16x8*>(
+                            Rg + (r_plain ? p.rmap.off + (long long)m * p.rmap.ld : row_addr(p.rmap, m)) + n);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+                    }
+                    long long c_col = n;
+                    if (p.c_colblk > 0) {
+                        const int blk = n / p.c_colblk;
+                        c_col = (long long)blk * p.c_colblk_stride + (n - blk * p.c_colblk);
+                    }
+                    bf16x8 ov;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ov[e] = (bf16_t)v[e];
+                    *reinterpret_cast<bf16x8*>(
+                        Cg + (c_plain ? p.cmap.off + (long long)m * p.cmap.ld : row_addr(p.cmap, m)) + c_col) = ov;
                 }
             }
         }
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int ABL = 0>
 inline hipError_t launch_gemm_bf16(GemmParams p, int groups, hipStream_t s, int extra_lds = 0) {
     using Cfg = Bf16Cfg<BM, BN, WM, WN>;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = p.N / BN;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_glds_kernel<BM, BN, WM, WN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_glds_kernel<BM, BN, WM, WN, ABL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     dim3 grid(p.tiles_m * p.tiles_n, groups);
-    hipLaunchKernelGGL((gemm_bf16_glds_kernel<BM, BN, WM, WN>), grid, dim3(Cfg::THREADS), Cfg::LDS_BYTES + extra_lds, s,
+    hipLaunchKernelGGL((gemm_bf16_glds_kernel<BM, BN, WM, WN, ABL>), grid, dim3(Cfg::THREADS), Cfg::LDS_BYTES + extra_lds, s,
                        p);
     return hipGetLastError();
 }

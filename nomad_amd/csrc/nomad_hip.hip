@@ -687,12 +687,11 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
     const double flops = 2.0 * p.M * (double)p.n_valid * p.K * groups;
     Scope sc(c, s, NOMAD_K_GEMM, flops);
     if (tile < 0) {
-        // measured (profiles/r01_gemm_sweep_bf16.json): 128x128 (8 waves) wins on the transformer shapes,
-        // 256x256 on the very tall conv problems
-        const long long tiles256sq = (long long)((p.M + 255) / 256) * (p.N / 256);
+        // measured (profiles/r01_gemm_sweep_bf16.json): 256x256 tiles (wave tile 64x128) win on wide (N >= 1024)
+        // and very tall problems, 128x128 (8 waves) on the N = 768 / 512 transformer shapes
         if (p.N % 128 != 0) tile = p.M < 512 ? 4 : 2;
         else if (p.M < 512) tile = 4;
-        else tile = (p.N % 256 == 0 && tiles256sq >= 2048) ? 3 : 1;
+        else tile = (p.N % 256 == 0 && (p.N >= 1024 || p.M >= 100000)) ? 3 : 1;
     }
     hipError_t e;
     switch (tile) {
@@ -703,6 +702,8 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
         case 4: e = launch_gemm_bf16<64, 64, 2, 2>(p, groups, s); break;
         case 5: e = launch_gemm_bf16<128, 128, 2, 2>(p, groups, s); break;
         case 6: e = launch_gemm_bf16<256, 128, 2, 2>(p, groups, s); break;
+        case 7: e = launch_gemm_bf16<128, 128, 4, 2, 1>(p, groups, s); break;   // ablation: no epilogue stores
+        case 8: e = launch_gemm_bf16<128, 128, 4, 2, 2>(p, groups, s); break;   // ablation: one K tile only
         default: return fail(NOMAD_ERR_INVALID, "unknown bf16 gemm tile id %d", tile);
     }
     if (e != hipSuccess) return fail(NOMAD_ERR_HIP, "bf16 gemm launch: %s", hipGetErrorString(e));
@@ -920,8 +921,8 @@ int nomad_embed_bf16(nomad_ctx* c, const float* wav, int B, int n_samples, float
 
 int nomad_diag_gemm_bf16(nomad_ctx* c, const void* A, const void* W, const float* bias, const void* R, void* C, int M,
                          int N, int K, int gelu, int tile, nomad_stream_t stream) {
-    static const int kBN[] = {128, 128, 64, 256, 64, 128, 128};
-    if (!c || !A || !W || !C || M <= 0 || tile < 0 || tile > 6) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: bad argument");
+    static const int kBN[] = {128, 128, 64, 256, 64, 128, 128, 128, 128};
+    if (!c || !A || !W || !C || M <= 0 || tile < 0 || tile > 8) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: bad argument");
     if (N % kBN[tile] || K % 64) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: N %% %d or K %% 64 != 0", kBN[tile]);
     GemmParams p = dense(static_cast<const float*>(A), K, static_cast<const float*>(W), bias, static_cast<const float*>(R),
                          static_cast<float*>(C), M, N, K, gelu);
