@@ -97,6 +97,17 @@ int nomad_embed(nomad_ctx* ctx, const float* wav_dev, int B, int n_samples,
                 void* workspace_dev, size_t workspace_bytes, nomad_stream_t stream);
 
 /*
+ * Embed B clips of DIFFERENT lengths in one launch sequence, with no padding in the arithmetic (the
+ * reference's per-file loop, nomad.py:171-183, batched): results are bit-identical to per-clip nomad_embed
+ * calls.  wav_dev is [B][stride] fp32 with clip b occupying the first lengths_host[b] samples of its row
+ * (the rest of the row is never read); lengths_host is a HOST array.
+ */
+int nomad_workspace_bytes_ragged(const nomad_ctx* ctx, int B, const int* lengths_host, size_t* bytes);
+int nomad_embed_ragged(nomad_ctx* ctx, const float* wav_dev, int B, int stride, const int* lengths_host,
+                       const float* head_w_dev, const float* head_b_dev, float* emb_dev,
+                       void* workspace_dev, size_t workspace_bytes, nomad_stream_t stream);
+
+/*
  * Euclidean distance matrix + row means, computed in float64 in the difference form
  * sqrt(sum_k (a_k - b_k)^2) like scipy's cdist on float32 inputs promoted to double.
  *   deg_dev [Nd][256] fp32, ref_dev [Nr][256] fp32

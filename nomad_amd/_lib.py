@@ -33,6 +33,9 @@ SIGNATURES = {
     "nomad_num_frames": (C.c_int, [C.c_int]),
     "nomad_workspace_bytes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     "nomad_embed": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_size_t, _fp]),
+    "nomad_workspace_bytes_ragged": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
+    "nomad_embed_ragged": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int, C.POINTER(C.c_int), _fp, _fp, _fp, _fp,
+                                     C.c_size_t, _fp]),
     "nomad_pairwise": (C.c_int, [C.c_void_p, _fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp]),
     "nomad_l1_scratch_bytes": (C.c_size_t, []),
     "nomad_l1_loss": (C.c_int, [C.c_void_p, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp]),

@@ -90,15 +90,23 @@ __device__ __forceinline__ void attn_tile(const float* __restrict__ Ks, const fl
 
 // lse (nullable): [B*12][T] log-sum-exp of every score row, saved for the backward pass.
 // T_ = storage type of qkv / out (fp32 or bf16); the arithmetic is fp32 MFMA either way.
+// tpref (nullable): ragged batches - clip b owns rows tpref[b] .. tpref[b+1]-1 of qkv / out.
 template <typename T_ = float>
 __global__ __launch_bounds__(256) void attention_f32_kernel(const T_* __restrict__ qkv, T_* __restrict__ out,
-                                                            float* __restrict__ lse, int T) {
+                                                            float* __restrict__ lse, int T,
+                                                            const int* __restrict__ tpref = nullptr) {
     __shared__ __attribute__((aligned(16))) float Ks[64 * kAttnLD];
     __shared__ __attribute__((aligned(16))) float Vs[64 * kAttnLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qi = lane & 15, g = lane >> 4;
     const int bh = blockIdx.y, b = bh / 12, h = bh - b * 12;
-    const long long base = (long long)b * T * 2304 + h * 64;
+    long long row0 = (long long)b * T;
+    if (tpref) {
+        row0 = tpref[b];
+        T = tpref[b + 1] - tpref[b];
+        if ((int)blockIdx.x * 64 >= T) return;  // whole workgroup: no barrier has been reached yet
+    }
+    const long long base = row0 * 2304 + h * 64;
     const int q_row = blockIdx.x * 64 + wave * 16 + qi;
     const int q_ld = q_row < T ? q_row : T - 1;
 
@@ -144,7 +152,7 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const T_* __restrict
     const float inv = 1.0f / l_tot;
     if (lse && q_row < T && g == 0) lse[(long long)bh * T + q_row] = m_run + logf(l_tot);
     if (q_row < T) {
-        T_* dst = out + ((long long)b * T + q_row) * 768 + h * 64 + g * 4;
+        T_* dst = out + (row0 + q_row) * 768 + h * 64 + g * 4;
 #pragma unroll
         for (int ds = 0; ds < 4; ++ds) {
             float4 r;

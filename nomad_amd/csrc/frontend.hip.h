@@ -21,10 +21,12 @@ namespace nomad {
 constexpr int kStatsPerClip = 65;  // 10 sums + 55 upper-triangular products
 
 // grid: B blocks of 256 threads.  stats[b][0..9] = S, stats[b][10..64] = R (j<=k, row-major).
+// Ragged batches: lens != nullptr gives each clip's sample count, clips are `n_samples` (the row stride) apart.
 __global__ __launch_bounds__(256) void wav_stats_kernel(const float* __restrict__ wav, int n_samples, int L0,
-                                                        double* __restrict__ stats) {
+                                                        double* __restrict__ stats, const int* __restrict__ lens) {
     const int b = blockIdx.x;
     const float* x = wav + (long long)b * n_samples;
+    if (lens) L0 = (lens[b] - 10) / 5 + 1;
     double acc[kStatsPerClip];
 #pragma unroll
     for (int i = 0; i < kStatsPerClip; ++i) acc[i] = 0.0;
@@ -59,8 +61,10 @@ __global__ __launch_bounds__(256) void wav_stats_kernel(const float* __restrict_
 __global__ __launch_bounds__(512) void gn_fold_kernel(const double* __restrict__ stats, const float* __restrict__ w0,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       int L0, float* __restrict__ scale, float* __restrict__ shift,
-                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                      const int* __restrict__ lens) {
     const int b = blockIdx.x, c = threadIdx.x;
+    if (lens) L0 = (lens[b] - 10) / 5 + 1;
     const double* st = stats + (long long)b * kStatsPerClip;
     double w[10];
 #pragma unroll
@@ -95,10 +99,17 @@ constexpr int kConv0Frames = 64;
 template <typename TOut>
 __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restrict__ wav, int n_samples, int L0,
                                                             const float* __restrict__ w0, const float* __restrict__ scale,
-                                                            const float* __restrict__ shift, TOut* __restrict__ out) {
+                                                            const float* __restrict__ shift, TOut* __restrict__ out,
+                                                            const int* __restrict__ lens, const int* __restrict__ pref0) {
     __shared__ float xs[kConv0Frames * 5 + 8];
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * kConv0Frames;
+    long long out_row0 = (long long)b * L0;
+    if (lens) {  // ragged: this clip's own frame count and packed output position
+        L0 = (lens[b] - 10) / 5 + 1;
+        out_row0 = pref0[b];
+        if (t0 >= L0) return;
+    }
     const int nfr = min(kConv0Frames, L0 - t0);
     const float* x = wav + (long long)b * n_samples + 5 * t0;
     const int nx = 5 * nfr + 5;
@@ -114,7 +125,7 @@ __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restr
         for (int j = 0; j < 10; ++j) w[q][j] = w0[c * 10 + j];
     }
     __syncthreads();
-    TOut* o = out + ((long long)b * L0 + t0) * 512 + cq * 4;
+    TOut* o = out + (out_row0 + t0) * 512 + cq * 4;
     for (int t = par; t < nfr; t += 2) {
         float xv[10];
 #pragma unroll
@@ -137,10 +148,19 @@ __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restr
 // (128 taps x 48 channels) for output frame t is 6144 CONTIGUOUS floats starting at frame t, so the
 // grouped conv is a plain GEMM with lda = 48 < K and every byte of every fetched line is used.
 // grid: 16*B blocks of 256 threads; zeroes the two 64-frame pads of one (group, clip).
+// Ragged batches (tpref != nullptr): blockIdx.x = group * B + clip, clip c has tpref[c+1]-tpref[c] frames and starts
+// at padded frame ppref[c]; a group spans ppref[B] frames.
 template <typename T_>
-__global__ __launch_bounds__(256) void zero_pad_rows_kernel(T_* __restrict__ xg, int T) {
+__global__ __launch_bounds__(256) void zero_pad_rows_kernel(T_* __restrict__ xg, int T, const int* __restrict__ tpref,
+                                                            const int* __restrict__ ppref, int B) {
     constexpr int V = 48 * sizeof(T_) / 16;  // 16-byte vectors per 48-channel frame
-    float4* base = reinterpret_cast<float4*>(xg + (long long)blockIdx.x * (T + 128) * 48);
+    long long first = (long long)blockIdx.x * (T + 128);
+    if (tpref) {
+        const int g = blockIdx.x / B, b = blockIdx.x - g * B;
+        T = tpref[b + 1] - tpref[b];
+        first = (long long)g * ppref[B] + ppref[b];
+    }
+    float4* base = reinterpret_cast<float4*>(xg + first * 48);
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     float4* tail = base + (long long)(T + 64) * V;
     for (int i = threadIdx.x; i < 64 * V; i += 256) {

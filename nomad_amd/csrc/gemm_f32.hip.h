@@ -21,15 +21,30 @@ namespace nomad {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Address of logical row m: rows are grouped in clips of `clip_rows` rows.
+// Address of logical row m: rows are grouped in clips of `clip_rows` rows.  Ragged batches (clips of different
+// lengths packed back to back) set `pref`/`base` instead: clip c owns logical rows pref[c] .. pref[c+1]-1 and
+// its row 0 sits at element off + base[c] * unit.
 struct RowMap {
     long long off;          // element offset of (clip 0, row 0)
-    long long clip_stride;  // elements between clips
-    int clip_rows;          // rows per clip in the logical M index
+    long long clip_stride;  // elements between clips (uniform batches)
+    int clip_rows;          // rows per clip in the logical M index (uniform batches); 0 for ragged maps
     int ld;                 // elements between consecutive rows of one clip
+    const int* pref;        // ragged: nclips + 1 logical-row prefix sums (device), or nullptr
+    const int* base;        // ragged: nclips + 1 per-clip base rows in the addressed buffer (device)
+    int nclips;
+    int unit;               // elements per base row
 };
 
 __device__ __forceinline__ long long row_addr(const RowMap& r, int m) {
+    if (r.pref) {
+        int lo = 0, hi = r.nclips;  // largest c with pref[c] <= m
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (r.pref[mid] <= m) lo = mid;
+            else hi = mid;
+        }
+        return r.off + (long long)r.base[lo] * r.unit + (long long)(m - r.pref[lo]) * r.ld;
+    }
     const int c = m / r.clip_rows;
     const int t = m - c * r.clip_rows;
     return r.off + (long long)c * r.clip_stride + (long long)t * r.ld;

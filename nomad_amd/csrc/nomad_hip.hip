@@ -51,6 +51,7 @@ int fail(int code, const char* fmt, ...) {
 constexpr int kConvK[7] = {10, 3, 3, 3, 3, 2, 2};
 constexpr int kConvS[7] = {5, 2, 2, 2, 2, 2, 2};
 constexpr int kMaxEvents = 8192;
+const int* const kNoInts = nullptr;  // "uniform batch" for the kernels' optional ragged-metadata pointers
 
 struct LayerDev {
     float *qkv_w, *qkv_b, *o_w, *o_b, *ln1_w, *ln1_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b, *ln2_w, *ln2_b;
@@ -217,6 +218,7 @@ struct nomad_ctx {
     bf16_t *qkv_w16[NOMAD_NUM_LAYERS] = {}, *o_w16[NOMAD_NUM_LAYERS] = {}, *fc1_w16[NOMAD_NUM_LAYERS] = {},
            *fc2_w16[NOMAD_NUM_LAYERS] = {};
     std::vector<void*> allocs;
+    std::vector<int> ragged_meta;  // host copy of the last ragged batch's metadata (source of an async H2D copy)
     // profiling
     bool prof = false;
     hipEvent_t ev[kMaxEvents];
@@ -368,7 +370,7 @@ int run_layernorm(nomad_ctx* c, const float* in, const float* g, const float* b,
 int run_attention(nomad_ctx* c, const float* qkv, float* out, float* lse, int B, int T, hipStream_t s) {
     const double flops = 4.0 * B * 12.0 * (double)T * T * 64;
     Scope sc(c, s, NOMAD_K_ATTN, flops);
-    hipLaunchKernelGGL(attention_f32_kernel<float>, dim3((T + 63) / 64, B * 12), dim3(256), 0, s, qkv, out, lse, T);
+    hipLaunchKernelGGL(attention_f32_kernel<float>, dim3((T + 63) / 64, B * 12), dim3(256), 0, s, qkv, out, lse, T, kNoInts);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -549,14 +551,14 @@ static int forward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, co
     float* gn_shift = sv ? sv->gn_shift : F(lay.shift);
     {
         Scope sc(c, s, NOMAD_K_FRONT, 0.0);
-        hipLaunchKernelGGL(wav_stats_kernel, dim3(B), dim3(256), 0, s, wav, n_samples, sh.L[0], stats);
+        hipLaunchKernelGGL(wav_stats_kernel, dim3(B), dim3(256), 0, s, wav, n_samples, sh.L[0], stats, kNoInts);
         hipLaunchKernelGGL(gn_fold_kernel, dim3(B), dim3(512), 0, s, stats, c->conv0_w, c->gn_w, c->gn_b, sh.L[0],
-                           gn_scale, gn_shift, sv ? sv->gn_mean : nullptr, sv ? sv->gn_rstd : nullptr);
+                           gn_scale, gn_shift, sv ? sv->gn_mean : nullptr, sv ? sv->gn_rstd : nullptr, kNoInts);
     }
     {
         Scope sc(c, s, NOMAD_K_FRONT, 2.0 * B * (double)sh.L[0] * 512 * 10);
         hipLaunchKernelGGL(conv0_gn_gelu_kernel<float>, dim3((sh.L[0] + kConv0Frames - 1) / kConv0Frames, B), dim3(256), 0, s,
-                           wav, n_samples, sh.L[0], c->conv0_w, gn_scale, gn_shift, F(lay.conv[0]));
+                           wav, n_samples, sh.L[0], c->conv0_w, gn_scale, gn_shift, F(lay.conv[0]), kNoInts, kNoInts);
     }
     HIP_TRY(hipGetLastError());
 
@@ -590,7 +592,7 @@ static int forward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, co
     const RowMap pad_map{64LL * 48, (long long)(T + 128) * 48, T, 48};
     {
         Scope sc(c, s, NOMAD_K_ROW, 0.0);
-        hipLaunchKernelGGL(zero_pad_rows_kernel<float>, dim3(16 * B), dim3(256), 0, s, xpad, T);
+        hipLaunchKernelGGL(zero_pad_rows_kernel<float>, dim3(16 * B), dim3(256), 0, s, xpad, T, kNoInts, kNoInts, B);
     }
     {
         GemmParams p = dense(F(lay.featln), 512, c->proj_w, c->proj_b, nullptr, xpad, M, 768, 512, 0);
@@ -658,7 +660,201 @@ static int forward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, co
     {
         Scope sc(c, s, NOMAD_K_ROW, 2.0 * B * 768 * 256);
         hipLaunchKernelGGL(head_kernel<float>, dim3(B), dim3(256), 0, s, x, T, head_w ? head_w : c->emb_w,
-                           head_b ? head_b : c->emb_b, emb);
+                           head_b ? head_b : c->emb_b, emb, kNoInts);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---- ragged batches: clips of different lengths packed back to back ----------------------------------------
+// The reference embeds files one at a time (nomad.py:171-183) because every file has its own length; zero-padding
+// a batch would change GroupNorm statistics and the time mean.  Here clips of ANY lengths share one launch
+// sequence with no padding: every per-frame tensor is packed [sum_c L_i(c)][channels], the transformer GEMMs and
+// LayerNorms see plain packed rows, and only the kernels that care about clip boundaries (front end, conv row maps,
+// pos-conv buffer, attention, head) read per-clip prefix sums.  Each row goes through exactly the arithmetic it
+// would see at batch 1, so results are bit-identical to per-clip calls.
+struct RaggedShapes {
+    int B = 0, max_l0 = 0, max_t = 0;
+    long long rows[7] = {};   // total frames per conv level
+    long long P = 0;          // total padded pos-conv frames, sum (T_c + 128)
+    std::vector<int> meta;    // [lens(B) | pref_0 (B+1) | ... | pref_6 (B+1) | ppref (B+1)]
+    size_t off_lens() const { return 0; }
+    size_t off_pref(int i) const { return (size_t)B + (size_t)i * (B + 1); }
+    size_t off_ppref() const { return (size_t)B + (size_t)7 * (B + 1); }
+};
+
+static bool make_ragged(int B, const int* lens, RaggedShapes* r) {
+    r->B = B;
+    r->meta.assign((size_t)B + 8 * (size_t)(B + 1), 0);
+    for (int c = 0; c < B; ++c) {
+        Shapes sh;
+        if (!make_shapes(1, lens[c], &sh)) return false;
+        r->meta[c] = lens[c];
+        for (int i = 0; i < 7; ++i) {
+            r->meta[r->off_pref(i) + c + 1] = r->meta[r->off_pref(i) + c] + sh.L[i];
+            r->rows[i] += sh.L[i];
+        }
+        r->meta[r->off_ppref() + c + 1] = r->meta[r->off_ppref() + c] + sh.T + 128;
+        r->P += sh.T + 128;
+        r->max_l0 = sh.L[0] > r->max_l0 ? sh.L[0] : r->max_l0;
+        r->max_t = sh.T > r->max_t ? sh.T : r->max_t;
+    }
+    return r->rows[0] < (1LL << 31) / 512 * 256;  // row counts stay well inside int
+}
+
+struct RaggedLayout {
+    size_t meta, stats, scale, shift, conva, convb, xpad, x, x2, y, qkv, ctxb, h, total;
+};
+
+static RaggedLayout make_ragged_layout(const RaggedShapes& r) {
+    RaggedLayout l{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += align_up(bytes);
+        return o;
+    };
+    const size_t M = (size_t)r.rows[6];
+    l.meta = take(sizeof(int) * r.meta.size());
+    l.stats = take(sizeof(double) * kStatsPerClip * r.B);
+    l.scale = take(sizeof(float) * 512 * r.B);
+    l.shift = take(sizeof(float) * 512 * r.B);
+    l.conva = take(sizeof(float) * 512 * (size_t)r.rows[0]);
+    l.convb = take(sizeof(float) * 512 * (size_t)r.rows[1]);
+    l.xpad = take(sizeof(float) * 768 * (size_t)r.P);
+    l.x = take(sizeof(float) * 768 * M);
+    l.x2 = take(sizeof(float) * 768 * M);
+    l.y = take(sizeof(float) * 768 * M);
+    l.qkv = take(sizeof(float) * 2304 * M);
+    l.ctxb = take(sizeof(float) * 768 * M);
+    l.h = take(sizeof(float) * 3072 * M);
+    l.total = off;
+    return l;
+}
+
+static int forward_ragged(nomad_ctx* c, const float* wav, int B, int stride, const int* lens_host, const float* head_w,
+                          const float* head_b, float* emb, void* workspace, size_t workspace_bytes,
+                          nomad_stream_t stream) {
+    RaggedShapes rs;
+    if (!c || !wav || !lens_host || !emb || !workspace || B <= 0 || !make_ragged(B, lens_host, &rs))
+        return fail(NOMAD_ERR_INVALID, "nomad_embed_ragged: bad argument (B=%d)", B);
+    for (int i = 0; i < B; ++i)
+        if (lens_host[i] > stride) return fail(NOMAD_ERR_INVALID, "nomad_embed_ragged: clip %d longer than the row stride", i);
+    const RaggedLayout lay = make_ragged_layout(rs);
+    if (workspace_bytes < lay.total)
+        return fail(NOMAD_ERR_WORKSPACE, "nomad_embed_ragged: workspace %zu < required %zu", workspace_bytes, lay.total);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    char* ws = static_cast<char*>(workspace);
+    auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    int* meta = reinterpret_cast<int*>(ws + lay.meta);
+    c->ragged_meta = rs.meta;  // must outlive the asynchronous copy
+    HIP_TRY(hipMemcpyAsync(meta, c->ragged_meta.data(), sizeof(int) * rs.meta.size(), hipMemcpyHostToDevice, s));
+    const int* lens = meta + rs.off_lens();
+    auto pref = [&](int i) { return static_cast<const int*>(meta + rs.off_pref(i)); };
+    const int* tpref = pref(6);
+    const int* ppref = meta + rs.off_ppref();
+    const int M = (int)rs.rows[6];
+    int rc;
+
+    double* stats = reinterpret_cast<double*>(ws + lay.stats);
+    float *scale = F(lay.scale), *shift = F(lay.shift);
+    float* cb[2] = {F(lay.conva), F(lay.convb)};
+    {
+        Scope sc(c, s, NOMAD_K_FRONT, 0.0);
+        hipLaunchKernelGGL(wav_stats_kernel, dim3(B), dim3(256), 0, s, wav, stride, 0, stats, lens);
+        hipLaunchKernelGGL(gn_fold_kernel, dim3(B), dim3(512), 0, s, stats, c->conv0_w, c->gn_w, c->gn_b, 0, scale, shift,
+                           static_cast<float*>(nullptr), static_cast<float*>(nullptr), lens);
+    }
+    {
+        Scope sc(c, s, NOMAD_K_FRONT, 2.0 * (double)rs.rows[0] * 512 * 10);
+        hipLaunchKernelGGL(conv0_gn_gelu_kernel<float>, dim3((rs.max_l0 + kConv0Frames - 1) / kConv0Frames, B), dim3(256), 0,
+                           s, wav, stride, 0, c->conv0_w, scale, shift, cb[0], lens, pref(0));
+    }
+    for (int i = 1; i < 7; ++i) {
+        GemmParams p{};
+        p.A = cb[(i - 1) % 2];
+        p.amap = RowMap{0, 0, 0, kConvS[i] * 512, pref(i), pref(i - 1), B, 512};
+        p.K = kConvK[i] * 512;
+        p.kchunk = p.K;
+        p.W = c->conv_w[i];
+        p.ldw = p.K;
+        p.C = cb[i % 2];
+        p.M = (int)rs.rows[i];
+        p.N = 512;
+        p.n_valid = 512;
+        p.cmap = plain_map(p.M, 512);
+        p.rmap = p.cmap;
+        p.gelu = 1;
+        if ((rc = run_gemm(c, p, 1, pick_tile(p.M, 512, p.K), s))) return rc;
+    }
+    float* featln = cb[1];
+    if ((rc = run_layernorm(c, cb[0], c->fln_w, c->fln_b, featln, nullptr, M, 512, s))) return rc;
+    float* xpad = F(lay.xpad);
+    const long long grp_stride = rs.P * 48;
+    const RowMap pad_map{64LL * 48, 0, 0, 48, tpref, ppref, B, 48};
+    {
+        Scope sc(c, s, NOMAD_K_ROW, 0.0);
+        hipLaunchKernelGGL(zero_pad_rows_kernel<float>, dim3(16 * B), dim3(256), 0, s, xpad, 0, tpref, ppref, B);
+    }
+    {
+        GemmParams p = dense(featln, 512, c->proj_w, c->proj_b, nullptr, xpad, M, 768, 512, 0);
+        p.cmap = pad_map;
+        p.c_colblk = 48;
+        p.c_colblk_stride = grp_stride;
+        if ((rc = run_gemm(c, p, 1, pick_tile(M, 768, 512), s))) return rc;
+    }
+    float *x = F(lay.x), *x2 = F(lay.x2), *y = F(lay.y), *qkv = F(lay.qkv), *ctxb = F(lay.ctxb), *hbuf = F(lay.h);
+    {
+        GemmParams p{};
+        p.A = xpad;
+        p.amap = RowMap{0, 0, 0, 48, tpref, ppref, B, 48};
+        p.a_goff = grp_stride;
+        p.K = 6144;
+        p.kchunk = 6144;
+        p.W = c->pos_w;
+        p.ldw = 6144;
+        p.w_goff = 64LL * 6144;
+        p.bias = c->pos_b;
+        p.bias_goff = 48;
+        p.C = y;
+        p.cmap = plain_map(M, 768);
+        p.c_goff = 48;
+        p.R = xpad;
+        p.rmap = pad_map;
+        p.r_goff = grp_stride;
+        p.M = M;
+        p.N = 64;
+        p.n_valid = 48;
+        p.gelu = 1;
+        if ((rc = run_gemm(c, p, 16, M >= 1024 ? 29 : 2, s))) return rc;
+    }
+    if ((rc = run_layernorm(c, y, c->eln_w, c->eln_b, x, nullptr, M, 768, s))) return rc;
+    double attn_flops = 0.0;
+    for (int i = 0; i < B; ++i) {
+        const double t = rs.meta[rs.off_pref(6) + i + 1] - rs.meta[rs.off_pref(6) + i];
+        attn_flops += 4.0 * 12.0 * t * t * 64;
+    }
+    for (int l = 0; l < NOMAD_NUM_LAYERS; ++l) {
+        const LayerDev& d = c->layers[l];
+        if ((rc = run_gemm(c, dense(x, 768, d.qkv_w, d.qkv_b, nullptr, qkv, M, 2304, 768, 0), 1, pick_tile(M, 2304, 768), s)))
+            return rc;
+        {
+            Scope sc(c, s, NOMAD_K_ATTN, attn_flops);
+            hipLaunchKernelGGL(attention_f32_kernel<float>, dim3((rs.max_t + 63) / 64, B * 12), dim3(256), 0, s, qkv, ctxb,
+                               static_cast<float*>(nullptr), 0, tpref);
+        }
+        if ((rc = run_gemm(c, dense(ctxb, 768, d.o_w, d.o_b, x, y, M, 768, 768, 0), 1, pick_tile(M, 768, 768), s))) return rc;
+        if ((rc = run_layernorm(c, y, d.ln1_w, d.ln1_b, x2, nullptr, M, 768, s))) return rc;
+        if ((rc = run_gemm(c, dense(x2, 768, d.fc1_w, d.fc1_b, nullptr, hbuf, M, 3072, 768, 1), 1, pick_tile(M, 3072, 768), s)))
+            return rc;
+        if ((rc = run_gemm(c, dense(hbuf, 3072, d.fc2_w, d.fc2_b, x2, y, M, 768, 3072, 0), 1, pick_tile(M, 768, 3072), s)))
+            return rc;
+        if ((rc = run_layernorm(c, y, d.ln2_w, d.ln2_b, x, nullptr, M, 768, s))) return rc;
+    }
+    {
+        Scope sc(c, s, NOMAD_K_ROW, 2.0 * B * 768 * 256);
+        hipLaunchKernelGGL(head_kernel<float>, dim3(B), dim3(256), 0, s, x, 0, head_w ? head_w : c->emb_w,
+                           head_b ? head_b : c->emb_b, emb, tpref);
     }
     HIP_TRY(hipGetLastError());
     return 0;
@@ -769,14 +965,14 @@ static int forward_bf16(nomad_ctx* c, const float* wav, int B, int n_samples, fl
     bf16_t* cb[2] = {H(lay.conva), H(lay.convb)};
     {
         Scope sc(c, s, NOMAD_K_FRONT, 0.0);
-        hipLaunchKernelGGL(wav_stats_kernel, dim3(B), dim3(256), 0, s, wav, n_samples, sh.L[0], stats);
+        hipLaunchKernelGGL(wav_stats_kernel, dim3(B), dim3(256), 0, s, wav, n_samples, sh.L[0], stats, kNoInts);
         hipLaunchKernelGGL(gn_fold_kernel, dim3(B), dim3(512), 0, s, stats, c->conv0_w, c->gn_w, c->gn_b, sh.L[0], scale,
-                           shift, static_cast<float*>(nullptr), static_cast<float*>(nullptr));
+                           shift, static_cast<float*>(nullptr), static_cast<float*>(nullptr), kNoInts);
     }
     {
         Scope sc(c, s, NOMAD_K_FRONT, 2.0 * B * (double)sh.L[0] * 512 * 10);
         hipLaunchKernelGGL(conv0_gn_gelu_kernel<bf16_t>, dim3((sh.L[0] + kConv0Frames - 1) / kConv0Frames, B), dim3(256), 0,
-                           s, wav, n_samples, sh.L[0], c->conv0_w, scale, shift, cb[0]);
+                           s, wav, n_samples, sh.L[0], c->conv0_w, scale, shift, cb[0], kNoInts, kNoInts);
     }
     for (int i = 1; i < 7; ++i) {
         GemmParams p{};
@@ -806,7 +1002,7 @@ static int forward_bf16(nomad_ctx* c, const float* wav, int B, int n_samples, fl
     const RowMap pad_map{64LL * 48, (long long)(T + 128) * 48, T, 48};
     {
         Scope sc(c, s, NOMAD_K_ROW, 0.0);
-        hipLaunchKernelGGL(zero_pad_rows_kernel<bf16_t>, dim3(16 * B), dim3(256), 0, s, xpad, T);
+        hipLaunchKernelGGL(zero_pad_rows_kernel<bf16_t>, dim3(16 * B), dim3(256), 0, s, xpad, T, kNoInts, kNoInts, B);
     }
     {
         GemmParams p = dense(asf(featln), 512, asf(c->proj_w16), c->proj_b, nullptr, asfm(xpad), M, 768, 512, 0);
@@ -869,7 +1065,7 @@ static int forward_bf16(nomad_ctx* c, const float* wav, int B, int n_samples, fl
     }
     {
         Scope sc(c, s, NOMAD_K_ROW, 2.0 * B * 768 * 256);
-        hipLaunchKernelGGL(head_kernel<bf16_t>, dim3(B), dim3(256), 0, s, x, T, c->emb_w, c->emb_b, emb);
+        hipLaunchKernelGGL(head_kernel<bf16_t>, dim3(B), dim3(256), 0, s, x, T, c->emb_w, c->emb_b, emb, kNoInts);
     }
     HIP_TRY(hipGetLastError());
     return 0;
@@ -933,6 +1129,19 @@ int nomad_diag_gemm_bf16(nomad_ctx* c, const void* A, const void* W, const float
 int nomad_embed(nomad_ctx* c, const float* wav, int B, int n_samples, const float* head_w, const float* head_b,
                 float* emb, float* layers_out, void* workspace, size_t workspace_bytes, nomad_stream_t stream) {
     return forward_impl(c, wav, B, n_samples, head_w, head_b, emb, layers_out, workspace, workspace_bytes, stream, nullptr);
+}
+
+int nomad_workspace_bytes_ragged(const nomad_ctx* c, int B, const int* lengths_host, size_t* bytes) {
+    RaggedShapes rs;
+    if (!c || !bytes || !lengths_host || B <= 0 || !make_ragged(B, lengths_host, &rs))
+        return fail(NOMAD_ERR_INVALID, "nomad_workspace_bytes_ragged: bad argument");
+    *bytes = make_ragged_layout(rs).total;
+    return 0;
+}
+
+int nomad_embed_ragged(nomad_ctx* c, const float* wav, int B, int stride, const int* lengths_host, const float* head_w,
+                       const float* head_b, float* emb, void* workspace, size_t workspace_bytes, nomad_stream_t stream) {
+    return forward_ragged(c, wav, B, stride, lengths_host, head_w, head_b, emb, workspace, workspace_bytes, stream);
 }
 
 int nomad_saved_bytes(const nomad_ctx* c, int B, int n_samples, size_t* bytes) {
@@ -1079,7 +1288,7 @@ int nomad_embed_backward(nomad_ctx* c, const float* wav, int B, int n_samples, c
         const long long grp_stride = (long long)B * (T + 128) * 48;
         {
             Scope sc(c, s, NOMAD_K_ROW, 0.0);
-            hipLaunchKernelGGL(zero_pad_rows_kernel<float>, dim3(16 * B), dim3(256), 0, s, dug, T);
+            hipLaunchKernelGGL(zero_pad_rows_kernel<float>, dim3(16 * B), dim3(256), 0, s, dug, T, kNoInts, kNoInts, B);
             hipLaunchKernelGGL(dgelu_to_groups_kernel, dim3(M), dim3(192), 0, s, dya, sv.upc, dug, T, grp_stride);
         }
         GemmParams p{};

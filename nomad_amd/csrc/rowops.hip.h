@@ -66,12 +66,18 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TIn* __restrict__ 
 // grid: B blocks of 256 threads.  x [B][T][768] -> emb [B][256].
 template <typename TIn = float>
 __global__ __launch_bounds__(256) void head_kernel(const TIn* __restrict__ x, int T, const float* __restrict__ w,
-                                                   const float* __restrict__ bias, float* __restrict__ emb) {
+                                                   const float* __restrict__ bias, float* __restrict__ emb,
+                                                   const int* __restrict__ tpref = nullptr) {
     __shared__ float pooled[768];
     __shared__ float e[256];
     __shared__ float wsum[4];
     const int b = blockIdx.x, tid = threadIdx.x;
-    const TIn* xb = x + (long long)b * T * 768;
+    long long row0 = (long long)b * T;
+    if (tpref) {  // ragged batch: this clip's own frame range
+        row0 = tpref[b];
+        T = tpref[b + 1] - tpref[b];
+    }
+    const TIn* xb = x + row0 * 768;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
     for (int t = 0; t < T; ++t) {
         const TIn* r = xb + (long long)t * 768;

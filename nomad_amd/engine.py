@@ -137,6 +137,35 @@ class Engine:
                                         ws.data_ptr(), ws.numel(), self._stream()), "nomad_embed")
         return (emb, layers) if want_layers else emb
 
+    def embed_ragged(self, waves, head: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
+        """Embed clips of different lengths in ONE launch sequence (no padding in the arithmetic).
+
+        waves: list of 1-D (or (1,N)) fp32 tensors / numpy arrays (host or device).  Returns (B,256) fp32 on the
+        GPU, bit-identical to embedding every clip on its own."""
+        flat = [torch.as_tensor(w, dtype=torch.float32).reshape(-1) for w in waves]
+        lens = [int(w.numel()) for w in flat]
+        B, stride = len(flat), max(lens)
+        stride = (stride + 3) // 4 * 4
+        buf = torch.zeros(B, stride, dtype=torch.float32)
+        on_dev = all(w.is_cuda for w in flat)
+        if on_dev:
+            buf = buf.to(self.device)
+        for i, w in enumerate(flat):
+            buf[i, :lens[i]] = w
+        buf = buf.to(self.device)
+        arr = (C.c_int * B)(*lens)
+        nb = C.c_size_t()
+        _lib.check(self.lib.nomad_workspace_bytes_ragged(self.ctx, B, arr, C.byref(nb)), "nomad_workspace_bytes_ragged")
+        ws = self._workspace(nb.value)
+        emb = torch.empty(B, 256, dtype=torch.float32, device=self.device)
+        hw, hb = head if head is not None else (None, None)
+        _lib.check(self.lib.nomad_embed_ragged(self.ctx, buf.data_ptr(), B, stride, arr,
+                                               hw.data_ptr() if hw is not None else None,
+                                               hb.data_ptr() if hb is not None else None,
+                                               emb.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()),
+                   "nomad_embed_ragged")
+        return emb
+
     def pairwise(self, deg: torch.Tensor, ref: torch.Tensor, want_matrix: bool = True):
         """deg (Nd,256), ref (Nr,256) fp32 on GPU -> (dist (Nd,Nr) float64 or None, mean (Nd,) float64)."""
         self._check_dev(deg, "deg")

@@ -17,9 +17,9 @@ What differs, deliberately:
 * nothing is downloaded at import time (no network in production clusters); the checkpoint is read
   from ``pt-models/nomad_best_model.pt`` (the reference's location, nomad.py:28) or from
   ``$NOMAD_CHECKPOINT``; ``Nomad(weights=...)`` accepts a state dict or ``'seeded'``.
-* ``get_embeddings_csv`` batches clips of equal length into one launch instead of the
-  reference's batch-1 loop with a device sync per clip (nomad.py:171-183); clips are never
-  zero-padded, so every clip sees exactly the arithmetic it sees at batch 1.
+* ``get_embeddings_csv`` packs clips of ANY lengths into ragged batches (one launch sequence, no
+  padding in the arithmetic) instead of the reference's batch-1 loop with a device sync per clip
+  (nomad.py:171-183); every clip sees exactly the arithmetic it sees at batch 1 (bit-identical).
 * the distance matrix is computed on the GPU (float64, difference form) instead of SciPy.
 """
 from __future__ import annotations
@@ -262,8 +262,12 @@ class Nomad:
             raise Exception(f"Path {path} does not exist")
         return self.get_embeddings_csv(self.model, data)
 
-    def get_embeddings_csv(self, model, file_names, root=False, max_batch: int = 256):
-        """Embeddings for every row of ``file_names`` (a DataFrame with the path in column 0)."""
+    def get_embeddings_csv(self, model, file_names, root=False, max_batch_samples: int = 256 * 64000):
+        """Embeddings for every row of ``file_names`` (a DataFrame with the path in column 0).
+
+        The reference embeds one file per iteration with a device sync each time (nomad.py:171-183).  Here files
+        of arbitrary lengths are packed into ragged batches (``nomad_embed_ragged``: no padding enters the
+        arithmetic, results are bit-identical to per-file calls) of at most ``max_batch_samples`` samples."""
         file_names_arr = np.array(file_names)
         paths = []
         for row in file_names_arr:
@@ -271,15 +275,20 @@ class Nomad:
             paths.append(os.path.join(root, name) if root else name)
         waves = [self.load_processing(p, trim=False) for p in paths]
         embeddings = np.zeros((len(waves), EMB_DIM), dtype=np.float32)
-        by_len: "OrderedDict[int, list]" = OrderedDict()
+        batch, total = [], 0
+        batches = []
         for i, w in enumerate(waves):
-            by_len.setdefault(w.shape[1], []).append(i)
-        for n, idxs in by_len.items():
-            for s in range(0, len(idxs), max_batch):
-                chunk = idxs[s:s + max_batch]
-                batch = torch.from_numpy(np.concatenate([waves[i] for i in chunk], axis=0))
-                emb = model(batch.to(self.engine.device), None)
-                embeddings[chunk] = emb.cpu().numpy()
+            n = int(w.shape[1])
+            if batch and total + n > max_batch_samples:
+                batches.append(batch)
+                batch, total = [], 0
+            batch.append(i)
+            total += n
+        if batch:
+            batches.append(batch)
+        for idxs in batches:
+            emb = self.engine.embed_ragged([torch.from_numpy(waves[i][0]) for i in idxs])
+            embeddings[idxs] = emb.cpu().numpy()
         emb_df = pd.DataFrame(embeddings)
         df_emb = pd.concat([file_names.reset_index(), emb_df], axis=1).drop("index", axis=1)
         return df_emb

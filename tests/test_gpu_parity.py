@@ -171,3 +171,30 @@ def test_c3_distance_stage_full_size(engine):
     assert np.abs(d[rows].cpu().numpy() - dref).max() < 1e-13
     assert np.abs(m[rows].cpu().numpy() - mref).max() < 1e-13
     assert (m - d.mean(dim=1)).abs().max().item() < 1e-12   # mean of means identity over the whole matrix
+
+
+def test_ragged_batch_is_bit_identical_to_per_clip(engine):
+    """Clips of different lengths in one launch sequence == each clip on its own (the reference's per-file loop)."""
+    gen = torch.Generator().manual_seed(21)
+    lens = [16384, 400, 27225, 9001, 64000, 30267, 5000, 12345]      # includes the conv stack's minimum (T = 1)
+    waves = [(0.1 * torch.randn(n, generator=gen)).clamp(-1, 1) for n in lens]
+    emb = engine.embed_ragged(waves)
+    torch.cuda.synchronize()
+    assert emb.shape == (len(lens), 256) and torch.isfinite(emb).all()
+    for i, w in enumerate(waves):
+        one = engine.embed(w[None, :].cuda())
+        assert torch.equal(one[0], emb[i]), (i, lens[i], (one[0] - emb[i]).abs().max().item())
+    # a ragged batch of equal lengths equals the uniform path too
+    same = [waves[0], waves[0].flip(0)]
+    assert torch.equal(engine.embed_ragged(same), engine.embed(torch.stack(same).cuda()))
+
+
+def test_ragged_example_wavs_vs_hf_golden(engine):
+    g = np.load(os.path.join(GOLD, "hf_example_wavs.npz"))
+    waves, want = [], []
+    for d, names, embs in (("nmr-data", g["nmr_names"], g["nmr_emb"]), ("test-data", g["deg_names"], g["deg_emb"])):
+        for n, e in zip(names, embs):
+            waves.append(O.load_processing(os.path.join(GOLD, "wavs", d, f"{n}.wav"))[0])
+            want.append(e)
+    emb = engine.embed_ragged(waves).cpu().numpy()       # six clips, six different lengths, one launch sequence
+    assert np.abs(emb - np.stack(want)).max() < EMB_TOL
