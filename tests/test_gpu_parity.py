@@ -198,3 +198,29 @@ def test_ragged_example_wavs_vs_hf_golden(engine):
             want.append(e)
     emb = engine.embed_ragged(waves).cpu().numpy()       # six clips, six different lengths, one launch sequence
     assert np.abs(emb - np.stack(want)).max() < EMB_TOL
+
+
+def test_predict_csv_mode_and_cli(built_lib, sd0, tmp_path, monkeypatch):
+    """csv mode (nomad.py:91-95,154-159): a `filename` column of wav paths; same scores as dir mode; CLI entry."""
+    import pandas as pd
+    from nomad_amd.nomad import Nomad
+    g = np.load(os.path.join(GOLD, "hf_example_wavs.npz"))
+    nmr_csv, deg_csv = tmp_path / "nmr.csv", tmp_path / "deg.csv"
+    pd.DataFrame({"filename": [os.path.join(GOLD, "wavs", "nmr-data", f"{n}.wav") for n in g["nmr_names"]]}).to_csv(nmr_csv, index=False)
+    pd.DataFrame({"filename": [os.path.join(GOLD, "wavs", "test-data", f"{n}.wav") for n in g["deg_names"]]}).to_csv(deg_csv, index=False)
+    nmd = Nomad(weights=sd0)
+    avg, dm = nmd.predict("csv", str(nmr_csv), str(deg_csv), results_path=str(tmp_path))
+    assert list(dm.columns) == [str(n) for n in g["nmr_names"]]          # csv order is preserved
+    assert np.abs(dm.to_numpy() - np.round(g["dist"], 3)).max() <= 1.01e-3
+    assert np.abs(avg["NOMAD"].to_numpy() - np.round(g["mean"], 3)).max() <= 1.01e-3
+    bad = tmp_path / "bad.csv"
+    pd.DataFrame({"path": ["x.wav"]}).to_csv(bad, index=False)
+    with pytest.raises(Exception, match="column called filename"):
+        nmd.get_embeddings(str(bad))
+    # results_path=None writes results-csv/<dd-mm-YYYY_HH-MM-SS>/..._nomad_avg.csv (nomad.py:122-133)
+    monkeypatch.chdir(tmp_path)
+    nmd.predict("csv", str(nmr_csv), str(deg_csv))
+    stamped = os.listdir(tmp_path / "results-csv")
+    assert len(stamped) == 1
+    files = sorted(os.listdir(tmp_path / "results-csv" / stamped[0]))
+    assert files[0].endswith("_nomad_avg.csv") and files[1].endswith("_nomad_scores.csv")
