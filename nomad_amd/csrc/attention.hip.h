@@ -27,6 +27,9 @@ namespace nomad {
 
 constexpr int kAttnLD = 68;  // 64 + 4 floats: 272-B rows
 
+// exp(x) = 2^(x log2 e) on the hardware exp2 (v_exp_f32, ~1 ulp); x <= 0 here, exp(-inf) = 0.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+
 // One 64-key tile for one wave: NSUB = number of 16-key sub-tiles that hold at least one valid key,
 // `valid` = number of valid keys in the tile (keys >= valid are masked to -inf).
 template <int NSUB>
@@ -62,13 +65,13 @@ __device__ __forceinline__ void attn_tile(const float* __restrict__ Ks, const fl
     m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 16));
     m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));
     const float m_new = fmaxf(m_run, m_tile);  // finite: every tile holds at least one valid key
-    const float alpha = expf(m_run - m_new);   // first tile: exp(-inf) = 0
+    const float alpha = fast_exp(m_run - m_new);   // first tile: exp(-inf) = 0
     float psum = 0.f;
 #pragma unroll
     for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float pv = expf(s[sub][r] - m_new);
+            const float pv = fast_exp(s[sub][r] - m_new);
             s[sub][r] = pv;
             psum += pv;
         }
@@ -126,18 +129,31 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const T_* __restrict
     // its NSUB sub-tiles that hold a valid key (straight-line code per NSUB, no branches among the MFMAs).
     const bool wave_active = blockIdx.x * 64 + wave * 16 < T;  // wave-uniform
     const int ntiles = (T + 63) / 64;
-    for (int kt = 0; kt < ntiles; ++kt) {
-        __syncthreads();  // previous tile fully consumed
+    // K/V tiles are prefetched into registers one tile ahead, so the global-load latency of tile kt+1 runs
+    // under the MFMAs of tile kt instead of in front of them.
+    float4 kreg[4], vreg[4];
+    auto fetch = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int id = tid + i * 256, row = id >> 4, c4 = id & 15;
             int key = kt * 64 + row;
             key = key < T ? key : T - 1;
             const T_* src = qkv + base + (long long)key * 2304 + c4 * 4;
-            *reinterpret_cast<float4*>(Ks + row * kAttnLD + c4 * 4) = load4<T_>(src + 768);
-            *reinterpret_cast<float4*>(Vs + row * kAttnLD + c4 * 4) = load4<T_>(src + 1536);
+            kreg[i] = load4<T_>(src + 768);
+            vreg[i] = load4<T_>(src + 1536);
+        }
+    };
+    fetch(0);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        __syncthreads();  // previous tile fully consumed
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = tid + i * 256, row = id >> 4, c4 = id & 15;
+            *reinterpret_cast<float4*>(Ks + row * kAttnLD + c4 * 4) = kreg[i];
+            *reinterpret_cast<float4*>(Vs + row * kAttnLD + c4 * 4) = vreg[i];
         }
         __syncthreads();
+        if (kt + 1 < ntiles) fetch(kt + 1);
         if (!wave_active) continue;
         const int valid = T - kt * 64;  // valid keys in this tile (>= 1)
         if (valid >= 64) attn_tile<4>(Ks, Vs, qf, o, m_run, l_run, qi, g, 64);
@@ -202,13 +218,13 @@ __device__ __forceinline__ void attn_tile_bf16(const char* __restrict__ Ks, cons
     m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 16));
     m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));
     const float m_new = fmaxf(m_run, m_tile);
-    const float alpha = expf(m_run - m_new);
+    const float alpha = fast_exp(m_run - m_new);
     float psum = 0.f;
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float pv = expf(s[sub][r] - m_new);
+            const float pv = fast_exp(s[sub][r] - m_new);
             s[sub][r] = pv;
             psum += pv;
         }
@@ -263,18 +279,29 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(const bf16_t* __res
     float m_run = -INFINITY, l_run = 0.f;
     const bool wave_active = blockIdx.x * 64 + wave * 16 < T;
     const int ntiles = (T + 63) / 64;
-    for (int kt = 0; kt < ntiles; ++kt) {
-        __syncthreads();
+    bf16x8 kreg[2], vreg[2];  // next tile, prefetched under the current tile's MFMAs
+    auto fetch = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int id = tid + i * 256, row = id >> 3, ch = id & 7;
             int key = kt * 64 + row;
             key = key < T ? key : T - 1;
             const bf16_t* src = qkv + base + (long long)key * 2304 + ch * 8;
-            *reinterpret_cast<bf16x8*>(Ks + row * kAttn16LD + ch * 16) = *reinterpret_cast<const bf16x8*>(src + 768);
-            *reinterpret_cast<bf16x8*>(Vs + row * kAttn16LD + ch * 16) = *reinterpret_cast<const bf16x8*>(src + 1536);
+            kreg[i] = *reinterpret_cast<const bf16x8*>(src + 768);
+            vreg[i] = *reinterpret_cast<const bf16x8*>(src + 1536);
+        }
+    };
+    fetch(0);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = tid + i * 256, row = id >> 3, ch = id & 7;
+            *reinterpret_cast<bf16x8*>(Ks + row * kAttn16LD + ch * 16) = kreg[i];
+            *reinterpret_cast<bf16x8*>(Vs + row * kAttn16LD + ch * 16) = vreg[i];
         }
         __syncthreads();
+        if (kt + 1 < ntiles) fetch(kt + 1);
         if (!wave_active) continue;  // wave-uniform: the transposing reads below need a full EXEC mask
         const int valid = T - kt * 64;
         if (valid > 48) attn_tile_bf16<4>(Ks, Vs, qf, o, m_run, l_run, qi, g, valid);
