@@ -298,13 +298,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_kernel(const GemmParams 
 // again on the fragment read (cdna_hip_programming.md rule 21): 16-B chunk c of row r lives at chunk
 // c ^ ((r / RB) % KC), RB = rows per 256-B bank row.  A 16-lane ds_read_b128 group touches 16 rows that
 // are distinct mod 16 at one logical chunk, which that map spreads over all 16 slots of the bank row.
-template <int BM, int BN, int BK, int WM, int WN>
+template <int BM, int BN, int BK, int WM, int WN, int STAGES = 2>
 struct GldsCfg {
     static constexpr int THREADS = WM * WN * 64;
     static constexpr int KC = BK / 4, RB = 16 / KC;
     static constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
     static constexpr int A_CHUNKS = BM * KC / THREADS, B_CHUNKS = BN * KC / THREADS;
-    static constexpr int STAGE_BYTES = 2 * (BM + BN) * BK * 4;
+    static constexpr int STAGE_BYTES = STAGES * (BM + BN) * BK * 4;
     static constexpr int EPI_BYTES = WM * WN * 32 * (WTN + 4) * 4;  // one 32-row fp32 slab per wave
     static constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
 };
@@ -312,18 +312,20 @@ struct GldsCfg {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-// MINW: second __launch_bounds__ argument (minimum waves per SIMD the register allocation must allow).
-// EARLY: issue the first fragment reads of a K tile before the LDS-DMA of the next tile (hides the DMA's
-// address arithmetic under the LDS read latency).
-template <int BM, int BN, int BK, int WM, int WN, int MINW = 1, bool EARLY = false, bool NOEPI = false>
-__global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_f32_glds_kernel(const GemmParams p) {
-    using Cfg = GldsCfg<BM, BN, BK, WM, WN>;
+// STAGES = 2: double-buffered LDS, __syncthreads() (vmcnt(0) + barrier) once per K tile.
+// STAGES = 3: the DMA of tile kt+2 is issued while tile kt is multiplied; the wait before the barrier is a
+//             COUNTED vmcnt that leaves tile kt+1's loads in flight, and the barrier is the raw s_barrier
+//             (cdna_hip_programming.md "Pipelining across barriers").
+// NOEPI: timing-only ablation (no epilogue stores).
+template <int BM, int BN, int BK, int WM, int WN, int STAGES = 2, bool NOEPI = false>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_f32_glds_kernel(const GemmParams p) {
+    using Cfg = GldsCfg<BM, BN, BK, WM, WN, STAGES>;
     constexpr int TM = Cfg::TM, TN = Cfg::TN, NT = Cfg::THREADS, KC = Cfg::KC, RB = Cfg::RB;
     static_assert(BK == 8 || BK == 16 || BK == 32, "swizzle is written for 32-, 64- and 128-B rows");
     static_assert(BM * KC % NT == 0 && BN * KC % NT == 0 && TM >= 1 && TN >= 1, "bad tile");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                 // [2][BM][BK]
-    float* Bs = smem + 2 * BM * BK;   // [2][BN][BK]
+    float* As = smem;                      // [STAGES][BM][BK]
+    float* Bs = smem + STAGES * BM * BK;   // [STAGES][BN][BK]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -377,6 +379,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_f32_glds_kernel(const 
     }
 
     NOMAD_GLDS_TILE(0, 0)
+    if (STAGES == 3 && nk > 1) NOMAD_GLDS_TILE(1, 1)
 
     // fragment read offsets (floats): row R, logical chunk 2*kq + h -> physical chunk ^ swz(R)
     const int frag_row = lane & 31, h = lane >> 5;
@@ -387,34 +390,32 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_f32_glds_kernel(const 
     const int a_row_off = (wm * Cfg::WTM + frag_row) * BK;
     const int b_row_off = (wn * Cfg::WTN + frag_row) * BK;
 
+    int cur = 0;  // LDS buffer of tile kt
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        __syncthreads();  // tile kt has landed (vmcnt(0)) and every wave is done with buffer cur^1
+        if (STAGES == 2) {
+            __syncthreads();  // tile kt has landed (vmcnt(0)) and every wave is done with the other buffer
+        } else {
+            // this wave's loads of tile kt are done once at most one newer tile (kt+1) is still outstanding
+            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::A_CHUNKS + Cfg::B_CHUNKS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // every wave's share of tile kt has landed; buffer of tile kt-1 is free
+            asm volatile("" ::: "memory");
+        }
+        {
+            const int nxt = kt + STAGES - 1;
+            int nb = cur + STAGES - 1;
+            nb = nb >= STAGES ? nb - STAGES : nb;
+            if (nxt < nk) NOMAD_GLDS_TILE(nxt, nb)
+        }
         const float* as = As + cur * BM * BK + a_row_off;
         const float* bs = Bs + cur * BN * BK + b_row_off;
-        f32x4 af0[TM], bf0[TN];
-        if (EARLY) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af0[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * BK + koff[0]);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf0[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * BK + koff[0]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (kt + 1 < nk) NOMAD_GLDS_TILE(kt + 1, cur ^ 1)
 #pragma unroll
         for (int kq = 0; kq < BK / 8; ++kq) {
             f32x4 af[TM], bf[TN];
-            if (EARLY && kq == 0) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[i] = af0[i];
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * BK + koff[kq]);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bf[j] = bf0[j];
-            } else {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * BK + koff[kq]);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * BK + koff[kq]);
-            }
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * BK + koff[kq]);
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -423,6 +424,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_f32_glds_kernel(const 
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][c], bf[j][c], acc[i][j], 0, 0, 0);
         }
+        cur = cur + 1 == STAGES ? 0 : cur + 1;
     }
 #undef NOMAD_GLDS_TILE
 
@@ -490,20 +492,20 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_f32_glds_kernel(const 
     }
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int MINW = 1, bool EARLY = false, bool NOEPI = false>
+template <int BM, int BN, int BK, int WM, int WN, int STAGES = 2, bool NOEPI = false>
 inline hipError_t launch_gemm_glds(GemmParams p, int groups, hipStream_t s, int extra_lds = 0) {
-    using Cfg = GldsCfg<BM, BN, BK, WM, WN>;
+    using Cfg = GldsCfg<BM, BN, BK, WM, WN, STAGES>;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = p.N / BN;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_glds_kernel<BM, BN, BK, WM, WN, MINW, EARLY, NOEPI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_glds_kernel<BM, BN, BK, WM, WN, STAGES, NOEPI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     dim3 grid(p.tiles_m * p.tiles_n, groups);
-    hipLaunchKernelGGL((gemm_f32_glds_kernel<BM, BN, BK, WM, WN, MINW, EARLY, NOEPI>), grid, dim3(Cfg::THREADS),
+    hipLaunchKernelGGL((gemm_f32_glds_kernel<BM, BN, BK, WM, WN, STAGES, NOEPI>), grid, dim3(Cfg::THREADS),
                        Cfg::LDS_BYTES + extra_lds, s, p);
     return hipGetLastError();
 }

@@ -303,9 +303,10 @@ int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, in
         case 29: e = launch_gemm_glds<128, 64, 32, 4, 2>(p, groups, s, occ_pad(occ, GldsCfg<128, 64, 32, 4, 2>::LDS_BYTES)); break;
         case 30: e = launch_gemm_glds<128, 64, 32, 2, 2>(p, groups, s, occ_pad(occ, GldsCfg<128, 64, 32, 2, 2>::LDS_BYTES)); break;
         case 31: e = launch_gemm_glds<128, 128, 32, 4, 2>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 4, 2>::LDS_BYTES)); break;
-        case 32: e = launch_gemm_glds<256, 128, 16, 4, 2, 1, false, true>(p, groups, s); break;  // ablation: no epilogue stores
-        case 33: e = launch_gemm_glds<256, 128, 16, 4, 2, 1, true>(p, groups, s, occ_pad(occ, GldsCfg<256, 128, 16, 4, 2>::LDS_BYTES)); break;
-        case 35: e = launch_gemm_glds<128, 64, 32, 4, 2, 1, true>(p, groups, s, occ_pad(occ, GldsCfg<128, 64, 32, 4, 2>::LDS_BYTES)); break;
+        case 32: e = launch_gemm_glds<256, 128, 16, 4, 2, 2, true>(p, groups, s); break;  // ablation: no epilogue stores
+        case 33: e = launch_gemm_glds<256, 128, 16, 4, 2, 3>(p, groups, s); break;   // 3-stage LDS-DMA pipeline, counted vmcnt
+        case 34: e = launch_gemm_glds<128, 64, 32, 4, 2, 3>(p, groups, s); break;
+        case 35: e = launch_gemm_glds<256, 128, 32, 4, 2, 3>(p, groups, s); break;
         case 14: e = launch_gemm<128, 128, 32, 2, 2, 1>(p, groups, s); break;            // ablations of tile 0
         case 15: e = launch_gemm<128, 128, 32, 2, 2, 2>(p, groups, s); break;
         case 16: e = launch_gemm<128, 128, 32, 2, 2, 3>(p, groups, s); break;
@@ -340,20 +341,18 @@ GemmParams dense(const float* A, int lda, const float* W, const float* bias, con
     return p;
 }
 
-// Kernel instantiation for a dense problem (measured on MI355X, tools/gemm_sweep.py, profiles/):
-//   21 = LDS-DMA 256x128x16, 8 waves: best when the grid is many rounds deep (QKV, fc1, conv1-4)
-//   29 = LDS-DMA 128x64x32, 8 waves: finer tiles for N = 768 / 512 problems where a 256x128 grid is only
-//        2-3 rounds deep and the last partial round would idle a third of the CUs
+// Kernel instantiation for a dense problem (measured on MI355X, tools/gemm_sweep.py, profiles/r01_gemm_sweep_*.json):
+//   33 = LDS-DMA 256x128x16, 8 waves, 3-stage pipeline: best when the grid is many tiles deep (QKV, fc1, conv1-4)
+//        and for the long-K / short-K N = 768 problems of the full batch (fc2, proj)
+//   34 = LDS-DMA 128x64x32, 8 waves, 3-stage: finer tiles for out_proj, conv5/6, the pos-conv groups and for
+//        small batches (config C4), where a 256x128 grid would leave most CUs idle
 //    2 = register-staged 64x64x32 for tiny batches
 int pick_tile(int M, int N, int K) {
     if (M < 1024) return 2;
     const long long tiles256 = (long long)((M + 255) / 256) * (N / 128);
-    if (N % 128 == 0 && tiles256 >= 2048) return 21;
-    // N = 768 / 512 problems of the full batch (about 1200 tiles): the 256x128 kernel still wins for the long-K
-    // (fc2) and short-K (proj) cases; below one round of tiles (small batches, config C4) the finer 128x64
-    // tiles keep more CUs busy (profiles/r01_gemm_sweep_small_m.json).
-    if (N % 128 == 0 && tiles256 >= 512 && (K >= 2048 || K <= 512)) return 21;
-    return 29;
+    if (N % 128 == 0 && tiles256 >= 2048) return 33;
+    if (N % 128 == 0 && tiles256 >= 512 && (K >= 2048 || K <= 512)) return 33;
+    return 34;
 }
 
 int run_layernorm(nomad_ctx* c, const float* in, const float* g, const float* b, float* out, float* out2, int M, int N,
@@ -625,7 +624,7 @@ static int forward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, co
         p.N = 64;
         p.n_valid = 48;
         p.gelu = 1;
-        if ((rc = run_gemm(c, p, 16, M >= 1024 ? 29 : 2, s))) return rc;
+        if ((rc = run_gemm(c, p, 16, M >= 1024 ? 34 : 2, s))) return rc;
     }
     float* x = F(lay.x);
     float* x2 = F(lay.x2);
@@ -826,7 +825,7 @@ static int forward_ragged(nomad_ctx* c, const float* wav, int B, int stride, con
         p.N = 64;
         p.n_valid = 48;
         p.gelu = 1;
-        if ((rc = run_gemm(c, p, 16, M >= 1024 ? 29 : 2, s))) return rc;
+        if ((rc = run_gemm(c, p, 16, M >= 1024 ? 34 : 2, s))) return rc;
     }
     if ((rc = run_layernorm(c, y, c->eln_w, c->eln_b, x, nullptr, M, 768, s))) return rc;
     double attn_flops = 0.0;
@@ -1309,7 +1308,7 @@ int nomad_embed_backward(nomad_ctx* c, const float* wav, int B, int n_samples, c
         p.M = M;
         p.N = 64;
         p.n_valid = 48;
-        if ((rc = run_gemm(c, p, 16, M >= 1024 ? 29 : 2, s))) return rc;                                // dxp
+        if ((rc = run_gemm(c, p, 16, M >= 1024 ? 34 : 2, s))) return rc;                                // dxp
     }
     // ---- post_extract_proj, LayerNorm(512), GELU of conv6 ----------------------------------------------
     if ((rc = bwd_gemm(c, dyb, c->proj_wT, F(lay.f1), M, 512, 768, nullptr, nullptr, s))) return rc;
@@ -1469,9 +1468,9 @@ int nomad_diag_gemm(nomad_ctx* c, const float* A, const float* W, const float* b
     const int group_m = (tile % 10000) / 100;
     tile %= 100;
     static const int kBN[] = {128, 64, 64, 128, 128, 256, 128, 256, 256, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128,
-                              128, 128, 128, 128, 256, 256, 128, 256, 64, 64, 64, 128, 128, 128, 128, 64, 128};
+                              128, 128, 128, 128, 256, 256, 128, 256, 64, 64, 64, 128, 128, 128, 64, 128};
     static const int kBK[] = {32, 16, 32, 16, 32, 32, 16, 32, 16, 16, 16, 32, 32, 16, 32, 32, 32, 16, 16, 16,
-                              32, 16, 16, 32, 16, 32, 16, 16, 16, 32, 32, 32, 16, 16, 16, 32, 8};
+                              32, 16, 16, 32, 16, 32, 16, 16, 16, 32, 32, 32, 16, 16, 32, 32};
     if (tile < 0 || tile > 35) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile id %d", tile);
     const int bn = kBN[tile], bk = kBK[tile];
     if (N % bn || K % bk) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: N %% %d or K %% %d != 0", bn, bk);

@@ -8,7 +8,8 @@ pytestmark = pytest.mark.gpu
 
 # nomad_diag_gemm tile ids -> (BM, BN, BK); >= 20 are the LDS-DMA (global_load_lds) instantiations
 TILES = {0: (128, 128, 32), 1: (128, 64, 16), 2: (64, 64, 32), 6: (256, 128, 16),
-         21: (256, 128, 16), 22: (128, 128, 16), 28: (128, 64, 16), 29: (128, 64, 32), 31: (128, 128, 32)}
+         21: (256, 128, 16), 22: (128, 128, 16), 28: (128, 64, 16), 29: (128, 64, 32), 31: (128, 128, 32),
+         33: (256, 128, 16), 34: (128, 64, 32), 35: (256, 128, 32)}
 
 
 def _dev(x):
@@ -33,7 +34,9 @@ def test_gemm_exact_integer_asymmetric(engine, tile, M):
 
 @pytest.mark.parametrize("tile,M,N,K", [(0, 500, 256, 768), (0, 130, 768, 3072), (2, 84, 768, 512),
                                         (2, 300, 512, 1536), (1, 260, 64, 96), (21, 1500, 256, 768),
-                                        (29, 1100, 768, 3072), (28, 260, 64, 96), (21, 700, 384, 1536)])
+                                        (29, 1100, 768, 3072), (28, 260, 64, 96), (21, 700, 384, 1536),
+                                        (33, 1500, 256, 768), (34, 1100, 768, 3072), (33, 300, 128, 16),
+                                        (34, 260, 64, 32), (33, 700, 384, 48)])
 @pytest.mark.parametrize("epi", ["none", "bias", "bias_gelu", "bias_res", "bias_gelu_res"])
 def test_gemm_epilogues(engine, tile, M, N, K, epi):
     g = torch.Generator().manual_seed(11)

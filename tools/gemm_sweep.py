@@ -40,9 +40,9 @@ TILE_NAMES.update({20: "glds 128x128x32 w2x2", 21: "glds 256x128x16 w4x2", 22: "
                    23: "glds 256x128x32 w4x2", 24: "glds 256x256x16 w4x2", 25: "glds 256x256x32 w4x2",
                    26: "glds 128x128x16 w2x2", 27: "glds 256x256x16 w4x4"})
 BN.update({20: 128, 21: 128, 22: 128, 23: 128, 24: 256, 25: 256, 26: 128, 27: 256, 28: 64, 29: 64, 30: 64, 31: 128})
-TILE_NAMES.update({32: "glds 256x128x16 ABL no-epilogue", 33: "glds 256x128x16 w4x2 early", 34: "glds 256x128x16 minw6 early",
-                   35: "glds 128x64x32 w4x2 early", 36: "glds 256x128x8 w4x2"})
-BN.update({32: 128, 33: 128, 34: 128, 35: 64, 36: 128})
+TILE_NAMES.update({32: "glds 256x128x16 ABL no-epilogue", 33: "glds 256x128x16 w4x2 3-stage", 34: "glds 128x64x32 w4x2 3-stage",
+                   35: "glds 256x128x32 w4x2 3-stage"})
+BN.update({32: 128, 33: 128, 34: 64, 35: 128})
 TILE_NAMES.update({28: "glds 128x64x16 w2x2", 29: "glds 128x64x32 w4x2", 30: "glds 128x64x32 w2x2", 31: "glds 128x128x32 w4x2"})
 
 
