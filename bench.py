@@ -33,7 +33,7 @@ FLOP_LAYERS_4S = 35.264e9        # the 12 encoder layers ("attention-GEMM" subse
 PEAK_FP32_MFMA = 157.3e12        # MI355X_MICROARCH.md chip table
 
 
-def cpu_baseline(sd, n_samples, budget_s=20.0, max_clips=64):
+def cpu_baseline(sd, n_samples, budget_s=20.0, max_clips=256):
     """The CPU oracle on this box's host cores: batch-1 loop like nomad.py:171-183 + float64 cdist.
     The thread count is calibrated first (torch's default of one thread per core is pathological on
     many-core hosts at batch 1); `cores` reports the threads actually used."""
@@ -175,22 +175,35 @@ def main():
             out["model_frac_of_mfma_peak"] = round(value * flop_clip / world / peak, 4)
             if n_samples == 64000:
                 out["encoder_layers_frac_of_mfma_peak"] = round(value * FLOP_LAYERS_4S / world / peak, 4)
-        traffic = None
+        traffic_tab = None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if args.dtype == "f32" and n_samples == 64000 and B == 256 and os.path.isfile(tfile):
-            # HBM-side bytes per GEMM launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
-            # same command (tools/gpu_round3.sh); fabric-side counters, Infinity-Cache hits included
-            traffic = round(json.load(open(tfile))["gemm_all_launches"]["hbm_bytes_per_launch"])
+            # HBM-side bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
+            # command (tools/gpu_round3.sh + tools/pmc_traffic.py); fabric-side counters, Infinity-Cache hits included
+            traffic_tab = json.load(open(tfile))
         if prof:
-            gm = prof["gemm_f32_mfma"]
-            ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
-            kname = ("gemm_bf16_glds_kernel (v_mfma_f32_32x32x16_bf16)" if args.dtype == "bf16"
-                     else "gemm_f32_glds_kernel (v_mfma_f32_32x32x2_f32)") + ", all launches"
+            def rate(cls):
+                return cls["flops"] / (cls["ms"] * 1e-3) / 1e12 if cls["ms"] > 0 else 0.0
+            allg, big, fine = prof["gemm_mfma_all"], prof["gemm_mfma_256x128"], prof["gemm_mfma_128x64"]
+            dom = big if big["ms"] >= fine["ms"] else fine      # the dominant kernel = the instantiation with most time
+            if args.dtype == "bf16":
+                kname = "gemm_bf16_glds_kernel (v_mfma_f32_32x32x16_bf16), " + ("128x128/256x256" if dom is big else "128x64") + " instantiation"
+            else:
+                kname = "gemm_f32_glds_kernel<" + ("256,128,16,4,2,3" if dom is big else "128,64,32,4,2,3") + "> (v_mfma_f32_32x32x2_f32)"
+            ach = rate(dom)
+            traffic = None
+            if traffic_tab:
+                traffic = round(traffic_tab["gemm_256x128" if dom is big else "gemm_128x64"]["hbm_bytes_per_launch"])
             out["roofline"] = {"bound": "mfma", "kernel": kname,
                                "achieved": round(ach, 2), "peak": round(peak / 1e12, 1), "unit": "TFLOP/s",
                                "frac": round(ach * 1e12 / peak, 4), "traffic": traffic,
-                               "launches": gm["launches"], "avg_launch_ms": round(gm["ms"] / max(gm["launches"], 1), 4),
-                               "algorithmic_gflop_per_launch": round(gm["flops"] / max(gm["launches"], 1) / 1e9, 3)}
+                               "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4),
+                               "algorithmic_gflop_per_launch": round(dom["flops"] / max(dom["launches"], 1) / 1e9, 3),
+                               "share_of_step_time": round(dom["ms"] / args.steps / (1e3 * elapsed / args.steps), 4),
+                               "all_gemm_launches": {"achieved": round(rate(allg), 2), "launches": allg["launches"],
+                                                     "frac": round(rate(allg) * 1e12 / peak, 4)},
+                               "other_instantiation": {"achieved": round(rate(fine if dom is big else big), 2),
+                                                       "launches": (fine if dom is big else big)["launches"]}}
             out["kernel_time_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in prof.items()}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, n_samples)

@@ -170,7 +170,16 @@ int nomad_embed_bf16(nomad_ctx* ctx, const float* wav_dev, int B, int n_samples,
 
 /* ---- measurement ------------------------------------------------------------------------- */
 /* Kernel classes for the in-library HIP-event timers. */
-enum { NOMAD_K_GEMM = 0, NOMAD_K_ATTN = 1, NOMAD_K_FRONT = 2, NOMAD_K_ROW = 3, NOMAD_K_PAIR = 4, NOMAD_K_COUNT = 5 };
+enum {
+    NOMAD_K_GEMM = 0,       /* every GEMM launch (all instantiations) */
+    NOMAD_K_ATTN = 1,
+    NOMAD_K_FRONT = 2,
+    NOMAD_K_ROW = 3,
+    NOMAD_K_PAIR = 4,
+    NOMAD_K_GEMM_BIG = 5,   /* of which: the 256x128 instantiation (gemm_*_glds_kernel<256,128,...>; bf16: 128x128 / 256x256) */
+    NOMAD_K_GEMM_FINE = 6,  /* of which: the 128x64 instantiation */
+    NOMAD_K_COUNT = 7
+};
 /* When enabled every kernel launch of nomad_embed/nomad_pairwise is bracketed by hipEvents on the
  * launch stream.  nomad_profile_read synchronises those events and returns, per class, the summed
  * device time (ms), launch count and algorithmic FLOPs (2*M*N*K of the true problem, no padding)

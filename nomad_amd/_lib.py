@@ -6,8 +6,9 @@ import ctypes as C
 import os
 
 NUM_LAYERS = 12
-K_GEMM, K_ATTN, K_FRONT, K_ROW, K_PAIR, K_COUNT = 0, 1, 2, 3, 4, 5
-KERNEL_CLASS_NAMES = ("gemm_f32_mfma", "attention_f32_mfma", "frontend", "rowwise", "pairwise_f64")
+K_GEMM, K_ATTN, K_FRONT, K_ROW, K_PAIR, K_GEMM_BIG, K_GEMM_FINE, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7
+KERNEL_CLASS_NAMES = ("gemm_mfma_all", "attention_mfma", "frontend", "rowwise", "pairwise_f64",
+                      "gemm_mfma_256x128", "gemm_mfma_128x64")
 
 _fp = C.c_void_p  # every pointer is passed as an address
 

@@ -246,13 +246,18 @@ struct Scope {
     nomad_ctx* c;
     hipStream_t s;
     int slot = -1;
-    Scope(nomad_ctx* c_, hipStream_t s_, int cls, double flops) : c(c_), s(s_) {
+    // cls2 (optional): a sub-class that receives the same time / launch / FLOP counts
+    Scope(nomad_ctx* c_, hipStream_t s_, int cls, double flops, int cls2 = -1) : c(c_), s(s_) {
         if (!c->prof) return;
         if (c->ev_used + 2 > kMaxEvents) return;  // pool exhausted: neither counted nor timed
         c->p_fl[cls] += flops;
         c->p_n[cls] += 1;
+        if (cls2 >= 0) {
+            c->p_fl[cls2] += flops;
+            c->p_n[cls2] += 1;
+        }
         slot = c->ev_used;
-        c->ev_class[slot / 2] = cls;
+        c->ev_class[slot / 2] = cls | ((cls2 + 1) << 8);
         c->ev_used += 2;
         (void)hipEventRecord(c->ev[slot], s);
     }
@@ -273,7 +278,7 @@ int occ_pad(int occ, int lds) {
 int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, int occ = 0) {
     if (tile == 29 && occ == 0) occ = 4;  // measured: 4 workgroups/CU is the best residency for the 128x64x32 kernel
     const double flops = 2.0 * p.M * (double)p.n_valid * p.K * groups;
-    Scope sc(c, s, NOMAD_K_GEMM, flops);
+    Scope sc(c, s, NOMAD_K_GEMM, flops, tile == 33 ? NOMAD_K_GEMM_BIG : (tile == 34 ? NOMAD_K_GEMM_FINE : -1));
     hipError_t e;
     switch (tile) {
         case 0: e = launch_gemm<128, 128, 32, 2, 2>(p, groups, s); break;
@@ -881,7 +886,6 @@ static int run_ln_bwd(nomad_ctx* c, const float* x, const float* g, const float*
 // ---- bf16 path (config C5) -----------------------------------------------------------------------------
 static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, int tile = -1) {
     const double flops = 2.0 * p.M * (double)p.n_valid * p.K * groups;
-    Scope sc(c, s, NOMAD_K_GEMM, flops);
     if (tile < 0) {
         // measured (profiles/r01_gemm_sweep_bf16.json): 256x256 tiles (wave tile 64x128) win on wide (N >= 1024)
         // and very tall problems, 128x128 (8 waves) on the N = 768 / 512 transformer shapes
@@ -889,6 +893,7 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
         else if (p.M < 512) tile = 4;
         else tile = (p.N % 256 == 0 && (p.N >= 1024 || p.M >= 100000)) ? 3 : 1;
     }
+    Scope sc(c, s, NOMAD_K_GEMM, flops, (tile == 1 || tile == 3) ? NOMAD_K_GEMM_BIG : (tile == 2 ? NOMAD_K_GEMM_FINE : -1));
     hipError_t e;
     switch (tile) {
         case 0: e = launch_gemm_bf16<256, 128, 4, 2>(p, groups, s); break;
@@ -1429,7 +1434,9 @@ static int profile_drain(nomad_ctx* c) {
         HIP_TRY(hipEventSynchronize(c->ev[i + 1]));
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
-        c->p_ms[c->ev_class[i / 2]] += ms;
+        const int code = c->ev_class[i / 2];
+        c->p_ms[code & 0xff] += ms;
+        if (code >> 8) c->p_ms[(code >> 8) - 1] += ms;
     }
     c->ev_used = 0;
     return 0;

@@ -69,6 +69,11 @@ for k, v in sorted(agg.items()):
         gw += sum(w)
 out["gemm_all_launches"] = {"launches": gl, "hbm_bytes_per_launch": (gf + gw) / gl, "fetch": gf / gl, "write": gw / gl,
                             "algorithmic_bytes_per_launch": alg, "ratio": (gf + gw) / gl / alg}
+for key, pat in (("gemm_256x128", "<256, 128,"), ("gemm_128x64", "<128, 64,")):
+    n = sum(v["launches"] for k, v in out["kernels"].items() if "gemm" in k and pat in k)
+    b = sum(v["launches"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"])
+            for k, v in out["kernels"].items() if "gemm" in k and pat in k)
+    out[key] = {"launches": n, "hbm_bytes_per_launch": b / max(n, 1)}
 for dst in (os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json"), os.path.join(ROOT, "profiles", "pmc_traffic.json")):
     json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps(out["gemm_all_launches"]))
