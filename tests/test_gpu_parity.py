@@ -224,3 +224,22 @@ def test_predict_csv_mode_and_cli(built_lib, sd0, tmp_path, monkeypatch):
     assert len(stamped) == 1
     files = sorted(os.listdir(tmp_path / "results-csv" / stamped[0]))
     assert files[0].endswith("_nomad_avg.csv") and files[1].endswith("_nomad_scores.csv")
+
+
+def test_plain_c_client_of_the_abi(built_lib, tmp_path):
+    """The boundary is a C ABI: a C99 program (no Python, no torch, no C++) drives create / embed / pairwise."""
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    exe = str(tmp_path / "abi_smoke")
+    libdir = os.path.join(ROOT, "nomad_amd")
+    cmd = [gcc, "-std=c99", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "c", "abi_smoke.c"), "-L" + libdir, "-lnomad_hip", "-L/opt/rocm/lib", "-lamdhip64",
+           "-lm", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "status = 0" in res.stdout
