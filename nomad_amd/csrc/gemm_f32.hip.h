@@ -510,6 +510,161 @@ inline hipError_t launch_gemm_glds(GemmParams p, int groups, hipStream_t s, int 
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// N = 48 variant for the grouped pos-conv (16 groups x [M x 48 x 6144], forward and backward): the 32x32
+// MFMA kernels above must pad N to 64 and throw a quarter of their matrix-core work away.  Here a wave owns
+// 32 rows x 48 columns as 2 x 3 tiles of v_mfma_f32_16x16x4_f32 (lane l: A[row l&15][k = l>>4], D: col = l&15,
+// row = 4*(l>>4) + reg; same 64 FLOP/clk/SIMD), 8 waves = 256 rows per workgroup, BK = 16, the same 3-stage
+// LDS-DMA pipeline, source-side swizzle and LDS-staged 16-byte epilogue.  One ds_read_b128 per 16-row operand
+// tile feeds four MFMAs: lane group g reads k = 4g..4g+3 and MFMA j contracts {j, 4+j, 8+j, 12+j}.
+struct N48Cfg {
+    static constexpr int BM = 256, BN = 48, BK = 16, THREADS = 512, STAGES = 3, KC = 4, RB = 4;
+    static constexpr int STAGE_BYTES = STAGES * (BM + BN) * BK * 4;
+    static constexpr int ELD = BN + 4;
+    static constexpr int EPI_BYTES = 8 * 32 * ELD * 4;
+    static constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
+};
+
+__global__ __launch_bounds__(512) void gemm_f32_n48_kernel(const GemmParams p) {
+    using Cfg = N48Cfg;
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, NT = Cfg::THREADS, KC = Cfg::KC, RB = Cfg::RB, ST = Cfg::STAGES;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                 // [ST][256][16]
+    float* Bs = smem + ST * BM * BK;  // [ST][48][16]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = xcd_remap(blockIdx.x, p.tiles_m) * BM;
+    const int grp = blockIdx.y;
+    const float* Ag = p.A + grp * p.a_goff;
+    const float* Wg = p.W + grp * p.w_goff;
+
+    const float* a_src[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int id = tid + i * NT, row = id / KC, pc = id - row * KC;
+        int m = m0 + row;
+        m = m < p.M ? m : p.M - 1;
+        a_src[i] = Ag + row_addr(p.amap, m) + ((pc ^ ((row / RB) % KC)) * 4);
+    }
+    const bool loads_b = wave < 3;  // 48 rows x 4 chunks = 192 chunks = waves 0..2 (wave-uniform)
+    const float* b_src = nullptr;
+    if (loads_b) {
+        const int row = tid / KC, pc = tid - row * KC;
+        b_src = Wg + (long long)row * p.ldw + ((pc ^ ((row / RB) % KC)) * 4);
+    }
+    f32x4 acc[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+#define NOMAD_N48_TILE(KT, BUF)                                                                          \
+    {                                                                                                    \
+        const int k0_ = (KT)*BK;                                                                         \
+        float* as_ = As + (BUF)*BM * BK + wave * 256;                                                    \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                    \
+            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + k0_), (lptr_t)(as_ + i * NT * 4), 16, 0, 0); \
+        if (loads_b)                                                                                     \
+            __builtin_amdgcn_global_load_lds((gptr_t)(b_src + k0_), (lptr_t)(Bs + (BUF)*BN * BK + wave * 256), 16, 0, 0); \
+    }
+    NOMAD_N48_TILE(0, 0)
+    if (nk > 1) NOMAD_N48_TILE(1, 1)
+
+    const int fi = lane & 15, g = lane >> 4;
+    const int frag_off = ((g ^ ((fi >> 2) & 3)) * 4);  // this lane's chunk inside a 16-float row
+    const int a_row_off = (wave * 32 + fi) * BK + frag_off;
+    const int b_row_off = fi * BK + frag_off;
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        // waves 0..2 issue three DMA instructions per tile, the others two: wait for "all but the newest tile"
+        if (kt + 1 < nk) {
+            if (loads_b) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        {
+            int nb = cur + 2;
+            nb = nb >= ST ? nb - ST : nb;
+            if (kt + 2 < nk) NOMAD_N48_TILE(kt + 2, nb)
+        }
+        const float* as = As + cur * BM * BK + a_row_off;
+        const float* bs = Bs + cur * BN * BK + b_row_off;
+        f32x4 af[2], bf[3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const f32x4*>(as + i * 16 * BK);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) bf[j] = *reinterpret_cast<const f32x4*>(bs + j * 16 * BK);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][c], bf[j][c], acc[i][j], 0, 0, 0);
+        cur = cur + 1 == ST ? 0 : cur + 1;
+    }
+#undef NOMAD_N48_TILE
+
+    float* Cg = p.C + grp * p.c_goff;
+    const float* Rg = p.R ? p.R + grp * p.r_goff : nullptr;
+    const float* biasg = p.bias ? p.bias + grp * p.bias_goff : nullptr;
+    const float* DGg = p.DG ? p.DG + grp * p.dg_goff : nullptr;
+    float* Ug = p.Upre ? p.Upre + grp * p.c_goff : nullptr;
+    const bool c_plain = p.cmap.clip_rows >= p.M, r_plain = p.rmap.clip_rows >= p.M;
+    constexpr int ELD = Cfg::ELD;
+    float* slab = smem + wave * (32 * ELD);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float bv = biasg ? biasg[j * 16 + fi] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) slab[(i * 16 + 4 * g + r) * ELD + j * 16 + fi] = acc[i][j][r] + bv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {  // 32 rows x 12 float4 groups = 384 items
+        const int id = lane + 64 * it, row = id / 12, cg = id - row * 12;
+        const int m = m0 + wave * 32 + row, n = cg * 4;
+        if (m < p.M) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * ELD + n);
+            const long long c_idx = (c_plain ? p.cmap.off + (long long)m * p.cmap.ld : row_addr(p.cmap, m)) + n;
+            if (Ug) *reinterpret_cast<f32x4*>(Ug + c_idx) = v;
+            if (p.gelu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+            }
+            if (DGg) {
+                const f32x4 u = *reinterpret_cast<const f32x4*>(DGg + row_addr(p.dgmap, m) + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= dgelu_erf_(u[e]);
+            }
+            if (Rg) v += *reinterpret_cast<const f32x4*>(
+                        Rg + (r_plain ? p.rmap.off + (long long)m * p.rmap.ld : row_addr(p.rmap, m)) + n);
+            *reinterpret_cast<f32x4*>(Cg + c_idx) = v;
+        }
+    }
+}
+
+inline hipError_t launch_gemm_n48(GemmParams p, int groups, hipStream_t s) {
+    p.tiles_m = (p.M + N48Cfg::BM - 1) / N48Cfg::BM;
+    p.tiles_n = 1;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_n48_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_f32_n48_kernel, dim3(p.tiles_m, groups), dim3(N48Cfg::THREADS), N48Cfg::LDS_BYTES, s, p);
+    return hipGetLastError();
+}
+
 template <int BM, int BN, int BK, int WM = 2, int WN = 2, int ABL = 0>
 inline hipError_t launch_gemm(GemmParams p, int groups, hipStream_t s, int extra_lds = 0) {
     using Cfg = GemmCfg<BM, BN, BK, WM, WN>;

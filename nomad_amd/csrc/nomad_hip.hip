@@ -278,7 +278,7 @@ int occ_pad(int occ, int lds) {
 int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, int occ = 0) {
     if (tile == 29 && occ == 0) occ = 4;  // measured: 4 workgroups/CU is the best residency for the 128x64x32 kernel
     const double flops = 2.0 * p.M * (double)p.n_valid * p.K * groups;
-    Scope sc(c, s, NOMAD_K_GEMM, flops, tile == 33 ? NOMAD_K_GEMM_BIG : (tile == 34 ? NOMAD_K_GEMM_FINE : -1));
+    Scope sc(c, s, NOMAD_K_GEMM, flops, tile == 33 ? NOMAD_K_GEMM_BIG : ((tile == 34 || tile == 48) ? NOMAD_K_GEMM_FINE : -1));
     hipError_t e;
     switch (tile) {
         case 0: e = launch_gemm<128, 128, 32, 2, 2>(p, groups, s); break;
@@ -312,6 +312,7 @@ int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, in
         case 33: e = launch_gemm_glds<256, 128, 16, 4, 2, 3>(p, groups, s); break;   // 3-stage LDS-DMA pipeline, counted vmcnt
         case 34: e = launch_gemm_glds<128, 64, 32, 4, 2, 3>(p, groups, s); break;
         case 35: e = launch_gemm_glds<256, 128, 32, 4, 2, 3>(p, groups, s); break;
+        case 48: e = launch_gemm_n48(p, groups, s); break;   // N = 48 exactly (16x16x4 MFMA): the grouped pos-conv
         case 14: e = launch_gemm<128, 128, 32, 2, 2, 1>(p, groups, s); break;            // ablations of tile 0
         case 15: e = launch_gemm<128, 128, 32, 2, 2, 2>(p, groups, s); break;
         case 16: e = launch_gemm<128, 128, 32, 2, 2, 3>(p, groups, s); break;
@@ -629,7 +630,7 @@ static int forward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, co
         p.N = 64;
         p.n_valid = 48;
         p.gelu = 1;
-        if ((rc = run_gemm(c, p, 16, M >= 1024 ? 34 : 2, s))) return rc;
+        if ((rc = run_gemm(c, p, 16, 48, s))) return rc;  // one instantiation for every batch size: same summation order
     }
     float* x = F(lay.x);
     float* x2 = F(lay.x2);
@@ -830,7 +831,7 @@ static int forward_ragged(nomad_ctx* c, const float* wav, int B, int stride, con
         p.N = 64;
         p.n_valid = 48;
         p.gelu = 1;
-        if ((rc = run_gemm(c, p, 16, M >= 1024 ? 34 : 2, s))) return rc;
+        if ((rc = run_gemm(c, p, 16, 48, s))) return rc;  // one instantiation for every batch size: same summation order
     }
     if ((rc = run_layernorm(c, y, c->eln_w, c->eln_b, x, nullptr, M, 768, s))) return rc;
     double attn_flops = 0.0;
@@ -1313,7 +1314,7 @@ int nomad_embed_backward(nomad_ctx* c, const float* wav, int B, int n_samples, c
         p.M = M;
         p.N = 64;
         p.n_valid = 48;
-        if ((rc = run_gemm(c, p, 16, M >= 1024 ? 34 : 2, s))) return rc;                                // dxp
+        if ((rc = run_gemm(c, p, 16, 48, s))) return rc;  // one instantiation for every batch size: same summation order                                // dxp
     }
     // ---- post_extract_proj, LayerNorm(512), GELU of conv6 ----------------------------------------------
     if ((rc = bwd_gemm(c, dyb, c->proj_wT, F(lay.f1), M, 512, 768, nullptr, nullptr, s))) return rc;
@@ -1478,6 +1479,11 @@ int nomad_diag_gemm(nomad_ctx* c, const float* A, const float* W, const float* b
                               128, 128, 128, 128, 256, 256, 128, 256, 64, 64, 64, 128, 128, 128, 64, 128};
     static const int kBK[] = {32, 16, 32, 16, 32, 32, 16, 32, 16, 16, 16, 32, 32, 16, 32, 32, 32, 16, 16, 16,
                               32, 16, 16, 32, 16, 32, 16, 16, 16, 32, 32, 32, 16, 16, 32, 32};
+    if (tile == 48) {
+        if (N != 48 || K % 16) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile 48 needs N == 48 and K %% 16 == 0");
+        GemmParams p48 = dense(A, K, W, bias, R, C, M, N, K, gelu);
+        return run_gemm(c, p48, 1, 48, static_cast<hipStream_t>(stream));
+    }
     if (tile < 0 || tile > 35) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile id %d", tile);
     const int bn = kBN[tile], bk = kBK[tile];
     if (N % bn || K % bk) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: N %% %d or K %% %d != 0", bn, bk);

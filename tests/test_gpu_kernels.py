@@ -57,6 +57,27 @@ def test_gemm_epilogues(engine, tile, M, N, K, epi):
     assert err < 1e-5 * max(1.0, ref.abs().max().item()), err
 
 
+@pytest.mark.parametrize("M", [1, 255, 256, 1000, 1500])
+@pytest.mark.parametrize("epi", ["exact", "bias_gelu_res"])
+def test_gemm_n48_kernel(engine, M, epi):
+    """The N = 48 instantiation (16x16x4 MFMA, used by the grouped pos-conv): exact integers + fused epilogue."""
+    g = torch.Generator().manual_seed(M)
+    K = 6144 if M == 1500 else 160
+    if epi == "exact":
+        A = torch.randint(-3, 4, (M, K), generator=g).float()
+        W = torch.randint(-3, 4, (48, K), generator=g).float()
+        W += (torch.arange(48)[:, None] % 5).float() - (torch.arange(K)[None, :] % 3).float()
+        out = engine.diag_gemm(_dev(A), _dev(W), tile=48).cpu()
+        assert torch.equal(out, (A.double() @ W.double().T).float())
+    else:
+        A = torch.randn(M, K, generator=g)
+        W = torch.randn(48, K, generator=g) * K ** -0.5
+        bias, R = torch.randn(48, generator=g), torch.randn(M, 48, generator=g)
+        ref = F.gelu(A.double() @ W.double().T + bias.double()) + R.double()
+        out = engine.diag_gemm(_dev(A), _dev(W), _dev(bias), _dev(R), gelu=True, tile=48).cpu()
+        assert (out.double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("N", [512, 768])
 @pytest.mark.parametrize("M", [1, 5, 199, 1030])
 def test_layernorm(engine, M, N):
