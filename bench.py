@@ -191,12 +191,15 @@ def main():
             else:
                 kname = "gemm_f32_glds_kernel<" + ("256,128,16,4,2,3" if dom is big else "128,64,32,4,2,3") + "> (v_mfma_f32_32x32x2_f32)"
             ach = rate(dom)
-            traffic = None
+            traffic = alg_bytes = None
             if traffic_tab:
-                traffic = round(traffic_tab["gemm_256x128" if dom is big else "gemm_128x64"]["hbm_bytes_per_launch"])
+                row = traffic_tab["gemm_256x128" if dom is big else "gemm_128x64"]
+                traffic = round(row["hbm_bytes_per_launch"])
+                alg_bytes = round(row.get("algorithmic_bytes_per_launch", 0)) or None
             out["roofline"] = {"bound": "mfma", "kernel": kname,
                                "achieved": round(ach, 2), "peak": round(peak / 1e12, 1), "unit": "TFLOP/s",
                                "frac": round(ach * 1e12 / peak, 4), "traffic": traffic,
+                               "algorithmic_bytes_per_launch": alg_bytes,
                                "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4),
                                "algorithmic_gflop_per_launch": round(dom["flops"] / max(dom["launches"], 1) / 1e9, 3),
                                "share_of_step_time": round(dom["ms"] / args.steps / (1e3 * elapsed / args.steps), 4),

@@ -16,6 +16,23 @@ M = B * T
 L = [12799, 6399, 3199, 1599, 799, 399, 199]
 
 
+def algorithmic_by_kernel():
+    """Algorithmic bytes (A + W + C + residual) per launch, split by the instantiation pick_tile() selects at
+    B = 256 x 4 s: 256x128 = conv1-4, proj, qkv, fc1, fc2; 128x64 = conv5, conv6, out_proj; n48 = pos-conv."""
+    big, fine = [], []
+    for i in range(1, 7):
+        k = 3 if i < 5 else 2
+        b = B * L[i - 1] * 512 * 4 + 512 * 512 * k * 4 + B * L[i] * 512 * 4
+        (big if i <= 4 else fine).append(b)
+    big.append(M * 512 * 4 + 768 * 512 * 4 + M * 768 * 4)
+    for _ in range(12):
+        big.append(M * 768 * 4 + 2304 * 768 * 4 + M * 2304 * 4)
+        fine.append(M * 768 * 4 + 768 * 768 * 4 + 2 * M * 768 * 4)
+        big.append(M * 768 * 4 + 3072 * 768 * 4 + M * 3072 * 4)
+        big.append(M * 3072 * 4 + 3072 * 768 * 4 + 2 * M * 768 * 4)
+    return sum(big) / len(big), sum(fine) / len(fine)
+
+
 def algorithmic_gemm_bytes():
     """A + W + C (+ residual) of every GEMM launch of one forward at B = 256 x 4 s, fp32."""
     alg, n = 0, 0
@@ -73,7 +90,8 @@ for key, pat in (("gemm_256x128", "<256, 128,"), ("gemm_128x64", "<128, 64,")):
     n = sum(v["launches"] for k, v in out["kernels"].items() if "gemm" in k and pat in k)
     b = sum(v["launches"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"])
             for k, v in out["kernels"].items() if "gemm" in k and pat in k)
-    out[key] = {"launches": n, "hbm_bytes_per_launch": b / max(n, 1)}
+    out[key] = {"launches": n, "hbm_bytes_per_launch": b / max(n, 1),
+                "algorithmic_bytes_per_launch": algorithmic_by_kernel()[0 if key == "gemm_256x128" else 1]}
 for dst in (os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json"), os.path.join(ROOT, "profiles", "pmc_traffic.json")):
     json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps(out["gemm_all_launches"]))
