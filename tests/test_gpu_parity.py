@@ -243,3 +243,25 @@ def test_plain_c_client_of_the_abi(built_lib, tmp_path):
     res = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "status = 0" in res.stdout
+
+
+@pytest.mark.parametrize("kind", ["silence", "dc_offset", "square", "impulse", "loud_noise"])
+def test_degenerate_waveforms_vs_oracle(engine, sd0, kind):
+    """Inputs that stress the GroupNorm statistics (zero variance, large mean^2 / variance) and saturation."""
+    gen = torch.Generator().manual_seed(17)
+    n = 24000
+    t = torch.arange(n, dtype=torch.float32)
+    wav = {
+        "silence": torch.zeros(n),
+        "dc_offset": 0.5 + 1e-3 * torch.randn(n, generator=gen),
+        "square": torch.sign(torch.sin(2 * torch.pi * 220.0 * t / 16000.0)),
+        "impulse": torch.zeros(n).index_fill_(0, torch.tensor([n // 2]), 1.0),
+        "loud_noise": torch.randn(n, generator=gen).clamp(-1, 1),
+    }[kind][None, :]
+    with torch.no_grad():
+        ref = O.triplet_forward(sd0, wav)
+    emb = engine.embed(wav.cuda()).cpu()
+    assert torch.isfinite(emb).all()
+    # dc_offset: mean^2 / variance of the conv output is ~1e5, where torch's fp32 group_norm itself carries ~1e-4
+    tol = 2e-4 if kind == "dc_offset" else 2e-5
+    assert (emb - ref).abs().max().item() < tol, (kind, (emb - ref).abs().max().item())
