@@ -312,6 +312,10 @@ int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, in
         case 33: e = launch_gemm_glds<256, 128, 16, 4, 2, 3>(p, groups, s); break;   // 3-stage LDS-DMA pipeline, counted vmcnt
         case 34: e = launch_gemm_glds<128, 64, 32, 4, 2, 3>(p, groups, s); break;
         case 35: e = launch_gemm_glds<256, 128, 32, 4, 2, 3>(p, groups, s); break;
+        case 36: e = launch_gemm_glds<64, 32, 32, 2, 1, 3>(p, groups, s); break;    // small problems: many small workgroups
+        case 37: e = launch_gemm_glds<64, 64, 32, 2, 2, 3>(p, groups, s); break;
+        case 38: e = launch_gemm_glds<128, 32, 32, 4, 1, 3>(p, groups, s); break;
+        case 39: e = launch_gemm_glds<32, 32, 32, 1, 1, 3>(p, groups, s); break;
         case 48: e = launch_gemm_n48(p, groups, s); break;   // N = 48 exactly (16x16x4 MFMA): the grouped pos-conv
         case 14: e = launch_gemm<128, 128, 32, 2, 2, 1>(p, groups, s); break;            // ablations of tile 0
         case 15: e = launch_gemm<128, 128, 32, 2, 2, 2>(p, groups, s); break;
@@ -352,12 +356,15 @@ GemmParams dense(const float* A, int lda, const float* W, const float* bias, con
 //        and for the long-K / short-K N = 768 problems of the full batch (fc2, proj)
 //   34 = LDS-DMA 128x64x32, 8 waves, 3-stage: finer tiles for out_proj, conv5/6, the pos-conv groups and for
 //        small batches (config C4), where a 256x128 grid would leave most CUs idle
-//    2 = register-staged 64x64x32 for tiny batches
+//   37 = LDS-DMA 64x64x32, 4 waves, 3-stage: small problems
+// (all 32x32x2-MFMA instantiations contract k in the same order, so the choice never changes a result bit)
 int pick_tile(int M, int N, int K) {
-    if (M < 1024) return 2;
     const long long tiles256 = (long long)((M + 255) / 256) * (N / 128);
     if (N % 128 == 0 && tiles256 >= 2048) return 33;
     if (N % 128 == 0 && tiles256 >= 512 && (K >= 2048 || K <= 512)) return 33;
+    // less than one round of 256x128 tiles (batch 1 .. a few dozen short clips, config C4): 64x64 tiles keep the
+    // most CUs busy; one wave's K loop is the latency floor there (profiles/r01_gemm_sweep_small_m.json)
+    if (tiles256 < 512) return 37;
     return 34;
 }
 
@@ -1476,15 +1483,15 @@ int nomad_diag_gemm(nomad_ctx* c, const float* A, const float* W, const float* b
     const int group_m = (tile % 10000) / 100;
     tile %= 100;
     static const int kBN[] = {128, 64, 64, 128, 128, 256, 128, 256, 256, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128,
-                              128, 128, 128, 128, 256, 256, 128, 256, 64, 64, 64, 128, 128, 128, 64, 128};
+                              128, 128, 128, 128, 256, 256, 128, 256, 64, 64, 64, 128, 128, 128, 64, 128, 32, 64, 32, 32};
     static const int kBK[] = {32, 16, 32, 16, 32, 32, 16, 32, 16, 16, 16, 32, 32, 16, 32, 32, 32, 16, 16, 16,
-                              32, 16, 16, 32, 16, 32, 16, 16, 16, 32, 32, 32, 16, 16, 32, 32};
+                              32, 16, 16, 32, 16, 32, 16, 16, 16, 32, 32, 32, 16, 16, 32, 32, 32, 32, 32, 32};
     if (tile == 48) {
         if (N != 48 || K % 16) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile 48 needs N == 48 and K %% 16 == 0");
         GemmParams p48 = dense(A, K, W, bias, R, C, M, N, K, gelu);
         return run_gemm(c, p48, 1, 48, static_cast<hipStream_t>(stream));
     }
-    if (tile < 0 || tile > 35) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile id %d", tile);
+    if (tile < 0 || tile > 39) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile id %d", tile);
     const int bn = kBN[tile], bk = kBK[tile];
     if (N % bn || K % bk) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: N %% %d or K %% %d != 0", bn, bk);
     GemmParams p = dense(A, K, W, bias, R, C, M, N, K, gelu);

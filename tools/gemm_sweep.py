@@ -28,6 +28,9 @@ SHAPES = {  # name: (M, N, K, bias, gelu, residual)
     "c4_fc1": (1600, 3072, 768, True, True, False),
     "c4_fc2": (1600, 768, 3072, True, False, True),
     "c4_out": (1600, 768, 768, True, False, True),
+    "b1_qkv": (199, 2304, 768, True, False, False),
+    "b1_fc2": (199, 768, 3072, True, False, True),
+    "b8_fc1": (1592, 3072, 768, True, True, False),
 }
 TILE_NAMES = {0: "128x128x32 w2x2", 1: "128x64x16 w2x2", 2: "64x64x32 w2x2", 3: "128x128x16 w2x2",
               4: "256x128x32 w4x2", 5: "256x256x32 w4x2", 6: "256x128x16 w4x2", 7: "128x256x32 w2x2",
@@ -41,8 +44,9 @@ TILE_NAMES.update({20: "glds 128x128x32 w2x2", 21: "glds 256x128x16 w4x2", 22: "
                    26: "glds 128x128x16 w2x2", 27: "glds 256x256x16 w4x4"})
 BN.update({20: 128, 21: 128, 22: 128, 23: 128, 24: 256, 25: 256, 26: 128, 27: 256, 28: 64, 29: 64, 30: 64, 31: 128})
 TILE_NAMES.update({32: "glds 256x128x16 ABL no-epilogue", 33: "glds 256x128x16 w4x2 3-stage", 34: "glds 128x64x32 w4x2 3-stage",
-                   35: "glds 256x128x32 w4x2 3-stage"})
-BN.update({32: 128, 33: 128, 34: 64, 35: 128})
+                   35: "glds 256x128x32 w4x2 3-stage", 36: "glds 64x32x32 w2x1 3-stage", 37: "glds 64x64x32 w2x2 3-stage",
+                   38: "glds 128x32x32 w4x1 3-stage", 39: "glds 32x32x32 w1x1 3-stage"})
+BN.update({32: 128, 33: 128, 34: 64, 35: 128, 36: 32, 37: 64, 38: 32, 39: 32})
 TILE_NAMES.update({28: "glds 128x64x16 w2x2", 29: "glds 128x64x32 w4x2", 30: "glds 128x64x32 w2x2", 31: "glds 128x128x32 w4x2"})
 
 
