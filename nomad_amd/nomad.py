@@ -287,11 +287,12 @@ class Nomad:
         if batch:
             batches.append(batch)
         for idxs in batches:
-            emb = self.engine.embed_ragged([torch.from_numpy(waves[i][0]) for i in idxs])
+            emb = self.engine.embed_ragged([waves[i][0] for i in idxs])
             embeddings[idxs] = emb.cpu().numpy()
         emb_df = pd.DataFrame(embeddings)
         df_emb = pd.concat([file_names.reset_index(), emb_df], axis=1).drop("index", axis=1)
         return df_emb
 
     def load_processing(self, filepath, target_sr=16000, trim=False):
-        return wavio.load_processing(filepath, target_sr, trim)
+        """file -> (1, N) fp32 mono tensor at 16 kHz, like the reference (nomad.py:192-212) but without torchaudio."""
+        return torch.from_numpy(wavio.load_processing(filepath, target_sr, trim))
