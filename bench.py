@@ -114,7 +114,7 @@ def main():
     ckpt = find_checkpoint()
     sd = load_checkpoint(ckpt) if ckpt else seeded_state_dict(0)
     eng = Engine(sd, local_rank)
-    scorer = ShardedScorer(eng.embed_bf16 if args.dtype == "bf16" else eng.embed, eng.pairwise)
+    scorer = ShardedScorer(eng.embed_bf16 if args.dtype == "bf16" else eng.embed, eng.pairwise, equal_shards=True)
 
     n_samples = int(round(args.seconds * 16000))
     B, n_ref = args.batch, args.refs

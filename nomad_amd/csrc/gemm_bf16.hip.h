@@ -15,26 +15,31 @@
 
 namespace nomad {
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BK = 64, int STAGES = 2>
 struct Bf16Cfg {
     static constexpr int THREADS = WM * WN * 64;
-    static constexpr int BK = 64, KC = 8, RB = 2;  // 8 chunks of 16 B per row, 2 rows per 256-B bank row
+    static constexpr int ROWB = BK * 2;                  // bytes per LDS row: 128 (BK = 64) or 64 (BK = 32)
+    static constexpr int KC = ROWB / 16, RB = 256 / ROWB;  // 16-B chunks per row, rows per 256-B bank row
     static constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
     static constexpr int A_CHUNKS = BM * KC / THREADS, B_CHUNKS = BN * KC / THREADS;
-    static constexpr int STAGE_BYTES = 2 * (BM + BN) * 128;
+    static constexpr int STAGE_BYTES = STAGES * (BM + BN) * ROWB;
     static constexpr int EPI_BYTES = WM * WN * 32 * (WTN + 4) * 4;  // one 32-row fp32 slab per wave
     static constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
 };
 
 // ABL (timing-only ablations, wrong results): 1 = no epilogue stores, 2 = no K loop (prologue + epilogue only).
-template <int BM, int BN, int WM, int WN, int ABL = 0>
+// STAGES = 2: __syncthreads() per K tile; STAGES >= 3: LDS-DMA issued STAGES-1 tiles ahead, counted vmcnt +
+// raw s_barrier (as in gemm_f32_glds_kernel).
+template <int BM, int BN, int WM, int WN, int ABL = 0, int BK = 64, int STAGES = 2>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_glds_kernel(const GemmParams p) {
-    using Cfg = Bf16Cfg<BM, BN, WM, WN>;
-    constexpr int TM = Cfg::TM, TN = Cfg::TN, NT = Cfg::THREADS, KC = Cfg::KC, RB = Cfg::RB, BK = Cfg::BK;
+    using Cfg = Bf16Cfg<BM, BN, WM, WN, BK, STAGES>;
+    constexpr int TM = Cfg::TM, TN = Cfg::TN, NT = Cfg::THREADS, KC = Cfg::KC, RB = Cfg::RB, ROWB = Cfg::ROWB;
+    constexpr int LPT = Cfg::A_CHUNKS + Cfg::B_CHUNKS;  // DMA instructions per thread and K tile
+    static_assert(BK == 32 || BK == 64, "BK");
     static_assert(BM * KC % NT == 0 && BN * KC % NT == 0 && TM >= 1 && TN >= 1, "bad tile");
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
-    char* As = smem_b;                   // [2][BM][128 B]
-    char* Bs = smem_b + 2 * BM * 128;    // [2][BN][128 B]
+    char* As = smem_b;                          // [STAGES][BM][ROWB]
+    char* Bs = smem_b + STAGES * BM * ROWB;     // [STAGES][BN][ROWB]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -78,8 +83,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_glds_kernel(const GemmP
         const int k0_ = (KT)*BK;                                                                         \
         const int kq_ = k0_ / p.kchunk;                                                                  \
         const long long a_koff_ = (long long)kq_ * p.kstride + (k0_ - kq_ * p.kchunk);                   \
-        char* as_ = As + (BUF)*BM * 128 + wave * 1024;                                                   \
-        char* bs_ = Bs + (BUF)*BN * 128 + wave * 1024;                                                   \
+        char* as_ = As + (BUF)*BM * ROWB + wave * 1024;                                                  \
+        char* bs_ = Bs + (BUF)*BN * ROWB + wave * 1024;                                                  \
         _Pragma("unroll") for (int i = 0; i < Cfg::A_CHUNKS; ++i)                                        \
             __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + a_koff_), (lptr_t)(as_ + i * NT * 16), 16, 0, 0); \
         _Pragma("unroll") for (int i = 0; i < Cfg::B_CHUNKS; ++i)                                        \
@@ -87,34 +92,51 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_glds_kernel(const GemmP
     }
 
     NOMAD_GLDS_TILE(0, 0)
+    if (STAGES >= 3 && nk > 1) NOMAD_GLDS_TILE(1, 1)
+    if (STAGES >= 4 && nk > 2) NOMAD_GLDS_TILE(2, 2)
 
     const int frag_row = lane & 31, h = lane >> 5;
     const int swz = (frag_row / RB) % KC;
     int koff[BK / 16];  // byte offset of this lane's chunk for k-step kq
 #pragma unroll
     for (int kq = 0; kq < BK / 16; ++kq) koff[kq] = ((kq * 2 + h) ^ swz) * 16;
-    const int a_row_off = (wm * Cfg::WTM + frag_row) * 128;
-    const int b_row_off = (wn * Cfg::WTN + frag_row) * 128;
+    const int a_row_off = (wm * Cfg::WTM + frag_row) * ROWB;
+    const int b_row_off = (wn * Cfg::WTN + frag_row) * ROWB;
 
+    int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        __syncthreads();  // tile kt has landed (vmcnt(0)) and every wave is done with buffer cur^1
-        if (kt + 1 < nk) NOMAD_GLDS_TILE(kt + 1, cur ^ 1)
-        const char* as = As + cur * BM * 128 + a_row_off;
-        const char* bs = Bs + cur * BN * 128 + b_row_off;
+        if (STAGES == 2) {
+            __syncthreads();  // tile kt has landed (vmcnt(0)) and every wave is done with the other buffer
+        } else {
+            // tiles kt+1 .. kt+STAGES-2 may stay in flight
+            if (STAGES == 4 && kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+            else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        {
+            const int nxt = kt + STAGES - 1;
+            int nb = cur + STAGES - 1;
+            nb = nb >= STAGES ? nb - STAGES : nb;
+            if (nxt < nk) NOMAD_GLDS_TILE(nxt, nb)
+        }
+        const char* as = As + cur * BM * ROWB + a_row_off;
+        const char* bs = Bs + cur * BN * ROWB + b_row_off;
 #pragma unroll
         for (int kq = 0; kq < BK / 16; ++kq) {
             bf16x8 af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(as + i * 32 * 128 + koff[kq]);
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(as + i * 32 * ROWB + koff[kq]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(bs + j * 32 * 128 + koff[kq]);
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(bs + j * 32 * ROWB + koff[kq]);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
+        cur = cur + 1 == STAGES ? 0 : cur + 1;
     }
 #undef NOMAD_GLDS_TILE
 
@@ -179,20 +201,20 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_glds_kernel(const GemmP
     }
 }
 
-template <int BM, int BN, int WM, int WN, int ABL = 0>
+template <int BM, int BN, int WM, int WN, int ABL = 0, int BK = 64, int STAGES = 2>
 inline hipError_t launch_gemm_bf16(GemmParams p, int groups, hipStream_t s, int extra_lds = 0) {
-    using Cfg = Bf16Cfg<BM, BN, WM, WN>;
+    using Cfg = Bf16Cfg<BM, BN, WM, WN, BK, STAGES>;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = p.N / BN;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_glds_kernel<BM, BN, WM, WN, ABL>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_glds_kernel<BM, BN, WM, WN, ABL, BK, STAGES>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     dim3 grid(p.tiles_m * p.tiles_n, groups);
-    hipLaunchKernelGGL((gemm_bf16_glds_kernel<BM, BN, WM, WN, ABL>), grid, dim3(Cfg::THREADS), Cfg::LDS_BYTES + extra_lds, s,
+    hipLaunchKernelGGL((gemm_bf16_glds_kernel<BM, BN, WM, WN, ABL, BK, STAGES>), grid, dim3(Cfg::THREADS), Cfg::LDS_BYTES + extra_lds, s,
                        p);
     return hipGetLastError();
 }

@@ -913,6 +913,13 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
         case 6: e = launch_gemm_bf16<256, 128, 2, 2>(p, groups, s); break;
         case 7: e = launch_gemm_bf16<128, 128, 4, 2, 1>(p, groups, s); break;   // ablation: no epilogue stores
         case 8: e = launch_gemm_bf16<128, 128, 4, 2, 2>(p, groups, s); break;   // ablation: one K tile only
+        case 9: e = launch_gemm_bf16<256, 256, 2, 4, 0, 32, 4>(p, groups, s); break;   // wave 128x64, BK 32, 4-stage
+        case 10: e = launch_gemm_bf16<256, 256, 4, 2, 0, 32, 4>(p, groups, s); break;  // wave 64x128
+        case 11: e = launch_gemm_bf16<128, 128, 4, 2, 0, 32, 4>(p, groups, s); break;
+        case 12: e = launch_gemm_bf16<128, 128, 4, 2, 0, 64, 3>(p, groups, s); break;
+        case 13: e = launch_gemm_bf16<256, 128, 4, 2, 0, 64, 3>(p, groups, s); break;
+        case 14: e = launch_gemm_bf16<256, 128, 4, 2, 0, 32, 4>(p, groups, s); break;
+        case 15: e = launch_gemm_bf16<256, 256, 2, 4, 0, 64, 2>(p, groups, s); break;
         default: return fail(NOMAD_ERR_INVALID, "unknown bf16 gemm tile id %d", tile);
     }
     if (e != hipSuccess) return fail(NOMAD_ERR_HIP, "bf16 gemm launch: %s", hipGetErrorString(e));
@@ -1130,8 +1137,8 @@ int nomad_embed_bf16(nomad_ctx* c, const float* wav, int B, int n_samples, float
 
 int nomad_diag_gemm_bf16(nomad_ctx* c, const void* A, const void* W, const float* bias, const void* R, void* C, int M,
                          int N, int K, int gelu, int tile, nomad_stream_t stream) {
-    static const int kBN[] = {128, 128, 64, 256, 64, 128, 128, 128, 128};
-    if (!c || !A || !W || !C || M <= 0 || tile < 0 || tile > 8) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: bad argument");
+    static const int kBN[] = {128, 128, 64, 256, 64, 128, 128, 128, 128, 256, 256, 128, 128, 128, 128, 256};
+    if (!c || !A || !W || !C || M <= 0 || tile < 0 || tile > 15) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: bad argument");
     if (N % kBN[tile] || K % 64) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: N %% %d or K %% 64 != 0", kBN[tile]);
     GemmParams p = dense(static_cast<const float*>(A), K, static_cast<const float*>(W), bias, static_cast<const float*>(R),
                          static_cast<float*>(C), M, N, K, gelu);

@@ -27,11 +27,18 @@ def partition(n_items: int, world_size: int, rank: int) -> Tuple[int, int]:
     return start, start + base + (1 if rank < rem else 0)
 
 
-def all_gather_rows(x: torch.Tensor, group=None) -> torch.Tensor:
-    """Concatenate per-rank (n_r, ...) tensors along dim 0 (n_r may differ between ranks)."""
+def all_gather_rows(x: torch.Tensor, group=None, equal: bool = False) -> torch.Tensor:
+    """Concatenate per-rank (n_r, ...) tensors along dim 0 (n_r may differ between ranks).
+
+    equal=True promises that every rank contributes the same number of rows: one collective, no size exchange and
+    no host synchronisation (the steady-state path of bench.py)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return x
     world = dist.get_world_size(group)
+    if equal:
+        out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x.contiguous(), group=group)
+        return out
     counts = torch.zeros(world, dtype=torch.int64, device=x.device)
     mine = torch.tensor([x.shape[0]], dtype=torch.int64, device=x.device)
     dist.all_gather_into_tensor(counts, mine, group=group)
@@ -56,10 +63,11 @@ class ShardedScorer:
     ``Engine.pairwise``.
     """
 
-    def __init__(self, embed_fn: Callable, pairwise_fn: Callable, group=None):
+    def __init__(self, embed_fn: Callable, pairwise_fn: Callable, group=None, equal_shards: bool = False):
         self.embed_fn = embed_fn
         self.pairwise_fn = pairwise_fn
         self.group = group
+        self.equal_shards = equal_shards  # every rank holds the same number of reference clips
 
     def score(self, deg_wav: torch.Tensor, ref_wav: Optional[torch.Tensor], want_matrix: bool = False,
               ref_emb_local: Optional[torch.Tensor] = None):
@@ -76,7 +84,7 @@ class ShardedScorer:
                 ref_emb_local = self.embed_fn(ref_wav)
         else:
             deg_emb = self.embed_fn(deg_wav)
-        ref_all = all_gather_rows(ref_emb_local.contiguous(), self.group)
+        ref_all = all_gather_rows(ref_emb_local.contiguous(), self.group, equal=self.equal_shards)
         d, mean = self.pairwise_fn(deg_emb.contiguous(), ref_all, want_matrix)
         return mean, d, ref_all
 

@@ -41,7 +41,7 @@ def _worker(rank, world, port, n_deg, n_ref, out_dir):
     ref = torch.randn(n_ref, 320, generator=g)
     ds, de = partition(n_deg, world, rank)
     rs, re_ = partition(n_ref, world, rank)
-    scorer = ShardedScorer(_fake_embed, _fake_pairwise)
+    scorer = ShardedScorer(_fake_embed, _fake_pairwise, equal_shards=(n_ref % world == 0))
     mean, d, ref_all = scorer.score(deg[ds:de], ref[rs:re_], want_matrix=True)
     full = scorer.gather_scores(mean)
     rows = all_gather_rows(d)

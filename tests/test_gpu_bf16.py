@@ -6,7 +6,8 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-BF16_TILES = {0: (256, 128), 1: (128, 128), 2: (128, 64), 3: (256, 256), 4: (64, 64), 5: (128, 128), 6: (256, 128)}
+BF16_TILES = {0: (256, 128), 1: (128, 128), 2: (128, 64), 3: (256, 256), 4: (64, 64), 5: (128, 128), 6: (256, 128),
+              9: (256, 256), 10: (256, 256), 11: (128, 128), 12: (128, 128), 13: (256, 128), 14: (256, 128), 15: (256, 256)}
 
 
 @pytest.mark.parametrize("tile", sorted(BF16_TILES))

@@ -64,8 +64,12 @@ def main():
     if a.bf16:
         names = {0: "bf16 256x128 w4x2", 1: "bf16 128x128 w4x2", 2: "bf16 128x64 w4x2", 3: "bf16 256x256 w4x2",
                  4: "bf16 64x64 w2x2", 5: "bf16 128x128 w2x2", 6: "bf16 256x128 w2x2",
-                 7: "bf16 128x128 ABL no-epilogue", 8: "bf16 128x128 ABL one-k-tile"}
-        bn = {0: 128, 1: 128, 2: 64, 3: 256, 4: 64, 5: 128, 6: 128, 7: 128, 8: 128}
+                 7: "bf16 128x128 ABL no-epilogue", 8: "bf16 128x128 ABL one-k-tile",
+                 9: "bf16 256x256 w2x4 bk32 4st", 10: "bf16 256x256 w4x2 bk32 4st", 11: "bf16 128x128 w4x2 bk32 4st",
+                 12: "bf16 128x128 w4x2 bk64 3st", 13: "bf16 256x128 w4x2 bk64 3st", 14: "bf16 256x128 w4x2 bk32 4st",
+                 15: "bf16 256x256 w2x4 bk64 2st"}
+        bn = {0: 128, 1: 128, 2: 64, 3: 256, 4: 64, 5: 128, 6: 128, 7: 128, 8: 128, 9: 256, 10: 256, 11: 128, 12: 128,
+              13: 128, 14: 128, 15: 256}
         for sname in a.shapes.split(","):
             M, N, K, has_b, gelu, has_r = SHAPES[sname]
             A = torch.randn(M, K, generator=g).bfloat16().cuda()
