@@ -265,3 +265,22 @@ def test_degenerate_waveforms_vs_oracle(engine, sd0, kind):
     # dc_offset: mean^2 / variance of the conv output is ~1e5, where torch's fp32 group_norm itself carries ~1e-4
     tol = 2e-4 if kind == "dc_offset" else 2e-5
     assert (emb - ref).abs().max().item() < tol, (kind, (emb - ref).abs().max().item())
+
+
+def test_repeat_runs_are_bit_identical(engine):
+    """Race screen for the multi-stage LDS-DMA pipelines: the same batch must give the same bits every time, also
+    while another stream keeps the chip busy (a hand-off that only works on an idle GPU shows up here)."""
+    gen = torch.Generator().manual_seed(33)
+    wav = (0.1 * torch.randn(64, 64000, generator=gen)).clamp(-1, 1).cuda()
+    ref = engine.embed(wav).clone()
+    ref16 = engine.embed_bf16(wav).clone()
+    side = torch.cuda.Stream()
+    junk = torch.randn(4096, 4096, device="cuda")
+    for it in range(12):
+        with torch.cuda.stream(side):
+            for _ in range(4):
+                junk = junk @ junk * 1e-3          # uneven background load on the other queue
+        assert torch.equal(engine.embed(wav), ref), it
+        if it % 4 == 0:
+            assert torch.equal(engine.embed_bf16(wav), ref16), it
+    torch.cuda.synchronize()
