@@ -154,6 +154,48 @@ int nomad_embed_backward(nomad_ctx* ctx, const float* wav_dev, int B, int n_samp
                          const void* saved_dev, size_t saved_bytes, const float* dlayers_dev, const float* demb_dev,
                          float* dwav_dev, void* workspace_dev, size_t workspace_bytes, nomad_stream_t stream);
 
+/* ---- triplet fine-tuning step (src/training/train_triplet.py:112-133, src/config/train_triplet.yaml) ---- */
+/*
+ * The reference fine-tunes wav2vec 2.0 + head with A/P/N forwards, nn.TripletMarginLoss(margin),
+ * loss.backward() and Adam (1e-5 on the backbone, `lr` on embedding_layer), conv feature extractor frozen
+ * (freeze_convnet: True).  Here the trainable parameters live in ONE flat fp32 device vector (master copy in
+ * checkpoint layout), with gradients and the two Adam moments in vectors of the same layout:
+ *
+ *   nomad_train_param_count   floats in the vector; head_begin = first float of embedding_layer (own lr)
+ *   nomad_train_num_segments / nomad_train_segment   checkpoint key -> (offset, count) of the vector
+ *   nomad_train_enable        allocates the vectors, fills the parameters from `host_weights` (the same struct
+ *                             nomad_create took), re-points the engine at them (also calls nomad_enable_backward)
+ *   nomad_train_zero_grad     gradients = 0
+ *   nomad_embed_train         (above) forward that saves activations
+ *   nomad_train_backward      given d loss / d emb [B][256]: ACCUMULATES d loss / d parameters into the gradient
+ *                             vector (dW as MFMA GEMMs, split over the B*T contraction, fixed-order reduction);
+ *                             scratch: nomad_train_workspace_bytes.  Stops at the frozen feature extractor.
+ *   nomad_triplet_loss        loss [1] = mean_i max(||a-p+eps|| - ||a-n+eps|| + margin, 0), eps = 1e-6
+ *                             (torch.pairwise_distance); da/dp/dn [B][256] nullable together (validation pass)
+ *   nomad_train_adam_step     torch.optim.Adam update (amsgrad off, no weight decay) with the step count kept in
+ *                             the context, then rebuilds the derived kernel-layout weights
+ *   nomad_train_read / write  copy a whole vector out of / into the context (device pointers, async on stream);
+ *                             what: 0 parameters, 1 gradients, 2 exp_avg, 3 exp_avg_sq
+ *   nomad_train_set_step      set Adam's step counter (resume)
+ */
+int nomad_train_param_count(size_t* total, size_t* head_begin);
+int nomad_train_num_segments(void);
+int nomad_train_segment(int i, char* name, size_t name_cap, size_t* offset, size_t* count);
+int nomad_train_enable(nomad_ctx* ctx, const nomad_weights* host_weights);
+int nomad_train_workspace_bytes(const nomad_ctx* ctx, int B, int n_samples, size_t* bytes);
+int nomad_train_zero_grad(nomad_ctx* ctx, nomad_stream_t stream);
+int nomad_train_backward(nomad_ctx* ctx, const float* wav_dev, int B, int n_samples, const float* layers_dev,
+                         const void* saved_dev, size_t saved_bytes, const float* demb_dev,
+                         void* workspace_dev, size_t workspace_bytes, nomad_stream_t stream);
+int nomad_triplet_loss(nomad_ctx* ctx, const float* a_dev, const float* p_dev, const float* n_dev, int B,
+                       float margin, float* loss_dev, float* da_dev, float* dp_dev, float* dn_dev,
+                       nomad_stream_t stream);
+int nomad_train_adam_step(nomad_ctx* ctx, float lr_body, float lr_head, float beta1, float beta2, float eps,
+                          nomad_stream_t stream);
+int nomad_train_read(nomad_ctx* ctx, int what, float* dst_dev, nomad_stream_t stream);
+int nomad_train_write(nomad_ctx* ctx, int what, const float* src_dev, nomad_stream_t stream);
+int nomad_train_set_step(nomad_ctx* ctx, long long step);
+
 /* ---- bf16 path (BASELINE config C5: long-form clips) ---------------------------------------- */
 /*
  * The reference is fp32 only (torch 1.12, no AMP); this path exists for throughput on long clips.

@@ -48,6 +48,18 @@ SIGNATURES = {
     "nomad_l1_loss_backward": (C.c_int, [C.c_void_p, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp]),
     "nomad_embed_backward": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, C.c_size_t, _fp, _fp,
                                        _fp, _fp, C.c_size_t, _fp]),
+    "nomad_train_param_count": (C.c_int, [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "nomad_train_num_segments": (C.c_int, []),
+    "nomad_train_segment": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "nomad_train_enable": (C.c_int, [C.c_void_p, C.POINTER(Weights)]),
+    "nomad_train_workspace_bytes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
+    "nomad_train_zero_grad": (C.c_int, [C.c_void_p, _fp]),
+    "nomad_train_backward": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int, _fp, _fp, C.c_size_t, _fp, _fp, C.c_size_t, _fp]),
+    "nomad_triplet_loss": (C.c_int, [C.c_void_p, _fp, _fp, _fp, C.c_int, C.c_float, _fp, _fp, _fp, _fp, _fp]),
+    "nomad_train_adam_step": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _fp]),
+    "nomad_train_read": (C.c_int, [C.c_void_p, C.c_int, _fp, _fp]),
+    "nomad_train_write": (C.c_int, [C.c_void_p, C.c_int, _fp, _fp]),
+    "nomad_train_set_step": (C.c_int, [C.c_void_p, C.c_longlong]),
     "nomad_enable_bf16": (C.c_int, [C.c_void_p]),
     "nomad_workspace_bytes_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     "nomad_embed_bf16": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int, _fp, _fp, C.c_size_t, _fp]),

@@ -143,7 +143,8 @@ __global__ __launch_bounds__(192) void dgelu_to_groups_kernel(const float* __res
 // grid: B blocks of 256 threads.
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ x, int T, const float* __restrict__ w,
                                                        const float* __restrict__ bias, const float* __restrict__ de,
-                                                       float* __restrict__ gx) {
+                                                       float* __restrict__ gx, float* __restrict__ pooled_out = nullptr,
+                                                       float* __restrict__ dz_out = nullptr) {
     __shared__ float pooled[768], mask[768], z[256], dz[256], red[4], red2[4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* xb = x + (long long)b * T * 768;
@@ -180,6 +181,12 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     __syncthreads();
     const float edot = (red2[0] + red2[1]) + (red2[2] + red2[3]);
     dz[tid] = (dev - ev * edot) / nrm;
+    if (dz_out) {  // what the head's own parameter gradients need (train.hip.h: head_param_grad_kernel)
+        dz_out[(long long)b * 256 + tid] = dz[tid];
+        pooled_out[(long long)b * 768 + tid] = pooled[tid];
+        pooled_out[(long long)b * 768 + tid + 256] = pooled[tid + 256];
+        pooled_out[(long long)b * 768 + tid + 512] = pooled[tid + 512];
+    }
     __syncthreads();
     // dp[c] = sum_o W[o][c] dz[o]; thread handles c = tid, tid+256, tid+512 (coalesced over c)
     float d0 = 0.f, d1 = 0.f, d2 = 0.f;

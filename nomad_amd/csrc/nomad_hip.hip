@@ -17,6 +17,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "../../include/nomad_hip.h"
@@ -27,6 +28,7 @@
 #include "gemm_f32.hip.h"
 #include "pairwise.hip.h"
 #include "rowops.hip.h"
+#include "train.hip.h"
 
 using namespace nomad;
 
@@ -157,13 +159,18 @@ Saved make_saved(const Shapes& s, void* base) {
     return v;
 }
 
-// Scratch of nomad_embed_backward.
+// Scratch of nomad_embed_backward.  train = true adds what the parameter gradients need (nomad_train_backward):
+// two transposed operand buffers [3072][Mp], split-K partial products, the recomputed pos-conv input.
 struct BwdLayout {
     size_t gx, dya, dyb, dh, dqkv, dug, f1, f2, bufa, bufb, partial, total;
     int nchunks;
+    size_t ta, tb, kpart, xg, dwe, lnpart, headp, headdz, dmask;
+    int Mp, pos_split, ln_blocks;
 };
 
-BwdLayout make_bwd_layout(const Shapes& s) {
+constexpr size_t kSplitPartFloats = (size_t)16 * 768 * 768 * 2;  // >= S * Nout * Kin for every split chosen below
+
+BwdLayout make_bwd_layout(const Shapes& s, bool train = false) {
     BwdLayout l{};
     size_t off = 0;
     auto take = [&](size_t floats) {
@@ -184,8 +191,60 @@ BwdLayout make_bwd_layout(const Shapes& s) {
     l.bufb = take(512 * (size_t)s.B * (s.L[1] + 2));
     l.nchunks = (s.L[0] + kGnChunk - 1) / kGnChunk;
     l.partial = take(1024 * (size_t)s.B * l.nchunks);
+    if (train) {
+        l.Mp = (s.M + 511) / 512 * 512;  // contraction length of the dW GEMMs: any split S | 16 keeps K % 32 == 0
+        l.pos_split = s.B < 4 ? s.B : 4;
+        l.ln_blocks = (s.M + kLnRows - 1) / kLnRows;
+        l.ta = take((size_t)3072 * l.Mp);
+        l.tb = take((size_t)3072 * l.Mp);
+        const size_t pos_part = (size_t)l.pos_split * 16 * 128 * 2304;
+        l.kpart = take(pos_part > kSplitPartFloats ? pos_part : kSplitPartFloats);
+        l.xg = take(768 * (size_t)s.B * (s.T + 128));
+        l.dwe = take((size_t)768 * 6144);
+        l.lnpart = take((size_t)l.ln_blocks * 2 * 768);
+        l.headp = take((size_t)s.B * 768);
+        l.headdz = take((size_t)s.B * 256);
+        l.dmask = take(768 * M);
+    }
     l.total = off;
     return l;
+}
+
+// Trainable parameters (everything after the frozen conv feature extractor) as ONE flat fp32 vector; gradients and
+// the Adam moments use the same offsets.  q/k/v of a layer are stored fused [q | k | v] in checkpoint scale.
+struct LayerOffsets {
+    size_t qkv_w, qkv_b, o_w, o_b, ln1_w, ln1_b, fc1_w, fc1_b, fc2_w, fc2_b, ln2_w, ln2_b;
+};
+struct ParamOffsets {
+    size_t fln_w, fln_b, proj_w, proj_b, pos_g, pos_v, pos_b, eln_w, eln_b;
+    LayerOffsets L[NOMAD_NUM_LAYERS];
+    size_t emb_w, emb_b, total;
+};
+
+ParamOffsets make_param_offsets() {
+    ParamOffsets o{};
+    size_t off = 0;
+    auto take = [&](size_t n) {
+        size_t r = off;
+        off += n;  // every segment is a multiple of 4 floats: 16-byte alignment is preserved
+        return r;
+    };
+    o.fln_w = take(512); o.fln_b = take(512);
+    o.proj_w = take(768 * 512); o.proj_b = take(768);
+    o.pos_g = take(128); o.pos_v = take((size_t)768 * 48 * 128); o.pos_b = take(768);
+    o.eln_w = take(768); o.eln_b = take(768);
+    for (int l = 0; l < NOMAD_NUM_LAYERS; ++l) {
+        LayerOffsets& q = o.L[l];
+        q.qkv_w = take((size_t)2304 * 768); q.qkv_b = take(2304);
+        q.o_w = take(768 * 768); q.o_b = take(768);
+        q.ln1_w = take(768); q.ln1_b = take(768);
+        q.fc1_w = take((size_t)3072 * 768); q.fc1_b = take(3072);
+        q.fc2_w = take((size_t)768 * 3072); q.fc2_b = take(768);
+        q.ln2_w = take(768); q.ln2_b = take(768);
+    }
+    o.emb_w = take(256 * 768); o.emb_b = take(256);
+    o.total = off;
+    return o;
 }
 
 }  // namespace
@@ -217,6 +276,11 @@ struct nomad_ctx {
     bf16_t *proj_w16 = nullptr, *pos_w16 = nullptr;
     bf16_t *qkv_w16[NOMAD_NUM_LAYERS] = {}, *o_w16[NOMAD_NUM_LAYERS] = {}, *fc1_w16[NOMAD_NUM_LAYERS] = {},
            *fc2_w16[NOMAD_NUM_LAYERS] = {};
+    // fine-tuning state (nomad_train_enable): master parameters, gradients, Adam moments; see ParamOffsets
+    bool train_ready = false;
+    float *theta = nullptr, *grad = nullptr, *adam_m = nullptr, *adam_v = nullptr;
+    double *pos_nrm2 = nullptr, *tap_partial = nullptr, *tap_dot = nullptr;
+    long long adam_t = 0;
     std::vector<void*> allocs;
     std::vector<int> ragged_meta;  // host copy of the last ragged batch's metadata (source of an async H2D copy)
     // profiling
@@ -316,6 +380,8 @@ int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, in
         case 37: e = launch_gemm_glds<64, 64, 32, 2, 2, 3>(p, groups, s); break;
         case 38: e = launch_gemm_glds<128, 32, 32, 4, 1, 3>(p, groups, s); break;
         case 39: e = launch_gemm_glds<32, 32, 32, 1, 1, 3>(p, groups, s); break;
+        case 40: e = launch_gemm_glds<256, 256, 16, 4, 4, 3>(p, groups, s); break;   // one 16-wave workgroup per CU
+        case 41: e = launch_gemm_glds<256, 256, 16, 4, 4, 2>(p, groups, s); break;
         case 48: e = launch_gemm_n48(p, groups, s); break;   // N = 48 exactly (16x16x4 MFMA): the grouped pos-conv
         case 14: e = launch_gemm<128, 128, 32, 2, 2, 1>(p, groups, s); break;            // ablations of tile 0
         case 15: e = launch_gemm<128, 128, 32, 2, 2, 2>(p, groups, s); break;
@@ -1256,16 +1322,51 @@ int nomad_l1_loss_backward(nomad_ctx* c, const float* a_layers, const float* b_l
     return 0;
 }
 
-int nomad_embed_backward(nomad_ctx* c, const float* wav, int B, int n_samples, const float* head_w, const float* head_b,
+}  // extern "C"
+
+// dW[Nout][Kin] += scale * dY^T X from the transposed operands TA = dY^T [Nout][Mp], TB = X^T [Kin][Mp]: the forward's
+// GEMM kernel with the contraction split over `S` groups, partial products folded in fixed order.
+static int dw_gemm(nomad_ctx* c, const float* TA, const float* TB, int Nout, int Kin, int Mp, float* part, float* out,
+                   int rows_scaled, float scale, hipStream_t s) {
+    const int tiles = (Nout / 128) * (Kin / 64);
+    int S = 1;
+    while (S < 16 && tiles * S < 512) S *= 2;
+    if ((size_t)S * Nout * Kin > kSplitPartFloats) return fail(NOMAD_ERR_INVALID, "dw_gemm: partial buffer too small");
+    const int Kc = Mp / S;
+    GemmParams p = dense(TA, Mp, TB, nullptr, nullptr, part, Nout, Kin, Kc, 0);
+    p.ldw = Mp;
+    p.a_goff = Kc;
+    p.w_goff = Kc;
+    p.c_goff = (long long)Nout * Kin;
+    int rc;
+    if ((rc = run_gemm(c, p, S, 34, s))) return rc;
+    Scope sc(c, s, NOMAD_K_ROW, 0.0);
+    const long long n4 = (long long)Nout * Kin / 4, n4s = (long long)rows_scaled * Kin / 4;
+    const float4* p4 = reinterpret_cast<const float4*>(part);
+    float4* o4 = reinterpret_cast<float4*>(out);
+    if (n4s > 0)  // leading rows with their own scale (q rows of the fused q/k/v weight); every partial keeps stride n4
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4s + 255) / 256)), dim3(256), 0, s, p4, S, n4, n4s, o4, scale);
+    if (n4 > n4s) {
+        // rows after the scaled block: same partial stride, shifted start
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 - n4s + 255) / 256)), dim3(256), 0, s, p4 + n4s, S, n4,
+                           n4 - n4s, o4 + n4s, 1.0f);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, const float* head_w, const float* head_b,
                          const float* layers_out, const void* saved, size_t saved_bytes, const float* dlayers,
                          const float* demb, float* dwav, void* workspace, size_t workspace_bytes,
-                         nomad_stream_t stream) {
+                         nomad_stream_t stream, bool train) {
     Shapes sh;
-    if (!c || !wav || !layers_out || !saved || !demb || !dwav || !workspace || B <= 0 || !make_shapes(B, n_samples, &sh))
+    if (!c || !wav || !layers_out || !saved || !demb || (!dwav && !train) || !workspace || B <= 0 ||
+        !make_shapes(B, n_samples, &sh))
         return fail(NOMAD_ERR_INVALID, "nomad_embed_backward: bad argument");
     if (!c->bwd_ready) return fail(NOMAD_ERR_INVALID, "nomad_embed_backward: call nomad_enable_backward first");
+    if (train && !c->train_ready) return fail(NOMAD_ERR_INVALID, "nomad_train_backward: call nomad_train_enable first");
     const Saved sv = make_saved(sh, const_cast<void*>(saved));
-    const BwdLayout lay = make_bwd_layout(sh);
+    const BwdLayout lay = make_bwd_layout(sh, train);
     if (saved_bytes < sv.total || workspace_bytes < lay.total)
         return fail(NOMAD_ERR_WORKSPACE, "nomad_embed_backward: saved %zu/%zu, workspace %zu/%zu", saved_bytes, sv.total,
                     workspace_bytes, lay.total);
@@ -1276,21 +1377,71 @@ int nomad_embed_backward(nomad_ctx* c, const float* wav, int B, int n_samples, c
     float *gx = F(lay.gx), *dya = F(lay.dya), *dyb = F(lay.dyb), *dh = F(lay.dh), *dqkv = F(lay.dqkv);
     int rc;
 
+    // ---- parameter-gradient helpers (train only) ---------------------------------------------------------
+    const ParamOffsets po = make_param_offsets();
+    auto G = [&](size_t off) { return c->grad + off; };
+    float *TA = train ? F(lay.ta) : nullptr, *TB = train ? F(lay.tb) : nullptr, *part = train ? F(lay.kpart) : nullptr;
+    const int Mp = lay.Mp;
+    auto tpose = [&](const float* in, int C, float* out, bool gelu) {  // out[C][Mp] = f(in[M][C])^T, zero padded
+        Scope sc(c, s, NOMAD_K_ROW, 0.0);
+        const dim3 grid(Mp / 32, (C + 31) / 32), blk(32, 8);
+        if (gelu) hipLaunchKernelGGL(transpose_pad_kernel<1>, grid, blk, 0, s, in, C, out, Mp, M, C);
+        else hipLaunchKernelGGL(transpose_pad_kernel<0>, grid, blk, 0, s, in, C, out, Mp, M, C);
+    };
+    auto rowsum = [&](const float* in, int rows, float* out, float scale) {  // bias gradient from dY^T
+        Scope sc(c, s, NOMAD_K_ROW, 0.0);
+        hipLaunchKernelGGL(rowsum_acc_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, in, Mp, rows, out, scale);
+    };
+    auto ln_params = [&](const float* x, const float* g, const float* g2, int N, float* dgam, float* dbet) {
+        Scope sc(c, s, NOMAD_K_ROW, 0.0);
+        float* lp = F(lay.lnpart);
+        if (N == 768) hipLaunchKernelGGL(ln_param_partial_kernel<3>, dim3(lay.ln_blocks), dim3(256), 0, s, x, g, g2, lp, M);
+        else hipLaunchKernelGGL(ln_param_partial_kernel<2>, dim3(lay.ln_blocks), dim3(256), 0, s, x, g, g2, lp, M);
+        hipLaunchKernelGGL(ln_param_final_kernel, dim3((2 * N + 255) / 256), dim3(256), 0, s, lp, lay.ln_blocks, N, dgam, dbet);
+    };
+
     // ---- head -> d loss / d x_12 -------------------------------------------------------------------
     {
         Scope sc(c, s, NOMAD_K_ROW, 0.0);
         hipLaunchKernelGGL(head_bwd_kernel, dim3(B), dim3(256), 0, s, layers_out + (size_t)11 * M * 768, T,
-                           head_w ? head_w : c->emb_w, head_b ? head_b : c->emb_b, demb, gx);
+                           head_w ? head_w : c->emb_w, head_b ? head_b : c->emb_b, demb, gx,
+                           train ? F(lay.headp) : nullptr, train ? F(lay.headdz) : nullptr);
+        if (train)
+            hipLaunchKernelGGL(head_param_grad_kernel, dim3(256), dim3(256), 0, s, F(lay.headp), F(lay.headdz), B,
+                               G(po.emb_w), G(po.emb_b));
     }
     // ---- 12 transformer layers, last to first ---------------------------------------------------------
     for (int l = NOMAD_NUM_LAYERS - 1; l >= 0; --l) {
         const LayerDev& d = c->layers[l];
         const SavedLayer& sl = sv.L[l];
+        const LayerOffsets& lo = po.L[l];
         const float* dl = dlayers ? dlayers + (size_t)l * M * 768 : nullptr;
         if ((rc = run_ln_bwd(c, sl.y2, gx, dl, d.ln2_w, dya, M, 768, s))) return rc;                   // dy2
+        if (train) {
+            ln_params(sl.y2, gx, dl, 768, G(lo.ln2_w), G(lo.ln2_b));
+            tpose(dya, 768, TA, false);
+            rowsum(TA, 768, G(lo.fc2_b), 1.0f);
+            tpose(sl.u, 3072, TB, true);  // h = gelu(u), recomputed
+            if ((rc = dw_gemm(c, TA, TB, 768, 3072, Mp, part, G(lo.fc2_w), 0, 1.0f, s))) return rc;
+        }
         if ((rc = bwd_gemm(c, dya, c->fc2_wT[l], dh, M, 3072, 768, sl.u, nullptr, s))) return rc;      // du = (dy2 W2) * gelu'(u)
+        if (train) {
+            tpose(dh, 3072, TA, false);
+            rowsum(TA, 3072, G(lo.fc1_b), 1.0f);
+            // fc1's input = LayerNorm(y1), recomputed into gx (the upstream gradient it held has been consumed)
+            if ((rc = run_layernorm(c, sl.y1, d.ln1_w, d.ln1_b, gx, nullptr, M, 768, s))) return rc;
+            tpose(gx, 768, TB, false);
+            if ((rc = dw_gemm(c, TA, TB, 3072, 768, Mp, part, G(lo.fc1_w), 0, 1.0f, s))) return rc;
+        }
         if ((rc = bwd_gemm(c, dh, c->fc1_wT[l], dyb, M, 768, 3072, nullptr, dya, s))) return rc;       // dx1 = du W1 + dy2
         if ((rc = run_ln_bwd(c, sl.y1, dyb, nullptr, d.ln1_w, dya, M, 768, s))) return rc;             // dy1
+        if (train) {
+            ln_params(sl.y1, dyb, nullptr, 768, G(lo.ln1_w), G(lo.ln1_b));
+            tpose(dya, 768, TA, false);
+            rowsum(TA, 768, G(lo.o_b), 1.0f);
+            tpose(sl.ctx, 768, TB, false);
+            if ((rc = dw_gemm(c, TA, TB, 768, 768, Mp, part, G(lo.o_w), 0, 1.0f, s))) return rc;
+        }
         if ((rc = bwd_gemm(c, dya, c->o_wT[l], dyb, M, 768, 768, nullptr, nullptr, s))) return rc;     // dctx
         {
             Scope sc(c, s, NOMAD_K_ATTN, 10.0 * B * 12.0 * (double)T * T * 64);
@@ -1298,13 +1449,27 @@ int nomad_embed_backward(nomad_ctx* c, const float* wav, int B, int n_samples, c
             hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, s, sl.qkv, sl.ctx, dyb, sl.lse, dqkv, T);
             hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, s, sl.qkv, sl.ctx, dyb, sl.lse, dqkv, T);
         }
+        if (train) {
+            // the forward's fused weight holds q scaled by head_dim^-0.5: d q_proj = 0.125 * d fused rows 0..767
+            tpose(dqkv, 2304, TA, false);
+            rowsum(TA, 768, G(lo.qkv_b), 0.125f);
+            rowsum(TA + (size_t)768 * Mp, 1536, G(lo.qkv_b) + 768, 1.0f);
+            const float* xin = layers_out + (size_t)(l > 0 ? l - 1 : 0) * M * 768;
+            if (l == 0) {  // layer 0 reads LayerNorm(y0): recomputed into dyb (dctx has been consumed)
+                if ((rc = run_layernorm(c, sv.y0, c->eln_w, c->eln_b, dyb, nullptr, M, 768, s))) return rc;
+                xin = dyb;
+            }
+            tpose(xin, 768, TB, false);
+            if ((rc = dw_gemm(c, TA, TB, 2304, 768, Mp, part, G(lo.qkv_w), 768, 0.125f, s))) return rc;
+        }
         if ((rc = bwd_gemm(c, dqkv, c->qkv_wT[l], gx, M, 768, 2304, nullptr, dya, s))) return rc;      // dx_in = dqkv Wqkv + dy1
     }
     // ---- encoder input: LayerNorm, x + gelu(pos_conv(x)) --------------------------------------------
     if ((rc = run_ln_bwd(c, sv.y0, gx, nullptr, c->eln_w, dya, M, 768, s))) return rc;                   // dy0
+    if (train) ln_params(sv.y0, gx, nullptr, 768, G(po.eln_w), G(po.eln_b));
+    const long long grp_stride = (long long)B * (T + 128) * 48;
     {
         float* dug = F(lay.dug);
-        const long long grp_stride = (long long)B * (T + 128) * 48;
         {
             Scope sc(c, s, NOMAD_K_ROW, 0.0);
             hipLaunchKernelGGL(zero_pad_rows_kernel<float>, dim3(16 * B), dim3(256), 0, s, dug, T, kNoInts, kNoInts, B);
@@ -1328,10 +1493,49 @@ int nomad_embed_backward(nomad_ctx* c, const float* wav, int B, int n_samples, c
         p.M = M;
         p.N = 64;
         p.n_valid = 48;
-        if ((rc = run_gemm(c, p, 16, 48, s))) return rc;  // one instantiation for every batch size: same summation order                                // dxp
+        if ((rc = run_gemm(c, p, 16, 48, s))) return rc;  // one instantiation for every batch size: same summation order
+    }
+    if (train) {
+        // ---- pos-conv parameters: bias, then weight_g / weight_v through the weight norm --------------------
+        float *dug = F(lay.dug), *xg = F(lay.xg), *dwe = F(lay.dwe), *featln = F(lay.f2);
+        {
+            Scope sc(c, s, NOMAD_K_ROW, 0.0);
+            hipLaunchKernelGGL(posconv_bias_grad_kernel, dim3(16), dim3(256), 0, s, dug, (long long)B * (T + 128), G(po.pos_b));
+        }
+        // the conv's input (post_extract_proj output, group-major, zero padded) is recomputed, not saved
+        if ((rc = run_layernorm(c, sv.c6, c->fln_w, c->fln_b, featln, nullptr, M, 512, s))) return rc;
+        {
+            Scope sc(c, s, NOMAD_K_ROW, 0.0);
+            hipLaunchKernelGGL(zero_pad_rows_kernel<float>, dim3(16 * B), dim3(256), 0, s, xg, T, kNoInts, kNoInts, B);
+        }
+        {
+            GemmParams p = dense(featln, 512, c->proj_w, c->proj_b, nullptr, xg, M, 768, 512, 0);
+            p.cmap = RowMap{64LL * 48, (long long)(T + 128) * 48, T, 48};
+            p.c_colblk = 48;
+            p.c_colblk_stride = grp_stride;
+            if ((rc = run_gemm(c, p, 1, pick_tile(M, 768, 512), s))) return rc;
+        }
+        {
+            const int S = lay.pos_split, cps = (B + S - 1) / S;
+            Scope sc(c, s, NOMAD_K_GEMM, 2.0 * M * 768.0 * 48 * 128);
+            hipLaunchKernelGGL(posconv_dw_kernel, dim3(128 / kPdwTaps, 16, S), dim3(256), 0, s, dug, xg, part, B, T, cps);
+            hipLaunchKernelGGL(posconv_dw_gather_kernel, dim3(768), dim3(256), 0, s, part, S, dwe);
+            hipLaunchKernelGGL(tap_dot_partial_kernel, dim3(576), dim3(256), 0, s, dwe, c->theta + po.pos_v, c->tap_partial);
+            hipLaunchKernelGGL(tap_sum_final_kernel, dim3(1), dim3(128), 0, s, c->tap_partial, 576, c->tap_dot);
+            hipLaunchKernelGGL(posconv_wn_bwd_kernel, dim3(768 * 48 * 128 / 256), dim3(256), 0, s, dwe, c->theta + po.pos_v,
+                               c->theta + po.pos_g, c->pos_nrm2, c->tap_dot, G(po.pos_v), G(po.pos_g));
+        }
+        // ---- post_extract_proj parameters ---------------------------------------------------------------
+        tpose(dyb, 768, TA, false);
+        rowsum(TA, 768, G(po.proj_b), 1.0f);
+        tpose(featln, 512, TB, false);
+        if ((rc = dw_gemm(c, TA, TB, 768, 512, Mp, part, G(po.proj_w), 0, 1.0f, s))) return rc;
     }
     // ---- post_extract_proj, LayerNorm(512), GELU of conv6 ----------------------------------------------
     if ((rc = bwd_gemm(c, dyb, c->proj_wT, F(lay.f1), M, 512, 768, nullptr, nullptr, s))) return rc;
+    if (train) ln_params(sv.c6, F(lay.f1), nullptr, 512, G(po.fln_w), G(po.fln_b));
+    HIP_TRY(hipGetLastError());
+    if (!dwav) return 0;  // frozen conv feature extractor (freeze_convnet: True): nothing upstream needs a gradient
     if ((rc = run_ln_bwd(c, sv.c6, F(lay.f1), nullptr, c->fln_w, F(lay.f2), M, 512, s))) return rc;
     float* bufs[2] = {F(lay.bufa), F(lay.bufb)};  // dU6 -> a, dU5 -> b, ..., dU1 -> b, G0 -> a
     {
@@ -1400,6 +1604,277 @@ int nomad_embed_backward(nomad_ctx* c, const float* wav, int B, int n_samples, c
                            sv.gn_shift, sv.gn_mean, sv.gn_rstd, G0, partial, lay.nchunks, dwav);
     }
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---- fine-tuning state ------------------------------------------------------------------------------------
+namespace {
+
+struct Segment {
+    std::string name;
+    size_t offset, count;
+};
+
+// Checkpoint key -> slice of the flat parameter vector (the keys of nomad_best_model.pt that train_triplet.py
+// leaves trainable with freeze_convnet: True).
+const std::vector<Segment>& segments() {
+    static const std::vector<Segment> segs = [] {
+        std::vector<Segment> v;
+        const ParamOffsets o = make_param_offsets();
+        const std::string p = "ssl_model.";
+        v.push_back({p + "layer_norm.weight", o.fln_w, 512});
+        v.push_back({p + "layer_norm.bias", o.fln_b, 512});
+        v.push_back({p + "post_extract_proj.weight", o.proj_w, 768 * 512});
+        v.push_back({p + "post_extract_proj.bias", o.proj_b, 768});
+        v.push_back({p + "encoder.pos_conv.0.weight_g", o.pos_g, 128});
+        v.push_back({p + "encoder.pos_conv.0.weight_v", o.pos_v, (size_t)768 * 48 * 128});
+        v.push_back({p + "encoder.pos_conv.0.bias", o.pos_b, 768});
+        v.push_back({p + "encoder.layer_norm.weight", o.eln_w, 768});
+        v.push_back({p + "encoder.layer_norm.bias", o.eln_b, 768});
+        for (int l = 0; l < NOMAD_NUM_LAYERS; ++l) {
+            const LayerOffsets& q = o.L[l];
+            const std::string b = p + "encoder.layers." + std::to_string(l) + ".";
+            const size_t ww = 768 * 768;
+            v.push_back({b + "self_attn.q_proj.weight", q.qkv_w, ww});
+            v.push_back({b + "self_attn.k_proj.weight", q.qkv_w + ww, ww});
+            v.push_back({b + "self_attn.v_proj.weight", q.qkv_w + 2 * ww, ww});
+            v.push_back({b + "self_attn.q_proj.bias", q.qkv_b, 768});
+            v.push_back({b + "self_attn.k_proj.bias", q.qkv_b + 768, 768});
+            v.push_back({b + "self_attn.v_proj.bias", q.qkv_b + 1536, 768});
+            v.push_back({b + "self_attn.out_proj.weight", q.o_w, ww});
+            v.push_back({b + "self_attn.out_proj.bias", q.o_b, 768});
+            v.push_back({b + "self_attn_layer_norm.weight", q.ln1_w, 768});
+            v.push_back({b + "self_attn_layer_norm.bias", q.ln1_b, 768});
+            v.push_back({b + "fc1.weight", q.fc1_w, (size_t)3072 * 768});
+            v.push_back({b + "fc1.bias", q.fc1_b, 3072});
+            v.push_back({b + "fc2.weight", q.fc2_w, (size_t)768 * 3072});
+            v.push_back({b + "fc2.bias", q.fc2_b, 768});
+            v.push_back({b + "final_layer_norm.weight", q.ln2_w, 768});
+            v.push_back({b + "final_layer_norm.bias", q.ln2_b, 768});
+        }
+        v.push_back({"embedding_layer.1.weight", o.emb_w, 256 * 768});
+        v.push_back({"embedding_layer.1.bias", o.emb_b, 256});
+        return v;
+    }();
+    return segs;
+}
+
+// Rebuild every kernel-layout weight that is not a plain alias of the master vector: the fused, q-scaled q/k/v
+// weights, the weight-normed pos-conv kernel, and the transposed copies the backward contracts with.
+int refresh_weights(nomad_ctx* c, hipStream_t s) {
+    const ParamOffsets po = make_param_offsets();
+    auto transpose = [&](const float* in, int ld_in, float* out, int ld_out, int R, int C) {
+        hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(32, 8), 0, s, in, ld_in, out, ld_out, R, C);
+    };
+    hipLaunchKernelGGL(tap_dot_partial_kernel, dim3(576), dim3(256), 0, s, c->theta + po.pos_v, (const float*)nullptr,
+                       c->tap_partial);
+    hipLaunchKernelGGL(tap_sum_final_kernel, dim3(1), dim3(128), 0, s, c->tap_partial, 576, c->pos_nrm2);
+    hipLaunchKernelGGL(posconv_fold_kernel, dim3(768), dim3(256), 0, s, c->theta + po.pos_v, c->theta + po.pos_g,
+                       c->pos_nrm2, c->pos_w);
+    hipLaunchKernelGGL(posconv_bwd_weight_kernel, dim3(16 * 64), dim3(256), 0, s, c->pos_w, c->pos_wb);
+    transpose(c->proj_w, 512, c->proj_wT, 768, 768, 512);
+    for (int l = 0; l < NOMAD_NUM_LAYERS; ++l) {
+        const LayerDev& d = c->layers[l];
+        const LayerOffsets& lo = po.L[l];
+        const long long w4 = (long long)2304 * 768 / 4, q4 = (long long)768 * 768 / 4;
+        hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((w4 + 255) / 256)), dim3(256), 0, s,
+                           reinterpret_cast<const float4*>(c->theta + lo.qkv_w), reinterpret_cast<float4*>(d.qkv_w), w4, q4, 0.125f);
+        hipLaunchKernelGGL(scale_rows_kernel, dim3(3), dim3(256), 0, s, reinterpret_cast<const float4*>(c->theta + lo.qkv_b),
+                           reinterpret_cast<float4*>(d.qkv_b), 576LL, 192LL, 0.125f);
+        transpose(d.qkv_w, 768, c->qkv_wT[l], 2304, 2304, 768);
+        transpose(d.o_w, 768, c->o_wT[l], 768, 768, 768);
+        transpose(d.fc1_w, 768, c->fc1_wT[l], 3072, 3072, 768);
+        transpose(d.fc2_w, 3072, c->fc2_wT[l], 768, 768, 3072);
+    }
+    HIP_TRY(hipGetLastError());
+    c->bf16_ready = false;  // the bf16 copies (if any) are stale now; nomad_enable_bf16 rebuilds them
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nomad_embed_backward(nomad_ctx* c, const float* wav, int B, int n_samples, const float* head_w, const float* head_b,
+                         const float* layers_out, const void* saved, size_t saved_bytes, const float* dlayers,
+                         const float* demb, float* dwav, void* workspace, size_t workspace_bytes,
+                         nomad_stream_t stream) {
+    if (!dwav) return fail(NOMAD_ERR_INVALID, "nomad_embed_backward: bad argument");
+    return backward_impl(c, wav, B, n_samples, head_w, head_b, layers_out, saved, saved_bytes, dlayers, demb, dwav,
+                         workspace, workspace_bytes, stream, false);
+}
+
+int nomad_train_num_segments(void) { return (int)segments().size(); }
+
+int nomad_train_segment(int i, char* name, size_t name_cap, size_t* offset, size_t* count) {
+    const auto& v = segments();
+    if (i < 0 || i >= (int)v.size() || !name || !offset || !count || name_cap <= v[i].name.size())
+        return fail(NOMAD_ERR_INVALID, "nomad_train_segment: bad argument");
+    memcpy(name, v[i].name.c_str(), v[i].name.size() + 1);
+    *offset = v[i].offset;
+    *count = v[i].count;
+    return 0;
+}
+
+int nomad_train_param_count(size_t* total, size_t* head_begin) {
+    if (!total) return fail(NOMAD_ERR_INVALID, "nomad_train_param_count: null argument");
+    const ParamOffsets po = make_param_offsets();
+    *total = po.total;
+    if (head_begin) *head_begin = po.emb_w;
+    return 0;
+}
+
+int nomad_train_enable(nomad_ctx* c, const nomad_weights* w) {
+    if (!c || !w) return fail(NOMAD_ERR_INVALID, "nomad_train_enable: null argument");
+    if (c->train_ready) return 0;
+    int rc;
+    if ((rc = nomad_enable_backward(c))) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    const ParamOffsets po = make_param_offsets();
+    auto alloc = [&](size_t bytes, void** out) -> int {
+        void* d = nullptr;
+        HIP_TRY(hipMalloc(&d, bytes));
+        c->allocs.push_back(d);
+        HIP_TRY(hipMemset(d, 0, bytes));
+        *out = d;
+        return 0;
+    };
+    if ((rc = alloc(po.total * sizeof(float), (void**)&c->theta))) return rc;
+    if ((rc = alloc(po.total * sizeof(float), (void**)&c->grad))) return rc;
+    if ((rc = alloc(po.total * sizeof(float), (void**)&c->adam_m))) return rc;
+    if ((rc = alloc(po.total * sizeof(float), (void**)&c->adam_v))) return rc;
+    if ((rc = alloc(128 * sizeof(double), (void**)&c->pos_nrm2))) return rc;
+    if ((rc = alloc(128 * sizeof(double), (void**)&c->tap_dot))) return rc;
+    if ((rc = alloc((size_t)576 * 128 * sizeof(double), (void**)&c->tap_partial))) return rc;
+    auto put = [&](size_t off, const float* host, size_t n) {
+        if (rc == 0 && hipMemcpy(c->theta + off, host, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+            rc = fail(NOMAD_ERR_HIP, "nomad_train_enable: upload failed");
+    };
+    put(po.fln_w, w->feat_ln_w, 512); put(po.fln_b, w->feat_ln_b, 512);
+    put(po.proj_w, w->proj_w, 768 * 512); put(po.proj_b, w->proj_b, 768);
+    put(po.pos_g, w->pos_g, 128); put(po.pos_v, w->pos_v, (size_t)768 * 48 * 128); put(po.pos_b, w->pos_b, 768);
+    put(po.eln_w, w->enc_ln_w, 768); put(po.eln_b, w->enc_ln_b, 768);
+    for (int l = 0; l < NOMAD_NUM_LAYERS; ++l) {
+        const nomad_layer_weights& lw = w->layers[l];
+        const LayerOffsets& lo = po.L[l];
+        const size_t ww = 768 * 768;
+        put(lo.qkv_w, lw.q_w, ww); put(lo.qkv_w + ww, lw.k_w, ww); put(lo.qkv_w + 2 * ww, lw.v_w, ww);
+        put(lo.qkv_b, lw.q_b, 768); put(lo.qkv_b + 768, lw.k_b, 768); put(lo.qkv_b + 1536, lw.v_b, 768);
+        put(lo.o_w, lw.o_w, ww); put(lo.o_b, lw.o_b, 768);
+        put(lo.ln1_w, lw.ln1_w, 768); put(lo.ln1_b, lw.ln1_b, 768);
+        put(lo.fc1_w, lw.fc1_w, (size_t)3072 * 768); put(lo.fc1_b, lw.fc1_b, 3072);
+        put(lo.fc2_w, lw.fc2_w, (size_t)768 * 3072); put(lo.fc2_b, lw.fc2_b, 768);
+        put(lo.ln2_w, lw.ln2_w, 768); put(lo.ln2_b, lw.ln2_b, 768);
+    }
+    put(po.emb_w, w->emb_w, 256 * 768); put(po.emb_b, w->emb_b, 256);
+    if (rc) return rc;
+    // From here on the engine reads these parameters straight from the master vector (same layout as the
+    // checkpoint); only q/k/v (fused, q scaled), the pos-conv kernel and the transposes are derived copies.
+    float* th = c->theta;
+    c->fln_w = th + po.fln_w; c->fln_b = th + po.fln_b;
+    c->proj_w = th + po.proj_w; c->proj_b = th + po.proj_b;
+    c->pos_b = th + po.pos_b;
+    c->eln_w = th + po.eln_w; c->eln_b = th + po.eln_b;
+    for (int l = 0; l < NOMAD_NUM_LAYERS; ++l) {
+        LayerDev& d = c->layers[l];
+        const LayerOffsets& lo = po.L[l];
+        d.o_w = th + lo.o_w; d.o_b = th + lo.o_b;
+        d.ln1_w = th + lo.ln1_w; d.ln1_b = th + lo.ln1_b;
+        d.fc1_w = th + lo.fc1_w; d.fc1_b = th + lo.fc1_b;
+        d.fc2_w = th + lo.fc2_w; d.fc2_b = th + lo.fc2_b;
+        d.ln2_w = th + lo.ln2_w; d.ln2_b = th + lo.ln2_b;
+    }
+    c->emb_w = th + po.emb_w; c->emb_b = th + po.emb_b;
+    if ((rc = refresh_weights(c, 0))) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    c->adam_t = 0;
+    c->train_ready = true;
+    return 0;
+}
+
+int nomad_train_workspace_bytes(const nomad_ctx* c, int B, int n_samples, size_t* bytes) {
+    Shapes sh;
+    if (!c || !bytes || B <= 0 || !make_shapes(B, n_samples, &sh))
+        return fail(NOMAD_ERR_INVALID, "nomad_train_workspace_bytes: bad shape B=%d N=%d", B, n_samples);
+    *bytes = make_bwd_layout(sh, true).total;
+    return 0;
+}
+
+int nomad_train_zero_grad(nomad_ctx* c, nomad_stream_t stream) {
+    if (!c || !c->train_ready) return fail(NOMAD_ERR_INVALID, "nomad_train_zero_grad: call nomad_train_enable first");
+    HIP_TRY(hipMemsetAsync(c->grad, 0, make_param_offsets().total * sizeof(float), static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+int nomad_train_backward(nomad_ctx* c, const float* wav, int B, int n_samples, const float* layers_out, const void* saved,
+                         size_t saved_bytes, const float* demb, void* workspace, size_t workspace_bytes,
+                         nomad_stream_t stream) {
+    return backward_impl(c, wav, B, n_samples, nullptr, nullptr, layers_out, saved, saved_bytes, nullptr, demb, nullptr,
+                         workspace, workspace_bytes, stream, true);
+}
+
+int nomad_triplet_loss(nomad_ctx* c, const float* a, const float* p, const float* n, int B, float margin, float* loss,
+                       float* da, float* dp, float* dn, nomad_stream_t stream) {
+    if (!c || !a || !p || !n || !loss || B <= 0 || (da && (!dp || !dn)))
+        return fail(NOMAD_ERR_INVALID, "nomad_triplet_loss: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Scope sc(c, s, NOMAD_K_ROW, 0.0);
+    hipLaunchKernelGGL(triplet_loss_kernel, dim3(1), dim3(256), 0, s, a, p, n, B, margin, loss, da, dp, dn);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int nomad_train_adam_step(nomad_ctx* c, float lr_body, float lr_head, float beta1, float beta2, float eps,
+                          nomad_stream_t stream) {
+    if (!c || !c->train_ready) return fail(NOMAD_ERR_INVALID, "nomad_train_adam_step: call nomad_train_enable first");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const ParamOffsets po = make_param_offsets();
+    c->adam_t += 1;
+    const double bc1 = 1.0 - std::pow((double)beta1, (double)c->adam_t);
+    const double bc2 = 1.0 - std::pow((double)beta2, (double)c->adam_t);
+    const long long n4 = (long long)po.total / 4;
+    {
+        Scope sc(c, s, NOMAD_K_ROW, 0.0);
+        hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, reinterpret_cast<float4*>(c->theta),
+                           reinterpret_cast<const float4*>(c->grad), reinterpret_cast<float4*>(c->adam_m),
+                           reinterpret_cast<float4*>(c->adam_v), n4, (long long)po.emb_w / 4, lr_body, lr_head, beta1, beta2,
+                           eps, (float)bc1, (float)std::sqrt(bc2));
+    }
+    HIP_TRY(hipGetLastError());
+    return refresh_weights(c, s);
+}
+
+// what: 0 parameters, 1 gradients, 2 Adam exp_avg, 3 Adam exp_avg_sq.  Device-to-device on the stream.
+static float* train_buffer(nomad_ctx* c, int what) {
+    switch (what) {
+        case 0: return c->theta;
+        case 1: return c->grad;
+        case 2: return c->adam_m;
+        case 3: return c->adam_v;
+        default: return nullptr;
+    }
+}
+
+int nomad_train_read(nomad_ctx* c, int what, float* dst_dev, nomad_stream_t stream) {
+    if (!c || !c->train_ready || !dst_dev || !train_buffer(c, what))
+        return fail(NOMAD_ERR_INVALID, "nomad_train_read: bad argument");
+    HIP_TRY(hipMemcpyAsync(dst_dev, train_buffer(c, what), make_param_offsets().total * sizeof(float),
+                           hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+int nomad_train_write(nomad_ctx* c, int what, const float* src_dev, nomad_stream_t stream) {
+    if (!c || !c->train_ready || !src_dev || !train_buffer(c, what))
+        return fail(NOMAD_ERR_INVALID, "nomad_train_write: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemcpyAsync(train_buffer(c, what), src_dev, make_param_offsets().total * sizeof(float),
+                           hipMemcpyDeviceToDevice, s));
+    return what == 0 ? refresh_weights(c, s) : 0;
+}
+
+int nomad_train_set_step(nomad_ctx* c, long long step) {
+    if (!c || !c->train_ready || step < 0) return fail(NOMAD_ERR_INVALID, "nomad_train_set_step: bad argument");
+    c->adam_t = step;
     return 0;
 }
 
@@ -1490,15 +1965,15 @@ int nomad_diag_gemm(nomad_ctx* c, const float* A, const float* W, const float* b
     const int group_m = (tile % 10000) / 100;
     tile %= 100;
     static const int kBN[] = {128, 64, 64, 128, 128, 256, 128, 256, 256, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128,
-                              128, 128, 128, 128, 256, 256, 128, 256, 64, 64, 64, 128, 128, 128, 64, 128, 32, 64, 32, 32};
+                              128, 128, 128, 128, 256, 256, 128, 256, 64, 64, 64, 128, 128, 128, 64, 128, 32, 64, 32, 32, 256, 256};
     static const int kBK[] = {32, 16, 32, 16, 32, 32, 16, 32, 16, 16, 16, 32, 32, 16, 32, 32, 32, 16, 16, 16,
-                              32, 16, 16, 32, 16, 32, 16, 16, 16, 32, 32, 32, 16, 16, 32, 32, 32, 32, 32, 32};
+                              32, 16, 16, 32, 16, 32, 16, 16, 16, 32, 32, 32, 16, 16, 32, 32, 32, 32, 32, 32, 16, 16};
     if (tile == 48) {
         if (N != 48 || K % 16) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile 48 needs N == 48 and K %% 16 == 0");
         GemmParams p48 = dense(A, K, W, bias, R, C, M, N, K, gelu);
         return run_gemm(c, p48, 1, 48, static_cast<hipStream_t>(stream));
     }
-    if (tile < 0 || tile > 39) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile id %d", tile);
+    if (tile < 0 || tile > 41) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile id %d", tile);
     const int bn = kBN[tile], bk = kBK[tile];
     if (N % bn || K % bk) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: N %% %d or K %% %d != 0", bn, bk);
     GemmParams p = dense(A, K, W, bias, R, C, M, N, K, gelu);

@@ -1,0 +1,435 @@
+// Parameter-gradient and optimiser kernels for the triplet fine-tuning step
+// (/root/reference/src/training/train_triplet.py:112-133: A/P/N forward, nn.TripletMarginLoss, loss.backward(),
+// Adam step).  The reference trains with freeze_convnet: True
+// (src/config/train_triplet.yaml), so the trainable set is everything after the conv feature extractor.
+//
+// Every weight gradient dW[out][in] = sum_m dY[m][out] X[m][in] is the SAME fp32 MFMA GEMM kernel as the forward:
+// the two operands are transposed (zero-padded along the contraction) by transpose_pad_kernel and the long
+// contraction is split across workgroups as "groups" whose partial products are folded in fixed order by
+// splitk_reduce_kernel - deterministic, no atomics.  This file holds the rest: bias / LayerNorm / head / pos-conv
+// (weight-norm) parameter gradients, the triplet loss, dropout, and Adam.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "gemm_f32.hip.h"
+#include "rowops.hip.h"
+
+namespace nomad {
+
+// out[c][m] = f(in[m][c]) for m < M, 0 for M <= m < ld_out (ld_out % 32 == 0).  ACT: 0 identity, 1 GELU (the fc2
+// input is recomputed from the saved pre-activation).  grid: (ld_out/32, ceil(C/32)), block (32, 8).
+template <int ACT>
+__global__ void transpose_pad_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ out, int ld_out, int M,
+                                     int C) {
+    __shared__ float tile[32][33];
+    const int m0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int m = m0 + i, c = c0 + threadIdx.x;
+        float v = (m < M && c < C) ? in[(long long)m * ld_in + c] : 0.f;
+        if (ACT == 1) v = gelu_erf(v);
+        tile[i][threadIdx.x] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int c = c0 + i, m = m0 + threadIdx.x;
+        if (c < C) out[(long long)c * ld_out + m] = tile[threadIdx.x][i];
+    }
+}
+
+// out[i] += scale * sum_s partial[s * stride4 + i], s in fixed order, i < count4 (float4 units).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float4* __restrict__ partial, int S, long long stride4,
+                                                            long long count4, float4* __restrict__ out, float scale) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count4) return;
+    float4 a = partial[i];
+    for (int s = 1; s < S; ++s) {
+        const float4 b = partial[(long long)s * stride4 + i];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    float4 o = out[i];
+    o.x = fmaf(scale, a.x, o.x); o.y = fmaf(scale, a.y, o.y); o.z = fmaf(scale, a.z, o.z); o.w = fmaf(scale, a.w, o.w);
+    out[i] = o;
+}
+
+// Bias gradient from the transposed dY: out[r] += scale * sum_m in[r][m].  One wave per row; ld % 4 == 0.
+__global__ __launch_bounds__(256) void rowsum_acc_kernel(const float* __restrict__ in, int ld, int rows,
+                                                         float* __restrict__ out, float scale) {
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float4* p = reinterpret_cast<const float4*>(in + (long long)r * ld);
+    float s = 0.f;
+    for (int i = lane; i < ld / 4; i += 64) {
+        const float4 v = p[i];
+        s += (v.x + v.y) + (v.z + v.w);
+    }
+    s = wave_sum(s);
+    if (lane == 0) out[r] = fmaf(scale, s, out[r]);
+}
+
+// LayerNorm parameter gradients: dgamma[n] = sum_m g[m][n] * xhat[m][n], dbeta[n] = sum_m g[m][n]  (g = g1 + g2).
+// Stage 1: a block of 4 waves walks kLnRows rows (wave w takes rows w, w+4, ...), partial[blk][2][N].
+constexpr int kLnRows = 64;
+template <int VPT>
+__global__ __launch_bounds__(256) void ln_param_partial_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                               const float* __restrict__ g2, float* __restrict__ partial,
+                                                               int M) {
+    constexpr int N = 256 * VPT;
+    __shared__ float red[4][2][N];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float dg[VPT][4], db[VPT][4];
+#pragma unroll
+    for (int i = 0; i < VPT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dg[i][j] = db[i][j] = 0.f;
+    const int m_end = min(M, (int)(blockIdx.x + 1) * kLnRows);
+    for (int m = blockIdx.x * kLnRows + wave; m < m_end; m += 4) {
+        const float4* xr = reinterpret_cast<const float4*>(x + (long long)m * N);
+        const float4* gr = reinterpret_cast<const float4*>(g + (long long)m * N);
+        const float4* g2r = g2 ? reinterpret_cast<const float4*>(g2 + (long long)m * N) : nullptr;
+        float xv[VPT][4], gv[VPT][4];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const float4 a = xr[lane + 64 * i];
+            float4 b = gr[lane + 64 * i];
+            if (g2r) {
+                const float4 c = g2r[lane + 64 * i];
+                b.x += c.x; b.y += c.y; b.z += c.z; b.w += c.w;
+            }
+            xv[i][0] = a.x; xv[i][1] = a.y; xv[i][2] = a.z; xv[i][3] = a.w;
+            gv[i][0] = b.x; gv[i][1] = b.y; gv[i][2] = b.z; gv[i][3] = b.w;
+            s += (a.x + a.y) + (a.z + a.w);
+        }
+        const float mean = wave_sum(s) * (1.0f / N);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                xv[i][j] -= mean;
+                q += xv[i][j] * xv[i][j];
+            }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / N) + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < VPT; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                dg[i][j] = fmaf(gv[i][j], xv[i][j] * rstd, dg[i][j]);
+                db[i][j] += gv[i][j];
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            red[wave][0][4 * (lane + 64 * i) + j] = dg[i][j];
+            red[wave][1][4 * (lane + 64 * i) + j] = db[i][j];
+        }
+    __syncthreads();
+    float* p = partial + (long long)blockIdx.x * 2 * N;
+    for (int i = threadIdx.x; i < 2 * N; i += 256) {
+        const int which = i / N, n = i - which * N;
+        p[i] = (red[0][which][n] + red[1][which][n]) + (red[2][which][n] + red[3][which][n]);
+    }
+}
+
+// Stage 2: dgamma[n] += sum_blk partial[blk][0][n], dbeta[n] += sum_blk partial[blk][1][n] (block order).
+__global__ __launch_bounds__(256) void ln_param_final_kernel(const float* __restrict__ partial, int nblk, int N,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * N) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += partial[(long long)b * 2 * N + i];
+    if (i < N) dgamma[i] += s;
+    else dbeta[i - N] += s;
+}
+
+// Head parameter gradients from what head_bwd_kernel leaves behind: pooled[B][768] (after ReLU), dz[B][256].
+// dW[o][c] += sum_b dz[b][o] pooled[b][c]; db[o] += sum_b dz[b][o].  grid: 256 blocks (o) of 256 threads.
+__global__ __launch_bounds__(256) void head_param_grad_kernel(const float* __restrict__ pooled,
+                                                              const float* __restrict__ dz, int B,
+                                                              float* __restrict__ dW, float* __restrict__ db) {
+    const int o = blockIdx.x, tid = threadIdx.x;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, sb = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float d = dz[b * 256 + o];
+        const float* p = pooled + (long long)b * 768;
+        a0 = fmaf(d, p[tid], a0); a1 = fmaf(d, p[tid + 256], a1); a2 = fmaf(d, p[tid + 512], a2);
+        sb += d;
+    }
+    float* w = dW + (long long)o * 768;
+    w[tid] += a0; w[tid + 256] += a1; w[tid + 512] += a2;
+    if (tid == 0) db[o] += sb;
+}
+
+// ---- pos-conv weight gradient ----------------------------------------------------------------------------
+// Forward (group g): out[b][tau][n] = sum_{t,ci} w[g][n][t*48+ci] * xg[g][b][tau + t][ci]  (x at frames 64..64+T).
+// dw[g][t][n][ci] = sum_{b,tau} dU[b][tau][n] * xg[g][b][tau + t][ci], dU stored at frame 64 + tau of dug.
+// One workgroup: one group, kPdwTaps taps, a slice of the clips; 16x16x4 fp32 MFMA with the frames as the
+// contraction.  Wave w owns taps 2w, 2w+1 (3 x 3 tiles of 16 x 16 each).  Pad frames of both buffers are zero,
+// so chunks may run past the clip's last frame.  partial[split][g][t][n][ci].
+constexpr int kPdwTaps = 8, kPdwChunk = 64;
+__global__ __launch_bounds__(256) void posconv_dw_kernel(const float* __restrict__ dug, const float* __restrict__ xg,
+                                                         float* __restrict__ partial, int B, int T,
+                                                         int clips_per_split) {
+    __shared__ __attribute__((aligned(16))) float dUs[kPdwChunk * 48];
+    __shared__ __attribute__((aligned(16))) float Xs[(kPdwChunk + kPdwTaps) * 48];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fi = lane & 15, g4 = lane >> 4;
+    const int t0 = blockIdx.x * kPdwTaps, grp = blockIdx.y, sp = blockIdx.z;
+    const int P = T + 128;
+    f32x4 acc[2][3][3];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[a][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int b_end = min(B, (sp + 1) * clips_per_split);
+    for (int b = sp * clips_per_split; b < b_end; ++b) {
+        const float* dub = dug + ((long long)grp * B + b) * P * 48;
+        const float* xb = xg + ((long long)grp * B + b) * P * 48;
+        for (int tau0 = 0; tau0 < T; tau0 += kPdwChunk) {
+            __syncthreads();
+            // dU frames 64+tau0 .. +63 (always inside the clip's padded block), X frames tau0+t0 .. +71
+            for (int i = tid; i < kPdwChunk * 12; i += 256) {
+                const int r = i / 12, c4 = i - r * 12;
+                reinterpret_cast<float4*>(dUs)[i] = (64 + tau0 + r < P)
+                    ? reinterpret_cast<const float4*>(dub + (long long)(64 + tau0 + r) * 48)[c4]
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            for (int i = tid; i < (kPdwChunk + kPdwTaps) * 12; i += 256) {
+                const int r = i / 12, c4 = i - r * 12;
+                reinterpret_cast<float4*>(Xs)[i] = (tau0 + t0 + r < P)
+                    ? reinterpret_cast<const float4*>(xb + (long long)(tau0 + t0 + r) * 48)[c4]
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int ks = 0; ks < kPdwChunk / 4; ++ks) {
+                const int k = ks * 4 + g4;
+                float af[3], bf[2][3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) af[i] = dUs[k * 48 + i * 16 + fi];
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) bf[a][j] = Xs[(k + 2 * wave + a) * 48 + j * 16 + fi];
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j)
+                            acc[a][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[a][j], acc[a][i][j], 0, 0, 0);
+            }
+        }
+    }
+    float* out = partial + (((long long)sp * 16 + grp) * 128 + t0 + 2 * wave) * 2304;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    out[(long long)a * 2304 + (i * 16 + 4 * g4 + r) * 48 + j * 16 + fi] = acc[a][i][j][r];
+}
+
+// Fold the split partials into the checkpoint layout of weight_v: dwe[o = g*48+n][ci][t].
+// grid: 768 blocks (o) of 256 threads.
+__global__ __launch_bounds__(256) void posconv_dw_gather_kernel(const float* __restrict__ partial, int S,
+                                                                float* __restrict__ dwe) {
+    __shared__ float tile[128 * 49];
+    const int o = blockIdx.x, grp = o / 48, n = o - grp * 48;
+    for (int i = threadIdx.x; i < 128 * 48; i += 256) {
+        const int t = i / 48, ci = i - t * 48;
+        float s = 0.f;
+        for (int sp = 0; sp < S; ++sp) s += partial[((((long long)sp * 16 + grp) * 128 + t) * 48 + n) * 48 + ci];
+        tile[t * 49 + ci] = s;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 48 * 128; i += 256) {
+        const int ci = i >> 7, t = i & 127;
+        dwe[(long long)o * 6144 + i] = tile[t * 49 + ci];
+    }
+}
+
+// Per-tap sums over the (o, ci) rows of two [36864][128] arrays: out_partial[blk][t] = sum_rows a*b (b == nullptr:
+// a*a).  grid: 576 blocks of 256 threads, 64 rows each; folded by tap_sum_final_kernel.  fp64 accumulation.
+__global__ __launch_bounds__(256) void tap_dot_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                              double* __restrict__ partial) {
+    __shared__ double red[128];
+    const int t = threadIdx.x & 127, half = threadIdx.x >> 7;
+    double s = 0.0;
+    for (int r = half; r < 64; r += 2) {
+        const long long idx = ((long long)blockIdx.x * 64 + r) * 128 + t;
+        const float av = a[idx];
+        s += (double)av * (double)(b ? b[idx] : av);
+    }
+    if (half == 1) red[t] = s;
+    __syncthreads();
+    if (half == 0) partial[(long long)blockIdx.x * 128 + t] = s + red[t];
+}
+__global__ __launch_bounds__(128) void tap_sum_final_kernel(const double* __restrict__ partial, int nblk,
+                                                            double* __restrict__ out) {
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += partial[(long long)b * 128 + threadIdx.x];
+    out[threadIdx.x] = s;
+}
+
+// weight_norm(dim=2): w[o][ci][t] = v[o][ci][t] * g[t] / ||v[:, :, t]||.
+// Fold into the forward's layout pos_w[grp][64][t*48 + ci] (rows 48..63 stay zero).  grid: 768 blocks (o).
+__global__ __launch_bounds__(256) void posconv_fold_kernel(const float* __restrict__ v, const float* __restrict__ g,
+                                                           const double* __restrict__ nrm2, float* __restrict__ w) {
+    __shared__ float sc[128];
+    const int o = blockIdx.x, grp = o / 48, n = o - grp * 48;
+    if (threadIdx.x < 128) sc[threadIdx.x] = (float)((double)g[threadIdx.x] / sqrt(nrm2[threadIdx.x]));
+    __syncthreads();
+    float* dst = w + ((long long)grp * 64 + n) * 6144;
+    for (int i = threadIdx.x; i < 6144; i += 256) {  // i = ci*128 + t (coalesced read), scattered write
+        const int ci = i >> 7, t = i & 127;
+        dst[t * 48 + ci] = v[(long long)o * 6144 + i] * sc[t];
+    }
+}
+
+// Weight-norm backward: dot[t] = sum dwe*v, n = ||v_t||:  dg[t] += dot/n;  dv += g/n * (dwe - v * dot / n^2).
+__global__ __launch_bounds__(256) void posconv_wn_bwd_kernel(const float* __restrict__ dwe, const float* __restrict__ v,
+                                                             const float* __restrict__ g, const double* __restrict__ nrm2,
+                                                             const double* __restrict__ dot, float* __restrict__ dv,
+                                                             float* __restrict__ dg) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // over 768*48*128
+    const int t = (int)(i & 127);
+    const double n2 = nrm2[t], n = sqrt(n2);
+    const float a = (float)((double)g[t] / n), c = (float)(dot[t] / n2);
+    dv[i] += a * (dwe[i] - v[i] * c);
+    if (i < 128) dg[i] += (float)(dot[i] / sqrt(nrm2[i]));
+}
+
+// Column sums of the group-major padded pos-conv gradient (bias gradient): db[grp*48 + c] += sum_frames dug.
+// grid: 16 blocks (group) of 256 threads; rows = B * (T + 128) frames of 48 floats (pad frames are zero).
+__global__ __launch_bounds__(256) void posconv_bias_grad_kernel(const float* __restrict__ dug, long long rows,
+                                                                float* __restrict__ db) {
+    __shared__ float red[5][48];
+    const int grp = blockIdx.x, c = threadIdx.x % 48, part = threadIdx.x / 48;  // 5 row-parts x 48 columns = 240 threads
+    const float* base = dug + (long long)grp * rows * 48;
+    float s = 0.f;
+    if (part < 5)
+        for (long long r = part; r < rows; r += 5) s += base[r * 48 + c];
+    if (part < 5) red[part][c] = s;
+    __syncthreads();
+    if (threadIdx.x < 48)
+        db[grp * 48 + threadIdx.x] += ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x])) +
+                                      red[4][threadIdx.x];
+}
+
+// Fused q/k/v weight in the forward's layout from the master copy: rows 0..767 (q) scaled by head_dim^-0.5.
+__global__ __launch_bounds__(256) void scale_rows_kernel(const float4* __restrict__ in, float4* __restrict__ out,
+                                                         long long n4, long long n4_scaled, float scale) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 v = in[i];
+    if (i < n4_scaled) { v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale; }
+    out[i] = v;
+}
+
+// ---- nn.TripletMarginLoss(margin, p=2, eps=1e-6, reduction='mean') forward + backward -------------------------
+// d(x, y) = ||x - y + eps||_2 (torch.pairwise_distance);  loss = mean_i max(d(a,p) - d(a,n) + margin, 0).
+// One block; wave w takes rows w, w+4, ...; gradients are optional (validation pass).
+__global__ __launch_bounds__(256) void triplet_loss_kernel(const float* __restrict__ a, const float* __restrict__ p,
+                                                           const float* __restrict__ n, int B, float margin,
+                                                           float* __restrict__ loss, float* __restrict__ da,
+                                                           float* __restrict__ dp, float* __restrict__ dn) {
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float eps = 1e-6f, invB = 1.0f / (float)B;
+    float total = 0.f;
+    for (int i = wave; i < B; i += 4) {
+        const float4 av = reinterpret_cast<const float4*>(a + (long long)i * 256)[lane];
+        const float4 pv = reinterpret_cast<const float4*>(p + (long long)i * 256)[lane];
+        const float4 nv = reinterpret_cast<const float4*>(n + (long long)i * 256)[lane];
+        float ap[4] = {av.x - pv.x + eps, av.y - pv.y + eps, av.z - pv.z + eps, av.w - pv.w + eps};
+        float an[4] = {av.x - nv.x + eps, av.y - nv.y + eps, av.z - nv.z + eps, av.w - nv.w + eps};
+        const float dap = sqrtf(wave_sum((ap[0] * ap[0] + ap[1] * ap[1]) + (ap[2] * ap[2] + ap[3] * ap[3])));
+        const float dan = sqrtf(wave_sum((an[0] * an[0] + an[1] * an[1]) + (an[2] * an[2] + an[3] * an[3])));
+        const float l = dap - dan + margin;
+        total += fmaxf(l, 0.f);
+        if (da) {
+            const float on = l > 0.f ? invB : 0.f;
+            const float ip = dap > 0.f ? on / dap : 0.f, in_ = dan > 0.f ? on / dan : 0.f;
+            float4 ga, gp, gn;
+            gp.x = -ap[0] * ip; gp.y = -ap[1] * ip; gp.z = -ap[2] * ip; gp.w = -ap[3] * ip;
+            gn.x = an[0] * in_; gn.y = an[1] * in_; gn.z = an[2] * in_; gn.w = an[3] * in_;
+            ga.x = -gp.x - gn.x; ga.y = -gp.y - gn.y; ga.z = -gp.z - gn.z; ga.w = -gp.w - gn.w;
+            reinterpret_cast<float4*>(da + (long long)i * 256)[lane] = ga;
+            reinterpret_cast<float4*>(dp + (long long)i * 256)[lane] = gp;
+            reinterpret_cast<float4*>(dn + (long long)i * 256)[lane] = gn;
+        }
+    }
+    if (lane == 0) red[wave] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = ((red[0] + red[1]) + (red[2] + red[3])) * invB;
+}
+
+// ---- torch.optim.Adam (amsgrad=False, weight_decay=0), two learning rates (train_triplet.py:98-107) ------------
+// theta[i >= head_begin] uses lr_head.  bc1 = 1 - beta1^t, bc2 = 1 - beta2^t computed on the host in double.
+__global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ theta, const float4* __restrict__ grad,
+                                                   float4* __restrict__ m, float4* __restrict__ v, long long n4,
+                                                   long long head_begin4, float lr_body, float lr_head, float beta1,
+                                                   float beta2, float eps, float bc1, float sqrt_bc2) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float step = (i >= head_begin4 ? lr_head : lr_body) / bc1;
+    const float4 g = grad[i];
+    float4 mi = m[i], vi = v[i], th = theta[i];
+#define NOMAD_ADAM(c)                                                   \
+    mi.c = mi.c + (g.c - mi.c) * (1.0f - beta1);                        \
+    vi.c = vi.c * beta2 + (1.0f - beta2) * g.c * g.c;                   \
+    th.c = th.c - step * (mi.c / (sqrtf(vi.c) / sqrt_bc2 + eps));
+    NOMAD_ADAM(x) NOMAD_ADAM(y) NOMAD_ADAM(z) NOMAD_ADAM(w)
+#undef NOMAD_ADAM
+    m[i] = mi; v[i] = vi; theta[i] = th;
+}
+
+// ---- dropout (model.train(): fairseq dropout 0.1 after the encoder LayerNorm, out_proj, fc2 and on the attention
+// probabilities; dropout_input 0.1 after post_extract_proj).  Counter-based: the keep decision of element `idx` at
+// `site` is a pure function of (seed, site, idx), so the backward recomputes the mask instead of storing it. -----
+__host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+__host__ __device__ __forceinline__ uint32_t dropout_bits(uint32_t seed_lo, uint32_t seed_hi, uint32_t site,
+                                                          unsigned long long idx) {
+    uint32_t h = fmix32((uint32_t)idx ^ seed_lo ^ (site * 0x9E3779B9u));
+    h = fmix32(h + (uint32_t)(idx >> 32) * 0x85EBCA77u + seed_hi);
+    return h;
+}
+// keep <=> bits >= threshold, threshold = round(p * 2^32)
+struct DropCfg {
+    uint32_t seed_lo, seed_hi, threshold;
+    float scale;  // 1 / (1 - p)
+};
+
+// y[i] = (resid ? resid[i] : 0) + keep(i) * scale * x[i];  x == y allowed.
+__global__ __launch_bounds__(256) void dropout_add_kernel(const float4* __restrict__ x, const float4* __restrict__ resid,
+                                                          float4* __restrict__ y, long long n4, DropCfg d,
+                                                          uint32_t site) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 v = x[i];
+    const unsigned long long e = (unsigned long long)i * 4;
+    v.x = dropout_bits(d.seed_lo, d.seed_hi, site, e) >= d.threshold ? v.x * d.scale : 0.f;
+    v.y = dropout_bits(d.seed_lo, d.seed_hi, site, e + 1) >= d.threshold ? v.y * d.scale : 0.f;
+    v.z = dropout_bits(d.seed_lo, d.seed_hi, site, e + 2) >= d.threshold ? v.z * d.scale : 0.f;
+    v.w = dropout_bits(d.seed_lo, d.seed_hi, site, e + 3) >= d.threshold ? v.w * d.scale : 0.f;
+    if (resid) {
+        const float4 r = resid[i];
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    y[i] = v;
+}
+
+}  // namespace nomad

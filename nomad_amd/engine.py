@@ -63,6 +63,8 @@ class Engine:
         _lib.check(self.lib.nomad_create(C.byref(handle), self.device_index, C.byref(w)), "nomad_create")
         del keep
         self.ctx = handle
+        self._state_dict = state_dict     # host copy: nomad_train_enable re-reads it for the master parameters
+        self._train_segments = None
         self._ws: Optional[torch.Tensor] = None
         self._ws_side: Optional[torch.Tensor] = None   # second workspace for a concurrent forward on a side stream
         self._side_stream: Optional[torch.cuda.Stream] = None
@@ -280,6 +282,103 @@ class Engine:
                                                    b_emb.data_ptr(), B, T, up.data_ptr(), dl.data_ptr(), de.data_ptr(),
                                                    self._stream()), "nomad_l1_loss_backward")
         return dl, de
+
+    # ---- triplet fine-tuning step (train_triplet.py:112-133) ---------------------------------------
+    def train_enable(self):
+        """Allocate master parameters / gradients / Adam moments and re-point the engine at them."""
+        if self._train_segments is not None:
+            return
+        w, keep = _weights_struct(self._state_dict)
+        _lib.check(self.lib.nomad_train_enable(self.ctx, C.byref(w)), "nomad_train_enable")
+        del keep
+        segs = []
+        name = C.create_string_buffer(128)
+        off, cnt = C.c_size_t(), C.c_size_t()
+        for i in range(self.lib.nomad_train_num_segments()):
+            _lib.check(self.lib.nomad_train_segment(i, name, 128, C.byref(off), C.byref(cnt)), "nomad_train_segment")
+            segs.append((name.value.decode(), off.value, cnt.value))
+        self._train_segments = segs
+
+    def train_segments(self):
+        """[(checkpoint key, offset, count)] of the flat parameter vector."""
+        self.train_enable()
+        return list(self._train_segments)
+
+    def train_param_count(self) -> Tuple[int, int]:
+        total, head = C.c_size_t(), C.c_size_t()
+        _lib.check(self.lib.nomad_train_param_count(C.byref(total), C.byref(head)), "nomad_train_param_count")
+        return total.value, head.value
+
+    def train_zero_grad(self):
+        _lib.check(self.lib.nomad_train_zero_grad(self.ctx, self._stream()), "nomad_train_zero_grad")
+
+    def train_backward(self, wav: torch.Tensor, layers: torch.Tensor, saved: torch.Tensor, demb: torch.Tensor):
+        """Accumulate d loss / d parameters for one embed_train call, given d loss / d emb (B,256)."""
+        if wav.dim() == 3:
+            wav = wav.squeeze(1)
+        self._check_dev(wav, "wav")
+        self._check_dev(demb, "demb")
+        B, N = wav.shape
+        ws = self._workspace(self._size(self.lib.nomad_train_workspace_bytes, B, N, "nomad_train_workspace_bytes"))
+        _lib.check(self.lib.nomad_train_backward(self.ctx, wav.data_ptr(), B, N, layers.data_ptr(), saved.data_ptr(),
+                                                 saved.numel(), demb.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                 self._stream()), "nomad_train_backward")
+
+    def triplet_loss(self, a: torch.Tensor, p: torch.Tensor, n: torch.Tensor, margin: float, want_grad: bool = True):
+        """nn.TripletMarginLoss(margin) -> (loss (1,), da, dp, dn) (gradients None when want_grad=False)."""
+        for t, nm in ((a, "a"), (p, "p"), (n, "n")):
+            self._check_dev(t, nm)
+        B = a.shape[0]
+        loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        da, dp, dn = (torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)) if want_grad else (None, None, None)
+        _lib.check(self.lib.nomad_triplet_loss(self.ctx, a.data_ptr(), p.data_ptr(), n.data_ptr(), B, float(margin),
+                                               loss.data_ptr(), da.data_ptr() if want_grad else None,
+                                               dp.data_ptr() if want_grad else None,
+                                               dn.data_ptr() if want_grad else None, self._stream()),
+                   "nomad_triplet_loss")
+        return loss, da, dp, dn
+
+    def adam_step(self, lr_body: float, lr_head: float, betas=(0.9, 0.999), eps: float = 1e-8):
+        _lib.check(self.lib.nomad_train_adam_step(self.ctx, float(lr_body), float(lr_head), float(betas[0]),
+                                                  float(betas[1]), float(eps), self._stream()), "nomad_train_adam_step")
+
+    def train_read(self, what: int = 0) -> torch.Tensor:
+        """Flat copy of: 0 parameters, 1 gradients, 2 Adam exp_avg, 3 Adam exp_avg_sq."""
+        total, _ = self.train_param_count()
+        out = torch.empty(total, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.nomad_train_read(self.ctx, what, out.data_ptr(), self._stream()), "nomad_train_read")
+        return out
+
+    def train_write(self, what: int, flat: torch.Tensor):
+        self._check_dev(flat, "flat")
+        total, _ = self.train_param_count()
+        if flat.numel() != total:
+            raise ValueError(f"expected {total} floats, got {flat.numel()}")
+        _lib.check(self.lib.nomad_train_write(self.ctx, what, flat.data_ptr(), self._stream()), "nomad_train_write")
+
+    def train_set_step(self, step: int):
+        _lib.check(self.lib.nomad_train_set_step(self.ctx, int(step)), "nomad_train_set_step")
+
+    def train_unflatten(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """Flat vector -> {checkpoint key: CPU tensor in the checkpoint's shape}."""
+        from .weights import expected_shapes
+        shapes = expected_shapes()
+        host = flat.detach().cpu()
+        return {k: host[o:o + n].reshape(shapes[k]).clone() for k, o, n in self.train_segments()}
+
+    def train_flatten(self, tensors: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """{checkpoint key: tensor} (every trainable key) -> flat device vector."""
+        total, _ = self.train_param_count()
+        host = torch.empty(total, dtype=torch.float32)
+        for k, o, n in self.train_segments():
+            host[o:o + n] = tensors[k].detach().reshape(-1).to(torch.float32)
+        return host.to(self.device)
+
+    def train_state_dict(self) -> Dict[str, torch.Tensor]:
+        """Full checkpoint-layout state dict with the current (fine-tuned) parameters (torch.save-able)."""
+        sd = {k: v.detach().cpu().clone() for k, v in self._state_dict.items()}
+        sd.update(self.train_unflatten(self.train_read(0)))
+        return sd
 
     # ---- measurement -----------------------------------------------------------------------------
     def profile_enable(self, on: bool = True):

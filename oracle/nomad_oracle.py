@@ -197,3 +197,38 @@ def load_processing(path: str) -> torch.Tensor:
     if sr != 16000:
         raise NotImplementedError("oracle covers 16 kHz input only (all reference fixtures are 16 kHz)")
     return torch.from_numpy(np.ascontiguousarray(x))
+
+
+# ---- triplet fine-tuning step (/root/reference/src/training/train_triplet.py:112-133) ---------------------------
+# Checked in tests against torch's own autograd / torch.optim.Adam, which ARE what the reference executes for
+# these lines (nn.TripletMarginLoss, loss.backward(), torch.optim.Adam); the backbone underneath is the restatement
+# above, with its pinning status.
+
+def trainable_keys(sd: Dict[str, torch.Tensor]) -> List[str]:
+    """Parameters train_triplet.py leaves trainable with freeze_convnet: True (src/config/train_triplet.yaml):
+    everything outside ``ssl_model.feature_extractor``.  ``mask_emb`` gets no gradient with mask=False."""
+    return [k for k in sd if "feature_extractor" not in k and not k.endswith("mask_emb")]
+
+
+def triplet_step_grads(sd: Dict[str, torch.Tensor], A: torch.Tensor, Pw: torch.Tensor, N: torch.Tensor,
+                       margin: float) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+    """One eval-mode (no dropout) A/P/N forward + nn.TripletMarginLoss(margin) + backward (train_triplet.py:121-128).
+    -> (loss, {key: d loss / d parameter})."""
+    sd = {k: v.clone() for k, v in sd.items()}
+    keys = trainable_keys(sd)
+    for k in keys:
+        sd[k].requires_grad_(True)
+    ea, ep, en = triplet_forward(sd, A), triplet_forward(sd, Pw), triplet_forward(sd, N)
+    loss = torch.nn.TripletMarginLoss(margin=margin)(ea, ep, en)
+    grads = torch.autograd.grad(loss, [sd[k] for k in keys])
+    return loss.detach(), dict(zip(keys, grads))
+
+
+def make_adam(sd: Dict[str, torch.Tensor], lr: float, lr_body: float = 1e-5):
+    """The reference's optimiser (train_triplet.py:98-107): Adam, backbone at 1e-5, embedding_layer at ``lr``.
+    -> (optimizer, {key: Parameter})."""
+    head = ("embedding_layer.1.weight", "embedding_layer.1.bias")
+    params = {k: torch.nn.Parameter(sd[k].clone()) for k in trainable_keys(sd)}
+    body = [p for k, p in params.items() if k not in head]
+    opt = torch.optim.Adam([{"params": body, "lr": lr_body}, {"params": [params[k] for k in head]}], lr=lr)
+    return opt, params

@@ -1,0 +1,153 @@
+"""GPU: the triplet fine-tuning step (/root/reference/src/training/train_triplet.py:112-133)
+against torch autograd / torch.optim.Adam on the CPU oracle: loss, every parameter gradient, the Adam update,
+and that the derived kernel-layout weights follow the master copy."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nomad_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+MARGIN = 0.2
+
+
+@pytest.fixture(scope="module")
+def sd_train():
+    from nomad_amd.weights import seeded_state_dict
+    return seeded_state_dict(3, qk_gain=3.0)
+
+
+@pytest.fixture(scope="module")
+def teng(built_lib, sd_train):
+    from nomad_amd.engine import Engine
+    eng = Engine({k: v.clone() for k, v in sd_train.items()}, 0)
+    eng.train_enable()
+    yield eng
+    eng.close()
+
+
+def _triplet_batch(B, n, seed):
+    g = torch.Generator().manual_seed(seed)
+    return [(0.1 * torch.randn(B, n, generator=g)).clamp(-1, 1) for _ in range(3)]
+
+
+def _gpu_step_grads(eng, A, P, N, margin):
+    """zero_grad + the reference's three forwards + loss + backward -> (loss, flat grads)."""
+    eng.train_zero_grad()
+    outs = [eng.embed_train(w.cuda()) for w in (A, P, N)]
+    loss, da, dp, dn = eng.triplet_loss(outs[0][0], outs[1][0], outs[2][0], margin)
+    for w, (emb, layers, saved), d in zip((A, P, N), outs, (da, dp, dn)):
+        eng.train_backward(w.cuda(), layers, saved, d)
+    return loss.cpu(), eng.train_read(1)
+
+
+def test_segment_table_covers_trainable_keys(teng, sd_train):
+    from nomad_amd.weights import expected_shapes
+    shapes = expected_shapes()
+    segs = teng.train_segments()
+    total, head = teng.train_param_count()
+    assert sorted(k for k, _, _ in segs) == sorted(O.trainable_keys(sd_train))
+    spans = sorted((o, n) for _, o, n in segs)
+    assert spans[0][0] == 0 and all(a[0] + a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    assert spans[-1][0] + spans[-1][1] == total
+    for k, o, n in segs:
+        assert n == int(np.prod(shapes[k])) and o % 4 == 0
+    assert head == dict((k, o) for k, o, _ in segs)["embedding_layer.1.weight"]
+    # the master copy starts as the checkpoint
+    got = teng.train_unflatten(teng.train_read(0))
+    for k in got:
+        assert torch.equal(got[k], sd_train[k]), k
+
+
+@pytest.mark.parametrize("B,margin", [(5, 0.2), (3, 1.0), (9, 0.05)])
+def test_triplet_loss_and_gradient(teng, B, margin):
+    g = torch.Generator().manual_seed(B)
+    a, p, n = (torch.nn.functional.normalize(torch.randn(B, 256, generator=g), dim=1).requires_grad_(True) for _ in range(3))
+    ref = torch.nn.TripletMarginLoss(margin=margin)(a, p, n)
+    ga, gp, gn = torch.autograd.grad(ref, (a, p, n))
+    loss, da, dp, dn = teng.triplet_loss(a.detach().cuda(), p.detach().cuda(), n.detach().cuda(), margin)
+    assert abs(loss.item() - ref.item()) < 2e-6
+    for got, want in ((da, ga), (dp, gp), (dn, gn)):
+        assert (got.cpu() - want).abs().max().item() < 1e-6
+    loss2, none_a, _, _ = teng.triplet_loss(a.detach().cuda(), p.detach().cuda(), n.detach().cuda(), margin, want_grad=False)
+    assert none_a is None and loss2.item() == loss.item()
+
+
+@pytest.mark.parametrize("B,n,margin", [(2, 8000, 1.0), (3, 5000, MARGIN)])
+def test_parameter_gradients_match_autograd(teng, sd_train, B, n, margin):
+    A, P, N = _triplet_batch(B, n, seed=B)
+    ref_loss, ref = O.triplet_step_grads(sd_train, A, P, N, margin)
+    assert ref_loss.item() > 0  # some triplet is active, otherwise the test is vacuous
+    loss, flat = _gpu_step_grads(teng, A, P, N, margin)
+    assert abs(loss.item() - ref_loss.item()) < 2e-5
+    got = teng.train_unflatten(flat)
+    # per-tensor bound: 2e-4 of that tensor's largest gradient, plus 1e-6 of the largest gradient anywhere
+    # (k_proj.bias has an exactly-zero gradient - softmax is shift invariant - so both sides hold rounding noise)
+    top = max(v.abs().max().item() for v in ref.values())
+    worst = ("", 0.0)
+    for k, want in ref.items():
+        err = (got[k] - want).abs().max().item() / (2e-4 * want.abs().max().item() + 1e-6 * top)
+        if err > worst[1]:
+            worst = (k, err)
+    assert worst[1] < 1.0, worst
+    # global direction: cosine over the whole parameter vector
+    w = torch.cat([ref[k].reshape(-1) for k, _, _ in teng.train_segments()]).double()
+    gflat = flat.cpu().double()
+    cos = (w @ gflat / (w.norm() * gflat.norm())).item()
+    assert cos > 0.999999, cos
+
+
+def test_gradients_accumulate_and_repeat_bit_identically(teng):
+    A, P, N = _triplet_batch(2, 5000, seed=11)
+    _, g1 = _gpu_step_grads(teng, A, P, N, 1.0)
+    _, g2 = _gpu_step_grads(teng, A, P, N, 1.0)
+    assert torch.equal(g1, g2)
+    # a second backward without zero_grad doubles the gradient (A branch only here)
+    teng.train_zero_grad()
+    emb, layers, saved = teng.embed_train(A.cuda())
+    d = torch.randn(2, 256, generator=torch.Generator().manual_seed(0)).cuda()
+    teng.train_backward(A.cuda(), layers, saved, d)
+    once = teng.train_read(1)
+    teng.train_backward(A.cuda(), layers, saved, d)
+    twice = teng.train_read(1)
+    assert torch.allclose(twice, 2 * once, rtol=1e-6, atol=1e-12)
+
+
+def test_adam_matches_torch_and_weights_follow(built_lib, sd_train):
+    """Three optimiser steps with fixed gradients vs torch.optim.Adam (two learning rates, train_triplet.py:98-107);
+    afterwards the forward and the gradients of the updated model match the oracle on the updated state dict
+    (fused q/k/v, weight-normed pos-conv and the backward's transposed copies were all rebuilt)."""
+    from nomad_amd.engine import Engine
+    eng = Engine({k: v.clone() for k, v in sd_train.items()}, 0)
+    try:
+        eng.train_enable()
+        lr, lr_body = 1e-2, 1e-3  # large steps so that stale derived weights would be obvious
+        opt, params = O.make_adam(sd_train, lr=lr, lr_body=lr_body)
+        g = torch.Generator().manual_seed(5)
+        for step in range(3):
+            grads = {k: torch.randn(p.shape, generator=g) * 1e-3 for k, p in params.items()}
+            for k, p in params.items():
+                p.grad = grads[k].clone()
+            opt.step()
+            eng.train_write(1, eng.train_flatten(grads))
+            eng.adam_step(lr_body, lr)
+        got = eng.train_unflatten(eng.train_read(0))
+        for k, p in params.items():
+            assert (got[k] - p.detach()).abs().max().item() < 2e-6 * max(1.0, p.detach().abs().max().item()), k
+        new_sd = eng.train_state_dict()
+        assert set(new_sd) == set(sd_train)
+        wav = _triplet_batch(2, 6000, seed=2)[0]
+        want = O.triplet_forward(new_sd, wav)
+        have = eng.embed(wav.cuda()).cpu()
+        assert (have - want).abs().max().item() < 2e-5
+        A, P, N = _triplet_batch(2, 5000, seed=4)
+        ref_loss, ref = O.triplet_step_grads(new_sd, A, P, N, 1.0)
+        loss, flat = _gpu_step_grads(eng, A, P, N, 1.0)
+        assert abs(loss.item() - ref_loss.item()) < 5e-5
+        gg = eng.train_unflatten(flat)
+        top = max(v.abs().max().item() for v in ref.values())
+        for k, want_g in ref.items():
+            assert (gg[k] - want_g).abs().max().item() < 5e-4 * want_g.abs().max().item() + 1e-6 * top, k
+    finally:
+        eng.close()
