@@ -177,6 +177,12 @@ int nomad_embed_backward(nomad_ctx* ctx, const float* wav_dev, int B, int n_samp
  *   nomad_train_read / write  copy a whole vector out of / into the context (device pointers, async on stream);
  *                             what: 0 parameters, 1 gradients, 2 exp_avg, 3 exp_avg_sq
  *   nomad_train_set_step      set Adam's step counter (resume)
+ *   nomad_train_set_stochastic   model.train() regularisation for the following nomad_embed_train /
+ *                             nomad_train_backward calls: fairseq's dropout (after the encoder LayerNorm, out_proj
+ *                             and fc2), attention_dropout (softmax probabilities), dropout_input (after
+ *                             post_extract_proj) and LayerDrop (layer_mask bit l clear = layer l skipped).  Masks are a
+ *                             counter-based hash of (seed, site, element): set the SAME values before a forward
+ *                             and before its backward.  All zero + mask 0xFFF (the default) = eval-mode arithmetic.
  */
 int nomad_train_param_count(size_t* total, size_t* head_begin);
 int nomad_train_num_segments(void);
@@ -195,6 +201,8 @@ int nomad_train_adam_step(nomad_ctx* ctx, float lr_body, float lr_head, float be
 int nomad_train_read(nomad_ctx* ctx, int what, float* dst_dev, nomad_stream_t stream);
 int nomad_train_write(nomad_ctx* ctx, int what, const float* src_dev, nomad_stream_t stream);
 int nomad_train_set_step(nomad_ctx* ctx, long long step);
+int nomad_train_set_stochastic(nomad_ctx* ctx, float dropout, float attention_dropout, float dropout_input,
+                               unsigned long long seed, unsigned layer_mask);
 
 /* ---- bf16 path (BASELINE config C5: long-form clips) ---------------------------------------- */
 /*

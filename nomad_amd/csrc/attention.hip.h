@@ -20,6 +20,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "dropout.hip.h"
 #include "dtypes.hip.h"
 #include "gemm_f32.hip.h"
 
@@ -32,10 +33,13 @@ __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp
 
 // One 64-key tile for one wave: NSUB = number of 16-key sub-tiles that hold at least one valid key,
 // `valid` = number of valid keys in the tile (keys >= valid are masked to -inf).
-template <int NSUB>
+// DROP: attention dropout (training) - the probabilities that multiply V are masked and rescaled, the softmax
+// normaliser l_run is not (fairseq: dropout(softmax(scores)) @ v).  drow = ((b*12+h)*T + q)*T + first key of the tile.
+template <int NSUB, bool DROP = false>
 __device__ __forceinline__ void attn_tile(const float* __restrict__ Ks, const float* __restrict__ Vs,
                                           const float4 (&qf)[4], f32x4 (&o)[4], float& m_run, float& l_run, int qi,
-                                          int g, int valid) {
+                                          int g, int valid, const DropCfg* dc = nullptr, uint32_t site = 0,
+                                          unsigned long long drow = 0) {
     f32x4 s[NSUB];
 #pragma unroll
     for (int i = 0; i < NSUB; ++i) s[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -72,8 +76,8 @@ __device__ __forceinline__ void attn_tile(const float* __restrict__ Ks, const fl
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float pv = fast_exp(s[sub][r] - m_new);
-            s[sub][r] = pv;
             psum += pv;
+            s[sub][r] = DROP ? pv * drop_mult(*dc, site, drow + (sub * 16 + g * 4 + r)) : pv;
         }
     l_run = l_run * alpha + psum;  // per-lane partial (this lane's keys); folded across g at the end
     m_run = m_new;
@@ -94,10 +98,11 @@ __device__ __forceinline__ void attn_tile(const float* __restrict__ Ks, const fl
 // lse (nullable): [B*12][T] log-sum-exp of every score row, saved for the backward pass.
 // T_ = storage type of qkv / out (fp32 or bf16); the arithmetic is fp32 MFMA either way.
 // tpref (nullable): ragged batches - clip b owns rows tpref[b] .. tpref[b+1]-1 of qkv / out.
-template <typename T_ = float>
+template <typename T_ = float, bool DROP = false>
 __global__ __launch_bounds__(256) void attention_f32_kernel(const T_* __restrict__ qkv, T_* __restrict__ out,
                                                             float* __restrict__ lse, int T,
-                                                            const int* __restrict__ tpref = nullptr) {
+                                                            const int* __restrict__ tpref = nullptr,
+                                                            DropCfg dc = DropCfg{}, uint32_t site = 0) {
     __shared__ __attribute__((aligned(16))) float Ks[64 * kAttnLD];
     __shared__ __attribute__((aligned(16))) float Vs[64 * kAttnLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -156,11 +161,12 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const T_* __restrict
         if (kt + 1 < ntiles) fetch(kt + 1);
         if (!wave_active) continue;
         const int valid = T - kt * 64;  // valid keys in this tile (>= 1)
-        if (valid >= 64) attn_tile<4>(Ks, Vs, qf, o, m_run, l_run, qi, g, 64);
-        else if (valid > 48) attn_tile<4>(Ks, Vs, qf, o, m_run, l_run, qi, g, valid);
-        else if (valid > 32) attn_tile<3>(Ks, Vs, qf, o, m_run, l_run, qi, g, valid);
-        else if (valid > 16) attn_tile<2>(Ks, Vs, qf, o, m_run, l_run, qi, g, valid);
-        else attn_tile<1>(Ks, Vs, qf, o, m_run, l_run, qi, g, valid);
+        const unsigned long long drow = ((unsigned long long)bh * T + q_ld) * T + kt * 64;
+        if (valid >= 64) attn_tile<4, DROP>(Ks, Vs, qf, o, m_run, l_run, qi, g, 64, &dc, site, drow);
+        else if (valid > 48) attn_tile<4, DROP>(Ks, Vs, qf, o, m_run, l_run, qi, g, valid, &dc, site, drow);
+        else if (valid > 32) attn_tile<3, DROP>(Ks, Vs, qf, o, m_run, l_run, qi, g, valid, &dc, site, drow);
+        else if (valid > 16) attn_tile<2, DROP>(Ks, Vs, qf, o, m_run, l_run, qi, g, valid, &dc, site, drow);
+        else attn_tile<1, DROP>(Ks, Vs, qf, o, m_run, l_run, qi, g, valid, &dc, site, drow);
     }
 
     float l_tot = l_run + __shfl_xor(l_run, 16);

@@ -9,6 +9,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "dropout.hip.h"
 #include "gemm_f32.hip.h"
 #include "rowops.hip.h"
 
@@ -239,9 +240,12 @@ __device__ __forceinline__ void ab_load_tile(float* dst, const float* src, long 
 }
 
 // Computes P and dS for the (q tile, k tile) pair held in LDS; thread -> 4 entries (qi = tid>>3, kj = (tid&7)*4..+3)
+// Attention dropout (dc.threshold > 0): O = (P * Mk) V with Mk = mask / (1 - p), so Ps receives P * Mk (what dV
+// contracts with) and dS = P * (dP * Mk - D); D = rowsum(dO * O) is unchanged.  drow0 = (b*12+h)*T.
 __device__ __forceinline__ void ab_scores(const float* Qs, const float* Ks, const float* Vs, const float* dOs,
                                           const float* lse_s, const float* D_s, float* Ps, float* dSs, int q0, int k0,
-                                          int T, int tid) {
+                                          int T, int tid, const DropCfg& dc, uint32_t site,
+                                          unsigned long long drow0) {
     const int qi = tid >> 3, kj0 = (tid & 7) * 4;
     float s[4] = {0.f, 0.f, 0.f, 0.f}, dp[4] = {0.f, 0.f, 0.f, 0.f};
     for (int d = 0; d < 64; ++d) {
@@ -257,8 +261,9 @@ __device__ __forceinline__ void ab_scores(const float* Qs, const float* Ks, cons
     for (int j = 0; j < 4; ++j) {
         const bool ok = q_ok && (k0 + kj0 + j < T);
         const float pv = ok ? expf(s[j] - lse_s[qi]) : 0.f;
-        Ps[qi * 33 + kj0 + j] = pv;
-        dSs[qi * 33 + kj0 + j] = pv * (dp[j] - D_s[qi]);
+        const float mk = (dc.threshold != 0 && ok) ? drop_mult(dc, site, (drow0 + q0 + qi) * T + k0 + kj0 + j) : 1.0f;
+        Ps[qi * 33 + kj0 + j] = pv * mk;
+        dSs[qi * 33 + kj0 + j] = pv * (dp[j] * mk - D_s[qi]);
     }
 }
 
@@ -279,7 +284,8 @@ __device__ __forceinline__ void ab_row_stats(const float* dOs, const float* Os, 
 
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
                                                            const float* __restrict__ dO, const float* __restrict__ lse,
-                                                           float* __restrict__ dqkv, int T) {
+                                                           float* __restrict__ dqkv, int T, DropCfg dc = DropCfg{},
+                                                           uint32_t site = 0) {
     __shared__ float Qs[kAB * kABLD], Ks[kAB * kABLD], Vs[kAB * kABLD], dOs[kAB * kABLD], Os[kAB * kABLD];
     __shared__ float Ps[kAB * 33], dSs[kAB * 33], lse_s[kAB], D_s[kAB];
     const int tid = threadIdx.x, bh = blockIdx.y, b = bh / 12, h = bh - b * 12;
@@ -303,7 +309,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
         __syncthreads();
         ab_row_stats(dOs, Os, lb, lse_s, D_s, q0, T, tid);
         __syncthreads();
-        ab_scores(Qs, Ks, Vs, dOs, lse_s, D_s, Ps, dSs, q0, k0, T, tid);
+        ab_scores(Qs, Ks, Vs, dOs, lse_s, D_s, Ps, dSs, q0, k0, T, tid, dc, site, (unsigned long long)bh * T);
         __syncthreads();
         for (int qi = 0; qi < kAB; ++qi) {
             const float pv = Ps[qi * 33 + kj], ds = dSs[qi * 33 + kj];
@@ -326,7 +332,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
 
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
                                                           const float* __restrict__ dO, const float* __restrict__ lse,
-                                                          float* __restrict__ dqkv, int T) {
+                                                          float* __restrict__ dqkv, int T, DropCfg dc = DropCfg{},
+                                                          uint32_t site = 0) {
     __shared__ float Qs[kAB * kABLD], Ks[kAB * kABLD], Vs[kAB * kABLD], dOs[kAB * kABLD], Os[kAB * kABLD];
     __shared__ float Ps[kAB * 33], dSs[kAB * 33], lse_s[kAB], D_s[kAB];
     const int tid = threadIdx.x, bh = blockIdx.y, b = bh / 12, h = bh - b * 12;
@@ -349,7 +356,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
         ab_load_tile(Ks, qb + 768, 2304, k0, T, tid);
         ab_load_tile(Vs, qb + 1536, 2304, k0, T, tid);
         __syncthreads();
-        ab_scores(Qs, Ks, Vs, dOs, lse_s, D_s, Ps, dSs, q0, k0, T, tid);
+        ab_scores(Qs, Ks, Vs, dOs, lse_s, D_s, Ps, dSs, q0, k0, T, tid, dc, site, (unsigned long long)bh * T);
         __syncthreads();
         for (int kj = 0; kj < kAB; ++kj) {
             const float ds = dSs[qi * 33 + kj];

@@ -281,6 +281,10 @@ struct nomad_ctx {
     float *theta = nullptr, *grad = nullptr, *adam_m = nullptr, *adam_v = nullptr;
     double *pos_nrm2 = nullptr, *tap_partial = nullptr, *tap_dot = nullptr;
     long long adam_t = 0;
+    // model.train() regularisation applied by nomad_embed_train / nomad_train_backward (nomad_train_set_stochastic)
+    float p_drop = 0.f, p_attn = 0.f, p_input = 0.f;
+    unsigned long long drop_seed = 0;
+    unsigned layer_mask = 0xFFFu;  // bit l set: encoder layer l runs (LayerDrop clears bits)
     std::vector<void*> allocs;
     std::vector<int> ragged_meta;  // host copy of the last ragged batch's metadata (source of an async H2D copy)
     // profiling
@@ -445,10 +449,36 @@ int run_layernorm(nomad_ctx* c, const float* in, const float* g, const float* b,
     return 0;
 }
 
-int run_attention(nomad_ctx* c, const float* qkv, float* out, float* lse, int B, int T, hipStream_t s) {
+DropCfg make_drop(const nomad_ctx* c, float p) {
+    DropCfg d{};
+    d.seed_lo = (uint32_t)c->drop_seed;
+    d.seed_hi = (uint32_t)(c->drop_seed >> 32);
+    const double t = (double)p * 4294967296.0;
+    d.threshold = p <= 0.f ? 0u : (t >= 4294967295.0 ? 4294967295u : (uint32_t)(t + 0.5));
+    d.scale = 1.0f / (1.0f - p);
+    return d;
+}
+
+int run_attention(nomad_ctx* c, const float* qkv, float* out, float* lse, int B, int T, hipStream_t s,
+                  const DropCfg* dc = nullptr, uint32_t site = 0) {
     const double flops = 4.0 * B * 12.0 * (double)T * T * 64;
     Scope sc(c, s, NOMAD_K_ATTN, flops);
-    hipLaunchKernelGGL(attention_f32_kernel<float>, dim3((T + 63) / 64, B * 12), dim3(256), 0, s, qkv, out, lse, T, kNoInts);
+    const dim3 grid((T + 63) / 64, B * 12);
+    if (dc && dc->threshold)
+        hipLaunchKernelGGL((attention_f32_kernel<float, true>), grid, dim3(256), 0, s, qkv, out, lse, T, kNoInts, *dc, site);
+    else
+        hipLaunchKernelGGL((attention_f32_kernel<float, false>), grid, dim3(256), 0, s, qkv, out, lse, T, kNoInts, DropCfg{}, 0u);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// y = (resid ? resid : 0) + dropout(x) over n floats of an [M][768] tensor (x == y allowed)
+int run_dropout(nomad_ctx* c, const float* x, const float* resid, float* y, long long n, const DropCfg& d, uint32_t site,
+                hipStream_t s) {
+    Scope sc(c, s, NOMAD_K_ROW, 0.0);
+    hipLaunchKernelGGL(dropout_add_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s,
+                       reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(resid),
+                       reinterpret_cast<float4*>(y), n / 4, d, site);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -622,6 +652,12 @@ static int forward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, co
     auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     const int T = sh.T, M = sh.M;
     int rc;
+    // model.train() regularisation: only in the training-mode forward, only when switched on
+    const bool reg = sv != nullptr;
+    const DropCfg d_in = make_drop(c, reg ? c->p_input : 0.f), d_res = make_drop(c, reg ? c->p_drop : 0.f),
+                  d_att = make_drop(c, reg ? c->p_attn : 0.f);
+    const unsigned layer_mask = reg ? c->layer_mask : 0xFFFu;
+    const long long act = (long long)M * 768;
 
     // ---- front end: conv0 + GroupNorm + GELU ------------------------------------------------
     double* stats = reinterpret_cast<double*>(ws + lay.stats);
@@ -679,6 +715,10 @@ static int forward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, co
         p.c_colblk_stride = grp_stride;
         if ((rc = run_gemm(c, p, 1, pick_tile(M, 768, 512), s))) return rc;
     }
+    if (d_in.threshold) {  // dropout_input: on the features that feed both the pos-conv and its residual
+        Scope sc(c, s, NOMAD_K_ROW, 0.0);
+        hipLaunchKernelGGL(dropout_groups_kernel, dim3(M), dim3(192), 0, s, xpad, T, grp_stride, d_in, kSiteInput);
+    }
     // ---- pos-conv: 16 groups x (M x 48 x 6144), x + gelu(conv + bias) -------------------------
     {
         GemmParams p{};
@@ -709,28 +749,39 @@ static int forward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, co
     float* x2 = F(lay.x2);
     float* y = F(lay.y);
     if ((rc = run_layernorm(c, sv ? sv->y0 : y, c->eln_w, c->eln_b, x, nullptr, M, 768, s))) return rc;
+    if (d_res.threshold && (rc = run_dropout(c, x, nullptr, x, act, d_res, kSiteEncoder, s))) return rc;
 
     // ---- 12 post-LN transformer layers --------------------------------------------------------
     for (int l = 0; l < NOMAD_NUM_LAYERS; ++l) {
         const LayerDev& d = c->layers[l];
+        float* lo = layers_out ? layers_out + (size_t)l * M * 768 : nullptr;
+        if (!((layer_mask >> l) & 1u)) {  // LayerDrop: the layer is the identity for this call
+            if (lo) HIP_TRY(hipMemcpyAsync(lo, x, sizeof(float) * act, hipMemcpyDeviceToDevice, s));
+            continue;
+        }
         float* qkv = sv ? sv->L[l].qkv : F(lay.qkv);
         float* ctxb = sv ? sv->L[l].ctx : F(lay.ctxb);
         float* y1 = sv ? sv->L[l].y1 : y;
         float* y2 = sv ? sv->L[l].y2 : y;
         if ((rc = run_gemm(c, dense(x, 768, d.qkv_w, d.qkv_b, nullptr, qkv, M, 2304, 768, 0), 1, pick_tile(M, 2304, 768), s)))
             return rc;
-        if ((rc = run_attention(c, qkv, ctxb, sv ? sv->L[l].lse : nullptr, B, T, s))) return rc;
-        if ((rc = run_gemm(c, dense(ctxb, 768, d.o_w, d.o_b, x, y1, M, 768, 768, 0), 1, pick_tile(M, 768, 768), s)))
+        if ((rc = run_attention(c, qkv, ctxb, sv ? sv->L[l].lse : nullptr, B, T, s, &d_att, site_attn(l)))) return rc;
+        // residual dropout: y = x + dropout(W a + b) needs the branch on its own, so the residual add moves out
+        // of the GEMM epilogue into the dropout kernel
+        if ((rc = run_gemm(c, dense(ctxb, 768, d.o_w, d.o_b, d_res.threshold ? nullptr : x, y1, M, 768, 768, 0), 1,
+                           pick_tile(M, 768, 768), s)))
             return rc;
+        if (d_res.threshold && (rc = run_dropout(c, y1, x, y1, act, d_res, site_proj(l), s))) return rc;
         if ((rc = run_layernorm(c, y1, d.ln1_w, d.ln1_b, x2, nullptr, M, 768, s))) return rc;
         {
             GemmParams p = dense(x2, 768, d.fc1_w, d.fc1_b, nullptr, F(lay.h), M, 3072, 768, 1);
             p.Upre = sv ? sv->L[l].u : nullptr;
             if ((rc = run_gemm(c, p, 1, pick_tile(M, 3072, 768), s))) return rc;
         }
-        if ((rc = run_gemm(c, dense(F(lay.h), 3072, d.fc2_w, d.fc2_b, x2, y2, M, 768, 3072, 0), 1, pick_tile(M, 768, 3072), s)))
+        if ((rc = run_gemm(c, dense(F(lay.h), 3072, d.fc2_w, d.fc2_b, d_res.threshold ? nullptr : x2, y2, M, 768, 3072, 0), 1,
+                           pick_tile(M, 768, 3072), s)))
             return rc;
-        float* lo = layers_out ? layers_out + (size_t)l * M * 768 : nullptr;
+        if (d_res.threshold && (rc = run_dropout(c, y2, x2, y2, act, d_res, site_ffn(l), s))) return rc;
         if ((rc = run_layernorm(c, y2, d.ln2_w, d.ln2_b, x, lo, M, 768, s))) return rc;
     }
 
@@ -1376,6 +1427,12 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
     const int T = sh.T, M = sh.M;
     float *gx = F(lay.gx), *dya = F(lay.dya), *dyb = F(lay.dyb), *dh = F(lay.dh), *dqkv = F(lay.dqkv);
     int rc;
+    // the regularisation of the forward this backward belongs to (the caller re-sets it: nomad_train_set_stochastic)
+    const DropCfg d_in = make_drop(c, train ? c->p_input : 0.f), d_res = make_drop(c, train ? c->p_drop : 0.f),
+                  d_att = make_drop(c, train ? c->p_attn : 0.f);
+    const unsigned layer_mask = train ? c->layer_mask : 0xFFFu;
+    const long long act = (long long)M * 768;
+    float* dmask = train ? F(lay.dmask) : nullptr;
 
     // ---- parameter-gradient helpers (train only) ---------------------------------------------------------
     const ParamOffsets po = make_param_offsets();
@@ -1416,15 +1473,22 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
         const SavedLayer& sl = sv.L[l];
         const LayerOffsets& lo = po.L[l];
         const float* dl = dlayers ? dlayers + (size_t)l * M * 768 : nullptr;
+        if (!((layer_mask >> l) & 1u)) continue;  // LayerDrop: identity in the forward, identity here
         if ((rc = run_ln_bwd(c, sl.y2, gx, dl, d.ln2_w, dya, M, 768, s))) return rc;                   // dy2
+        // dy2 feeds the residual as is and the fc2 branch through its dropout mask
+        const float* dy2b = dya;
+        if (d_res.threshold) {
+            if ((rc = run_dropout(c, dya, nullptr, dmask, act, d_res, site_ffn(l), s))) return rc;
+            dy2b = dmask;
+        }
         if (train) {
             ln_params(sl.y2, gx, dl, 768, G(lo.ln2_w), G(lo.ln2_b));
-            tpose(dya, 768, TA, false);
+            tpose(dy2b, 768, TA, false);
             rowsum(TA, 768, G(lo.fc2_b), 1.0f);
             tpose(sl.u, 3072, TB, true);  // h = gelu(u), recomputed
             if ((rc = dw_gemm(c, TA, TB, 768, 3072, Mp, part, G(lo.fc2_w), 0, 1.0f, s))) return rc;
         }
-        if ((rc = bwd_gemm(c, dya, c->fc2_wT[l], dh, M, 3072, 768, sl.u, nullptr, s))) return rc;      // du = (dy2 W2) * gelu'(u)
+        if ((rc = bwd_gemm(c, dy2b, c->fc2_wT[l], dh, M, 3072, 768, sl.u, nullptr, s))) return rc;     // du = (dy2 W2) * gelu'(u)
         if (train) {
             tpose(dh, 3072, TA, false);
             rowsum(TA, 3072, G(lo.fc1_b), 1.0f);
@@ -1435,19 +1499,26 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
         }
         if ((rc = bwd_gemm(c, dh, c->fc1_wT[l], dyb, M, 768, 3072, nullptr, dya, s))) return rc;       // dx1 = du W1 + dy2
         if ((rc = run_ln_bwd(c, sl.y1, dyb, nullptr, d.ln1_w, dya, M, 768, s))) return rc;             // dy1
+        if (train) ln_params(sl.y1, dyb, nullptr, 768, G(lo.ln1_w), G(lo.ln1_b));
+        const float* dy1b = dya;  // dy1 through out_proj's dropout mask
+        if (d_res.threshold) {
+            if ((rc = run_dropout(c, dya, nullptr, dmask, act, d_res, site_proj(l), s))) return rc;
+            dy1b = dmask;
+        }
         if (train) {
-            ln_params(sl.y1, dyb, nullptr, 768, G(lo.ln1_w), G(lo.ln1_b));
-            tpose(dya, 768, TA, false);
+            tpose(dy1b, 768, TA, false);
             rowsum(TA, 768, G(lo.o_b), 1.0f);
             tpose(sl.ctx, 768, TB, false);
             if ((rc = dw_gemm(c, TA, TB, 768, 768, Mp, part, G(lo.o_w), 0, 1.0f, s))) return rc;
         }
-        if ((rc = bwd_gemm(c, dya, c->o_wT[l], dyb, M, 768, 768, nullptr, nullptr, s))) return rc;     // dctx
+        if ((rc = bwd_gemm(c, dy1b, c->o_wT[l], dyb, M, 768, 768, nullptr, nullptr, s))) return rc;    // dctx
         {
             Scope sc(c, s, NOMAD_K_ATTN, 10.0 * B * 12.0 * (double)T * T * 64);
             const dim3 grid((T + kAB - 1) / kAB, B * 12);
-            hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, s, sl.qkv, sl.ctx, dyb, sl.lse, dqkv, T);
-            hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, s, sl.qkv, sl.ctx, dyb, sl.lse, dqkv, T);
+            hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, s, sl.qkv, sl.ctx, dyb, sl.lse, dqkv, T, d_att,
+                               site_attn(l));
+            hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, s, sl.qkv, sl.ctx, dyb, sl.lse, dqkv, T, d_att,
+                               site_attn(l));
         }
         if (train) {
             // the forward's fused weight holds q scaled by head_dim^-0.5: d q_proj = 0.125 * d fused rows 0..767
@@ -1455,8 +1526,9 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
             rowsum(TA, 768, G(lo.qkv_b), 0.125f);
             rowsum(TA + (size_t)768 * Mp, 1536, G(lo.qkv_b) + 768, 1.0f);
             const float* xin = layers_out + (size_t)(l > 0 ? l - 1 : 0) * M * 768;
-            if (l == 0) {  // layer 0 reads LayerNorm(y0): recomputed into dyb (dctx has been consumed)
+            if (l == 0) {  // layer 0 reads dropout(LayerNorm(y0)): recomputed into dyb (dctx has been consumed)
                 if ((rc = run_layernorm(c, sv.y0, c->eln_w, c->eln_b, dyb, nullptr, M, 768, s))) return rc;
+                if (d_res.threshold && (rc = run_dropout(c, dyb, nullptr, dyb, act, d_res, kSiteEncoder, s))) return rc;
                 xin = dyb;
             }
             tpose(xin, 768, TB, false);
@@ -1465,6 +1537,7 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
         if ((rc = bwd_gemm(c, dqkv, c->qkv_wT[l], gx, M, 768, 2304, nullptr, dya, s))) return rc;      // dx_in = dqkv Wqkv + dy1
     }
     // ---- encoder input: LayerNorm, x + gelu(pos_conv(x)) --------------------------------------------
+    if (d_res.threshold && (rc = run_dropout(c, gx, nullptr, gx, act, d_res, kSiteEncoder, s))) return rc;
     if ((rc = run_ln_bwd(c, sv.y0, gx, nullptr, c->eln_w, dya, M, 768, s))) return rc;                   // dy0
     if (train) ln_params(sv.y0, gx, nullptr, 768, G(po.eln_w), G(po.eln_b));
     const long long grp_stride = (long long)B * (T + 128) * 48;
@@ -1515,6 +1588,10 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
             p.c_colblk_stride = grp_stride;
             if ((rc = run_gemm(c, p, 1, pick_tile(M, 768, 512), s))) return rc;
         }
+        if (d_in.threshold) {
+            Scope sc(c, s, NOMAD_K_ROW, 0.0);
+            hipLaunchKernelGGL(dropout_groups_kernel, dim3(M), dim3(192), 0, s, xg, T, grp_stride, d_in, kSiteInput);
+        }
         {
             const int S = lay.pos_split, cps = (B + S - 1) / S;
             Scope sc(c, s, NOMAD_K_GEMM, 2.0 * M * 768.0 * 48 * 128);
@@ -1525,7 +1602,8 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
             hipLaunchKernelGGL(posconv_wn_bwd_kernel, dim3(768 * 48 * 128 / 256), dim3(256), 0, s, dwe, c->theta + po.pos_v,
                                c->theta + po.pos_g, c->pos_nrm2, c->tap_dot, G(po.pos_v), G(po.pos_g));
         }
-        // ---- post_extract_proj parameters ---------------------------------------------------------------
+        // ---- post_extract_proj parameters (its output went through dropout_input) ------------------------
+        if (d_in.threshold && (rc = run_dropout(c, dyb, nullptr, dyb, act, d_in, kSiteInput, s))) return rc;
         tpose(dyb, 768, TA, false);
         rowsum(TA, 768, G(po.proj_b), 1.0f);
         tpose(featln, 512, TB, false);
@@ -1870,6 +1948,19 @@ int nomad_train_write(nomad_ctx* c, int what, const float* src_dev, nomad_stream
     HIP_TRY(hipMemcpyAsync(train_buffer(c, what), src_dev, make_param_offsets().total * sizeof(float),
                            hipMemcpyDeviceToDevice, s));
     return what == 0 ? refresh_weights(c, s) : 0;
+}
+
+int nomad_train_set_stochastic(nomad_ctx* c, float dropout, float attention_dropout, float dropout_input,
+                               unsigned long long seed, unsigned layer_mask) {
+    auto bad = [](float p) { return !(p >= 0.f && p < 1.f); };
+    if (!c || bad(dropout) || bad(attention_dropout) || bad(dropout_input))
+        return fail(NOMAD_ERR_INVALID, "nomad_train_set_stochastic: probabilities must be in [0, 1)");
+    c->p_drop = dropout;
+    c->p_attn = attention_dropout;
+    c->p_input = dropout_input;
+    c->drop_seed = seed;
+    c->layer_mask = layer_mask & 0xFFFu;
+    return 0;
 }
 
 int nomad_train_set_step(nomad_ctx* c, long long step) {

@@ -13,6 +13,7 @@
 
 #include <cstdint>
 
+#include "dropout.hip.h"
 #include "gemm_f32.hip.h"
 #include "rowops.hip.h"
 
@@ -394,25 +395,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ theta, c
     m[i] = mi; v[i] = vi; theta[i] = th;
 }
 
-// ---- dropout (model.train(): fairseq dropout 0.1 after the encoder LayerNorm, out_proj, fc2 and on the attention
-// probabilities; dropout_input 0.1 after post_extract_proj).  Counter-based: the keep decision of element `idx` at
-// `site` is a pure function of (seed, site, idx), so the backward recomputes the mask instead of storing it. -----
-__host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
-    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
-    return h;
-}
-__host__ __device__ __forceinline__ uint32_t dropout_bits(uint32_t seed_lo, uint32_t seed_hi, uint32_t site,
-                                                          unsigned long long idx) {
-    uint32_t h = fmix32((uint32_t)idx ^ seed_lo ^ (site * 0x9E3779B9u));
-    h = fmix32(h + (uint32_t)(idx >> 32) * 0x85EBCA77u + seed_hi);
-    return h;
-}
-// keep <=> bits >= threshold, threshold = round(p * 2^32)
-struct DropCfg {
-    uint32_t seed_lo, seed_hi, threshold;
-    float scale;  // 1 / (1 - p)
-};
-
+// ---- dropout (dropout.hip.h) -------------------------------------------------------------------------------
 // y[i] = (resid ? resid[i] : 0) + keep(i) * scale * x[i];  x == y allowed.
 __global__ __launch_bounds__(256) void dropout_add_kernel(const float4* __restrict__ x, const float4* __restrict__ resid,
                                                           float4* __restrict__ y, long long n4, DropCfg d,
@@ -421,15 +404,27 @@ __global__ __launch_bounds__(256) void dropout_add_kernel(const float4* __restri
     if (i >= n4) return;
     float4 v = x[i];
     const unsigned long long e = (unsigned long long)i * 4;
-    v.x = dropout_bits(d.seed_lo, d.seed_hi, site, e) >= d.threshold ? v.x * d.scale : 0.f;
-    v.y = dropout_bits(d.seed_lo, d.seed_hi, site, e + 1) >= d.threshold ? v.y * d.scale : 0.f;
-    v.z = dropout_bits(d.seed_lo, d.seed_hi, site, e + 2) >= d.threshold ? v.z * d.scale : 0.f;
-    v.w = dropout_bits(d.seed_lo, d.seed_hi, site, e + 3) >= d.threshold ? v.w * d.scale : 0.f;
+    v.x *= drop_mult(d, site, e); v.y *= drop_mult(d, site, e + 1);
+    v.z *= drop_mult(d, site, e + 2); v.w *= drop_mult(d, site, e + 3);
     if (resid) {
         const float4 r = resid[i];
         v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
     }
     y[i] = v;
+}
+
+// In-place dropout of the group-major pos-conv input xg[grp][clip][64 + t][48] (element index m*768 + c as if the
+// tensor were the plain [M][768] post_extract_proj output).  grid: M blocks of 192 threads.
+__global__ __launch_bounds__(192) void dropout_groups_kernel(float* __restrict__ xg, int T, long long grp_stride,
+                                                             DropCfg d, uint32_t site) {
+    const int m = blockIdx.x, b = m / T, t = m - b * T;
+    const int col = threadIdx.x * 4, grp = col / 48, cc = col - grp * 48;
+    float4* p = reinterpret_cast<float4*>(xg + grp * grp_stride + ((long long)b * (T + 128) + 64 + t) * 48 + cc);
+    const unsigned long long e = (unsigned long long)m * 768 + col;
+    float4 v = *p;
+    v.x *= drop_mult(d, site, e); v.y *= drop_mult(d, site, e + 1);
+    v.z *= drop_mult(d, site, e + 2); v.w *= drop_mult(d, site, e + 3);
+    *p = v;
 }
 
 }  // namespace nomad

@@ -356,6 +356,13 @@ class Engine:
             raise ValueError(f"expected {total} floats, got {flat.numel()}")
         _lib.check(self.lib.nomad_train_write(self.ctx, what, flat.data_ptr(), self._stream()), "nomad_train_write")
 
+    def train_set_stochastic(self, dropout: float = 0.0, attention_dropout: float = 0.0, dropout_input: float = 0.0,
+                             seed: int = 0, layer_mask: int = 0xFFF):
+        """model.train() regularisation for the following embed_train / train_backward calls (defaults = eval)."""
+        _lib.check(self.lib.nomad_train_set_stochastic(self.ctx, float(dropout), float(attention_dropout),
+                                                       float(dropout_input), int(seed) & (2 ** 64 - 1),
+                                                       int(layer_mask) & 0xFFF), "nomad_train_set_stochastic")
+
     def train_set_step(self, step: int):
         _lib.check(self.lib.nomad_train_set_step(self.ctx, int(step)), "nomad_train_set_step")
 

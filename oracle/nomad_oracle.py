@@ -68,8 +68,10 @@ def feature_extractor(sd: Dict[str, torch.Tensor], wav: torch.Tensor, taps: Opti
     return x.transpose(1, 2)
 
 
-def encoder_layer(sd: Dict[str, torch.Tensor], l: int, x: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
-    """One post-LN TransformerSentenceEncoderLayer (layer_norm_first=False), eval mode. x: (B,T,768)."""
+def encoder_layer(sd: Dict[str, torch.Tensor], l: int, x: torch.Tensor, taps: Optional[dict] = None,
+                  stoch: Optional["Stochastic"] = None) -> torch.Tensor:
+    """One post-LN TransformerSentenceEncoderLayer (layer_norm_first=False). x: (B,T,768).
+    stoch=None is eval mode; otherwise fairseq's train-mode dropouts with the engine's counter-based masks."""
     q_ = P + f"encoder.layers.{l}."
     B, T, C = x.shape
     hd = C // NUM_HEADS
@@ -79,20 +81,27 @@ def encoder_layer(sd: Dict[str, torch.Tensor], l: int, x: torch.Tensor, taps: Op
     q = q.view(B, T, NUM_HEADS, hd).transpose(1, 2)
     k = k.view(B, T, NUM_HEADS, hd).transpose(1, 2)
     v = v.view(B, T, NUM_HEADS, hd).transpose(1, 2)
-    a = torch.softmax(q @ k.transpose(-1, -2), dim=-1) @ v
+    probs = torch.softmax(q @ k.transpose(-1, -2), dim=-1)
+    if stoch is not None:
+        probs = probs * stoch.mult(2 + 3 * l, probs.shape, stoch.attention_dropout)
+    a = probs @ v
     a = a.transpose(1, 2).reshape(B, T, C)
     if taps is not None and l == 0:
         taps["attn0"] = a
     a = F.linear(a, sd[q_ + "self_attn.out_proj.weight"], sd[q_ + "self_attn.out_proj.bias"])
+    if stoch is not None:
+        a = a * stoch.mult(3 + 3 * l, a.shape, stoch.dropout)
     x = F.layer_norm(x + a, (C,), sd[q_ + "self_attn_layer_norm.weight"], sd[q_ + "self_attn_layer_norm.bias"], 1e-5)
     h = F.gelu(F.linear(x, sd[q_ + "fc1.weight"], sd[q_ + "fc1.bias"]))
     h = F.linear(h, sd[q_ + "fc2.weight"], sd[q_ + "fc2.bias"])
+    if stoch is not None:
+        h = h * stoch.mult(4 + 3 * l, h.shape, stoch.dropout)
     x = F.layer_norm(x + h, (C,), sd[q_ + "final_layer_norm.weight"], sd[q_ + "final_layer_norm.bias"], 1e-5)
     return x
 
 
-def backbone(sd: Dict[str, torch.Tensor], wav: torch.Tensor, taps: Optional[dict] = None
-             ) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+def backbone(sd: Dict[str, torch.Tensor], wav: torch.Tensor, taps: Optional[dict] = None,
+             stoch: Optional["Stochastic"] = None) -> Tuple[torch.Tensor, List[torch.Tensor]]:
     """wav (B,N) -> (x (B,T,768), [12 layer outputs (B,T,768)]).
 
     The reference gets ``layer_results`` as (T,B,768) tuples and permutes them to (B,T,768)
@@ -101,6 +110,8 @@ def backbone(sd: Dict[str, torch.Tensor], wav: torch.Tensor, taps: Optional[dict
     x = feature_extractor(sd, wav, taps)
     x = F.layer_norm(x, (512,), sd[P + "layer_norm.weight"], sd[P + "layer_norm.bias"], 1e-5)
     x = F.linear(x, sd[P + "post_extract_proj.weight"], sd[P + "post_extract_proj.bias"])
+    if stoch is not None:  # dropout_input
+        x = x * stoch.mult(0, x.shape, stoch.dropout_input)
     if taps is not None:
         taps["proj"] = x
     w = fold_pos_conv_weight(sd)
@@ -108,11 +119,14 @@ def backbone(sd: Dict[str, torch.Tensor], wav: torch.Tensor, taps: Optional[dict
     pc = pc[:, :, :-1]  # SamePad: even kernel drops the last frame
     x = x + F.gelu(pc).transpose(1, 2)
     x = F.layer_norm(x, (768,), sd[P + "encoder.layer_norm.weight"], sd[P + "encoder.layer_norm.bias"], 1e-5)
+    if stoch is not None:  # TransformerEncoder: F.dropout(x, p=self.dropout) after the LayerNorm
+        x = x * stoch.mult(1, x.shape, stoch.dropout)
     if taps is not None:
         taps["enc_in"] = x
     layers = []
     for l in range(NUM_LAYERS):
-        x = encoder_layer(sd, l, x, taps)
+        if stoch is None or (stoch.layer_mask >> l) & 1:  # LayerDrop: a dropped layer is the identity
+            x = encoder_layer(sd, l, x, taps, stoch)
         layers.append(x)
     return x, layers
 
@@ -123,11 +137,11 @@ def head(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return F.normalize(e, dim=1)
 
 
-def triplet_forward(sd: Dict[str, torch.Tensor], wav: torch.Tensor) -> torch.Tensor:
+def triplet_forward(sd: Dict[str, torch.Tensor], wav: torch.Tensor, stoch: Optional["Stochastic"] = None) -> torch.Tensor:
     """``TripletModel.forward`` (nomad.py:224-231): wav (B,1,N) or (B,N) -> (B,256) unit-norm."""
     if wav.dim() == 3:
         wav = wav.squeeze(1)
-    x, _ = backbone(sd, wav)
+    x, _ = backbone(sd, wav, stoch=stoch)
     return head(x, sd["embedding_layer.1.weight"], sd["embedding_layer.1.bias"])
 
 
@@ -210,15 +224,57 @@ def trainable_keys(sd: Dict[str, torch.Tensor]) -> List[str]:
     return [k for k in sd if "feature_extractor" not in k and not k.endswith("mask_emb")]
 
 
+class Stochastic:
+    """model.train() regularisation of one forward call, with the ENGINE's mask generator restated
+    (nomad_amd/csrc/dropout.hip.h: keep <=> hash(seed, site, element) >= round(p * 2^32)).
+
+    Which elements fairseq's own dropout would drop depends on torch's RNG stream of the device it runs on and is
+    not reproducible anywhere else; what the restatement pins is WHERE dropout is applied and HOW (sites, scaling,
+    softmax normaliser untouched, LayerDrop as identity) - fairseq wav2vec2.py / transformer_sentence_encoder_layer
+    semantics - given the same masks on both sides."""
+
+    def __init__(self, seed: int, dropout: float = 0.1, attention_dropout: float = 0.1, dropout_input: float = 0.1,
+                 layer_mask: int = 0xFFF):
+        self.seed, self.dropout, self.attention_dropout = int(seed), float(dropout), float(attention_dropout)
+        self.dropout_input, self.layer_mask = float(dropout_input), int(layer_mask)
+
+    @staticmethod
+    def _fmix32(h: np.ndarray) -> np.ndarray:
+        h = h ^ (h >> np.uint32(16))
+        h = h * np.uint32(0x85EBCA6B)
+        h = h ^ (h >> np.uint32(13))
+        h = h * np.uint32(0xC2B2AE35)
+        return h ^ (h >> np.uint32(16))
+
+    def mult(self, site: int, shape, p: float) -> torch.Tensor:
+        """Per-element multiplier (1/(1-p) kept, 0 dropped) for a C-ordered tensor of ``shape``."""
+        p32 = np.float32(p)
+        if p32 <= 0:
+            return torch.ones(tuple(shape))
+        t = float(p32) * 4294967296.0
+        threshold = np.uint32(4294967295 if t >= 4294967295.0 else int(t + 0.5))
+        n = int(np.prod(shape))
+        idx = np.arange(n, dtype=np.uint64)
+        lo, hi = np.uint32(self.seed & 0xFFFFFFFF), np.uint32((self.seed >> 32) & 0xFFFFFFFF)
+        with np.errstate(over="ignore"):
+            h = self._fmix32(idx.astype(np.uint32) ^ lo ^ np.uint32((site * 0x9E3779B9) & 0xFFFFFFFF))
+            h = self._fmix32(h + (idx >> np.uint64(32)).astype(np.uint32) * np.uint32(0x85EBCA77) + hi)
+        scale = np.float32(1.0) / (np.float32(1.0) - p32)
+        return torch.from_numpy(np.where(h >= threshold, scale, np.float32(0)).astype(np.float32).reshape(tuple(shape)))
+
+
 def triplet_step_grads(sd: Dict[str, torch.Tensor], A: torch.Tensor, Pw: torch.Tensor, N: torch.Tensor,
-                       margin: float) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
-    """One eval-mode (no dropout) A/P/N forward + nn.TripletMarginLoss(margin) + backward (train_triplet.py:121-128).
+                       margin: float, stoch: Optional[Sequence[Optional[Stochastic]]] = None
+                       ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+    """One A/P/N forward + nn.TripletMarginLoss(margin) + backward (train_triplet.py:121-128).
+    stoch: None = eval-mode arithmetic, or one Stochastic per branch (A, P, N).
     -> (loss, {key: d loss / d parameter})."""
+    st = list(stoch) if stoch is not None else [None, None, None]
     sd = {k: v.clone() for k, v in sd.items()}
     keys = trainable_keys(sd)
     for k in keys:
         sd[k].requires_grad_(True)
-    ea, ep, en = triplet_forward(sd, A), triplet_forward(sd, Pw), triplet_forward(sd, N)
+    ea, ep, en = triplet_forward(sd, A, st[0]), triplet_forward(sd, Pw, st[1]), triplet_forward(sd, N, st[2])
     loss = torch.nn.TripletMarginLoss(margin=margin)(ea, ep, en)
     grads = torch.autograd.grad(loss, [sd[k] for k in keys])
     return loss.detach(), dict(zip(keys, grads))

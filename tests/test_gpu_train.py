@@ -151,3 +151,73 @@ def test_adam_matches_torch_and_weights_follow(built_lib, sd_train):
             assert (gg[k] - want_g).abs().max().item() < 5e-4 * want_g.abs().max().item() + 1e-6 * top, k
     finally:
         eng.close()
+
+
+# ---- model.train(): dropout / attention dropout / dropout_input / LayerDrop -------------------------------------
+def _gpu_step_grads_stoch(eng, A, P, N, margin, stochs):
+    """Like _gpu_step_grads, with one regularisation setting per branch, re-set before each backward."""
+    def apply(st):
+        eng.train_set_stochastic(st.dropout, st.attention_dropout, st.dropout_input, st.seed, st.layer_mask)
+    eng.train_zero_grad()
+    outs = []
+    for w, st in zip((A, P, N), stochs):
+        apply(st)
+        outs.append(eng.embed_train(w.cuda()))
+    loss, da, dp, dn = eng.triplet_loss(outs[0][0], outs[1][0], outs[2][0], margin)
+    for w, (emb, layers, saved), d, st in zip((A, P, N), outs, (da, dp, dn), stochs):
+        apply(st)
+        eng.train_backward(w.cuda(), layers, saved, d)
+    eng.train_set_stochastic()  # back to eval-mode arithmetic
+    return loss.cpu(), [o[0].cpu() for o in outs], eng.train_read(1)
+
+
+@pytest.mark.parametrize("case", ["all", "residual_only", "attention_only", "input_only", "layerdrop_only"])
+def test_train_mode_matches_oracle_with_the_same_masks(teng, sd_train, case):
+    B, n, margin = 2, 6000, 1.0
+    A, P, N = _triplet_batch(B, n, seed=21)
+    kw = {"all": dict(dropout=0.1, attention_dropout=0.1, dropout_input=0.1),
+          "residual_only": dict(dropout=0.2, attention_dropout=0.0, dropout_input=0.0),
+          "attention_only": dict(dropout=0.0, attention_dropout=0.3, dropout_input=0.0),
+          "input_only": dict(dropout=0.0, attention_dropout=0.0, dropout_input=0.25),
+          "layerdrop_only": dict(dropout=0.0, attention_dropout=0.0, dropout_input=0.0)}[case]
+    masks = (0xFFF, 0xFFF, 0xFFF) if case not in ("all", "layerdrop_only") else (0xFFF & ~(1 << 3), 0xFFE, 0x7FF & ~(1 << 6))
+    stochs = [O.Stochastic(seed=(0x1234567 << 20) + 977 * i, layer_mask=m, **kw) for i, m in enumerate(masks)]
+    ref_loss, ref = O.triplet_step_grads(sd_train, A, P, N, margin, stochs)
+    loss, embs, flat = _gpu_step_grads_stoch(teng, A, P, N, margin, stochs)
+    for e, w, st in zip(embs, (A, P, N), stochs):
+        assert (e - O.triplet_forward(sd_train, w, st)).abs().max().item() < 2e-5
+    assert abs(loss.item() - ref_loss.item()) < 5e-5
+    got = teng.train_unflatten(flat)
+    top = max(v.abs().max().item() for v in ref.values())
+    worst = ("", 0.0)
+    for k, want in ref.items():
+        err = (got[k] - want).abs().max().item() / (2e-4 * want.abs().max().item() + 1e-6 * top)
+        if err > worst[1]:
+            worst = (k, err)
+    assert worst[1] < 1.0, worst
+
+
+def test_train_mode_differs_from_eval_and_is_seed_deterministic(teng):
+    A = _triplet_batch(2, 6000, seed=5)[0].cuda()
+    teng.train_set_stochastic()
+    e_eval = teng.embed_train(A)[0].clone()
+    assert torch.equal(e_eval, teng.embed(A))  # training-mode forward without regularisation == scoring forward
+    teng.train_set_stochastic(0.1, 0.1, 0.1, seed=7)
+    e1 = teng.embed_train(A)[0].clone()
+    e2 = teng.embed_train(A)[0].clone()
+    teng.train_set_stochastic(0.1, 0.1, 0.1, seed=8)
+    e3 = teng.embed_train(A)[0].clone()
+    teng.train_set_stochastic()
+    assert torch.equal(e1, e2) and not torch.equal(e1, e3) and not torch.equal(e1, e_eval)
+    assert torch.equal(teng.embed(A), e_eval)  # scoring is never regularised
+
+
+def test_dropout_keep_rate(teng):
+    """The counter-based generator drops about p of the elements at every site (statistics of the oracle's
+    restated mask; the engine uses the same masks, as the parity test above shows)."""
+    st = O.Stochastic(seed=99)
+    for site in (0, 1, 2, 17, 37):
+        m = st.mult(site, (4, 50, 768), 0.1)
+        assert abs((m == 0).float().mean().item() - 0.1) < 0.005
+    a, b = st.mult(3, (1000,), 0.5), st.mult(4, (1000,), 0.5)
+    assert 0.35 < ((a == 0) == (b == 0)).float().mean().item() < 0.65  # sites are independent
