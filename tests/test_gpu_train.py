@@ -1,6 +1,8 @@
 """GPU: the triplet fine-tuning step (/root/reference/src/training/train_triplet.py:112-133)
 against torch autograd / torch.optim.Adam on the CPU oracle: loss, every parameter gradient, the Adam update,
 and that the derived kernel-layout weights follow the master copy."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -221,3 +223,93 @@ def test_dropout_keep_rate(teng):
         assert abs((m == 0).float().mean().item() - 0.1) < 0.005
     a, b = st.mult(3, (1000,), 0.5), st.mult(4, (1000,), 0.5)
     assert 0.35 < ((a == 0) == (b == 0)).float().mean().item() < 0.65  # sites are independent
+
+
+# ---- the Training class (host-side mirror of train_triplet.py) ------------------------------------------------------
+def _write_wav(path, x, sr=16000):
+    import struct
+    pcm = (np.clip(x, -1, 1) * 32767).astype("<i2").tobytes()
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 36 + len(pcm)) + b"WAVEfmt " +
+                struct.pack("<IHHIIHH", 16, 1, 1, sr, sr * 2, 2, 16) + b"data" + struct.pack("<I", len(pcm)) + pcm)
+
+
+def _toy_dataset(tmp_path, n_rows=6):
+    import pandas as pd
+    rng = np.random.RandomState(0)
+    rows = []
+    for i in range(n_rows):
+        base = 0.1 * rng.randn(6000 + 700 * (i % 3))
+        names = {}
+        for role, noise in (("Anchor", 0.0), ("Positive", 0.01), ("Negative", 0.2)):
+            name = f"/{role}_{i}.wav"
+            _write_wav(str(tmp_path) + name, base + noise * rng.randn(base.size))
+            names[role] = name
+        rows.append(dict(db=1 + i % 2, **names))
+    csv = str(tmp_path / "triplets.csv")
+    pd.DataFrame(rows).to_csv(csv, index=False)
+    return csv
+
+
+def _config(tmp_path, csv, **over):
+    cfg = dict(experiment_name="Training", out_dir="toy", training_script="src.training.train_triplet", root=str(tmp_path),
+               train_df=csv, valid_df=csv, sampling_rate=16000, train_bs=3, val_bs=3, test_bs=1, lr=1e-4,
+               lr_decay_factor=0.5, lr_decay_step=1, num_epochs=2, num_workers=0, emb_dim=256, patience=200,
+               checkpoint_path="seeded", ssl_out_dim=768, margin=0.2, freeze_convnet=True, freeze_all=False,
+               current_level=[1, 2], trim=True, eval_w2v=False)
+    cfg.update(over)
+    return cfg
+
+
+def test_training_class_step_matches_torch_training_step(tmp_path):
+    """One Training.train_step in eval-mode arithmetic == the reference's lines 121-131 executed by torch on the CPU
+    oracle: zero_grad, three forwards, TripletMarginLoss, backward, Adam(1e-5 backbone / lr head)."""
+    from nomad_amd.train import Training
+    csv = _toy_dataset(tmp_path)
+    tr = Training(_config(tmp_path, csv), regularisation=dict(dropout=0.0, attention_dropout=0.0, dropout_input=0.0,
+                                                              encoder_layerdrop=0.0))
+    try:
+        sd = tr.engine.train_state_dict()
+        A, P, N = next(iter(tr.valid_loader))
+        assert A.shape[0] == 3 and A.dim() == 3 and A.shape == P.shape == N.shape  # zero padded to the batch maximum
+        opt, params = O.make_adam(sd, lr=1e-4)
+        sd_live = dict(sd)
+        sd_live.update(params)
+        loss_ref = torch.nn.TripletMarginLoss(margin=0.2)(*(O.triplet_forward(sd_live, w) for w in (A, P, N)))
+        opt.zero_grad()
+        loss_ref.backward()
+        opt.step()
+        loss = tr.train_step(A, P, N)
+        assert abs(loss.item() - loss_ref.item()) < 2e-5
+        got = tr.engine.train_unflatten(tr.engine.train_read(0))
+        for k, p in params.items():
+            # first Adam step moves every coordinate by ~lr * sign(g); compare the update itself
+            upd_ref, upd = p.detach() - sd[k], got[k] - sd[k]
+            lr_k = 1e-4 if k.startswith("embedding_layer") else 1e-5
+            frac_bad = ((upd - upd_ref).abs() > 0.05 * lr_k).float().mean().item()
+            assert frac_bad < 2e-3, (k, frac_bad)  # sign flips only where |g| is at rounding level
+    finally:
+        tr.engine.close()
+
+
+def test_training_loop_runs_and_saves_a_loadable_checkpoint(tmp_path, monkeypatch):
+    from nomad_amd.train import Training
+    from nomad_amd.weights import load_checkpoint
+    csv = _toy_dataset(tmp_path)
+    monkeypatch.chdir(tmp_path)
+    tr = Training(_config(tmp_path, csv, lr=1e-3))
+    try:
+        before = tr.eval()
+        best = tr.training_loop()
+        assert np.isfinite(best)
+        assert tr.lr_scheduler.get_last_lr()[1] < 1e-3  # lr_decay_step = 1: ExponentialLR stepped
+        path = os.path.join(tr.PATH_DIR, "best_model.pt")
+        sd = load_checkpoint(path)  # same key layout as nomad_best_model.pt, loadable by the scoring path
+        assert os.path.isfile(os.path.join(tr.PATH_DIR, "config.yaml"))
+        changed = [k for k in O.trainable_keys(sd) if not torch.equal(sd[k], tr.engine._state_dict[k])]
+        frozen_same = all(torch.equal(sd[k], tr.engine._state_dict[k]) for k in sd if "feature_extractor" in k)
+        assert len(changed) > 150 and frozen_same
+        after = tr.eval()
+        assert after < before + 0.05  # two tiny epochs: the validation loss does not blow up
+    finally:
+        tr.engine.close()

@@ -98,3 +98,63 @@ def test_partition_covers_everything():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---- nomad_amd.train host logic (no GPU) -----------------------------------------------------------------------------
+def test_triplet_dataset_collate_and_schedule(tmp_path):
+    import struct
+    import numpy as np
+    import pandas as pd
+    import torch
+    from nomad_amd.train import ExponentialLR, TripletDataset
+
+    def write(path, n, sr=16000):
+        pcm = (np.clip(0.1 * np.random.RandomState(n).randn(n), -1, 1) * 32767).astype("<i2").tobytes()
+        with open(path, "wb") as f:
+            f.write(b"RIFF" + struct.pack("<I", 36 + len(pcm)) + b"WAVEfmt " +
+                    struct.pack("<IHHIIHH", 16, 1, 1, sr, sr * 2, 2, 16) + b"data" + struct.pack("<I", len(pcm)) + pcm)
+
+    rows = []
+    for i, n in enumerate((3000, 170000, 5000)):  # the middle one is longer than 10 s
+        for role in ("Anchor", "Positive", "Negative"):
+            write(str(tmp_path / f"{role}_{i}.wav"), n + 10 * len(role))
+        rows.append(dict(Anchor=f"/Anchor_{i}.wav", Positive=f"/Positive_{i}.wav", Negative=f"/Negative_{i}.wav", db=1 + (i == 2)))
+    rows.append(dict(rows[0]))  # duplicate row: dropped (triplet_dataloader.py:46)
+    csv = str(tmp_path / "t.csv")
+    pd.DataFrame(rows).to_csv(csv, index=False)
+    cfg = dict(root=str(tmp_path), train_df=csv, trim=True)
+    ds = TripletDataset(cfg, "train_df", level=[1, 2])
+    assert len(ds) == 3
+    assert len(TripletDataset(cfg, "train_df", level=[2])) == 1
+    a, p, n = ds[1]
+    assert a.shape == (1, 160000) and p.shape == (1, 160000)  # trimmed to 10 s
+    A, P, N = ds.collate_fn([ds[0], ds[2]])
+    assert A.shape == (2, 1, 5000 + 60) and A.dtype == torch.float32
+    assert torch.all(A[0, 0, 3060:] == 0) and A[0, 0, :3060].abs().sum() > 0  # zero padded to the batch maximum
+    cfg["trim"] = False
+    assert TripletDataset(cfg, "train_df")[1][0].shape == (1, 170060)
+    sch = ExponentialLR([1e-5, 1e-4], 0.99)
+    sch.step(); sch.step()
+    ref = torch.optim.lr_scheduler.ExponentialLR(torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=1e-4), gamma=0.99)
+    ref.optimizer.step(); ref.step(); ref.step()
+    assert abs(sch.get_last_lr()[1] - ref.get_last_lr()[0]) < 1e-12 and abs(sch.get_last_lr()[0] - 1e-5 * 0.99 ** 2) < 1e-15
+
+
+def test_load_pretrained_accepts_a_fairseq_style_checkpoint(tmp_path):
+    import torch
+    from nomad_amd.train import load_pretrained
+    from nomad_amd.weights import check_state_dict, seeded_state_dict
+    sd = seeded_state_dict(4)
+    model = {k[len("ssl_model."):]: v for k, v in sd.items() if k.startswith("ssl_model.")}
+    model["quantizer.vars"] = torch.zeros(3)          # pre-training modules the reference removes
+    model["final_proj.weight"] = torch.zeros(2, 2)
+    path = str(tmp_path / "wav2vec_small.pt")
+    torch.save({"model": model, "cfg": {"whatever": 1}}, path)
+    got = load_pretrained(path)
+    check_state_dict(got)
+    assert all(torch.equal(got[k], sd[k]) for k in sd if k.startswith("ssl_model."))
+    w = got["embedding_layer.1.weight"]
+    assert w.shape == (256, 768) and w.abs().max() <= 1 / 768 ** 0.5 and w.std() > 0.01
+    nomad_path = str(tmp_path / "nomad.pt")
+    torch.save(sd, nomad_path)
+    assert torch.equal(load_pretrained(nomad_path)["embedding_layer.1.weight"], sd["embedding_layer.1.weight"])
