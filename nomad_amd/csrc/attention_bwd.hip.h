@@ -1,0 +1,279 @@
+// Attention backward on the matrix cores (v_mfma_f32_16x16x4_f32), flash style: the T x T probabilities are
+// recomputed from the saved log-sum-exp, nothing of size T x T touches HBM.  Deterministic: no atomics - two
+// kernels, each owning its output rows and streaming the other side through LDS:
+//
+//   attn_bwd_rowdot_kernel  D[b,h,q]   = sum_d dO[q,d] O[q,d]                                  (one pass, HBM-bound)
+//   attn_bwd_dkv_kernel     one workgroup = 64 keys of one (clip, head), wave = 16 keys, loops over query tiles:
+//       S[q][key]  = Q K^T,  dP[q][key] = dO V^T          A = Q / dO rows from LDS, B = K / V from registers
+//       P = exp(S - lse[q]),  Pm = P * Mk (attention dropout),  dS = P * (dP * Mk - D[q])
+//       dV[key][d] += sum_q Pm[q][key] dO[q][d],  dK[key][d] += sum_q dS[q][key] Q[q][d]
+//     The S / dP accumulators are directly the A operand of the second pair of products: lane (key = lane&15,
+//     g = lane>>4) holds queries {16*sub + 4g + r}, and MFMA k-step r contracts exactly those (the contraction order
+//     is free) - the same register-reuse trick as the forward kernel (attention.hip.h), mirrored.
+//   attn_bwd_dq_kernel      one workgroup = 64 queries, wave = 16 queries, loops over key tiles; the forward's own
+//     transposed layout: S^T[key][q] = K Q^T, dP^T = V dO^T (A from LDS, B = Q / dO registers), then
+//       dQ^T[d][q] += sum_key K[key][d] dS^T[key][q]        A = K from LDS, B = the dS^T accumulator itself
+//
+// qkv / dqkv: [B*T][2304] = [q (pre-scaled by 1/8) | k | v]; dO: [B*T][768]; lse, D: [B*12][T].
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "attention.hip.h"
+#include "dropout.hip.h"
+
+namespace nomad {
+
+// grid: ceil(M/4) blocks of 256 threads, one wave per row m = b*T + t; 16 lanes per head.
+__global__ __launch_bounds__(256) void attn_bwd_rowdot_kernel(const float* __restrict__ o, const float* __restrict__ dO,
+                                                              float* __restrict__ D, int M, int T) {
+    const int lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int b = m / T, t = m - b * T;
+    const float4* op = reinterpret_cast<const float4*>(o + (long long)m * 768);
+    const float4* gp = reinterpret_cast<const float4*>(dO + (long long)m * 768);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float4 a = op[lane + 64 * i], g = gp[lane + 64 * i];
+        float s = (a.x * g.x + a.y * g.y) + (a.z * g.z + a.w * g.w);
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        s += __shfl_xor(s, 8);
+        if ((lane & 15) == 0) D[((long long)b * 12 + (lane >> 4) + 4 * i) * T + t] = s;
+    }
+}
+
+// Stage a 64-row x 64-float tile (rows row0.., clamped to T-1) of a [.][ld] tensor into LDS via registers.
+__device__ __forceinline__ void abw_fetch(f32x4 (&reg)[4], const float* __restrict__ src, long long ld, int row0, int T,
+                                          int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = tid + i * 256, row = id >> 4, c4 = id & 15;
+        int r = row0 + row;
+        r = r < T ? r : T - 1;
+        reg[i] = *reinterpret_cast<const f32x4*>(src + (long long)r * ld + c4 * 4);
+    }
+}
+__device__ __forceinline__ void abw_store(float* __restrict__ dst, const f32x4 (&reg)[4], int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = tid + i * 256, row = id >> 4, c4 = id & 15;
+        *reinterpret_cast<f32x4*>(dst + row * kAttnLD + c4 * 4) = reg[i];
+    }
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dO,
+                                                           const float* __restrict__ lse, const float* __restrict__ D,
+                                                           float* __restrict__ dqkv, int T, DropCfg dc, uint32_t site) {
+    __shared__ __attribute__((aligned(16))) float Qs[64 * kAttnLD];
+    __shared__ __attribute__((aligned(16))) float Gs[64 * kAttnLD];  // dO tile
+    __shared__ __attribute__((aligned(16))) float lse_s[64];
+    __shared__ __attribute__((aligned(16))) float D_s[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fi = lane & 15, g = lane >> 4;
+    const int bh = blockIdx.y, b = bh / 12, h = bh - b * 12;
+    const int k0 = blockIdx.x * 64;
+    const float* qb = qkv + (long long)b * T * 2304 + h * 64;
+    const float* gb = dO + (long long)b * T * 768 + h * 64;
+    const float* lb = lse + (long long)bh * T;
+    const float* Db = D + (long long)bh * T;
+    const int key = k0 + wave * 16 + fi;
+    const int key_ld = key < T ? key : T - 1;
+    const bool wave_active = k0 + wave * 16 < T;  // wave-uniform
+
+    // B operands: this lane's key, d = 16*dd + 4g + c
+    f32x4 kf[4], vf[4];
+#pragma unroll
+    for (int dd = 0; dd < 4; ++dd) {
+        kf[dd] = *reinterpret_cast<const f32x4*>(qb + (long long)key_ld * 2304 + 768 + dd * 16 + g * 4);
+        vf[dd] = *reinterpret_cast<const f32x4*>(qb + (long long)key_ld * 2304 + 1536 + dd * 16 + g * 4);
+    }
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dk[i] = dv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int ntiles = (T + 63) / 64;
+    f32x4 qreg[4], greg[4];
+    float lreg = 0.f, dreg = 0.f;
+    auto fetch = [&](int qt) {
+        abw_fetch(qreg, qb, 2304, qt * 64, T, tid);
+        abw_fetch(greg, gb, 768, qt * 64, T, tid);
+        if (tid < 64) {
+            const int q = qt * 64 + tid;
+            lreg = q < T ? lb[q] : 0.f;
+            dreg = q < T ? Db[q] : 0.f;
+        }
+    };
+    fetch(0);
+    for (int qt = 0; qt < ntiles; ++qt) {
+        __syncthreads();
+        abw_store(Qs, qreg, tid);
+        abw_store(Gs, greg, tid);
+        if (tid < 64) {
+            lse_s[tid] = lreg;
+            D_s[tid] = dreg;
+        }
+        __syncthreads();
+        if (qt + 1 < ntiles) fetch(qt + 1);
+        if (!wave_active) continue;
+        const int q0 = qt * 64;
+        const int nsub = min(4, (T - q0 + 15) / 16);  // query sub-tiles holding at least one valid row (uniform)
+        for (int sub = 0; sub < nsub; ++sub) {
+            f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) {
+                const f32x4 qa = *reinterpret_cast<const f32x4*>(Qs + (sub * 16 + fi) * kAttnLD + dd * 16 + g * 4);
+                const f32x4 ga = *reinterpret_cast<const f32x4*>(Gs + (sub * 16 + fi) * kAttnLD + dd * 16 + g * 4);
+                s = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[0], kf[dd][0], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[0], vf[dd][0], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[1], kf[dd][1], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[1], vf[dd][1], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[2], kf[dd][2], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[2], vf[dd][2], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[3], kf[dd][3], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[3], vf[dd][3], dp, 0, 0, 0);
+            }
+            // lane: key (column fi), queries q0 + 16*sub + 4g + r
+            const f32x4 lv = *reinterpret_cast<const f32x4*>(lse_s + sub * 16 + g * 4);
+            const f32x4 Dv = *reinterpret_cast<const f32x4*>(D_s + sub * 16 + g * 4);
+            f32x4 pm, ds;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = q0 + sub * 16 + g * 4 + r;
+                const bool ok = q < T && key < T;
+                const float p = ok ? fast_exp(s[r] - lv[r]) : 0.f;
+                const float mk = (DROP && ok) ? drop_mult(dc, site, ((unsigned long long)bh * T + q) * T + key) : 1.0f;
+                pm[r] = p * mk;
+                ds[r] = p * (dp[r] * mk - Dv[r]);
+            }
+            // dV += Pm^T dO, dK += dS^T Q : k-step r contracts queries 16*sub + 4g + r
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float* grow = Gs + (sub * 16 + g * 4 + r) * kAttnLD + fi;
+                const float* qrow = Qs + (sub * 16 + g * 4 + r) * kAttnLD + fi;
+#pragma unroll
+                for (int di = 0; di < 4; ++di) {
+                    dv[di] = __builtin_amdgcn_mfma_f32_16x16x4f32(pm[r], grow[di * 16], dv[di], 0, 0, 0);
+                    dk[di] = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[r], qrow[di * 16], dk[di], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // accumulators: row = key 4g + r of this wave's 16, column d = 16*di + fi
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int kk = k0 + wave * 16 + g * 4 + r;
+        if (kk < T) {
+            float* dst = dqkv + ((long long)b * T + kk) * 2304 + h * 64 + fi;
+#pragma unroll
+            for (int di = 0; di < 4; ++di) {
+                dst[768 + di * 16] = dk[di][r];
+                dst[1536 + di * 16] = dv[di][r];
+            }
+        }
+    }
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ dO,
+                                                          const float* __restrict__ lse, const float* __restrict__ D,
+                                                          float* __restrict__ dqkv, int T, DropCfg dc, uint32_t site) {
+    __shared__ __attribute__((aligned(16))) float Ks[64 * kAttnLD];
+    __shared__ __attribute__((aligned(16))) float Vs[64 * kAttnLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fi = lane & 15, g = lane >> 4;
+    const int bh = blockIdx.y, b = bh / 12, h = bh - b * 12;
+    const float* qb = qkv + (long long)b * T * 2304 + h * 64;
+    const float* gb = dO + (long long)b * T * 768 + h * 64;
+    const int q = blockIdx.x * 64 + wave * 16 + fi;
+    const int q_ld = q < T ? q : T - 1;
+    const bool wave_active = blockIdx.x * 64 + wave * 16 < T;
+
+    f32x4 qf[4], gf[4];
+#pragma unroll
+    for (int dd = 0; dd < 4; ++dd) {
+        qf[dd] = *reinterpret_cast<const f32x4*>(qb + (long long)q_ld * 2304 + dd * 16 + g * 4);
+        gf[dd] = *reinterpret_cast<const f32x4*>(gb + (long long)q_ld * 768 + dd * 16 + g * 4);
+    }
+    const float lse_q = lse[(long long)bh * T + q_ld], D_q = D[(long long)bh * T + q_ld];
+    f32x4 dq[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int ntiles = (T + 63) / 64;
+    f32x4 kreg[4], vreg[4];
+    auto fetch = [&](int kt) {
+        abw_fetch(kreg, qb + 768, 2304, kt * 64, T, tid);
+        abw_fetch(vreg, qb + 1536, 2304, kt * 64, T, tid);
+    };
+    fetch(0);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        __syncthreads();
+        abw_store(Ks, kreg, tid);
+        abw_store(Vs, vreg, tid);
+        __syncthreads();
+        if (kt + 1 < ntiles) fetch(kt + 1);
+        if (!wave_active) continue;
+        const int k0 = kt * 64;
+        const int nsub = min(4, (T - k0 + 15) / 16);
+        for (int sub = 0; sub < nsub; ++sub) {
+            f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) {
+                const f32x4 ka = *reinterpret_cast<const f32x4*>(Ks + (sub * 16 + fi) * kAttnLD + dd * 16 + g * 4);
+                const f32x4 va = *reinterpret_cast<const f32x4*>(Vs + (sub * 16 + fi) * kAttnLD + dd * 16 + g * 4);
+                s = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[0], qf[dd][0], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x4f32(va[0], gf[dd][0], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[1], qf[dd][1], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x4f32(va[1], gf[dd][1], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[2], qf[dd][2], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x4f32(va[2], gf[dd][2], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[3], qf[dd][3], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x4f32(va[3], gf[dd][3], dp, 0, 0, 0);
+            }
+            // lane: query (column fi), keys k0 + 16*sub + 4g + r
+            f32x4 ds;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = k0 + sub * 16 + g * 4 + r;
+                const bool ok = q < T && key < T;
+                const float p = ok ? fast_exp(s[r] - lse_q) : 0.f;
+                const float mk = (DROP && ok) ? drop_mult(dc, site, ((unsigned long long)bh * T + q) * T + key) : 1.0f;
+                ds[r] = p * (dp[r] * mk - D_q);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float* krow = Ks + (sub * 16 + g * 4 + r) * kAttnLD + fi;
+#pragma unroll
+                for (int di = 0; di < 4; ++di)
+                    dq[di] = __builtin_amdgcn_mfma_f32_16x16x4f32(krow[di * 16], ds[r], dq[di], 0, 0, 0);
+            }
+        }
+    }
+    if (q < T) {  // dQ^T accumulators: row d = 16*di + 4g + r, column = this lane's query
+        float* dst = dqkv + ((long long)b * T + q) * 2304 + h * 64 + g * 4;
+#pragma unroll
+        for (int di = 0; di < 4; ++di) {
+            *reinterpret_cast<f32x4*>(dst + di * 16) = dq[di];
+        }
+    }
+}
+
+// D scratch: [B*12][T] floats.
+inline hipError_t launch_attention_bwd(const float* qkv, const float* o, const float* dO, const float* lse, float* D,
+                                       float* dqkv, int B, int T, const DropCfg& dc, uint32_t site, hipStream_t s) {
+    const int M = B * T;
+    hipLaunchKernelGGL(attn_bwd_rowdot_kernel, dim3((M + 3) / 4), dim3(256), 0, s, o, dO, D, M, T);
+    const dim3 grid((T + 63) / 64, B * 12);
+    if (dc.threshold) {
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, grid, dim3(256), 0, s, qkv, dO, lse, D, dqkv, T, dc, site);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, grid, dim3(256), 0, s, qkv, dO, lse, D, dqkv, T, dc, site);
+    } else {
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, grid, dim3(256), 0, s, qkv, dO, lse, D, dqkv, T, dc, site);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, grid, dim3(256), 0, s, qkv, dO, lse, D, dqkv, T, dc, site);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace nomad

@@ -3,9 +3,9 @@
 // Weights are frozen (the user's purpose is the gradient w.r.t. `estimate`), so only dX is propagated:
 // every dense contraction of the backward is the SAME fp32 MFMA GEMM kernel as the forward, fed with
 // transposed weight copies; this file holds what is not a GEMM:
-//   LayerNorm backward, GELU' multiplies (fused into GEMM epilogues or as row kernels), attention backward
-//   (recompute P from the saved log-sum-exp, flash style, deterministic: no atomics), head / L1-loss
-//   backward, GroupNorm + conv0 backward, and the one-time weight transposes.
+//   LayerNorm backward, GELU' multiplies (fused into GEMM epilogues or as row kernels), head / L1-loss
+//   backward, GroupNorm + conv0 backward, and the one-time weight transposes.  The attention backward
+//   (MFMA, flash style, no atomics) is in attention_bwd.hip.h.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -220,156 +220,7 @@ __global__ __launch_bounds__(256) void l1_bwd_kernel(const float4* __restrict__ 
     }
 }
 
-// ---- attention backward -----------------------------------------------------------------------------
-// Per (clip, head): S = q k^T (q pre-scaled), P = exp(S - lse), dP = dO v^T, D = rowsum(dO * O),
-// dS = P * (dP - D); dV = P^T dO, dK = dS^T q, dQ = dS k.  Tiles of 32 x 32 through LDS, fp32 VALU
-// (the backward's FLOPs are in the GEMMs; T x T work is 0.3 % at T = 50).  Two kernels, no atomics:
-//   attn_bwd_dkv_kernel: one workgroup per 32-key tile, loops over query tiles  -> dk, dv
-//   attn_bwd_dq_kernel : one workgroup per 32-query tile, loops over key tiles  -> dq
-// qkv/dqkv: [B*T][2304] = [q | k | v]; o, dO: [B*T][768]; lse: [B*12][T].
-constexpr int kAB = 32;        // tile edge
-constexpr int kABLD = 65;      // 64 + 1 floats per LDS row
-
-__device__ __forceinline__ void ab_load_tile(float* dst, const float* src, long long row_stride, int row0, int T,
-                                             int tid) {
-    // 32 rows x 64 floats; rows past T are zero-filled
-    for (int i = tid; i < kAB * 64; i += 256) {
-        const int r = i >> 6, c = i & 63;
-        dst[r * kABLD + c] = (row0 + r < T) ? src[(long long)(row0 + r) * row_stride + c] : 0.f;
-    }
-}
-
-// Computes P and dS for the (q tile, k tile) pair held in LDS; thread -> 4 entries (qi = tid>>3, kj = (tid&7)*4..+3)
-// Attention dropout (dc.threshold > 0): O = (P * Mk) V with Mk = mask / (1 - p), so Ps receives P * Mk (what dV
-// contracts with) and dS = P * (dP * Mk - D); D = rowsum(dO * O) is unchanged.  drow0 = (b*12+h)*T.
-__device__ __forceinline__ void ab_scores(const float* Qs, const float* Ks, const float* Vs, const float* dOs,
-                                          const float* lse_s, const float* D_s, float* Ps, float* dSs, int q0, int k0,
-                                          int T, int tid, const DropCfg& dc, uint32_t site,
-                                          unsigned long long drow0) {
-    const int qi = tid >> 3, kj0 = (tid & 7) * 4;
-    float s[4] = {0.f, 0.f, 0.f, 0.f}, dp[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int d = 0; d < 64; ++d) {
-        const float qv = Qs[qi * kABLD + d], dov = dOs[qi * kABLD + d];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            s[j] = fmaf(qv, Ks[(kj0 + j) * kABLD + d], s[j]);
-            dp[j] = fmaf(dov, Vs[(kj0 + j) * kABLD + d], dp[j]);
-        }
-    }
-    const bool q_ok = q0 + qi < T;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const bool ok = q_ok && (k0 + kj0 + j < T);
-        const float pv = ok ? expf(s[j] - lse_s[qi]) : 0.f;
-        const float mk = (dc.threshold != 0 && ok) ? drop_mult(dc, site, (drow0 + q0 + qi) * T + k0 + kj0 + j) : 1.0f;
-        Ps[qi * 33 + kj0 + j] = pv * mk;
-        dSs[qi * 33 + kj0 + j] = pv * (dp[j] * mk - D_s[qi]);
-    }
-}
-
-__device__ __forceinline__ void ab_row_stats(const float* dOs, const float* Os, const float* lse, float* lse_s,
-                                             float* D_s, int q0, int T, int tid) {
-    // D[q] = sum_d dO[q][d] * O[q][d]; 8 threads per row
-    const int qi = tid >> 3, part = tid & 7;
-    float acc = 0.f;
-    for (int d = part * 8; d < part * 8 + 8; ++d) acc = fmaf(dOs[qi * kABLD + d], Os[qi * kABLD + d], acc);
-    acc += __shfl_xor(acc, 1);
-    acc += __shfl_xor(acc, 2);
-    acc += __shfl_xor(acc, 4);
-    if (part == 0) {
-        D_s[qi] = acc;
-        lse_s[qi] = (q0 + qi < T) ? lse[q0 + qi] : 0.f;
-    }
-}
-
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
-                                                           const float* __restrict__ dO, const float* __restrict__ lse,
-                                                           float* __restrict__ dqkv, int T, DropCfg dc = DropCfg{},
-                                                           uint32_t site = 0) {
-    __shared__ float Qs[kAB * kABLD], Ks[kAB * kABLD], Vs[kAB * kABLD], dOs[kAB * kABLD], Os[kAB * kABLD];
-    __shared__ float Ps[kAB * 33], dSs[kAB * 33], lse_s[kAB], D_s[kAB];
-    const int tid = threadIdx.x, bh = blockIdx.y, b = bh / 12, h = bh - b * 12;
-    const int k0 = blockIdx.x * kAB;
-    const float* qb = qkv + (long long)b * T * 2304 + h * 64;
-    const float* ob = o + (long long)b * T * 768 + h * 64;
-    const float* dob = dO + (long long)b * T * 768 + h * 64;
-    const float* lb = lse + (long long)bh * T;
-    ab_load_tile(Ks, qb + 768, 2304, k0, T, tid);
-    ab_load_tile(Vs, qb + 1536, 2304, k0, T, tid);
-    // outputs: thread -> key kj = tid >> 3, d = (tid & 7) * 8 .. +7
-    const int kj = tid >> 3, d0 = (tid & 7) * 8;
-    float dk[8], dv[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) dk[i] = dv[i] = 0.f;
-    for (int q0 = 0; q0 < T; q0 += kAB) {
-        __syncthreads();
-        ab_load_tile(Qs, qb, 2304, q0, T, tid);
-        ab_load_tile(dOs, dob, 768, q0, T, tid);
-        ab_load_tile(Os, ob, 768, q0, T, tid);
-        __syncthreads();
-        ab_row_stats(dOs, Os, lb, lse_s, D_s, q0, T, tid);
-        __syncthreads();
-        ab_scores(Qs, Ks, Vs, dOs, lse_s, D_s, Ps, dSs, q0, k0, T, tid, dc, site, (unsigned long long)bh * T);
-        __syncthreads();
-        for (int qi = 0; qi < kAB; ++qi) {
-            const float pv = Ps[qi * 33 + kj], ds = dSs[qi * 33 + kj];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                dv[i] = fmaf(pv, dOs[qi * kABLD + d0 + i], dv[i]);
-                dk[i] = fmaf(ds, Qs[qi * kABLD + d0 + i], dk[i]);
-            }
-        }
-    }
-    if (k0 + kj < T) {
-        float* dst = dqkv + ((long long)b * T + k0 + kj) * 2304 + h * 64 + d0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            dst[768 + i] = dk[i];
-            dst[1536 + i] = dv[i];
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
-                                                          const float* __restrict__ dO, const float* __restrict__ lse,
-                                                          float* __restrict__ dqkv, int T, DropCfg dc = DropCfg{},
-                                                          uint32_t site = 0) {
-    __shared__ float Qs[kAB * kABLD], Ks[kAB * kABLD], Vs[kAB * kABLD], dOs[kAB * kABLD], Os[kAB * kABLD];
-    __shared__ float Ps[kAB * 33], dSs[kAB * 33], lse_s[kAB], D_s[kAB];
-    const int tid = threadIdx.x, bh = blockIdx.y, b = bh / 12, h = bh - b * 12;
-    const int q0 = blockIdx.x * kAB;
-    const float* qb = qkv + (long long)b * T * 2304 + h * 64;
-    const float* ob = o + (long long)b * T * 768 + h * 64;
-    const float* dob = dO + (long long)b * T * 768 + h * 64;
-    const float* lb = lse + (long long)bh * T;
-    ab_load_tile(Qs, qb, 2304, q0, T, tid);
-    ab_load_tile(dOs, dob, 768, q0, T, tid);
-    ab_load_tile(Os, ob, 768, q0, T, tid);
-    __syncthreads();
-    ab_row_stats(dOs, Os, lb, lse_s, D_s, q0, T, tid);
-    const int qi = tid >> 3, d0 = (tid & 7) * 8;
-    float dq[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) dq[i] = 0.f;
-    for (int k0 = 0; k0 < T; k0 += kAB) {
-        __syncthreads();
-        ab_load_tile(Ks, qb + 768, 2304, k0, T, tid);
-        ab_load_tile(Vs, qb + 1536, 2304, k0, T, tid);
-        __syncthreads();
-        ab_scores(Qs, Ks, Vs, dOs, lse_s, D_s, Ps, dSs, q0, k0, T, tid, dc, site, (unsigned long long)bh * T);
-        __syncthreads();
-        for (int kj = 0; kj < kAB; ++kj) {
-            const float ds = dSs[qi * 33 + kj];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) dq[i] = fmaf(ds, Ks[kj * kABLD + d0 + i], dq[i]);
-        }
-    }
-    if (q0 + qi < T) {
-        float* dst = dqkv + ((long long)b * T + q0 + qi) * 2304 + h * 64 + d0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) dst[i] = dq[i];
-    }
-}
+// (attention backward: attention_bwd.hip.h)
 
 // ---- conv0 + GroupNorm backward ---------------------------------------------------------------------
 // Forward: y[t,c] = sum_j w[c,j] x[5t+j];  z = (y - mean_c) * rstd_c * gamma_c + beta_c;  out = gelu(z).

@@ -22,6 +22,7 @@
 
 #include "../../include/nomad_hip.h"
 #include "attention.hip.h"
+#include "attention_bwd.hip.h"
 #include "backward.hip.h"
 #include "frontend.hip.h"
 #include "gemm_bf16.hip.h"
@@ -162,7 +163,7 @@ Saved make_saved(const Shapes& s, void* base) {
 // Scratch of nomad_embed_backward.  train = true adds what the parameter gradients need (nomad_train_backward):
 // two transposed operand buffers [3072][Mp], split-K partial products, the recomputed pos-conv input.
 struct BwdLayout {
-    size_t gx, dya, dyb, dh, dqkv, dug, f1, f2, bufa, bufb, partial, total;
+    size_t gx, dya, dyb, dh, dqkv, dug, f1, f2, bufa, bufb, partial, attnd, total;
     int nchunks;
     size_t ta, tb, kpart, xg, dwe, lnpart, headp, headdz, dmask;
     int Mp, pos_split, ln_blocks;
@@ -191,6 +192,7 @@ BwdLayout make_bwd_layout(const Shapes& s, bool train = false) {
     l.bufb = take(512 * (size_t)s.B * (s.L[1] + 2));
     l.nchunks = (s.L[0] + kGnChunk - 1) / kGnChunk;
     l.partial = take(1024 * (size_t)s.B * l.nchunks);
+    l.attnd = take(12 * M);
     if (train) {
         l.Mp = (s.M + 511) / 512 * 512;  // contraction length of the dW GEMMs: any split S | 16 keeps K % 32 == 0
         l.pos_split = s.B < 4 ? s.B : 4;
@@ -1513,12 +1515,8 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
         }
         if ((rc = bwd_gemm(c, dy1b, c->o_wT[l], dyb, M, 768, 768, nullptr, nullptr, s))) return rc;    // dctx
         {
-            Scope sc(c, s, NOMAD_K_ATTN, 10.0 * B * 12.0 * (double)T * T * 64);
-            const dim3 grid((T + kAB - 1) / kAB, B * 12);
-            hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, s, sl.qkv, sl.ctx, dyb, sl.lse, dqkv, T, d_att,
-                               site_attn(l));
-            hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, s, sl.qkv, sl.ctx, dyb, sl.lse, dqkv, T, d_att,
-                               site_attn(l));
+            Scope sc(c, s, NOMAD_K_ATTN, 14.0 * B * 12.0 * (double)T * T * 64);  // 7 T x T x 64 products (S, dP twice)
+            HIP_TRY(launch_attention_bwd(sl.qkv, sl.ctx, dyb, sl.lse, F(lay.attnd), dqkv, B, T, d_att, site_attn(l), s));
         }
         if (train) {
             // the forward's fused weight holds q scaled by head_dim^-0.5: d q_proj = 0.125 * d fused rows 0..767
@@ -2092,10 +2090,12 @@ int nomad_diag_attention_bwd(nomad_ctx* c, const float* qkv, const float* dctx, 
     hipStream_t s = static_cast<hipStream_t>(stream);
     int rc = run_attention(c, qkv, ctx_out, lse, B, T, s);
     if (rc) return rc;
-    const dim3 grid((T + kAB - 1) / kAB, B * 12);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, s, qkv, ctx_out, dctx, lse, dqkv, T);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, s, qkv, ctx_out, dctx, lse, dqkv, T);
-    HIP_TRY(hipGetLastError());
+    float* D = nullptr;  // diagnostics only: the product path carves this from the caller's workspace
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&D), sizeof(float) * 12 * (size_t)B * T));
+    const hipError_t e = launch_attention_bwd(qkv, ctx_out, dctx, lse, D, dqkv, B, T, DropCfg{}, 0, s);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(D);
+    if (e != hipSuccess) return fail(NOMAD_ERR_HIP, "attention backward: %s", hipGetErrorString(e));
     return 0;
 }
 
