@@ -147,13 +147,28 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
                                                        float* __restrict__ gx, float* __restrict__ pooled_out = nullptr,
                                                        float* __restrict__ dz_out = nullptr) {
     __shared__ float pooled[768], mask[768], z[256], dz[256], red[4], red2[4];
+    __shared__ __attribute__((aligned(16))) float psum[4][768];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* xb = x + (long long)b * T * 768;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    for (int t = 0; t < T; ++t) {
-        const float* r = xb + (long long)t * 768;
-        s0 += r[tid]; s1 += r[tid + 256]; s2 += r[tid + 512];
+    {   // time sum: wave w takes frames w, w+4, ... (16-byte loads), the four partial sums are combined in fixed order
+        float4 acc[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = wave; t < T; t += 4) {
+            const float4* r = reinterpret_cast<const float4*>(xb + (long long)t * 768);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float4 v = r[lane + 64 * i];
+                acc[i].x += v.x; acc[i].y += v.y; acc[i].z += v.z; acc[i].w += v.w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) reinterpret_cast<float4*>(psum[wave])[lane + 64 * i] = acc[i];
     }
+    __syncthreads();
+    const float s0 = (psum[0][tid] + psum[1][tid]) + (psum[2][tid] + psum[3][tid]);
+    const float s1 = (psum[0][tid + 256] + psum[1][tid + 256]) + (psum[2][tid + 256] + psum[3][tid + 256]);
+    const float s2 = (psum[0][tid + 512] + psum[1][tid + 512]) + (psum[2][tid + 512] + psum[3][tid + 512]);
     const float inv = 1.0f / (float)T;
     const float m0 = s0 * inv, m1 = s1 * inv, m2 = s2 * inv;
     pooled[tid] = fmaxf(m0, 0.f); pooled[tid + 256] = fmaxf(m1, 0.f); pooled[tid + 512] = fmaxf(m2, 0.f);
@@ -196,11 +211,17 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
         const float dzo = dz[o];
         d0 = fmaf(wr[tid], dzo, d0); d1 = fmaf(wr[tid + 256], dzo, d1); d2 = fmaf(wr[tid + 512], dzo, d2);
     }
-    d0 *= mask[tid]; d1 *= mask[tid + 256]; d2 *= mask[tid + 512];
+    __syncthreads();  // psum is free again: row 0 carries the per-column gradient to the broadcast below
+    psum[0][tid] = d0 * mask[tid]; psum[0][tid + 256] = d1 * mask[tid + 256]; psum[0][tid + 512] = d2 * mask[tid + 512];
+    __syncthreads();
+    float4 gv[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) gv[i] = reinterpret_cast<const float4*>(psum[0])[lane + 64 * i];
     float* gb = gx + (long long)b * T * 768;
-    for (int t = 0; t < T; ++t) {
-        float* r = gb + (long long)t * 768;
-        r[tid] = d0; r[tid + 256] = d1; r[tid + 512] = d2;
+    for (int t = wave; t < T; t += 4) {
+        float4* r = reinterpret_cast<float4*>(gb + (long long)t * 768);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) r[lane + 64 * i] = gv[i];
     }
 }
 

@@ -13,6 +13,7 @@
 //   head (mean_t, ReLU, Linear 768->256, L2 normalise)
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -203,7 +204,7 @@ BwdLayout make_bwd_layout(const Shapes& s, bool train = false) {
         l.kpart = take(pos_part > kSplitPartFloats ? pos_part : kSplitPartFloats);
         l.xg = take(768 * (size_t)s.B * (s.T + 128));
         l.dwe = take((size_t)768 * 6144);
-        l.lnpart = take((size_t)l.ln_blocks * 2 * 768);
+        l.lnpart = take(std::max((size_t)l.ln_blocks * 2 * 768, (size_t)16 * kPbChunks * 48));  // also the pos-conv bias partials
         l.headp = take((size_t)s.B * 768);
         l.headdz = take((size_t)s.B * 256);
         l.dmask = take(768 * M);
@@ -1443,7 +1444,7 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
     const int Mp = lay.Mp;
     auto tpose = [&](const float* in, int C, float* out, bool gelu) {  // out[C][Mp] = f(in[M][C])^T, zero padded
         Scope sc(c, s, NOMAD_K_ROW, 0.0);
-        const dim3 grid(Mp / 32, (C + 31) / 32), blk(32, 8);
+        const dim3 grid(Mp / 64, (C + 63) / 64), blk(256);
         if (gelu) hipLaunchKernelGGL(transpose_pad_kernel<1>, grid, blk, 0, s, in, C, out, Mp, M, C);
         else hipLaunchKernelGGL(transpose_pad_kernel<0>, grid, blk, 0, s, in, C, out, Mp, M, C);
     };
@@ -1456,7 +1457,7 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
         float* lp = F(lay.lnpart);
         if (N == 768) hipLaunchKernelGGL(ln_param_partial_kernel<3>, dim3(lay.ln_blocks), dim3(256), 0, s, x, g, g2, lp, M);
         else hipLaunchKernelGGL(ln_param_partial_kernel<2>, dim3(lay.ln_blocks), dim3(256), 0, s, x, g, g2, lp, M);
-        hipLaunchKernelGGL(ln_param_final_kernel, dim3((2 * N + 255) / 256), dim3(256), 0, s, lp, lay.ln_blocks, N, dgam, dbet);
+        hipLaunchKernelGGL(ln_param_final_kernel, dim3(2 * N / 64), dim3(256), 0, s, lp, lay.ln_blocks, N, dgam, dbet);
     };
 
     // ---- head -> d loss / d x_12 -------------------------------------------------------------------
@@ -1571,7 +1572,9 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
         float *dug = F(lay.dug), *xg = F(lay.xg), *dwe = F(lay.dwe), *featln = F(lay.f2);
         {
             Scope sc(c, s, NOMAD_K_ROW, 0.0);
-            hipLaunchKernelGGL(posconv_bias_grad_kernel, dim3(16), dim3(256), 0, s, dug, (long long)B * (T + 128), G(po.pos_b));
+            hipLaunchKernelGGL(posconv_bias_partial_kernel, dim3(kPbChunks, 16), dim3(256), 0, s, dug, (long long)B * (T + 128),
+                               F(lay.lnpart));
+            hipLaunchKernelGGL(posconv_bias_final_kernel, dim3(1), dim3(768), 0, s, F(lay.lnpart), G(po.pos_b));
         }
         // the conv's input (post_extract_proj output, group-major, zero padded) is recomputed, not saved
         if ((rc = run_layernorm(c, sv.c6, c->fln_w, c->fln_b, featln, nullptr, M, 512, s))) return rc;
@@ -1596,7 +1599,7 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
             hipLaunchKernelGGL(posconv_dw_kernel, dim3(128 / kPdwTaps, 16, S), dim3(256), 0, s, dug, xg, part, B, T, cps);
             hipLaunchKernelGGL(posconv_dw_gather_kernel, dim3(768), dim3(256), 0, s, part, S, dwe);
             hipLaunchKernelGGL(tap_dot_partial_kernel, dim3(576), dim3(256), 0, s, dwe, c->theta + po.pos_v, c->tap_partial);
-            hipLaunchKernelGGL(tap_sum_final_kernel, dim3(1), dim3(128), 0, s, c->tap_partial, 576, c->tap_dot);
+            hipLaunchKernelGGL(tap_sum_final_kernel, dim3(1), dim3(1024), 0, s, c->tap_partial, 576, c->tap_dot);
             hipLaunchKernelGGL(posconv_wn_bwd_kernel, dim3(768 * 48 * 128 / 256), dim3(256), 0, s, dwe, c->theta + po.pos_v,
                                c->theta + po.pos_g, c->pos_nrm2, c->tap_dot, G(po.pos_v), G(po.pos_g));
         }
@@ -1744,7 +1747,7 @@ int refresh_weights(nomad_ctx* c, hipStream_t s) {
     };
     hipLaunchKernelGGL(tap_dot_partial_kernel, dim3(576), dim3(256), 0, s, c->theta + po.pos_v, (const float*)nullptr,
                        c->tap_partial);
-    hipLaunchKernelGGL(tap_sum_final_kernel, dim3(1), dim3(128), 0, s, c->tap_partial, 576, c->pos_nrm2);
+    hipLaunchKernelGGL(tap_sum_final_kernel, dim3(1), dim3(1024), 0, s, c->tap_partial, 576, c->pos_nrm2);
     hipLaunchKernelGGL(posconv_fold_kernel, dim3(768), dim3(256), 0, s, c->theta + po.pos_v, c->theta + po.pos_g,
                        c->pos_nrm2, c->pos_w);
     hipLaunchKernelGGL(posconv_bwd_weight_kernel, dim3(16 * 64), dim3(256), 0, s, c->pos_w, c->pos_wb);

@@ -19,23 +19,32 @@
 
 namespace nomad {
 
-// out[c][m] = f(in[m][c]) for m < M, 0 for M <= m < ld_out (ld_out % 32 == 0).  ACT: 0 identity, 1 GELU (the fc2
-// input is recomputed from the saved pre-activation).  grid: (ld_out/32, ceil(C/32)), block (32, 8).
+// out[c][m] = f(in[m][c]) for m < M, 0 for M <= m < ld_out (ld_out % 64 == 0, C % 4 == 0).  ACT: 0 identity, 1 GELU
+// (the fc2 input is recomputed from the saved pre-activation).  64 x 64 tiles, 16-byte loads and stores.
+// grid: (ld_out/64, ceil(C/64)), 256 threads.
 template <int ACT>
-__global__ void transpose_pad_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ out, int ld_out, int M,
-                                     int C) {
-    __shared__ float tile[32][33];
-    const int m0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
-    for (int i = threadIdx.y; i < 32; i += 8) {
-        const int m = m0 + i, c = c0 + threadIdx.x;
-        float v = (m < M && c < C) ? in[(long long)m * ld_in + c] : 0.f;
-        if (ACT == 1) v = gelu_erf(v);
-        tile[i][threadIdx.x] = v;
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ out,
+                                                            int ld_out, int M, int C) {
+    __shared__ float tile[64][65];
+    const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tid = threadIdx.x;
+    const int r = tid >> 4, q = (tid & 15) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + r + 16 * i, c = c0 + q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < M && c < C) v = *reinterpret_cast<const float4*>(in + (long long)m * ld_in + c);
+        if (ACT == 1) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+        tile[r + 16 * i][q] = v.x; tile[r + 16 * i][q + 1] = v.y; tile[r + 16 * i][q + 2] = v.z; tile[r + 16 * i][q + 3] = v.w;
     }
     __syncthreads();
-    for (int i = threadIdx.y; i < 32; i += 8) {
-        const int c = c0 + i, m = m0 + threadIdx.x;
-        if (c < C) out[(long long)c * ld_out + m] = tile[threadIdx.x][i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + r + 16 * i;
+        if (c < C) {
+            float4 v;
+            v.x = tile[q][r + 16 * i]; v.y = tile[q + 1][r + 16 * i]; v.z = tile[q + 2][r + 16 * i]; v.w = tile[q + 3][r + 16 * i];
+            *reinterpret_cast<float4*>(out + (long long)c * ld_out + m0 + q) = v;
+        }
     }
 }
 
@@ -71,7 +80,7 @@ __global__ __launch_bounds__(256) void rowsum_acc_kernel(const float* __restrict
 
 // LayerNorm parameter gradients: dgamma[n] = sum_m g[m][n] * xhat[m][n], dbeta[n] = sum_m g[m][n]  (g = g1 + g2).
 // Stage 1: a block of 4 waves walks kLnRows rows (wave w takes rows w, w+4, ...), partial[blk][2][N].
-constexpr int kLnRows = 64;
+constexpr int kLnRows = 16;
 template <int VPT>
 __global__ __launch_bounds__(256) void ln_param_partial_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                                const float* __restrict__ g2, float* __restrict__ partial,
@@ -136,15 +145,24 @@ __global__ __launch_bounds__(256) void ln_param_partial_kernel(const float* __re
     }
 }
 
-// Stage 2: dgamma[n] += sum_blk partial[blk][0][n], dbeta[n] += sum_blk partial[blk][1][n] (block order).
+// Stage 2: dgamma[n] += sum_blk partial[blk][0][n], dbeta[n] += sum_blk partial[blk][1][n].  A block owns 64 of the
+// 2N outputs; its 4 waves each fold every 4th partial block, then the 4 sums are combined in fixed order.
+// grid: 2N/64 blocks of 256 threads.
 __global__ __launch_bounds__(256) void ln_param_final_kernel(const float* __restrict__ partial, int nblk, int N,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= 2 * N) return;
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partial[(long long)b * 2 * N + i];
-    if (i < N) dgamma[i] += s;
-    else dbeta[i - N] += s;
+#pragma unroll 8
+    for (int b = wave; b < nblk; b += 4) s += partial[(long long)b * 2 * N + i];
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0) {
+        const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        if (i < N) dgamma[i] += t;
+        else dbeta[i - N] += t;
+    }
 }
 
 // Head parameter gradients from what head_bwd_kernel leaves behind: pooled[B][768] (after ReLU), dz[B][256].
@@ -275,11 +293,17 @@ __global__ __launch_bounds__(256) void tap_dot_partial_kernel(const float* __res
     __syncthreads();
     if (half == 0) partial[(long long)blockIdx.x * 128 + t] = s + red[t];
 }
-__global__ __launch_bounds__(128) void tap_sum_final_kernel(const double* __restrict__ partial, int nblk,
-                                                            double* __restrict__ out) {
+// one block of 1024 threads: 8 parts x 128 taps, part p folds blocks p, p+8, ...; parts combined in fixed order
+__global__ __launch_bounds__(1024) void tap_sum_final_kernel(const double* __restrict__ partial, int nblk,
+                                                             double* __restrict__ out) {
+    __shared__ double red[8][128];
+    const int t = threadIdx.x & 127, part = threadIdx.x >> 7;
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += partial[(long long)b * 128 + threadIdx.x];
-    out[threadIdx.x] = s;
+    for (int b = part; b < nblk; b += 8) s += partial[(long long)b * 128 + t];
+    red[part][t] = s;
+    __syncthreads();
+    if (part == 0)
+        out[t] = ((red[0][t] + red[1][t]) + (red[2][t] + red[3][t])) + ((red[4][t] + red[5][t]) + (red[6][t] + red[7][t]));
 }
 
 // weight_norm(dim=2): w[o][ci][t] = v[o][ci][t] * g[t] / ||v[:, :, t]||.
@@ -311,20 +335,29 @@ __global__ __launch_bounds__(256) void posconv_wn_bwd_kernel(const float* __rest
 }
 
 // Column sums of the group-major padded pos-conv gradient (bias gradient): db[grp*48 + c] += sum_frames dug.
-// grid: 16 blocks (group) of 256 threads; rows = B * (T + 128) frames of 48 floats (pad frames are zero).
-__global__ __launch_bounds__(256) void posconv_bias_grad_kernel(const float* __restrict__ dug, long long rows,
-                                                                float* __restrict__ db) {
+// rows = B * (T + 128) frames of 48 floats per group (pad frames are zero).  Stage 1: grid (kPbChunks, 16), block =
+// 5 row-parts x 48 columns; partial[grp][chunk][48].  Stage 2: one block of 768 threads folds the chunks in order.
+constexpr int kPbChunks = 64;
+__global__ __launch_bounds__(256) void posconv_bias_partial_kernel(const float* __restrict__ dug, long long rows,
+                                                                   float* __restrict__ partial) {
     __shared__ float red[5][48];
-    const int grp = blockIdx.x, c = threadIdx.x % 48, part = threadIdx.x / 48;  // 5 row-parts x 48 columns = 240 threads
+    const int grp = blockIdx.y, c = threadIdx.x % 48, part = threadIdx.x / 48;
+    const long long per = (rows + kPbChunks - 1) / kPbChunks, r0 = blockIdx.x * per, r1 = min(rows, r0 + per);
     const float* base = dug + (long long)grp * rows * 48;
     float s = 0.f;
     if (part < 5)
-        for (long long r = part; r < rows; r += 5) s += base[r * 48 + c];
+        for (long long r = r0 + part; r < r1; r += 5) s += base[r * 48 + c];
     if (part < 5) red[part][c] = s;
     __syncthreads();
     if (threadIdx.x < 48)
-        db[grp * 48 + threadIdx.x] += ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x])) +
-                                      red[4][threadIdx.x];
+        partial[((long long)grp * kPbChunks + blockIdx.x) * 48 + threadIdx.x] =
+            ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x])) + red[4][threadIdx.x];
+}
+__global__ __launch_bounds__(768) void posconv_bias_final_kernel(const float* __restrict__ partial, float* __restrict__ db) {
+    const int grp = threadIdx.x / 48, c = threadIdx.x - grp * 48;
+    float s = 0.f;
+    for (int k = 0; k < kPbChunks; ++k) s += partial[((long long)grp * kPbChunks + k) * 48 + c];
+    db[threadIdx.x] += s;
 }
 
 // Fused q/k/v weight in the forward's layout from the master copy: rows 0..767 (q) scaled by head_dim^-0.5.

@@ -174,8 +174,16 @@ class Training:
         eng = self.engine
         wavs = [w.to(self.DEVICE, torch.float32).squeeze(1).contiguous() for w in (A, P, N)]
         if not training:
-            embs = [eng.embed(w) for w in wavs]
-            return eng.triplet_loss(embs[0], embs[1], embs[2], self.margin, want_grad=False)[0]
+            # model.eval(): clips are independent and the engine is batch invariant bit for bit, so the three
+            # forwards of train_triplet.py:146-148 run as ONE batch of 3B clips when the lengths agree
+            if wavs[0].shape == wavs[1].shape == wavs[2].shape:
+                B = wavs[0].shape[0]
+                e = eng.embed(torch.cat(wavs, dim=0))
+                embs = [e[:B], e[B:2 * B], e[2 * B:]]
+            else:
+                embs = [eng.embed(w) for w in wavs]
+            return eng.triplet_loss(embs[0].contiguous(), embs[1].contiguous(), embs[2].contiguous(), self.margin,
+                                    want_grad=False)[0]
         draws = [self._draw() for _ in wavs]
         outs = []
         for w, d in zip(wavs, draws):

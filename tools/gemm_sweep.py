@@ -31,6 +31,14 @@ SHAPES = {  # name: (M, N, K, bias, gelu, residual)
     "b1_qkv": (199, 2304, 768, True, False, False),
     "b1_fc2": (199, 768, 3072, True, False, True),
     "b8_fc1": (1592, 3072, 768, True, True, False),
+    # one branch of the reference's training batch: 8 clips x 10 s (T = 499)
+    "tr_qkv": (3992, 2304, 768, True, False, False),
+    "tr_fc1": (3992, 3072, 768, True, True, False),
+    "tr_fc2": (3992, 768, 3072, True, False, True),
+    "tr_out": (3992, 768, 768, True, False, True),
+    # weight-gradient shapes (rows = out features, cols = in features, contraction = padded rows / split)
+    "dw_fc1": (3072, 768, 2048, False, False, False),
+    "dw_out": (768, 768, 512, False, False, False),
 }
 TILE_NAMES = {0: "128x128x32 w2x2", 1: "128x64x16 w2x2", 2: "64x64x32 w2x2", 3: "128x128x16 w2x2",
               4: "256x128x32 w4x2", 5: "256x256x32 w4x2", 6: "256x128x16 w4x2", 7: "128x256x32 w2x2",
