@@ -183,6 +183,10 @@ int nomad_embed_backward(nomad_ctx* ctx, const float* wav_dev, int B, int n_samp
  *                             post_extract_proj) and LayerDrop (layer_mask bit l clear = layer l skipped).  Masks are a
  *                             counter-based hash of (seed, site, element): set the SAME values before a forward
  *                             and before its backward.  All zero + mask 0xFFF (the default) = eval-mode arithmetic.
+ *   nomad_train_set_branches  the batch of the following nomad_embed_train / nomad_train_backward calls is `branches`
+ *                             equal groups of clips (anchor | positive | negative), each with its own LayerDrop mask -
+ *                             as if each group had been its own forward call, but one launch sequence over all of
+ *                             them wherever the masks agree.  branches = 1 (default): layer_mask of set_stochastic.
  */
 int nomad_train_param_count(size_t* total, size_t* head_begin);
 int nomad_train_num_segments(void);
@@ -203,6 +207,7 @@ int nomad_train_write(nomad_ctx* ctx, int what, const float* src_dev, nomad_stre
 int nomad_train_set_step(nomad_ctx* ctx, long long step);
 int nomad_train_set_stochastic(nomad_ctx* ctx, float dropout, float attention_dropout, float dropout_input,
                                unsigned long long seed, unsigned layer_mask);
+int nomad_train_set_branches(nomad_ctx* ctx, int branches, const unsigned* layer_masks);
 
 /* ---- bf16 path (BASELINE config C5: long-form clips) ---------------------------------------- */
 /*

@@ -102,7 +102,7 @@ template <typename T_ = float, bool DROP = false>
 __global__ __launch_bounds__(256) void attention_f32_kernel(const T_* __restrict__ qkv, T_* __restrict__ out,
                                                             float* __restrict__ lse, int T,
                                                             const int* __restrict__ tpref = nullptr,
-                                                            DropCfg dc = DropCfg{}, uint32_t site = 0) {
+                                                            DropCfg dc = DropCfg{}, uint32_t site = 0, int bh0 = 0) {
     __shared__ __attribute__((aligned(16))) float Ks[64 * kAttnLD];
     __shared__ __attribute__((aligned(16))) float Vs[64 * kAttnLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const T_* __restrict
         if (kt + 1 < ntiles) fetch(kt + 1);
         if (!wave_active) continue;
         const int valid = T - kt * 64;  // valid keys in this tile (>= 1)
-        const unsigned long long drow = ((unsigned long long)bh * T + q_ld) * T + kt * 64;
+        const unsigned long long drow = ((unsigned long long)(bh0 + bh) * T + q_ld) * T + kt * 64;
         if (valid >= 64) attn_tile<4, DROP>(Ks, Vs, qf, o, m_run, l_run, qi, g, 64, &dc, site, drow);
         else if (valid > 48) attn_tile<4, DROP>(Ks, Vs, qf, o, m_run, l_run, qi, g, valid, &dc, site, drow);
         else if (valid > 32) attn_tile<3, DROP>(Ks, Vs, qf, o, m_run, l_run, qi, g, valid, &dc, site, drow);

@@ -65,7 +65,7 @@ __device__ __forceinline__ void abw_store(float* __restrict__ dst, const f32x4 (
 template <bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dO,
                                                            const float* __restrict__ lse, const float* __restrict__ D,
-                                                           float* __restrict__ dqkv, int T, DropCfg dc, uint32_t site) {
+                                                           float* __restrict__ dqkv, int T, DropCfg dc, uint32_t site, int bh0) {
     __shared__ __attribute__((aligned(16))) float Qs[64 * kAttnLD];
     __shared__ __attribute__((aligned(16))) float Gs[64 * kAttnLD];  // dO tile
     __shared__ __attribute__((aligned(16))) float lse_s[64];
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
                 const int q = q0 + sub * 16 + g * 4 + r;
                 const bool ok = q < T && key < T;
                 const float p = ok ? fast_exp(s[r] - lv[r]) : 0.f;
-                const float mk = (DROP && ok) ? drop_mult(dc, site, ((unsigned long long)bh * T + q) * T + key) : 1.0f;
+                const float mk = (DROP && ok) ? drop_mult(dc, site, ((unsigned long long)(bh0 + bh) * T + q) * T + key) : 1.0f;
                 pm[r] = p * mk;
                 ds[r] = p * (dp[r] * mk - Dv[r]);
             }
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
 template <bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ dO,
                                                           const float* __restrict__ lse, const float* __restrict__ D,
-                                                          float* __restrict__ dqkv, int T, DropCfg dc, uint32_t site) {
+                                                          float* __restrict__ dqkv, int T, DropCfg dc, uint32_t site, int bh0) {
     __shared__ __attribute__((aligned(16))) float Ks[64 * kAttnLD];
     __shared__ __attribute__((aligned(16))) float Vs[64 * kAttnLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
                 const int key = k0 + sub * 16 + g * 4 + r;
                 const bool ok = q < T && key < T;
                 const float p = ok ? fast_exp(s[r] - lse_q) : 0.f;
-                const float mk = (DROP && ok) ? drop_mult(dc, site, ((unsigned long long)bh * T + q) * T + key) : 1.0f;
+                const float mk = (DROP && ok) ? drop_mult(dc, site, ((unsigned long long)(bh0 + bh) * T + q) * T + key) : 1.0f;
                 ds[r] = p * (dp[r] * mk - D_q);
             }
 #pragma unroll
@@ -261,17 +261,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
 }
 
 // D scratch: [B*12][T] floats.
+// bh0: (clip, head) index of the first clip within the whole batch (dropout mask indexing of a per-branch call)
 inline hipError_t launch_attention_bwd(const float* qkv, const float* o, const float* dO, const float* lse, float* D,
-                                       float* dqkv, int B, int T, const DropCfg& dc, uint32_t site, hipStream_t s) {
+                                       float* dqkv, int B, int T, const DropCfg& dc, uint32_t site, hipStream_t s,
+                                       int bh0 = 0) {
     const int M = B * T;
     hipLaunchKernelGGL(attn_bwd_rowdot_kernel, dim3((M + 3) / 4), dim3(256), 0, s, o, dO, D, M, T);
     const dim3 grid((T + 63) / 64, B * 12);
     if (dc.threshold) {
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, grid, dim3(256), 0, s, qkv, dO, lse, D, dqkv, T, dc, site);
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, grid, dim3(256), 0, s, qkv, dO, lse, D, dqkv, T, dc, site);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, grid, dim3(256), 0, s, qkv, dO, lse, D, dqkv, T, dc, site, bh0);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, grid, dim3(256), 0, s, qkv, dO, lse, D, dqkv, T, dc, site, bh0);
     } else {
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, grid, dim3(256), 0, s, qkv, dO, lse, D, dqkv, T, dc, site);
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, grid, dim3(256), 0, s, qkv, dO, lse, D, dqkv, T, dc, site);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, grid, dim3(256), 0, s, qkv, dO, lse, D, dqkv, T, dc, site, bh0);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, grid, dim3(256), 0, s, qkv, dO, lse, D, dqkv, T, dc, site, bh0);
     }
     return hipGetLastError();
 }

@@ -288,6 +288,10 @@ struct nomad_ctx {
     float p_drop = 0.f, p_attn = 0.f, p_input = 0.f;
     unsigned long long drop_seed = 0;
     unsigned layer_mask = 0xFFFu;  // bit l set: encoder layer l runs (LayerDrop clears bits)
+    // A training batch may be several equal groups of clips ("branches": anchor | positive | negative), each with
+    // its own LayerDrop mask, as if each had been its own forward call (nomad_train_set_branches)
+    int branches = 1;
+    unsigned branch_mask[4] = {0xFFFu, 0xFFFu, 0xFFFu, 0xFFFu};
     std::vector<void*> allocs;
     std::vector<int> ragged_meta;  // host copy of the last ragged batch's metadata (source of an async H2D copy)
     // profiling
@@ -463,25 +467,25 @@ DropCfg make_drop(const nomad_ctx* c, float p) {
 }
 
 int run_attention(nomad_ctx* c, const float* qkv, float* out, float* lse, int B, int T, hipStream_t s,
-                  const DropCfg* dc = nullptr, uint32_t site = 0) {
+                  const DropCfg* dc = nullptr, uint32_t site = 0, int bh0 = 0) {
     const double flops = 4.0 * B * 12.0 * (double)T * T * 64;
     Scope sc(c, s, NOMAD_K_ATTN, flops);
     const dim3 grid((T + 63) / 64, B * 12);
     if (dc && dc->threshold)
-        hipLaunchKernelGGL((attention_f32_kernel<float, true>), grid, dim3(256), 0, s, qkv, out, lse, T, kNoInts, *dc, site);
+        hipLaunchKernelGGL((attention_f32_kernel<float, true>), grid, dim3(256), 0, s, qkv, out, lse, T, kNoInts, *dc, site, bh0);
     else
-        hipLaunchKernelGGL((attention_f32_kernel<float, false>), grid, dim3(256), 0, s, qkv, out, lse, T, kNoInts, DropCfg{}, 0u);
+        hipLaunchKernelGGL((attention_f32_kernel<float, false>), grid, dim3(256), 0, s, qkv, out, lse, T, kNoInts, DropCfg{}, 0u, 0);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
 // y = (resid ? resid : 0) + dropout(x) over n floats of an [M][768] tensor (x == y allowed)
 int run_dropout(nomad_ctx* c, const float* x, const float* resid, float* y, long long n, const DropCfg& d, uint32_t site,
-                hipStream_t s) {
+                hipStream_t s, unsigned long long idx0 = 0) {
     Scope sc(c, s, NOMAD_K_ROW, 0.0);
     hipLaunchKernelGGL(dropout_add_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s,
                        reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(resid),
-                       reinterpret_cast<float4*>(y), n / 4, d, site);
+                       reinterpret_cast<float4*>(y), n / 4, d, site, idx0);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -659,7 +663,14 @@ static int forward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, co
     const bool reg = sv != nullptr;
     const DropCfg d_in = make_drop(c, reg ? c->p_input : 0.f), d_res = make_drop(c, reg ? c->p_drop : 0.f),
                   d_att = make_drop(c, reg ? c->p_attn : 0.f);
-    const unsigned layer_mask = reg ? c->layer_mask : 0xFFFu;
+    // LayerDrop: one mask for the call, or one per branch (equal groups of clips) of a merged batch
+    int nbr = 1;
+    unsigned bmask[4] = {reg ? c->layer_mask : 0xFFFu, 0xFFFu, 0xFFFu, 0xFFFu};
+    if (reg && c->branches > 1) {
+        if (B % c->branches) return fail(NOMAD_ERR_INVALID, "nomad_embed_train: B=%d is not %d equal branches", B, c->branches);
+        nbr = c->branches;
+        for (int i = 0; i < nbr; ++i) bmask[i] = c->branch_mask[i];
+    }
     const long long act = (long long)M * 768;
 
     // ---- front end: conv0 + GroupNorm + GELU ------------------------------------------------
@@ -755,37 +766,66 @@ static int forward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, co
     if (d_res.threshold && (rc = run_dropout(c, x, nullptr, x, act, d_res, kSiteEncoder, s))) return rc;
 
     // ---- 12 post-LN transformer layers --------------------------------------------------------
-    for (int l = 0; l < NOMAD_NUM_LAYERS; ++l) {
+    // One layer over clips [c0, c0 + nc) (rows r0 = c0*T ..): the whole batch, or one branch of it when LayerDrop
+    // decided differently for the branches.  Rows are independent, so a sub-range call is the same arithmetic.
+    auto run_layer = [&](int l, int c0, int nc) -> int {
         const LayerDev& d = c->layers[l];
-        float* lo = layers_out ? layers_out + (size_t)l * M * 768 : nullptr;
-        if (!((layer_mask >> l) & 1u)) {  // LayerDrop: the layer is the identity for this call
-            if (lo) HIP_TRY(hipMemcpyAsync(lo, x, sizeof(float) * act, hipMemcpyDeviceToDevice, s));
-            continue;
-        }
-        float* qkv = sv ? sv->L[l].qkv : F(lay.qkv);
-        float* ctxb = sv ? sv->L[l].ctx : F(lay.ctxb);
-        float* y1 = sv ? sv->L[l].y1 : y;
-        float* y2 = sv ? sv->L[l].y2 : y;
-        if ((rc = run_gemm(c, dense(x, 768, d.qkv_w, d.qkv_b, nullptr, qkv, M, 2304, 768, 0), 1, pick_tile(M, 2304, 768), s)))
+        const long long r0 = (long long)c0 * T;
+        const int Ms = nc * T;
+        const long long acts = (long long)Ms * 768;
+        float* xs = x + r0 * 768;
+        float* x2s = x2 + r0 * 768;
+        float* hs = F(lay.h) + r0 * 3072;
+        float* qkv = (sv ? sv->L[l].qkv : F(lay.qkv)) + r0 * 2304;
+        float* ctxb = (sv ? sv->L[l].ctx : F(lay.ctxb)) + r0 * 768;
+        float* y1 = (sv ? sv->L[l].y1 : y) + r0 * 768;
+        float* y2 = (sv ? sv->L[l].y2 : y) + r0 * 768;
+        float* lse = sv ? sv->L[l].lse + (long long)c0 * 12 * T : nullptr;
+        float* lo = layers_out ? layers_out + (size_t)l * M * 768 + r0 * 768 : nullptr;
+        const unsigned long long idx0 = (unsigned long long)r0 * 768;
+        int rc;
+        if ((rc = run_gemm(c, dense(xs, 768, d.qkv_w, d.qkv_b, nullptr, qkv, Ms, 2304, 768, 0), 1, pick_tile(Ms, 2304, 768), s)))
             return rc;
-        if ((rc = run_attention(c, qkv, ctxb, sv ? sv->L[l].lse : nullptr, B, T, s, &d_att, site_attn(l)))) return rc;
+        if ((rc = run_attention(c, qkv, ctxb, lse, nc, T, s, &d_att, site_attn(l), c0 * 12))) return rc;
         // residual dropout: y = x + dropout(W a + b) needs the branch on its own, so the residual add moves out
         // of the GEMM epilogue into the dropout kernel
-        if ((rc = run_gemm(c, dense(ctxb, 768, d.o_w, d.o_b, d_res.threshold ? nullptr : x, y1, M, 768, 768, 0), 1,
-                           pick_tile(M, 768, 768), s)))
+        if ((rc = run_gemm(c, dense(ctxb, 768, d.o_w, d.o_b, d_res.threshold ? nullptr : xs, y1, Ms, 768, 768, 0), 1,
+                           pick_tile(Ms, 768, 768), s)))
             return rc;
-        if (d_res.threshold && (rc = run_dropout(c, y1, x, y1, act, d_res, site_proj(l), s))) return rc;
-        if ((rc = run_layernorm(c, y1, d.ln1_w, d.ln1_b, x2, nullptr, M, 768, s))) return rc;
+        if (d_res.threshold && (rc = run_dropout(c, y1, xs, y1, acts, d_res, site_proj(l), s, idx0))) return rc;
+        if ((rc = run_layernorm(c, y1, d.ln1_w, d.ln1_b, x2s, nullptr, Ms, 768, s))) return rc;
         {
-            GemmParams p = dense(x2, 768, d.fc1_w, d.fc1_b, nullptr, F(lay.h), M, 3072, 768, 1);
-            p.Upre = sv ? sv->L[l].u : nullptr;
-            if ((rc = run_gemm(c, p, 1, pick_tile(M, 3072, 768), s))) return rc;
+            GemmParams p = dense(x2s, 768, d.fc1_w, d.fc1_b, nullptr, hs, Ms, 3072, 768, 1);
+            p.Upre = sv ? sv->L[l].u + r0 * 3072 : nullptr;
+            if ((rc = run_gemm(c, p, 1, pick_tile(Ms, 3072, 768), s))) return rc;
         }
-        if ((rc = run_gemm(c, dense(F(lay.h), 3072, d.fc2_w, d.fc2_b, d_res.threshold ? nullptr : x2, y2, M, 768, 3072, 0), 1,
-                           pick_tile(M, 768, 3072), s)))
+        if ((rc = run_gemm(c, dense(hs, 3072, d.fc2_w, d.fc2_b, d_res.threshold ? nullptr : x2s, y2, Ms, 768, 3072, 0), 1,
+                           pick_tile(Ms, 768, 3072), s)))
             return rc;
-        if (d_res.threshold && (rc = run_dropout(c, y2, x2, y2, act, d_res, site_ffn(l), s))) return rc;
-        if ((rc = run_layernorm(c, y2, d.ln2_w, d.ln2_b, x, lo, M, 768, s))) return rc;
+        if (d_res.threshold && (rc = run_dropout(c, y2, x2s, y2, acts, d_res, site_ffn(l), s, idx0))) return rc;
+        return run_layernorm(c, y2, d.ln2_w, d.ln2_b, xs, lo, Ms, 768, s);
+    };
+    for (int l = 0; l < NOMAD_NUM_LAYERS; ++l) {
+        unsigned all = 1u, any = 0u;
+        for (int br = 0; br < nbr; ++br) {
+            all &= (bmask[br] >> l) & 1u;
+            any |= (bmask[br] >> l) & 1u;
+        }
+        if (all) {
+            if ((rc = run_layer(l, 0, B))) return rc;
+            continue;
+        }
+        for (int br = 0; br < nbr; ++br) {  // LayerDrop: identity for a dropped branch, the layer for the others
+            const int c0 = br * (B / nbr), nc = B / nbr;
+            if ((bmask[br] >> l) & 1u) {
+                if ((rc = run_layer(l, c0, nc))) return rc;
+            } else if (layers_out) {
+                const long long r0 = (long long)c0 * T;
+                HIP_TRY(hipMemcpyAsync(layers_out + (size_t)l * M * 768 + r0 * 768, x + r0 * 768,
+                                       sizeof(float) * (size_t)nc * T * 768, hipMemcpyDeviceToDevice, s));
+            }
+        }
+        (void)any;
     }
 
     // ---- head -----------------------------------------------------------------------------------
@@ -1433,31 +1473,37 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
     // the regularisation of the forward this backward belongs to (the caller re-sets it: nomad_train_set_stochastic)
     const DropCfg d_in = make_drop(c, train ? c->p_input : 0.f), d_res = make_drop(c, train ? c->p_drop : 0.f),
                   d_att = make_drop(c, train ? c->p_attn : 0.f);
-    const unsigned layer_mask = train ? c->layer_mask : 0xFFFu;
+    int nbr = 1;  // LayerDrop masks: one for the call, or one per branch of a merged batch (see forward_impl)
+    unsigned bmask[4] = {train ? c->layer_mask : 0xFFFu, 0xFFFu, 0xFFFu, 0xFFFu};
+    if (train && c->branches > 1) {
+        if (B % c->branches) return fail(NOMAD_ERR_INVALID, "nomad_train_backward: B=%d is not %d equal branches", B, c->branches);
+        nbr = c->branches;
+        for (int i = 0; i < nbr; ++i) bmask[i] = c->branch_mask[i];
+    }
     const long long act = (long long)M * 768;
     float* dmask = train ? F(lay.dmask) : nullptr;
 
-    // ---- parameter-gradient helpers (train only) ---------------------------------------------------------
+    // ---- parameter-gradient helpers (train only); Ms rows of the (sub-)batch, Mps = Ms rounded up to 512 ------
     const ParamOffsets po = make_param_offsets();
     auto G = [&](size_t off) { return c->grad + off; };
     float *TA = train ? F(lay.ta) : nullptr, *TB = train ? F(lay.tb) : nullptr, *part = train ? F(lay.kpart) : nullptr;
-    const int Mp = lay.Mp;
-    auto tpose = [&](const float* in, int C, float* out, bool gelu) {  // out[C][Mp] = f(in[M][C])^T, zero padded
+    auto tpose = [&](const float* in, int C, float* out, bool gelu, int Ms, int Mps) {  // out[C][Mps] = f(in[Ms][C])^T, zero padded
         Scope sc(c, s, NOMAD_K_ROW, 0.0);
-        const dim3 grid(Mp / 64, (C + 63) / 64), blk(256);
-        if (gelu) hipLaunchKernelGGL(transpose_pad_kernel<1>, grid, blk, 0, s, in, C, out, Mp, M, C);
-        else hipLaunchKernelGGL(transpose_pad_kernel<0>, grid, blk, 0, s, in, C, out, Mp, M, C);
+        const dim3 grid(Mps / 64, (C + 63) / 64), blk(256);
+        if (gelu) hipLaunchKernelGGL(transpose_pad_kernel<1>, grid, blk, 0, s, in, C, out, Mps, Ms, C);
+        else hipLaunchKernelGGL(transpose_pad_kernel<0>, grid, blk, 0, s, in, C, out, Mps, Ms, C);
     };
-    auto rowsum = [&](const float* in, int rows, float* out, float scale) {  // bias gradient from dY^T
+    auto rowsum = [&](const float* in, int rows, float* out, float scale, int Mps) {  // bias gradient from dY^T
         Scope sc(c, s, NOMAD_K_ROW, 0.0);
-        hipLaunchKernelGGL(rowsum_acc_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, in, Mp, rows, out, scale);
+        hipLaunchKernelGGL(rowsum_acc_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, in, Mps, rows, out, scale);
     };
-    auto ln_params = [&](const float* x, const float* g, const float* g2, int N, float* dgam, float* dbet) {
+    auto ln_params = [&](const float* x, const float* g, const float* g2, int N, float* dgam, float* dbet, int Ms) {
         Scope sc(c, s, NOMAD_K_ROW, 0.0);
         float* lp = F(lay.lnpart);
-        if (N == 768) hipLaunchKernelGGL(ln_param_partial_kernel<3>, dim3(lay.ln_blocks), dim3(256), 0, s, x, g, g2, lp, M);
-        else hipLaunchKernelGGL(ln_param_partial_kernel<2>, dim3(lay.ln_blocks), dim3(256), 0, s, x, g, g2, lp, M);
-        hipLaunchKernelGGL(ln_param_final_kernel, dim3(2 * N / 64), dim3(256), 0, s, lp, lay.ln_blocks, N, dgam, dbet);
+        const int nblk = (Ms + kLnRows - 1) / kLnRows;
+        if (N == 768) hipLaunchKernelGGL(ln_param_partial_kernel<3>, dim3(nblk), dim3(256), 0, s, x, g, g2, lp, Ms);
+        else hipLaunchKernelGGL(ln_param_partial_kernel<2>, dim3(nblk), dim3(256), 0, s, x, g, g2, lp, Ms);
+        hipLaunchKernelGGL(ln_param_final_kernel, dim3(2 * N / 64), dim3(256), 0, s, lp, nblk, N, dgam, dbet);
     };
 
     // ---- head -> d loss / d x_12 -------------------------------------------------------------------
@@ -1471,74 +1517,95 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
                                G(po.emb_w), G(po.emb_b));
     }
     // ---- 12 transformer layers, last to first ---------------------------------------------------------
-    for (int l = NOMAD_NUM_LAYERS - 1; l >= 0; --l) {
+    // One layer over clips [c0, c0 + nc): the whole batch, or one branch when LayerDrop split the branches.
+    auto bwd_layer = [&](int l, int c0, int nc) -> int {
         const LayerDev& d = c->layers[l];
-        const SavedLayer& sl = sv.L[l];
         const LayerOffsets& lo = po.L[l];
-        const float* dl = dlayers ? dlayers + (size_t)l * M * 768 : nullptr;
-        if (!((layer_mask >> l) & 1u)) continue;  // LayerDrop: identity in the forward, identity here
-        if ((rc = run_ln_bwd(c, sl.y2, gx, dl, d.ln2_w, dya, M, 768, s))) return rc;                   // dy2
+        const long long r0 = (long long)c0 * T;
+        const int Ms = nc * T, Mps = (Ms + 511) / 512 * 512;
+        const long long acts = (long long)Ms * 768;
+        const unsigned long long idx0 = (unsigned long long)r0 * 768;
+        const SavedLayer& sl0 = sv.L[l];
+        const float *y2 = sl0.y2 + r0 * 768, *y1 = sl0.y1 + r0 * 768, *u = sl0.u + r0 * 3072, *qkv = sl0.qkv + r0 * 2304,
+                    *ctx = sl0.ctx + r0 * 768, *lse = sl0.lse + (long long)c0 * 12 * T;
+        float *gxs = gx + r0 * 768, *dyas = dya + r0 * 768, *dybs = dyb + r0 * 768, *dhs = dh + r0 * 3072,
+              *dqkvs = dqkv + r0 * 2304, *dmasks = dmask ? dmask + r0 * 768 : nullptr;
+        const float* dl = dlayers ? dlayers + (size_t)l * M * 768 + r0 * 768 : nullptr;
+        int rc;
+        if ((rc = run_ln_bwd(c, y2, gxs, dl, d.ln2_w, dyas, Ms, 768, s))) return rc;                    // dy2
         // dy2 feeds the residual as is and the fc2 branch through its dropout mask
-        const float* dy2b = dya;
+        const float* dy2b = dyas;
         if (d_res.threshold) {
-            if ((rc = run_dropout(c, dya, nullptr, dmask, act, d_res, site_ffn(l), s))) return rc;
-            dy2b = dmask;
+            if ((rc = run_dropout(c, dyas, nullptr, dmasks, acts, d_res, site_ffn(l), s, idx0))) return rc;
+            dy2b = dmasks;
         }
         if (train) {
-            ln_params(sl.y2, gx, dl, 768, G(lo.ln2_w), G(lo.ln2_b));
-            tpose(dy2b, 768, TA, false);
-            rowsum(TA, 768, G(lo.fc2_b), 1.0f);
-            tpose(sl.u, 3072, TB, true);  // h = gelu(u), recomputed
-            if ((rc = dw_gemm(c, TA, TB, 768, 3072, Mp, part, G(lo.fc2_w), 0, 1.0f, s))) return rc;
+            ln_params(y2, gxs, dl, 768, G(lo.ln2_w), G(lo.ln2_b), Ms);
+            tpose(dy2b, 768, TA, false, Ms, Mps);
+            rowsum(TA, 768, G(lo.fc2_b), 1.0f, Mps);
+            tpose(u, 3072, TB, true, Ms, Mps);  // h = gelu(u), recomputed
+            if ((rc = dw_gemm(c, TA, TB, 768, 3072, Mps, part, G(lo.fc2_w), 0, 1.0f, s))) return rc;
         }
-        if ((rc = bwd_gemm(c, dy2b, c->fc2_wT[l], dh, M, 3072, 768, sl.u, nullptr, s))) return rc;     // du = (dy2 W2) * gelu'(u)
+        if ((rc = bwd_gemm(c, dy2b, c->fc2_wT[l], dhs, Ms, 3072, 768, u, nullptr, s))) return rc;      // du = (dy2 W2) * gelu'(u)
         if (train) {
-            tpose(dh, 3072, TA, false);
-            rowsum(TA, 3072, G(lo.fc1_b), 1.0f);
+            tpose(dhs, 3072, TA, false, Ms, Mps);
+            rowsum(TA, 3072, G(lo.fc1_b), 1.0f, Mps);
             // fc1's input = LayerNorm(y1), recomputed into gx (the upstream gradient it held has been consumed)
-            if ((rc = run_layernorm(c, sl.y1, d.ln1_w, d.ln1_b, gx, nullptr, M, 768, s))) return rc;
-            tpose(gx, 768, TB, false);
-            if ((rc = dw_gemm(c, TA, TB, 3072, 768, Mp, part, G(lo.fc1_w), 0, 1.0f, s))) return rc;
+            if ((rc = run_layernorm(c, y1, d.ln1_w, d.ln1_b, gxs, nullptr, Ms, 768, s))) return rc;
+            tpose(gxs, 768, TB, false, Ms, Mps);
+            if ((rc = dw_gemm(c, TA, TB, 3072, 768, Mps, part, G(lo.fc1_w), 0, 1.0f, s))) return rc;
         }
-        if ((rc = bwd_gemm(c, dh, c->fc1_wT[l], dyb, M, 768, 3072, nullptr, dya, s))) return rc;       // dx1 = du W1 + dy2
-        if ((rc = run_ln_bwd(c, sl.y1, dyb, nullptr, d.ln1_w, dya, M, 768, s))) return rc;             // dy1
-        if (train) ln_params(sl.y1, dyb, nullptr, 768, G(lo.ln1_w), G(lo.ln1_b));
-        const float* dy1b = dya;  // dy1 through out_proj's dropout mask
+        if ((rc = bwd_gemm(c, dhs, c->fc1_wT[l], dybs, Ms, 768, 3072, nullptr, dyas, s))) return rc;   // dx1 = du W1 + dy2
+        if ((rc = run_ln_bwd(c, y1, dybs, nullptr, d.ln1_w, dyas, Ms, 768, s))) return rc;             // dy1
+        if (train) ln_params(y1, dybs, nullptr, 768, G(lo.ln1_w), G(lo.ln1_b), Ms);
+        const float* dy1b = dyas;  // dy1 through out_proj's dropout mask
         if (d_res.threshold) {
-            if ((rc = run_dropout(c, dya, nullptr, dmask, act, d_res, site_proj(l), s))) return rc;
-            dy1b = dmask;
+            if ((rc = run_dropout(c, dyas, nullptr, dmasks, acts, d_res, site_proj(l), s, idx0))) return rc;
+            dy1b = dmasks;
         }
         if (train) {
-            tpose(dy1b, 768, TA, false);
-            rowsum(TA, 768, G(lo.o_b), 1.0f);
-            tpose(sl.ctx, 768, TB, false);
-            if ((rc = dw_gemm(c, TA, TB, 768, 768, Mp, part, G(lo.o_w), 0, 1.0f, s))) return rc;
+            tpose(dy1b, 768, TA, false, Ms, Mps);
+            rowsum(TA, 768, G(lo.o_b), 1.0f, Mps);
+            tpose(ctx, 768, TB, false, Ms, Mps);
+            if ((rc = dw_gemm(c, TA, TB, 768, 768, Mps, part, G(lo.o_w), 0, 1.0f, s))) return rc;
         }
-        if ((rc = bwd_gemm(c, dy1b, c->o_wT[l], dyb, M, 768, 768, nullptr, nullptr, s))) return rc;    // dctx
+        if ((rc = bwd_gemm(c, dy1b, c->o_wT[l], dybs, Ms, 768, 768, nullptr, nullptr, s))) return rc;  // dctx
         {
-            Scope sc(c, s, NOMAD_K_ATTN, 14.0 * B * 12.0 * (double)T * T * 64);  // 7 T x T x 64 products (S, dP twice)
-            HIP_TRY(launch_attention_bwd(sl.qkv, sl.ctx, dyb, sl.lse, F(lay.attnd), dqkv, B, T, d_att, site_attn(l), s));
+            Scope sc(c, s, NOMAD_K_ATTN, 14.0 * nc * 12.0 * (double)T * T * 64);  // 7 T x T x 64 products (S, dP twice)
+            HIP_TRY(launch_attention_bwd(qkv, ctx, dybs, lse, F(lay.attnd), dqkvs, nc, T, d_att, site_attn(l), s, c0 * 12));
         }
         if (train) {
             // the forward's fused weight holds q scaled by head_dim^-0.5: d q_proj = 0.125 * d fused rows 0..767
-            tpose(dqkv, 2304, TA, false);
-            rowsum(TA, 768, G(lo.qkv_b), 0.125f);
-            rowsum(TA + (size_t)768 * Mp, 1536, G(lo.qkv_b) + 768, 1.0f);
-            const float* xin = layers_out + (size_t)(l > 0 ? l - 1 : 0) * M * 768;
+            tpose(dqkvs, 2304, TA, false, Ms, Mps);
+            rowsum(TA, 768, G(lo.qkv_b), 0.125f, Mps);
+            rowsum(TA + (size_t)768 * Mps, 1536, G(lo.qkv_b) + 768, 1.0f, Mps);
+            const float* xin = layers_out + (size_t)(l > 0 ? l - 1 : 0) * M * 768 + r0 * 768;
             if (l == 0) {  // layer 0 reads dropout(LayerNorm(y0)): recomputed into dyb (dctx has been consumed)
-                if ((rc = run_layernorm(c, sv.y0, c->eln_w, c->eln_b, dyb, nullptr, M, 768, s))) return rc;
-                if (d_res.threshold && (rc = run_dropout(c, dyb, nullptr, dyb, act, d_res, kSiteEncoder, s))) return rc;
-                xin = dyb;
+                if ((rc = run_layernorm(c, sv.y0 + r0 * 768, c->eln_w, c->eln_b, dybs, nullptr, Ms, 768, s))) return rc;
+                if (d_res.threshold && (rc = run_dropout(c, dybs, nullptr, dybs, acts, d_res, kSiteEncoder, s, idx0))) return rc;
+                xin = dybs;
             }
-            tpose(xin, 768, TB, false);
-            if ((rc = dw_gemm(c, TA, TB, 2304, 768, Mp, part, G(lo.qkv_w), 768, 0.125f, s))) return rc;
+            tpose(xin, 768, TB, false, Ms, Mps);
+            if ((rc = dw_gemm(c, TA, TB, 2304, 768, Mps, part, G(lo.qkv_w), 768, 0.125f, s))) return rc;
         }
-        if ((rc = bwd_gemm(c, dqkv, c->qkv_wT[l], gx, M, 768, 2304, nullptr, dya, s))) return rc;      // dx_in = dqkv Wqkv + dy1
+        return bwd_gemm(c, dqkvs, c->qkv_wT[l], gxs, Ms, 768, 2304, nullptr, dyas, s);                 // dx_in = dqkv Wqkv + dy1
+    };
+    for (int l = NOMAD_NUM_LAYERS - 1; l >= 0; --l) {
+        unsigned all = 1u;
+        for (int br = 0; br < nbr; ++br) all &= (bmask[br] >> l) & 1u;
+        if (all) {
+            if ((rc = bwd_layer(l, 0, B))) return rc;
+            continue;
+        }
+        for (int br = 0; br < nbr; ++br)  // LayerDrop: identity in the forward, identity here, per branch
+            if ((bmask[br] >> l) & 1u)
+                if ((rc = bwd_layer(l, br * (B / nbr), B / nbr))) return rc;
     }
+    const int Mp = lay.Mp;
     // ---- encoder input: LayerNorm, x + gelu(pos_conv(x)) --------------------------------------------
     if (d_res.threshold && (rc = run_dropout(c, gx, nullptr, gx, act, d_res, kSiteEncoder, s))) return rc;
     if ((rc = run_ln_bwd(c, sv.y0, gx, nullptr, c->eln_w, dya, M, 768, s))) return rc;                   // dy0
-    if (train) ln_params(sv.y0, gx, nullptr, 768, G(po.eln_w), G(po.eln_b));
+    if (train) ln_params(sv.y0, gx, nullptr, 768, G(po.eln_w), G(po.eln_b), M);
     const long long grp_stride = (long long)B * (T + 128) * 48;
     {
         float* dug = F(lay.dug);
@@ -1605,14 +1672,14 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
         }
         // ---- post_extract_proj parameters (its output went through dropout_input) ------------------------
         if (d_in.threshold && (rc = run_dropout(c, dyb, nullptr, dyb, act, d_in, kSiteInput, s))) return rc;
-        tpose(dyb, 768, TA, false);
-        rowsum(TA, 768, G(po.proj_b), 1.0f);
-        tpose(featln, 512, TB, false);
+        tpose(dyb, 768, TA, false, M, Mp);
+        rowsum(TA, 768, G(po.proj_b), 1.0f, Mp);
+        tpose(featln, 512, TB, false, M, Mp);
         if ((rc = dw_gemm(c, TA, TB, 768, 512, Mp, part, G(po.proj_w), 0, 1.0f, s))) return rc;
     }
     // ---- post_extract_proj, LayerNorm(512), GELU of conv6 ----------------------------------------------
     if ((rc = bwd_gemm(c, dyb, c->proj_wT, F(lay.f1), M, 512, 768, nullptr, nullptr, s))) return rc;
-    if (train) ln_params(sv.c6, F(lay.f1), nullptr, 512, G(po.fln_w), G(po.fln_b));
+    if (train) ln_params(sv.c6, F(lay.f1), nullptr, 512, G(po.fln_w), G(po.fln_b), M);
     HIP_TRY(hipGetLastError());
     if (!dwav) return 0;  // frozen conv feature extractor (freeze_convnet: True): nothing upstream needs a gradient
     if ((rc = run_ln_bwd(c, sv.c6, F(lay.f1), nullptr, c->fln_w, F(lay.f2), M, 512, s))) return rc;
@@ -1961,6 +2028,14 @@ int nomad_train_set_stochastic(nomad_ctx* c, float dropout, float attention_drop
     c->p_input = dropout_input;
     c->drop_seed = seed;
     c->layer_mask = layer_mask & 0xFFFu;
+    return 0;
+}
+
+int nomad_train_set_branches(nomad_ctx* c, int branches, const unsigned* layer_masks) {
+    if (!c || branches < 1 || branches > 4 || (branches > 1 && !layer_masks))
+        return fail(NOMAD_ERR_INVALID, "nomad_train_set_branches: 1..4 branches, one mask each");
+    c->branches = branches;
+    for (int i = 0; i < branches && layer_masks; ++i) c->branch_mask[i] = layer_masks[i] & 0xFFFu;
     return 0;
 }
 

@@ -429,14 +429,15 @@ __global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ theta, c
 }
 
 // ---- dropout (dropout.hip.h) -------------------------------------------------------------------------------
-// y[i] = (resid ? resid[i] : 0) + keep(i) * scale * x[i];  x == y allowed.
+// y[i] = (resid ? resid[i] : 0) + keep(idx0 + i) * scale * x[i];  x == y allowed.  idx0: element index of x[0] in the
+// whole tensor (a call on one branch of a merged batch keeps the whole batch's mask).
 __global__ __launch_bounds__(256) void dropout_add_kernel(const float4* __restrict__ x, const float4* __restrict__ resid,
                                                           float4* __restrict__ y, long long n4, DropCfg d,
-                                                          uint32_t site) {
+                                                          uint32_t site, unsigned long long idx0) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     float4 v = x[i];
-    const unsigned long long e = (unsigned long long)i * 4;
+    const unsigned long long e = idx0 + (unsigned long long)i * 4;
     v.x *= drop_mult(d, site, e); v.y *= drop_mult(d, site, e + 1);
     v.z *= drop_mult(d, site, e + 2); v.w *= drop_mult(d, site, e + 3);
     if (resid) {

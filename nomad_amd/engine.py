@@ -363,6 +363,15 @@ class Engine:
                                                        float(dropout_input), int(seed) & (2 ** 64 - 1),
                                                        int(layer_mask) & 0xFFF), "nomad_train_set_stochastic")
 
+    def train_set_branches(self, layer_masks=None):
+        """The following training batches are len(layer_masks) equal groups of clips, each with its own LayerDrop
+        mask (None: back to one group using train_set_stochastic's layer_mask)."""
+        if not layer_masks:
+            _lib.check(self.lib.nomad_train_set_branches(self.ctx, 1, None), "nomad_train_set_branches")
+            return
+        arr = (C.c_uint * len(layer_masks))(*[int(m) & 0xFFF for m in layer_masks])
+        _lib.check(self.lib.nomad_train_set_branches(self.ctx, len(layer_masks), arr), "nomad_train_set_branches")
+
     def train_set_step(self, step: int):
         _lib.check(self.lib.nomad_train_set_step(self.ctx, int(step)), "nomad_train_set_step")
 

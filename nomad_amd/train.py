@@ -114,7 +114,7 @@ class ExponentialLR:
 
 class Training:
     def __init__(self, config_file, device: int = 0, engine: Optional[Engine] = None,
-                 regularisation: Optional[dict] = None):
+                 regularisation: Optional[dict] = None, merge_branches: bool = True):
         import yaml
         if isinstance(config_file, dict):
             self.config = dict(config_file)
@@ -141,6 +141,7 @@ class Training:
         self.reg = dict(W2V_BASE_REGULARISATION)
         self.reg.update(regularisation or {})
         self._rng = np.random.RandomState(SEED)  # LayerDrop draws + per-call dropout seeds
+        self.merge_branches = merge_branches     # A/P/N as one 3B-clip launch sequence when their padded lengths agree
         if self.config["experiment_name"] == "Training":
             self.current_level = self.config.get("current_level")
             g = torch.Generator()
@@ -185,15 +186,31 @@ class Training:
             return eng.triplet_loss(embs[0].contiguous(), embs[1].contiguous(), embs[2].contiguous(), self.margin,
                                     want_grad=False)[0]
         draws = [self._draw() for _ in wavs]
-        outs = []
-        for w, d in zip(wavs, draws):
+        if self.merge_branches and wavs[0].shape == wavs[1].shape == wavs[2].shape:
+            # The three forwards as ONE batch of 3B clips: every clip goes through the same arithmetic as in its own
+            # call, LayerDrop stays per branch (the engine runs a layer per branch where the draws disagree), and
+            # the dropout masks of the three branches are disjoint slices of one counter-based stream.
+            B = wavs[0].shape[0]
+            d = dict(draws[0], layer_mask=0xFFF)
             eng.train_set_stochastic(**d)
-            outs.append(eng.embed_train(w))
-        loss, da, dp, dn = eng.triplet_loss(outs[0][0], outs[1][0], outs[2][0], self.margin)
-        eng.train_zero_grad()
-        for w, (_, layers, saved), g, d in zip(wavs, outs, (da, dp, dn), draws):
-            eng.train_set_stochastic(**d)
-            eng.train_backward(w, layers, saved, g)
+            eng.train_set_branches([x["layer_mask"] for x in draws])
+            w = torch.cat(wavs, dim=0)
+            emb, layers, saved = eng.embed_train(w)
+            loss, da, dp, dn = eng.triplet_loss(emb[:B].contiguous(), emb[B:2 * B].contiguous(), emb[2 * B:].contiguous(),
+                                                self.margin)
+            eng.train_zero_grad()
+            eng.train_backward(w, layers, saved, torch.cat([da, dp, dn], dim=0))
+            eng.train_set_branches(None)
+        else:
+            outs = []
+            for w, d in zip(wavs, draws):
+                eng.train_set_stochastic(**d)
+                outs.append(eng.embed_train(w))
+            loss, da, dp, dn = eng.triplet_loss(outs[0][0], outs[1][0], outs[2][0], self.margin)
+            eng.train_zero_grad()
+            for w, (_, layers, saved), g, d in zip(wavs, outs, (da, dp, dn), draws):
+                eng.train_set_stochastic(**d)
+                eng.train_backward(w, layers, saved, g)
         eng.train_set_stochastic()
         lr_body, lr_head = self.lr_scheduler.get_last_lr()
         eng.adam_step(lr_body, lr_head)

@@ -125,8 +125,19 @@ def backbone(sd: Dict[str, torch.Tensor], wav: torch.Tensor, taps: Optional[dict
         taps["enc_in"] = x
     layers = []
     for l in range(NUM_LAYERS):
-        if stoch is None or (stoch.layer_mask >> l) & 1:  # LayerDrop: a dropped layer is the identity
+        if stoch is None:
             x = encoder_layer(sd, l, x, taps, stoch)
+        elif stoch.branch_masks is None:
+            if (stoch.layer_mask >> l) & 1:  # LayerDrop: a dropped layer is the identity
+                x = encoder_layer(sd, l, x, taps, stoch)
+        else:
+            # merged batch of equal branches (anchor | positive | negative), LayerDrop decided per branch: clips are
+            # independent, so "the layer on the kept branches" = the layer on everything, kept where it applies
+            nb = len(stoch.branch_masks)
+            keep = torch.tensor([(m >> l) & 1 for m in stoch.branch_masks], dtype=torch.bool)
+            if bool(keep.any()):
+                keep_rows = keep.repeat_interleave(x.shape[0] // nb)[:, None, None]
+                x = torch.where(keep_rows, encoder_layer(sd, l, x, taps, stoch), x)
         layers.append(x)
     return x, layers
 
@@ -234,9 +245,10 @@ class Stochastic:
     semantics - given the same masks on both sides."""
 
     def __init__(self, seed: int, dropout: float = 0.1, attention_dropout: float = 0.1, dropout_input: float = 0.1,
-                 layer_mask: int = 0xFFF):
+                 layer_mask: int = 0xFFF, branch_masks: Optional[Sequence[int]] = None):
         self.seed, self.dropout, self.attention_dropout = int(seed), float(dropout), float(attention_dropout)
         self.dropout_input, self.layer_mask = float(dropout_input), int(layer_mask)
+        self.branch_masks = list(branch_masks) if branch_masks is not None else None  # one LayerDrop mask per branch
 
     @staticmethod
     def _fmix32(h: np.ndarray) -> np.ndarray:

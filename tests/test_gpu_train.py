@@ -313,3 +313,59 @@ def test_training_loop_runs_and_saves_a_loadable_checkpoint(tmp_path, monkeypatc
         assert after < before + 0.05  # two tiny epochs: the validation loss does not blow up
     finally:
         tr.engine.close()
+
+
+# ---- A/P/N as one merged batch with per-branch LayerDrop ----------------------------------------------------------
+@pytest.mark.parametrize("masks", [(0xFFF, 0xFFF, 0xFFF), (0xFFF & ~(1 << 3), 0xFFE, 0x7FF & ~(1 << 3)), (0x0F0, 0xF0F, 0xFFF)])
+def test_merged_branches_match_oracle(teng, sd_train, masks):
+    B, n, margin = 2, 6000, 1.0
+    A, P, N = _triplet_batch(B, n, seed=31)
+    st = O.Stochastic(seed=(77 << 33) + 5, dropout=0.1, attention_dropout=0.1, dropout_input=0.1, branch_masks=masks)
+    # oracle: one forward over the concatenated batch, loss on its three thirds
+    sd = {k: v.clone() for k, v in sd_train.items()}
+    keys = O.trainable_keys(sd)
+    for k in keys:
+        sd[k].requires_grad_(True)
+    e = O.triplet_forward(sd, torch.cat([A, P, N]), st)
+    ref_loss = torch.nn.TripletMarginLoss(margin=margin)(e[:B], e[B:2 * B], e[2 * B:])
+    ref = dict(zip(keys, torch.autograd.grad(ref_loss, [sd[k] for k in keys])))
+    # engine: merged batch, per-branch masks
+    w = torch.cat([A, P, N]).cuda()
+    teng.train_set_stochastic(st.dropout, st.attention_dropout, st.dropout_input, st.seed, 0xFFF)
+    teng.train_set_branches(list(masks))
+    try:
+        emb, layers, saved = teng.embed_train(w)
+        loss, da, dp, dn = teng.triplet_loss(emb[:B].contiguous(), emb[B:2 * B].contiguous(), emb[2 * B:].contiguous(), margin)
+        teng.train_zero_grad()
+        teng.train_backward(w, layers, saved, torch.cat([da, dp, dn]))
+        flat = teng.train_read(1)
+    finally:
+        teng.train_set_branches(None)
+        teng.train_set_stochastic()
+    assert (emb.cpu() - e.detach()).abs().max().item() < 2e-5
+    assert abs(loss.item() - ref_loss.item()) < 5e-5
+    got = teng.train_unflatten(flat)
+    top = max(v.abs().max().item() for v in ref.values())
+    for k, want in ref.items():
+        assert (got[k] - want).abs().max().item() < 2e-4 * want.abs().max().item() + 1e-6 * top, k
+
+
+def test_merged_equals_separate_calls_in_eval_arithmetic(teng):
+    """Without regularisation the merged batch and the reference's three calls are the same function: embeddings
+    bit-identical (batch invariance), gradients equal up to the summation order of the weight-gradient GEMMs."""
+    B = 2
+    A, P, N = _triplet_batch(B, 6000, seed=41)
+    _, g_sep = _gpu_step_grads(teng, A, P, N, 1.0)
+    w = torch.cat([A, P, N]).cuda()
+    teng.train_set_branches([0xFFF] * 3)
+    try:
+        emb, layers, saved = teng.embed_train(w)
+        for i, x in enumerate((A, P, N)):
+            assert torch.equal(emb[i * B:(i + 1) * B], teng.embed(x.cuda()))
+        loss, da, dp, dn = teng.triplet_loss(emb[:B].contiguous(), emb[B:2 * B].contiguous(), emb[2 * B:].contiguous(), 1.0)
+        teng.train_zero_grad()
+        teng.train_backward(w, layers, saved, torch.cat([da, dp, dn]))
+        g_m = teng.train_read(1)
+    finally:
+        teng.train_set_branches(None)
+    assert (g_m - g_sep).abs().max().item() < 1e-5 * g_sep.abs().max().item()

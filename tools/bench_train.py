@@ -13,6 +13,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--eval-mode", action="store_true", help="no dropout / LayerDrop")
+    ap.add_argument("--separate", action="store_true", help="three separate forward/backward calls (no merged batch)")
     ap.add_argument("--cpu", action="store_true", help="also time one torch-autograd step of the CPU oracle")
     ap.add_argument("--out", type=str, default="")
     args = ap.parse_args()
@@ -25,7 +26,7 @@ def main():
     cfg = dict(experiment_name="bench", checkpoint_path="seeded", margin=0.2, lr=1e-4, lr_decay_factor=0.99)
     reg = dict(dropout=0.0, attention_dropout=0.0, dropout_input=0.0, encoder_layerdrop=0.0) if args.eval_mode else None
     sd = seeded_state_dict(0)
-    tr = Training(cfg, engine=Engine(sd, 0), regularisation=reg)
+    tr = Training(cfg, engine=Engine(sd, 0), regularisation=reg, merge_branches=not args.separate)
     from nomad_amd.train import ExponentialLR
     tr.margin, tr.lr_scheduler = 0.2, ExponentialLR([1e-5, 1e-4], 0.99)
     eng = tr.engine
@@ -44,6 +45,7 @@ def main():
     T = num_frames(n)
     fwd_flop = 3 * args.bs * (56.925e9 * T / 199.0)  # ~linear in T except the T^2 attention term (small)
     res = {"workload": f"triplet step 3x({args.bs},1,{n}) T={T}", "mode": "eval-arith" if args.eval_mode else "train (dropout+layerdrop)",
+           "branches": "separate calls" if args.separate else "merged 3B batch",
            "ms_per_step": dt * 1e3, "triplets_per_s": args.bs / dt, "loss": loss.item(),
            "approx_model_tflops": 3 * fwd_flop / dt / 1e12,
            "classes_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
