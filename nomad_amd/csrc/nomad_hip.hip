@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -170,7 +171,7 @@ struct BwdLayout {
     int Mp, pos_split, ln_blocks;
 };
 
-constexpr size_t kSplitPartFloats = (size_t)16 * 768 * 768 * 2;  // >= S * Nout * Kin for every split chosen below
+constexpr size_t kSplitPartFloats = (size_t)16 * 2304 * 768;  // >= S * Nout * Kin for every split chosen below
 
 BwdLayout make_bwd_layout(const Shapes& s, bool train = false) {
     BwdLayout l{};
@@ -442,6 +443,9 @@ int pick_tile(int M, int N, int K) {
     // less than one round of 256x128 tiles (batch 1 .. a few dozen short clips, config C4): 64x64 tiles keep the
     // most CUs busy; one wave's K loop is the latency floor there (profiles/r01_gemm_sweep_small_m.json)
     if (tiles256 < 512) return 37;
+    // a few rounds of tiles with wide N (the merged training batch, M ~ 12k): 128x128 tiles, 4 waves
+    // (profiles/r01_gemm_sweep_train_m.json)
+    if (N >= 2048 && N % 128 == 0 && tiles256 < 2048) return 20;
     return 34;
 }
 
@@ -1422,9 +1426,12 @@ int nomad_l1_loss_backward(nomad_ctx* c, const float* a_layers, const float* b_l
 // GEMM kernel with the contraction split over `S` groups, partial products folded in fixed order.
 static int dw_gemm(nomad_ctx* c, const float* TA, const float* TB, int Nout, int Kin, int Mp, float* part, float* out,
                    int rows_scaled, float scale, hipStream_t s) {
+    // 128x64 tiles; enough splits for ~1500 workgroups (measured on the training shapes: 512 -> 1536 workgroups
+    // is 4 % of a step, beyond that nothing)
+    const int tile = 34;
     const int tiles = (Nout / 128) * (Kin / 64);
     int S = 1;
-    while (S < 16 && tiles * S < 512) S *= 2;
+    while (S < 16 && tiles * S < 1536) S *= 2;
     if ((size_t)S * Nout * Kin > kSplitPartFloats) return fail(NOMAD_ERR_INVALID, "dw_gemm: partial buffer too small");
     const int Kc = Mp / S;
     GemmParams p = dense(TA, Mp, TB, nullptr, nullptr, part, Nout, Kin, Kc, 0);
@@ -1433,7 +1440,7 @@ static int dw_gemm(nomad_ctx* c, const float* TA, const float* TB, int Nout, int
     p.w_goff = Kc;
     p.c_goff = (long long)Nout * Kin;
     int rc;
-    if ((rc = run_gemm(c, p, S, 34, s))) return rc;
+    if ((rc = run_gemm(c, p, S, tile, s))) return rc;
     Scope sc(c, s, NOMAD_K_ROW, 0.0);
     const long long n4 = (long long)Nout * Kin / 4, n4s = (long long)rows_scaled * Kin / 4;
     const float4* p4 = reinterpret_cast<const float4*>(part);

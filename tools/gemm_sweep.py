@@ -36,6 +36,12 @@ SHAPES = {  # name: (M, N, K, bias, gelu, residual)
     "tr_fc1": (3992, 3072, 768, True, True, False),
     "tr_fc2": (3992, 768, 3072, True, False, True),
     "tr_out": (3992, 768, 768, True, False, True),
+    # the merged training batch: 3 x 8 clips x 10 s
+    "tm_qkv": (11976, 2304, 768, True, False, False),
+    "tm_fc1": (11976, 3072, 768, True, True, False),
+    "tm_fc2": (11976, 768, 3072, True, False, True),
+    "tm_out": (11976, 768, 768, True, False, True),
+    "tm_dxin": (11976, 768, 2304, False, False, True),
     # weight-gradient shapes (rows = out features, cols = in features, contraction = padded rows / split)
     "dw_fc1": (3072, 768, 2048, False, False, False),
     "dw_out": (768, 768, 512, False, False, False),
