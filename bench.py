@@ -166,7 +166,8 @@ def main():
             "data": "synthetic (0.1*randn waveforms, seed 1000+rank; " +
                     ("real nomad_best_model.pt" if ckpt else "seeded random-init wav2vec2-base + head weights") + ")",
             "config": {"workload": f"configs[1]: batch={B} x {n_samples} samples (T={T}) per GPU, wav2vec2-base + "
-                                   f"projection head fp32, {B - n_ref} deg x {n_ref}*N ref float64 distances + means",
+                                   f"projection head {'bf16 storage / fp32 accumulate' if args.dtype == 'bf16' else 'fp32'}, {B - n_ref} deg x {n_ref}*N "
+                                   f"ref float64 distances + means",
                        "clips_per_gpu_per_step": B, "deg_per_gpu": B - n_ref, "ref_total": n_ref * world,
                        "parallelism": f"clip-sharded x{world}, all-gather of ref embeddings"},
         }
@@ -187,7 +188,8 @@ def main():
             allg, big, fine = prof["gemm_mfma_all"], prof["gemm_mfma_256x128"], prof["gemm_mfma_128x64"]
             dom = big if big["ms"] >= fine["ms"] else fine      # the dominant kernel = the instantiation with most time
             if args.dtype == "bf16":
-                kname = "gemm_bf16_glds_kernel (v_mfma_f32_32x32x16_bf16), " + ("128x128/256x256" if dom is big else "128x64") + " instantiation"
+                kname = ("gemm_bf16_8phase_kernel 256x256 (v_mfma_f32_16x16x32_bf16) + gemm_bf16_glds_kernel 128x128/256x256"
+                         if dom is big else "gemm_bf16_glds_kernel 128x64 (v_mfma_f32_32x32x16_bf16)")
             else:
                 kname = "gemm_f32_glds_kernel<" + ("256,128,16,4,2,3" if dom is big else "128,64,32,4,2,3") + "> (v_mfma_f32_32x32x2_f32)"
             ach = rate(dom)

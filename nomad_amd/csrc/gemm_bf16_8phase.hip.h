@@ -1,0 +1,268 @@
+// bf16 GEMM, 256 x 256 tile, deep-pipelined "8-phase" schedule for gfx950 (config C5, the wide transformer and conv
+// GEMMs).  The two-barrier-per-K-tile kernel of gemm_bf16.hip.h stalls every K tile on the LDS-DMA it just
+// issued (measured ceiling ~800 TFLOP/s, no-epilogue ablation); this one keeps loads in flight across barriers:
+//
+//   * one workgroup per CU: 8 waves (2 x 4), wave tile 128 x 64 = 8 x 4 accumulators of v_mfma_f32_16x16x32_bf16;
+//   * LDS = 2 K-tile buffers x (A 256 x 64 + B 256 x 64 bf16) = 128 KB, staged by global_load_lds in HALF-tiles
+//     (128 rows, 2 DMA instructions per thread), same XOR chunk swizzle as gemm_bf16.hip.h (4 lanes per 16-byte
+//     slot of a 256-byte bank row = the minimum for a 1 KB wave read);
+//   * a K tile is 4 phases of 16 MFMAs (one 64 x 32 quadrant of the wave tile x K = 64); every phase issues one
+//     half-tile of DMA for a LATER K tile, so 2-3 half-tiles are always in flight:
+//         phase 1: read A rows 0..63 (8 x ds_read_b128) + B columns 0..31 (4),   DMA B-half0 of tile t+1
+//         phase 2: read A rows 64..127 (8),                                       DMA B-half1 of tile t+1
+//         phase 3: read B columns 32..63 (4)
+//         phase 4: DMA A-half0 and A-half1 of tile t+2, then s_waitcnt vmcnt(4) = "tile t+1 has landed"
+//   * the only waits are that counted vmcnt once per K tile and lgkmcnt(0) before each MFMA cluster; barriers are
+//     raw s_barrier.  The two wave rows run one barrier apart (ping-pong): while one row's 16 MFMAs occupy the matrix
+//     cores, the other row issues its LDS reads and DMA.
+//   Hazards (with the one-barrier stagger a buffer may be re-staged no earlier than TWO phases after its last read,
+//   and is read no earlier than the phase after the wait that retires its DMA):
+//     A halves: read in phases 1-2 of tile t     -> re-staged in phase 4 of tile t (for t+2), waited in phase 4 of t+1
+//     B halves: read in phases 1 and 3 of tile t -> re-staged in phases 1/2 of tile t+1 (for t+2), waited in phase 4 of t+1
+//
+// Requirements: N % 256 == 0, K % 128 == 0 (K tiles are processed in pairs so that buffer addresses are constants).
+// Epilogue: fp32 slabs through LDS, bias / GELU / residual in fp32, 16-byte bf16 stores (as gemm_bf16_glds_kernel).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "dtypes.hip.h"
+#include "gemm_f32.hip.h"
+
+namespace nomad {
+
+struct P8Cfg {
+    static constexpr int BM = 256, BN = 256, BK = 64, THREADS = 512;
+    static constexpr int HALF_BYTES = 128 * 128;            // 128 rows x 64 bf16
+    static constexpr int BUF_BYTES = 4 * HALF_BYTES;        // A0 A1 B0 B1
+    static constexpr int LDS_BYTES = 2 * BUF_BYTES;         // 128 KB
+    static constexpr int ELD = 64 + 4;                      // epilogue slab row (floats)
+};
+
+// ABL (timing-only ablations): 1 = no epilogue stores.
+template <int ABL = 0>
+__global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams p) {
+    using Cfg = P8Cfg;
+    extern __shared__ __attribute__((aligned(16))) char smem8[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int wg = xcd_remap(blockIdx.x, nwg);
+    int tile_m, tile_n;
+    tile_coords(wg, p.tiles_m, p.tiles_n, p.group_m, tile_m, tile_n);
+    const int m0 = tile_m * Cfg::BM, n0 = tile_n * Cfg::BN;
+    const int grp = blockIdx.y;
+    const bf16_t* Ag = reinterpret_cast<const bf16_t*>(p.A) + grp * p.a_goff;
+    const bf16_t* Wg = reinterpret_cast<const bf16_t*>(p.W) + grp * p.w_goff;
+
+    // DMA sources as (uniform 64-bit base) + (per-thread 32-bit byte offset): one VGPR per address instead of two, so
+    // that the whole working set stays inside the 256 registers a wave has at 2 waves/SIMD - a spilled address
+    // would come back through a scratch load whose s_waitcnt drains the whole DMA queue.
+    // Instruction i of a half-tile covers rows (tid + 512 i) / 8, physical chunk (tid + 512 i) % 8.
+    unsigned a_off[2][2], b_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int id = tid + i * 512, row = id >> 3, pc = id & 7;
+        const int sw = (pc ^ ((row >> 1) & 7)) * 8;
+        b_off[i] = (unsigned)(((long long)row * p.ldw + sw) * 2);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int m = m0 + h * 128 + row;
+            m = m < p.M ? m : p.M - 1;
+            a_off[h][i] = (unsigned)((row_addr(p.amap, m) + sw) * 2);
+        }
+    }
+    const char* const a_base = reinterpret_cast<const char*>(Ag);
+    const char* const b_base[2] = {reinterpret_cast<const char*>(Wg + (long long)n0 * p.ldw),
+                                   reinterpret_cast<const char*>(Wg + (long long)(n0 + 128) * p.ldw)};
+    char* const dma_dst = smem8 + wave * 1024;  // + lane * 16 implicit (lane-linear LDS-DMA destination)
+
+    // The K-tile term goes into the 32-bit per-thread offset (a VALU add into a temporary), the 64-bit base stays a
+    // loop-invariant scalar: the compiler then uses the saddr form and has no 64-bit VGPR pointers to hoist.
+#define NOMAD_P8_DMA_A(KT, H)                                                                                   \
+    {                                                                                                           \
+        const int k0_ = (KT)*64;                                                                                \
+        const int kq_ = k0_ / p.kchunk;                                                                         \
+        const unsigned ko_ = (unsigned)((kq_ * p.kstride + (k0_ - kq_ * p.kchunk)) * 2);                        \
+        char* d_ = dma_dst + ((KT)&1) * Cfg::BUF_BYTES + (H)*Cfg::HALF_BYTES;                                   \
+        __builtin_amdgcn_global_load_lds((gptr_t)(a_base + (a_off[H][0] + ko_)), (lptr_t)(d_), 16, 0, 0);        \
+        __builtin_amdgcn_global_load_lds((gptr_t)(a_base + (a_off[H][1] + ko_)), (lptr_t)(d_ + 8192), 16, 0, 0); \
+    }
+#define NOMAD_P8_DMA_B(KT, H)                                                                                   \
+    {                                                                                                           \
+        const unsigned ko_ = (unsigned)((KT)*128);                                                              \
+        char* d_ = dma_dst + ((KT)&1) * Cfg::BUF_BYTES + (2 + (H)) * Cfg::HALF_BYTES;                           \
+        __builtin_amdgcn_global_load_lds((gptr_t)(b_base[H] + (b_off[0] + ko_)), (lptr_t)(d_), 16, 0, 0);        \
+        __builtin_amdgcn_global_load_lds((gptr_t)(b_base[H] + (b_off[1] + ko_)), (lptr_t)(d_ + 8192), 16, 0, 0); \
+    }
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / 64;  // even
+    // prologue: tile 0 complete, A of tile 1 on its way
+    NOMAD_P8_DMA_A(0, 0)
+    NOMAD_P8_DMA_A(0, 1)
+    NOMAD_P8_DMA_B(0, 0)
+    NOMAD_P8_DMA_B(0, 1)
+    NOMAD_P8_DMA_A(1, 0)
+    NOMAD_P8_DMA_A(1, 1)
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (wr == 1) __builtin_amdgcn_s_barrier();  // second wave row runs one barrier behind (ping-pong)
+
+    // fragment addresses: this lane's row fr of a 16-row tile, chunk (4 kh + fq) ^ swizzle
+    const int sw = (fr >> 1) & 7;
+    const int koff0 = ((0 + fq) ^ sw) * 16, koff1 = ((4 + fq) ^ sw) * 16;
+    const int a_frag = wr * Cfg::HALF_BYTES + fr * 128;                                         // + i * 2048
+    const int b_frag = (2 + (wc >> 1)) * Cfg::HALF_BYTES + ((wc & 1) * 64 + fr) * 128;          // + j * 2048
+
+    bf16x8 af[8][2], bf[2][2];
+#define NOMAD_P8_MMA(I0, J0)                                                                               \
+    _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                       \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                  \
+                acc[(I0) + i][(J0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[(I0) + i][kh], bf[j][kh], acc[(I0) + i][(J0) + j], 0, 0, 0);
+#define NOMAD_P8_SYNC_COMPUTE(I0, J0)                   \
+    __builtin_amdgcn_s_barrier();                       \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
+    __builtin_amdgcn_s_setprio(1);                      \
+    NOMAD_P8_MMA(I0, J0)                                \
+    __builtin_amdgcn_s_setprio(0);                      \
+    __builtin_amdgcn_s_barrier();                       \
+    asm volatile("" ::: "memory");
+
+    // one K tile (buffer BUF = KT & 1, a compile-time constant per call site)
+#define NOMAD_P8_KTILE(KT, BUF)                                                                            \
+    {                                                                                                      \
+        const char* ab_ = smem8 + (BUF)*Cfg::BUF_BYTES + a_frag;                                           \
+        const char* bb_ = smem8 + (BUF)*Cfg::BUF_BYTES + b_frag;                                           \
+        /* phase 1: B columns 0..31, A rows 0..63 */                                                       \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                    \
+            bf[j][0] = *reinterpret_cast<const bf16x8*>(bb_ + j * 2048 + koff0);                           \
+            bf[j][1] = *reinterpret_cast<const bf16x8*>(bb_ + j * 2048 + koff1);                           \
+        }                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                    \
+            af[i][0] = *reinterpret_cast<const bf16x8*>(ab_ + i * 2048 + koff0);                           \
+            af[i][1] = *reinterpret_cast<const bf16x8*>(ab_ + i * 2048 + koff1);                           \
+        }                                                                                                  \
+        if ((KT) + 1 < nk) NOMAD_P8_DMA_B((KT) + 1, 0)                                                     \
+        NOMAD_P8_SYNC_COMPUTE(0, 0)                                                                        \
+        /* phase 2: A rows 64..127 */                                                                      \
+        _Pragma("unroll") for (int i = 4; i < 8; ++i) {                                                    \
+            af[i][0] = *reinterpret_cast<const bf16x8*>(ab_ + i * 2048 + koff0);                           \
+            af[i][1] = *reinterpret_cast<const bf16x8*>(ab_ + i * 2048 + koff1);                           \
+        }                                                                                                  \
+        if ((KT) + 1 < nk) NOMAD_P8_DMA_B((KT) + 1, 1)                                                     \
+        NOMAD_P8_SYNC_COMPUTE(4, 0)                                                                        \
+        /* phase 3: B columns 32..63 */                                                                    \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                    \
+            bf[j][0] = *reinterpret_cast<const bf16x8*>(bb_ + (2 + j) * 2048 + koff0);                     \
+            bf[j][1] = *reinterpret_cast<const bf16x8*>(bb_ + (2 + j) * 2048 + koff1);                     \
+        }                                                                                                  \
+        NOMAD_P8_SYNC_COMPUTE(0, 2)                                                                        \
+        /* phase 4: both A halves of tile t+2 (their last read was phase 2), then "tile t+1 has landed" */ \
+        if ((KT) + 2 < nk) {                                                                               \
+            NOMAD_P8_DMA_A((KT) + 2, 0)                                                                    \
+            NOMAD_P8_DMA_A((KT) + 2, 1)                                                                    \
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                               \
+        } else {                                                                                           \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                               \
+        }                                                                                                  \
+        NOMAD_P8_SYNC_COMPUTE(4, 2)                                                                        \
+    }
+
+    for (int kt = 0; kt < nk; kt += 2) {
+        NOMAD_P8_KTILE(kt, 0)
+        NOMAD_P8_KTILE(kt + 1, 1)
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();  // re-join the two wave rows
+#undef NOMAD_P8_KTILE
+#undef NOMAD_P8_SYNC_COMPUTE
+#undef NOMAD_P8_MMA
+#undef NOMAD_P8_DMA_A
+#undef NOMAD_P8_DMA_B
+
+    // ---- epilogue: 32-row fp32 slabs through LDS (accumulator: column fr, rows 4 fq + r of each 16 x 16 tile) ----
+    bf16_t* Cg = reinterpret_cast<bf16_t*>(p.C) + grp * p.c_goff;
+    const bf16_t* Rg = p.R ? reinterpret_cast<const bf16_t*>(p.R) + grp * p.r_goff : nullptr;
+    const float* biasg = p.bias ? p.bias + grp * p.bias_goff : nullptr;
+    const bool c_plain = p.cmap.clip_rows >= p.M, r_plain = p.rmap.clip_rows >= p.M;
+    constexpr int ELD = Cfg::ELD;
+    float* slab = reinterpret_cast<float*>(smem8) + wave * (32 * ELD);
+    float bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wc * 64 + j * 16 + fr;
+        bv[j] = (biasg && n < p.n_valid) ? biasg[n] : 0.f;
+    }
+    __syncthreads();  // every wave is done with the staging buffers
+    // The slab is private to the wave and a wave's LDS operations execute in order, so inside the loop only the
+    // compiler needs a fence: a workgroup barrier here would also wait (vmcnt) for the previous slab's global stores.
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {  // rows 32 s4 .. 32 s4 + 31 of the wave tile = accumulator row-tiles 2 s4, 2 s4 + 1
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[2 * s4 + ii][j][r] + bv[j];
+                    if (p.gelu) v = gelu_erf(v);
+                    slab[(ii * 16 + 4 * fq + r) * ELD + j * 16 + fr] = v;
+                }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (ABL != 1) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {  // 32 rows x 8 groups of 8 columns
+                const int id = lane + 64 * it, row = id >> 3, cg = id & 7;
+                const int m = m0 + wr * 128 + s4 * 32 + row;
+                const int n = n0 + wc * 64 + cg * 8;
+                if (m < p.M && n < p.n_valid) {
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(slab + row * ELD + cg * 8);
+                    const f32x4 hi = *reinterpret_cast<const f32x4*>(slab + row * ELD + cg * 8 + 4);
+                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    if (Rg) {
+                        const bf16x8 rv = *reinterpret_cast<const bf16x8*>(
+                            Rg + (r_plain ? p.rmap.off + (long long)m * p.rmap.ld : row_addr(p.rmap, m)) + n);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+                    }
+                    long long c_col = n;
+                    if (p.c_colblk > 0) {
+                        const int blk = n / p.c_colblk;
+                        c_col = (long long)blk * p.c_colblk_stride + (n - blk * p.c_colblk);
+                    }
+                    bf16x8 ov;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ov[e] = (bf16_t)v[e];
+                    *reinterpret_cast<bf16x8*>(
+                        Cg + (c_plain ? p.cmap.off + (long long)m * p.cmap.ld : row_addr(p.cmap, m)) + c_col) = ov;
+                }
+            }
+        }
+    }
+}
+
+template <int ABL = 0>
+inline hipError_t launch_gemm_bf16_8phase(GemmParams p, int groups, hipStream_t s) {
+    p.tiles_m = (p.M + P8Cfg::BM - 1) / P8Cfg::BM;
+    p.tiles_n = p.N / P8Cfg::BN;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_8phase_kernel<ABL>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_bf16_8phase_kernel<ABL>, dim3(p.tiles_m * p.tiles_n, groups), dim3(P8Cfg::THREADS), P8Cfg::LDS_BYTES, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace nomad

@@ -28,6 +28,7 @@
 #include "backward.hip.h"
 #include "frontend.hip.h"
 #include "gemm_bf16.hip.h"
+#include "gemm_bf16_8phase.hip.h"
 #include "gemm_f32.hip.h"
 #include "pairwise.hip.h"
 #include "rowops.hip.h"
@@ -1063,9 +1064,11 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
         // and very tall problems, 128x128 (8 waves) on the N = 768 / 512 transformer shapes
         if (p.N % 128 != 0) tile = p.M < 512 ? 4 : 2;
         else if (p.M < 512) tile = 4;
+        else if (p.N % 256 == 0 && p.K % 128 == 0 && groups == 1 && (long long)((p.M + 255) / 256) * (p.N / 256) >= 512)
+            tile = 16;  // deep-pipelined 256x256 kernel once there are >= 2 rounds of tiles (profiles/r01_gemm_sweep_bf16_8phase.json)
         else tile = (p.N % 256 == 0 && (p.N >= 1024 || p.M >= 100000)) ? 3 : 1;
     }
-    Scope sc(c, s, NOMAD_K_GEMM, flops, (tile == 1 || tile == 3) ? NOMAD_K_GEMM_BIG : (tile == 2 ? NOMAD_K_GEMM_FINE : -1));
+    Scope sc(c, s, NOMAD_K_GEMM, flops, (tile == 1 || tile == 3 || tile == 16) ? NOMAD_K_GEMM_BIG : (tile == 2 ? NOMAD_K_GEMM_FINE : -1));
     hipError_t e;
     switch (tile) {
         case 0: e = launch_gemm_bf16<256, 128, 4, 2>(p, groups, s); break;
@@ -1084,6 +1087,11 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
         case 13: e = launch_gemm_bf16<256, 128, 4, 2, 0, 64, 3>(p, groups, s); break;
         case 14: e = launch_gemm_bf16<256, 128, 4, 2, 0, 32, 4>(p, groups, s); break;
         case 15: e = launch_gemm_bf16<256, 256, 2, 4, 0, 64, 2>(p, groups, s); break;
+        case 16:  // 256x256 deep-pipelined schedule (gemm_bf16_8phase.hip.h)
+        case 17:  // ablation: no epilogue stores
+            if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
+            e = tile == 16 ? launch_gemm_bf16_8phase<0>(p, groups, s) : launch_gemm_bf16_8phase<1>(p, groups, s);
+            break;
         default: return fail(NOMAD_ERR_INVALID, "unknown bf16 gemm tile id %d", tile);
     }
     if (e != hipSuccess) return fail(NOMAD_ERR_HIP, "bf16 gemm launch: %s", hipGetErrorString(e));
@@ -1302,7 +1310,7 @@ int nomad_embed_bf16(nomad_ctx* c, const float* wav, int B, int n_samples, float
 int nomad_diag_gemm_bf16(nomad_ctx* c, const void* A, const void* W, const float* bias, const void* R, void* C, int M,
                          int N, int K, int gelu, int tile, nomad_stream_t stream) {
     static const int kBN[] = {128, 128, 64, 256, 64, 128, 128, 128, 128, 256, 256, 128, 128, 128, 128, 256};
-    if (!c || !A || !W || !C || M <= 0 || tile < 0 || tile > 15) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: bad argument");
+    if (!c || !A || !W || !C || M <= 0 || tile < 0 || tile > 17) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: bad argument");
     if (N % kBN[tile] || K % 64) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: N %% %d or K %% 64 != 0", kBN[tile]);
     GemmParams p = dense(static_cast<const float*>(A), K, static_cast<const float*>(W), bias, static_cast<const float*>(R),
                          static_cast<float*>(C), M, N, K, gelu);

@@ -217,7 +217,7 @@ class Engine:
     def diag_gemm_bf16(self, A, W, bias=None, R=None, gelu=False, tile=0):
         M, K = A.shape
         N = W.shape[0]
-        out = torch.empty(M, N, dtype=torch.bfloat16, device=self.device)
+        out = torch.zeros(M, N, dtype=torch.bfloat16, device=self.device)  # zeros: a kernel that writes nothing shows
         _lib.check(self.lib.nomad_diag_gemm_bf16(self.ctx, A.data_ptr(), W.data_ptr(),
                                                  bias.data_ptr() if bias is not None else None,
                                                  R.data_ptr() if R is not None else None, out.data_ptr(),

@@ -82,19 +82,23 @@ def main():
                  7: "bf16 128x128 ABL no-epilogue", 8: "bf16 128x128 ABL one-k-tile",
                  9: "bf16 256x256 w2x4 bk32 4st", 10: "bf16 256x256 w4x2 bk32 4st", 11: "bf16 128x128 w4x2 bk32 4st",
                  12: "bf16 128x128 w4x2 bk64 3st", 13: "bf16 256x128 w4x2 bk64 3st", 14: "bf16 256x128 w4x2 bk32 4st",
-                 15: "bf16 256x256 w2x4 bk64 2st"}
+                 15: "bf16 256x256 w2x4 bk64 2st", 16: "bf16 256x256 8-phase", 17: "bf16 256x256 8-phase ABL no-epilogue"}
         bn = {0: 128, 1: 128, 2: 64, 3: 256, 4: 64, 5: 128, 6: 128, 7: 128, 8: 128, 9: 256, 10: 256, 11: 128, 12: 128,
-              13: 128, 14: 128, 15: 256}
+              13: 128, 14: 128, 15: 256, 16: 256, 17: 256}
         for sname in a.shapes.split(","):
             M, N, K, has_b, gelu, has_r = SHAPES[sname]
             A = torch.randn(M, K, generator=g).bfloat16().cuda()
             W = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16().cuda()
             b = torch.randn(N, generator=g).cuda() if has_b else None
             R = torch.randn(M, N, generator=g).bfloat16().cuda() if has_r else None
+            first = None
             for t in (int(x) for x in a.tiles.split(",")):
-                if N % bn[t]:
+                if N % bn[t] or (t in (16, 17) and K % 128):
                     continue
-                eng.diag_gemm_bf16(A, W, b, R, gelu=gelu, tile=t)
+                out = eng.diag_gemm_bf16(A, W, b, R, gelu=gelu, tile=t).float()
+                if first is None:
+                    first = out
+                diff = (out - first).abs().max().item() / max(first.abs().max().item(), 1e-30)
                 ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.iters + 1)]
                 ev[0].record()
                 for i in range(a.iters):
@@ -104,7 +108,8 @@ def main():
                 ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(a.iters))
                 tf = 2.0 * M * N * K / (ms[len(ms) // 2] * 1e-3) / 1e12
                 row = {"shape": sname, "tile": t, "cfg": names[t], "ms_med": round(ms[len(ms) // 2], 4),
-                       "ms_min": round(ms[0], 4), "tflops": round(tf, 1), "bit_identical": True}
+                       "ms_min": round(ms[0], 4), "tflops": round(tf, 1), "bit_identical": True,
+                       "rel_diff_vs_first": diff}
                 res.append(row)
                 print(json.dumps(row), flush=True)
         if a.json:
