@@ -7,25 +7,27 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 BF16_TILES = {0: (256, 128), 1: (128, 128), 2: (128, 64), 3: (256, 256), 4: (64, 64), 5: (128, 128), 6: (256, 128),
-              9: (256, 256), 10: (256, 256), 11: (128, 128), 12: (128, 128), 13: (256, 128), 14: (256, 128), 15: (256, 256)}
+              9: (256, 256), 10: (256, 256), 11: (128, 128), 12: (128, 128), 13: (256, 128), 14: (256, 128), 15: (256, 256),
+              16: (256, 256)}
 
 
 @pytest.mark.parametrize("tile", sorted(BF16_TILES))
 @pytest.mark.parametrize("M", [1, 200, 257, 1000])
 def test_gemm_bf16_exact_integer_asymmetric(engine, tile, M):
     bm, bn = BF16_TILES[tile]
-    N, K = 2 * bn, 192
+    N, K = 2 * bn, (256 if tile == 16 else 192)  # the deep-pipelined kernel walks K tiles in pairs: K % 128 == 0
     g = torch.Generator().manual_seed(M + tile)
     A = torch.randint(-1, 2, (M, K), generator=g).float()
     W = torch.randint(-1, 2, (N, K), generator=g).float()
-    W[:, ::7] = 1.0                      # break symmetry; |C| <= 192 stays exactly representable in bf16? no: use
-    ref = (A.double() @ W.double().T)    # values up to 192 need 8 bits: exact in bf16 (8-bit significand) up to 256
+    W[:, ::7] = 1.0                      # break symmetry
+    ref = (A.double() @ W.double().T)    # |C| <= K <= 256: exact in bf16 (8-bit significand)
     out = engine.diag_gemm_bf16(A.bfloat16().cuda(), W.bfloat16().cuda(), tile=tile).float().cpu()
     assert torch.equal(out.double(), ref)
 
 
 @pytest.mark.parametrize("tile,M,N,K", [(0, 1500, 256, 768), (1, 700, 768, 3072), (2, 260, 64, 6144), (4, 84, 768, 512),
-                                        (3, 600, 512, 1536)])
+                                        (3, 600, 512, 1536), (16, 777, 768, 3072), (16, 1500, 512, 1536),
+                                        (16, 300, 2304, 768), (16, 4113, 256, 128)])
 @pytest.mark.parametrize("epi", ["none", "bias_gelu", "bias_res"])
 def test_gemm_bf16_epilogues(engine, tile, M, N, K, epi):
     g = torch.Generator().manual_seed(5)
