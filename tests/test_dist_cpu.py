@@ -70,3 +70,43 @@ def test_sharded_equals_unsharded_even(tmp_path):
 
 def test_sharded_equals_unsharded_ragged(tmp_path):
     _run(13, 5, tmp_path)  # unequal shards: 7+6 deg, 3+2 ref
+
+
+# ---- data-parallel fine-tuning: gradient averaging across ranks (gloo, world_size 2) ------------------------------
+def _ddp_worker(rank, world, port, out):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nomad_amd.train import allreduce_mean_gradients
+
+    class FakeEngine:  # the two calls allreduce_mean_gradients makes on an Engine
+        def __init__(self):
+            self.grad = torch.arange(10, dtype=torch.float32) * (rank + 1)
+        def train_read(self, what):
+            assert what == 1
+            return self.grad.clone()
+        def train_write(self, what, flat):
+            assert what == 1
+            self.grad = flat.clone()
+    eng = FakeEngine()
+    allreduce_mean_gradients(eng)
+    out.put((rank, eng.grad.tolist()))
+    dist.destroy_process_group()
+
+
+def test_allreduce_mean_gradients_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 400) + 17
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = [i * 1.5 for i in range(10)]  # mean of 1x and 2x
+    assert res[0] == want and res[1] == want
