@@ -258,6 +258,10 @@ int nomad_diag_gemm_bf16(nomad_ctx* ctx, const void* A_dev, const void* W_dev, c
 /* bf16 attention: qkv [B*T][2304] bf16 (q pre-scaled) -> out [B*T][768] bf16. */
 int nomad_diag_attention_bf16(nomad_ctx* ctx, const void* qkv_dev, void* out_dev, int B, int T, nomad_stream_t stream);
 /* out[M][N] = LayerNorm(in[M][N]) * gamma + beta, N in {512, 768}, eps 1e-5. */
+/* one wave spins for spin_ticks of the 100 MHz wall counter; out_dev[0] = shader-clock cycles elapsed, out_dev[1] = wall
+ * ticks: run it on a second stream to read the clock a kernel under test actually gets */
+int nomad_diag_clock_probe(nomad_ctx* ctx, unsigned long long spin_ticks, unsigned long long* out_dev,
+                           nomad_stream_t stream);
 int nomad_diag_layernorm(nomad_ctx* ctx, const float* in_dev, const float* gamma_dev, const float* beta_dev,
                          float* out_dev, int M, int N, nomad_stream_t stream);
 /* ctx_out[B*T][768] = softmax(q k^T) v per head, from qkv[B*T][2304] (q pre-scaled). */

@@ -71,6 +71,7 @@ SIGNATURES = {
     "nomad_profile_reset": (C.c_int, [C.c_void_p]),
     "nomad_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
     "nomad_diag_gemm": (C.c_int, [C.c_void_p, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    "nomad_diag_clock_probe": (C.c_int, [C.c_void_p, C.c_ulonglong, _fp, _fp]),
     "nomad_diag_layernorm": (C.c_int, [C.c_void_p, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp]),
     "nomad_diag_attention": (C.c_int, [C.c_void_p, _fp, _fp, C.c_int, C.c_int, _fp]),
     "nomad_diag_layernorm_bwd": (C.c_int, [C.c_void_p, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp]),

@@ -317,7 +317,9 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 //             COUNTED vmcnt that leaves tile kt+1's loads in flight, and the barrier is the raw s_barrier
 //             (cdna_hip_programming.md "Pipelining across barriers").
 // NOEPI: timing-only ablation (no epilogue stores).
-template <int BM, int BN, int BK, int WM, int WN, int STAGES = 2, bool NOEPI = false>
+// OPT (experiments, results unchanged): bit 0 = epilogue slabs fenced per wave (lgkmcnt) instead of per workgroup
+//      (__syncthreads also waits for the previous slab's global stores); bit 1 = s_setprio(1) around the MFMA cluster.
+template <int BM, int BN, int BK, int WM, int WN, int STAGES = 2, bool NOEPI = false, int OPT = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_glds_kernel(const GemmParams p) {
     using Cfg = GldsCfg<BM, BN, BK, WM, WN, STAGES>;
     constexpr int TM = Cfg::TM, TN = Cfg::TN, NT = Cfg::THREADS, KC = Cfg::KC, RB = Cfg::RB;
@@ -332,7 +334,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_glds_kernel(const GemmPa
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave - wm * WN;
     const int nwg = p.tiles_m * p.tiles_n;
-    const int wg = xcd_remap(blockIdx.x, nwg);
+    // Persistent launch (gridDim.x < nwg): a workgroup walks tiles blockIdx.x, + gridDim.x, ...; its output stores
+    // drain under the next tile's prologue instead of holding the wave slots until they are acknowledged.
+    for (int t_ = blockIdx.x; t_ < nwg; t_ += gridDim.x) {
+    const int wg = xcd_remap(t_, nwg);
     int tile_m, tile_n;
     tile_coords(wg, p.tiles_m, p.tiles_n, p.group_m, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -416,6 +421,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_glds_kernel(const GemmPa
             for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * BK + koff[kq]);
 #pragma unroll
             for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * BK + koff[kq]);
+            if (OPT & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -423,6 +429,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_glds_kernel(const GemmPa
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][c], bf[j][c], acc[i][j], 0, 0, 0);
+            if (OPT & 2) __builtin_amdgcn_s_setprio(0);
         }
         cur = cur + 1 == STAGES ? 0 : cur + 1;
     }
@@ -449,13 +456,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_glds_kernel(const GemmPa
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        __syncthreads();  // main loop (or the previous slab) is done with this LDS
+        // the slab is private to the wave: after the first barrier (main loop done with the staging LDS) a wave-local
+        // fence is enough, LDS operations of one wave execute in order
+        if (!(OPT & 1) || i == 0) __syncthreads();
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 slab[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * ELD + j * 32 + (lane & 31)] = acc[i][j][r] + bv[j];
-        __syncthreads();
+        if (!(OPT & 1)) __syncthreads();
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (!NOEPI) {
 #pragma unroll
             for (int it = 0; it < 32 * CG / 64; ++it) {
@@ -490,22 +501,27 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_glds_kernel(const GemmPa
             }
         }
     }
+    if (t_ + (int)gridDim.x < nwg) __syncthreads();  // every wave has read its slab: the staging LDS may be refilled
+    }
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int STAGES = 2, bool NOEPI = false>
-inline hipError_t launch_gemm_glds(GemmParams p, int groups, hipStream_t s, int extra_lds = 0) {
+// persist_blocks > 0: launch at most that many workgroups, each walking several tiles (see the kernel)
+template <int BM, int BN, int BK, int WM, int WN, int STAGES = 2, bool NOEPI = false, int OPT = 0>
+inline hipError_t launch_gemm_glds(GemmParams p, int groups, hipStream_t s, int extra_lds = 0, int persist_blocks = 0) {
     using Cfg = GldsCfg<BM, BN, BK, WM, WN, STAGES>;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = p.N / BN;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_glds_kernel<BM, BN, BK, WM, WN, STAGES, NOEPI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_glds_kernel<BM, BN, BK, WM, WN, STAGES, NOEPI, OPT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    dim3 grid(p.tiles_m * p.tiles_n, groups);
-    hipLaunchKernelGGL((gemm_f32_glds_kernel<BM, BN, BK, WM, WN, STAGES, NOEPI>), grid, dim3(Cfg::THREADS),
+    int gx = p.tiles_m * p.tiles_n;
+    if (persist_blocks > 0 && gx > persist_blocks) gx = persist_blocks;
+    dim3 grid(gx, groups);
+    hipLaunchKernelGGL((gemm_f32_glds_kernel<BM, BN, BK, WM, WN, STAGES, NOEPI, OPT>), grid, dim3(Cfg::THREADS),
                        Cfg::LDS_BYTES + extra_lds, s, p);
     return hipGetLastError();
 }

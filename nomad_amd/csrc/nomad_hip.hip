@@ -386,7 +386,7 @@ int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, in
         case 30: e = launch_gemm_glds<128, 64, 32, 2, 2>(p, groups, s, occ_pad(occ, GldsCfg<128, 64, 32, 2, 2>::LDS_BYTES)); break;
         case 31: e = launch_gemm_glds<128, 128, 32, 4, 2>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 4, 2>::LDS_BYTES)); break;
         case 32: e = launch_gemm_glds<256, 128, 16, 4, 2, 2, true>(p, groups, s); break;  // ablation: no epilogue stores
-        case 33: e = launch_gemm_glds<256, 128, 16, 4, 2, 3>(p, groups, s); break;   // 3-stage LDS-DMA pipeline, counted vmcnt
+        case 33: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 1>(p, groups, s); break;   // 3-stage LDS-DMA pipeline, counted vmcnt
         case 34: e = launch_gemm_glds<128, 64, 32, 4, 2, 3>(p, groups, s); break;
         case 35: e = launch_gemm_glds<256, 128, 32, 4, 2, 3>(p, groups, s); break;
         case 36: e = launch_gemm_glds<64, 32, 32, 2, 1, 3>(p, groups, s); break;    // small problems: many small workgroups
@@ -395,6 +395,10 @@ int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, in
         case 39: e = launch_gemm_glds<32, 32, 32, 1, 1, 3>(p, groups, s); break;
         case 40: e = launch_gemm_glds<256, 256, 16, 4, 4, 3>(p, groups, s); break;   // one 16-wave workgroup per CU
         case 41: e = launch_gemm_glds<256, 256, 16, 4, 4, 2>(p, groups, s); break;
+        case 42: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 0>(p, groups, s); break;   // t33 with workgroup barriers between epilogue slabs
+        case 43: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 3>(p, groups, s); break;   // t33 + s_setprio around the MFMAs (-4 %)
+        case 44: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 1>(p, groups, s, 0, 512); break;    // t33 persistent, 2 workgroups/CU
+        case 45: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 1>(p, groups, s, 0, 1024); break;   // t33 persistent, 4 per CU slot
         case 48: e = launch_gemm_n48(p, groups, s); break;   // N = 48 exactly (16x16x4 MFMA): the grouped pos-conv
         case 14: e = launch_gemm<128, 128, 32, 2, 2, 1>(p, groups, s); break;            // ablations of tile 0
         case 15: e = launch_gemm<128, 128, 32, 2, 2, 2>(p, groups, s); break;
@@ -2147,20 +2151,42 @@ int nomad_diag_gemm(nomad_ctx* c, const float* A, const float* W, const float* b
     const int group_m = (tile % 10000) / 100;
     tile %= 100;
     static const int kBN[] = {128, 64, 64, 128, 128, 256, 128, 256, 256, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128,
-                              128, 128, 128, 128, 256, 256, 128, 256, 64, 64, 64, 128, 128, 128, 64, 128, 32, 64, 32, 32, 256, 256};
+                              128, 128, 128, 128, 256, 256, 128, 256, 64, 64, 64, 128, 128, 128, 64, 128, 32, 64, 32, 32, 256, 256,
+                              128, 128, 128, 128, 128, 128};
     static const int kBK[] = {32, 16, 32, 16, 32, 32, 16, 32, 16, 16, 16, 32, 32, 16, 32, 32, 32, 16, 16, 16,
-                              32, 16, 16, 32, 16, 32, 16, 16, 16, 32, 32, 32, 16, 16, 32, 32, 32, 32, 32, 32, 16, 16};
+                              32, 16, 16, 32, 16, 32, 16, 16, 16, 32, 32, 32, 16, 16, 32, 32, 32, 32, 32, 32, 16, 16,
+                              16, 16, 16, 16, 16, 16};
     if (tile == 48) {
         if (N != 48 || K % 16) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile 48 needs N == 48 and K %% 16 == 0");
         GemmParams p48 = dense(A, K, W, bias, R, C, M, N, K, gelu);
         return run_gemm(c, p48, 1, 48, static_cast<hipStream_t>(stream));
     }
-    if (tile < 0 || tile > 41) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile id %d", tile);
+    if (tile < 0 || tile > 47) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile id %d", tile);
     const int bn = kBN[tile], bk = kBK[tile];
     if (N % bn || K % bk) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: N %% %d or K %% %d != 0", bn, bk);
     GemmParams p = dense(A, K, W, bias, R, C, M, N, K, gelu);
     p.group_m = group_m;
     return run_gemm(c, p, 1, tile, static_cast<hipStream_t>(stream), occ);
+}
+
+// One wave spins for `spin_ticks` ticks of the 100 MHz wall counter and reports the shader-clock cycles that passed:
+// launched on a second stream while a kernel under test runs, it reads the clock that kernel actually gets.
+__global__ void clock_probe_kernel(unsigned long long spin_ticks, unsigned long long* out) {
+    const unsigned long long w0 = wall_clock64(), c0 = __builtin_readcyclecounter();
+    unsigned long long w1 = w0;
+    while (w1 - w0 < spin_ticks) {
+        __builtin_amdgcn_s_sleep(32);
+        w1 = wall_clock64();
+    }
+    out[0] = __builtin_readcyclecounter() - c0;
+    out[1] = w1 - w0;
+}
+
+int nomad_diag_clock_probe(nomad_ctx* c, unsigned long long spin_ticks, unsigned long long* out_dev, nomad_stream_t stream) {
+    if (!c || !out_dev) return fail(NOMAD_ERR_INVALID, "nomad_diag_clock_probe: bad argument");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), spin_ticks, out_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 int nomad_diag_layernorm(nomad_ctx* c, const float* in, const float* g, const float* b, float* out, int M, int N,

@@ -412,6 +412,15 @@ class Engine:
                 for i, name in enumerate(_lib.KERNEL_CLASS_NAMES)}
 
     # ---- diagnostics (tests) ---------------------------------------------------------------------
+    def diag_clock_probe(self, ms: float, stream: "torch.cuda.Stream") -> torch.Tensor:
+        """Launch the one-wave clock probe on `stream` for ~ms milliseconds; returns the (2,) int64 device tensor
+        [shader cycles, 100 MHz ticks] (read it after synchronising)."""
+        with torch.cuda.stream(stream):  # the zero fill must not queue behind the load on the main stream
+            out = torch.zeros(2, dtype=torch.int64, device=self.device)
+        _lib.check(self.lib.nomad_diag_clock_probe(self.ctx, int(ms * 1e5), out.data_ptr(), stream.cuda_stream),
+                   "nomad_diag_clock_probe")
+        return out
+
     def diag_gemm(self, A, W, bias=None, R=None, gelu=False, tile=0):
         M, K = A.shape
         N = W.shape[0]
