@@ -77,16 +77,38 @@ __global__ __launch_bounds__(512) void k(float* out, int iters, const float* src
             }
             if (FLAGS & 1) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (FLAGS & 2) {
-                float* d = stage + cur * 384 * 16 + wave * 256;
-                const float* gs = g + (size_t)(it & 1023) * 2048;
+            float* d = stage + cur * 384 * 16 + wave * 256;
+            const float* gs = g + (size_t)(it & 1023) * 2048;
+            if ((FLAGS & 2) && !(FLAGS & 4)) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
                     __builtin_amdgcn_global_load_lds((gptr_t)(gs + c * 8192), (lptr_t)(d + c * 2048), 16, 0, 0);
-                cur = cur == 2 ? 0 : cur + 1;
             }
             rd(0, it & 1);
-            mm(0);
+            if (FLAGS & 4) {  // DMA issued between the two halves of the MFMA cluster
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][i][0][c], bf[0][j][0][c], acc[i][j], 0, 0, 0);
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(gs + c * 8192), (lptr_t)(d + c * 2048), 16, 0, 0);
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][i][1][c], bf[0][j][1][c], acc[i][j], 0, 0, 0);
+            } else {
+                mm(0);
+            }
+            cur = cur == 2 ? 0 : cur + 1;
             asm volatile("" ::: "memory");
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -136,6 +158,9 @@ int main() {
     run<2, 2, false, 1>("64x64, + s_barrier per K tile", 2, 512, out, src);
     run<2, 2, false, 2>("64x64, + LDS-DMA per K tile (counted vmcnt)", 2, 512, out, src);
     run<2, 2, false, 3>("64x64, + barrier + LDS-DMA (the production main loop)", 2, 512, out, src);
+    run<2, 2, false, 7>("64x64, + barrier + LDS-DMA issued mid-cluster", 2, 512, out, src);
+    run<2, 2, false, 3>("64x64, + barrier + LDS-DMA (the production main loop)", 2, 512, out, src);
+    run<2, 2, false, 7>("64x64, + barrier + LDS-DMA issued mid-cluster", 2, 512, out, src);
     run<2, 2, false, 3>("64x64, + barrier + LDS-DMA, 1 workgroup/CU", 1, 512, out, src);
     run<4, 2, false, 3>("128x64, + barrier + LDS-DMA, 1 workgroup/CU x 8 waves", 1, 512, out, src);
     return 0;
