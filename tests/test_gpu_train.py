@@ -316,7 +316,8 @@ def test_training_loop_runs_and_saves_a_loadable_checkpoint(tmp_path, monkeypatc
 
 
 # ---- A/P/N as one merged batch with per-branch LayerDrop ----------------------------------------------------------
-@pytest.mark.parametrize("masks", [(0xFFF, 0xFFF, 0xFFF), (0xFFF & ~(1 << 3), 0xFFE, 0x7FF & ~(1 << 3)), (0x0F0, 0xF0F, 0xFFF)])
+@pytest.mark.parametrize("masks", [(0xFFF, 0xFFF, 0xFFF), (0xFFF & ~(1 << 3), 0xFFE, 0x7FF & ~(1 << 3)), (0x0F0, 0xF0F, 0xFFF),
+                                   (0xFFE & ~(1 << 5), 0xFFE & ~(1 << 5), 0x7FE & ~(1 << 5))])  # last: layers 0 and 5 dropped by all
 def test_merged_branches_match_oracle(teng, sd_train, masks):
     B, n, margin = 2, 6000, 1.0
     A, P, N = _triplet_batch(B, n, seed=31)
@@ -328,7 +329,8 @@ def test_merged_branches_match_oracle(teng, sd_train, masks):
         sd[k].requires_grad_(True)
     e = O.triplet_forward(sd, torch.cat([A, P, N]), st)
     ref_loss = torch.nn.TripletMarginLoss(margin=margin)(e[:B], e[B:2 * B], e[2 * B:])
-    ref = dict(zip(keys, torch.autograd.grad(ref_loss, [sd[k] for k in keys])))
+    grads = torch.autograd.grad(ref_loss, [sd[k] for k in keys], allow_unused=True)
+    ref = {k: (gk if gk is not None else torch.zeros_like(sd[k])) for k, gk in zip(keys, grads)}  # None: layer dropped by all
     # engine: merged batch, per-branch masks
     w = torch.cat([A, P, N]).cuda()
     teng.train_set_stochastic(st.dropout, st.attention_dropout, st.dropout_input, st.seed, 0xFFF)
@@ -348,6 +350,9 @@ def test_merged_branches_match_oracle(teng, sd_train, masks):
     top = max(v.abs().max().item() for v in ref.values())
     for k, want in ref.items():
         assert (got[k] - want).abs().max().item() < 2e-4 * want.abs().max().item() + 1e-6 * top, k
+    dropped_by_all = [l for l in range(12) if not any((m >> l) & 1 for m in masks)]
+    for l in dropped_by_all:  # a layer no branch ran gets exactly no gradient
+        assert all(float(got[k].abs().max()) == 0.0 for k in got if f"encoder.layers.{l}." in k)
 
 
 def test_merged_equals_separate_calls_in_eval_arithmetic(teng):
