@@ -374,3 +374,29 @@ def test_merged_equals_separate_calls_in_eval_arithmetic(teng):
     finally:
         teng.train_set_branches(None)
     assert (g_m - g_sep).abs().max().item() < 1e-5 * g_sep.abs().max().item()
+
+
+def test_training_api_error_paths(engine, teng):
+    """Same conventions as the rest of the C ABI: negative status + message, nothing thrown inside the library."""
+    from nomad_amd._lib import NomadHipError
+    wav = _triplet_batch(2, 5000, seed=1)[0].cuda()
+    with pytest.raises(NomadHipError, match="nomad_train_enable"):   # the shared scoring engine never enabled training
+        engine.train_zero_grad()
+    with pytest.raises(NomadHipError, match="probabilities"):
+        teng.train_set_stochastic(dropout=1.0)
+    with pytest.raises(NomadHipError, match="branches"):
+        teng.train_set_branches([0xFFF] * 5)
+    teng.train_set_branches([0xFFF] * 3)
+    try:
+        with pytest.raises(NomadHipError, match="equal branches"):  # 2 clips cannot be 3 equal branches
+            teng.embed_train(wav)
+    finally:
+        teng.train_set_branches(None)
+    emb, layers, saved = teng.embed_train(wav)
+    with pytest.raises(NomadHipError, match="workspace|saved"):
+        teng.lib.nomad_train_backward  # noqa: B018 (exists)
+        from nomad_amd import _lib
+        _lib.check(teng.lib.nomad_train_backward(teng.ctx, wav.data_ptr(), 2, 5000, layers.data_ptr(), saved.data_ptr(),
+                                                 16, emb.data_ptr(), saved.data_ptr(), 16, None), "nomad_train_backward")
+    with pytest.raises(ValueError):
+        teng.train_write(1, torch.zeros(7, device="cuda"))
