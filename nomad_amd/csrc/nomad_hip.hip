@@ -30,6 +30,7 @@
 #include "gemm_bf16.hip.h"
 #include "gemm_bf16_8phase.hip.h"
 #include "gemm_f32.hip.h"
+#include "gemm_f32_pp.hip.h"
 #include "pairwise.hip.h"
 #include "rowops.hip.h"
 #include "train.hip.h"
@@ -399,6 +400,11 @@ int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, in
         case 43: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 3>(p, groups, s); break;   // t33 + s_setprio around the MFMAs (-4 %)
         case 44: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 1>(p, groups, s, 0, 512); break;    // t33 persistent, 2 workgroups/CU
         case 45: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 1>(p, groups, s, 0, 1024); break;   // t33 persistent, 4 per CU slot
+        case 46:  // 256x256, one workgroup/CU, ping-pong wave rows (gemm_f32_pp.hip.h)
+        case 47:  // ablation: no epilogue stores
+            if (p.N % 256 != 0 || p.K % 64 != 0) return fail(NOMAD_ERR_INVALID, "fp32 ping-pong gemm: N %% 256, K %% 64");
+            e = tile == 46 ? launch_gemm_f32_pp<false>(p, groups, s) : launch_gemm_f32_pp<true>(p, groups, s);
+            break;
         case 48: e = launch_gemm_n48(p, groups, s); break;   // N = 48 exactly (16x16x4 MFMA): the grouped pos-conv
         case 14: e = launch_gemm<128, 128, 32, 2, 2, 1>(p, groups, s); break;            // ablations of tile 0
         case 15: e = launch_gemm<128, 128, 32, 2, 2, 2>(p, groups, s); break;
@@ -2152,10 +2158,10 @@ int nomad_diag_gemm(nomad_ctx* c, const float* A, const float* W, const float* b
     tile %= 100;
     static const int kBN[] = {128, 64, 64, 128, 128, 256, 128, 256, 256, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128,
                               128, 128, 128, 128, 256, 256, 128, 256, 64, 64, 64, 128, 128, 128, 64, 128, 32, 64, 32, 32, 256, 256,
-                              128, 128, 128, 128, 128, 128};
+                              128, 128, 128, 128, 256, 256};
     static const int kBK[] = {32, 16, 32, 16, 32, 32, 16, 32, 16, 16, 16, 32, 32, 16, 32, 32, 32, 16, 16, 16,
                               32, 16, 16, 32, 16, 32, 16, 16, 16, 32, 32, 32, 16, 16, 32, 32, 32, 32, 32, 32, 16, 16,
-                              16, 16, 16, 16, 16, 16};
+                              16, 16, 16, 16, 64, 64};
     if (tile == 48) {
         if (N != 48 || K % 16) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile 48 needs N == 48 and K %% 16 == 0");
         GemmParams p48 = dense(A, K, W, bias, R, C, M, N, K, gelu);
