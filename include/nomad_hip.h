@@ -232,7 +232,7 @@ enum {
     NOMAD_K_ROW = 3,
     NOMAD_K_PAIR = 4,
     NOMAD_K_GEMM_BIG = 5,   /* of which: the 256x128 instantiation (gemm_*_glds_kernel<256,128,...>; bf16: 128x128 / 256x256) */
-    NOMAD_K_GEMM_FINE = 6,  /* of which: the 128x64 instantiation */
+    NOMAD_K_GEMM_FINE = 6,  /* of which: the finer instantiations (128x128x32, 128x64x32, N = 48) */
     NOMAD_K_COUNT = 7
 };
 /* When enabled every kernel launch of nomad_embed/nomad_pairwise is bracketed by hipEvents on the

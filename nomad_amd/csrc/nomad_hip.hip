@@ -356,7 +356,7 @@ int occ_pad(int occ, int lds) {
 int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, int occ = 0) {
     if (tile == 29 && occ == 0) occ = 4;  // measured: 4 workgroups/CU is the best residency for the 128x64x32 kernel
     const double flops = 2.0 * p.M * (double)p.n_valid * p.K * groups;
-    Scope sc(c, s, NOMAD_K_GEMM, flops, tile == 33 ? NOMAD_K_GEMM_BIG : ((tile == 34 || tile == 48) ? NOMAD_K_GEMM_FINE : -1));
+    Scope sc(c, s, NOMAD_K_GEMM, flops, tile == 33 ? NOMAD_K_GEMM_BIG : ((tile == 34 || tile == 31 || tile == 48) ? NOMAD_K_GEMM_FINE : -1));
     hipError_t e;
     switch (tile) {
         case 0: e = launch_gemm<128, 128, 32, 2, 2>(p, groups, s); break;
@@ -443,8 +443,8 @@ GemmParams dense(const float* A, int lda, const float* W, const float* bias, con
 // Kernel instantiation for a dense problem (measured on MI355X, tools/gemm_sweep.py, profiles/r01_gemm_sweep_*.json):
 //   33 = LDS-DMA 256x128x16, 8 waves, 3-stage pipeline: best when the grid is many tiles deep (QKV, fc1, conv1-4)
 //        and for the long-K / short-K N = 768 problems of the full batch (fc2, proj)
-//   34 = LDS-DMA 128x64x32, 8 waves, 3-stage: finer tiles for out_proj, conv5/6, the pos-conv groups and for
-//        small batches (config C4), where a 256x128 grid would leave most CUs idle
+//   31 = LDS-DMA 128x128x32, 8 waves, 2-stage: out_proj, conv5/6 (N = 768 / 512 with K around 1000: 2.3 rounds of
+//        256x128 tiles are too few); 34 = 128x64x32 for N not a multiple of 128
 //   37 = LDS-DMA 64x64x32, 4 waves, 3-stage: small problems
 // (all 32x32x2-MFMA instantiations contract k in the same order, so the choice never changes a result bit)
 int pick_tile(int M, int N, int K) {
@@ -457,7 +457,9 @@ int pick_tile(int M, int N, int K) {
     // a few rounds of tiles with wide N (the merged training batch, M ~ 12k): 128x128 tiles, 4 waves
     // (profiles/r01_gemm_sweep_train_m.json)
     if (N >= 2048 && N % 128 == 0 && tiles256 < 2048) return 20;
-    return 34;
+    // out_proj, conv5/6 at full batch (K = 768 / 1024, N = 768 / 512): 128x128x32 tiles, 8 waves, 2 stages: +2..5 % over
+    // 128x64 (profiles/r01_gemm_sweep_n768_128x128.json)
+    return N % 128 == 0 ? 31 : 34;
 }
 
 int run_layernorm(nomad_ctx* c, const float* in, const float* g, const float* b, float* out, float* out2, int M, int N,

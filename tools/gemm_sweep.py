@@ -19,6 +19,7 @@ SHAPES = {  # name: (M, N, K, bias, gelu, residual)
     "fc2": (50944, 768, 3072, True, False, True),
     "conv3": (409344, 512, 1536, False, True, False),
     "conv5": (102144, 512, 1024, False, True, False),
+    "conv6": (50944, 512, 1024, False, True, False),
     "fc1_nogelu": (50944, 3072, 768, True, False, False),
     "proj": (50944, 768, 512, True, False, False),
     # quantisation probes for the 256x128 kernel at 2 workgroups/CU (512 slots): 9.0, 9.33 and 9.98 rounds
