@@ -60,6 +60,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
     // that the whole working set stays inside the 256 registers a wave has at 2 waves/SIMD - a spilled address
     // would come back through a scratch load whose s_waitcnt drains the whole DMA queue.
     // Instruction i of a half-tile covers rows (tid + 512 i) / 8, physical chunk (tid + 512 i) % 8.
+    // The 32-bit offsets are relative to the tile's FIRST row (row addresses grow with the row index, a 256-row tile
+    // spans far less than 4 GB); the tensor itself may be larger than 4 GB (conv1 input at batch 512: 6.7 GB).
+    const long long tile_row0 = row_addr(p.amap, m0 < p.M ? m0 : p.M - 1);  // wave-uniform
     unsigned a_off[2][2], b_off[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -70,10 +73,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
         for (int h = 0; h < 2; ++h) {
             int m = m0 + h * 128 + row;
             m = m < p.M ? m : p.M - 1;
-            a_off[h][i] = (unsigned)((row_addr(p.amap, m) + sw) * 2);
+            a_off[h][i] = (unsigned)((row_addr(p.amap, m) - tile_row0 + sw) * 2);
         }
     }
-    const char* const a_base = reinterpret_cast<const char*>(Ag);
+    const char* const a_base = reinterpret_cast<const char*>(Ag + tile_row0);
     const char* const b_base[2] = {reinterpret_cast<const char*>(Wg + (long long)n0 * p.ldw),
                                    reinterpret_cast<const char*>(Wg + (long long)(n0 + 128) * p.ldw)};
     char* const dma_dst = smem8 + wave * 1024;  // + lane * 16 implicit (lane-linear LDS-DMA destination)

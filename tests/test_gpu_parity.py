@@ -284,3 +284,22 @@ def test_repeat_runs_are_bit_identical(engine):
         if it % 4 == 0:
             assert torch.equal(engine.embed_bf16(wav), ref16), it
     torch.cuda.synchronize()
+
+
+def test_large_batch_crosses_2_pow_31_elements(engine):
+    """512 x 4 s clips: the conv0 output alone is 3.36e9 floats (> 2^31, > 2^32 bytes several times over), so any 32-bit
+    element or byte offset anywhere in the path would corrupt the late clips.  Batch invariance is bit-exact, so the
+    first and last clips must equal what a batch of two gives."""
+    g = torch.Generator().manual_seed(77)
+    wav = (0.1 * torch.randn(512, 64000, generator=g)).clamp(-1, 1).cuda()
+    emb = engine.embed(wav)
+    ref = engine.embed(torch.stack([wav[0], wav[511]]).contiguous())
+    mid = engine.embed(torch.stack([wav[300], wav[421]]).contiguous())
+    assert torch.equal(emb[0], ref[0]) and torch.equal(emb[511], ref[1])
+    assert torch.equal(emb[300], mid[0]) and torch.equal(emb[421], mid[1])
+    e16 = engine.embed_bf16(wav)
+    r16 = engine.embed_bf16(torch.stack([wav[0], wav[511]]).contiguous())
+    assert torch.equal(e16[0], r16[0]) and torch.equal(e16[511], r16[1])
+    del wav, emb, e16
+    engine._ws = None  # hand the 26 GB workspace back
+    torch.cuda.empty_cache()
