@@ -426,3 +426,26 @@ def test_optimisation_actually_learns(built_lib, sd_train):
         assert float(gap_after.mean()) < losses[0] - 0.2
     finally:
         eng.close()
+
+
+def test_train_step_with_branches_of_different_lengths(built_lib, sd_train):
+    """The reference pads anchor, positive and negative batches separately, so their lengths may differ: then the step
+    falls back to three forward/backward calls - same numbers as torch on the CPU oracle."""
+    from nomad_amd.engine import Engine
+    from nomad_amd.train import ExponentialLR, Training
+    g = torch.Generator().manual_seed(9)
+    A, P, N = [(0.1 * torch.randn(2, 1, n, generator=g)).clamp(-1, 1) for n in (6000, 7300, 5200)]
+    eng = Engine({k: v.clone() for k, v in sd_train.items()}, 0)
+    try:
+        tr = Training(dict(experiment_name="x", checkpoint_path="seeded", margin=1.0), engine=eng,
+                      regularisation=dict(dropout=0.0, attention_dropout=0.0, dropout_input=0.0, encoder_layerdrop=0.0))
+        tr.margin, tr.lr_scheduler = 1.0, ExponentialLR([1e-5, 1e-4], 0.99)
+        ref_loss, ref = O.triplet_step_grads(sd_train, A.squeeze(1), P.squeeze(1), N.squeeze(1), 1.0)
+        loss = tr.train_step(A, P, N)
+        assert abs(loss.item() - ref_loss.item()) < 2e-5
+        got = eng.train_unflatten(eng.train_read(1))  # gradients of the step just taken are still in the vector
+        top = max(v.abs().max().item() for v in ref.values())
+        for k, want in ref.items():
+            assert (got[k] - want).abs().max().item() < 2e-4 * want.abs().max().item() + 1e-6 * top, k
+    finally:
+        eng.close()
