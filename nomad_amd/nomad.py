@@ -25,9 +25,8 @@ What differs, deliberately:
 from __future__ import annotations
 
 import os
-from collections import OrderedDict
 from datetime import datetime
-from typing import Dict, List, Optional, Union
+from typing import Dict, List, Union
 
 import numpy as np
 import pandas as pd

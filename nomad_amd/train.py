@@ -26,7 +26,7 @@ from __future__ import annotations
 import os
 import random
 from datetime import datetime
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, Optional, Sequence
 
 import numpy as np
 import torch
