@@ -18,7 +18,8 @@ L = [12799, 6399, 3199, 1599, 799, 399, 199]
 
 def algorithmic_by_kernel():
     """Algorithmic bytes (A + W + C + residual) per launch, split by the instantiation pick_tile() selects at
-    B = 256 x 4 s: 256x128 = conv1-4, proj, qkv, fc1, fc2; 128x64 = conv5, conv6, out_proj; n48 = pos-conv."""
+    B = 256 x 4 s: 256x128 = conv1-4, proj, qkv, fc1, fc2; 128x128 (key "gemm_128x64") = conv5, conv6, out_proj;
+    n48 = pos-conv."""
     big, fine = [], []
     for i in range(1, 7):
         k = 3 if i < 5 else 2
@@ -86,10 +87,11 @@ for k, v in sorted(agg.items()):
         gw += sum(w)
 out["gemm_all_launches"] = {"launches": gl, "hbm_bytes_per_launch": (gf + gw) / gl, "fetch": gf / gl, "write": gw / gl,
                             "algorithmic_bytes_per_launch": alg, "ratio": (gf + gw) / gl / alg}
-for key, pat in (("gemm_256x128", "<256, 128,"), ("gemm_128x64", "<128, 64,")):
-    n = sum(v["launches"] for k, v in out["kernels"].items() if "gemm" in k and pat in k)
-    b = sum(v["launches"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"])
-            for k, v in out["kernels"].items() if "gemm" in k and pat in k)
+# "gemm_128x64" keeps its name (bench.py's key) but now covers the finer instantiations: 128x128x32 and 128x64x32
+for key, pats in (("gemm_256x128", ("<256, 128,",)), ("gemm_128x64", ("<128, 64,", "<128, 128,"))):
+    sel = [v for k, v in out["kernels"].items() if "gemm" in k and any(p in k for p in pats)]
+    n = sum(v["launches"] for v in sel)
+    b = sum(v["launches"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) for v in sel)
     out[key] = {"launches": n, "hbm_bytes_per_launch": b / max(n, 1),
                 "algorithmic_bytes_per_launch": algorithmic_by_kernel()[0 if key == "gemm_256x128" else 1]}
 for dst in (os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json"), os.path.join(ROOT, "profiles", "pmc_traffic.json")):
