@@ -222,6 +222,11 @@ int nomad_enable_bf16(nomad_ctx* ctx);
 int nomad_workspace_bytes_bf16(const nomad_ctx* ctx, int B, int n_samples, size_t* bytes);
 int nomad_embed_bf16(nomad_ctx* ctx, const float* wav_dev, int B, int n_samples, float* emb_dev,
                      void* workspace_dev, size_t workspace_bytes, nomad_stream_t stream);
+/* bf16 counterpart of nomad_embed_ragged (files of different lengths, e.g. long-form recordings through predict):
+ * same arguments, no head override; every clip's result equals its own single-clip nomad_embed_bf16 call */
+int nomad_workspace_bytes_ragged_bf16(const nomad_ctx* ctx, int B, const int* lengths_host, size_t* bytes);
+int nomad_embed_ragged_bf16(nomad_ctx* ctx, const float* wav_dev, int B, int stride, const int* lengths_host,
+                            float* emb_dev, void* workspace_dev, size_t workspace_bytes, nomad_stream_t stream);
 
 /* ---- measurement ------------------------------------------------------------------------- */
 /* Kernel classes for the in-library HIP-event timers. */

@@ -14,8 +14,10 @@ def main():
     ap.add_argument("--results_path", type=str, default=None)
     ap.add_argument("--device", type=str, default=None)
     ap.add_argument("--weights", type=str, default=None, help="checkpoint path, or 'seeded'")
+    ap.add_argument("--precision", type=str, default="fp32", choices=("fp32", "bf16"),
+                    help="bf16: faster embeddings for long recordings (scores within ~5e-4 of fp32)")
     a = ap.parse_args()
-    nomad_avg, _ = Nomad(device=a.device, weights=a.weights).predict(a.mode, a.nmr, a.deg, a.results_path)
+    nomad_avg, _ = Nomad(device=a.device, weights=a.weights, precision=a.precision).predict(a.mode, a.nmr, a.deg, a.results_path)
     print("Nomad average scores, printing top 5 test files")
     print(nomad_avg.head())
 

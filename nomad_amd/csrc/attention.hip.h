@@ -265,14 +265,21 @@ __device__ __forceinline__ void attn_tile_bf16(const char* __restrict__ Ks, cons
     }
 }
 
+// tpref (nullable): ragged batches, as in attention_f32_kernel.
 __global__ __launch_bounds__(256) void attention_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                             int T) {
+                                                             int T, const int* __restrict__ tpref = nullptr) {
     __shared__ __attribute__((aligned(16))) char Ks[64 * kAttn16LD];
     __shared__ __attribute__((aligned(16))) char Vs[64 * kAttn16LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qi = lane & 15, g = lane >> 4;
     const int bh = blockIdx.y, b = bh / 12, h = bh - b * 12;
-    const long long base = (long long)b * T * 2304 + h * 64;
+    long long row0 = (long long)b * T;
+    if (tpref) {
+        row0 = tpref[b];
+        T = tpref[b + 1] - tpref[b];
+        if ((int)blockIdx.x * 64 >= T) return;  // whole workgroup: no barrier has been reached yet
+    }
+    const long long base = row0 * 2304 + h * 64;
     const int q_row = blockIdx.x * 64 + wave * 16 + qi;
     const int q_ld = q_row < T ? q_row : T - 1;
     bf16x8 qf[2];
@@ -319,7 +326,7 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(const bf16_t* __res
     l_tot += __shfl_xor(l_tot, 32);
     const float inv = 1.0f / l_tot;
     if (q_row < T) {
-        bf16_t* dst = out + ((long long)b * T + q_row) * 768 + h * 64 + g * 4;
+        bf16_t* dst = out + (row0 + q_row) * 768 + h * 64 + g * 4;
 #pragma unroll
         for (int ds = 0; ds < 4; ++ds)
             store4<bf16_t>(dst + ds * 16, make_float4(o[ds][0] * inv, o[ds][1] * inv, o[ds][2] * inv, o[ds][3] * inv));

@@ -1274,6 +1274,175 @@ static int forward_bf16(nomad_ctx* c, const float* wav, int B, int n_samples, fl
     return 0;
 }
 
+// Ragged bf16 forward: forward_ragged with the bf16 kernels of forward_bf16 (mixed-length long-form files, config C5
+// through predict).  Every clip sees the arithmetic of its own single-clip bf16 call.
+static size_t ragged_bf16_layout(const RaggedShapes& r, RaggedLayout* l) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += align_up(bytes);
+        return o;
+    };
+    const size_t e = sizeof(bf16_t), M = (size_t)r.rows[6];
+    l->meta = take(sizeof(int) * r.meta.size());
+    l->stats = take(sizeof(double) * kStatsPerClip * r.B);
+    l->scale = take(sizeof(float) * 512 * r.B);
+    l->shift = take(sizeof(float) * 512 * r.B);
+    l->conva = take(e * 512 * (size_t)r.rows[0]);
+    l->convb = take(e * 512 * (size_t)r.rows[1]);
+    l->xpad = take(e * 768 * (size_t)r.P);
+    l->x = take(e * 768 * M);
+    l->x2 = take(e * 768 * M);
+    l->y = take(e * 768 * M);
+    l->qkv = take(e * 2304 * M);
+    l->ctxb = take(e * 768 * M);
+    l->h = take(e * 3072 * M);
+    l->total = off;
+    return off;
+}
+
+static int forward_ragged_bf16(nomad_ctx* c, const float* wav, int B, int stride, const int* lens_host, float* emb,
+                               void* workspace, size_t workspace_bytes, nomad_stream_t stream) {
+    RaggedShapes rs;
+    if (!c || !wav || !lens_host || !emb || !workspace || B <= 0 || !make_ragged(B, lens_host, &rs))
+        return fail(NOMAD_ERR_INVALID, "nomad_embed_ragged_bf16: bad argument (B=%d)", B);
+    if (!c->bf16_ready) return fail(NOMAD_ERR_INVALID, "nomad_embed_ragged_bf16: call nomad_enable_bf16 first");
+    for (int i = 0; i < B; ++i)
+        if (lens_host[i] > stride) return fail(NOMAD_ERR_INVALID, "nomad_embed_ragged_bf16: clip %d longer than the row stride", i);
+    RaggedLayout lay{};
+    ragged_bf16_layout(rs, &lay);
+    if (workspace_bytes < lay.total)
+        return fail(NOMAD_ERR_WORKSPACE, "nomad_embed_ragged_bf16: workspace %zu < required %zu", workspace_bytes, lay.total);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    char* ws = static_cast<char*>(workspace);
+    auto H = [&](size_t off) { return reinterpret_cast<bf16_t*>(ws + off); };
+    auto asf = [](const bf16_t* p_) { return reinterpret_cast<const float*>(p_); };
+    auto asfm = [](bf16_t* p_) { return reinterpret_cast<float*>(p_); };
+    int* meta = reinterpret_cast<int*>(ws + lay.meta);
+    c->ragged_meta = rs.meta;  // must outlive the asynchronous copy
+    HIP_TRY(hipMemcpyAsync(meta, c->ragged_meta.data(), sizeof(int) * rs.meta.size(), hipMemcpyHostToDevice, s));
+    const int* lens = meta + rs.off_lens();
+    auto pref = [&](int i) { return static_cast<const int*>(meta + rs.off_pref(i)); };
+    const int* tpref = pref(6);
+    const int* ppref = meta + rs.off_ppref();
+    const int M = (int)rs.rows[6];
+    int rc;
+    double* stats = reinterpret_cast<double*>(ws + lay.stats);
+    float* scale = reinterpret_cast<float*>(ws + lay.scale);
+    float* shift = reinterpret_cast<float*>(ws + lay.shift);
+    bf16_t* cb[2] = {H(lay.conva), H(lay.convb)};
+    {
+        Scope sc(c, s, NOMAD_K_FRONT, 0.0);
+        hipLaunchKernelGGL(wav_stats_kernel, dim3(B), dim3(256), 0, s, wav, stride, 0, stats, lens);
+        hipLaunchKernelGGL(gn_fold_kernel, dim3(B), dim3(512), 0, s, stats, c->conv0_w, c->gn_w, c->gn_b, 0, scale, shift,
+                           static_cast<float*>(nullptr), static_cast<float*>(nullptr), lens);
+    }
+    {
+        Scope sc(c, s, NOMAD_K_FRONT, 2.0 * (double)rs.rows[0] * 512 * 10);
+        hipLaunchKernelGGL(conv0_gn_gelu_kernel<bf16_t>, dim3((rs.max_l0 + kConv0Frames - 1) / kConv0Frames, B), dim3(256), 0,
+                           s, wav, stride, 0, c->conv0_w, scale, shift, cb[0], lens, pref(0));
+    }
+    for (int i = 1; i < 7; ++i) {
+        GemmParams p{};
+        p.A = asf(cb[(i - 1) % 2]);
+        p.amap = RowMap{0, 0, 0, kConvS[i] * 512, pref(i), pref(i - 1), B, 512};
+        p.K = kConvK[i] * 512;
+        p.kchunk = p.K;
+        p.W = asf(c->conv_w16[i]);
+        p.ldw = p.K;
+        p.C = asfm(cb[i % 2]);
+        p.M = (int)rs.rows[i];
+        p.N = 512;
+        p.n_valid = 512;
+        p.cmap = plain_map(p.M, 512);
+        p.rmap = p.cmap;
+        p.gelu = 1;
+        if ((rc = run_gemm_bf16(c, p, 1, s))) return rc;
+    }
+    bf16_t* featln = cb[1];
+    {
+        Scope sc(c, s, NOMAD_K_ROW, 0.0);
+        launch_ln_bf16<2>(cb[0], c->fln_w, c->fln_b, featln, M, s);
+    }
+    bf16_t* xpad = H(lay.xpad);
+    const long long grp_stride = rs.P * 48;
+    const RowMap pad_map{64LL * 48, 0, 0, 48, tpref, ppref, B, 48};
+    {
+        Scope sc(c, s, NOMAD_K_ROW, 0.0);
+        hipLaunchKernelGGL(zero_pad_rows_kernel<bf16_t>, dim3(16 * B), dim3(256), 0, s, xpad, 0, tpref, ppref, B);
+    }
+    {
+        GemmParams p = dense(asf(featln), 512, asf(c->proj_w16), c->proj_b, nullptr, asfm(xpad), M, 768, 512, 0);
+        p.cmap = pad_map;
+        p.c_colblk = 48;
+        p.c_colblk_stride = grp_stride;
+        if ((rc = run_gemm_bf16(c, p, 1, s))) return rc;
+    }
+    bf16_t *x = H(lay.x), *x2 = H(lay.x2), *y = H(lay.y), *qkv = H(lay.qkv), *ctxb = H(lay.ctxb), *hb = H(lay.h);
+    {
+        GemmParams p{};
+        p.A = asf(xpad);
+        p.amap = RowMap{0, 0, 0, 48, tpref, ppref, B, 48};
+        p.a_goff = grp_stride;
+        p.K = 6144;
+        p.kchunk = 6144;
+        p.W = asf(c->pos_w16);
+        p.ldw = 6144;
+        p.w_goff = 64LL * 6144;
+        p.bias = c->pos_b;
+        p.bias_goff = 48;
+        p.C = asfm(y);
+        p.cmap = plain_map(M, 768);
+        p.c_goff = 48;
+        p.R = asf(xpad);
+        p.rmap = pad_map;
+        p.r_goff = grp_stride;
+        p.M = M;
+        p.N = 64;
+        p.n_valid = 48;
+        p.gelu = 1;
+        if ((rc = run_gemm_bf16(c, p, 16, s))) return rc;
+    }
+    {
+        Scope sc(c, s, NOMAD_K_ROW, 0.0);
+        launch_ln_bf16<3>(y, c->eln_w, c->eln_b, x, M, s);
+    }
+    double attn_flops = 0.0;
+    for (int i = 0; i < B; ++i) {
+        const double t = rs.meta[rs.off_pref(6) + i + 1] - rs.meta[rs.off_pref(6) + i];
+        attn_flops += 4.0 * 12.0 * t * t * 64;
+    }
+    for (int l = 0; l < NOMAD_NUM_LAYERS; ++l) {
+        const LayerDev& d = c->layers[l];
+        if ((rc = run_gemm_bf16(c, dense(asf(x), 768, asf(c->qkv_w16[l]), d.qkv_b, nullptr, asfm(qkv), M, 2304, 768, 0), 1, s)))
+            return rc;
+        {
+            Scope sc(c, s, NOMAD_K_ATTN, attn_flops);
+            hipLaunchKernelGGL(attention_bf16_kernel, dim3((rs.max_t + 63) / 64, B * 12), dim3(256), 0, s, qkv, ctxb, 0, tpref);
+        }
+        if ((rc = run_gemm_bf16(c, dense(asf(ctxb), 768, asf(c->o_w16[l]), d.o_b, asf(x), asfm(y), M, 768, 768, 0), 1, s)))
+            return rc;
+        {
+            Scope sc(c, s, NOMAD_K_ROW, 0.0);
+            launch_ln_bf16<3>(y, d.ln1_w, d.ln1_b, x2, M, s);
+        }
+        if ((rc = run_gemm_bf16(c, dense(asf(x2), 768, asf(c->fc1_w16[l]), d.fc1_b, nullptr, asfm(hb), M, 3072, 768, 1), 1, s)))
+            return rc;
+        if ((rc = run_gemm_bf16(c, dense(asf(hb), 3072, asf(c->fc2_w16[l]), d.fc2_b, asf(x2), asfm(y), M, 768, 3072, 0), 1, s)))
+            return rc;
+        {
+            Scope sc(c, s, NOMAD_K_ROW, 0.0);
+            launch_ln_bf16<3>(y, d.ln2_w, d.ln2_b, x, M, s);
+        }
+    }
+    {
+        Scope sc(c, s, NOMAD_K_ROW, 2.0 * B * 768 * 256);
+        hipLaunchKernelGGL(head_kernel<bf16_t>, dim3(B), dim3(256), 0, s, x, 0, c->emb_w, c->emb_b, emb, tpref);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 extern "C" {
 
 int nomad_enable_bf16(nomad_ctx* c) {
@@ -1317,6 +1486,20 @@ int nomad_workspace_bytes_bf16(const nomad_ctx* c, int B, int n_samples, size_t*
 int nomad_embed_bf16(nomad_ctx* c, const float* wav, int B, int n_samples, float* emb, void* workspace,
                      size_t workspace_bytes, nomad_stream_t stream) {
     return forward_bf16(c, wav, B, n_samples, emb, workspace, workspace_bytes, stream);
+}
+
+int nomad_workspace_bytes_ragged_bf16(const nomad_ctx* c, int B, const int* lengths_host, size_t* bytes) {
+    RaggedShapes rs;
+    if (!c || !bytes || !lengths_host || B <= 0 || !make_ragged(B, lengths_host, &rs))
+        return fail(NOMAD_ERR_INVALID, "nomad_workspace_bytes_ragged_bf16: bad argument");
+    RaggedLayout lay{};
+    *bytes = ragged_bf16_layout(rs, &lay);
+    return 0;
+}
+
+int nomad_embed_ragged_bf16(nomad_ctx* c, const float* wav, int B, int stride, const int* lengths_host, float* emb,
+                            void* workspace, size_t workspace_bytes, nomad_stream_t stream) {
+    return forward_ragged_bf16(c, wav, B, stride, lengths_host, emb, workspace, workspace_bytes, stream);
 }
 
 int nomad_diag_gemm_bf16(nomad_ctx* c, const void* A, const void* W, const float* bias, const void* R, void* C, int M,

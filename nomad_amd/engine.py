@@ -139,11 +139,13 @@ class Engine:
                                         ws.data_ptr(), ws.numel(), self._stream()), "nomad_embed")
         return (emb, layers) if want_layers else emb
 
-    def embed_ragged(self, waves, head: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
+    def embed_ragged(self, waves, head: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, bf16: bool = False) -> torch.Tensor:
         """Embed clips of different lengths in ONE launch sequence (no padding in the arithmetic).
 
         waves: list of 1-D (or (1,N)) fp32 tensors / numpy arrays (host or device).  Returns (B,256) fp32 on the
-        GPU, bit-identical to embedding every clip on its own."""
+        GPU, bit-identical to embedding every clip on its own.  bf16=True: the bf16 path (no head override)."""
+        if bf16 and head is not None:
+            raise ValueError("the bf16 path has no head override")
         flat = [torch.as_tensor(w, dtype=torch.float32).reshape(-1) for w in waves]
         lens = [int(w.numel()) for w in flat]
         B, stride = len(flat), max(lens)
@@ -157,9 +159,16 @@ class Engine:
         buf = buf.to(self.device)
         arr = (C.c_int * B)(*lens)
         nb = C.c_size_t()
+        emb = torch.empty(B, 256, dtype=torch.float32, device=self.device)
+        if bf16:
+            _lib.check(self.lib.nomad_enable_bf16(self.ctx), "nomad_enable_bf16")
+            _lib.check(self.lib.nomad_workspace_bytes_ragged_bf16(self.ctx, B, arr, C.byref(nb)), "nomad_workspace_bytes_ragged_bf16")
+            ws = self._workspace(nb.value)
+            _lib.check(self.lib.nomad_embed_ragged_bf16(self.ctx, buf.data_ptr(), B, stride, arr, emb.data_ptr(), ws.data_ptr(),
+                                                        ws.numel(), self._stream()), "nomad_embed_ragged_bf16")
+            return emb
         _lib.check(self.lib.nomad_workspace_bytes_ragged(self.ctx, B, arr, C.byref(nb)), "nomad_workspace_bytes_ragged")
         ws = self._workspace(nb.value)
-        emb = torch.empty(B, 256, dtype=torch.float32, device=self.device)
         hw, hb = head if head is not None else (None, None)
         _lib.check(self.lib.nomad_embed_ragged(self.ctx, buf.data_ptr(), B, stride, arr,
                                                hw.data_ptr() if hw is not None else None,

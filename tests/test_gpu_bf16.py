@@ -90,3 +90,37 @@ def test_embed_bf16_long_form(engine):
     assert F.cosine_similarity(e16, e32, dim=1).min().item() > 0.999
     one = engine.embed_bf16(wav[1:2].contiguous())
     assert torch.equal(one[0], e16[1])      # batch invariance holds in bf16 too
+
+
+def test_ragged_bf16_bit_identical_to_single_clips(engine):
+    """nomad_embed_ragged_bf16: clips of different lengths in one launch sequence, each bit-equal to its own
+    nomad_embed_bf16 call (and close to the fp32 path)."""
+    g = torch.Generator().manual_seed(21)
+    lens = [16384, 400, 27225, 9001, 64000, 30267, 5000, 12345, 48000]
+    waves = [(0.1 * torch.randn(n, generator=g)).clamp(-1, 1) for n in lens]
+    rag = engine.embed_ragged(waves, bf16=True)
+    for i, w in enumerate(waves):
+        single = engine.embed_bf16(w[None, :].cuda())
+        assert torch.equal(rag[i], single[0]), (i, lens[i])
+    f32 = engine.embed_ragged(waves)
+    assert (rag - f32).abs().max().item() < 5e-3
+    assert torch.nn.functional.cosine_similarity(rag, f32, dim=1).min().item() > 0.9995  # the 1-frame clip has no time averaging
+    with pytest.raises(ValueError):
+        engine.embed_ragged(waves, head=(torch.zeros(256, 768).cuda(), torch.zeros(256).cuda()), bf16=True)
+
+
+def test_predict_in_bf16_precision(built_lib):
+    """Nomad(precision='bf16').predict on the reference's example files: same files, same layout, scores within 1e-3 of
+    the fp32 run."""
+    import os
+    from conftest import GOLD
+    from nomad_amd.nomad import Nomad
+    nmr, deg = os.path.join(GOLD, "wavs", "nmr-data"), os.path.join(GOLD, "wavs", "test-data")
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        a32, m32 = Nomad(weights="seeded").predict("dir", nmr, deg, results_path=d)
+        a16, m16 = Nomad(weights="seeded", precision="bf16").predict("dir", nmr, deg, results_path=d)
+    assert list(m16.columns) == list(m32.columns) and list(m16.index) == list(m32.index)
+    assert abs(m16.values - m32.values).max() < 2e-3
+    with pytest.raises(ValueError):
+        Nomad(weights="seeded", precision="fp16")
