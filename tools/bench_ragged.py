@@ -43,3 +43,19 @@ for name, fn in (("ragged_batch", ragged), ("per_file_loop", per_file)):
     else:
         out["bit_identical"] = bool(torch.equal(ref, r))
 print(json.dumps(out))
+
+# long recordings of mixed lengths (config C5 through predict): fp32 vs bf16 ragged batches
+n_long = 48
+lens = torch.randint(10 * 16000, 40 * 16000, (n_long,), generator=g).tolist()   # 10 s .. 40 s
+waves = [(0.1 * torch.randn(n, generator=g)).clamp(-1, 1).cuda() for n in lens]
+out = {"workload": f"{n_long} recordings, uniform random lengths 10-40 s ({sum(lens) / 16000:.0f} s of audio)"}
+for name, kw in (("ragged_fp32", {}), ("ragged_bf16", {"bf16": True})):
+    eng.embed_ragged(waves, **kw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        r = eng.embed_ragged(waves, **kw)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    out[name] = {"clips_per_s": round(n_long / dt, 1), "audio_s_per_s": round(sum(lens) / 16000 / dt, 1)}
+print(json.dumps(out))
