@@ -169,11 +169,11 @@ class Training:
             self.train_loader = torch.utils.data.DataLoader(
                 self.train_set, batch_size=self.config["train_bs"], shuffle=self.train_sampler is None,
                 sampler=self.train_sampler, num_workers=self.config["num_workers"],
-                collate_fn=self.train_set.collate_fn, generator=g)
+                collate_fn=self.train_set.collate_fn, generator=g, pin_memory=True)
             self.valid_set = TripletDataset(self.config, data_mode="valid_df", level=self.current_level)
             self.valid_loader = torch.utils.data.DataLoader(
                 self.valid_set, batch_size=self.config["val_bs"], shuffle=False, num_workers=self.config["num_workers"],
-                collate_fn=self.valid_set.collate_fn)
+                collate_fn=self.valid_set.collate_fn, pin_memory=True)
             self.margin = float(self.config["margin"])
             # train_triplet.py:98-107: Adam, pretrained parameters at 1e-5, embedding_layer at `lr`
             self.lr_scheduler = ExponentialLR([1e-5, float(self.config["lr"])], float(self.config["lr_decay_factor"]))
@@ -193,7 +193,7 @@ class Training:
         """A_embs = model(A); P_embs = model(P); N_embs = model(N); loss = criterion(...); zero_grad; backward; step.
         Returns the loss as a 1-element device tensor (no host sync here)."""
         eng = self.engine
-        wavs = [w.to(self.DEVICE, torch.float32).squeeze(1).contiguous() for w in (A, P, N)]
+        wavs = [w.to(self.DEVICE, torch.float32, non_blocking=True).squeeze(1).contiguous() for w in (A, P, N)]
         if not training:
             # model.eval(): clips are independent and the engine is batch invariant bit for bit, so the three
             # forwards of train_triplet.py:146-148 run as ONE batch of 3B clips when the lengths agree
