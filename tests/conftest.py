@@ -11,6 +11,8 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # torch's own DataLoader pin_memory thread calls deprecated Tensor.pin_memory(device)/is_pinned(device)
+    config.addinivalue_line("filterwarnings", "ignore:The argument 'device' of Tensor:DeprecationWarning")
 
 
 @pytest.fixture(scope="session")
