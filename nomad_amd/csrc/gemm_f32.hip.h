@@ -312,6 +312,13 @@ struct GldsCfg {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// 16 bytes per lane from `base + voff + soff` (bytes) straight into LDS through a raw buffer descriptor
+// (buffer_load_dwordx4 ... offen lds): the base is wave-uniform (SGPRs), the per-lane part is one 32-bit VGPR.
+__device__ __forceinline__ void dma16_buffer(const float* base, lptr_t dst, int voff, int soff) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voff, soff, 0, 0);
+}
+
 // STAGES = 2: double-buffered LDS, __syncthreads() (vmcnt(0) + barrier) once per K tile.
 // STAGES = 3: the DMA of tile kt+2 is issued while tile kt is multiplied; the wait before the barrier is a
 //             COUNTED vmcnt that leaves tile kt+1's loads in flight, and the barrier is the raw s_barrier
@@ -345,21 +352,30 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_glds_kernel(const GemmPa
     const float* Ag = p.A + grp * p.a_goff;
     const float* Wg = p.W + grp * p.w_goff;
 
-    // Per-lane source pointers; LDS chunk id = tid + i*NT is linear in the lane within each wave-instruction.
+    // Per-lane DMA sources; LDS chunk id = tid + i*NT is linear in the lane within each wave-instruction.
+    // OPT & 4: buffer_load ... lds - an SGPR resource descriptor per operand (base = this tile's first row, so the
+    // 32-bit per-lane offsets stay small whatever the tensor size), the K-tile offset as the scalar offset; otherwise
+    // global_load_lds with 64-bit per-lane pointers.
     const float* a_src[Cfg::A_CHUNKS];
     const float* b_src[Cfg::B_CHUNKS];
+    int a_voff[Cfg::A_CHUNKS], b_voff[Cfg::B_CHUNKS];
+    const long long tile_row0 = (OPT & 4) ? row_addr(p.amap, m0 < p.M ? m0 : p.M - 1) : 0;
 #pragma unroll
     for (int i = 0; i < Cfg::A_CHUNKS; ++i) {
         const int id = tid + i * NT, row = id / KC, pc = id - row * KC;
         int m = m0 + row;
         m = m < p.M ? m : p.M - 1;
         a_src[i] = Ag + row_addr(p.amap, m) + ((pc ^ ((row / RB) % KC)) * 4);
+        a_voff[i] = (int)((row_addr(p.amap, m) - tile_row0 + ((pc ^ ((row / RB) % KC)) * 4)) * 4);
     }
 #pragma unroll
     for (int i = 0; i < Cfg::B_CHUNKS; ++i) {
         const int id = tid + i * NT, row = id / KC, pc = id - row * KC;
         b_src[i] = Wg + (long long)(n0 + row) * p.ldw + ((pc ^ ((row / RB) % KC)) * 4);
+        b_voff[i] = (int)(((long long)row * p.ldw + ((pc ^ ((row / RB) % KC)) * 4)) * 4);
     }
+    const float* const a_tile = Ag + tile_row0;
+    const float* const b_tile = Wg + (long long)n0 * p.ldw;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -377,10 +393,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_glds_kernel(const GemmPa
         const long long a_koff_ = (long long)kq_ * p.kstride + (k0_ - kq_ * p.kchunk);                   \
         float* as_ = As + (BUF)*BM * BK + wave * 256;                                                    \
         float* bs_ = Bs + (BUF)*BN * BK + wave * 256;                                                    \
-        _Pragma("unroll") for (int i = 0; i < Cfg::A_CHUNKS; ++i)                                        \
-            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + a_koff_), (lptr_t)(as_ + i * NT * 4), 16, 0, 0); \
-        _Pragma("unroll") for (int i = 0; i < Cfg::B_CHUNKS; ++i)                                        \
-            __builtin_amdgcn_global_load_lds((gptr_t)(b_src[i] + k0_), (lptr_t)(bs_ + i * NT * 4), 16, 0, 0);     \
+        if (OPT & 4) {                                                                                   \
+            _Pragma("unroll") for (int i = 0; i < Cfg::A_CHUNKS; ++i)                                    \
+                dma16_buffer(a_tile, (lptr_t)(as_ + i * NT * 4), a_voff[i], (int)(a_koff_ * 4));      \
+            _Pragma("unroll") for (int i = 0; i < Cfg::B_CHUNKS; ++i)                                    \
+                dma16_buffer(b_tile, (lptr_t)(bs_ + i * NT * 4), b_voff[i], k0_ * 4);                 \
+        } else {                                                                                         \
+            _Pragma("unroll") for (int i = 0; i < Cfg::A_CHUNKS; ++i)                                    \
+                __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + a_koff_), (lptr_t)(as_ + i * NT * 4), 16, 0, 0); \
+            _Pragma("unroll") for (int i = 0; i < Cfg::B_CHUNKS; ++i)                                    \
+                __builtin_amdgcn_global_load_lds((gptr_t)(b_src[i] + k0_), (lptr_t)(bs_ + i * NT * 4), 16, 0, 0);     \
+        }                                                                                                \
     }
 
     NOMAD_GLDS_TILE(0, 0)

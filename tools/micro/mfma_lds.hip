@@ -69,6 +69,7 @@ __global__ __launch_bounds__(512) void k(float* out, int iters, const float* src
         // staging area behind the two read stages: [3][384][16] floats, written by DMA only (the fragment reads keep
         // using the static image, so arithmetic stays finite)
         float* stage = lds + 2 * 384 * 16;
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 0x7fffffff, 0x00020000);
         const float* g = src + ((size_t)blockIdx.x * 4096 + tid * 4) % (1 << 21);
         int cur = 0;
         for (int it = 0; it < iters; ++it) {
@@ -80,9 +81,17 @@ __global__ __launch_bounds__(512) void k(float* out, int iters, const float* src
             float* d = stage + cur * 384 * 16 + wave * 256;
             const float* gs = g + (size_t)(it & 1023) * 2048;
             if ((FLAGS & 2) && !(FLAGS & 4)) {
+                if (FLAGS & 8) {  // buffer_load ... lds: SGPR descriptor + 32-bit offsets instead of 64-bit addresses
+                    const int vo = (int)(((size_t)blockIdx.x * 4096 + tid * 4) % (1 << 21)) * 4;
+                    const int so = (it & 1023) * 2048 * 4;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(d), 16, vo, so, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(d + 2048), 16, vo, so + 32768, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(d + 4096), 16, vo, so + 65536, 0, 0);
+                } else {
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    __builtin_amdgcn_global_load_lds((gptr_t)(gs + c * 8192), (lptr_t)(d + c * 2048), 16, 0, 0);
+                    for (int c = 0; c < 3; ++c)
+                        __builtin_amdgcn_global_load_lds((gptr_t)(gs + c * 8192), (lptr_t)(d + c * 2048), 16, 0, 0);
+                }
             }
             rd(0, it & 1);
             if (FLAGS & 4) {  // DMA issued between the two halves of the MFMA cluster
@@ -161,6 +170,10 @@ int main() {
     run<2, 2, false, 7>("64x64, + barrier + LDS-DMA issued mid-cluster", 2, 512, out, src);
     run<2, 2, false, 3>("64x64, + barrier + LDS-DMA (the production main loop)", 2, 512, out, src);
     run<2, 2, false, 7>("64x64, + barrier + LDS-DMA issued mid-cluster", 2, 512, out, src);
+    run<2, 2, false, 10>("64x64, + buffer_load..lds per K tile", 2, 512, out, src);
+    run<2, 2, false, 11>("64x64, + barrier + buffer_load..lds", 2, 512, out, src);
+    run<2, 2, false, 3>("64x64, + barrier + LDS-DMA (global_load_lds)", 2, 512, out, src);
+    run<2, 2, false, 11>("64x64, + barrier + buffer_load..lds", 2, 512, out, src);
     run<2, 2, false, 3>("64x64, + barrier + LDS-DMA, 1 workgroup/CU", 1, 512, out, src);
     run<4, 2, false, 3>("128x64, + barrier + LDS-DMA, 1 workgroup/CU x 8 waves", 1, 512, out, src);
     return 0;
