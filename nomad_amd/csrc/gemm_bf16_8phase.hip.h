@@ -39,7 +39,8 @@ struct P8Cfg {
 };
 
 // ABL (timing-only ablations): 1 = no epilogue stores.
-template <int ABL = 0>
+// BUFLD: LDS-DMA through buffer descriptors (dma16_buffer) instead of global_load_lds - an A/B switch, measured below.
+template <int ABL = 0, bool BUFLD = false>
 __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams p) {
     using Cfg = P8Cfg;
     extern __shared__ __attribute__((aligned(16))) char smem8[];
@@ -81,23 +82,33 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
                                    reinterpret_cast<const char*>(Wg + (long long)(n0 + 128) * p.ldw)};
     char* const dma_dst = smem8 + wave * 1024;  // + lane * 16 implicit (lane-linear LDS-DMA destination)
 
-    // The K-tile term goes into the 32-bit per-thread offset (a VALU add into a temporary), the 64-bit base stays a
-    // loop-invariant scalar: the compiler then uses the saddr form and has no 64-bit VGPR pointers to hoist.
+    // LDS-DMA through buffer descriptors (dma16_buffer, gemm_f32.hip.h): wave-uniform base in SGPRs, one 32-bit VGPR
+    // per lane, the K-tile term as the scalar offset - no 64-bit VGPR pointers for the compiler to hoist or spill.
 #define NOMAD_P8_DMA_A(KT, H)                                                                                   \
     {                                                                                                           \
         const int k0_ = (KT)*64;                                                                                \
         const int kq_ = k0_ / p.kchunk;                                                                         \
         const unsigned ko_ = (unsigned)((kq_ * p.kstride + (k0_ - kq_ * p.kchunk)) * 2);                        \
         char* d_ = dma_dst + ((KT)&1) * Cfg::BUF_BYTES + (H)*Cfg::HALF_BYTES;                                   \
-        __builtin_amdgcn_global_load_lds((gptr_t)(a_base + (a_off[H][0] + ko_)), (lptr_t)(d_), 16, 0, 0);        \
-        __builtin_amdgcn_global_load_lds((gptr_t)(a_base + (a_off[H][1] + ko_)), (lptr_t)(d_ + 8192), 16, 0, 0); \
+        if (BUFLD) {                                                                                            \
+            dma16_buffer(reinterpret_cast<const float*>(a_base), (lptr_t)(d_), (int)a_off[H][0], (int)ko_);       \
+            dma16_buffer(reinterpret_cast<const float*>(a_base), (lptr_t)(d_ + 8192), (int)a_off[H][1], (int)ko_); \
+        } else {                                                                                                \
+            __builtin_amdgcn_global_load_lds((gptr_t)(a_base + (a_off[H][0] + ko_)), (lptr_t)(d_), 16, 0, 0);        \
+            __builtin_amdgcn_global_load_lds((gptr_t)(a_base + (a_off[H][1] + ko_)), (lptr_t)(d_ + 8192), 16, 0, 0); \
+        }                                                                                                       \
     }
 #define NOMAD_P8_DMA_B(KT, H)                                                                                   \
     {                                                                                                           \
         const unsigned ko_ = (unsigned)((KT)*128);                                                              \
         char* d_ = dma_dst + ((KT)&1) * Cfg::BUF_BYTES + (2 + (H)) * Cfg::HALF_BYTES;                           \
-        __builtin_amdgcn_global_load_lds((gptr_t)(b_base[H] + (b_off[0] + ko_)), (lptr_t)(d_), 16, 0, 0);        \
-        __builtin_amdgcn_global_load_lds((gptr_t)(b_base[H] + (b_off[1] + ko_)), (lptr_t)(d_ + 8192), 16, 0, 0); \
+        if (BUFLD) {                                                                                            \
+            dma16_buffer(reinterpret_cast<const float*>(b_base[H]), (lptr_t)(d_), (int)b_off[0], (int)ko_);       \
+            dma16_buffer(reinterpret_cast<const float*>(b_base[H]), (lptr_t)(d_ + 8192), (int)b_off[1], (int)ko_); \
+        } else {                                                                                                \
+            __builtin_amdgcn_global_load_lds((gptr_t)(b_base[H] + (b_off[0] + ko_)), (lptr_t)(d_), 16, 0, 0);        \
+            __builtin_amdgcn_global_load_lds((gptr_t)(b_base[H] + (b_off[1] + ko_)), (lptr_t)(d_ + 8192), 16, 0, 0); \
+        }                                                                                                       \
     }
 
     f32x4 acc[8][4];
@@ -253,18 +264,18 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
     }
 }
 
-template <int ABL = 0>
+template <int ABL = 0, bool BUFLD = false>
 inline hipError_t launch_gemm_bf16_8phase(GemmParams p, int groups, hipStream_t s) {
     p.tiles_m = (p.M + P8Cfg::BM - 1) / P8Cfg::BM;
     p.tiles_n = p.N / P8Cfg::BN;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_8phase_kernel<ABL>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_8phase_kernel<ABL, BUFLD>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_bf16_8phase_kernel<ABL>, dim3(p.tiles_m * p.tiles_n, groups), dim3(P8Cfg::THREADS), P8Cfg::LDS_BYTES, s, p);
+    hipLaunchKernelGGL((gemm_bf16_8phase_kernel<ABL, BUFLD>), dim3(p.tiles_m * p.tiles_n, groups), dim3(P8Cfg::THREADS), P8Cfg::LDS_BYTES, s, p);
     return hipGetLastError();
 }
 

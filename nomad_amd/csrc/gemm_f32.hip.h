@@ -564,6 +564,8 @@ struct N48Cfg {
     static constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
 };
 
+// BUFLD: LDS-DMA through buffer descriptors instead of global_load_lds (A/B switch).
+template <bool BUFLD = false>
 __global__ __launch_bounds__(512) void gemm_f32_n48_kernel(const GemmParams p) {
     using Cfg = N48Cfg;
     constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, NT = Cfg::THREADS, KC = Cfg::KC, RB = Cfg::RB, ST = Cfg::STAGES;
@@ -577,19 +579,22 @@ __global__ __launch_bounds__(512) void gemm_f32_n48_kernel(const GemmParams p) {
     const float* Ag = p.A + grp * p.a_goff;
     const float* Wg = p.W + grp * p.w_goff;
 
-    const float* a_src[2];
+    // LDS-DMA through buffer descriptors (see dma16_buffer): base = this tile's first row, 32-bit lane offsets
+    const long long tile_row0 = row_addr(p.amap, m0 < p.M ? m0 : p.M - 1);
+    const float* const a_tile = Ag + tile_row0;
+    int a_voff[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int id = tid + i * NT, row = id / KC, pc = id - row * KC;
         int m = m0 + row;
         m = m < p.M ? m : p.M - 1;
-        a_src[i] = Ag + row_addr(p.amap, m) + ((pc ^ ((row / RB) % KC)) * 4);
+        a_voff[i] = (int)((row_addr(p.amap, m) - tile_row0 + ((pc ^ ((row / RB) % KC)) * 4)) * 4);
     }
     const bool loads_b = wave < 3;  // 48 rows x 4 chunks = 192 chunks = waves 0..2 (wave-uniform)
-    const float* b_src = nullptr;
+    int b_voff = 0;
     if (loads_b) {
         const int row = tid / KC, pc = tid - row * KC;
-        b_src = Wg + (long long)row * p.ldw + ((pc ^ ((row / RB) % KC)) * 4);
+        b_voff = (int)(((long long)row * p.ldw + ((pc ^ ((row / RB) % KC)) * 4)) * 4);
     }
     f32x4 acc[2][3];
 #pragma unroll
@@ -602,10 +607,16 @@ __global__ __launch_bounds__(512) void gemm_f32_n48_kernel(const GemmParams p) {
     {                                                                                                    \
         const int k0_ = (KT)*BK;                                                                         \
         float* as_ = As + (BUF)*BM * BK + wave * 256;                                                    \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                    \
-            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + k0_), (lptr_t)(as_ + i * NT * 4), 16, 0, 0); \
-        if (loads_b)                                                                                     \
-            __builtin_amdgcn_global_load_lds((gptr_t)(b_src + k0_), (lptr_t)(Bs + (BUF)*BN * BK + wave * 256), 16, 0, 0); \
+        if (BUFLD) {                                                                                     \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                \
+                dma16_buffer(a_tile, (lptr_t)(as_ + i * NT * 4), a_voff[i], k0_ * 4);                     \
+            if (loads_b) dma16_buffer(Wg, (lptr_t)(Bs + (BUF)*BN * BK + wave * 256), b_voff, k0_ * 4);    \
+        } else {                                                                                         \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                \
+                __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(a_tile) + (unsigned)a_voff[i] + k0_ * 4), (lptr_t)(as_ + i * NT * 4), 16, 0, 0); \
+            if (loads_b)                                                                                 \
+                __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(Wg) + (unsigned)b_voff + k0_ * 4), (lptr_t)(Bs + (BUF)*BN * BK + wave * 256), 16, 0, 0); \
+        }                                                                                                \
     }
     NOMAD_N48_TILE(0, 0)
     if (nk > 1) NOMAD_N48_TILE(1, 1)
@@ -690,17 +701,18 @@ __global__ __launch_bounds__(512) void gemm_f32_n48_kernel(const GemmParams p) {
     }
 }
 
+template <bool BUFLD = false>
 inline hipError_t launch_gemm_n48(GemmParams p, int groups, hipStream_t s) {
     p.tiles_m = (p.M + N48Cfg::BM - 1) / N48Cfg::BM;
     p.tiles_n = 1;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_n48_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_n48_kernel<BUFLD>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_f32_n48_kernel, dim3(p.tiles_m, groups), dim3(N48Cfg::THREADS), N48Cfg::LDS_BYTES, s, p);
+    hipLaunchKernelGGL(gemm_f32_n48_kernel<BUFLD>, dim3(p.tiles_m, groups), dim3(N48Cfg::THREADS), N48Cfg::LDS_BYTES, s, p);
     return hipGetLastError();
 }
 

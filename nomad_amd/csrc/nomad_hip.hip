@@ -405,7 +405,8 @@ int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, in
             if (p.N % 256 != 0 || p.K % 64 != 0) return fail(NOMAD_ERR_INVALID, "fp32 ping-pong gemm: N %% 256, K %% 64");
             e = tile == 46 ? launch_gemm_f32_pp<false>(p, groups, s) : launch_gemm_f32_pp<true>(p, groups, s);
             break;
-        case 48: e = launch_gemm_n48(p, groups, s); break;   // N = 48 exactly (16x16x4 MFMA): the grouped pos-conv
+        case 48: e = launch_gemm_n48<true>(p, groups, s); break;    // N = 48 exactly (16x16x4 MFMA): the grouped pos-conv
+        case 49: e = launch_gemm_n48<false>(p, groups, s); break;   // A/B: global_load_lds instead of buffer_load..lds   // N = 48 exactly (16x16x4 MFMA): the grouped pos-conv
         case 14: e = launch_gemm<128, 128, 32, 2, 2, 1>(p, groups, s); break;            // ablations of tile 0
         case 15: e = launch_gemm<128, 128, 32, 2, 2, 2>(p, groups, s); break;
         case 16: e = launch_gemm<128, 128, 32, 2, 2, 3>(p, groups, s); break;
@@ -1104,6 +1105,10 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
             if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
             e = tile == 16 ? launch_gemm_bf16_8phase<0>(p, groups, s) : launch_gemm_bf16_8phase<1>(p, groups, s);
             break;
+        case 18:  // A/B: 8-phase kernel with buffer_load..lds
+            if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
+            e = launch_gemm_bf16_8phase<0, true>(p, groups, s);
+            break;
         default: return fail(NOMAD_ERR_INVALID, "unknown bf16 gemm tile id %d", tile);
     }
     if (e != hipSuccess) return fail(NOMAD_ERR_HIP, "bf16 gemm launch: %s", hipGetErrorString(e));
@@ -1505,7 +1510,7 @@ int nomad_embed_ragged_bf16(nomad_ctx* c, const float* wav, int B, int stride, c
 int nomad_diag_gemm_bf16(nomad_ctx* c, const void* A, const void* W, const float* bias, const void* R, void* C, int M,
                          int N, int K, int gelu, int tile, nomad_stream_t stream) {
     static const int kBN[] = {128, 128, 64, 256, 64, 128, 128, 128, 128, 256, 256, 128, 128, 128, 128, 256};
-    if (!c || !A || !W || !C || M <= 0 || tile < 0 || tile > 17) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: bad argument");
+    if (!c || !A || !W || !C || M <= 0 || tile < 0 || tile > 18) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: bad argument");
     if (N % kBN[tile] || K % 64) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: N %% %d or K %% 64 != 0", kBN[tile]);
     GemmParams p = dense(static_cast<const float*>(A), K, static_cast<const float*>(W), bias, static_cast<const float*>(R),
                          static_cast<float*>(C), M, N, K, gelu);
@@ -2347,10 +2352,10 @@ int nomad_diag_gemm(nomad_ctx* c, const float* A, const float* W, const float* b
     static const int kBK[] = {32, 16, 32, 16, 32, 32, 16, 32, 16, 16, 16, 32, 32, 16, 32, 32, 32, 16, 16, 16,
                               32, 16, 16, 32, 16, 32, 16, 16, 16, 32, 32, 32, 16, 16, 32, 32, 32, 32, 32, 32, 16, 16,
                               16, 16, 16, 16, 64, 64};
-    if (tile == 48) {
+    if (tile == 48 || tile == 49) {
         if (N != 48 || K % 16) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile 48 needs N == 48 and K %% 16 == 0");
         GemmParams p48 = dense(A, K, W, bias, R, C, M, N, K, gelu);
-        return run_gemm(c, p48, 1, 48, static_cast<hipStream_t>(stream));
+        return run_gemm(c, p48, 1, tile, static_cast<hipStream_t>(stream));
     }
     if (tile < 0 || tile > 47) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile id %d", tile);
     const int bn = kBN[tile], bk = kBK[tile];

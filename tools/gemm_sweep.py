@@ -22,6 +22,7 @@ SHAPES = {  # name: (M, N, K, bias, gelu, residual)
     "conv6": (50944, 512, 1024, False, True, False),
     "fc1_nogelu": (50944, 3072, 768, True, False, False),
     "proj": (50944, 768, 512, True, False, False),
+    "pos": (50944, 48, 6144, True, True, False),   # one group of the pos-conv (tile ids 48 / 49 only)
     # quantisation probes for the 256x128 kernel at 2 workgroups/CU (512 slots): 9.0, 9.33 and 9.98 rounds
     "fc1_9r": (49152, 3072, 768, True, True, False),
     "fc1_10r": (54528, 3072, 768, True, True, False),
@@ -63,8 +64,9 @@ TILE_NAMES.update({32: "glds 256x128x16 ABL no-epilogue", 33: "glds 256x128x16 w
                    38: "glds 128x32x32 w4x1 3-stage", 39: "glds 32x32x32 w1x1 3-stage",
                    40: "glds 256x256x16 w4x4 3-stage", 41: "glds 256x256x16 w4x4 2-stage",
                    42: "t33 with workgroup barriers in the epilogue", 43: "t33 + setprio", 44: "t33 with global_load_lds", 45: "t33 persistent 1024 wgs",
-                   46: "ping-pong 256x256x32 1wg/cu", 47: "ping-pong 256x256x32 ABL no-epilogue"})
-BN.update({32: 128, 33: 128, 34: 64, 35: 128, 36: 32, 37: 64, 38: 32, 39: 32, 40: 256, 41: 256, 42: 128, 43: 128, 44: 128, 45: 128, 46: 256, 47: 256})
+                   46: "ping-pong 256x256x32 1wg/cu", 47: "ping-pong 256x256x32 ABL no-epilogue",
+                   48: "n48 16x16x4 buffer_load..lds", 49: "n48 16x16x4 global_load_lds"})
+BN.update({32: 128, 33: 128, 34: 64, 35: 128, 36: 32, 37: 64, 38: 32, 39: 32, 40: 256, 41: 256, 42: 128, 43: 128, 44: 128, 45: 128, 46: 256, 47: 256, 48: 48, 49: 48})
 TILE_NAMES.update({28: "glds 128x64x16 w2x2", 29: "glds 128x64x32 w4x2", 30: "glds 128x64x32 w2x2", 31: "glds 128x128x32 w4x2"})
 
 
@@ -85,9 +87,9 @@ def main():
                  7: "bf16 128x128 ABL no-epilogue", 8: "bf16 128x128 ABL one-k-tile",
                  9: "bf16 256x256 w2x4 bk32 4st", 10: "bf16 256x256 w4x2 bk32 4st", 11: "bf16 128x128 w4x2 bk32 4st",
                  12: "bf16 128x128 w4x2 bk64 3st", 13: "bf16 256x128 w4x2 bk64 3st", 14: "bf16 256x128 w4x2 bk32 4st",
-                 15: "bf16 256x256 w2x4 bk64 2st", 16: "bf16 256x256 8-phase", 17: "bf16 256x256 8-phase ABL no-epilogue"}
+                 15: "bf16 256x256 w2x4 bk64 2st", 16: "bf16 256x256 8-phase", 17: "bf16 256x256 8-phase ABL no-epilogue", 18: "bf16 256x256 8-phase buffer_load..lds"}
         bn = {0: 128, 1: 128, 2: 64, 3: 256, 4: 64, 5: 128, 6: 128, 7: 128, 8: 128, 9: 256, 10: 256, 11: 128, 12: 128,
-              13: 128, 14: 128, 15: 256, 16: 256, 17: 256}
+              13: 128, 14: 128, 15: 256, 16: 256, 17: 256, 18: 256}
         for sname in a.shapes.split(","):
             M, N, K, has_b, gelu, has_r = SHAPES[sname]
             A = torch.randn(M, K, generator=g).bfloat16().cuda()
@@ -96,7 +98,7 @@ def main():
             R = torch.randn(M, N, generator=g).bfloat16().cuda() if has_r else None
             first = None
             for t in (int(x) for x in a.tiles.split(",")):
-                if N % bn[t] or (t in (16, 17) and K % 128):
+                if N % bn[t] or (t in (16, 17, 18) and K % 128):
                     continue
                 out = eng.diag_gemm_bf16(A, W, b, R, gelu=gelu, tile=t).float()
                 if first is None:
