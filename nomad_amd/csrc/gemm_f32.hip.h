@@ -429,16 +429,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_glds_kernel(const GemmPa
             __builtin_amdgcn_s_barrier();  // every wave's share of tile kt has landed; buffer of tile kt-1 is free
             asm volatile("" ::: "memory");
         }
-        {
-            const int nxt = kt + STAGES - 1;
-            int nb = cur + STAGES - 1;
-            nb = nb >= STAGES ? nb - STAGES : nb;
-            if (nxt < nk) NOMAD_GLDS_TILE(nxt, nb)
-        }
+        const int nxt = kt + STAGES - 1;
+        int nb = cur + STAGES - 1;
+        nb = nb >= STAGES ? nb - STAGES : nb;
+        // OPT & 8: the DMA of tile kt+STAGES-1 is issued after the first k-quarter's MFMAs instead of right behind the
+        // barrier, where all eight waves would queue on the memory pipe before any of them reaches its MFMAs
+        if (!(OPT & 8) && nxt < nk) NOMAD_GLDS_TILE(nxt, nb)
         const float* as = As + cur * BM * BK + a_row_off;
         const float* bs = Bs + cur * BN * BK + b_row_off;
 #pragma unroll
         for (int kq = 0; kq < BK / 8; ++kq) {
+            if ((OPT & 8) && kq == 1 && nxt < nk) NOMAD_GLDS_TILE(nxt, nb)
             f32x4 af[TM], bf[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * BK + koff[kq]);

@@ -374,7 +374,7 @@ int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, in
         case 11: e = launch_gemm<128, 128, 32, 4, 2>(p, groups, s); break;
         case 12: e = launch_gemm<128, 128, 32, 2, 4>(p, groups, s); break;
         case 13: e = launch_gemm<128, 128, 16, 4, 2>(p, groups, s); break;               // 3 WG/CU if registers allow
-        case 20: e = launch_gemm_glds<128, 128, 32, 2, 2, 2, false, 4>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 2, 2>::LDS_BYTES)); break;
+        case 20: e = launch_gemm_glds<128, 128, 32, 2, 2, 2, false, 12>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 2, 2>::LDS_BYTES)); break;
         case 21: e = launch_gemm_glds<256, 128, 16, 4, 2>(p, groups, s, occ_pad(occ, GldsCfg<256, 128, 16, 4, 2>::LDS_BYTES)); break;
         case 22: e = launch_gemm_glds<128, 128, 16, 4, 2>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 16, 4, 2>::LDS_BYTES)); break;
         case 23: e = launch_gemm_glds<256, 128, 32, 4, 2>(p, groups, s, occ_pad(occ, GldsCfg<256, 128, 32, 4, 2>::LDS_BYTES)); break;
@@ -385,13 +385,13 @@ int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, in
         case 28: e = launch_gemm_glds<128, 64, 16, 2, 2>(p, groups, s, occ_pad(occ, GldsCfg<128, 64, 16, 2, 2>::LDS_BYTES)); break;
         case 29: e = launch_gemm_glds<128, 64, 32, 4, 2>(p, groups, s, occ_pad(occ, GldsCfg<128, 64, 32, 4, 2>::LDS_BYTES)); break;
         case 30: e = launch_gemm_glds<128, 64, 32, 2, 2>(p, groups, s, occ_pad(occ, GldsCfg<128, 64, 32, 2, 2>::LDS_BYTES)); break;
-        case 31: e = launch_gemm_glds<128, 128, 32, 4, 2, 2, false, 4>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 4, 2>::LDS_BYTES)); break;
+        case 31: e = launch_gemm_glds<128, 128, 32, 4, 2, 2, false, 12>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 4, 2>::LDS_BYTES)); break;
         case 32: e = launch_gemm_glds<256, 128, 16, 4, 2, 2, true>(p, groups, s); break;  // ablation: no epilogue stores
-        case 33: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 5>(p, groups, s); break;   // 3-stage LDS-DMA pipeline (buffer_load..lds), counted vmcnt
-        case 34: e = launch_gemm_glds<128, 64, 32, 4, 2, 3, false, 4>(p, groups, s); break;
+        case 33: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13>(p, groups, s); break;   // 3-stage LDS-DMA pipeline (buffer_load..lds, issued mid-cluster), counted vmcnt
+        case 34: e = launch_gemm_glds<128, 64, 32, 4, 2, 3, false, 12>(p, groups, s); break;
         case 35: e = launch_gemm_glds<256, 128, 32, 4, 2, 3>(p, groups, s); break;
         case 36: e = launch_gemm_glds<64, 32, 32, 2, 1, 3>(p, groups, s); break;    // small problems: many small workgroups
-        case 37: e = launch_gemm_glds<64, 64, 32, 2, 2, 3, false, 4>(p, groups, s); break;
+        case 37: e = launch_gemm_glds<64, 64, 32, 2, 2, 3, false, 12>(p, groups, s); break;
         case 38: e = launch_gemm_glds<128, 32, 32, 4, 1, 3>(p, groups, s); break;
         case 39: e = launch_gemm_glds<32, 32, 32, 1, 1, 3>(p, groups, s); break;
         case 40: e = launch_gemm_glds<256, 256, 16, 4, 4, 3>(p, groups, s); break;   // one 16-wave workgroup per CU
@@ -399,7 +399,7 @@ int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, in
         case 42: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 0>(p, groups, s); break;   // t33 with workgroup barriers between epilogue slabs
         case 43: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 3>(p, groups, s); break;   // t33 + s_setprio around the MFMAs (-4 %)
         case 44: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 1>(p, groups, s); break;            // t33 with global_load_lds (64-bit per-lane pointers)
-        case 45: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 1>(p, groups, s, 0, 1024); break;   // t33 persistent, 4 per CU slot
+        case 45: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 5>(p, groups, s); break;            // t33 with the DMA issued right behind the barrier
         case 46:  // 256x256, one workgroup/CU, ping-pong wave rows (gemm_f32_pp.hip.h)
         case 47:  // ablation: no epilogue stores
             if (p.N % 256 != 0 || p.K % 64 != 0) return fail(NOMAD_ERR_INVALID, "fp32 ping-pong gemm: N %% 256, K %% 64");

@@ -63,7 +63,7 @@ TILE_NAMES.update({32: "glds 256x128x16 ABL no-epilogue", 33: "glds 256x128x16 w
                    35: "glds 256x128x32 w4x2 3-stage", 36: "glds 64x32x32 w2x1 3-stage", 37: "glds 64x64x32 w2x2 3-stage",
                    38: "glds 128x32x32 w4x1 3-stage", 39: "glds 32x32x32 w1x1 3-stage",
                    40: "glds 256x256x16 w4x4 3-stage", 41: "glds 256x256x16 w4x4 2-stage",
-                   42: "t33 with workgroup barriers in the epilogue", 43: "t33 + setprio", 44: "t33 with global_load_lds", 45: "t33 persistent 1024 wgs",
+                   42: "t33 with workgroup barriers in the epilogue", 43: "t33 + setprio", 44: "t33 with global_load_lds", 45: "t33 with DMA right behind the barrier",
                    46: "ping-pong 256x256x32 1wg/cu", 47: "ping-pong 256x256x32 ABL no-epilogue",
                    48: "n48 16x16x4 buffer_load..lds", 49: "n48 16x16x4 global_load_lds"})
 BN.update({32: 128, 33: 128, 34: 64, 35: 128, 36: 32, 37: 64, 38: 32, 39: 32, 40: 256, 41: 256, 42: 128, 43: 128, 44: 128, 45: 128, 46: 256, 47: 256, 48: 48, 49: 48})
