@@ -637,11 +637,9 @@ __global__ __launch_bounds__(512) void gemm_f32_n48_kernel(const GemmParams p) {
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        {
-            int nb = cur + 2;
-            nb = nb >= ST ? nb - ST : nb;
-            if (kt + 2 < nk) NOMAD_N48_TILE(kt + 2, nb)
-        }
+        int nb = cur + 2;
+        nb = nb >= ST ? nb - ST : nb;
+        if (!BUFLD && kt + 2 < nk) NOMAD_N48_TILE(kt + 2, nb)
         const float* as = As + cur * BM * BK + a_row_off;
         const float* bs = Bs + cur * BN * BK + b_row_off;
         f32x4 af[2], bf[3];
@@ -650,12 +648,15 @@ __global__ __launch_bounds__(512) void gemm_f32_n48_kernel(const GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) bf[j] = *reinterpret_cast<const f32x4*>(bs + j * 16 * BK);
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < 4; ++c) {
+            // production variant: the DMA is issued behind the first quarter of the tile's MFMAs (as in the big GEMM)
+            if (BUFLD && c == 1 && kt + 2 < nk) NOMAD_N48_TILE(kt + 2, nb)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][c], bf[j][c], acc[i][j], 0, 0, 0);
+        }
         cur = cur + 1 == ST ? 0 : cur + 1;
     }
 #undef NOMAD_N48_TILE
