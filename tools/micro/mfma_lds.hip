@@ -103,9 +103,17 @@ __global__ __launch_bounds__(512) void k(float* out, int iters, const float* src
                         for (int j = 0; j < TN; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][i][0][c], bf[0][j][0][c], acc[i][j], 0, 0, 0);
                 asm volatile("" ::: "memory");
+                if (FLAGS & 8) {
+                    const int vo = (int)(((size_t)blockIdx.x * 4096 + tid * 4) % (1 << 21)) * 4;
+                    const int so = (it & 1023) * 2048 * 4;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(d), 16, vo, so, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(d + 2048), 16, vo, so + 32768, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(d + 4096), 16, vo, so + 65536, 0, 0);
+                } else {
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    __builtin_amdgcn_global_load_lds((gptr_t)(gs + c * 8192), (lptr_t)(d + c * 2048), 16, 0, 0);
+                    for (int c = 0; c < 3; ++c)
+                        __builtin_amdgcn_global_load_lds((gptr_t)(gs + c * 8192), (lptr_t)(d + c * 2048), 16, 0, 0);
+                }
                 asm volatile("" ::: "memory");
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
@@ -170,6 +178,7 @@ int main() {
     run<2, 2, false, 7>("64x64, + barrier + LDS-DMA issued mid-cluster", 2, 512, out, src);
     run<2, 2, false, 3>("64x64, + barrier + LDS-DMA (the production main loop)", 2, 512, out, src);
     run<2, 2, false, 7>("64x64, + barrier + LDS-DMA issued mid-cluster", 2, 512, out, src);
+    run<2, 2, false, 15>("64x64, + barrier + buffer_load..lds issued mid-cluster (production now)", 2, 512, out, src);
     run<2, 2, false, 10>("64x64, + buffer_load..lds per K tile", 2, 512, out, src);
     run<2, 2, false, 11>("64x64, + barrier + buffer_load..lds", 2, 512, out, src);
     run<2, 2, false, 3>("64x64, + barrier + LDS-DMA (global_load_lds)", 2, 512, out, src);
