@@ -38,7 +38,7 @@ struct P8Cfg {
     static constexpr int ELD = 64 + 4;                      // epilogue slab row (floats)
 };
 
-// ABL (timing-only ablations): 1 = no epilogue stores.
+// ABL: 1 = no epilogue stores (timing only); 2 = no s_setprio around the MFMA clusters (A/B, same results).
 // BUFLD: LDS-DMA through buffer descriptors (dma16_buffer) instead of global_load_lds - an A/B switch, measured below.
 template <int ABL = 0, bool BUFLD = false>
 __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams p) {
@@ -145,9 +145,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
 #define NOMAD_P8_SYNC_COMPUTE(I0, J0)                   \
     __builtin_amdgcn_s_barrier();                       \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
-    __builtin_amdgcn_s_setprio(1);                      \
+    if (ABL != 2) __builtin_amdgcn_s_setprio(1);        \
     NOMAD_P8_MMA(I0, J0)                                \
-    __builtin_amdgcn_s_setprio(0);                      \
+    if (ABL != 2) __builtin_amdgcn_s_setprio(0);        \
     __builtin_amdgcn_s_barrier();                       \
     asm volatile("" ::: "memory");
 

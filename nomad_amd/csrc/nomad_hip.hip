@@ -1109,6 +1109,10 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
             if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
             e = launch_gemm_bf16_8phase<0, true>(p, groups, s);
             break;
+        case 19:  // A/B: 8-phase kernel without s_setprio
+            if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
+            e = launch_gemm_bf16_8phase<2>(p, groups, s);
+            break;
         default: return fail(NOMAD_ERR_INVALID, "unknown bf16 gemm tile id %d", tile);
     }
     if (e != hipSuccess) return fail(NOMAD_ERR_HIP, "bf16 gemm launch: %s", hipGetErrorString(e));
@@ -1509,8 +1513,8 @@ int nomad_embed_ragged_bf16(nomad_ctx* c, const float* wav, int B, int stride, c
 
 int nomad_diag_gemm_bf16(nomad_ctx* c, const void* A, const void* W, const float* bias, const void* R, void* C, int M,
                          int N, int K, int gelu, int tile, nomad_stream_t stream) {
-    static const int kBN[] = {128, 128, 64, 256, 64, 128, 128, 128, 128, 256, 256, 128, 128, 128, 128, 256};
-    if (!c || !A || !W || !C || M <= 0 || tile < 0 || tile > 18) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: bad argument");
+    static const int kBN[] = {128, 128, 64, 256, 64, 128, 128, 128, 128, 256, 256, 128, 128, 128, 128, 256, 256, 256, 256, 256};
+    if (!c || !A || !W || !C || M <= 0 || tile < 0 || tile >= static_cast<int>(sizeof(kBN) / sizeof(kBN[0]))) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: bad argument");
     if (N % kBN[tile] || K % 64) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: N %% %d or K %% 64 != 0", kBN[tile]);
     GemmParams p = dense(static_cast<const float*>(A), K, static_cast<const float*>(W), bias, static_cast<const float*>(R),
                          static_cast<float*>(C), M, N, K, gelu);
