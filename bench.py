@@ -73,6 +73,10 @@ def cpu_baseline(sd, n_samples, budget_s=20.0, max_clips=256):
                       f"over 8/16/32/64"}
 
 
+PRECISION_NOTE = {"f32": "fp32", "bf16": "bf16 storage / fp32 accumulate",
+                  "bf16x3": "bf16x3 (hi/lo-split operands, 3 bf16 MFMA products, fp32 accumulate; fp32 attention / norms)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -81,9 +85,10 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="clips per GPU per step")
     ap.add_argument("--refs", type=int, default=32, help="of which non-matching references")
     ap.add_argument("--seconds", type=float, default=4.0)
-    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+    ap.add_argument("--dtype", choices=("f32", "bf16", "bf16x3"), default="f32",
                     help="f32 = the BASELINE metric (configs[1]); bf16 = the long-form config C5 path "
-                         "(use with --seconds 30 --batch 32)")
+                         "(use with --seconds 30 --batch 32); bf16x3 = fp32-class scores from three bf16 MFMA "
+                         "products over hi/lo-split operands (an extra line, never the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with hipEvents")
     args = ap.parse_args()
@@ -114,7 +119,8 @@ def main():
     ckpt = find_checkpoint()
     sd = load_checkpoint(ckpt) if ckpt else seeded_state_dict(0)
     eng = Engine(sd, local_rank)
-    scorer = ShardedScorer(eng.embed_bf16 if args.dtype == "bf16" else eng.embed, eng.pairwise, equal_shards=True)
+    embed_fn = {"f32": eng.embed, "bf16": eng.embed_bf16, "bf16x3": eng.embed_bf16x3}[args.dtype]
+    scorer = ShardedScorer(embed_fn, eng.pairwise, equal_shards=True)
 
     n_samples = int(round(args.seconds * 16000))
     B, n_ref = args.batch, args.refs
@@ -157,7 +163,8 @@ def main():
         value = clips / elapsed
         T = num_frames(n_samples)
         flop_clip = {64000: FLOP_PER_CLIP_4S, 480000: 500.044e9}.get(n_samples)
-        peak = 2.5e15 if args.dtype == "bf16" else PEAK_FP32_MFMA
+        # bf16x3 executes 3 bf16 MFMA flops per algorithmic (fp32-equivalent) flop: its ceiling is a third of the bf16 peak
+        peak = {"f32": PEAK_FP32_MFMA, "bf16": 2.5e15, "bf16x3": 2.5e15 / 3}[args.dtype]
         out = {
             "metric": "clips/sec embedded + NxM NOMAD distances, 16kHz x 4s batches",
             "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
@@ -166,7 +173,7 @@ def main():
             "data": "synthetic (0.1*randn waveforms, seed 1000+rank; " +
                     ("real nomad_best_model.pt" if ckpt else "seeded random-init wav2vec2-base + head weights") + ")",
             "config": {"workload": f"configs[1]: batch={B} x {n_samples} samples (T={T}) per GPU, wav2vec2-base + "
-                                   f"projection head {'bf16 storage / fp32 accumulate' if args.dtype == 'bf16' else 'fp32'}, {B - n_ref} deg x {n_ref}*N "
+                                   f"projection head {PRECISION_NOTE[args.dtype]}, {B - n_ref} deg x {n_ref}*N "
                                    f"ref float64 distances + means",
                        "clips_per_gpu_per_step": B, "deg_per_gpu": B - n_ref, "ref_total": n_ref * world,
                        "parallelism": f"clip-sharded x{world}, all-gather of ref embeddings"},
@@ -187,7 +194,9 @@ def main():
                 return cls["flops"] / (cls["ms"] * 1e-3) / 1e12 if cls["ms"] > 0 else 0.0
             allg, big, fine = prof["gemm_mfma_all"], prof["gemm_mfma_256x128"], prof["gemm_mfma_128x64"]
             dom = big if big["ms"] >= fine["ms"] else fine      # the dominant kernel = the instantiation with most time
-            if args.dtype == "bf16":
+            if args.dtype == "bf16x3":
+                kname = "gemm_bf16_8phase_kernel 256x256 X3 (3 x v_mfma_f32_16x16x32_bf16 per fp32-equivalent product)"
+            elif args.dtype == "bf16":
                 kname = ("gemm_bf16_8phase_kernel 256x256 (v_mfma_f32_16x16x32_bf16) + gemm_bf16_glds_kernel 128x128/256x256"
                          if dom is big else "gemm_bf16_glds_kernel 128x64 (v_mfma_f32_32x32x16_bf16)")
             else:

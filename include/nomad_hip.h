@@ -228,6 +228,28 @@ int nomad_workspace_bytes_ragged_bf16(const nomad_ctx* ctx, int B, const int* le
 int nomad_embed_ragged_bf16(nomad_ctx* ctx, const float* wav_dev, int B, int stride, const int* lengths_host,
                             float* emb_dev, void* workspace_dev, size_t workspace_bytes, nomad_stream_t stream);
 
+/* ---- bf16x3: fp32-class scoring on the bf16 matrix cores -------------------------------------
+ * Same surface as nomad_embed (TripletModel.forward, nomad.py:224-231), for callers who want the reference's
+ * scores to its stated tolerance (1e-4) at more than the fp32 MFMA rate.  Every GEMM operand is kept as two bf16
+ * planes, hi = bf16(x) and lo = bf16(x - hi) (16 mantissa bits, the bytes of one fp32), and multiplied as three
+ * bf16 MFMA products hi*hi + hi*lo + lo*hi with fp32 accumulation; bias, GELU, residuals, LayerNorm, the attention
+ * (fp32 MFMA) and the head are fp32.  Accuracy is measured against the fp32 path in tests/test_gpu_bf16x3.py
+ * (NOMAD scores agree to ~1e-6).  Scoring only: no layer outputs, no backward.
+ *   nomad_enable_bf16x3          builds the split weight copies (allocates once; call again after nomad_train_* /
+ *                                weight updates)
+ *   nomad_embed_bf16x3           wav [B][n_samples] fp32 -> emb [B][256] fp32
+ *   nomad_workspace_bytes_bf16x3 scratch size for it
+ */
+int nomad_enable_bf16x3(nomad_ctx* ctx);
+int nomad_workspace_bytes_bf16x3(const nomad_ctx* ctx, int B, int n_samples, size_t* bytes);
+int nomad_embed_bf16x3(nomad_ctx* ctx, const float* wav_dev, int B, int n_samples, float* emb_dev,
+                       void* workspace_dev, size_t workspace_bytes, nomad_stream_t stream);
+/* bf16x3 counterpart of nomad_embed_ragged (files of different lengths in one launch sequence - what predict uses):
+ * same arguments, no head override; every clip's result equals its own single-clip nomad_embed_bf16x3 call */
+int nomad_workspace_bytes_ragged_bf16x3(const nomad_ctx* ctx, int B, const int* lengths_host, size_t* bytes);
+int nomad_embed_ragged_bf16x3(nomad_ctx* ctx, const float* wav_dev, int B, int stride, const int* lengths_host,
+                              float* emb_dev, void* workspace_dev, size_t workspace_bytes, nomad_stream_t stream);
+
 /* ---- measurement ------------------------------------------------------------------------- */
 /* Kernel classes for the in-library HIP-event timers. */
 enum {
@@ -260,6 +282,14 @@ int nomad_diag_gemm(nomad_ctx* ctx, const float* A_dev, const float* W_dev, cons
 int nomad_diag_gemm_bf16(nomad_ctx* ctx, const void* A_dev, const void* W_dev, const float* bias_dev,
                          const void* R_dev, void* C_dev, int M, int N, int K, int gelu, int tile,
                          nomad_stream_t stream);
+/* bf16x3 pieces.  nomad_diag_split_bf16: fp32 in[n] -> split planes out (hi at 0, lo at `plane` bf16 elements), or back
+ * (inverse != 0: `in` is the split buffer, `out` fp32).  nomad_diag_gemm_bf16x3: the split GEMM on split A [M][K]
+ * (planes M*K apart), W [N][K] (N*K apart), optional R [M][N] (M*N apart); C is split (M*N apart) or fp32 (out_f32). */
+int nomad_diag_split_bf16(nomad_ctx* ctx, const float* in_dev, void* out_dev, long long plane, long long n, int inverse,
+                          nomad_stream_t stream);
+int nomad_diag_gemm_bf16x3(nomad_ctx* ctx, const void* A_dev, const void* W_dev, const float* bias_dev,
+                           const void* R_dev, void* C_dev, int M, int N, int K, int gelu, int out_f32,
+                           nomad_stream_t stream);
 /* bf16 attention: qkv [B*T][2304] bf16 (q pre-scaled) -> out [B*T][768] bf16. */
 int nomad_diag_attention_bf16(nomad_ctx* ctx, const void* qkv_dev, void* out_dev, int B, int T, nomad_stream_t stream);
 /* out[M][N] = LayerNorm(in[M][N]) * gamma + beta, N in {512, 768}, eps 1e-5. */

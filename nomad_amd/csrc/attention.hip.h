@@ -98,11 +98,13 @@ __device__ __forceinline__ void attn_tile(const float* __restrict__ Ks, const fl
 // lse (nullable): [B*12][T] log-sum-exp of every score row, saved for the backward pass.
 // T_ = storage type of qkv / out (fp32 or bf16); the arithmetic is fp32 MFMA either way.
 // tpref (nullable): ragged batches - clip b owns rows tpref[b] .. tpref[b+1]-1 of qkv / out.
-template <typename T_ = float, bool DROP = false>
-__global__ __launch_bounds__(256) void attention_f32_kernel(const T_* __restrict__ qkv, T_* __restrict__ out,
+// TO_ = storage type of out when it differs from qkv's (split planes `out_plane` apart in the bf16x3 path).
+template <typename T_ = float, bool DROP = false, typename TO_ = T_>
+__global__ __launch_bounds__(256) void attention_f32_kernel(const T_* __restrict__ qkv, TO_* __restrict__ out,
                                                             float* __restrict__ lse, int T,
                                                             const int* __restrict__ tpref = nullptr,
-                                                            DropCfg dc = DropCfg{}, uint32_t site = 0, int bh0 = 0) {
+                                                            DropCfg dc = DropCfg{}, uint32_t site = 0, int bh0 = 0,
+                                                            long long out_plane = 0) {
     __shared__ __attribute__((aligned(16))) float Ks[64 * kAttnLD];
     __shared__ __attribute__((aligned(16))) float Vs[64 * kAttnLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -174,12 +176,12 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const T_* __restrict
     const float inv = 1.0f / l_tot;
     if (lse && q_row < T && g == 0) lse[(long long)bh * T + q_row] = m_run + logf(l_tot);
     if (q_row < T) {
-        T_* dst = out + (row0 + q_row) * 768 + h * 64 + g * 4;
+        TO_* dst = out + (row0 + q_row) * 768 + h * 64 + g * 4;
 #pragma unroll
         for (int ds = 0; ds < 4; ++ds) {
             float4 r;
             r.x = o[ds][0] * inv; r.y = o[ds][1] * inv; r.z = o[ds][2] * inv; r.w = o[ds][3] * inv;
-            store4<T_>(dst + ds * 16, r);
+            store4p<TO_>(dst + ds * 16, out_plane, r);
         }
     }
 }

@@ -37,6 +37,53 @@ __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float4 v) {
 template <typename T>
 __device__ __forceinline__ float load1(const T* p) { return (float)*p; }
 
+// Split storage ("bf16x3" path): an fp32 value x is kept as TWO bf16 planes, hi = bf16(x) and lo = bf16(x - hi),
+// `plane` elements apart (hi + lo carries 16 mantissa bits; same bytes per element as fp32).  The GEMMs of that
+// path multiply the planes as three bf16 MFMA products, hi*hi + hi*lo + lo*hi, accumulated in fp32
+// (gemm_bf16_8phase.hip.h, X3); everything else reads hi + lo.  bf16s_t tags such a buffer (2-byte pointer steps).
+struct bf16s_t {
+    bf16_t v;
+};
+
+// load4p / store4p: load4 / store4 with the plane distance of a split buffer (ignored by the plain types).
+template <typename T>
+__device__ __forceinline__ float4 load4p(const T* p, long long) {
+    return load4<T>(p);
+}
+template <>
+__device__ __forceinline__ float4 load4p<bf16s_t>(const bf16s_t* p, long long plane) {
+    const bf16x4 h = *reinterpret_cast<const bf16x4*>(p);
+    const bf16x4 l = *reinterpret_cast<const bf16x4*>(p + plane);
+    return make_float4((float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2],
+                       (float)h[3] + (float)l[3]);
+}
+template <typename T>
+__device__ __forceinline__ void store4p(T* p, long long, float4 v) {
+    store4<T>(p, v);
+}
+template <>
+__device__ __forceinline__ void store4p<bf16s_t>(bf16s_t* p, long long plane, float4 v) {
+    bf16x4 h, l;
+    h[0] = (bf16_t)v.x; h[1] = (bf16_t)v.y; h[2] = (bf16_t)v.z; h[3] = (bf16_t)v.w;
+    l[0] = (bf16_t)(v.x - (float)h[0]); l[1] = (bf16_t)(v.y - (float)h[1]);
+    l[2] = (bf16_t)(v.z - (float)h[2]); l[3] = (bf16_t)(v.w - (float)h[3]);
+    *reinterpret_cast<bf16x4*>(p) = h;
+    *reinterpret_cast<bf16x4*>(p + plane) = l;
+}
+
+// fp32 -> split planes (weights at nomad_enable_bf16x3, test inputs).  out[0..n) = hi, out[plane..plane+n) = lo.
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ in, bf16s_t* __restrict__ out,
+                                                         long long plane, long long n4) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256)
+        store4p<bf16s_t>(out + 4 * i, plane, *reinterpret_cast<const float4*>(in + 4 * i));
+}
+// split planes -> fp32 (tests)
+__global__ __launch_bounds__(256) void unsplit_bf16_kernel(const bf16s_t* __restrict__ in, long long plane,
+                                                           float* __restrict__ out, long long n4) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256)
+        *reinterpret_cast<float4*>(out + 4 * i) = load4p<bf16s_t>(in + 4 * i, plane);
+}
+
 // fp32 -> bf16 copy (weights at nomad_enable_bf16).  n % 4 == 0.
 __global__ __launch_bounds__(256) void to_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long long n4) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256)

@@ -100,7 +100,8 @@ template <typename TOut>
 __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restrict__ wav, int n_samples, int L0,
                                                             const float* __restrict__ w0, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, TOut* __restrict__ out,
-                                                            const int* __restrict__ lens, const int* __restrict__ pref0) {
+                                                            const int* __restrict__ lens, const int* __restrict__ pref0,
+                                                            long long out_plane = 0) {
     __shared__ float xs[kConv0Frames * 5 + 8];
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * kConv0Frames;
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restr
             for (int j = 0; j < 10; ++j) y = fmaf(w[q][j], xv[j], y);
             rp[q] = gelu_erf(fmaf(y, sc[q], sh[q]));
         }
-        store4<TOut>(o + (long long)t * 512, r);
+        store4p<TOut>(o + (long long)t * 512, out_plane, r);
     }
 }
 

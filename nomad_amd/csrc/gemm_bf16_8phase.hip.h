@@ -40,7 +40,13 @@ struct P8Cfg {
 
 // ABL: 1 = no epilogue stores (timing only); 2 = no s_setprio around the MFMA clusters (A/B, same results).
 // BUFLD: LDS-DMA through buffer descriptors (dma16_buffer) instead of global_load_lds - an A/B switch, measured below.
-template <int ABL = 0, bool BUFLD = false>
+// X3 ("bf16x3", fp32-class results on the bf16 matrix cores): A, W and R are SPLIT buffers (dtypes.hip.h: hi and lo
+//   bf16 planes p.a_plane / p.w_plane / p.r_plane elements apart) and the K loop walks 3 K/64 tiles - tile 3 kk + s
+//   multiplies k-range kk of (A_hi, W_hi), (A_hi, W_lo), (A_lo, W_hi) for s = 0, 1, 2 - into the same fp32
+//   accumulators: a.w = (ah + al)(wh + wl) minus the al*wl term (2^-16 relative), i.e. the plain kernel run on
+//   operands concatenated along K, with no other change to the schedule.  X3 = 1 stores the result split
+//   (p.c_plane), X3 = 2 stores fp32.
+template <int ABL = 0, bool BUFLD = false, int X3 = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams p) {
     using Cfg = P8Cfg;
     extern __shared__ __attribute__((aligned(16))) char smem8[];
@@ -80,34 +86,51 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
     const char* const a_base = reinterpret_cast<const char*>(Ag + tile_row0);
     const char* const b_base[2] = {reinterpret_cast<const char*>(Wg + (long long)n0 * p.ldw),
                                    reinterpret_cast<const char*>(Wg + (long long)(n0 + 128) * p.ldw)};
+    // lo planes (X3): wave-uniform bases, selected per K tile by scalar code
+    const char* const a_base_lo = a_base + (X3 ? p.a_plane * 2 : 0);
+    const char* const b_base_lo[2] = {b_base[0] + (X3 ? p.w_plane * 2 : 0), b_base[1] + (X3 ? p.w_plane * 2 : 0)};
     char* const dma_dst = smem8 + wave * 1024;  // + lane * 16 implicit (lane-linear LDS-DMA destination)
 
     // LDS-DMA through buffer descriptors (dma16_buffer, gemm_f32.hip.h): wave-uniform base in SGPRs, one 32-bit VGPR
     // per lane, the K-tile term as the scalar offset - no 64-bit VGPR pointers for the compiler to hoist or spill.
 #define NOMAD_P8_DMA_A(KT, H)                                                                                   \
     {                                                                                                           \
-        const int k0_ = (KT)*64;                                                                                \
+        int kt_ = (KT);                                                                                         \
+        const char* ab_ = a_base;                                                                               \
+        if (X3) {                                                                                               \
+            const int kk_ = kt_ / 3;                                                                            \
+            if (kt_ - 3 * kk_ == 2) ab_ = a_base_lo;                                                            \
+            kt_ = kk_;                                                                                          \
+        }                                                                                                       \
+        const int k0_ = kt_ * 64;                                                                               \
         const int kq_ = k0_ / p.kchunk;                                                                         \
         const unsigned ko_ = (unsigned)((kq_ * p.kstride + (k0_ - kq_ * p.kchunk)) * 2);                        \
         char* d_ = dma_dst + ((KT)&1) * Cfg::BUF_BYTES + (H)*Cfg::HALF_BYTES;                                   \
         if (BUFLD) {                                                                                            \
-            dma16_buffer(reinterpret_cast<const float*>(a_base), (lptr_t)(d_), (int)a_off[H][0], (int)ko_);       \
-            dma16_buffer(reinterpret_cast<const float*>(a_base), (lptr_t)(d_ + 8192), (int)a_off[H][1], (int)ko_); \
+            dma16_buffer(reinterpret_cast<const float*>(ab_), (lptr_t)(d_), (int)a_off[H][0], (int)ko_);          \
+            dma16_buffer(reinterpret_cast<const float*>(ab_), (lptr_t)(d_ + 8192), (int)a_off[H][1], (int)ko_);   \
         } else {                                                                                                \
-            __builtin_amdgcn_global_load_lds((gptr_t)(a_base + (a_off[H][0] + ko_)), (lptr_t)(d_), 16, 0, 0);        \
-            __builtin_amdgcn_global_load_lds((gptr_t)(a_base + (a_off[H][1] + ko_)), (lptr_t)(d_ + 8192), 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds((gptr_t)(ab_ + (a_off[H][0] + ko_)), (lptr_t)(d_), 16, 0, 0);         \
+            __builtin_amdgcn_global_load_lds((gptr_t)(ab_ + (a_off[H][1] + ko_)), (lptr_t)(d_ + 8192), 16, 0, 0);  \
         }                                                                                                       \
     }
 #define NOMAD_P8_DMA_B(KT, H)                                                                                   \
     {                                                                                                           \
-        const unsigned ko_ = (unsigned)((KT)*128);                                                              \
+        int kt_ = (KT);                                                                                         \
+        const char* bb_ = b_base[H];                                                                            \
+        if (X3) {                                                                                               \
+            const int kk_ = kt_ / 3;                                                                            \
+            if (kt_ - 3 * kk_ == 1) bb_ = b_base_lo[H];                                                         \
+            kt_ = kk_;                                                                                          \
+        }                                                                                                       \
+        const unsigned ko_ = (unsigned)(kt_ * 128);                                                             \
         char* d_ = dma_dst + ((KT)&1) * Cfg::BUF_BYTES + (2 + (H)) * Cfg::HALF_BYTES;                           \
         if (BUFLD) {                                                                                            \
-            dma16_buffer(reinterpret_cast<const float*>(b_base[H]), (lptr_t)(d_), (int)b_off[0], (int)ko_);       \
-            dma16_buffer(reinterpret_cast<const float*>(b_base[H]), (lptr_t)(d_ + 8192), (int)b_off[1], (int)ko_); \
+            dma16_buffer(reinterpret_cast<const float*>(bb_), (lptr_t)(d_), (int)b_off[0], (int)ko_);             \
+            dma16_buffer(reinterpret_cast<const float*>(bb_), (lptr_t)(d_ + 8192), (int)b_off[1], (int)ko_);      \
         } else {                                                                                                \
-            __builtin_amdgcn_global_load_lds((gptr_t)(b_base[H] + (b_off[0] + ko_)), (lptr_t)(d_), 16, 0, 0);        \
-            __builtin_amdgcn_global_load_lds((gptr_t)(b_base[H] + (b_off[1] + ko_)), (lptr_t)(d_ + 8192), 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds((gptr_t)(bb_ + (b_off[0] + ko_)), (lptr_t)(d_), 16, 0, 0);            \
+            __builtin_amdgcn_global_load_lds((gptr_t)(bb_ + (b_off[1] + ko_)), (lptr_t)(d_ + 8192), 16, 0, 0);     \
         }                                                                                                       \
     }
 
@@ -117,7 +140,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K / 64;  // even
+    const int nk = (X3 ? 3 : 1) * (p.K / 64);  // even
     // prologue: tile 0 complete, A of tile 1 on its way
     NOMAD_P8_DMA_A(0, 0)
     NOMAD_P8_DMA_A(0, 1)
@@ -154,30 +177,30 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
     // one K tile (buffer BUF = KT & 1, a compile-time constant per call site)
 #define NOMAD_P8_KTILE(KT, BUF)                                                                            \
     {                                                                                                      \
-        const char* ab_ = smem8 + (BUF)*Cfg::BUF_BYTES + a_frag;                                           \
-        const char* bb_ = smem8 + (BUF)*Cfg::BUF_BYTES + b_frag;                                           \
+        const char* la_ = smem8 + (BUF)*Cfg::BUF_BYTES + a_frag;                                           \
+        const char* lb_ = smem8 + (BUF)*Cfg::BUF_BYTES + b_frag;                                           \
         /* phase 1: B columns 0..31, A rows 0..63 */                                                       \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                    \
-            bf[j][0] = *reinterpret_cast<const bf16x8*>(bb_ + j * 2048 + koff0);                           \
-            bf[j][1] = *reinterpret_cast<const bf16x8*>(bb_ + j * 2048 + koff1);                           \
+            bf[j][0] = *reinterpret_cast<const bf16x8*>(lb_ + j * 2048 + koff0);                           \
+            bf[j][1] = *reinterpret_cast<const bf16x8*>(lb_ + j * 2048 + koff1);                           \
         }                                                                                                  \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                    \
-            af[i][0] = *reinterpret_cast<const bf16x8*>(ab_ + i * 2048 + koff0);                           \
-            af[i][1] = *reinterpret_cast<const bf16x8*>(ab_ + i * 2048 + koff1);                           \
+            af[i][0] = *reinterpret_cast<const bf16x8*>(la_ + i * 2048 + koff0);                           \
+            af[i][1] = *reinterpret_cast<const bf16x8*>(la_ + i * 2048 + koff1);                           \
         }                                                                                                  \
         if ((KT) + 1 < nk) NOMAD_P8_DMA_B((KT) + 1, 0)                                                     \
         NOMAD_P8_SYNC_COMPUTE(0, 0)                                                                        \
         /* phase 2: A rows 64..127 */                                                                      \
         _Pragma("unroll") for (int i = 4; i < 8; ++i) {                                                    \
-            af[i][0] = *reinterpret_cast<const bf16x8*>(ab_ + i * 2048 + koff0);                           \
-            af[i][1] = *reinterpret_cast<const bf16x8*>(ab_ + i * 2048 + koff1);                           \
+            af[i][0] = *reinterpret_cast<const bf16x8*>(la_ + i * 2048 + koff0);                           \
+            af[i][1] = *reinterpret_cast<const bf16x8*>(la_ + i * 2048 + koff1);                           \
         }                                                                                                  \
         if ((KT) + 1 < nk) NOMAD_P8_DMA_B((KT) + 1, 1)                                                     \
         NOMAD_P8_SYNC_COMPUTE(4, 0)                                                                        \
         /* phase 3: B columns 32..63 */                                                                    \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                    \
-            bf[j][0] = *reinterpret_cast<const bf16x8*>(bb_ + (2 + j) * 2048 + koff0);                     \
-            bf[j][1] = *reinterpret_cast<const bf16x8*>(bb_ + (2 + j) * 2048 + koff1);                     \
+            bf[j][0] = *reinterpret_cast<const bf16x8*>(lb_ + (2 + j) * 2048 + koff0);                     \
+            bf[j][1] = *reinterpret_cast<const bf16x8*>(lb_ + (2 + j) * 2048 + koff1);                     \
         }                                                                                                  \
         NOMAD_P8_SYNC_COMPUTE(0, 2)                                                                        \
         /* phase 4: both A halves of tile t+2 (their last read was phase 2), then "tile t+1 has landed" */ \
@@ -204,6 +227,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
 
     // ---- epilogue: 32-row fp32 slabs through LDS (accumulator: column fr, rows 4 fq + r of each 16 x 16 tile) ----
     bf16_t* Cg = reinterpret_cast<bf16_t*>(p.C) + grp * p.c_goff;
+    float* Cf = p.C + grp * p.c_goff;  // X3 == 2: fp32 output
     const bf16_t* Rg = p.R ? reinterpret_cast<const bf16_t*>(p.R) + grp * p.r_goff : nullptr;
     const float* biasg = p.bias ? p.bias + grp * p.bias_goff : nullptr;
     const bool c_plain = p.cmap.clip_rows >= p.M, r_plain = p.rmap.clip_rows >= p.M;
@@ -243,39 +267,56 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
                     const f32x4 hi = *reinterpret_cast<const f32x4*>(slab + row * ELD + cg * 8 + 4);
                     float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     if (Rg) {
-                        const bf16x8 rv = *reinterpret_cast<const bf16x8*>(
-                            Rg + (r_plain ? p.rmap.off + (long long)m * p.rmap.ld : row_addr(p.rmap, m)) + n);
+                        const bf16_t* rp = Rg + (r_plain ? p.rmap.off + (long long)m * p.rmap.ld : row_addr(p.rmap, m)) + n;
+                        const bf16x8 rv = *reinterpret_cast<const bf16x8*>(rp);
+                        if (X3) {
+                            const bf16x8 rl = *reinterpret_cast<const bf16x8*>(rp + p.r_plane);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+                            for (int e = 0; e < 8; ++e) v[e] += (float)rv[e] + (float)rl[e];
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+                        }
                     }
                     long long c_col = n;
                     if (p.c_colblk > 0) {
                         const int blk = n / p.c_colblk;
                         c_col = (long long)blk * p.c_colblk_stride + (n - blk * p.c_colblk);
                     }
-                    bf16x8 ov;
+                    const long long ci = (c_plain ? p.cmap.off + (long long)m * p.cmap.ld : row_addr(p.cmap, m)) + c_col;
+                    if (X3 == 2) {
+                        *reinterpret_cast<f32x4*>(Cf + ci) = (f32x4){v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(Cf + ci + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+                    } else {
+                        bf16x8 ov;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) ov[e] = (bf16_t)v[e];
-                    *reinterpret_cast<bf16x8*>(
-                        Cg + (c_plain ? p.cmap.off + (long long)m * p.cmap.ld : row_addr(p.cmap, m)) + c_col) = ov;
+                        for (int e = 0; e < 8; ++e) ov[e] = (bf16_t)v[e];
+                        *reinterpret_cast<bf16x8*>(Cg + ci) = ov;
+                        if (X3 == 1) {
+                            bf16x8 ol;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) ol[e] = (bf16_t)(v[e] - (float)ov[e]);
+                            *reinterpret_cast<bf16x8*>(Cg + ci + p.c_plane) = ol;
+                        }
+                    }
                 }
             }
         }
     }
 }
 
-template <int ABL = 0, bool BUFLD = false>
+template <int ABL = 0, bool BUFLD = false, int X3 = 0>
 inline hipError_t launch_gemm_bf16_8phase(GemmParams p, int groups, hipStream_t s) {
     p.tiles_m = (p.M + P8Cfg::BM - 1) / P8Cfg::BM;
     p.tiles_n = p.N / P8Cfg::BN;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_8phase_kernel<ABL, BUFLD>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_8phase_kernel<ABL, BUFLD, X3>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_8phase_kernel<ABL, BUFLD>), dim3(p.tiles_m * p.tiles_n, groups), dim3(P8Cfg::THREADS), P8Cfg::LDS_BYTES, s, p);
+    hipLaunchKernelGGL((gemm_bf16_8phase_kernel<ABL, BUFLD, X3>), dim3(p.tiles_m * p.tiles_n, groups), dim3(P8Cfg::THREADS), P8Cfg::LDS_BYTES, s, p);
     return hipGetLastError();
 }
 

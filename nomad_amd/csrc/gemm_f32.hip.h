@@ -81,6 +81,8 @@ struct GemmParams {
     const float* DG;
     RowMap dgmap;
     long long dg_goff;
+    // bf16x3 path (gemm_bf16_8phase.hip.h, X3): element distance from the hi to the lo plane of A, W, C and R
+    long long a_plane, w_plane, c_plane, r_plane;
 };
 
 __device__ __forceinline__ float dgelu_erf_(float u) {

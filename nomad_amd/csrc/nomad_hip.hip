@@ -282,6 +282,13 @@ struct nomad_ctx {
     bf16_t *proj_w16 = nullptr, *pos_w16 = nullptr;
     bf16_t *qkv_w16[NOMAD_NUM_LAYERS] = {}, *o_w16[NOMAD_NUM_LAYERS] = {}, *fc1_w16[NOMAD_NUM_LAYERS] = {},
            *fc2_w16[NOMAD_NUM_LAYERS] = {};
+    // split (hi | lo bf16 planes) weight copies for the bf16x3 path (built by nomad_enable_bf16x3); the grouped
+    // pos-conv stays on the fp32 kernel and uses pos_w
+    bool x3_ready = false;
+    bf16s_t* conv_wx[7] = {};
+    bf16s_t* proj_wx = nullptr;
+    bf16s_t *qkv_wx[NOMAD_NUM_LAYERS] = {}, *o_wx[NOMAD_NUM_LAYERS] = {}, *fc1_wx[NOMAD_NUM_LAYERS] = {},
+            *fc2_wx[NOMAD_NUM_LAYERS] = {};
     // fine-tuning state (nomad_train_enable): master parameters, gradients, Adam moments; see ParamOffsets
     bool train_ready = false;
     float *theta = nullptr, *grad = nullptr, *adam_m = nullptr, *adam_v = nullptr;
@@ -1071,7 +1078,7 @@ static int run_ln_bwd(nomad_ctx* c, const float* x, const float* g, const float*
 
 // ---- bf16 path (config C5) -----------------------------------------------------------------------------
 static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, int tile = -1) {
-    const double flops = 2.0 * p.M * (double)p.n_valid * p.K * groups;
+    const double flops = 2.0 * p.M * (double)p.n_valid * p.K * groups;  // bf16x3: the fp32-equivalent count, not 3x
     if (tile < 0) {
         // measured (profiles/r01_gemm_sweep_bf16.json): 256x256 tiles (wave tile 64x128) win on wide (N >= 1024)
         // and very tall problems, 128x128 (8 waves) on the N = 768 / 512 transformer shapes
@@ -1081,7 +1088,7 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
             tile = 16;  // deep-pipelined 256x256 kernel once there are >= 2 rounds of tiles (profiles/r01_gemm_sweep_bf16_8phase.json)
         else tile = (p.N % 256 == 0 && (p.N >= 1024 || p.M >= 100000)) ? 3 : 1;
     }
-    Scope sc(c, s, NOMAD_K_GEMM, flops, (tile == 1 || tile == 3 || tile == 16) ? NOMAD_K_GEMM_BIG : (tile == 2 ? NOMAD_K_GEMM_FINE : -1));
+    Scope sc(c, s, NOMAD_K_GEMM, flops, (tile == 1 || tile == 3 || tile == 16 || tile == 20 || tile == 21) ? NOMAD_K_GEMM_BIG : (tile == 2 ? NOMAD_K_GEMM_FINE : -1));
     hipError_t e;
     switch (tile) {
         case 0: e = launch_gemm_bf16<256, 128, 4, 2>(p, groups, s); break;
@@ -1108,6 +1115,11 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
         case 18:  // A/B: 8-phase kernel with buffer_load..lds
             if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
             e = launch_gemm_bf16_8phase<0, true>(p, groups, s);
+            break;
+        case 20:  // bf16x3: split operands, split output
+        case 21:  // bf16x3: split operands, fp32 output
+            if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16x3 gemm: N %% 256, K %% 128");
+            e = tile == 20 ? launch_gemm_bf16_8phase<0, false, 1>(p, groups, s) : launch_gemm_bf16_8phase<0, false, 2>(p, groups, s);
             break;
         case 19:  // A/B: 8-phase kernel without s_setprio
             if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
@@ -1281,6 +1293,273 @@ static int forward_bf16(nomad_ctx* c, const float* wav, int B, int n_samples, fl
     }
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+
+// ---- bf16x3 path: fp32-class results on the bf16 matrix cores ------------------------------------------------
+// Every dense / conv GEMM runs as three bf16 MFMA products over split operands (gemm_bf16_8phase.hip.h, X3), the
+// activations between them live as split planes (dtypes.hip.h) or fp32 - 4 bytes per element either way:
+//   conv0 -> split -> conv1..6 (split) -> LN -> split -> post_extract_proj -> fp32 (group-major, padded)
+//   -> grouped pos-conv on the fp32 kernel (N = 48 per group is no shape for a 256-wide tile) -> fp32 -> LN -> split
+//   per layer: QKV -> fp32 -> fp32 MFMA attention -> split -> out-proj (+ split residual) -> fp32 -> LN -> split
+//              -> fc1 + GELU -> split -> fc2 (+ split residual) -> fp32 -> LN -> split (fp32 after the last layer)
+// Accumulators, bias / GELU / residual, LayerNorm statistics, softmax and the head are fp32 as in the fp32 path.
+// One implementation serves equal-length batches and ragged ones: X3Geom carries the row maps of either.
+struct X3Geom {
+    int B = 0;
+    long long rows[7] = {};      // total frames per conv level; rows[6] = M
+    long long pad_rows = 0;      // rows of one group of the padded pos-conv buffer
+    int max_l0 = 0, max_t = 0;
+    int wav_ld = 0;              // samples between clips of the wav buffer
+    int L0 = 0, T = 0;           // equal-length batches; 0 when ragged (the kernels read lens / prefixes instead)
+    RowMap conv_amap[7];         // im2col rows of conv layer i over the output of layer i - 1
+    RowMap pad_map, pos_amap;    // proj output / pos-conv residual rows, pos-conv input rows (group-major, padded)
+    double attn_flops = 0.0;
+    const RaggedShapes* ragged = nullptr;
+};
+
+struct X3Layout {
+    size_t meta, stats, scale, shift, conva, convb, xpad, x, x2, y, qkv, ctxb, h, total;
+    long long capa, capb;  // elements per plane of the two conv ping-pong buffers
+};
+
+static X3Layout make_x3_layout(const X3Geom& g) {
+    X3Layout l{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += align_up(bytes);
+        return o;
+    };
+    const size_t e = 4, M = (size_t)g.rows[6];  // fp32, or two bf16 planes
+    l.capa = 512LL * g.rows[0];
+    l.capb = 512LL * g.rows[1];
+    l.meta = take(g.ragged ? sizeof(int) * g.ragged->meta.size() : 0);
+    l.stats = take(sizeof(double) * kStatsPerClip * g.B);
+    l.scale = take(sizeof(float) * 512 * g.B);
+    l.shift = take(sizeof(float) * 512 * g.B);
+    l.conva = take(e * l.capa);
+    l.convb = take(e * l.capb);
+    l.xpad = take(e * 768 * (size_t)g.pad_rows);
+    l.x = take(e * 768 * M);
+    l.x2 = take(e * 768 * M);
+    l.y = take(e * 768 * M);
+    l.qkv = take(e * 2304 * M);
+    l.ctxb = take(e * 768 * M);
+    l.h = take(e * 3072 * M);
+    l.total = off;
+    return l;
+}
+
+static X3Geom x3_geom_fixed(const Shapes& sh) {
+    X3Geom g;
+    g.B = sh.B;
+    for (int i = 0; i < 7; ++i) g.rows[i] = (long long)sh.B * sh.L[i];
+    g.pad_rows = (long long)sh.B * (sh.T + 128);
+    g.max_l0 = sh.L[0];
+    g.max_t = sh.T;
+    g.wav_ld = sh.N;
+    g.L0 = sh.L[0];
+    g.T = sh.T;
+    for (int i = 1; i < 7; ++i) g.conv_amap[i] = RowMap{0, (long long)sh.L[i - 1] * 512, sh.L[i], kConvS[i] * 512};
+    g.pad_map = RowMap{64LL * 48, (long long)(sh.T + 128) * 48, sh.T, 48};
+    g.pos_amap = RowMap{0, (long long)(sh.T + 128) * 48, sh.T, 48};
+    g.attn_flops = 4.0 * sh.B * 12.0 * (double)sh.T * sh.T * 64;
+    return g;
+}
+
+// meta: the device copy of rs.meta (prefix tables); the row maps point into it
+static X3Geom x3_geom_ragged(const RaggedShapes& rs, int stride, const int* meta) {
+    X3Geom g;
+    g.B = rs.B;
+    for (int i = 0; i < 7; ++i) g.rows[i] = rs.rows[i];
+    g.pad_rows = rs.P;
+    g.max_l0 = rs.max_l0;
+    g.max_t = rs.max_t;
+    g.wav_ld = stride;
+    g.ragged = &rs;
+    auto pref = [&](int i) { return meta ? meta + rs.off_pref(i) : nullptr; };
+    const int* ppref = meta ? meta + rs.off_ppref() : nullptr;
+    for (int i = 1; i < 7; ++i) g.conv_amap[i] = RowMap{0, 0, 0, kConvS[i] * 512, pref(i), pref(i - 1), rs.B, 512};
+    g.pad_map = RowMap{64LL * 48, 0, 0, 48, pref(6), ppref, rs.B, 48};
+    g.pos_amap = RowMap{0, 0, 0, 48, pref(6), ppref, rs.B, 48};
+    for (int i = 0; i < rs.B; ++i) {
+        const double t = rs.meta[rs.off_pref(6) + i + 1] - rs.meta[rs.off_pref(6) + i];
+        g.attn_flops += 4.0 * 12.0 * t * t * 64;
+    }
+    return g;
+}
+
+static GemmParams dense_x3(const bf16s_t* A, long long a_plane, int lda, const bf16s_t* W, const float* bias,
+                           const bf16s_t* R, long long r_plane, void* C, long long c_plane, int M, int N, int K, int gelu) {
+    GemmParams p = dense(reinterpret_cast<const float*>(A), lda, reinterpret_cast<const float*>(W), bias,
+                         reinterpret_cast<const float*>(R), static_cast<float*>(C), M, N, K, gelu);
+    p.a_plane = a_plane;
+    p.w_plane = (long long)N * K;
+    p.r_plane = r_plane;
+    p.c_plane = c_plane;
+    return p;
+}
+
+// meta (ragged only): device prefix tables, already on their way (same stream)
+static int forward_x3_run(nomad_ctx* c, const float* wav, const X3Geom& g, const X3Layout& lay, const int* meta, float* emb,
+                          char* ws, hipStream_t s) {
+    auto S = [&](size_t off) { return reinterpret_cast<bf16s_t*>(ws + off); };
+    auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    const int B = g.B, M = (int)g.rows[6];
+    const int* lens = g.ragged ? meta + g.ragged->off_lens() : kNoInts;
+    const int* pref0 = g.ragged ? meta + g.ragged->off_pref(0) : kNoInts;
+    const int* tpref = g.ragged ? meta + g.ragged->off_pref(6) : kNoInts;
+    const int* ppref = g.ragged ? meta + g.ragged->off_ppref() : kNoInts;
+    const long long pl768 = 768LL * M, pl3072 = 3072LL * M;
+    int rc;
+    double* stats = reinterpret_cast<double*>(ws + lay.stats);
+    float* scale = F(lay.scale);
+    float* shift = F(lay.shift);
+    bf16s_t* cb[2] = {S(lay.conva), S(lay.convb)};
+    const long long cap[2] = {lay.capa, lay.capb};
+    {
+        Scope sc(c, s, NOMAD_K_FRONT, 0.0);
+        hipLaunchKernelGGL(wav_stats_kernel, dim3(B), dim3(256), 0, s, wav, g.wav_ld, g.L0, stats, lens);
+        hipLaunchKernelGGL(gn_fold_kernel, dim3(B), dim3(512), 0, s, stats, c->conv0_w, c->gn_w, c->gn_b, g.L0, scale,
+                           shift, static_cast<float*>(nullptr), static_cast<float*>(nullptr), lens);
+    }
+    {
+        Scope sc(c, s, NOMAD_K_FRONT, 2.0 * (double)g.rows[0] * 512 * 10);
+        hipLaunchKernelGGL(conv0_gn_gelu_kernel<bf16s_t>, dim3((g.max_l0 + kConv0Frames - 1) / kConv0Frames, B), dim3(256), 0,
+                           s, wav, g.wav_ld, g.L0, c->conv0_w, scale, shift, cb[0], lens, pref0, cap[0]);
+    }
+    for (int i = 1; i < 7; ++i) {
+        GemmParams p{};
+        p.A = reinterpret_cast<const float*>(cb[(i - 1) % 2]);
+        p.a_plane = cap[(i - 1) % 2];
+        p.amap = g.conv_amap[i];
+        p.K = kConvK[i] * 512;
+        p.kchunk = p.K;
+        p.W = reinterpret_cast<const float*>(c->conv_wx[i]);
+        p.w_plane = 512LL * p.K;
+        p.ldw = p.K;
+        p.C = reinterpret_cast<float*>(cb[i % 2]);
+        p.c_plane = cap[i % 2];
+        p.M = (int)g.rows[i];
+        p.N = 512;
+        p.n_valid = 512;
+        p.cmap = plain_map(p.M, 512);
+        p.rmap = p.cmap;
+        p.gelu = 1;
+        if ((rc = run_gemm_bf16(c, p, 1, s, 20))) return rc;
+    }
+    bf16s_t* conv6 = cb[0];
+    bf16s_t* featln = cb[1];
+    {
+        Scope sc(c, s, NOMAD_K_ROW, 0.0);
+        hipLaunchKernelGGL((layernorm_kernel<2, bf16s_t, bf16s_t>), dim3((M + 3) / 4), dim3(256), 0, s, conv6, c->fln_w,
+                           c->fln_b, featln, static_cast<float*>(nullptr), M, cap[0], cap[1]);
+    }
+    float* xpad = F(lay.xpad);
+    const long long grp_stride = g.pad_rows * 48;
+    {
+        Scope sc(c, s, NOMAD_K_ROW, 0.0);
+        hipLaunchKernelGGL(zero_pad_rows_kernel<float>, dim3(16 * B), dim3(256), 0, s, xpad, g.T, tpref, ppref, B);
+    }
+    {
+        GemmParams p = dense_x3(featln, cap[1], 512, c->proj_wx, c->proj_b, nullptr, 0, xpad, 0, M, 768, 512, 0);
+        p.cmap = g.pad_map;
+        p.c_colblk = 48;
+        p.c_colblk_stride = grp_stride;
+        if ((rc = run_gemm_bf16(c, p, 1, s, 21))) return rc;
+    }
+    bf16s_t *x = S(lay.x), *x2 = S(lay.x2), *ctxb = S(lay.ctxb), *hb = S(lay.h);
+    float *y = F(lay.y), *qkv = F(lay.qkv);
+    {   // grouped pos-conv, fp32 kernel and weights: x + gelu(conv + bias)
+        GemmParams p{};
+        p.A = xpad;
+        p.amap = g.pos_amap;
+        p.a_goff = grp_stride;
+        p.K = 6144;
+        p.kchunk = 6144;
+        p.W = c->pos_w;
+        p.ldw = 6144;
+        p.w_goff = 64LL * 6144;
+        p.bias = c->pos_b;
+        p.bias_goff = 48;
+        p.C = y;
+        p.cmap = plain_map(M, 768);
+        p.c_goff = 48;
+        p.R = xpad;
+        p.rmap = g.pad_map;
+        p.r_goff = grp_stride;
+        p.M = M;
+        p.N = 64;
+        p.n_valid = 48;
+        p.gelu = 1;
+        if ((rc = run_gemm(c, p, 16, 48, s))) return rc;
+    }
+    auto ln = [&](const float* in, const float* gm, const float* bt, bf16s_t* out) {
+        Scope sc(c, s, NOMAD_K_ROW, 0.0);
+        hipLaunchKernelGGL((layernorm_kernel<3, float, bf16s_t>), dim3((M + 3) / 4), dim3(256), 0, s, in, gm, bt, out,
+                           static_cast<float*>(nullptr), M, 0LL, pl768);
+    };
+    ln(y, c->eln_w, c->eln_b, x);
+    for (int l = 0; l < NOMAD_NUM_LAYERS; ++l) {
+        const LayerDev& d = c->layers[l];
+        if ((rc = run_gemm_bf16(c, dense_x3(x, pl768, 768, c->qkv_wx[l], d.qkv_b, nullptr, 0, qkv, 0, M, 2304, 768, 0), 1, s, 21)))
+            return rc;
+        {
+            Scope sc(c, s, NOMAD_K_ATTN, g.attn_flops);
+            hipLaunchKernelGGL((attention_f32_kernel<float, false, bf16s_t>), dim3((g.max_t + 63) / 64, B * 12), dim3(256), 0, s,
+                               qkv, ctxb, static_cast<float*>(nullptr), g.T, tpref, DropCfg{}, 0u, 0, pl768);
+        }
+        if ((rc = run_gemm_bf16(c, dense_x3(ctxb, pl768, 768, c->o_wx[l], d.o_b, x, pl768, y, 0, M, 768, 768, 0), 1, s, 21)))
+            return rc;
+        ln(y, d.ln1_w, d.ln1_b, x2);
+        if ((rc = run_gemm_bf16(c, dense_x3(x2, pl768, 768, c->fc1_wx[l], d.fc1_b, nullptr, 0, hb, pl3072, M, 3072, 768, 1), 1, s, 20)))
+            return rc;
+        if ((rc = run_gemm_bf16(c, dense_x3(hb, pl3072, 3072, c->fc2_wx[l], d.fc2_b, x2, pl768, y, 0, M, 768, 3072, 0), 1, s, 21)))
+            return rc;
+        if (l + 1 < NOMAD_NUM_LAYERS) ln(y, d.ln2_w, d.ln2_b, x);
+        else if ((rc = run_layernorm(c, y, d.ln2_w, d.ln2_b, reinterpret_cast<float*>(x), nullptr, M, 768, s))) return rc;
+    }
+    {
+        Scope sc(c, s, NOMAD_K_ROW, 2.0 * B * 768 * 256);
+        hipLaunchKernelGGL(head_kernel<float>, dim3(B), dim3(256), 0, s, reinterpret_cast<const float*>(x), g.T, c->emb_w,
+                           c->emb_b, emb, tpref);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static int forward_x3(nomad_ctx* c, const float* wav, int B, int n_samples, float* emb, void* workspace,
+                      size_t workspace_bytes, nomad_stream_t stream) {
+    Shapes sh;
+    if (!c || !wav || !emb || !workspace || B <= 0 || !make_shapes(B, n_samples, &sh))
+        return fail(NOMAD_ERR_INVALID, "nomad_embed_bf16x3: bad argument (B=%d, n_samples=%d)", B, n_samples);
+    if (!c->x3_ready) return fail(NOMAD_ERR_INVALID, "nomad_embed_bf16x3: call nomad_enable_bf16x3 first");
+    const X3Geom g = x3_geom_fixed(sh);
+    const X3Layout lay = make_x3_layout(g);
+    if (workspace_bytes < lay.total)
+        return fail(NOMAD_ERR_WORKSPACE, "nomad_embed_bf16x3: workspace %zu < required %zu", workspace_bytes, lay.total);
+    return forward_x3_run(c, wav, g, lay, nullptr, emb, static_cast<char*>(workspace), static_cast<hipStream_t>(stream));
+}
+
+static int forward_ragged_x3(nomad_ctx* c, const float* wav, int B, int stride, const int* lens_host, float* emb,
+                             void* workspace, size_t workspace_bytes, nomad_stream_t stream) {
+    RaggedShapes rs;
+    if (!c || !wav || !lens_host || !emb || !workspace || B <= 0 || !make_ragged(B, lens_host, &rs))
+        return fail(NOMAD_ERR_INVALID, "nomad_embed_ragged_bf16x3: bad argument (B=%d)", B);
+    if (!c->x3_ready) return fail(NOMAD_ERR_INVALID, "nomad_embed_ragged_bf16x3: call nomad_enable_bf16x3 first");
+    for (int i = 0; i < B; ++i)
+        if (lens_host[i] > stride) return fail(NOMAD_ERR_INVALID, "nomad_embed_ragged_bf16x3: clip %d longer than the row stride", i);
+    const X3Layout lay = make_x3_layout(x3_geom_ragged(rs, stride, nullptr));
+    if (workspace_bytes < lay.total)
+        return fail(NOMAD_ERR_WORKSPACE, "nomad_embed_ragged_bf16x3: workspace %zu < required %zu", workspace_bytes, lay.total);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    char* ws = static_cast<char*>(workspace);
+    int* meta = reinterpret_cast<int*>(ws + lay.meta);
+    c->ragged_meta = rs.meta;  // must outlive the asynchronous copy
+    HIP_TRY(hipMemcpyAsync(meta, c->ragged_meta.data(), sizeof(int) * rs.meta.size(), hipMemcpyHostToDevice, s));
+    const X3Geom g = x3_geom_ragged(rs, stride, meta);
+    return forward_x3_run(c, wav, g, lay, meta, emb, ws, s);
 }
 
 // Ragged bf16 forward: forward_ragged with the bf16 kernels of forward_bf16 (mixed-length long-form files, config C5
@@ -1495,6 +1774,86 @@ int nomad_workspace_bytes_bf16(const nomad_ctx* c, int B, int n_samples, size_t*
 int nomad_embed_bf16(nomad_ctx* c, const float* wav, int B, int n_samples, float* emb, void* workspace,
                      size_t workspace_bytes, nomad_stream_t stream) {
     return forward_bf16(c, wav, B, n_samples, emb, workspace, workspace_bytes, stream);
+}
+
+
+int nomad_enable_bf16x3(nomad_ctx* c) {
+    if (!c) return fail(NOMAD_ERR_INVALID, "null ctx");
+    if (c->x3_ready) return 0;
+    HIP_TRY(hipSetDevice(c->device));
+    auto conv = [&](const float* src, size_t n, bf16s_t** out) -> int {
+        if (!*out) {  // re-enabling after a weight update reuses the buffers
+            void* d = nullptr;
+            HIP_TRY(hipMalloc(&d, 2 * n * sizeof(bf16_t)));
+            c->allocs.push_back(d);
+            *out = static_cast<bf16s_t*>(d);
+        }
+        hipLaunchKernelGGL(split_bf16_kernel, dim3(1024), dim3(256), 0, 0, src, *out, (long long)n, (long long)(n / 4));
+        return 0;
+    };
+    int rc;
+    for (int i = 1; i < 7; ++i)
+        if ((rc = conv(c->conv_w[i], (size_t)512 * kConvK[i] * 512, &c->conv_wx[i]))) return rc;
+    if ((rc = conv(c->proj_w, (size_t)768 * 512, &c->proj_wx))) return rc;
+    for (int l = 0; l < NOMAD_NUM_LAYERS; ++l) {
+        const LayerDev& d = c->layers[l];
+        if ((rc = conv(d.qkv_w, (size_t)2304 * 768, &c->qkv_wx[l]))) return rc;
+        if ((rc = conv(d.o_w, (size_t)768 * 768, &c->o_wx[l]))) return rc;
+        if ((rc = conv(d.fc1_w, (size_t)3072 * 768, &c->fc1_wx[l]))) return rc;
+        if ((rc = conv(d.fc2_w, (size_t)768 * 3072, &c->fc2_wx[l]))) return rc;
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    c->x3_ready = true;
+    return 0;
+}
+
+int nomad_workspace_bytes_bf16x3(const nomad_ctx* c, int B, int n_samples, size_t* bytes) {
+    Shapes sh;
+    if (!c || !bytes || B <= 0 || !make_shapes(B, n_samples, &sh))
+        return fail(NOMAD_ERR_INVALID, "nomad_workspace_bytes_bf16x3: bad shape B=%d N=%d", B, n_samples);
+    *bytes = make_x3_layout(x3_geom_fixed(sh)).total;
+    return 0;
+}
+
+int nomad_workspace_bytes_ragged_bf16x3(const nomad_ctx* c, int B, const int* lengths_host, size_t* bytes) {
+    RaggedShapes rs;
+    if (!c || !bytes || !lengths_host || B <= 0 || !make_ragged(B, lengths_host, &rs))
+        return fail(NOMAD_ERR_INVALID, "nomad_workspace_bytes_ragged_bf16x3: bad argument");
+    *bytes = make_x3_layout(x3_geom_ragged(rs, 0, nullptr)).total;
+    return 0;
+}
+
+int nomad_embed_ragged_bf16x3(nomad_ctx* c, const float* wav, int B, int stride, const int* lengths_host, float* emb,
+                              void* workspace, size_t workspace_bytes, nomad_stream_t stream) {
+    return forward_ragged_x3(c, wav, B, stride, lengths_host, emb, workspace, workspace_bytes, stream);
+}
+
+int nomad_embed_bf16x3(nomad_ctx* c, const float* wav, int B, int n_samples, float* emb, void* workspace,
+                       size_t workspace_bytes, nomad_stream_t stream) {
+    return forward_x3(c, wav, B, n_samples, emb, workspace, workspace_bytes, stream);
+}
+
+int nomad_diag_split_bf16(nomad_ctx* c, const float* in, void* out, long long plane, long long n, int inverse,
+                          nomad_stream_t stream) {
+    if (!c || !in || !out || n <= 0 || n % 4 || plane < n) return fail(NOMAD_ERR_INVALID, "nomad_diag_split_bf16: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (inverse)  // `in` is the split buffer, `out` the fp32 one
+        hipLaunchKernelGGL(unsplit_bf16_kernel, dim3(1024), dim3(256), 0, s, reinterpret_cast<const bf16s_t*>(in), plane,
+                           static_cast<float*>(out), n / 4);
+    else
+        hipLaunchKernelGGL(split_bf16_kernel, dim3(1024), dim3(256), 0, s, in, static_cast<bf16s_t*>(out), plane, n / 4);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int nomad_diag_gemm_bf16x3(nomad_ctx* c, const void* A, const void* W, const float* bias, const void* R, void* C, int M,
+                           int N, int K, int gelu, int out_f32, nomad_stream_t stream) {
+    if (!c || !A || !W || !C || M <= 0 || N % 256 || K % 128)
+        return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16x3: bad argument (N %% 256, K %% 128)");
+    GemmParams p = dense_x3(static_cast<const bf16s_t*>(A), (long long)M * K, K, static_cast<const bf16s_t*>(W), bias,
+                            static_cast<const bf16s_t*>(R), (long long)M * N, C, (long long)M * N, M, N, K, gelu);
+    return run_gemm_bf16(c, p, 1, static_cast<hipStream_t>(stream), out_f32 ? 21 : 20);
 }
 
 int nomad_workspace_bytes_ragged_bf16(const nomad_ctx* c, int B, const int* lengths_host, size_t* bytes) {
@@ -2053,6 +2412,7 @@ int refresh_weights(nomad_ctx* c, hipStream_t s) {
     }
     HIP_TRY(hipGetLastError());
     c->bf16_ready = false;  // the bf16 copies (if any) are stale now; nomad_enable_bf16 rebuilds them
+    c->x3_ready = false;    // likewise the split copies (nomad_enable_bf16x3)
     return 0;
 }
 

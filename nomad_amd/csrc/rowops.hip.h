@@ -25,7 +25,8 @@ __device__ __forceinline__ double wave_sum(double v) {
 template <int VPT, typename TIn = float, typename TOut = float>
 __global__ __launch_bounds__(256) void layernorm_kernel(const TIn* __restrict__ in, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, TOut* __restrict__ out,
-                                                        float* __restrict__ out2, int M) {
+                                                        float* __restrict__ out2, int M, long long in_plane = 0,
+                                                        long long out_plane = 0) {
     constexpr int N = 256 * VPT;
     const int lane = threadIdx.x & 63;
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -35,7 +36,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TIn* __restrict__ 
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
-        v[i] = load4<TIn>(row + 4 * (lane + 64 * i));
+        v[i] = load4p<TIn>(row + 4 * (lane + 64 * i), in_plane);
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
     const float mean = wave_sum(s) * (1.0f / N);
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TIn* __restrict__ 
         r.y = (v[i].y - mean) * rstd * g.y + bb.y;
         r.z = (v[i].z - mean) * rstd * g.z + bb.z;
         r.w = (v[i].w - mean) * rstd * g.w + bb.w;
-        store4<TOut>(o + 4 * (lane + 64 * i), r);
+        store4p<TOut>(o + 4 * (lane + 64 * i), out_plane, r);
         if (o2) o2[lane + 64 * i] = r;
     }
 }

@@ -139,13 +139,18 @@ class Engine:
                                         ws.data_ptr(), ws.numel(), self._stream()), "nomad_embed")
         return (emb, layers) if want_layers else emb
 
-    def embed_ragged(self, waves, head: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, bf16: bool = False) -> torch.Tensor:
+    def embed_ragged(self, waves, head: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, bf16: bool = False,
+                     precision: Optional[str] = None) -> torch.Tensor:
         """Embed clips of different lengths in ONE launch sequence (no padding in the arithmetic).
 
         waves: list of 1-D (or (1,N)) fp32 tensors / numpy arrays (host or device).  Returns (B,256) fp32 on the
-        GPU, bit-identical to embedding every clip on its own.  bf16=True: the bf16 path (no head override)."""
-        if bf16 and head is not None:
-            raise ValueError("the bf16 path has no head override")
+        GPU, bit-identical to embedding every clip on its own.  precision: "fp32" (default), "bf16x3" (fp32-class
+        scores from split bf16 operands) or "bf16" (also bf16=True); the last two take no head override."""
+        precision = precision or ("bf16" if bf16 else "fp32")
+        if precision not in ("fp32", "bf16", "bf16x3"):
+            raise ValueError("precision must be 'fp32', 'bf16x3' or 'bf16'")
+        if precision != "fp32" and head is not None:
+            raise ValueError(f"the {precision} path has no head override")
         flat = [torch.as_tensor(w, dtype=torch.float32).reshape(-1) for w in waves]
         lens = [int(w.numel()) for w in flat]
         B, stride = len(flat), max(lens)
@@ -165,12 +170,15 @@ class Engine:
         arr = (C.c_int * B)(*lens)
         nb = C.c_size_t()
         emb = torch.empty(B, 256, dtype=torch.float32, device=self.device)
-        if bf16:
-            _lib.check(self.lib.nomad_enable_bf16(self.ctx), "nomad_enable_bf16")
-            _lib.check(self.lib.nomad_workspace_bytes_ragged_bf16(self.ctx, B, arr, C.byref(nb)), "nomad_workspace_bytes_ragged_bf16")
+        if precision != "fp32":
+            enable, size, run = ((self.lib.nomad_enable_bf16, self.lib.nomad_workspace_bytes_ragged_bf16, self.lib.nomad_embed_ragged_bf16)
+                                 if precision == "bf16" else
+                                 (self.lib.nomad_enable_bf16x3, self.lib.nomad_workspace_bytes_ragged_bf16x3, self.lib.nomad_embed_ragged_bf16x3))
+            _lib.check(enable(self.ctx), f"nomad_enable_{precision}")
+            _lib.check(size(self.ctx, B, arr, C.byref(nb)), f"nomad_workspace_bytes_ragged_{precision}")
             ws = self._workspace(nb.value)
-            _lib.check(self.lib.nomad_embed_ragged_bf16(self.ctx, buf.data_ptr(), B, stride, arr, emb.data_ptr(), ws.data_ptr(),
-                                                        ws.numel(), self._stream()), "nomad_embed_ragged_bf16")
+            _lib.check(run(self.ctx, buf.data_ptr(), B, stride, arr, emb.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()),
+                       f"nomad_embed_ragged_{precision}")
             return emb
         _lib.check(self.lib.nomad_workspace_bytes_ragged(self.ctx, B, arr, C.byref(nb)), "nomad_workspace_bytes_ragged")
         ws = self._workspace(nb.value)
@@ -221,6 +229,47 @@ class Engine:
         _lib.check(self.lib.nomad_embed_bf16(self.ctx, wav.data_ptr(), B, N, emb.data_ptr(), ws.data_ptr(), ws.numel(),
                                              self._stream()), "nomad_embed_bf16")
         return emb
+
+    # ---- bf16x3 path: fp32-class scores on the bf16 matrix cores ---------------------------------------
+    def embed_bf16x3(self, wav: torch.Tensor) -> torch.Tensor:
+        """Scoring forward whose GEMMs run as three bf16 MFMA products over hi/lo-split operands (fp32 accumulation,
+        fp32 attention / LayerNorm / head): NOMAD scores agree with the fp32 path to ~1e-6."""
+        if wav.dim() == 3:
+            wav = wav.squeeze(1)
+        self._check_dev(wav, "wav")
+        B, N = wav.shape
+        _lib.check(self.lib.nomad_enable_bf16x3(self.ctx), "nomad_enable_bf16x3")
+        ws = self._workspace(self._size(self.lib.nomad_workspace_bytes_bf16x3, B, N, "nomad_workspace_bytes_bf16x3"))
+        emb = torch.empty(B, 256, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.nomad_embed_bf16x3(self.ctx, wav.data_ptr(), B, N, emb.data_ptr(), ws.data_ptr(), ws.numel(),
+                                               self._stream()), "nomad_embed_bf16x3")
+        return emb
+
+    def diag_split_bf16(self, x: torch.Tensor) -> torch.Tensor:
+        """fp32 tensor -> split buffer (bf16 tensor of shape (2, *x.shape): plane 0 = hi, plane 1 = lo)."""
+        x = x.contiguous()
+        out = torch.empty((2,) + tuple(x.shape), dtype=torch.bfloat16, device=self.device)
+        _lib.check(self.lib.nomad_diag_split_bf16(self.ctx, x.data_ptr(), out.data_ptr(), x.numel(), x.numel(), 0,
+                                                  self._stream()), "nomad_diag_split_bf16")
+        return out
+
+    def diag_unsplit_bf16(self, xs: torch.Tensor) -> torch.Tensor:
+        out = torch.empty(tuple(xs.shape[1:]), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.nomad_diag_split_bf16(self.ctx, xs.data_ptr(), out.data_ptr(), out.numel(), out.numel(), 1,
+                                                  self._stream()), "nomad_diag_split_bf16")
+        return out
+
+    def diag_gemm_bf16x3(self, A, W, bias=None, R=None, gelu=False, out_f32=True):
+        """A (2,M,K), W (2,N,K), R (2,M,N) split buffers (diag_split_bf16); returns fp32 (M,N) or a split (2,M,N)."""
+        _, M, K = A.shape
+        N = W.shape[1]
+        out = (torch.zeros(M, N, dtype=torch.float32, device=self.device) if out_f32
+               else torch.zeros(2, M, N, dtype=torch.bfloat16, device=self.device))
+        _lib.check(self.lib.nomad_diag_gemm_bf16x3(self.ctx, A.data_ptr(), W.data_ptr(),
+                                                   bias.data_ptr() if bias is not None else None,
+                                                   R.data_ptr() if R is not None else None, out.data_ptr(),
+                                                   M, N, K, int(gelu), int(out_f32), self._stream()), "nomad_diag_gemm_bf16x3")
+        return out
 
     def diag_attention_bf16(self, qkv, B, T):
         out = torch.empty(B * T, 768, dtype=torch.bfloat16, device=self.device)

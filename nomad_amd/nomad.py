@@ -162,11 +162,14 @@ class _NomadLossFn(torch.autograd.Function):
 
 class Nomad:
     def __init__(self, device=None, weights: Union[None, str, Dict[str, torch.Tensor]] = None, precision: str = "fp32"):
-        """precision: "fp32" (the reference's arithmetic, scores within 1e-4) or "bf16" for the embeddings of
-        ``predict`` / ``get_embeddings*`` (bf16 storage, fp32 accumulation: scores within ~5e-4 of fp32, several times
-        faster on long recordings).  ``forward()`` (the training loss) is always fp32."""
-        if precision not in ("fp32", "bf16"):
-            raise ValueError("precision must be 'fp32' or 'bf16'")
+        """precision of the embeddings of ``predict`` / ``get_embeddings*``:
+        "fp32"   the reference's arithmetic (fp32 MFMA), scores within 1e-4 of the reference;
+        "bf16x3" GEMM operands split into hi + lo bf16 planes, three bf16 MFMA products per fp32 product, fp32
+                 accumulation / attention / norms: scores within ~1e-6 of the fp32 path, more than twice as fast;
+        "bf16"   bf16 storage, fp32 accumulation: scores within ~5e-4 of fp32, fastest on long recordings.
+        ``forward()`` (the training loss) is always fp32."""
+        if precision not in ("fp32", "bf16x3", "bf16"):
+            raise ValueError("precision must be 'fp32', 'bf16x3' or 'bf16'")
         self.precision = precision
         dev_index = _resolve_device(device)
         self.DEVICE = f"cuda:{dev_index}"
@@ -292,7 +295,7 @@ class Nomad:
         if batch:
             batches.append(batch)
         for idxs in batches:
-            emb = self.engine.embed_ragged([waves[i][0] for i in idxs], bf16=self.precision == "bf16")
+            emb = self.engine.embed_ragged([waves[i][0] for i in idxs], precision=self.precision)
             embeddings[idxs] = emb.cpu().numpy()
         emb_df = pd.DataFrame(embeddings)
         df_emb = pd.concat([file_names.reset_index(), emb_df], axis=1).drop("index", axis=1)

@@ -1,0 +1,171 @@
+"""GPU: the bf16x3 path - fp32-class results from the bf16 matrix cores.  GEMM operands are split into hi / lo bf16
+planes and multiplied as hi*hi + hi*lo + lo*hi with fp32 accumulation (gemm_bf16_8phase.hip.h, X3).  Checked against
+float64 references and this library's fp32 path; the bar is the north star's score tolerance (1e-4) with a wide margin."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def test_split_round_trip(engine):
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1000, 768, generator=g) * torch.logspace(-6, 6, 768)
+    xs = engine.diag_split_bf16(x.cuda())
+    hi, lo = xs[0].float().cpu(), xs[1].float().cpu()
+    assert torch.equal(hi, x.bfloat16().float())                       # hi = RNE bf16 of x
+    assert torch.equal(lo, (x - hi).bfloat16().float())                # lo = RNE bf16 of the remainder
+    back = engine.diag_unsplit_bf16(xs).cpu()
+    assert ((back - x).abs() <= x.abs() * 2.0 ** -16).all()            # 16+ significant bits survive
+    assert torch.equal(back, hi + lo)
+
+
+@pytest.mark.parametrize("M", [1, 200, 257, 1000])
+def test_gemm_bf16x3_exact_on_16_bit_integers(engine, M):
+    """Operands that hi + lo represents exactly (|a| < 2^16) whose lo*lo terms vanish (one operand has lo = 0):
+    the three products reproduce the exact integer result as long as it fits fp32."""
+    N, K = 512, 256
+    g = torch.Generator().manual_seed(M)
+    A = torch.randint(-40000, 40000, (M, K), generator=g).float()       # needs hi and lo
+    W = torch.randint(-3, 4, (N, K), generator=g).float()               # lo plane is zero
+    W[:, ::7] = 1.0
+    ref = A.double() @ W.double().T
+    assert ref.abs().max() < 2 ** 24
+    out = engine.diag_gemm_bf16x3(engine.diag_split_bf16(A.cuda()), engine.diag_split_bf16(W.cuda())).cpu()
+    assert torch.equal(out.double(), ref)
+    # and with the roles swapped: the lo plane on the W side
+    A2 = torch.randint(-3, 4, (M, K), generator=g).float()
+    W2 = torch.randint(-40000, 40000, (N, K), generator=g).float()
+    out2 = engine.diag_gemm_bf16x3(engine.diag_split_bf16(A2.cuda()), engine.diag_split_bf16(W2.cuda())).cpu()
+    assert torch.equal(out2.double(), A2.double() @ W2.double().T)
+
+
+@pytest.mark.parametrize("M,N,K", [(777, 768, 3072), (1500, 512, 1536), (300, 2304, 768), (4113, 256, 128), (600, 3072, 768)])
+@pytest.mark.parametrize("epi", ["none", "bias_gelu", "bias_res"])
+@pytest.mark.parametrize("out_f32", [True, False])
+def test_gemm_bf16x3_vs_float64(engine, M, N, K, epi, out_f32):
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) * K ** -0.5
+    bias = torch.randn(N, generator=g) if "bias" in epi else None
+    R = torch.randn(M, N, generator=g) if "res" in epi else None
+    ref = A.double() @ W.double().T
+    if bias is not None:
+        ref = ref + bias.double()
+    if "gelu" in epi:
+        ref = F.gelu(ref)
+    if R is not None:
+        ref = ref + R.double()
+    out = engine.diag_gemm_bf16x3(engine.diag_split_bf16(A.cuda()), engine.diag_split_bf16(W.cuda()),
+                                  bias.cuda() if bias is not None else None,
+                                  engine.diag_split_bf16(R.cuda()) if R is not None else None, gelu="gelu" in epi,
+                                  out_f32=out_f32)
+    if not out_f32:
+        out = engine.diag_unsplit_bf16(out)
+    err = (out.cpu().double() - ref).abs().max().item()
+    f32 = (A.cuda() @ W.cuda().T).cpu().double()
+    if epi == "none":
+        print(f"bf16x3 {M}x{N}x{K}: max|err| {err:.2e}  (torch fp32 matmul: {(f32 - (A.double() @ W.double().T)).abs().max().item():.2e})")
+    # per product 2^-16 relative (dropped lo*lo + two 2^-17 operand roundings), random signs over K, |a||w| ~ K^-1/2;
+    # measured ~3e-6 at unit-scale outputs; a plain bf16 GEMM is ~1e-2 here
+    assert err < 3e-5 * max(1.0, ref.abs().max().item()), err
+
+
+def test_embed_bf16x3_vs_fp32_path(engine):
+    gen = torch.Generator().manual_seed(0)
+    wav = (0.1 * torch.randn(8, 64000, generator=gen)).clamp(-1, 1).cuda()
+    e32 = engine.embed(wav)
+    ex3 = engine.embed_bf16x3(wav)
+    torch.cuda.synchronize()
+    assert torch.isfinite(ex3).all()
+    assert (ex3.norm(dim=1) - 1).abs().max().item() < 1e-5
+    err = (ex3 - e32).abs().max().item()
+    d32, m32 = engine.pairwise(e32[:6].contiguous(), e32[6:].contiguous())
+    dx3, mx3 = engine.pairwise(ex3[:6].contiguous(), ex3[6:].contiguous())
+    serr = (dx3 - d32).abs().max().item()
+    print(f"bf16x3 vs fp32: embedding max|err| {err:.3e}, score max|err| {serr:.3e}")
+    assert err < 1e-5 and serr < 2e-5          # the north star's score tolerance is 1e-4
+
+
+def test_embed_bf16x3_vs_oracle_scores(engine, sd0):
+    """Against the CPU oracle (fp32 torch + float64 distances): inside the 1e-4 score tolerance like the fp32 path."""
+    from oracle import nomad_oracle as O
+    gen = torch.Generator().manual_seed(3)
+    wav = (0.1 * torch.randn(5, 16000, generator=gen)).clamp(-1, 1)
+    ref = O.triplet_forward(sd0, wav)
+    ex3 = engine.embed_bf16x3(wav.cuda()).cpu()
+    assert (ex3 - ref).abs().max().item() < 2e-5
+    d_ref, m_ref = O.pairwise(ref[:3].numpy(), ref[3:].numpy())
+    d, m = O.pairwise(ex3[:3].numpy(), ex3[3:].numpy())
+    assert abs(d - d_ref).max() < 1e-4 / 4
+
+
+def test_embed_bf16x3_batch_invariance_and_repeat(engine):
+    gen = torch.Generator().manual_seed(4)
+    wav = (0.1 * torch.randn(6, 40000, generator=gen)).clamp(-1, 1).cuda()
+    a = engine.embed_bf16x3(wav)
+    b = engine.embed_bf16x3(wav)
+    assert torch.equal(a, b)
+    one = engine.embed_bf16x3(wav[2:3].contiguous())
+    assert torch.equal(one[0], a[2])
+
+
+def test_embed_bf16x3_peaky_weights(engine_peaky):
+    """Weights with large attention logits and activation outliers (the conftest 'peaky' model)."""
+    gen = torch.Generator().manual_seed(6)
+    wav = (0.3 * torch.randn(4, 32000, generator=gen)).clamp(-1, 1).cuda()
+    e32 = engine_peaky.embed(wav)
+    ex3 = engine_peaky.embed_bf16x3(wav)
+    err = (ex3 - e32).abs().max().item()
+    print(f"bf16x3 vs fp32 (peaky): embedding max|err| {err:.3e}")
+    assert err < 5e-5
+
+
+def test_ragged_bf16x3_bit_identical_to_single_clips(engine):
+    """nomad_embed_ragged_bf16x3: clips of different lengths in one launch sequence, each bit-equal to its own
+    nomad_embed_bf16x3 call and within 1e-5 of the fp32 ragged path."""
+    g = torch.Generator().manual_seed(21)
+    lens = [16384, 400, 27225, 9001, 64000, 30267, 5000, 12345, 48000]
+    waves = [(0.1 * torch.randn(n, generator=g)).clamp(-1, 1) for n in lens]
+    rag = engine.embed_ragged(waves, precision="bf16x3")
+    for i, w in enumerate(waves):
+        single = engine.embed_bf16x3(w[None, :].cuda())
+        assert torch.equal(rag[i], single[0]), (i, lens[i])
+    f32 = engine.embed_ragged(waves)
+    assert (rag - f32).abs().max().item() < 1e-5
+    with pytest.raises(ValueError):
+        engine.embed_ragged(waves, head=(torch.zeros(256, 768).cuda(), torch.zeros(256).cuda()), precision="bf16x3")
+    with pytest.raises(ValueError):
+        engine.embed_ragged(waves, precision="fp16")
+
+
+def test_predict_in_bf16x3_precision(built_lib):
+    """Nomad(precision='bf16x3').predict on the reference's example files: the 3-decimal tables the reference prints and
+    saves (nomad.py:115-117) come out identical to the fp32 run's, the raw scores agree to 1e-5."""
+    import os
+    import tempfile
+    from conftest import GOLD
+    from nomad_amd.nomad import Nomad
+    nmr, deg = os.path.join(GOLD, "wavs", "nmr-data"), os.path.join(GOLD, "wavs", "test-data")
+    with tempfile.TemporaryDirectory() as d:
+        a32, m32 = Nomad(weights="seeded").predict("dir", nmr, deg, results_path=d)
+        ax3, mx3 = Nomad(weights="seeded", precision="bf16x3").predict("dir", nmr, deg, results_path=d)
+    assert list(mx3.columns) == list(m32.columns) and list(mx3.index) == list(m32.index)
+    assert abs(mx3.values - m32.values).max() <= 1e-3 + 1e-9          # at most one unit of the 3rd decimal (rounding edge)
+    assert abs(ax3.values[:, -1].astype(float) - a32.values[:, -1].astype(float)).max() <= 1e-3 + 1e-9
+
+
+def test_bf16x3_follows_weight_updates(built_lib, sd0):
+    """The split weight copies are rebuilt after the master weights change (fine-tuning, nomad_train_write)."""
+    from nomad_amd.engine import Engine
+    eng = Engine(sd0, 0)
+    gen = torch.Generator().manual_seed(8)
+    wav = (0.1 * torch.randn(2, 20000, generator=gen)).cuda()
+    before = eng.embed_bf16x3(wav).clone()
+    eng.train_enable()
+    theta = eng.train_read()
+    eng.train_write(0, theta * 1.01)
+    after = eng.embed_bf16x3(wav)
+    ref = eng.embed(wav)
+    assert not torch.equal(before, after)
+    assert (after - ref).abs().max().item() < 1e-5

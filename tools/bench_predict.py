@@ -19,6 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--deg", type=int, default=512)
     ap.add_argument("--ref", type=int, default=64)
+    ap.add_argument("--precision", default="fp32", choices=("fp32", "bf16x3", "bf16"))
     a = ap.parse_args()
     from nomad_amd.nomad import Nomad
     rng = np.random.RandomState(0)
@@ -30,7 +31,7 @@ def main():
                 length = int(rng.uniform(1.0, 8.0) * 16000)
                 secs += length / 16000
                 write_wav(f"{d}/{sub}/f{i:05d}.wav", 0.1 * rng.randn(length))
-        nmd = Nomad(weights="seeded")
+        nmd = Nomad(weights="seeded", precision=a.precision)
         nmd.predict("dir", d + "/nmr", d + "/deg", results_path=d + "/out0")  # warm-up (first-touch, allocator)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -47,11 +48,11 @@ def main():
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         for i in range(0, len(dev), 256):
-            nmd.engine.embed_ragged(dev[i:i + 256])
+            nmd.engine.embed_ragged(dev[i:i + 256], precision=a.precision)
         torch.cuda.synchronize()
         t_emb = time.perf_counter() - t2
     n = a.deg + a.ref
-    print(json.dumps({"files": n, "audio_s": round(secs, 1), "predict_s": round(dt, 3), "files_per_s": round(n / dt, 1),
+    print(json.dumps({"precision": a.precision, "files": n, "audio_s": round(secs, 1), "predict_s": round(dt, 3), "files_per_s": round(n / dt, 1),
                       "audio_s_per_s": round(secs / dt, 1), "decode_only_s": round(t_dec, 3), "embed_only_s": round(t_emb, 3),
                       "score_shape": list(mat.shape)}))
 

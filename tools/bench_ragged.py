@@ -27,6 +27,10 @@ def per_file():
     return torch.cat([eng.embed(w[None, :]) for w in waves])
 
 
+def ragged_x3():
+    return eng.embed_ragged(waves, precision="bf16x3")
+
+
 out = {"workload": f"{n_clips} clips, uniform random lengths 1-8 s ({sum(lens) / 16000:.0f} s of audio)"}
 ref = None
 for name, fn in (("ragged_batch", ragged), ("per_file_loop", per_file)):
@@ -42,6 +46,16 @@ for name, fn in (("ragged_batch", ragged), ("per_file_loop", per_file)):
         ref = r
     else:
         out["bit_identical"] = bool(torch.equal(ref, r))
+fn = ragged_x3
+r = fn()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(3):
+    r = fn()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 3
+out["ragged_batch_bf16x3"] = {"clips_per_s": round(n_clips / dt, 1), "audio_s_per_s": round(sum(lens) / 16000 / dt, 1),
+                              "max_abs_err_vs_fp32": float((r - ref).abs().max())}
 print(json.dumps(out))
 
 # long recordings of mixed lengths (config C5 through predict): fp32 vs bf16 ragged batches
@@ -49,7 +63,7 @@ n_long = 48
 lens = torch.randint(10 * 16000, 40 * 16000, (n_long,), generator=g).tolist()   # 10 s .. 40 s
 waves = [(0.1 * torch.randn(n, generator=g)).clamp(-1, 1).cuda() for n in lens]
 out = {"workload": f"{n_long} recordings, uniform random lengths 10-40 s ({sum(lens) / 16000:.0f} s of audio)"}
-for name, kw in (("ragged_fp32", {}), ("ragged_bf16", {"bf16": True})):
+for name, kw in (("ragged_fp32", {}), ("ragged_bf16x3", {"precision": "bf16x3"}), ("ragged_bf16", {"bf16": True})):
     eng.embed_ragged(waves, **kw)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
