@@ -38,7 +38,8 @@ struct P8Cfg {
     static constexpr int ELD = 64 + 4;                      // epilogue slab row (floats)
 };
 
-// ABL: 1 = no epilogue stores (timing only); 2 = no s_setprio around the MFMA clusters (A/B, same results).
+// ABL: 1 = no epilogue stores (timing only); 2 = no s_setprio around the MFMA clusters (A/B, same results);
+//      3 = X3 timing probe: every third K tile keeps the previous tile's A fragments (skips its A reads from LDS).
 // BUFLD: LDS-DMA through buffer descriptors (dma16_buffer) instead of global_load_lds - an A/B switch, measured below.
 // X3 ("bf16x3", fp32-class results on the bf16 matrix cores): A, W and R are SPLIT buffers (dtypes.hip.h: hi and lo
 //   bf16 planes p.a_plane / p.w_plane / p.r_plane elements apart) and the K loop walks 3 K/64 tiles - tile 3 kk + s
@@ -184,14 +185,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
             bf[j][0] = *reinterpret_cast<const bf16x8*>(lb_ + j * 2048 + koff0);                           \
             bf[j][1] = *reinterpret_cast<const bf16x8*>(lb_ + j * 2048 + koff1);                           \
         }                                                                                                  \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                    \
+        if (!(ABL == 3 && (KT) % 3 == 1)) _Pragma("unroll") for (int i = 0; i < 4; ++i) {                  \
             af[i][0] = *reinterpret_cast<const bf16x8*>(la_ + i * 2048 + koff0);                           \
             af[i][1] = *reinterpret_cast<const bf16x8*>(la_ + i * 2048 + koff1);                           \
         }                                                                                                  \
         if ((KT) + 1 < nk) NOMAD_P8_DMA_B((KT) + 1, 0)                                                     \
         NOMAD_P8_SYNC_COMPUTE(0, 0)                                                                        \
         /* phase 2: A rows 64..127 */                                                                      \
-        _Pragma("unroll") for (int i = 4; i < 8; ++i) {                                                    \
+        if (!(ABL == 3 && (KT) % 3 == 1)) _Pragma("unroll") for (int i = 4; i < 8; ++i) {                  \
             af[i][0] = *reinterpret_cast<const bf16x8*>(la_ + i * 2048 + koff0);                           \
             af[i][1] = *reinterpret_cast<const bf16x8*>(la_ + i * 2048 + koff1);                           \
         }                                                                                                  \

@@ -1121,6 +1121,9 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
             if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16x3 gemm: N %% 256, K %% 128");
             e = tile == 20 ? launch_gemm_bf16_8phase<0, false, 1>(p, groups, s) : launch_gemm_bf16_8phase<0, false, 2>(p, groups, s);
             break;
+        case 22:  // bf16x3 timing probe (ABL 3), fp32 output
+            e = launch_gemm_bf16_8phase<3, false, 2>(p, groups, s);
+            break;
         case 19:  // A/B: 8-phase kernel without s_setprio
             if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
             e = launch_gemm_bf16_8phase<2>(p, groups, s);
@@ -1853,7 +1856,7 @@ int nomad_diag_gemm_bf16x3(nomad_ctx* c, const void* A, const void* W, const flo
         return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16x3: bad argument (N %% 256, K %% 128)");
     GemmParams p = dense_x3(static_cast<const bf16s_t*>(A), (long long)M * K, K, static_cast<const bf16s_t*>(W), bias,
                             static_cast<const bf16s_t*>(R), (long long)M * N, C, (long long)M * N, M, N, K, gelu);
-    return run_gemm_bf16(c, p, 1, static_cast<hipStream_t>(stream), out_f32 ? 21 : 20);
+    return run_gemm_bf16(c, p, 1, static_cast<hipStream_t>(stream), 20 + (out_f32 < 0 ? 0 : out_f32 > 2 ? 2 : out_f32));
 }
 
 int nomad_workspace_bytes_ragged_bf16(const nomad_ctx* c, int B, const int* lengths_host, size_t* bytes) {

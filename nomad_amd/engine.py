@@ -259,12 +259,13 @@ class Engine:
                                                   self._stream()), "nomad_diag_split_bf16")
         return out
 
-    def diag_gemm_bf16x3(self, A, W, bias=None, R=None, gelu=False, out_f32=True):
+    def diag_gemm_bf16x3(self, A, W, bias=None, R=None, gelu=False, out_f32=True, out=None):
         """A (2,M,K), W (2,N,K), R (2,M,N) split buffers (diag_split_bf16); returns fp32 (M,N) or a split (2,M,N)."""
         _, M, K = A.shape
         N = W.shape[1]
-        out = (torch.zeros(M, N, dtype=torch.float32, device=self.device) if out_f32
-               else torch.zeros(2, M, N, dtype=torch.bfloat16, device=self.device))
+        if out is None:
+            out = (torch.zeros(M, N, dtype=torch.float32, device=self.device) if out_f32
+                   else torch.zeros(2, M, N, dtype=torch.bfloat16, device=self.device))
         _lib.check(self.lib.nomad_diag_gemm_bf16x3(self.ctx, A.data_ptr(), W.data_ptr(),
                                                    bias.data_ptr() if bias is not None else None,
                                                    R.data_ptr() if R is not None else None, out.data_ptr(),
