@@ -9,9 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnomad_hip.so")
 SOURCES = ["nomad_hip.hip"]
-HEADERS = ["gemm_f32.hip.h", "gemm_bf16.hip.h", "dtypes.hip.h", "backward.hip.h", "frontend.hip.h", "rowops.hip.h",
-           "attention.hip.h", "pairwise.hip.h",
-           os.path.join("..", "..", "include", "nomad_hip.h")]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip.h")) + [os.path.join("..", "..", "include", "nomad_hip.h")]
 
 
 def hipcc_path() -> str:

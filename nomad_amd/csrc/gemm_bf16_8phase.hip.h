@@ -38,195 +38,14 @@ struct P8Cfg {
     static constexpr int ELD = 64 + 4;                      // epilogue slab row (floats)
 };
 
-// ABL: 1 = no epilogue stores (timing only); 2 = no s_setprio around the MFMA clusters (A/B, same results);
-//      3 = X3 timing probe: every third K tile keeps the previous tile's A fragments (skips its A reads from LDS).
-// BUFLD: LDS-DMA through buffer descriptors (dma16_buffer) instead of global_load_lds - an A/B switch, measured below.
-// X3 ("bf16x3", fp32-class results on the bf16 matrix cores): A, W and R are SPLIT buffers (dtypes.hip.h: hi and lo
-//   bf16 planes p.a_plane / p.w_plane / p.r_plane elements apart) and the K loop walks 3 K/64 tiles - tile 3 kk + s
-//   multiplies k-range kk of (A_hi, W_hi), (A_hi, W_lo), (A_lo, W_hi) for s = 0, 1, 2 - into the same fp32
-//   accumulators: a.w = (ah + al)(wh + wl) minus the al*wl term (2^-16 relative), i.e. the plain kernel run on
-//   operands concatenated along K, with no other change to the schedule.  X3 = 1 stores the result split
-//   (p.c_plane), X3 = 2 stores fp32.
-template <int ABL = 0, bool BUFLD = false, int X3 = 0>
-__global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams p) {
+// Epilogue shared by the 256 x 256 kernels (8 waves as 2 x 4, wave tile 128 x 64 = acc[8][4], accumulator: column fr,
+// rows 4 fq + r of each 16 x 16 tile): 32-row fp32 slabs through LDS, bias / GELU / residual in fp32, 16-byte stores.
+// OUT: 0 = bf16, 1 = split planes (p.c_plane; R split too), 2 = fp32 (R split).  NOSTORE: timing ablation.
+template <bool NOSTORE, int X3>
+__device__ __forceinline__ void p8_epilogue(const GemmParams& p, const f32x4 (&acc)[8][4], char* smem8, int grp, int m0, int n0,
+                                            int wave, int wr, int wc, int lane, int fr, int fq) {
     using Cfg = P8Cfg;
-    extern __shared__ __attribute__((aligned(16))) char smem8[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-    const int fr = lane & 15, fq = lane >> 4;
-    const int nwg = p.tiles_m * p.tiles_n;
-    const int wg = xcd_remap(blockIdx.x, nwg);
-    int tile_m, tile_n;
-    tile_coords(wg, p.tiles_m, p.tiles_n, p.group_m, tile_m, tile_n);
-    const int m0 = tile_m * Cfg::BM, n0 = tile_n * Cfg::BN;
-    const int grp = blockIdx.y;
-    const bf16_t* Ag = reinterpret_cast<const bf16_t*>(p.A) + grp * p.a_goff;
-    const bf16_t* Wg = reinterpret_cast<const bf16_t*>(p.W) + grp * p.w_goff;
-
-    // DMA sources as (uniform 64-bit base) + (per-thread 32-bit byte offset): one VGPR per address instead of two, so
-    // that the whole working set stays inside the 256 registers a wave has at 2 waves/SIMD - a spilled address
-    // would come back through a scratch load whose s_waitcnt drains the whole DMA queue.
-    // Instruction i of a half-tile covers rows (tid + 512 i) / 8, physical chunk (tid + 512 i) % 8.
-    // The 32-bit offsets are relative to the tile's FIRST row (row addresses grow with the row index, a 256-row tile
-    // spans far less than 4 GB); the tensor itself may be larger than 4 GB (conv1 input at batch 512: 6.7 GB).
-    const long long tile_row0 = row_addr(p.amap, m0 < p.M ? m0 : p.M - 1);  // wave-uniform
-    unsigned a_off[2][2], b_off[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int id = tid + i * 512, row = id >> 3, pc = id & 7;
-        const int sw = (pc ^ ((row >> 1) & 7)) * 8;
-        b_off[i] = (unsigned)(((long long)row * p.ldw + sw) * 2);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            int m = m0 + h * 128 + row;
-            m = m < p.M ? m : p.M - 1;
-            a_off[h][i] = (unsigned)((row_addr(p.amap, m) - tile_row0 + sw) * 2);
-        }
-    }
-    const char* const a_base = reinterpret_cast<const char*>(Ag + tile_row0);
-    const char* const b_base[2] = {reinterpret_cast<const char*>(Wg + (long long)n0 * p.ldw),
-                                   reinterpret_cast<const char*>(Wg + (long long)(n0 + 128) * p.ldw)};
-    // lo planes (X3): wave-uniform bases, selected per K tile by scalar code
-    const char* const a_base_lo = a_base + (X3 ? p.a_plane * 2 : 0);
-    const char* const b_base_lo[2] = {b_base[0] + (X3 ? p.w_plane * 2 : 0), b_base[1] + (X3 ? p.w_plane * 2 : 0)};
-    char* const dma_dst = smem8 + wave * 1024;  // + lane * 16 implicit (lane-linear LDS-DMA destination)
-
-    // LDS-DMA through buffer descriptors (dma16_buffer, gemm_f32.hip.h): wave-uniform base in SGPRs, one 32-bit VGPR
-    // per lane, the K-tile term as the scalar offset - no 64-bit VGPR pointers for the compiler to hoist or spill.
-#define NOMAD_P8_DMA_A(KT, H)                                                                                   \
-    {                                                                                                           \
-        int kt_ = (KT);                                                                                         \
-        const char* ab_ = a_base;                                                                               \
-        if (X3) {                                                                                               \
-            const int kk_ = kt_ / 3;                                                                            \
-            if (kt_ - 3 * kk_ == 2) ab_ = a_base_lo;                                                            \
-            kt_ = kk_;                                                                                          \
-        }                                                                                                       \
-        const int k0_ = kt_ * 64;                                                                               \
-        const int kq_ = k0_ / p.kchunk;                                                                         \
-        const unsigned ko_ = (unsigned)((kq_ * p.kstride + (k0_ - kq_ * p.kchunk)) * 2);                        \
-        char* d_ = dma_dst + ((KT)&1) * Cfg::BUF_BYTES + (H)*Cfg::HALF_BYTES;                                   \
-        if (BUFLD) {                                                                                            \
-            dma16_buffer(reinterpret_cast<const float*>(ab_), (lptr_t)(d_), (int)a_off[H][0], (int)ko_);          \
-            dma16_buffer(reinterpret_cast<const float*>(ab_), (lptr_t)(d_ + 8192), (int)a_off[H][1], (int)ko_);   \
-        } else {                                                                                                \
-            __builtin_amdgcn_global_load_lds((gptr_t)(ab_ + (a_off[H][0] + ko_)), (lptr_t)(d_), 16, 0, 0);         \
-            __builtin_amdgcn_global_load_lds((gptr_t)(ab_ + (a_off[H][1] + ko_)), (lptr_t)(d_ + 8192), 16, 0, 0);  \
-        }                                                                                                       \
-    }
-#define NOMAD_P8_DMA_B(KT, H)                                                                                   \
-    {                                                                                                           \
-        int kt_ = (KT);                                                                                         \
-        const char* bb_ = b_base[H];                                                                            \
-        if (X3) {                                                                                               \
-            const int kk_ = kt_ / 3;                                                                            \
-            if (kt_ - 3 * kk_ == 1) bb_ = b_base_lo[H];                                                         \
-            kt_ = kk_;                                                                                          \
-        }                                                                                                       \
-        const unsigned ko_ = (unsigned)(kt_ * 128);                                                             \
-        char* d_ = dma_dst + ((KT)&1) * Cfg::BUF_BYTES + (2 + (H)) * Cfg::HALF_BYTES;                           \
-        if (BUFLD) {                                                                                            \
-            dma16_buffer(reinterpret_cast<const float*>(bb_), (lptr_t)(d_), (int)b_off[0], (int)ko_);             \
-            dma16_buffer(reinterpret_cast<const float*>(bb_), (lptr_t)(d_ + 8192), (int)b_off[1], (int)ko_);      \
-        } else {                                                                                                \
-            __builtin_amdgcn_global_load_lds((gptr_t)(bb_ + (b_off[0] + ko_)), (lptr_t)(d_), 16, 0, 0);            \
-            __builtin_amdgcn_global_load_lds((gptr_t)(bb_ + (b_off[1] + ko_)), (lptr_t)(d_ + 8192), 16, 0, 0);     \
-        }                                                                                                       \
-    }
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int nk = (X3 ? 3 : 1) * (p.K / 64);  // even
-    // prologue: tile 0 complete, A of tile 1 on its way
-    NOMAD_P8_DMA_A(0, 0)
-    NOMAD_P8_DMA_A(0, 1)
-    NOMAD_P8_DMA_B(0, 0)
-    NOMAD_P8_DMA_B(0, 1)
-    NOMAD_P8_DMA_A(1, 0)
-    NOMAD_P8_DMA_A(1, 1)
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (wr == 1) __builtin_amdgcn_s_barrier();  // second wave row runs one barrier behind (ping-pong)
-
-    // fragment addresses: this lane's row fr of a 16-row tile, chunk (4 kh + fq) ^ swizzle
-    const int sw = (fr >> 1) & 7;
-    const int koff0 = ((0 + fq) ^ sw) * 16, koff1 = ((4 + fq) ^ sw) * 16;
-    const int a_frag = wr * Cfg::HALF_BYTES + fr * 128;                                         // + i * 2048
-    const int b_frag = (2 + (wc >> 1)) * Cfg::HALF_BYTES + ((wc & 1) * 64 + fr) * 128;          // + j * 2048
-
-    bf16x8 af[8][2], bf[2][2];
-#define NOMAD_P8_MMA(I0, J0)                                                                               \
-    _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                       \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                  \
-                acc[(I0) + i][(J0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[(I0) + i][kh], bf[j][kh], acc[(I0) + i][(J0) + j], 0, 0, 0);
-#define NOMAD_P8_SYNC_COMPUTE(I0, J0)                   \
-    __builtin_amdgcn_s_barrier();                       \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
-    if (ABL != 2) __builtin_amdgcn_s_setprio(1);        \
-    NOMAD_P8_MMA(I0, J0)                                \
-    if (ABL != 2) __builtin_amdgcn_s_setprio(0);        \
-    __builtin_amdgcn_s_barrier();                       \
-    asm volatile("" ::: "memory");
-
-    // one K tile (buffer BUF = KT & 1, a compile-time constant per call site)
-#define NOMAD_P8_KTILE(KT, BUF)                                                                            \
-    {                                                                                                      \
-        const char* la_ = smem8 + (BUF)*Cfg::BUF_BYTES + a_frag;                                           \
-        const char* lb_ = smem8 + (BUF)*Cfg::BUF_BYTES + b_frag;                                           \
-        /* phase 1: B columns 0..31, A rows 0..63 */                                                       \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                    \
-            bf[j][0] = *reinterpret_cast<const bf16x8*>(lb_ + j * 2048 + koff0);                           \
-            bf[j][1] = *reinterpret_cast<const bf16x8*>(lb_ + j * 2048 + koff1);                           \
-        }                                                                                                  \
-        if (!(ABL == 3 && (KT) % 3 == 1)) _Pragma("unroll") for (int i = 0; i < 4; ++i) {                  \
-            af[i][0] = *reinterpret_cast<const bf16x8*>(la_ + i * 2048 + koff0);                           \
-            af[i][1] = *reinterpret_cast<const bf16x8*>(la_ + i * 2048 + koff1);                           \
-        }                                                                                                  \
-        if ((KT) + 1 < nk) NOMAD_P8_DMA_B((KT) + 1, 0)                                                     \
-        NOMAD_P8_SYNC_COMPUTE(0, 0)                                                                        \
-        /* phase 2: A rows 64..127 */                                                                      \
-        if (!(ABL == 3 && (KT) % 3 == 1)) _Pragma("unroll") for (int i = 4; i < 8; ++i) {                  \
-            af[i][0] = *reinterpret_cast<const bf16x8*>(la_ + i * 2048 + koff0);                           \
-            af[i][1] = *reinterpret_cast<const bf16x8*>(la_ + i * 2048 + koff1);                           \
-        }                                                                                                  \
-        if ((KT) + 1 < nk) NOMAD_P8_DMA_B((KT) + 1, 1)                                                     \
-        NOMAD_P8_SYNC_COMPUTE(4, 0)                                                                        \
-        /* phase 3: B columns 32..63 */                                                                    \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                    \
-            bf[j][0] = *reinterpret_cast<const bf16x8*>(lb_ + (2 + j) * 2048 + koff0);                     \
-            bf[j][1] = *reinterpret_cast<const bf16x8*>(lb_ + (2 + j) * 2048 + koff1);                     \
-        }                                                                                                  \
-        NOMAD_P8_SYNC_COMPUTE(0, 2)                                                                        \
-        /* phase 4: both A halves of tile t+2 (their last read was phase 2), then "tile t+1 has landed" */ \
-        if ((KT) + 2 < nk) {                                                                               \
-            NOMAD_P8_DMA_A((KT) + 2, 0)                                                                    \
-            NOMAD_P8_DMA_A((KT) + 2, 1)                                                                    \
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                               \
-        } else {                                                                                           \
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                               \
-        }                                                                                                  \
-        NOMAD_P8_SYNC_COMPUTE(4, 2)                                                                        \
-    }
-
-    for (int kt = 0; kt < nk; kt += 2) {
-        NOMAD_P8_KTILE(kt, 0)
-        NOMAD_P8_KTILE(kt + 1, 1)
-    }
-    if (wr == 0) __builtin_amdgcn_s_barrier();  // re-join the two wave rows
-#undef NOMAD_P8_KTILE
-#undef NOMAD_P8_SYNC_COMPUTE
-#undef NOMAD_P8_MMA
-#undef NOMAD_P8_DMA_A
-#undef NOMAD_P8_DMA_B
-
-    // ---- epilogue: 32-row fp32 slabs through LDS (accumulator: column fr, rows 4 fq + r of each 16 x 16 tile) ----
+    constexpr int ABL = NOSTORE ? 1 : 0;
     bf16_t* Cg = reinterpret_cast<bf16_t*>(p.C) + grp * p.c_goff;
     float* Cf = p.C + grp * p.c_goff;  // X3 == 2: fp32 output
     const bf16_t* Rg = p.R ? reinterpret_cast<const bf16_t*>(p.R) + grp * p.r_goff : nullptr;
@@ -304,6 +123,206 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
             }
         }
     }
+}
+
+// ABL: 1 = no epilogue stores (timing only); 2 = no s_setprio around the MFMA clusters (A/B, same results);
+//      3 = X3 timing probe: every third K tile keeps the previous tile's A fragments (skips its A reads from LDS);
+//      4 / 5 / 6 = timing probes: no LDS-DMA / neither DMA nor LDS reads (MFMA + barriers only) / no LDS reads.
+// BUFLD: LDS-DMA through buffer descriptors (dma16_buffer) instead of global_load_lds - an A/B switch, measured below.
+// X3 ("bf16x3", fp32-class results on the bf16 matrix cores): A, W and R are SPLIT buffers (dtypes.hip.h: hi and lo
+//   bf16 planes p.a_plane / p.w_plane / p.r_plane elements apart) and the K loop walks 3 K/64 tiles - tile 3 kk + s
+//   multiplies k-range kk of (A_hi, W_hi), (A_hi, W_lo), (A_lo, W_hi) for s = 0, 1, 2 - into the same fp32
+//   accumulators: a.w = (ah + al)(wh + wl) minus the al*wl term (2^-16 relative), i.e. the plain kernel run on
+//   operands concatenated along K, with no other change to the schedule.  X3 = 1 stores the result split
+//   (p.c_plane), X3 = 2 stores fp32.
+template <int ABL = 0, bool BUFLD = false, int X3 = 0>
+__global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams p) {
+    using Cfg = P8Cfg;
+    extern __shared__ __attribute__((aligned(16))) char smem8[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int wg = xcd_remap(blockIdx.x, nwg);
+    int tile_m, tile_n;
+    tile_coords(wg, p.tiles_m, p.tiles_n, p.group_m, tile_m, tile_n);
+    const int m0 = tile_m * Cfg::BM, n0 = tile_n * Cfg::BN;
+    const int grp = blockIdx.y;
+    const bf16_t* Ag = reinterpret_cast<const bf16_t*>(p.A) + grp * p.a_goff;
+    const bf16_t* Wg = reinterpret_cast<const bf16_t*>(p.W) + grp * p.w_goff;
+
+    // DMA sources as (uniform 64-bit base) + (per-thread 32-bit byte offset): one VGPR per address instead of two, so
+    // that the whole working set stays inside the 256 registers a wave has at 2 waves/SIMD - a spilled address
+    // would come back through a scratch load whose s_waitcnt drains the whole DMA queue.
+    // Instruction i of a half-tile covers rows (tid + 512 i) / 8, physical chunk (tid + 512 i) % 8.
+    // The 32-bit offsets are relative to the tile's FIRST row (row addresses grow with the row index, a 256-row tile
+    // spans far less than 4 GB); the tensor itself may be larger than 4 GB (conv1 input at batch 512: 6.7 GB).
+    const long long tile_row0 = row_addr(p.amap, m0 < p.M ? m0 : p.M - 1);  // wave-uniform
+    unsigned a_off[2][2], b_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int id = tid + i * 512, row = id >> 3, pc = id & 7;
+        const int sw = (pc ^ ((row >> 1) & 7)) * 8;
+        b_off[i] = (unsigned)(((long long)row * p.ldw + sw) * 2);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int m = m0 + h * 128 + row;
+            m = m < p.M ? m : p.M - 1;
+            a_off[h][i] = (unsigned)((row_addr(p.amap, m) - tile_row0 + sw) * 2);
+        }
+    }
+    const char* const a_base = reinterpret_cast<const char*>(Ag + tile_row0);
+    const char* const b_base[2] = {reinterpret_cast<const char*>(Wg + (long long)n0 * p.ldw),
+                                   reinterpret_cast<const char*>(Wg + (long long)(n0 + 128) * p.ldw)};
+    // lo planes (X3): wave-uniform bases, selected per K tile by scalar code
+    const char* const a_base_lo = a_base + (X3 ? p.a_plane * 2 : 0);
+    const char* const b_base_lo[2] = {b_base[0] + (X3 ? p.w_plane * 2 : 0), b_base[1] + (X3 ? p.w_plane * 2 : 0)};
+    char* const dma_dst = smem8 + wave * 1024;  // + lane * 16 implicit (lane-linear LDS-DMA destination)
+
+    // LDS-DMA through buffer descriptors (dma16_buffer, gemm_f32.hip.h): wave-uniform base in SGPRs, one 32-bit VGPR
+    // per lane, the K-tile term as the scalar offset - no 64-bit VGPR pointers for the compiler to hoist or spill.
+#define NOMAD_P8_DMA_A(KT, H)                                                                                   \
+    {                                                                                                           \
+        int kt_ = (KT);                                                                                         \
+        const char* ab_ = a_base;                                                                               \
+        if (X3) {                                                                                               \
+            const int kk_ = kt_ / 3;                                                                            \
+            if (kt_ - 3 * kk_ == 2) ab_ = a_base_lo;                                                            \
+            kt_ = kk_;                                                                                          \
+        }                                                                                                       \
+        const int k0_ = kt_ * 64;                                                                               \
+        const int kq_ = k0_ / p.kchunk;                                                                         \
+        const unsigned ko_ = (unsigned)((kq_ * p.kstride + (k0_ - kq_ * p.kchunk)) * 2);                        \
+        char* d_ = dma_dst + ((KT)&1) * Cfg::BUF_BYTES + (H)*Cfg::HALF_BYTES;                                   \
+        if (ABL == 4 || ABL == 5) {                                                                             \
+        } else if (BUFLD) {                                                                                            \
+            dma16_buffer(reinterpret_cast<const float*>(ab_), (lptr_t)(d_), (int)a_off[H][0], (int)ko_);          \
+            dma16_buffer(reinterpret_cast<const float*>(ab_), (lptr_t)(d_ + 8192), (int)a_off[H][1], (int)ko_);   \
+        } else {                                                                                                \
+            __builtin_amdgcn_global_load_lds((gptr_t)(ab_ + (a_off[H][0] + ko_)), (lptr_t)(d_), 16, 0, 0);         \
+            __builtin_amdgcn_global_load_lds((gptr_t)(ab_ + (a_off[H][1] + ko_)), (lptr_t)(d_ + 8192), 16, 0, 0);  \
+        }                                                                                                       \
+    }
+#define NOMAD_P8_DMA_B(KT, H)                                                                                   \
+    {                                                                                                           \
+        int kt_ = (KT);                                                                                         \
+        const char* bb_ = b_base[H];                                                                            \
+        if (X3) {                                                                                               \
+            const int kk_ = kt_ / 3;                                                                            \
+            if (kt_ - 3 * kk_ == 1) bb_ = b_base_lo[H];                                                         \
+            kt_ = kk_;                                                                                          \
+        }                                                                                                       \
+        const unsigned ko_ = (unsigned)(kt_ * 128);                                                             \
+        char* d_ = dma_dst + ((KT)&1) * Cfg::BUF_BYTES + (2 + (H)) * Cfg::HALF_BYTES;                           \
+        if (ABL == 4 || ABL == 5) {                                                                             \
+        } else if (BUFLD) {                                                                                            \
+            dma16_buffer(reinterpret_cast<const float*>(bb_), (lptr_t)(d_), (int)b_off[0], (int)ko_);             \
+            dma16_buffer(reinterpret_cast<const float*>(bb_), (lptr_t)(d_ + 8192), (int)b_off[1], (int)ko_);      \
+        } else {                                                                                                \
+            __builtin_amdgcn_global_load_lds((gptr_t)(bb_ + (b_off[0] + ko_)), (lptr_t)(d_), 16, 0, 0);            \
+            __builtin_amdgcn_global_load_lds((gptr_t)(bb_ + (b_off[1] + ko_)), (lptr_t)(d_ + 8192), 16, 0, 0);     \
+        }                                                                                                       \
+    }
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (X3 ? 3 : 1) * (p.K / 64);  // even
+    // prologue: tile 0 complete, A of tile 1 on its way
+    NOMAD_P8_DMA_A(0, 0)
+    NOMAD_P8_DMA_A(0, 1)
+    NOMAD_P8_DMA_B(0, 0)
+    NOMAD_P8_DMA_B(0, 1)
+    NOMAD_P8_DMA_A(1, 0)
+    NOMAD_P8_DMA_A(1, 1)
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (wr == 1) __builtin_amdgcn_s_barrier();  // second wave row runs one barrier behind (ping-pong)
+
+    // fragment addresses: this lane's row fr of a 16-row tile, chunk (4 kh + fq) ^ swizzle
+    const int sw = (fr >> 1) & 7;
+    const int koff0 = ((0 + fq) ^ sw) * 16, koff1 = ((4 + fq) ^ sw) * 16;
+    const int a_frag = wr * Cfg::HALF_BYTES + fr * 128;                                         // + i * 2048
+    const int b_frag = (2 + (wc >> 1)) * Cfg::HALF_BYTES + ((wc & 1) * 64 + fr) * 128;          // + j * 2048
+
+    bf16x8 af[8][2], bf[2][2];
+    if (ABL >= 3) {  // timing probes may skip fragment loads: keep the registers defined
+#pragma unroll
+        for (int i = 0; i < 8; ++i) af[i][0] = af[i][1] = (bf16x8){1, 1, 1, 1, 1, 1, 1, 1};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bf[j][0] = bf[j][1] = (bf16x8){1, 1, 1, 1, 1, 1, 1, 1};
+    }
+#define NOMAD_P8_MMA(I0, J0)                                                                               \
+    _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                       \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                  \
+                acc[(I0) + i][(J0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[(I0) + i][kh], bf[j][kh], acc[(I0) + i][(J0) + j], 0, 0, 0);
+#define NOMAD_P8_SYNC_COMPUTE(I0, J0)                   \
+    __builtin_amdgcn_s_barrier();                       \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
+    if (ABL != 2) __builtin_amdgcn_s_setprio(1);        \
+    NOMAD_P8_MMA(I0, J0)                                \
+    if (ABL != 2) __builtin_amdgcn_s_setprio(0);        \
+    __builtin_amdgcn_s_barrier();                       \
+    asm volatile("" ::: "memory");
+
+    // one K tile (buffer BUF = KT & 1, a compile-time constant per call site)
+#define NOMAD_P8_KTILE(KT, BUF)                                                                            \
+    {                                                                                                      \
+        const char* la_ = smem8 + (BUF)*Cfg::BUF_BYTES + a_frag;                                           \
+        const char* lb_ = smem8 + (BUF)*Cfg::BUF_BYTES + b_frag;                                           \
+        /* phase 1: B columns 0..31, A rows 0..63 */                                                       \
+        if (ABL != 5 && ABL != 6) _Pragma("unroll") for (int j = 0; j < 2; ++j) {                          \
+            bf[j][0] = *reinterpret_cast<const bf16x8*>(lb_ + j * 2048 + koff0);                           \
+            bf[j][1] = *reinterpret_cast<const bf16x8*>(lb_ + j * 2048 + koff1);                           \
+        }                                                                                                  \
+        if (!(ABL == 3 && (KT) % 3 == 1) && ABL != 5 && ABL != 6) _Pragma("unroll") for (int i = 0; i < 4; ++i) {                  \
+            af[i][0] = *reinterpret_cast<const bf16x8*>(la_ + i * 2048 + koff0);                           \
+            af[i][1] = *reinterpret_cast<const bf16x8*>(la_ + i * 2048 + koff1);                           \
+        }                                                                                                  \
+        if ((KT) + 1 < nk) NOMAD_P8_DMA_B((KT) + 1, 0)                                                     \
+        NOMAD_P8_SYNC_COMPUTE(0, 0)                                                                        \
+        /* phase 2: A rows 64..127 */                                                                      \
+        if (!(ABL == 3 && (KT) % 3 == 1) && ABL != 5 && ABL != 6) _Pragma("unroll") for (int i = 4; i < 8; ++i) {                  \
+            af[i][0] = *reinterpret_cast<const bf16x8*>(la_ + i * 2048 + koff0);                           \
+            af[i][1] = *reinterpret_cast<const bf16x8*>(la_ + i * 2048 + koff1);                           \
+        }                                                                                                  \
+        if ((KT) + 1 < nk) NOMAD_P8_DMA_B((KT) + 1, 1)                                                     \
+        NOMAD_P8_SYNC_COMPUTE(4, 0)                                                                        \
+        /* phase 3: B columns 32..63 */                                                                    \
+        if (ABL != 5 && ABL != 6) _Pragma("unroll") for (int j = 0; j < 2; ++j) {                          \
+            bf[j][0] = *reinterpret_cast<const bf16x8*>(lb_ + (2 + j) * 2048 + koff0);                     \
+            bf[j][1] = *reinterpret_cast<const bf16x8*>(lb_ + (2 + j) * 2048 + koff1);                     \
+        }                                                                                                  \
+        NOMAD_P8_SYNC_COMPUTE(0, 2)                                                                        \
+        /* phase 4: both A halves of tile t+2 (their last read was phase 2), then "tile t+1 has landed" */ \
+        if ((KT) + 2 < nk) {                                                                               \
+            NOMAD_P8_DMA_A((KT) + 2, 0)                                                                    \
+            NOMAD_P8_DMA_A((KT) + 2, 1)                                                                    \
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                               \
+        } else {                                                                                           \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                               \
+        }                                                                                                  \
+        NOMAD_P8_SYNC_COMPUTE(4, 2)                                                                        \
+    }
+
+    for (int kt = 0; kt < nk; kt += 2) {
+        NOMAD_P8_KTILE(kt, 0)
+        NOMAD_P8_KTILE(kt + 1, 1)
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();  // re-join the two wave rows
+#undef NOMAD_P8_KTILE
+#undef NOMAD_P8_SYNC_COMPUTE
+#undef NOMAD_P8_MMA
+#undef NOMAD_P8_DMA_A
+#undef NOMAD_P8_DMA_B
+
+    p8_epilogue<ABL == 1, X3>(p, acc, smem8, grp, m0, n0, wave, wr, wc, lane, fr, fq);
 }
 
 template <int ABL = 0, bool BUFLD = false, int X3 = 0>

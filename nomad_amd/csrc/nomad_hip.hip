@@ -29,6 +29,7 @@
 #include "frontend.hip.h"
 #include "gemm_bf16.hip.h"
 #include "gemm_bf16_8phase.hip.h"
+#include "gemm_bf16x3.hip.h"
 #include "gemm_f32.hip.h"
 #include "gemm_f32_pp.hip.h"
 #include "pairwise.hip.h"
@@ -1088,7 +1089,7 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
             tile = 16;  // deep-pipelined 256x256 kernel once there are >= 2 rounds of tiles (profiles/r01_gemm_sweep_bf16_8phase.json)
         else tile = (p.N % 256 == 0 && (p.N >= 1024 || p.M >= 100000)) ? 3 : 1;
     }
-    Scope sc(c, s, NOMAD_K_GEMM, flops, (tile == 1 || tile == 3 || tile == 16 || tile == 20 || tile == 21) ? NOMAD_K_GEMM_BIG : (tile == 2 ? NOMAD_K_GEMM_FINE : -1));
+    Scope sc(c, s, NOMAD_K_GEMM, flops, (tile == 1 || tile == 3 || tile == 16 || tile == 20 || tile == 21 || tile == 27 || tile == 28 || tile == 32 || tile == 33) ? NOMAD_K_GEMM_BIG : (tile == 2 ? NOMAD_K_GEMM_FINE : -1));
     hipError_t e;
     switch (tile) {
         case 0: e = launch_gemm_bf16<256, 128, 4, 2>(p, groups, s); break;
@@ -1121,8 +1122,29 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
             if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16x3 gemm: N %% 256, K %% 128");
             e = tile == 20 ? launch_gemm_bf16_8phase<0, false, 1>(p, groups, s) : launch_gemm_bf16_8phase<0, false, 2>(p, groups, s);
             break;
-        case 22:  // bf16x3 timing probe (ABL 3), fp32 output
+        case 22:  // bf16x3 timing probes (gemm_bf16_8phase.hip.h ABL), fp32 output
             e = launch_gemm_bf16_8phase<3, false, 2>(p, groups, s);
+            break;
+        case 23: e = launch_gemm_bf16_8phase<4, false, 2>(p, groups, s); break;
+        case 24: e = launch_gemm_bf16_8phase<5, false, 2>(p, groups, s); break;
+        case 25: e = launch_gemm_bf16_8phase<6, false, 2>(p, groups, s); break;
+        case 26: e = launch_gemm_bf16_8phase<1, false, 2>(p, groups, s); break;
+        case 27:  // bf16x3, every plane staged once (gemm_bf16x3.hip.h): split output
+        case 28:  // ... fp32 output
+        case 29:  // timing probe: no epilogue stores
+        case 30:  // timing probe: no LDS-DMA
+        case 31:  // timing probe: every workgroup stages A tile 0 (A always hits in L2)
+        case 32:  // three A buffers (K % 192 == 0): split output
+        case 33:  // ... fp32 output
+            if (tile >= 32) {
+                if (p.N % 256 != 0 || p.K % 192 != 0) return fail(NOMAD_ERR_INVALID, "bf16x3 gemm (3 A buffers): N %% 256, K %% 192");
+                e = tile == 32 ? launch_gemm_bf16x3<0, 1, 3>(p, groups, s) : launch_gemm_bf16x3<0, 2, 3>(p, groups, s);
+                break;
+            }
+            if (p.N % 256 != 0 || p.K % 64 != 0) return fail(NOMAD_ERR_INVALID, "bf16x3 gemm: N %% 256, K %% 64");
+            e = tile == 27 ? launch_gemm_bf16x3<0, 1>(p, groups, s) : tile == 28 ? launch_gemm_bf16x3<0, 2>(p, groups, s)
+              : tile == 29 ? launch_gemm_bf16x3<1, 2>(p, groups, s) : tile == 30 ? launch_gemm_bf16x3<4, 2>(p, groups, s)
+              : launch_gemm_bf16x3<7, 2>(p, groups, s);
             break;
         case 19:  // A/B: 8-phase kernel without s_setprio
             if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
@@ -1405,6 +1427,11 @@ static GemmParams dense_x3(const bf16s_t* A, long long a_plane, int lda, const b
 }
 
 // meta (ragged only): device prefix tables, already on their way (same stream)
+// The GEMM instantiation of the path (run_gemm_bf16 tile ids): the kernel that stages every plane once
+// (gemm_bf16x3.hip.h), 2-3 % ahead of the K-concatenated form (20 / 21) in profiles/r01_gemm_bf16x3_shapes.json.
+// One instantiation for every shape and batch size: a clip's bits do not depend on the batch it is in.
+constexpr int kX3Split = 27, kX3F32 = 28;
+
 static int forward_x3_run(nomad_ctx* c, const float* wav, const X3Geom& g, const X3Layout& lay, const int* meta, float* emb,
                           char* ws, hipStream_t s) {
     auto S = [&](size_t off) { return reinterpret_cast<bf16s_t*>(ws + off); };
@@ -1450,7 +1477,7 @@ static int forward_x3_run(nomad_ctx* c, const float* wav, const X3Geom& g, const
         p.cmap = plain_map(p.M, 512);
         p.rmap = p.cmap;
         p.gelu = 1;
-        if ((rc = run_gemm_bf16(c, p, 1, s, 20))) return rc;
+        if ((rc = run_gemm_bf16(c, p, 1, s, kX3Split))) return rc;
     }
     bf16s_t* conv6 = cb[0];
     bf16s_t* featln = cb[1];
@@ -1470,7 +1497,7 @@ static int forward_x3_run(nomad_ctx* c, const float* wav, const X3Geom& g, const
         p.cmap = g.pad_map;
         p.c_colblk = 48;
         p.c_colblk_stride = grp_stride;
-        if ((rc = run_gemm_bf16(c, p, 1, s, 21))) return rc;
+        if ((rc = run_gemm_bf16(c, p, 1, s, kX3F32))) return rc;
     }
     bf16s_t *x = S(lay.x), *x2 = S(lay.x2), *ctxb = S(lay.ctxb), *hb = S(lay.h);
     float *y = F(lay.y), *qkv = F(lay.qkv);
@@ -1506,19 +1533,19 @@ static int forward_x3_run(nomad_ctx* c, const float* wav, const X3Geom& g, const
     ln(y, c->eln_w, c->eln_b, x);
     for (int l = 0; l < NOMAD_NUM_LAYERS; ++l) {
         const LayerDev& d = c->layers[l];
-        if ((rc = run_gemm_bf16(c, dense_x3(x, pl768, 768, c->qkv_wx[l], d.qkv_b, nullptr, 0, qkv, 0, M, 2304, 768, 0), 1, s, 21)))
+        if ((rc = run_gemm_bf16(c, dense_x3(x, pl768, 768, c->qkv_wx[l], d.qkv_b, nullptr, 0, qkv, 0, M, 2304, 768, 0), 1, s, kX3F32)))
             return rc;
         {
             Scope sc(c, s, NOMAD_K_ATTN, g.attn_flops);
             hipLaunchKernelGGL((attention_f32_kernel<float, false, bf16s_t>), dim3((g.max_t + 63) / 64, B * 12), dim3(256), 0, s,
                                qkv, ctxb, static_cast<float*>(nullptr), g.T, tpref, DropCfg{}, 0u, 0, pl768);
         }
-        if ((rc = run_gemm_bf16(c, dense_x3(ctxb, pl768, 768, c->o_wx[l], d.o_b, x, pl768, y, 0, M, 768, 768, 0), 1, s, 21)))
+        if ((rc = run_gemm_bf16(c, dense_x3(ctxb, pl768, 768, c->o_wx[l], d.o_b, x, pl768, y, 0, M, 768, 768, 0), 1, s, kX3F32)))
             return rc;
         ln(y, d.ln1_w, d.ln1_b, x2);
-        if ((rc = run_gemm_bf16(c, dense_x3(x2, pl768, 768, c->fc1_wx[l], d.fc1_b, nullptr, 0, hb, pl3072, M, 3072, 768, 1), 1, s, 20)))
+        if ((rc = run_gemm_bf16(c, dense_x3(x2, pl768, 768, c->fc1_wx[l], d.fc1_b, nullptr, 0, hb, pl3072, M, 3072, 768, 1), 1, s, kX3Split)))
             return rc;
-        if ((rc = run_gemm_bf16(c, dense_x3(hb, pl3072, 3072, c->fc2_wx[l], d.fc2_b, x2, pl768, y, 0, M, 768, 3072, 0), 1, s, 21)))
+        if ((rc = run_gemm_bf16(c, dense_x3(hb, pl3072, 3072, c->fc2_wx[l], d.fc2_b, x2, pl768, y, 0, M, 768, 3072, 0), 1, s, kX3F32)))
             return rc;
         if (l + 1 < NOMAD_NUM_LAYERS) ln(y, d.ln2_w, d.ln2_b, x);
         else if ((rc = run_layernorm(c, y, d.ln2_w, d.ln2_b, reinterpret_cast<float*>(x), nullptr, M, 768, s))) return rc;
@@ -1852,11 +1879,11 @@ int nomad_diag_split_bf16(nomad_ctx* c, const float* in, void* out, long long pl
 
 int nomad_diag_gemm_bf16x3(nomad_ctx* c, const void* A, const void* W, const float* bias, const void* R, void* C, int M,
                            int N, int K, int gelu, int out_f32, nomad_stream_t stream) {
-    if (!c || !A || !W || !C || M <= 0 || N % 256 || K % 128)
-        return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16x3: bad argument (N %% 256, K %% 128)");
+    if (!c || !A || !W || !C || M <= 0 || N % 256 || K % (out_f32 >= 12 ? 192 : out_f32 >= 7 ? 64 : 128))
+        return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16x3: bad argument (N %% 256, K %% 128; K %% 64 for the staged kernel)");
     GemmParams p = dense_x3(static_cast<const bf16s_t*>(A), (long long)M * K, K, static_cast<const bf16s_t*>(W), bias,
                             static_cast<const bf16s_t*>(R), (long long)M * N, C, (long long)M * N, M, N, K, gelu);
-    return run_gemm_bf16(c, p, 1, static_cast<hipStream_t>(stream), 20 + (out_f32 < 0 ? 0 : out_f32 > 2 ? 2 : out_f32));
+    return run_gemm_bf16(c, p, 1, static_cast<hipStream_t>(stream), 20 + (out_f32 < 0 ? 0 : out_f32 > 13 ? 13 : out_f32));
 }
 
 int nomad_workspace_bytes_ragged_bf16(const nomad_ctx* c, int B, const int* lengths_host, size_t* bytes) {

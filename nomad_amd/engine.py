@@ -259,8 +259,14 @@ class Engine:
                                                   self._stream()), "nomad_diag_split_bf16")
         return out
 
-    def diag_gemm_bf16x3(self, A, W, bias=None, R=None, gelu=False, out_f32=True, out=None):
-        """A (2,M,K), W (2,N,K), R (2,M,N) split buffers (diag_split_bf16); returns fp32 (M,N) or a split (2,M,N)."""
+    def diag_gemm_bf16x3(self, A, W, bias=None, R=None, gelu=False, out_f32=True, out=None, variant=None):
+        """A (2,M,K), W (2,N,K), R (2,M,N) split buffers (diag_split_bf16); returns fp32 (M,N) or a split (2,M,N).
+        variant (int, optional): kernel selector of nomad_diag_gemm_bf16x3 - 0/1 K-concatenated kernel (split / fp32 out),
+        7/8 staged-once kernel (split / fp32 out), 12/13 the same with three A buffers (K % 192 == 0), others are timing
+        probes with fp32 output."""
+        if variant is None:
+            variant = 8 if out_f32 else 7
+        out_f32 = variant not in (0, 7, 12)
         _, M, K = A.shape
         N = W.shape[1]
         if out is None:
@@ -269,7 +275,7 @@ class Engine:
         _lib.check(self.lib.nomad_diag_gemm_bf16x3(self.ctx, A.data_ptr(), W.data_ptr(),
                                                    bias.data_ptr() if bias is not None else None,
                                                    R.data_ptr() if R is not None else None, out.data_ptr(),
-                                                   M, N, K, int(gelu), int(out_f32), self._stream()), "nomad_diag_gemm_bf16x3")
+                                                   M, N, K, int(gelu), int(variant), self._stream()), "nomad_diag_gemm_bf16x3")
         return out
 
     def diag_attention_bf16(self, qkv, B, T):

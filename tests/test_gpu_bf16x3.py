@@ -20,30 +20,43 @@ def test_split_round_trip(engine):
     assert torch.equal(back, hi + lo)
 
 
+# the two GEMM kernels of the path: K-concatenated operands in the 8-phase bf16 kernel (variants 0 split / 1 fp32 out) and
+# the kernel that stages every plane once (gemm_bf16x3.hip.h, variants 7 / 8)
+KERNELS = {"kcat": (0, 1), "staged": (7, 8), "staged3": (12, 13)}   # staged3: three A buffers, K % 192 == 0
+
+
+@pytest.mark.parametrize("kernel", sorted(KERNELS))
 @pytest.mark.parametrize("M", [1, 200, 257, 1000])
-def test_gemm_bf16x3_exact_on_16_bit_integers(engine, M):
+def test_gemm_bf16x3_exact_on_16_bit_integers(engine, M, kernel):
     """Operands that hi + lo represents exactly (|a| < 2^16) whose lo*lo terms vanish (one operand has lo = 0):
     the three products reproduce the exact integer result as long as it fits fp32."""
-    N, K = 512, 256
+    N, K = 512, (384 if kernel == "staged3" else 256)
+    var = KERNELS[kernel][1]
     g = torch.Generator().manual_seed(M)
-    A = torch.randint(-40000, 40000, (M, K), generator=g).float()       # needs hi and lo
+    A = torch.randint(-20000, 20000, (M, K), generator=g).float()       # needs hi and lo
     W = torch.randint(-3, 4, (N, K), generator=g).float()               # lo plane is zero
     W[:, ::7] = 1.0
     ref = A.double() @ W.double().T
     assert ref.abs().max() < 2 ** 24
-    out = engine.diag_gemm_bf16x3(engine.diag_split_bf16(A.cuda()), engine.diag_split_bf16(W.cuda())).cpu()
+    out = engine.diag_gemm_bf16x3(engine.diag_split_bf16(A.cuda()), engine.diag_split_bf16(W.cuda()), variant=var).cpu()
     assert torch.equal(out.double(), ref)
     # and with the roles swapped: the lo plane on the W side
     A2 = torch.randint(-3, 4, (M, K), generator=g).float()
-    W2 = torch.randint(-40000, 40000, (N, K), generator=g).float()
-    out2 = engine.diag_gemm_bf16x3(engine.diag_split_bf16(A2.cuda()), engine.diag_split_bf16(W2.cuda())).cpu()
+    W2 = torch.randint(-20000, 20000, (N, K), generator=g).float()
+    out2 = engine.diag_gemm_bf16x3(engine.diag_split_bf16(A2.cuda()), engine.diag_split_bf16(W2.cuda()), variant=var).cpu()
     assert torch.equal(out2.double(), A2.double() @ W2.double().T)
 
 
-@pytest.mark.parametrize("M,N,K", [(777, 768, 3072), (1500, 512, 1536), (300, 2304, 768), (4113, 256, 128), (600, 3072, 768)])
+@pytest.mark.parametrize("kernel", sorted(KERNELS))
+@pytest.mark.parametrize("M,N,K", [(777, 768, 3072), (1500, 512, 1536), (300, 2304, 768), (4113, 256, 128), (600, 3072, 768),
+                                   (513, 256, 64), (255, 512, 192 + 64)])
 @pytest.mark.parametrize("epi", ["none", "bias_gelu", "bias_res"])
 @pytest.mark.parametrize("out_f32", [True, False])
-def test_gemm_bf16x3_vs_float64(engine, M, N, K, epi, out_f32):
+def test_gemm_bf16x3_vs_float64(engine, M, N, K, epi, out_f32, kernel):
+    if kernel == "kcat" and K % 128:
+        pytest.skip("the K-concatenated kernel walks K tiles of 64 in pairs")
+    if kernel == "staged3" and K % 192:
+        pytest.skip("three A buffers: stages in sixes")
     g = torch.Generator().manual_seed(5)
     A = torch.randn(M, K, generator=g)
     W = torch.randn(N, K, generator=g) * K ** -0.5
@@ -59,13 +72,13 @@ def test_gemm_bf16x3_vs_float64(engine, M, N, K, epi, out_f32):
     out = engine.diag_gemm_bf16x3(engine.diag_split_bf16(A.cuda()), engine.diag_split_bf16(W.cuda()),
                                   bias.cuda() if bias is not None else None,
                                   engine.diag_split_bf16(R.cuda()) if R is not None else None, gelu="gelu" in epi,
-                                  out_f32=out_f32)
+                                  variant=KERNELS[kernel][1 if out_f32 else 0])
     if not out_f32:
         out = engine.diag_unsplit_bf16(out)
     err = (out.cpu().double() - ref).abs().max().item()
     f32 = (A.cuda() @ W.cuda().T).cpu().double()
     if epi == "none":
-        print(f"bf16x3 {M}x{N}x{K}: max|err| {err:.2e}  (torch fp32 matmul: {(f32 - (A.double() @ W.double().T)).abs().max().item():.2e})")
+        print(f"bf16x3 {kernel} {M}x{N}x{K}: max|err| {err:.2e}  (torch fp32 matmul: {(f32 - (A.double() @ W.double().T)).abs().max().item():.2e})")
     # per product 2^-16 relative (dropped lo*lo + two 2^-17 operand roundings), random signs over K, |a||w| ~ K^-1/2;
     # measured ~3e-6 at unit-scale outputs; a plain bf16 GEMM is ~1e-2 here
     assert err < 3e-5 * max(1.0, ref.abs().max().item()), err
