@@ -335,4 +335,172 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(const bf16_t* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// bf16x3 attention: the bf16 kernel above on split operands (dtypes.hip.h: hi / lo bf16 planes `plane` elements apart).
+// Both products run as three bf16 MFMAs with fp32 accumulation,
+//   S^T  = K_hi Q_hi^T + K_hi Q_lo^T + K_lo Q_hi^T
+//   O^T += V_hi^T P_hi^T + V_hi^T P_lo^T + V_lo^T P_hi^T      (P split in registers: p_hi = bf16(p), p_lo = bf16(p - p_hi))
+// so logits and the output see 2^-16-relative product errors instead of bf16's 2^-8; softmax statistics, masks and the
+// accumulators are fp32 as everywhere.  6 bf16 MFMAs (16 cycles each) replace 8 fp32 MFMAs (32 cycles each) per
+// 16 x 16 x 64 block.  LDS: K_hi, K_lo, V_hi, V_lo tiles, 36 KB.
+template <int NSUB>
+__device__ __forceinline__ void attn_tile_x3(const char* __restrict__ Kh, const char* __restrict__ Kl,
+                                             const char* __restrict__ Vh, const char* __restrict__ Vl,
+                                             const bf16x8 (&qh)[2], const bf16x8 (&ql)[2], f32x4 (&o)[4], float& m_run,
+                                             float& l_run, int qi, int g, int valid) {
+    f32x4 s[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 kfh[NSUB], kfl[NSUB];
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {
+            kfh[sub] = *reinterpret_cast<const bf16x8*>(Kh + (sub * 16 + qi) * kAttn16LD + (4 * ks + g) * 16);
+            kfl[sub] = *reinterpret_cast<const bf16x8*>(Kl + (sub * 16 + qi) * kAttn16LD + (4 * ks + g) * 16);
+        }
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {
+            s[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfl[sub], qh[ks], s[sub], 0, 0, 0);
+            s[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfh[sub], ql[ks], s[sub], 0, 0, 0);
+            s[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfh[sub], qh[ks], s[sub], 0, 0, 0);
+        }
+    }
+    float m_tile = -INFINITY;
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (sub >= NSUB || sub * 16 + g * 4 + r >= valid) s[sub][r] = -INFINITY;
+            m_tile = fmaxf(m_tile, s[sub][r]);
+        }
+    m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 16));
+    m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));
+    const float m_new = fmaxf(m_run, m_tile);
+    const float alpha = fast_exp(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float pv = fast_exp(s[sub][r] - m_new);
+            s[sub][r] = pv;
+            psum += pv;
+        }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] *= alpha;
+    const int tr_row = (qi >> 2), tr_col = (qi & 3) * 4;
+#pragma unroll
+    for (int pb = 0; pb < (NSUB + 1) / 2; ++pb) {
+        bf16x8 ph, pl;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            ph[r] = (bf16_t)s[2 * pb][r];
+            ph[4 + r] = (bf16_t)s[2 * pb + 1][r];
+            pl[r] = (bf16_t)(s[2 * pb][r] - (float)ph[r]);
+            pl[4 + r] = (bf16_t)(s[2 * pb + 1][r] - (float)ph[4 + r]);
+        }
+        const int voff = ((2 * pb) * 16 + g * 4 + tr_row) * kAttn16LD + tr_col * 2;
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds) {
+            const bf16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(Vh + voff + ds * 32));
+            const bf16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(Vh + voff + 16 * kAttn16LD + ds * 32));
+            const bf16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(Vl + voff + ds * 32));
+            const bf16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(Vl + voff + 16 * kAttn16LD + ds * 32));
+            bf16x8 vh, vl;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                vh[r] = h0[r];
+                vh[4 + r] = h1[r];
+                vl[r] = l0[r];
+                vl[4 + r] = l1[r];
+            }
+            o[ds] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, ph, o[ds], 0, 0, 0);
+            o[ds] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pl, o[ds], 0, 0, 0);
+            o[ds] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, ph, o[ds], 0, 0, 0);
+        }
+    }
+}
+
+// qkv: split [M][2304] (q pre-scaled), out: split [M][768].  tpref (nullable): ragged batches, as above.
+__global__ __launch_bounds__(256) void attention_x3_kernel(const bf16s_t* __restrict__ qkv_s, long long in_plane,
+                                                           bf16s_t* __restrict__ out, long long out_plane, int T,
+                                                           const int* __restrict__ tpref = nullptr) {
+    __shared__ __attribute__((aligned(16))) char Kh[64 * kAttn16LD];
+    __shared__ __attribute__((aligned(16))) char Kl[64 * kAttn16LD];
+    __shared__ __attribute__((aligned(16))) char Vh[64 * kAttn16LD];
+    __shared__ __attribute__((aligned(16))) char Vl[64 * kAttn16LD];
+    const bf16_t* qkv = reinterpret_cast<const bf16_t*>(qkv_s);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qi = lane & 15, g = lane >> 4;
+    const int bh = blockIdx.y, b = bh / 12, h = bh - b * 12;
+    long long row0 = (long long)b * T;
+    if (tpref) {
+        row0 = tpref[b];
+        T = tpref[b + 1] - tpref[b];
+        if ((int)blockIdx.x * 64 >= T) return;  // whole workgroup: no barrier has been reached yet
+    }
+    const long long base = row0 * 2304 + h * 64;
+    const int q_row = blockIdx.x * 64 + wave * 16 + qi;
+    const int q_ld = q_row < T ? q_row : T - 1;
+    bf16x8 qh[2], ql[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const bf16_t* src = qkv + base + (long long)q_ld * 2304 + ks * 32 + g * 8;
+        qh[ks] = *reinterpret_cast<const bf16x8*>(src);
+        ql[ks] = *reinterpret_cast<const bf16x8*>(src + in_plane);
+    }
+    f32x4 o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    const bool wave_active = blockIdx.x * 64 + wave * 16 < T;
+    const int ntiles = (T + 63) / 64;
+    bf16x8 kh[2], kl[2], vh[2], vl[2];  // next tile, prefetched under the current tile's MFMAs
+    auto fetch = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = tid + i * 256, row = id >> 3, ch = id & 7;
+            int key = kt * 64 + row;
+            key = key < T ? key : T - 1;
+            const bf16_t* src = qkv + base + (long long)key * 2304 + ch * 8;
+            kh[i] = *reinterpret_cast<const bf16x8*>(src + 768);
+            kl[i] = *reinterpret_cast<const bf16x8*>(src + 768 + in_plane);
+            vh[i] = *reinterpret_cast<const bf16x8*>(src + 1536);
+            vl[i] = *reinterpret_cast<const bf16x8*>(src + 1536 + in_plane);
+        }
+    };
+    fetch(0);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = tid + i * 256, row = id >> 3, ch = id & 7;
+            *reinterpret_cast<bf16x8*>(Kh + row * kAttn16LD + ch * 16) = kh[i];
+            *reinterpret_cast<bf16x8*>(Kl + row * kAttn16LD + ch * 16) = kl[i];
+            *reinterpret_cast<bf16x8*>(Vh + row * kAttn16LD + ch * 16) = vh[i];
+            *reinterpret_cast<bf16x8*>(Vl + row * kAttn16LD + ch * 16) = vl[i];
+        }
+        __syncthreads();
+        if (kt + 1 < ntiles) fetch(kt + 1);
+        if (!wave_active) continue;  // wave-uniform: the transposing reads need a full EXEC mask
+        const int valid = T - kt * 64;
+        if (valid > 48) attn_tile_x3<4>(Kh, Kl, Vh, Vl, qh, ql, o, m_run, l_run, qi, g, valid);
+        else if (valid > 32) attn_tile_x3<3>(Kh, Kl, Vh, Vl, qh, ql, o, m_run, l_run, qi, g, valid);
+        else if (valid > 16) attn_tile_x3<2>(Kh, Kl, Vh, Vl, qh, ql, o, m_run, l_run, qi, g, valid);
+        else attn_tile_x3<1>(Kh, Kl, Vh, Vl, qh, ql, o, m_run, l_run, qi, g, valid);
+    }
+    float l_tot = l_run + __shfl_xor(l_run, 16);
+    l_tot += __shfl_xor(l_tot, 32);
+    const float inv = 1.0f / l_tot;
+    if (q_row < T) {
+        bf16s_t* dst = out + (row0 + q_row) * 768 + h * 64 + g * 4;
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds)
+            store4p<bf16s_t>(dst + ds * 16, out_plane, make_float4(o[ds][0] * inv, o[ds][1] * inv, o[ds][2] * inv, o[ds][3] * inv));
+    }
+}
+
 }  // namespace nomad

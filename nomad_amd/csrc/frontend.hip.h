@@ -170,4 +170,31 @@ __global__ __launch_bounds__(256) void zero_pad_rows_kernel(T_* __restrict__ xg,
     }
 }
 
+// bf16x3 pos-conv as a dense GEMM (nomad_hip.hip, forward_x3_run): kPosBlk consecutive output frames of one group
+// become the N dimension.  Row (j, co) of the Toeplitz weight of group g is the filter of output channel co shifted
+// by j taps over a window of 128 + kPosBlk - 1 input frames:
+//   Wt[g][j * 48 + co][tap * 48 + ci] = pos_w[g][co][(tap - j) * 48 + ci]  for 0 <= tap - j < 128, else 0
+// (rows kPosBlk * 48 .. 255 are zero padding up to the 256-wide tile).  pos_w: [16][64][6144] as in the fp32 path.
+// grid: 16 * 256 blocks; output written as split planes.
+constexpr int kPosBlk = 5;
+constexpr int kPosKt = (128 + kPosBlk - 1) * 48;  // 6336
+__global__ __launch_bounds__(256) void posconv_toeplitz_kernel(const float* __restrict__ pos_w, bf16s_t* __restrict__ out,
+                                                               long long plane) {
+    const int g = blockIdx.x >> 8, r = blockIdx.x & 255;
+    const int j = r / 48, co = r - j * 48;
+    bf16s_t* o = out + ((long long)g * 256 + r) * kPosKt;
+    const float* w = pos_w + ((long long)g * 64 + co) * 6144;
+    for (int k4 = threadIdx.x; k4 < kPosKt / 4; k4 += 256) {
+        const int k = k4 * 4, tap = k / 48;  // 48 % 4 == 0: the four elements share their tap
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < kPosBlk && tap >= j && tap - j < 128) v = *reinterpret_cast<const float4*>(w + k - j * 48);
+        store4p<bf16s_t>(o + k, plane, v);
+    }
+}
+// bias tiled to the Toeplitz rows: bt[g][j * 48 + co] = pos_b[g * 48 + co], zero beyond kPosBlk * 48
+__global__ __launch_bounds__(256) void posconv_toeplitz_bias_kernel(const float* __restrict__ pos_b, float* __restrict__ bt) {
+    const int g = blockIdx.x, r = threadIdx.x;
+    bt[g * 256 + r] = r < kPosBlk * 48 ? pos_b[g * 48 + r % 48] : 0.f;
+}
+
 }  // namespace nomad

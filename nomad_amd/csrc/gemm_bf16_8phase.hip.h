@@ -82,7 +82,13 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p, const f32x4 (&a
                 const int id = lane + 64 * it, row = id >> 3, cg = id & 7;
                 const int m = m0 + wr * 128 + s4 * 32 + row;
                 const int n = n0 + wc * 64 + cg * 8;
-                if (m < p.M && n < p.n_valid) {
+                bool live = m < p.M && n < p.n_valid;
+                if (live && p.c_blk_step > 0) {  // column blocks are frames: drop those past the clip's end
+                    int li, frames;
+                    clip_pos(p.cmap, m, p.c_clip_frames, li, frames);
+                    live = li * p.c_blk_step + n / p.c_colblk < frames;
+                }
+                if (live) {
                     const f32x4 lo = *reinterpret_cast<const f32x4*>(slab + row * ELD + cg * 8);
                     const f32x4 hi = *reinterpret_cast<const f32x4*>(slab + row * ELD + cg * 8 + 4);
                     float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};

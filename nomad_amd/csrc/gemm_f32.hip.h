@@ -83,7 +83,29 @@ struct GemmParams {
     long long dg_goff;
     // bf16x3 path (gemm_bf16_8phase.hip.h, X3): element distance from the hi to the lo plane of A, W, C and R
     long long a_plane, w_plane, c_plane, r_plane;
+    // Column blocks that are FRAMES (bf16x3 pos-conv, p8_epilogue): with c_blk_step > 0 a row is a block of
+    // c_blk_step consecutive frames of its clip and column block b (of c_colblk columns) is frame
+    // local_row * c_blk_step + b, stored only while that is < the clip's frame count (c_clip_frames for uniform
+    // batches, cmap.base[c + 1] - cmap.base[c] for ragged ones).
+    int c_blk_step, c_clip_frames;
 };
+
+// (local row, frames of its clip) of logical row m under map r - see GemmParams::c_blk_step
+__device__ __forceinline__ void clip_pos(const RowMap& r, int m, int uniform_frames, int& local, int& frames) {
+    if (r.pref) {
+        int lo = 0, hi = r.nclips;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (r.pref[mid] <= m) lo = mid;
+            else hi = mid;
+        }
+        local = m - r.pref[lo];
+        frames = r.base[lo + 1] - r.base[lo];
+    } else {
+        local = m % r.clip_rows;
+        frames = uniform_frames;
+    }
+}
 
 __device__ __forceinline__ float dgelu_erf_(float u) {
     const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752440f));

@@ -283,11 +283,12 @@ struct nomad_ctx {
     bf16_t *proj_w16 = nullptr, *pos_w16 = nullptr;
     bf16_t *qkv_w16[NOMAD_NUM_LAYERS] = {}, *o_w16[NOMAD_NUM_LAYERS] = {}, *fc1_w16[NOMAD_NUM_LAYERS] = {},
            *fc2_w16[NOMAD_NUM_LAYERS] = {};
-    // split (hi | lo bf16 planes) weight copies for the bf16x3 path (built by nomad_enable_bf16x3); the grouped
-    // pos-conv stays on the fp32 kernel and uses pos_w
+    // split (hi | lo bf16 planes) weight copies for the bf16x3 path (built by nomad_enable_bf16x3)
     bool x3_ready = false;
     bf16s_t* conv_wx[7] = {};
     bf16s_t* proj_wx = nullptr;
+    bf16s_t* pos_wx = nullptr;   // Toeplitz form [16][256][kPosKt] (posconv_toeplitz_kernel)
+    float* pos_bx = nullptr;     // [16][256]
     bf16s_t *qkv_wx[NOMAD_NUM_LAYERS] = {}, *o_wx[NOMAD_NUM_LAYERS] = {}, *fc1_wx[NOMAD_NUM_LAYERS] = {},
             *fc2_wx[NOMAD_NUM_LAYERS] = {};
     // fine-tuning state (nomad_train_enable): master parameters, gradients, Adam moments; see ParamOffsets
@@ -875,15 +876,17 @@ struct RaggedShapes {
     int B = 0, max_l0 = 0, max_t = 0;
     long long rows[7] = {};   // total frames per conv level
     long long P = 0;          // total padded pos-conv frames, sum (T_c + 128)
-    std::vector<int> meta;    // [lens(B) | pref_0 (B+1) | ... | pref_6 (B+1) | ppref (B+1)]
+    long long blocks = 0;     // total pos-conv frame blocks, sum ceil(T_c / kPosBlk) (bf16x3 path)
+    std::vector<int> meta;    // [lens(B) | pref_0 (B+1) | ... | pref_6 (B+1) | ppref (B+1) | bpref (B+1)]
     size_t off_lens() const { return 0; }
     size_t off_pref(int i) const { return (size_t)B + (size_t)i * (B + 1); }
     size_t off_ppref() const { return (size_t)B + (size_t)7 * (B + 1); }
+    size_t off_bpref() const { return (size_t)B + (size_t)8 * (B + 1); }
 };
 
 static bool make_ragged(int B, const int* lens, RaggedShapes* r) {
     r->B = B;
-    r->meta.assign((size_t)B + 8 * (size_t)(B + 1), 0);
+    r->meta.assign((size_t)B + 9 * (size_t)(B + 1), 0);
     for (int c = 0; c < B; ++c) {
         Shapes sh;
         if (!make_shapes(1, lens[c], &sh)) return false;
@@ -894,6 +897,9 @@ static bool make_ragged(int B, const int* lens, RaggedShapes* r) {
         }
         r->meta[r->off_ppref() + c + 1] = r->meta[r->off_ppref() + c] + sh.T + 128;
         r->P += sh.T + 128;
+        const int nb = (sh.T + kPosBlk - 1) / kPosBlk;
+        r->meta[r->off_bpref() + c + 1] = r->meta[r->off_bpref() + c] + nb;
+        r->blocks += nb;
         r->max_l0 = sh.L[0] > r->max_l0 ? sh.L[0] : r->max_l0;
         r->max_t = sh.T > r->max_t ? sh.T : r->max_t;
     }
@@ -1324,9 +1330,9 @@ static int forward_bf16(nomad_ctx* c, const float* wav, int B, int n_samples, fl
 // ---- bf16x3 path: fp32-class results on the bf16 matrix cores ------------------------------------------------
 // Every dense / conv GEMM runs as three bf16 MFMA products over split operands (gemm_bf16_8phase.hip.h, X3), the
 // activations between them live as split planes (dtypes.hip.h) or fp32 - 4 bytes per element either way:
-//   conv0 -> split -> conv1..6 (split) -> LN -> split -> post_extract_proj -> fp32 (group-major, padded)
-//   -> grouped pos-conv on the fp32 kernel (N = 48 per group is no shape for a 256-wide tile) -> fp32 -> LN -> split
-//   per layer: QKV -> fp32 -> fp32 MFMA attention -> split -> out-proj (+ split residual) -> fp32 -> LN -> split
+//   conv0 -> split -> conv1..6 (split) -> LN -> split -> post_extract_proj -> split (group-major, padded)
+//   -> grouped pos-conv as a Toeplitz GEMM over blocks of 5 frames (N = 5 x 48 per group) -> fp32 -> LN -> split
+//   per layer: QKV -> split -> bf16x3 attention -> split -> out-proj (+ split residual) -> fp32 -> LN -> split
 //              -> fc1 + GELU -> split -> fc2 (+ split residual) -> fp32 -> LN -> split (fp32 after the last layer)
 // Accumulators, bias / GELU / residual, LayerNorm statistics, softmax and the head are fp32 as in the fp32 path.
 // One implementation serves equal-length batches and ragged ones: X3Geom carries the row maps of either.
@@ -1338,7 +1344,10 @@ struct X3Geom {
     int wav_ld = 0;              // samples between clips of the wav buffer
     int L0 = 0, T = 0;           // equal-length batches; 0 when ragged (the kernels read lens / prefixes instead)
     RowMap conv_amap[7];         // im2col rows of conv layer i over the output of layer i - 1
-    RowMap pad_map, pos_amap;    // proj output / pos-conv residual rows, pos-conv input rows (group-major, padded)
+    RowMap pad_map;              // post_extract_proj output rows in the group-major, padded pos-conv buffer
+    // pos-conv as a GEMM over blocks of kPosBlk frames: input rows, output rows (in y), residual rows
+    long long pos_blocks = 0;
+    RowMap pos_amap, pos_cmap, pos_rmap;
     double attn_flops = 0.0;
     const RaggedShapes* ragged = nullptr;
 };
@@ -1346,7 +1355,10 @@ struct X3Geom {
 struct X3Layout {
     size_t meta, stats, scale, shift, conva, convb, xpad, x, x2, y, qkv, ctxb, h, total;
     long long capa, capb;  // elements per plane of the two conv ping-pong buffers
+    long long xpad_plane;  // elements per plane of the padded pos-conv buffer (+ kXpadSlack zeroed elements: the last
+                           // frame block of a clip reads up to kPosBlk - 1 frames past the clip's padding)
 };
+constexpr int kXpadSlack = 256;
 
 static X3Layout make_x3_layout(const X3Geom& g) {
     X3Layout l{};
@@ -1365,7 +1377,8 @@ static X3Layout make_x3_layout(const X3Geom& g) {
     l.shift = take(sizeof(float) * 512 * g.B);
     l.conva = take(e * l.capa);
     l.convb = take(e * l.capb);
-    l.xpad = take(e * 768 * (size_t)g.pad_rows);
+    l.xpad_plane = 768LL * g.pad_rows + kXpadSlack;
+    l.xpad = take(e * (size_t)l.xpad_plane);
     l.x = take(e * 768 * M);
     l.x2 = take(e * 768 * M);
     l.y = take(e * 768 * M);
@@ -1388,7 +1401,11 @@ static X3Geom x3_geom_fixed(const Shapes& sh) {
     g.T = sh.T;
     for (int i = 1; i < 7; ++i) g.conv_amap[i] = RowMap{0, (long long)sh.L[i - 1] * 512, sh.L[i], kConvS[i] * 512};
     g.pad_map = RowMap{64LL * 48, (long long)(sh.T + 128) * 48, sh.T, 48};
-    g.pos_amap = RowMap{0, (long long)(sh.T + 128) * 48, sh.T, 48};
+    const int nb = (sh.T + kPosBlk - 1) / kPosBlk;
+    g.pos_blocks = (long long)sh.B * nb;
+    g.pos_amap = RowMap{0, (long long)(sh.T + 128) * 48, nb, kPosBlk * 48};
+    g.pos_rmap = RowMap{64LL * 48, (long long)(sh.T + 128) * 48, nb, kPosBlk * 48};
+    g.pos_cmap = RowMap{0, (long long)sh.T * 768, nb, kPosBlk * 768};
     g.attn_flops = 4.0 * sh.B * 12.0 * (double)sh.T * sh.T * 64;
     return g;
 }
@@ -1406,8 +1423,12 @@ static X3Geom x3_geom_ragged(const RaggedShapes& rs, int stride, const int* meta
     auto pref = [&](int i) { return meta ? meta + rs.off_pref(i) : nullptr; };
     const int* ppref = meta ? meta + rs.off_ppref() : nullptr;
     for (int i = 1; i < 7; ++i) g.conv_amap[i] = RowMap{0, 0, 0, kConvS[i] * 512, pref(i), pref(i - 1), rs.B, 512};
+    const int* bpref = meta ? meta + rs.off_bpref() : nullptr;
     g.pad_map = RowMap{64LL * 48, 0, 0, 48, pref(6), ppref, rs.B, 48};
-    g.pos_amap = RowMap{0, 0, 0, 48, pref(6), ppref, rs.B, 48};
+    g.pos_blocks = rs.blocks;
+    g.pos_amap = RowMap{0, 0, 0, kPosBlk * 48, bpref, ppref, rs.B, 48};
+    g.pos_rmap = RowMap{64LL * 48, 0, 0, kPosBlk * 48, bpref, ppref, rs.B, 48};
+    g.pos_cmap = RowMap{0, 0, 0, kPosBlk * 768, bpref, pref(6), rs.B, 768};
     for (int i = 0; i < rs.B; ++i) {
         const double t = rs.meta[rs.off_pref(6) + i + 1] - rs.meta[rs.off_pref(6) + i];
         g.attn_flops += 4.0 * 12.0 * t * t * 64;
@@ -1486,44 +1507,59 @@ static int forward_x3_run(nomad_ctx* c, const float* wav, const X3Geom& g, const
         hipLaunchKernelGGL((layernorm_kernel<2, bf16s_t, bf16s_t>), dim3((M + 3) / 4), dim3(256), 0, s, conv6, c->fln_w,
                            c->fln_b, featln, static_cast<float*>(nullptr), M, cap[0], cap[1]);
     }
-    float* xpad = F(lay.xpad);
+    bf16s_t* xpad = S(lay.xpad);
     const long long grp_stride = g.pad_rows * 48;
     {
         Scope sc(c, s, NOMAD_K_ROW, 0.0);
-        hipLaunchKernelGGL(zero_pad_rows_kernel<float>, dim3(16 * B), dim3(256), 0, s, xpad, g.T, tpref, ppref, B);
+        for (int pl = 0; pl < 2; ++pl) {  // the padding frames (and the slack behind them) are zero in both planes
+            bf16_t* plane = reinterpret_cast<bf16_t*>(xpad) + pl * lay.xpad_plane;
+            hipLaunchKernelGGL(zero_pad_rows_kernel<bf16_t>, dim3(16 * B), dim3(256), 0, s, plane, g.T, tpref, ppref, B);
+            HIP_TRY(hipMemsetAsync(plane + 768LL * g.pad_rows, 0, kXpadSlack * sizeof(bf16_t), s));
+        }
     }
     {
-        GemmParams p = dense_x3(featln, cap[1], 512, c->proj_wx, c->proj_b, nullptr, 0, xpad, 0, M, 768, 512, 0);
+        GemmParams p = dense_x3(featln, cap[1], 512, c->proj_wx, c->proj_b, nullptr, 0, xpad, lay.xpad_plane, M, 768, 512, 0);
         p.cmap = g.pad_map;
         p.c_colblk = 48;
         p.c_colblk_stride = grp_stride;
-        if ((rc = run_gemm_bf16(c, p, 1, s, kX3F32))) return rc;
+        if ((rc = run_gemm_bf16(c, p, 1, s, kX3Split))) return rc;
     }
     bf16s_t *x = S(lay.x), *x2 = S(lay.x2), *ctxb = S(lay.ctxb), *hb = S(lay.h);
-    float *y = F(lay.y), *qkv = F(lay.qkv);
-    {   // grouped pos-conv, fp32 kernel and weights: x + gelu(conv + bias)
+    float* y = F(lay.y);
+    bf16s_t* qkv = S(lay.qkv);
+    const long long pl2304 = 2304LL * M;
+    {   // grouped pos-conv, x + gelu(conv + bias), as 16 dense GEMMs over blocks of kPosBlk frames:
+        // row = (clip, block i): the 132 padded input frames from 5 i on (contiguous in the group-major buffer);
+        // column (j, co) = output frame 5 i + j, channel co of the group (Toeplitz weight, posconv_toeplitz_kernel)
         GemmParams p{};
-        p.A = xpad;
+        p.A = reinterpret_cast<const float*>(xpad);
+        p.a_plane = lay.xpad_plane;
         p.amap = g.pos_amap;
         p.a_goff = grp_stride;
-        p.K = 6144;
-        p.kchunk = 6144;
-        p.W = c->pos_w;
-        p.ldw = 6144;
-        p.w_goff = 64LL * 6144;
-        p.bias = c->pos_b;
-        p.bias_goff = 48;
+        p.K = kPosKt;
+        p.kchunk = kPosKt;
+        p.W = reinterpret_cast<const float*>(c->pos_wx);
+        p.w_plane = 16LL * 256 * kPosKt;
+        p.ldw = kPosKt;
+        p.w_goff = 256LL * kPosKt;
+        p.bias = c->pos_bx;
+        p.bias_goff = 256;
         p.C = y;
-        p.cmap = plain_map(M, 768);
+        p.cmap = g.pos_cmap;
         p.c_goff = 48;
-        p.R = xpad;
-        p.rmap = g.pad_map;
+        p.c_colblk = 48;
+        p.c_colblk_stride = 768;   // column block j = the next frame's row of y
+        p.c_blk_step = kPosBlk;
+        p.c_clip_frames = g.T;
+        p.R = reinterpret_cast<const float*>(xpad);   // residual: frame 64 + 5 i + j of the same buffer = rmap(row) + j * 48 + co
+        p.r_plane = lay.xpad_plane;
+        p.rmap = g.pos_rmap;
         p.r_goff = grp_stride;
-        p.M = M;
-        p.N = 64;
-        p.n_valid = 48;
+        p.M = (int)g.pos_blocks;
+        p.N = 256;
+        p.n_valid = kPosBlk * 48;
         p.gelu = 1;
-        if ((rc = run_gemm(c, p, 16, 48, s))) return rc;
+        if ((rc = run_gemm_bf16(c, p, 16, s, kX3F32))) return rc;
     }
     auto ln = [&](const float* in, const float* gm, const float* bt, bf16s_t* out) {
         Scope sc(c, s, NOMAD_K_ROW, 0.0);
@@ -1533,12 +1569,12 @@ static int forward_x3_run(nomad_ctx* c, const float* wav, const X3Geom& g, const
     ln(y, c->eln_w, c->eln_b, x);
     for (int l = 0; l < NOMAD_NUM_LAYERS; ++l) {
         const LayerDev& d = c->layers[l];
-        if ((rc = run_gemm_bf16(c, dense_x3(x, pl768, 768, c->qkv_wx[l], d.qkv_b, nullptr, 0, qkv, 0, M, 2304, 768, 0), 1, s, kX3F32)))
+        if ((rc = run_gemm_bf16(c, dense_x3(x, pl768, 768, c->qkv_wx[l], d.qkv_b, nullptr, 0, qkv, pl2304, M, 2304, 768, 0), 1, s, kX3Split)))
             return rc;
         {
             Scope sc(c, s, NOMAD_K_ATTN, g.attn_flops);
-            hipLaunchKernelGGL((attention_f32_kernel<float, false, bf16s_t>), dim3((g.max_t + 63) / 64, B * 12), dim3(256), 0, s,
-                               qkv, ctxb, static_cast<float*>(nullptr), g.T, tpref, DropCfg{}, 0u, 0, pl768);
+            hipLaunchKernelGGL(attention_x3_kernel, dim3((g.max_t + 63) / 64, B * 12), dim3(256), 0, s, qkv, pl2304, ctxb, pl768,
+                               g.T, tpref);
         }
         if ((rc = run_gemm_bf16(c, dense_x3(ctxb, pl768, 768, c->o_wx[l], d.o_b, x, pl768, y, 0, M, 768, 768, 0), 1, s, kX3F32)))
             return rc;
@@ -1825,6 +1861,20 @@ int nomad_enable_bf16x3(nomad_ctx* c) {
     for (int i = 1; i < 7; ++i)
         if ((rc = conv(c->conv_w[i], (size_t)512 * kConvK[i] * 512, &c->conv_wx[i]))) return rc;
     if ((rc = conv(c->proj_w, (size_t)768 * 512, &c->proj_wx))) return rc;
+    {
+        const size_t n = (size_t)16 * 256 * kPosKt;
+        if (!c->pos_wx) {
+            void* d = nullptr;
+            HIP_TRY(hipMalloc(&d, 2 * n * sizeof(bf16_t)));
+            c->allocs.push_back(d);
+            c->pos_wx = static_cast<bf16s_t*>(d);
+            HIP_TRY(hipMalloc(&d, 16 * 256 * sizeof(float)));
+            c->allocs.push_back(d);
+            c->pos_bx = static_cast<float*>(d);
+        }
+        hipLaunchKernelGGL(posconv_toeplitz_kernel, dim3(16 * 256), dim3(256), 0, 0, c->pos_w, c->pos_wx, (long long)n);
+        hipLaunchKernelGGL(posconv_toeplitz_bias_kernel, dim3(16), dim3(256), 0, 0, c->pos_b, c->pos_bx);
+    }
     for (int l = 0; l < NOMAD_NUM_LAYERS; ++l) {
         const LayerDev& d = c->layers[l];
         if ((rc = conv(d.qkv_w, (size_t)2304 * 768, &c->qkv_wx[l]))) return rc;
@@ -1873,6 +1923,16 @@ int nomad_diag_split_bf16(nomad_ctx* c, const float* in, void* out, long long pl
                            static_cast<float*>(out), n / 4);
     else
         hipLaunchKernelGGL(split_bf16_kernel, dim3(1024), dim3(256), 0, s, in, static_cast<bf16s_t*>(out), plane, n / 4);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int nomad_diag_attention_bf16x3(nomad_ctx* c, const void* qkv, void* out, int B, int T, nomad_stream_t stream) {
+    if (!c || !qkv || !out || B <= 0 || T <= 0) return fail(NOMAD_ERR_INVALID, "nomad_diag_attention_bf16x3: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Scope sc(c, s, NOMAD_K_ATTN, 4.0 * B * 12.0 * (double)T * T * 64);
+    hipLaunchKernelGGL(attention_x3_kernel, dim3((T + 63) / 64, B * 12), dim3(256), 0, s, static_cast<const bf16s_t*>(qkv),
+                       (long long)B * T * 2304, static_cast<bf16s_t*>(out), (long long)B * T * 768, T, kNoInts);
     HIP_TRY(hipGetLastError());
     return 0;
 }

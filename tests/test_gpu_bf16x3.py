@@ -84,6 +84,25 @@ def test_gemm_bf16x3_vs_float64(engine, M, N, K, epi, out_f32, kernel):
     assert err < 3e-5 * max(1.0, ref.abs().max().item()), err
 
 
+@pytest.mark.parametrize("B,T", [(2, 50), (1, 64), (1, 65), (3, 199), (1, 330), (1, 1)])
+@pytest.mark.parametrize("gain", [1.0, 6.0, 40.0])
+def test_attention_bf16x3(engine, B, T, gain):
+    """Split-operand attention against float64: logits up to a few hundred (gain 40) still come out to ~1e-5."""
+    g = torch.Generator().manual_seed(T)
+    qkv = torch.randn(B * T, 2304, generator=g)
+    qkv[:, :1536] *= (gain ** 0.5) * 0.35
+    q, k, v = (qkv[:, i * 768:(i + 1) * 768].double().view(B, T, 12, 64).transpose(1, 2) for i in range(3))
+    ref = (torch.softmax(q @ k.transpose(-1, -2), -1) @ v).transpose(1, 2).reshape(B * T, 768)
+    out = engine.diag_unsplit_bf16(engine.diag_attention_bf16x3(engine.diag_split_bf16(qkv.cuda()), B, T)).cpu()
+    assert torch.isfinite(out).all()
+    err = (out.double() - ref).abs().max().item()
+    f32 = engine.diag_attention(qkv.cuda(), B, T).cpu() if hasattr(engine, "diag_attention") else None
+    e32 = (f32.double() - ref).abs().max().item() if f32 is not None else float("nan")
+    print(f"attention bf16x3 B={B} T={T} gain={gain}: max|err| {err:.2e} (fp32 kernel {e32:.2e})")
+    # the split products put ~2^-16 relative noise on the logits: 15-20x the fp32 kernel's error, which grows with the logits too
+    assert err < max(2e-5, 30 * e32) * max(1.0, ref.abs().max().item()), err
+
+
 def test_embed_bf16x3_vs_fp32_path(engine):
     gen = torch.Generator().manual_seed(0)
     wav = (0.1 * torch.randn(8, 64000, generator=gen)).clamp(-1, 1).cuda()
@@ -111,6 +130,18 @@ def test_embed_bf16x3_vs_oracle_scores(engine, sd0):
     d_ref, m_ref = O.pairwise(ref[:3].numpy(), ref[3:].numpy())
     d, m = O.pairwise(ex3[:3].numpy(), ex3[3:].numpy())
     assert abs(d - d_ref).max() < 1e-4 / 4
+
+
+@pytest.mark.parametrize("n_samples", [400, 16000, 16080, 16400, 16720, 17040, 17360, 40000])
+def test_embed_bf16x3_frame_counts(engine, n_samples):
+    """Frame counts in every residue class modulo the pos-conv's 5-frame blocks (T = 1, 49, 50, 51, 52, 53, 54, 124):
+    the last block's surplus frames must not be stored, its reads past the clip's padding must be harmless."""
+    gen = torch.Generator().manual_seed(n_samples)
+    wav = (0.1 * torch.randn(3, n_samples, generator=gen)).clamp(-1, 1).cuda()
+    e32 = engine.embed(wav)
+    ex3 = engine.embed_bf16x3(wav)
+    assert torch.isfinite(ex3).all()
+    assert (ex3 - e32).abs().max().item() < (1e-4 if n_samples == 400 else 1e-5)   # one frame: no time averaging
 
 
 def test_embed_bf16x3_batch_invariance_and_repeat(engine):
