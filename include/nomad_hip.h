@@ -232,8 +232,9 @@ int nomad_embed_ragged_bf16(nomad_ctx* ctx, const float* wav_dev, int B, int str
  * Same surface as nomad_embed (TripletModel.forward, nomad.py:224-231), for callers who want the reference's
  * scores to its stated tolerance (1e-4) at more than the fp32 MFMA rate.  Every GEMM operand is kept as two bf16
  * planes, hi = bf16(x) and lo = bf16(x - hi) (16 mantissa bits, the bytes of one fp32), and multiplied as three
- * bf16 MFMA products hi*hi + hi*lo + lo*hi with fp32 accumulation; bias, GELU, residuals, LayerNorm, the attention
- * (fp32 MFMA) and the head are fp32.  Accuracy is measured against the fp32 path in tests/test_gpu_bf16x3.py
+ * bf16 MFMA products hi*hi + hi*lo + lo*hi with fp32 accumulation - the conv stack, every dense layer, the grouped
+ * pos-conv (as a Toeplitz GEMM over 5-frame blocks) and both attention products; bias, GELU, residuals, LayerNorm,
+ * softmax and the head are fp32.  Accuracy is measured against the fp32 path in tests/test_gpu_bf16x3.py
  * (NOMAD scores agree to ~1e-6).  Scoring only: no layer outputs, no backward.
  *   nomad_enable_bf16x3          builds the split weight copies (allocates once; call again after nomad_train_* /
  *                                weight updates)
