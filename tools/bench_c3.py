@@ -21,6 +21,7 @@ from nomad_amd.engine import Engine  # noqa: E402
 from nomad_amd.weights import seeded_state_dict  # noqa: E402
 
 N_DEG, N_REF, N_SAMPLES, BATCH = int(os.environ.get("C3_DEG", 10000)), int(os.environ.get("C3_REF", 1000)), 64000, 256
+PRECISION = os.environ.get("C3_PRECISION", "fp32")   # fp32 | bf16x3 | bf16
 
 
 def embed_range(eng, start, stop, seed_base):
@@ -29,7 +30,7 @@ def embed_range(eng, start, stop, seed_base):
         n = min(BATCH, stop - s)
         g = torch.Generator(device="cuda").manual_seed(seed_base + s)       # clip content depends on the global index only
         wav = (0.1 * torch.randn(n, N_SAMPLES, generator=g, device="cuda")).clamp(-1, 1)
-        out.append(eng.embed(wav))
+        out.append({"fp32": eng.embed, "bf16x3": eng.embed_bf16x3, "bf16": eng.embed_bf16}[PRECISION](wav))
     return torch.cat(out) if out else torch.empty(0, 256, device="cuda")
 
 
@@ -41,7 +42,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     eng = Engine(seeded_state_dict(0), local)
-    eng.embed(torch.zeros(BATCH, N_SAMPLES, device="cuda"))                  # warm-up (workspace, clocks)
+    embed_range(eng, 0, BATCH, 3_000_000)                                    # warm-up (workspace, weight copies, clocks)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -59,7 +60,7 @@ def main():
     dt = time.perf_counter() - t0
     if rank == 0:
         assert scores.shape == (N_DEG,) and torch.isfinite(scores).all() and ref_all.shape == (N_REF, 256)
-        print(json.dumps({"config": f"C3: {N_DEG} deg x {N_REF} ref, 16 kHz x 4 s, fp32, clip-sharded x{world}",
+        print(json.dumps({"config": f"C3: {N_DEG} deg x {N_REF} ref, 16 kHz x 4 s, {PRECISION}, clip-sharded x{world}",
                           "n_gpus": world, "seconds": round(dt, 3), "clips_per_s": round((N_DEG + N_REF) / dt, 1),
                           "pairs": N_DEG * N_REF, "scaling": "strong",
                           "score_mean": float(scores.mean()), "score_min": float(scores.min())}))
