@@ -83,7 +83,7 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p, const f32x4 (&a
                 const int m = m0 + wr * 128 + s4 * 32 + row;
                 const int n = n0 + wc * 64 + cg * 8;
                 bool live = m < p.M && n < p.n_valid;
-                if (live && p.c_blk_step > 0) {  // column blocks are frames: drop those past the clip's end
+                if (live && p.c_blk_step > 0 && p.c_colblk > 0) {  // column blocks are frames: drop those past the clip's end
                     int li, frames;
                     clip_pos(p.cmap, m, p.c_clip_frames, li, frames);
                     live = li * p.c_blk_step + n / p.c_colblk < frames;
