@@ -1939,10 +1939,13 @@ int nomad_diag_attention_bf16x3(nomad_ctx* c, const void* qkv, void* out, int B,
 
 int nomad_diag_gemm_bf16x3(nomad_ctx* c, const void* A, const void* W, const float* bias, const void* R, void* C, int M,
                            int N, int K, int gelu, int out_f32, nomad_stream_t stream) {
-    if (!c || !A || !W || !C || M <= 0 || N % 256 || K % ((out_f32 == 12 || out_f32 == 13) ? 192 : out_f32 >= 7 ? 64 : 128))
+    if (!c || !A || !W || !C || M <= 0 || N % 256 || K % ((out_f32 % 100 == 12 || out_f32 % 100 == 13) ? 192 : out_f32 % 100 >= 7 ? 64 : 128))
         return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16x3: bad argument (N %% 256, K %% 128; K %% 64 for the staged kernel)");
+    const int group_m = out_f32 / 100;  // measurement knob: variant + 100 * group_m (tile_coords)
+    out_f32 %= 100;
     GemmParams p = dense_x3(static_cast<const bf16s_t*>(A), (long long)M * K, K, static_cast<const bf16s_t*>(W), bias,
                             static_cast<const bf16s_t*>(R), (long long)M * N, C, (long long)M * N, M, N, K, gelu);
+    p.group_m = group_m;
     return run_gemm_bf16(c, p, 1, static_cast<hipStream_t>(stream), 20 + (out_f32 < 0 ? 0 : out_f32 > 13 ? 13 : out_f32));
 }
 

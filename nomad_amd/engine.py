@@ -266,7 +266,7 @@ class Engine:
         probes with fp32 output."""
         if variant is None:
             variant = 8 if out_f32 else 7
-        out_f32 = variant not in (0, 7, 12)
+        out_f32 = variant % 100 not in (0, 7, 12)
         _, M, K = A.shape
         N = W.shape[1]
         if out is None:
