@@ -160,12 +160,18 @@ class _NomadLossFn(torch.autograd.Function):
         return dwav.reshape(ctx.shape), None, None
 
 
+# precision="bf16x3" pays off from about 8 clips of 4 s per batch (measured on MI355X, profiles/r01_bf16x3_small_batch.txt:
+# 2 clips 5.1 ms vs 3.2 ms in fp32, 8 clips 5.4 vs 6.1 ms, 32 clips 8.1 vs 17.3 ms); smaller batches take the fp32 path.
+BF16X3_MIN_SAMPLES = 8 * 64000
+
+
 class Nomad:
     def __init__(self, device=None, weights: Union[None, str, Dict[str, torch.Tensor]] = None, precision: str = "fp32"):
         """precision of the embeddings of ``predict`` / ``get_embeddings*``:
         "fp32"   the reference's arithmetic (fp32 MFMA), scores within 1e-4 of the reference;
         "bf16x3" GEMM operands split into hi + lo bf16 planes, three bf16 MFMA products per fp32 product, fp32
-                 accumulation / attention / norms: scores within ~1e-6 of the fp32 path, more than twice as fast;
+                 accumulation / softmax / norms: scores within ~1e-6 of the fp32 path, 2.7x as fast on full batches
+                 (batches of fewer than BF16X3_MIN_SAMPLES samples run the fp32 path, which is faster there);
         "bf16"   bf16 storage, fp32 accumulation: scores within ~5e-4 of fp32, fastest on long recordings.
         ``forward()`` (the training loss) is always fp32."""
         if precision not in ("fp32", "bf16x3", "bf16"):
@@ -295,7 +301,10 @@ class Nomad:
         if batch:
             batches.append(batch)
         for idxs in batches:
-            emb = self.engine.embed_ragged([waves[i][0] for i in idxs], precision=self.precision)
+            prec = self.precision
+            if prec == "bf16x3" and sum(int(waves[i].shape[1]) for i in idxs) < BF16X3_MIN_SAMPLES:
+                prec = "fp32"   # a handful of files does not fill the 256 x 256 tiles: the exact path is also the faster one
+            emb = self.engine.embed_ragged([waves[i][0] for i in idxs], precision=prec)
             embeddings[idxs] = emb.cpu().numpy()
         emb_df = pd.DataFrame(embeddings)
         df_emb = pd.concat([file_names.reset_index(), emb_df], axis=1).drop("index", axis=1)

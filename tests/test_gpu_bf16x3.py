@@ -199,6 +199,22 @@ def test_predict_in_bf16x3_precision(built_lib):
     assert abs(ax3.values[:, -1].astype(float) - a32.values[:, -1].astype(float)).max() <= 1e-3 + 1e-9
 
 
+def test_predict_bf16x3_small_batches_take_the_fp32_path(built_lib, monkeypatch):
+    """Six example files are far below BF16X3_MIN_SAMPLES: Nomad(precision='bf16x3') embeds them on the fp32 path (bit-equal
+    embeddings); with the threshold lowered the same call runs the split-operand kernels (close, not equal)."""
+    import os
+    import numpy as np
+    from conftest import GOLD
+    import nomad_amd.nomad as NM
+    nmr = os.path.join(GOLD, "wavs", "nmr-data")
+    e32 = NM.Nomad(weights="seeded").get_embeddings(nmr).iloc[:, 1:].values.astype(np.float32)
+    ex3 = NM.Nomad(weights="seeded", precision="bf16x3").get_embeddings(nmr).iloc[:, 1:].values.astype(np.float32)
+    assert np.array_equal(e32, ex3)
+    monkeypatch.setattr(NM, "BF16X3_MIN_SAMPLES", 0)
+    ex3b = NM.Nomad(weights="seeded", precision="bf16x3").get_embeddings(nmr).iloc[:, 1:].values.astype(np.float32)
+    assert not np.array_equal(e32, ex3b) and np.abs(e32 - ex3b).max() < 1e-5
+
+
 def test_bf16x3_follows_weight_updates(built_lib, sd0):
     """The split weight copies are rebuilt after the master weights change (fine-tuning, nomad_train_write)."""
     from nomad_amd.engine import Engine
