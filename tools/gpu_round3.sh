@@ -13,7 +13,7 @@ cat $OUT/bench_torchrun.json; tail -n 3 $OUT/bench_torchrun.err
 # HBM traffic of the bench kernels: separate PMC passes (FETCH_SIZE / WRITE_SIZE do not fit one pass)
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $ROOTDIR/$OUT/pmc_$c -o p -- python3 $ROOTDIR/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile > $ROOTDIR/$OUT/pmc_$c.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $ROOTDIR/$OUT/pmc_$c -o p -- python3 $ROOTDIR/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-also > $ROOTDIR/$OUT/pmc_$c.log 2>&1
   echo "pmc $c exit $?" | tee -a $ROOTDIR/$OUT/summary.txt
 done
 cd $ROOTDIR
