@@ -1,0 +1,45 @@
+"""GPU: bench.py prints exactly one JSON line with the driver's contract fields (small sizes; the numbers are not checked)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, launcher=()):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, *launcher, os.path.join(ROOT, "bench.py"), *args], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, res.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract():
+    out = _run(["--steps", "2", "--warmup", "1", "--batch", "16", "--refs", "4", "--no-cpu-baseline"])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in out, key
+    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1 and out["unit"] == "clips/s"
+    assert out["dtype"] == "f32" and out["higher_is_better"] is True and out["scaling"] == "weak" and out["vs_baseline"] is None
+    assert "workload" in out["config"] and "model" not in out["config"]
+    r = out["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(out["value"] - 16 * 2 / (out["ms_per_step"] * 2e-3)) / out["value"] < 1e-3
+    also = out["also_measured"]
+    assert also["unit"] == "clips/s" and also["value"] > 0 and also["max_abs_score_diff_vs_f32"] < 1e-4
+
+
+def test_bench_under_the_distributed_launcher():
+    """The way the driver starts it for N > 1, with N = 1 (one GPU on the box)."""
+    out = _run(["--gpus", "1", "--steps", "1", "--warmup", "1", "--batch", "8", "--refs", "2", "--no-cpu-baseline", "--no-also"],
+               launcher=("-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                         "--master-port", "29541"))
+    assert out["n_gpus"] == 1 and out["steps"] == 1 and "also_measured" not in out
