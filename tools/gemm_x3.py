@@ -22,7 +22,7 @@ def main():
     res = []
     for sname in a.shapes.split(","):
         M, N, K, has_b, gelu, has_r = SHAPES[sname]
-        A = eng.diag_split_bf16(torch.randn(M, K, generator=g).cuda())
+        A = eng.diag_split_bf16(torch.randn(M, K, device="cuda") if M * K > 5e8 else torch.randn(M, K, generator=g).cuda())
         W = eng.diag_split_bf16((torch.randn(N, K, generator=g) * K ** -0.5).cuda())
         b = torch.randn(N, generator=g).cuda() if has_b else None
         R = eng.diag_split_bf16(torch.randn(M, N, generator=g).cuda()) if has_r else None
