@@ -3,6 +3,8 @@ allocates, and launches on torch's current HIP stream.  PyTorch is plumbing here
 torch.distributed); every FLOP of the NOMAD path runs in libnomad_hip.so."""
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from typing import Dict, Optional, Tuple
 
@@ -231,18 +233,40 @@ class Engine:
         return emb
 
     # ---- bf16x3 path: fp32-class scores on the bf16 matrix cores ---------------------------------------
+    # Batches with at least this many frames (rows of the encoder GEMMs) are embedded as two halves on two streams: the
+    # path's kernels run one 256 x 256 workgroup per CU, and e.g. the N = 768 GEMMs of a 256-clip batch are 2.33 rounds of
+    # the 256 CUs - the other half's kernels fill the idle third round (+4 % at 256 clips of 4 s, +14 % at 128, break-even at 16; bit-identical results:
+    # profiles/r01_bf16x3_two_streams.txt).  NOMAD_X3_SPLIT_ROWS overrides; 0 disables.
+    X3_SPLIT_ROWS = int(os.environ.get("NOMAD_X3_SPLIT_ROWS", 4000))
+
+    def _embed_bf16x3_into(self, wav: torch.Tensor, emb: torch.Tensor, side: bool):
+        B, N = wav.shape
+        ws = self._workspace(self._size(self.lib.nomad_workspace_bytes_bf16x3, B, N, "nomad_workspace_bytes_bf16x3"), side=side)
+        _lib.check(self.lib.nomad_embed_bf16x3(self.ctx, wav.data_ptr(), B, N, emb.data_ptr(), ws.data_ptr(), ws.numel(),
+                                               self._stream()), "nomad_embed_bf16x3")
+
     def embed_bf16x3(self, wav: torch.Tensor) -> torch.Tensor:
         """Scoring forward whose GEMMs run as three bf16 MFMA products over hi/lo-split operands (fp32 accumulation,
-        fp32 attention / LayerNorm / head): NOMAD scores agree with the fp32 path to ~1e-6."""
+        fp32 softmax / LayerNorm / head): NOMAD scores agree with the fp32 path to ~1e-6."""
         if wav.dim() == 3:
             wav = wav.squeeze(1)
         self._check_dev(wav, "wav")
+        if not wav.is_contiguous():
+            wav = wav.contiguous()
         B, N = wav.shape
         _lib.check(self.lib.nomad_enable_bf16x3(self.ctx), "nomad_enable_bf16x3")
-        ws = self._workspace(self._size(self.lib.nomad_workspace_bytes_bf16x3, B, N, "nomad_workspace_bytes_bf16x3"))
         emb = torch.empty(B, 256, dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.nomad_embed_bf16x3(self.ctx, wav.data_ptr(), B, N, emb.data_ptr(), ws.data_ptr(), ws.numel(),
-                                               self._stream()), "nomad_embed_bf16x3")
+        rows = B * int(self.lib.nomad_num_frames(N))
+        if B < 2 or not self.X3_SPLIT_ROWS or rows < self.X3_SPLIT_ROWS:
+            self._embed_bf16x3_into(wav, emb, side=False)
+            return emb
+        h = B // 2
+        cur, side = torch.cuda.current_stream(self.device), self.side_stream()
+        side.wait_stream(cur)                      # the waveform (and anything queued before) is ready
+        with torch.cuda.stream(side):
+            self._embed_bf16x3_into(wav[h:], emb[h:], side=True)
+        self._embed_bf16x3_into(wav[:h], emb[:h], side=False)
+        cur.wait_stream(side)
         return emb
 
     def diag_split_bf16(self, x: torch.Tensor) -> torch.Tensor:

@@ -12,8 +12,15 @@ g = torch.Generator().manual_seed(0)
 wav = (0.1 * torch.randn(256, 64000, generator=g)).clamp(-1, 1).cuda()
 st = [torch.cuda.Stream(), torch.cuda.Stream()]
 
+MODE = sys.argv[1] if len(sys.argv) > 1 else "fp32"   # fp32 | bf16x3
+
+
+def emb(eng, w):
+    return eng.embed_bf16x3(w) if MODE == "bf16x3" else eng.embed(w)
+
+
 def single():
-    return e[0].embed(wav)
+    return emb(e[0], wav)
 
 def dual(parts=2):
     outs = []
@@ -23,7 +30,7 @@ def dual(parts=2):
         s = st[i % 2]
         s.wait_stream(cur)
         with torch.cuda.stream(s):
-            outs.append(e[i % 2].embed(wav[i * chunk:(i + 1) * chunk]))
+            outs.append(emb(e[i % 2], wav[i * chunk:(i + 1) * chunk]))
     for s in st:
         cur.wait_stream(s)
     return torch.cat(outs)
