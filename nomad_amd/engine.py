@@ -132,14 +132,36 @@ class Engine:
             hw, hb = head
             self._check_dev(hw, "head weight")
             self._check_dev(hb, "head bias")
-        nbytes = self.workspace_bytes(B, N)
-        ws = self._workspace(nbytes, side)
-        _lib.check(self.lib.nomad_embed(self.ctx, wav.data_ptr(), B, N,
-                                        hw.data_ptr() if hw is not None else None,
-                                        hb.data_ptr() if hb is not None else None,
-                                        emb.data_ptr(), layers.data_ptr() if layers is not None else None,
-                                        ws.data_ptr(), ws.numel(), self._stream()), "nomad_embed")
+
+        def run(w, e, use_side):
+            b = w.shape[0]
+            ws = self._workspace(self.workspace_bytes(b, N), use_side)
+            _lib.check(self.lib.nomad_embed(self.ctx, w.data_ptr(), b, N,
+                                            hw.data_ptr() if hw is not None else None,
+                                            hb.data_ptr() if hb is not None else None,
+                                            e.data_ptr(), layers.data_ptr() if layers is not None else None,
+                                            ws.data_ptr(), ws.numel(), self._stream()), "nomad_embed")
+
+        if side or want_layers or B < 2 or not (self.F32_SPLIT_ROWS <= B * T < self.F32_SPLIT_MAX_ROWS):
+            run(wav, emb, side)
+        else:
+            # two halves on two streams: each half's kernels fill the CUs the other's partial last round of tiles leaves
+            # idle (every instantiation contracts k in the same order, so the halves' bits equal the whole batch's)
+            h = B // 2
+            cur, ss = torch.cuda.current_stream(self.device), self.side_stream()
+            ss.wait_stream(cur)
+            with torch.cuda.stream(ss):
+                run(wav[h:], emb[h:], True)
+            run(wav[:h], emb[:h], False)
+            cur.wait_stream(ss)
         return (emb, layers) if want_layers else emb
+
+    # Plain scoring batches of F32_SPLIT_ROWS <= frames < F32_SPLIT_MAX_ROWS run as two halves on two streams:
+    # +7.6 % at 32 clips of 4 s, +4 % at 64, +5 % at 128 (profiles/r01_f32_two_streams.txt).  At 256 clips (the bench
+    # workload, 50 944 frames) the gain is 0.75 % and the overlapping launches would blur the per-kernel timings the
+    # roofline is computed from, so full batches stay on one stream.  NOMAD_F32_SPLIT_ROWS / _MAX_ROWS override.
+    F32_SPLIT_ROWS = int(os.environ.get("NOMAD_F32_SPLIT_ROWS", 4000))
+    F32_SPLIT_MAX_ROWS = int(os.environ.get("NOMAD_F32_SPLIT_MAX_ROWS", 40000))
 
     def embed_ragged(self, waves, head: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, bf16: bool = False,
                      precision: Optional[str] = None) -> torch.Tensor:
