@@ -305,7 +305,10 @@ struct nomad_ctx {
     int branches = 1;
     unsigned branch_mask[4] = {0xFFFu, 0xFFFu, 0xFFFu, 0xFFFu};
     std::vector<void*> allocs;
-    std::vector<int> ragged_meta;  // host copy of the last ragged batch's metadata (source of an async H2D copy)
+    // host copies of the last ragged batches' metadata (sources of asynchronous H2D copies); a ring, so that two
+    // forwards enqueued back to back on different streams do not share a staging vector
+    std::vector<int> ragged_meta_ring[4];
+    unsigned ragged_seq = 0;
     // profiling
     bool prof = false;
     hipEvent_t ev[kMaxEvents];
@@ -951,8 +954,9 @@ static int forward_ragged(nomad_ctx* c, const float* wav, int B, int stride, con
     char* ws = static_cast<char*>(workspace);
     auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     int* meta = reinterpret_cast<int*>(ws + lay.meta);
-    c->ragged_meta = rs.meta;  // must outlive the asynchronous copy
-    HIP_TRY(hipMemcpyAsync(meta, c->ragged_meta.data(), sizeof(int) * rs.meta.size(), hipMemcpyHostToDevice, s));
+    std::vector<int>& staged = c->ragged_meta_ring[c->ragged_seq++ & 3];  // must outlive the asynchronous copy
+    staged = rs.meta;
+    HIP_TRY(hipMemcpyAsync(meta, staged.data(), sizeof(int) * rs.meta.size(), hipMemcpyHostToDevice, s));
     const int* lens = meta + rs.off_lens();
     auto pref = [&](int i) { return static_cast<const int*>(meta + rs.off_pref(i)); };
     const int* tpref = pref(6);
@@ -1622,8 +1626,9 @@ static int forward_ragged_x3(nomad_ctx* c, const float* wav, int B, int stride, 
     hipStream_t s = static_cast<hipStream_t>(stream);
     char* ws = static_cast<char*>(workspace);
     int* meta = reinterpret_cast<int*>(ws + lay.meta);
-    c->ragged_meta = rs.meta;  // must outlive the asynchronous copy
-    HIP_TRY(hipMemcpyAsync(meta, c->ragged_meta.data(), sizeof(int) * rs.meta.size(), hipMemcpyHostToDevice, s));
+    std::vector<int>& staged = c->ragged_meta_ring[c->ragged_seq++ & 3];  // must outlive the asynchronous copy
+    staged = rs.meta;
+    HIP_TRY(hipMemcpyAsync(meta, staged.data(), sizeof(int) * rs.meta.size(), hipMemcpyHostToDevice, s));
     const X3Geom g = x3_geom_ragged(rs, stride, meta);
     return forward_x3_run(c, wav, g, lay, meta, emb, ws, s);
 }
@@ -1673,8 +1678,9 @@ static int forward_ragged_bf16(nomad_ctx* c, const float* wav, int B, int stride
     auto asf = [](const bf16_t* p_) { return reinterpret_cast<const float*>(p_); };
     auto asfm = [](bf16_t* p_) { return reinterpret_cast<float*>(p_); };
     int* meta = reinterpret_cast<int*>(ws + lay.meta);
-    c->ragged_meta = rs.meta;  // must outlive the asynchronous copy
-    HIP_TRY(hipMemcpyAsync(meta, c->ragged_meta.data(), sizeof(int) * rs.meta.size(), hipMemcpyHostToDevice, s));
+    std::vector<int>& staged = c->ragged_meta_ring[c->ragged_seq++ & 3];  // must outlive the asynchronous copy
+    staged = rs.meta;
+    HIP_TRY(hipMemcpyAsync(meta, staged.data(), sizeof(int) * rs.meta.size(), hipMemcpyHostToDevice, s));
     const int* lens = meta + rs.off_lens();
     auto pref = [&](int i) { return static_cast<const int*>(meta + rs.off_pref(i)); };
     const int* tpref = pref(6);

@@ -191,27 +191,53 @@ class Engine:
             for i, w in enumerate(flat):
                 host[i, :lens[i]] = w
             buf = host.to(self.device, non_blocking=True)
-        arr = (C.c_int * B)(*lens)
-        nb = C.c_size_t()
         emb = torch.empty(B, 256, dtype=torch.float32, device=self.device)
-        if precision != "fp32":
-            enable, size, run = ((self.lib.nomad_enable_bf16, self.lib.nomad_workspace_bytes_ragged_bf16, self.lib.nomad_embed_ragged_bf16)
-                                 if precision == "bf16" else
-                                 (self.lib.nomad_enable_bf16x3, self.lib.nomad_workspace_bytes_ragged_bf16x3, self.lib.nomad_embed_ragged_bf16x3))
-            _lib.check(enable(self.ctx), f"nomad_enable_{precision}")
-            _lib.check(size(self.ctx, B, arr, C.byref(nb)), f"nomad_workspace_bytes_ragged_{precision}")
-            ws = self._workspace(nb.value)
-            _lib.check(run(self.ctx, buf.data_ptr(), B, stride, arr, emb.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()),
-                       f"nomad_embed_ragged_{precision}")
-            return emb
-        _lib.check(self.lib.nomad_workspace_bytes_ragged(self.ctx, B, arr, C.byref(nb)), "nomad_workspace_bytes_ragged")
-        ws = self._workspace(nb.value)
         hw, hb = head if head is not None else (None, None)
-        _lib.check(self.lib.nomad_embed_ragged(self.ctx, buf.data_ptr(), B, stride, arr,
-                                               hw.data_ptr() if hw is not None else None,
-                                               hb.data_ptr() if hb is not None else None,
-                                               emb.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()),
-                   "nomad_embed_ragged")
+        if precision != "fp32":
+            enable = self.lib.nomad_enable_bf16 if precision == "bf16" else self.lib.nomad_enable_bf16x3
+            _lib.check(enable(self.ctx), f"nomad_enable_{precision}")
+
+        def run(lo, hi, side):
+            n = hi - lo
+            arr = (C.c_int * n)(*lens[lo:hi])
+            nb = C.c_size_t()
+            src, dst = buf[lo:hi], emb[lo:hi]
+            if precision == "fp32":
+                _lib.check(self.lib.nomad_workspace_bytes_ragged(self.ctx, n, arr, C.byref(nb)), "nomad_workspace_bytes_ragged")
+                ws = self._workspace(nb.value, side)
+                _lib.check(self.lib.nomad_embed_ragged(self.ctx, src.data_ptr(), n, stride, arr,
+                                                       hw.data_ptr() if hw is not None else None,
+                                                       hb.data_ptr() if hb is not None else None,
+                                                       dst.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()),
+                           "nomad_embed_ragged")
+                return
+            size, fwd = ((self.lib.nomad_workspace_bytes_ragged_bf16, self.lib.nomad_embed_ragged_bf16) if precision == "bf16" else
+                         (self.lib.nomad_workspace_bytes_ragged_bf16x3, self.lib.nomad_embed_ragged_bf16x3))
+            _lib.check(size(self.ctx, n, arr, C.byref(nb)), f"nomad_workspace_bytes_ragged_{precision}")
+            ws = self._workspace(nb.value, side)
+            _lib.check(fwd(self.ctx, src.data_ptr(), n, stride, arr, dst.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()),
+                       f"nomad_embed_ragged_{precision}")
+
+        # two halves (by audio length) on two streams where that pays, as in embed / embed_bf16x3; a clip's result does not
+        # depend on the batch it is in, so the split changes no bit
+        rows = sum(num_frames(n) for n in lens)
+        split = B >= 2 and ((precision == "bf16x3" and self.X3_SPLIT_ROWS and rows >= self.X3_SPLIT_ROWS) or
+                            (precision == "fp32" and self.F32_SPLIT_ROWS <= rows < self.F32_SPLIT_MAX_ROWS))
+        if not split:
+            run(0, B, False)
+            return emb
+        acc, h = 0, 1
+        for i, n in enumerate(lens[:-1]):
+            acc += n
+            h = i + 1
+            if 2 * acc >= sum(lens):
+                break
+        cur, ss = torch.cuda.current_stream(self.device), self.side_stream()
+        ss.wait_stream(cur)
+        with torch.cuda.stream(ss):
+            run(h, B, True)
+        run(0, h, False)
+        cur.wait_stream(ss)
         return emb
 
     def pairwise(self, deg: torch.Tensor, ref: torch.Tensor, want_matrix: bool = True):
