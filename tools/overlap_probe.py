@@ -36,7 +36,8 @@ def dual(parts=2):
     return torch.cat(outs)
 
 ref = single().clone()
-for name, fn in (("single B=256", single), ("2 streams x 128", dual), ("single B=256", single), ("2 streams x 128", dual)):
+for name, fn in (("single B=256", single), ("2 streams x 128", dual), ("2 streams, 4 x 64", lambda: dual(4)), ("single B=256", single),
+                 ("2 streams x 128", dual), ("2 streams, 4 x 64", lambda: dual(4))):
     for _ in range(2):
         out = fn()
     torch.cuda.synchronize()
