@@ -291,8 +291,11 @@ int nomad_diag_split_bf16(nomad_ctx* ctx, const float* in_dev, void* out_dev, lo
 int nomad_diag_gemm_bf16x3(nomad_ctx* ctx, const void* A_dev, const void* W_dev, const float* bias_dev,
                            const void* R_dev, void* C_dev, int M, int N, int K, int gelu, int out_f32,
                            nomad_stream_t stream);
-/* bf16x3 attention: split qkv [B*T][2304] (planes B*T*2304 apart, q pre-scaled) -> split out [B*T][768]. */
-int nomad_diag_attention_bf16x3(nomad_ctx* ctx, const void* qkv_dev, void* out_dev, int B, int T, nomad_stream_t stream);
+/* bf16x3 attention: split qkv [B*T][2304] (planes B*T*2304 apart, q pre-scaled) -> split out [B*T][768].
+ * waves: -1 = what the forward uses, 0 = the tiled kernel, 4 / 8 = the K/V-resident kernel (T <= 256) with that many
+ * waves per (clip, head). */
+int nomad_diag_attention_bf16x3(nomad_ctx* ctx, const void* qkv_dev, void* out_dev, int B, int T, int waves,
+                                nomad_stream_t stream);
 /* bf16 attention: qkv [B*T][2304] bf16 (q pre-scaled) -> out [B*T][768] bf16. */
 int nomad_diag_attention_bf16(nomad_ctx* ctx, const void* qkv_dev, void* out_dev, int B, int T, nomad_stream_t stream);
 /* out[M][N] = LayerNorm(in[M][N]) * gamma + beta, N in {512, 768}, eps 1e-5. */

@@ -72,7 +72,7 @@ SIGNATURES = {
     "nomad_embed_bf16x3": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int, _fp, _fp, C.c_size_t, _fp]),
     "nomad_workspace_bytes_ragged_bf16x3": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
     "nomad_embed_ragged_bf16x3": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int, C.POINTER(C.c_int), _fp, _fp, C.c_size_t, _fp]),
-    "nomad_diag_attention_bf16x3": (C.c_int, [C.c_void_p, _fp, _fp, C.c_int, C.c_int, _fp]),
+    "nomad_diag_attention_bf16x3": (C.c_int, [C.c_void_p, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     "nomad_diag_split_bf16": (C.c_int, [C.c_void_p, _fp, _fp, C.c_longlong, C.c_longlong, C.c_int, _fp]),
     "nomad_diag_gemm_bf16x3": (C.c_int, [C.c_void_p, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "nomad_diag_gemm_bf16": (C.c_int, [C.c_void_p, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),

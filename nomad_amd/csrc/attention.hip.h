@@ -507,4 +507,78 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const bf16s_t* __rest
     }
 }
 
+// The same attention with the head's whole K / V (split planes) resident in LDS: one workgroup per (clip, head), K / V
+// loaded once instead of once per 64-query block, no barrier inside the loop - waves walk the 16-query sub-tiles on
+// their own.  For short clips (4 x ceil(T / 32) * 32 rows of 160 B <= 160 KB, i.e. T <= 256; a 4 s clip has T = 199).
+// Same tile function, same key order: bit-identical to attention_x3_kernel.  Dynamic LDS: attn_x3_resident_lds(max T).
+__host__ __device__ inline int attn_x3_resident_rows(int T) { return (T + 31) / 32 * 32; }
+__host__ __device__ inline size_t attn_x3_resident_lds(int T) { return (size_t)4 * attn_x3_resident_rows(T) * kAttn16LD; }
+constexpr int kAttnResidentMaxT = 256;
+constexpr int kAttnResidentWaves = 8;   // waves per (clip, head) workgroup (measured: profiles/r01_attention_x3_resident.txt)
+
+__global__ __launch_bounds__(512) void attention_x3_resident_kernel(const bf16s_t* __restrict__ qkv_s, long long in_plane,
+                                                                    bf16s_t* __restrict__ out, long long out_plane, int T,
+                                                                    int rows_alloc, const int* __restrict__ tpref = nullptr) {
+    extern __shared__ __attribute__((aligned(16))) char attn_lds[];
+    const bf16_t* qkv = reinterpret_cast<const bf16_t*>(qkv_s);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int qi = lane & 15, g = lane >> 4;
+    const int bh = blockIdx.x, b = bh / 12, h = bh - b * 12;
+    long long row0 = (long long)b * T;
+    if (tpref) {
+        row0 = tpref[b];
+        T = tpref[b + 1] - tpref[b];
+    }
+    const int rows = attn_x3_resident_rows(T);
+    char* Kh = attn_lds;
+    char* Kl = Kh + (size_t)rows_alloc * kAttn16LD;
+    char* Vh = Kl + (size_t)rows_alloc * kAttn16LD;
+    char* Vl = Vh + (size_t)rows_alloc * kAttn16LD;
+    const long long base = row0 * 2304 + h * 64;
+    // stage K and V of this head: rows >= T repeat the last key (finite data under the masks)
+    for (int id = tid; id < rows * 8; id += blockDim.x) {
+        const int row = id >> 3, ch = id & 7;
+        const int key = row < T ? row : T - 1;
+        const bf16_t* src = qkv + base + (long long)key * 2304 + ch * 8;
+        *reinterpret_cast<bf16x8*>(Kh + row * kAttn16LD + ch * 16) = *reinterpret_cast<const bf16x8*>(src + 768);
+        *reinterpret_cast<bf16x8*>(Kl + row * kAttn16LD + ch * 16) = *reinterpret_cast<const bf16x8*>(src + 768 + in_plane);
+        *reinterpret_cast<bf16x8*>(Vh + row * kAttn16LD + ch * 16) = *reinterpret_cast<const bf16x8*>(src + 1536);
+        *reinterpret_cast<bf16x8*>(Vl + row * kAttn16LD + ch * 16) = *reinterpret_cast<const bf16x8*>(src + 1536 + in_plane);
+    }
+    __syncthreads();
+    const int ntiles = (T + 63) / 64;
+    for (int qs = wave; qs * 16 < T; qs += nwaves) {  // wave-uniform: the transposing reads need a full EXEC mask
+        const int q_row = qs * 16 + qi;
+        const int q_ld = q_row < T ? q_row : T - 1;
+        bf16x8 qh[2], ql[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16_t* src = qkv + base + (long long)q_ld * 2304 + ks * 32 + g * 8;
+            qh[ks] = *reinterpret_cast<const bf16x8*>(src);
+            ql[ks] = *reinterpret_cast<const bf16x8*>(src + in_plane);
+        }
+        f32x4 o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float m_run = -INFINITY, l_run = 0.f;
+        for (int kt = 0; kt < ntiles; ++kt) {
+            const int off = kt * 64 * kAttn16LD;
+            const int valid = T - kt * 64;
+            if (valid > 48) attn_tile_x3<4>(Kh + off, Kl + off, Vh + off, Vl + off, qh, ql, o, m_run, l_run, qi, g, valid);
+            else if (valid > 32) attn_tile_x3<3>(Kh + off, Kl + off, Vh + off, Vl + off, qh, ql, o, m_run, l_run, qi, g, valid);
+            else if (valid > 16) attn_tile_x3<2>(Kh + off, Kl + off, Vh + off, Vl + off, qh, ql, o, m_run, l_run, qi, g, valid);
+            else attn_tile_x3<1>(Kh + off, Kl + off, Vh + off, Vl + off, qh, ql, o, m_run, l_run, qi, g, valid);
+        }
+        float l_tot = l_run + __shfl_xor(l_run, 16);
+        l_tot += __shfl_xor(l_tot, 32);
+        const float inv = 1.0f / l_tot;
+        if (q_row < T) {
+            bf16s_t* dst = out + (row0 + q_row) * 768 + h * 64 + g * 4;
+#pragma unroll
+            for (int ds = 0; ds < 4; ++ds)
+                store4p<bf16s_t>(dst + ds * 16, out_plane, make_float4(o[ds][0] * inv, o[ds][1] * inv, o[ds][2] * inv, o[ds][3] * inv));
+        }
+    }
+}
+
 }  // namespace nomad

@@ -1339,6 +1339,31 @@ static int forward_bf16(nomad_ctx* c, const float* wav, int B, int n_samples, fl
 //   per layer: QKV -> split -> bf16x3 attention -> split -> out-proj (+ split residual) -> fp32 -> LN -> split
 //              -> fc1 + GELU -> split -> fc2 (+ split residual) -> fp32 -> LN -> split (fp32 after the last layer)
 // Accumulators, bias / GELU / residual, LayerNorm statistics, softmax and the head are fp32 as in the fp32 path.
+
+// bf16x3 attention: K / V of a head resident in LDS when every clip is short enough, the tiled kernel otherwise.
+// waves: 0 = tiled kernel, 4 / 8 = resident kernel with that many waves per (clip, head); -1 = the path's choice.
+static int run_attention_x3(nomad_ctx* c, const bf16s_t* qkv, long long in_plane, bf16s_t* out, long long out_plane, int B,
+                            int T, int max_t, const int* tpref, double flops, hipStream_t s, int waves = -1) {
+    Scope sc(c, s, NOMAD_K_ATTN, flops);
+    if (waves < 0) waves = max_t <= kAttnResidentMaxT ? kAttnResidentWaves : 0;
+    if (waves > 0) {
+        if (max_t > kAttnResidentMaxT) return fail(NOMAD_ERR_INVALID, "bf16x3 resident attention: T = %d > %d", max_t, kAttnResidentMaxT);
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_x3_resident_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(attention_x3_resident_kernel, dim3(B * 12), dim3(waves * 64), attn_x3_resident_lds(max_t), s, qkv,
+                           in_plane, out, out_plane, T, attn_x3_resident_rows(max_t), tpref);
+    } else {
+        hipLaunchKernelGGL(attention_x3_kernel, dim3((max_t + 63) / 64, B * 12), dim3(256), 0, s, qkv, in_plane, out, out_plane, T,
+                           tpref);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // One implementation serves equal-length batches and ragged ones: X3Geom carries the row maps of either.
 struct X3Geom {
     int B = 0;
@@ -1575,11 +1600,7 @@ static int forward_x3_run(nomad_ctx* c, const float* wav, const X3Geom& g, const
         const LayerDev& d = c->layers[l];
         if ((rc = run_gemm_bf16(c, dense_x3(x, pl768, 768, c->qkv_wx[l], d.qkv_b, nullptr, 0, qkv, pl2304, M, 2304, 768, 0), 1, s, kX3Split)))
             return rc;
-        {
-            Scope sc(c, s, NOMAD_K_ATTN, g.attn_flops);
-            hipLaunchKernelGGL(attention_x3_kernel, dim3((g.max_t + 63) / 64, B * 12), dim3(256), 0, s, qkv, pl2304, ctxb, pl768,
-                               g.T, tpref);
-        }
+        if ((rc = run_attention_x3(c, qkv, pl2304, ctxb, pl768, B, g.T, g.max_t, tpref, g.attn_flops, s))) return rc;
         if ((rc = run_gemm_bf16(c, dense_x3(ctxb, pl768, 768, c->o_wx[l], d.o_b, x, pl768, y, 0, M, 768, 768, 0), 1, s, kX3F32)))
             return rc;
         ln(y, d.ln1_w, d.ln1_b, x2);
@@ -1933,14 +1954,11 @@ int nomad_diag_split_bf16(nomad_ctx* c, const float* in, void* out, long long pl
     return 0;
 }
 
-int nomad_diag_attention_bf16x3(nomad_ctx* c, const void* qkv, void* out, int B, int T, nomad_stream_t stream) {
+int nomad_diag_attention_bf16x3(nomad_ctx* c, const void* qkv, void* out, int B, int T, int waves, nomad_stream_t stream) {
     if (!c || !qkv || !out || B <= 0 || T <= 0) return fail(NOMAD_ERR_INVALID, "nomad_diag_attention_bf16x3: bad argument");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    Scope sc(c, s, NOMAD_K_ATTN, 4.0 * B * 12.0 * (double)T * T * 64);
-    hipLaunchKernelGGL(attention_x3_kernel, dim3((T + 63) / 64, B * 12), dim3(256), 0, s, static_cast<const bf16s_t*>(qkv),
-                       (long long)B * T * 2304, static_cast<bf16s_t*>(out), (long long)B * T * 768, T, kNoInts);
-    HIP_TRY(hipGetLastError());
-    return 0;
+    return run_attention_x3(c, static_cast<const bf16s_t*>(qkv), (long long)B * T * 2304, static_cast<bf16s_t*>(out),
+                            (long long)B * T * 768, B, T, T, kNoInts, 4.0 * B * 12.0 * (double)T * T * 64,
+                            static_cast<hipStream_t>(stream), waves);
 }
 
 int nomad_diag_gemm_bf16x3(nomad_ctx* c, const void* A, const void* W, const float* bias, const void* R, void* C, int M,

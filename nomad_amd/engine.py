@@ -350,10 +350,11 @@ class Engine:
                                                    M, N, K, int(gelu), int(variant), self._stream()), "nomad_diag_gemm_bf16x3")
         return out
 
-    def diag_attention_bf16x3(self, qkv_split, B, T):
-        """qkv_split (2, B*T, 2304) split buffer -> split (2, B*T, 768)."""
+    def diag_attention_bf16x3(self, qkv_split, B, T, waves: int = -1):
+        """qkv_split (2, B*T, 2304) split buffer -> split (2, B*T, 768).  waves: -1 the forward's choice, 0 the tiled
+        kernel, 4 / 8 the K/V-resident kernel (T <= 256)."""
         out = torch.empty(2, B * T, 768, dtype=torch.bfloat16, device=self.device)
-        _lib.check(self.lib.nomad_diag_attention_bf16x3(self.ctx, qkv_split.data_ptr(), out.data_ptr(), B, T, self._stream()),
+        _lib.check(self.lib.nomad_diag_attention_bf16x3(self.ctx, qkv_split.data_ptr(), out.data_ptr(), B, T, waves, self._stream()),
                    "nomad_diag_attention_bf16x3")
         return out
 

@@ -84,7 +84,7 @@ def test_gemm_bf16x3_vs_float64(engine, M, N, K, epi, out_f32, kernel):
     assert err < 3e-5 * max(1.0, ref.abs().max().item()), err
 
 
-@pytest.mark.parametrize("B,T", [(2, 50), (1, 64), (1, 65), (3, 199), (1, 330), (1, 1)])
+@pytest.mark.parametrize("B,T", [(2, 50), (1, 64), (1, 65), (3, 199), (1, 330), (1, 1), (2, 256), (1, 225), (1, 17)])
 @pytest.mark.parametrize("gain", [1.0, 6.0, 40.0])
 def test_attention_bf16x3(engine, B, T, gain):
     """Split-operand attention against float64: logits up to a few hundred (gain 40) still come out to ~1e-5."""
@@ -93,8 +93,16 @@ def test_attention_bf16x3(engine, B, T, gain):
     qkv[:, :1536] *= (gain ** 0.5) * 0.35
     q, k, v = (qkv[:, i * 768:(i + 1) * 768].double().view(B, T, 12, 64).transpose(1, 2) for i in range(3))
     ref = (torch.softmax(q @ k.transpose(-1, -2), -1) @ v).transpose(1, 2).reshape(B * T, 768)
-    out = engine.diag_unsplit_bf16(engine.diag_attention_bf16x3(engine.diag_split_bf16(qkv.cuda()), B, T)).cpu()
+    qs = engine.diag_split_bf16(qkv.cuda())
+    tiled = engine.diag_attention_bf16x3(qs, B, T, waves=0)
+    out = engine.diag_unsplit_bf16(tiled).cpu()
     assert torch.isfinite(out).all()
+    if T <= 256:   # the K/V-resident kernel walks the same tiles in the same order: same bits
+        for waves in (4, 8):
+            assert torch.equal(engine.diag_attention_bf16x3(qs, B, T, waves=waves), tiled), waves
+    else:
+        with pytest.raises(Exception):
+            engine.diag_attention_bf16x3(qs, B, T, waves=8)
     err = (out.double() - ref).abs().max().item()
     f32 = engine.diag_attention(qkv.cuda(), B, T).cpu() if hasattr(engine, "diag_attention") else None
     e32 = (f32.double() - ref).abs().max().item() if f32 is not None else float("nan")
