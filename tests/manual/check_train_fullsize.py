@@ -2,7 +2,7 @@
 """Full-size parity of one fine-tuning step (the reference's shape: 3 x (8,1,160000), T = 499, 11 976 rows) in eval-mode
 arithmetic: loss and every parameter gradient, merged-branch engine path vs torch autograd on the CPU oracle (~15 s)."""
 import os, sys, time, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from nomad_amd.engine import Engine
 from nomad_amd.weights import seeded_state_dict

@@ -1,6 +1,6 @@
 """Per-parameter gradient error of the HIP fine-tuning step vs autograd on the CPU oracle (diagnostic)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from nomad_amd.weights import seeded_state_dict
 from nomad_amd.engine import Engine

@@ -1,6 +1,7 @@
 """Triplet fine-tuning step on the reference's training shape (src/config/train_triplet.yaml: train_bs 8, clips
 trimmed to 10 s): three forwards + TripletMarginLoss + backward to every trainable parameter + Adam, timed on the GPU.
-Usage: python tools/bench_train.py [--bs 8] [--seconds 10] [--steps 5] [--eval-mode] [--cpu]"""
+Usage: python tools/bench_train.py [--bs 8] [--seconds 10] [--steps 5] [--eval-mode]
+(the CPU-autograd timing of the same step lives with the other oracle users: tests/manual/train_step_cpu_baseline.py)"""
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -14,7 +15,6 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--eval-mode", action="store_true", help="no dropout / LayerDrop")
     ap.add_argument("--separate", action="store_true", help="three separate forward/backward calls (no merged batch)")
-    ap.add_argument("--cpu", action="store_true", help="also time one torch-autograd step of the CPU oracle")
     ap.add_argument("--out", type=str, default="")
     args = ap.parse_args()
     from nomad_amd.train import Training
@@ -50,16 +50,6 @@ def main():
            "approx_model_tflops": 3 * fwd_flop / dt / 1e12,
            "classes_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
            "classes_launches_per_step": {k: v["launches"] / args.steps for k, v in prof.items()}}
-    if args.cpu:
-        from oracle import nomad_oracle as O
-        torch.set_num_threads(min(32, os.cpu_count() or 1))
-        opt, params = O.make_adam(sd, lr=1e-4)
-        live = dict(sd); live.update(params)
-        t0 = time.perf_counter()
-        l = torch.nn.TripletMarginLoss(margin=0.2)(*(O.triplet_forward(live, w.cpu()) for w in (A, P, N)))
-        opt.zero_grad(); l.backward(); opt.step()
-        res["cpu_oracle_step_s"] = time.perf_counter() - t0
-        res["cpu_threads"] = torch.get_num_threads()
     line = json.dumps(res)
     print(line)
     if args.out:
