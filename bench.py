@@ -110,18 +110,23 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: nomad_amd has no CPU path")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # Under the distributed launcher (RANK / WORLD_SIZE in the environment) the RCCL process group is created at EVERY
+    # world size, 1 included, and the all-gather of the reference embeddings is really issued - so a 1-GPU box
+    # exercises the same collective path the 2/4/8-GPU runs take.  A plain `python bench.py` has no process group.
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    use_pg = world > 1 or launched
+    if use_pg:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if rank == 0:
         build.build_library()  # no-op when the in-tree .so is up to date; other ranks wait before dlopen
-    if world > 1:
+    if use_pg:
         dist.barrier()
 
     ckpt = find_checkpoint()
     sd = load_checkpoint(ckpt) if ckpt else seeded_state_dict(0)
     eng = Engine(sd, local_rank)
     embed_fn = {"f32": eng.embed, "bf16": eng.embed_bf16, "bf16x3": eng.embed_bf16x3}[args.dtype]
-    scorer = ShardedScorer(embed_fn, eng.pairwise, equal_shards=True)
+    scorer = ShardedScorer(embed_fn, eng.pairwise, equal_shards=True, force_collective=use_pg)
 
     n_samples = int(round(args.seconds * 16000))
     B, n_ref = args.batch, args.refs
@@ -134,7 +139,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_pg:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -170,7 +175,7 @@ def main():
         eng.profile_enable(False)
         eng.X3_SPLIT_ROWS = keep
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_pg:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     assert torch.isfinite(mean).all()
@@ -180,7 +185,7 @@ def main():
     also = None
     if args.dtype == "f32" and not args.no_also:
         try:
-            sc3 = ShardedScorer(eng.embed_bf16x3, eng.pairwise, equal_shards=True)
+            sc3 = ShardedScorer(eng.embed_bf16x3, eng.pairwise, equal_shards=True, force_collective=use_pg)
             for _ in range(args.warmup):
                 m3, _, _ = sc3.score(deg_wav, ref_wav, want_matrix=True)
             fence()
@@ -189,7 +194,7 @@ def main():
                 m3, _, _ = sc3.score(deg_wav, ref_wav, want_matrix=True)
             fence()
             t3 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
-            if world > 1:
+            if use_pg:
                 dist.all_reduce(t3, op=dist.ReduceOp.MAX)
             also = {"precision": "bf16x3 (hi/lo-split bf16 operands, 3 bf16 MFMA products per fp32 product, fp32 accumulate)",
                     "value": round(world * B * args.steps / float(t3.item()), 2), "unit": "clips/s",
@@ -197,12 +202,47 @@ def main():
                     "max_abs_score_diff_vs_f32": float((m3 - mean).abs().max().item())}
         except Exception as e:  # the headline line must not depend on the extra mode
             also = {"precision": "bf16x3", "error": str(e)[:200]}
+    # ... and BASELINE.json configs[4] (long-form 30 s clips, bf16, batch 32 per GPU), a few steps (~25 ms each), so that
+    # the driver's run carries a number for it too.  Only next to the default headline workload.
+    also_c5 = None
+    if args.dtype == "f32" and not args.no_also and n_samples == 64000 and B == 256:
+        try:
+            g5 = torch.Generator().manual_seed(2000 + rank)
+            wav5 = (0.1 * torch.randn(32, 480000, generator=g5)).clamp(-1, 1).cuda()
+            sc5 = ShardedScorer(eng.embed_bf16, eng.pairwise, equal_shards=True, force_collective=use_pg)
+            for _ in range(2):
+                m5, _, _ = sc5.score(wav5[:28], wav5[28:], want_matrix=True)
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                m5, _, _ = sc5.score(wav5[:28], wav5[28:], want_matrix=True)
+            fence()
+            t5 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
+            if use_pg:
+                dist.all_reduce(t5, op=dist.ReduceOp.MAX)
+            v5 = world * 32 * 5 / float(t5.item())
+            also_c5 = {"workload": "configs[4]: batch=32 x 480000 samples (T=1499) per GPU, bf16 storage / fp32 accumulate, "
+                                   "28 deg x 4*N ref float64 distances + means",
+                       "dtype": "bf16", "value": round(v5, 2), "unit": "clips/s", "steps": 5, "warmup": 2,
+                       "ms_per_step": round(1e3 * float(t5.item()) / 5, 3),
+                       "model_frac_of_mfma_peak": round(v5 * 500.044e9 / world / 2.5e15, 4),
+                       "finite": bool(torch.isfinite(m5).all().item())}
+            del wav5
+        except Exception as e:
+            also_c5 = {"workload": "configs[4]", "error": str(e)[:200]}
 
     if rank == 0:
         clips = world * B * args.steps
         value = clips / elapsed
         T = num_frames(n_samples)
         flop_clip = {64000: FLOP_PER_CLIP_4S, 480000: 500.044e9}.get(n_samples)
+        # which BASELINE.json config this command line is (anything else is labelled as what it is)
+        if args.dtype == "f32" and n_samples == 64000 and B == 256:
+            cfg_name = "configs[1]"
+        elif args.dtype == "bf16" and n_samples == 480000:
+            cfg_name = "configs[4] (long-form 30 s clips, bf16)"
+        else:
+            cfg_name = "custom (not a BASELINE.json config)"
         # bf16x3 executes 3 bf16 MFMA flops per algorithmic (fp32-equivalent) flop: its ceiling is a third of the bf16 peak
         peak = {"f32": PEAK_FP32_MFMA, "bf16": 2.5e15, "bf16x3": 2.5e15 / 3}[args.dtype]
         out = {
@@ -212,11 +252,14 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic (0.1*randn waveforms, seed 1000+rank; " +
                     ("real nomad_best_model.pt" if ckpt else "seeded random-init wav2vec2-base + head weights") + ")",
-            "config": {"workload": f"configs[1]: batch={B} x {n_samples} samples (T={T}) per GPU, wav2vec2-base + "
+            "config": {"workload": f"{cfg_name}: batch={B} x {n_samples} samples (T={T}) per GPU, wav2vec2-base + "
                                    f"projection head {PRECISION_NOTE[args.dtype]}, {B - n_ref} deg x {n_ref}*N "
                                    f"ref float64 distances + means",
                        "clips_per_gpu_per_step": B, "deg_per_gpu": B - n_ref, "ref_total": n_ref * world,
-                       "parallelism": f"clip-sharded x{world}, all-gather of ref embeddings"},
+                       "parallelism": f"clip-sharded x{world}, all-gather of ref embeddings",
+                       "collective": (f"RCCL all_gather_into_tensor executed every step (torch.distributed nccl, "
+                                      f"version {'.'.join(map(str, torch.cuda.nccl.version()))})" if use_pg
+                                      else "none (single process, no process group)")},
         }
         if flop_clip:
             out["model_tflops_per_gpu"] = round(value * flop_clip / world / 1e12, 2)
@@ -235,7 +278,7 @@ def main():
             allg, big, fine = prof["gemm_mfma_all"], prof["gemm_mfma_256x128"], prof["gemm_mfma_128x64"]
             dom = big if big["ms"] >= fine["ms"] else fine      # the dominant kernel = the instantiation with most time
             if args.dtype == "bf16x3":
-                kname = "gemm_bf16_8phase_kernel 256x256 X3 (3 x v_mfma_f32_16x16x32_bf16 per fp32-equivalent product)"
+                kname = "gemm_bf16x3_kernel 256x256 (3 x v_mfma_f32_16x16x32_bf16 per fp32-equivalent product)"
             elif args.dtype == "bf16":
                 kname = ("gemm_bf16_8phase_kernel 256x256 (v_mfma_f32_16x16x32_bf16) + gemm_bf16_glds_kernel 128x128/256x256"
                          if dom is big else "gemm_bf16_glds_kernel 128x64 (v_mfma_f32_32x32x16_bf16)")
@@ -250,6 +293,9 @@ def main():
             out["roofline"] = {"bound": "mfma", "kernel": kname,
                                "achieved": round(ach, 2), "peak": round(peak / 1e12, 1), "unit": "TFLOP/s",
                                "frac": round(ach * 1e12 / peak, 4), "traffic": traffic,
+                               "traffic_source": ("profiles/pmc_traffic.json (STATIC: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                                  "passes of this command taken earlier by tools/gpu_round3.sh, not measured "
+                                                  "in this run)" if traffic is not None else None),
                                "algorithmic_bytes_per_launch": alg_bytes,
                                "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4),
                                "algorithmic_gflop_per_launch": round(dom["flops"] / max(dom["launches"], 1) / 1e9, 3),
@@ -264,10 +310,12 @@ def main():
                                            "(kernels run alone); value / ms_per_step from the pass with it on")
         if also:
             out["also_measured"] = also
+        if also_c5:
+            out["also_measured_c5"] = also_c5
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, n_samples)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()

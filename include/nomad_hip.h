@@ -137,9 +137,21 @@ int nomad_l1_loss(nomad_ctx* ctx, const float* a_layers_dev, const float* b_laye
  *                              (nomad_saved_bytes) with what the backward needs
  *   nomad_l1_loss_backward   d NomadLoss / d a_layers, d a_emb  (sign(a-b)/numel, times *upstream_dev)
  *   nomad_embed_backward     given d loss / d layers [12][B][T][768] (nullable) and d loss / d emb [B][256]
- *                            writes d loss / d wav [B][n_samples]; scratch: nomad_backward_workspace_bytes
+ *                            writes d loss / d wav [B][n_samples]; scratch: nomad_backward_workspace_bytes;
+ *                            the gradient entering the conv feature extractor is scaled by feature_grad_mult (below)
  */
 int nomad_enable_backward(nomad_ctx* ctx);
+/*
+ * fairseq's Wav2Vec2Model wraps the conv feature extractor's output in GradMultiply(features, feature_grad_mult)
+ * whenever feature_grad_mult != 1 (wav2vec2.py, Wav2Vec2Model.forward; also in eval mode): the forward is the
+ * identity, the gradient flowing back INTO the extractor - and so d loss / d waveform of Nomad.forward(),
+ * nomad.py:142-146 - is multiplied by it.  The wav2vec 2.0 BASE config that wav2vec_small.pt carries (and that
+ * load_model_ensemble_and_task keeps, nomad.py:58) has feature_grad_mult = 0.1, which is the default here;
+ * 1.0 gives the plain chain rule, 0 means "extractor under no_grad" in fairseq and yields dwav = 0.
+ * Applies to nomad_embed_backward only (the fine-tuning step never reaches the frozen extractor).
+ */
+int nomad_set_feature_grad_mult(nomad_ctx* ctx, float mult);
+int nomad_get_feature_grad_mult(const nomad_ctx* ctx, float* mult);
 int nomad_saved_bytes(const nomad_ctx* ctx, int B, int n_samples, size_t* bytes);
 int nomad_backward_workspace_bytes(const nomad_ctx* ctx, int B, int n_samples, size_t* bytes);
 int nomad_embed_train(nomad_ctx* ctx, const float* wav_dev, int B, int n_samples,

@@ -115,11 +115,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 
 // out[map(m)][c] = g[m][c] * gelu'(u[m][c]) for rows of 512 floats: conv6 gradient into the padded dU layout.
 __global__ __launch_bounds__(128) void dgelu_rows512_kernel(const float* __restrict__ g, const float* __restrict__ u,
-                                                            float* __restrict__ out, RowMap omap, int M) {
+                                                            float* __restrict__ out, RowMap omap, int M, float scale) {
     const int m = blockIdx.x;
     if (m >= M) return;
-    const float4 a = reinterpret_cast<const float4*>(g + (long long)m * 512)[threadIdx.x];
+    float4 a = reinterpret_cast<const float4*>(g + (long long)m * 512)[threadIdx.x];
     const float4 b = reinterpret_cast<const float4*>(u + (long long)m * 512)[threadIdx.x];
+    a.x *= scale; a.y *= scale; a.z *= scale; a.w *= scale;  // GradMultiply's backward: grad * scale, then GELU'
     float4 r;
     r.x = a.x * dgelu_erf(b.x); r.y = a.y * dgelu_erf(b.y); r.z = a.z * dgelu_erf(b.z); r.w = a.w * dgelu_erf(b.w);
     reinterpret_cast<float4*>(out + row_addr(omap, m))[threadIdx.x] = r;

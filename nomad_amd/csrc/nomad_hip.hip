@@ -58,7 +58,7 @@ int fail(int code, const char* fmt, ...) {
 
 constexpr int kConvK[7] = {10, 3, 3, 3, 3, 2, 2};
 constexpr int kConvS[7] = {5, 2, 2, 2, 2, 2, 2};
-constexpr int kMaxEvents = 8192;
+constexpr int kEventChunk = 8192;  // the profiling event pool grows by this many events whenever it runs out
 const int* const kNoInts = nullptr;  // "uniform batch" for the kernels' optional ragged-metadata pointers
 
 struct LayerDev {
@@ -298,6 +298,9 @@ struct nomad_ctx {
     long long adam_t = 0;
     // model.train() regularisation applied by nomad_embed_train / nomad_train_backward (nomad_train_set_stochastic)
     float p_drop = 0.f, p_attn = 0.f, p_input = 0.f;
+    // fairseq Wav2Vec2Model.feature_grad_mult: the gradient entering the conv feature extractor is scaled by this
+    // (GradMultiply on the extractor's output); 0.1 in the wav2vec 2.0 BASE config that wav2vec_small.pt carries
+    float feature_grad_mult = 0.1f;
     unsigned long long drop_seed = 0;
     unsigned layer_mask = 0xFFFu;  // bit l set: encoder layer l runs (LayerDrop clears bits)
     // A training batch may be several equal groups of clips ("branches": anchor | positive | negative), each with
@@ -311,13 +314,14 @@ struct nomad_ctx {
     unsigned ragged_seq = 0;
     // profiling
     bool prof = false;
-    hipEvent_t ev[kMaxEvents];
-    int ev_class[kMaxEvents / 2];
+    std::vector<hipEvent_t> ev;   // grows on demand (Scope): a long timed region is never silently truncated
+    std::vector<int> ev_class;
     int ev_used = 0;
     double p_ms[NOMAD_K_COUNT] = {};
     long long p_n[NOMAD_K_COUNT] = {};
     double p_fl[NOMAD_K_COUNT] = {};
     bool ev_ready = false;
+    bool prof_overflow = false;   // an event could not be created: the counters are incomplete and profile_read says so
 };
 
 namespace {
@@ -339,7 +343,19 @@ struct Scope {
     // cls2 (optional): a sub-class that receives the same time / launch / FLOP counts
     Scope(nomad_ctx* c_, hipStream_t s_, int cls, double flops, int cls2 = -1) : c(c_), s(s_) {
         if (!c->prof) return;
-        if (c->ev_used + 2 > kMaxEvents) return;  // pool exhausted: neither counted nor timed
+        if (c->ev_used + 2 > (int)c->ev.size()) {  // pool used up: grow it (event creation is host-only work)
+            const size_t old = c->ev.size();
+            c->ev.resize(old + kEventChunk);
+            c->ev_class.resize((old + kEventChunk) / 2);
+            for (size_t i = old; i < c->ev.size(); ++i)
+                if (hipEventCreate(&c->ev[i]) != hipSuccess) {  // out of events: stop profiling LOUDLY (profile_read fails)
+                    for (size_t j = old; j < i; ++j) (void)hipEventDestroy(c->ev[j]);
+                    c->ev.resize(old);
+                    c->ev_class.resize(old / 2);
+                    c->prof_overflow = true;
+                    return;
+                }
+        }
         c->p_fl[cls] += flops;
         c->p_n[cls] += 1;
         if (cls2 >= 0) {
@@ -627,8 +643,7 @@ void nomad_destroy(nomad_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     for (void* p : c->allocs) (void)hipFree(p);
-    if (c->ev_ready)
-        for (int i = 0; i < kMaxEvents; ++i) (void)hipEventDestroy(c->ev[i]);
+    for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -1830,11 +1845,16 @@ int nomad_enable_bf16(nomad_ctx* c) {
     if (!c) return fail(NOMAD_ERR_INVALID, "null ctx");
     if (c->bf16_ready) return 0;
     HIP_TRY(hipSetDevice(c->device));
+    // A weight update (nomad_train_adam_step / nomad_train_write) rebuilt the fp32 kernel-layout weights on the CALLER's
+    // stream, which may be a non-blocking stream the null stream does not wait for: drain the device before converting.
+    HIP_TRY(hipDeviceSynchronize());
     auto conv = [&](const float* src, size_t n, bf16_t** out) -> int {
-        void* d = nullptr;
-        HIP_TRY(hipMalloc(&d, n * sizeof(bf16_t)));
-        c->allocs.push_back(d);
-        *out = static_cast<bf16_t*>(d);
+        if (!*out) {  // re-enabling after a weight update reuses the buffers
+            void* d = nullptr;
+            HIP_TRY(hipMalloc(&d, n * sizeof(bf16_t)));
+            c->allocs.push_back(d);
+            *out = static_cast<bf16_t*>(d);
+        }
         hipLaunchKernelGGL(to_bf16_kernel, dim3(1024), dim3(256), 0, 0, src, *out, (long long)(n / 4));
         return 0;
     };
@@ -1874,6 +1894,7 @@ int nomad_enable_bf16x3(nomad_ctx* c) {
     if (!c) return fail(NOMAD_ERR_INVALID, "null ctx");
     if (c->x3_ready) return 0;
     HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());  // see nomad_enable_bf16: the fp32 weights may have been rebuilt on another stream
     auto conv = [&](const float* src, size_t n, bf16s_t** out) -> int {
         if (!*out) {  // re-enabling after a weight update reuses the buffers
             void* d = nullptr;
@@ -2377,13 +2398,20 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
     if (train) ln_params(sv.c6, F(lay.f1), nullptr, 512, G(po.fln_w), G(po.fln_b), M);
     HIP_TRY(hipGetLastError());
     if (!dwav) return 0;  // frozen conv feature extractor (freeze_convnet: True): nothing upstream needs a gradient
+    if (c->feature_grad_mult == 0.f) {  // fairseq runs the extractor under no_grad then: no gradient reaches the waveform
+        HIP_TRY(hipMemsetAsync(dwav, 0, sizeof(float) * (size_t)B * n_samples, s));
+        return 0;
+    }
     if ((rc = run_ln_bwd(c, sv.c6, F(lay.f1), nullptr, c->fln_w, F(lay.f2), M, 512, s))) return rc;
     float* bufs[2] = {F(lay.bufa), F(lay.bufb)};  // dU6 -> a, dU5 -> b, ..., dU1 -> b, G0 -> a
     {
         HIP_TRY(hipMemsetAsync(bufs[0], 0, sizeof(float) * 512 * (size_t)B * (T + 2), s));
         Scope sc(c, s, NOMAD_K_ROW, 0.0);
         const RowMap om{512, (long long)(T + 2) * 512, T, 512};
-        hipLaunchKernelGGL(dgelu_rows512_kernel, dim3(M), dim3(128), 0, s, F(lay.f2), sv.u[6], bufs[0], om, M);
+        // GradMultiply(features, feature_grad_mult) sits on the extractor's (post-GELU) output: its backward scales the
+        // gradient that enters GELU'
+        hipLaunchKernelGGL(dgelu_rows512_kernel, dim3(M), dim3(128), 0, s, F(lay.f2), sv.u[6], bufs[0], om, M,
+                           c->feature_grad_mult);
     }
     // ---- conv6..conv1: transposed strided convolutions as GEMMs over the padded dU buffers -------------
     for (int i = 6; i >= 1; --i) {
@@ -2536,6 +2564,18 @@ int refresh_weights(nomad_ctx* c, hipStream_t s) {
 }  // namespace
 
 extern "C" {
+
+int nomad_set_feature_grad_mult(nomad_ctx* c, float mult) {
+    if (!c || !(mult >= 0.f)) return fail(NOMAD_ERR_INVALID, "nomad_set_feature_grad_mult: bad argument");
+    c->feature_grad_mult = mult;
+    return 0;
+}
+
+int nomad_get_feature_grad_mult(const nomad_ctx* c, float* mult) {
+    if (!c || !mult) return fail(NOMAD_ERR_INVALID, "nomad_get_feature_grad_mult: bad argument");
+    *mult = c->feature_grad_mult;
+    return 0;
+}
 
 int nomad_embed_backward(nomad_ctx* c, const float* wav, int B, int n_samples, const float* head_w, const float* head_b,
                          const float* layers_out, const void* saved, size_t saved_bytes, const float* dlayers,
@@ -2775,7 +2815,9 @@ int nomad_profile_enable(nomad_ctx* c, int on) {
     if (!c) return fail(NOMAD_ERR_INVALID, "null ctx");
     if (on && !c->ev_ready) {
         HIP_TRY(hipSetDevice(c->device));
-        for (int i = 0; i < kMaxEvents; ++i) HIP_TRY(hipEventCreate(&c->ev[i]));
+        c->ev.resize(kEventChunk);
+        c->ev_class.resize(kEventChunk / 2);
+        for (int i = 0; i < kEventChunk; ++i) HIP_TRY(hipEventCreate(&c->ev[i]));
         c->ev_ready = true;
     }
     c->prof = on != 0;
@@ -2798,6 +2840,7 @@ static int profile_drain(nomad_ctx* c) {
 int nomad_profile_reset(nomad_ctx* c) {
     if (!c) return fail(NOMAD_ERR_INVALID, "null ctx");
     int rc = profile_drain(c);
+    c->prof_overflow = false;
     for (int i = 0; i < NOMAD_K_COUNT; ++i) {
         c->p_ms[i] = 0;
         c->p_n[i] = 0;
@@ -2811,6 +2854,7 @@ int nomad_profile_read(nomad_ctx* c, double ms[NOMAD_K_COUNT], long long launche
     if (!c || !ms || !launches || !flops) return fail(NOMAD_ERR_INVALID, "null argument");
     int rc = profile_drain(c);
     if (rc) return rc;
+    if (c->prof_overflow) return fail(NOMAD_ERR_HIP, "nomad_profile_read: the event pool could not grow; counters are incomplete");
     for (int i = 0; i < NOMAD_K_COUNT; ++i) {
         ms[i] = c->p_ms[i];
         launches[i] = c->p_n[i];

@@ -27,12 +27,15 @@ def partition(n_items: int, world_size: int, rank: int) -> Tuple[int, int]:
     return start, start + base + (1 if rank < rem else 0)
 
 
-def all_gather_rows(x: torch.Tensor, group=None, equal: bool = False) -> torch.Tensor:
+def all_gather_rows(x: torch.Tensor, group=None, equal: bool = False, force_collective: bool = False) -> torch.Tensor:
     """Concatenate per-rank (n_r, ...) tensors along dim 0 (n_r may differ between ranks).
 
     equal=True promises that every rank contributes the same number of rows: one collective, no size exchange and
-    no host synchronisation (the steady-state path of bench.py)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    no host synchronisation (the steady-state path of bench.py).
+    force_collective=True issues the collective(s) even in a group of ONE rank, where the result is the input: that is
+    how the RCCL path (communicator set-up, the all-gather launch, its ordering against the engine's stream) is
+    exercised on a single-GPU box (tests/test_gpu_rccl.py, bench.py under the distributed launcher)."""
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force_collective):
         return x
     world = dist.get_world_size(group)
     if equal:
@@ -63,11 +66,13 @@ class ShardedScorer:
     ``Engine.pairwise``.
     """
 
-    def __init__(self, embed_fn: Callable, pairwise_fn: Callable, group=None, equal_shards: bool = False):
+    def __init__(self, embed_fn: Callable, pairwise_fn: Callable, group=None, equal_shards: bool = False,
+                 force_collective: bool = False):
         self.embed_fn = embed_fn
         self.pairwise_fn = pairwise_fn
         self.group = group
         self.equal_shards = equal_shards  # every rank holds the same number of reference clips
+        self.force_collective = force_collective  # run the all-gather even at world size 1 (see all_gather_rows)
 
     def score(self, deg_wav: torch.Tensor, ref_wav: Optional[torch.Tensor], want_matrix: bool = False,
               ref_emb_local: Optional[torch.Tensor] = None):
@@ -84,10 +89,11 @@ class ShardedScorer:
                 ref_emb_local = self.embed_fn(ref_wav)
         else:
             deg_emb = self.embed_fn(deg_wav)
-        ref_all = all_gather_rows(ref_emb_local.contiguous(), self.group, equal=self.equal_shards)
+        ref_all = all_gather_rows(ref_emb_local.contiguous(), self.group, equal=self.equal_shards,
+                                  force_collective=self.force_collective)
         d, mean = self.pairwise_fn(deg_emb.contiguous(), ref_all, want_matrix)
         return mean, d, ref_all
 
     def gather_scores(self, mean_local: torch.Tensor) -> torch.Tensor:
         """All ranks' row means in global deg order (for output on any rank)."""
-        return all_gather_rows(mean_local, self.group)
+        return all_gather_rows(mean_local, self.group, force_collective=self.force_collective)

@@ -52,6 +52,21 @@ def _weights_struct(sd: Dict[str, torch.Tensor]):
     return w, keep
 
 
+class _AsyncFetch:
+    """Device tensor -> pinned host copy enqueued behind the work that produces it; ``result()`` waits for THAT copy
+    only (an event), not for whatever has been enqueued on the stream since."""
+
+    def __init__(self, dev: torch.Tensor):
+        self.host = torch.empty(dev.shape, dtype=dev.dtype, pin_memory=True)
+        self.host.copy_(dev, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record(torch.cuda.current_stream(dev.device))
+
+    def result(self):
+        self.event.synchronize()
+        return self.host.numpy()
+
+
 class Engine:
     """One engine per (process, GPU).  Not thread-safe; asynchronous on torch's current stream."""
 
@@ -163,34 +178,53 @@ class Engine:
     F32_SPLIT_ROWS = int(os.environ.get("NOMAD_F32_SPLIT_ROWS", 4000))
     F32_SPLIT_MAX_ROWS = int(os.environ.get("NOMAD_F32_SPLIT_MAX_ROWS", 40000))
 
+    def fetch_async(self, dev: torch.Tensor) -> _AsyncFetch:
+        """Start copying a result to the host; ``.result()`` (numpy) later waits for this copy alone."""
+        return _AsyncFetch(dev)
+
+    def pack_ragged_host(self, waves):
+        """Host-side half of ``embed_ragged`` for host inputs: clips -> ONE pinned (B, stride) fp32 staging tensor
+        (rows are only read up to their length: no zero fill) + lengths.  Touches no GPU state, so a worker thread
+        can build the next batch's staging buffer while the GPU runs the current one (``Nomad.get_embeddings_csv``)."""
+        flat = [torch.as_tensor(w, dtype=torch.float32).reshape(-1) for w in waves]
+        lens = [int(w.numel()) for w in flat]
+        stride = (max(lens) + 3) // 4 * 4
+        host = torch.empty(len(flat), stride, dtype=torch.float32, pin_memory=True)
+        for i, w in enumerate(flat):
+            host[i, :lens[i]] = w
+        return host, lens
+
     def embed_ragged(self, waves, head: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, bf16: bool = False,
-                     precision: Optional[str] = None) -> torch.Tensor:
+                     precision: Optional[str] = None, packed: Optional[Tuple[torch.Tensor, list]] = None) -> torch.Tensor:
         """Embed clips of different lengths in ONE launch sequence (no padding in the arithmetic).
 
         waves: list of 1-D (or (1,N)) fp32 tensors / numpy arrays (host or device).  Returns (B,256) fp32 on the
         GPU, bit-identical to embedding every clip on its own.  precision: "fp32" (default), "bf16x3" (fp32-class
-        scores from split bf16 operands) or "bf16" (also bf16=True); the last two take no head override."""
+        scores from split bf16 operands) or "bf16" (also bf16=True); the last two take no head override.
+        packed: instead of ``waves``, the (staging tensor, lengths) pair ``pack_ragged_host`` made."""
         precision = precision or ("bf16" if bf16 else "fp32")
         if precision not in ("fp32", "bf16", "bf16x3"):
             raise ValueError("precision must be 'fp32', 'bf16x3' or 'bf16'")
         if precision != "fp32" and head is not None:
             raise ValueError(f"the {precision} path has no head override")
-        flat = [torch.as_tensor(w, dtype=torch.float32).reshape(-1) for w in waves]
-        lens = [int(w.numel()) for w in flat]
-        B, stride = len(flat), max(lens)
-        stride = (stride + 3) // 4 * 4
-        # rows are only read up to lens[i], so the buffer needs no zero fill; device inputs are packed on the device,
-        # host inputs in one pinned staging buffer and ONE asynchronous copy
-        on_dev = all(w.is_cuda for w in flat)
-        if on_dev:
-            buf = torch.empty(B, stride, dtype=torch.float32, device=self.device)
-            for i, w in enumerate(flat):
-                buf[i, :lens[i]] = w
-        else:
-            host = torch.empty(B, stride, dtype=torch.float32, pin_memory=True)
-            for i, w in enumerate(flat):
-                host[i, :lens[i]] = w
+        if packed is not None:
+            host, lens = packed
+            B, stride = host.shape
             buf = host.to(self.device, non_blocking=True)
+        else:
+            flat = [torch.as_tensor(w, dtype=torch.float32).reshape(-1) for w in waves]
+            lens = [int(w.numel()) for w in flat]
+            B, stride = len(flat), max(lens)
+            stride = (stride + 3) // 4 * 4
+            # rows are only read up to lens[i], so the buffer needs no zero fill; device inputs are packed on the device,
+            # host inputs in one pinned staging buffer and ONE asynchronous copy
+            if all(w.is_cuda for w in flat):
+                buf = torch.empty(B, stride, dtype=torch.float32, device=self.device)
+                for i, w in enumerate(flat):
+                    buf[i, :lens[i]] = w
+            else:
+                host, lens = self.pack_ragged_host(flat)
+                buf = host.to(self.device, non_blocking=True)
         emb = torch.empty(B, 256, dtype=torch.float32, device=self.device)
         hw, hb = head if head is not None else (None, None)
         if precision != "fp32":
@@ -375,6 +409,18 @@ class Engine:
         return out
 
     # ---- training (differentiable forward) ---------------------------------------------------------
+    @property
+    def feature_grad_mult(self) -> float:
+        """fairseq ``feature_grad_mult``: scale of the gradient entering the conv feature extractor in
+        ``embed_backward`` (0.1 = wav2vec 2.0 BASE / wav2vec_small.pt; 1.0 = plain chain rule)."""
+        v = C.c_float()
+        _lib.check(self.lib.nomad_get_feature_grad_mult(self.ctx, C.byref(v)), "nomad_get_feature_grad_mult")
+        return float(v.value)
+
+    @feature_grad_mult.setter
+    def feature_grad_mult(self, mult: float):
+        _lib.check(self.lib.nomad_set_feature_grad_mult(self.ctx, float(mult)), "nomad_set_feature_grad_mult")
+
     def enable_backward(self):
         _lib.check(self.lib.nomad_enable_backward(self.ctx), "nomad_enable_backward")
 

@@ -34,7 +34,7 @@ import torch
 
 from . import wavio
 from .engine import Engine
-from .weights import find_checkpoint, load_checkpoint, seeded_state_dict
+from .weights import find_checkpoint, find_feature_grad_mult, load_checkpoint, seeded_state_dict
 
 SSL_OUT_DIM = 768
 EMB_DIM = 256
@@ -165,9 +165,87 @@ class _NomadLossFn(torch.autograd.Function):
 BF16X3_MIN_SAMPLES = 8 * 64000
 
 
+def _staged_batches(paths, load, pack, max_batch_samples: int, decode_threads: int, max_alive: int):
+    """Generator of (row indices, pack(waves)) batches over ``paths`` in order, built ahead of the consumer.
+
+    ``load(path) -> (1, N) array`` runs on ``decode_threads`` worker threads with a bounded look-ahead; a packer thread
+    groups consecutive files into batches of at most ``max_batch_samples`` samples (a longer file is a batch of its
+    own) and calls ``pack(list of 1-D arrays)``.  At most ``max_alive`` packed batches exist between the packer and the
+    consumer: the packer takes a token before it starts a batch, and the token returns when the consumer asks for
+    the batch AFTER the next one (by then the consumer has fetched that batch's results).  Exceptions raised by
+    ``load`` / ``pack`` re-raise in the consumer."""
+    import queue
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+
+    if not paths:
+        return
+    tokens = threading.Semaphore(max_alive)
+    out: "queue.Queue" = queue.Queue()
+    stop = threading.Event()
+    lookahead = max(4 * decode_threads, 16)
+
+    def packer():
+        try:
+            with ThreadPoolExecutor(max_workers=max(1, decode_threads)) as pool:
+                futs, nxt = {}, 0
+
+                def top_up(upto):
+                    nonlocal nxt
+                    while nxt < len(paths) and nxt < upto:
+                        futs[nxt] = pool.submit(load, paths[nxt])
+                        nxt += 1
+                idxs, waves, total = [], [], 0
+                tokens.acquire()
+                for i in range(len(paths)):
+                    if stop.is_set():
+                        return
+                    top_up(i + lookahead)
+                    w = futs.pop(i).result()
+                    w = w[0] if getattr(w, "ndim", 1) == 2 else w
+                    n = int(w.shape[0])
+                    if idxs and total + n > max_batch_samples:
+                        out.put((idxs, pack(waves)))
+                        idxs, waves, total = [], [], 0
+                        tokens.acquire()
+                    idxs.append(i)
+                    waves.append(w)
+                    total += n
+                out.put((idxs, pack(waves)))
+            out.put(None)
+        except BaseException as e:  # noqa: BLE001 - handed to the consumer
+            out.put(e)
+
+    th = threading.Thread(target=packer, name="nomad-packer", daemon=True)
+    th.start()
+    handed = 0
+    try:
+        while True:
+            item = out.get()
+            if item is None:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            handed += 1
+            if handed >= max_alive:      # the consumer is done with batch (handed - max_alive + 1): its slot is free again
+                tokens.release()
+            yield item
+    finally:
+        stop.set()
+        for _ in range(max_alive + 1):   # unblock a packer waiting for a slot
+            tokens.release()
+        th.join(timeout=30)
+
+
 class Nomad:
-    def __init__(self, device=None, weights: Union[None, str, Dict[str, torch.Tensor]] = None, precision: str = "fp32"):
-        """precision of the embeddings of ``predict`` / ``get_embeddings*``:
+    def __init__(self, device=None, weights: Union[None, str, Dict[str, torch.Tensor]] = None, precision: str = "fp32",
+                 feature_grad_mult: Union[None, float] = None):
+        """feature_grad_mult: fairseq's ``Wav2Vec2Model.feature_grad_mult`` - ``forward()``'s gradient w.r.t. ``estimate``
+        passes through ``GradMultiply(features, feature_grad_mult)`` at the conv feature extractor's output, exactly as
+        in the reference's backbone (built from wav2vec_small.pt, whose config says 0.1; nomad.py:58).  None = the value
+        in ``pt-models/wav2vec_small.pt`` if that file is present, else 0.1; 1.0 = plain chain rule.
+
+        precision of the embeddings of ``predict`` / ``get_embeddings*``:
         "fp32"   the reference's arithmetic (fp32 MFMA), scores within 1e-4 of the reference;
         "bf16x3" GEMM operands split into hi + lo bf16 planes, three bf16 MFMA products per fp32 product, fp32
                  accumulation / softmax / norms: scores within ~1e-6 of the fp32 path, 2.7x as fast on full batches
@@ -195,6 +273,7 @@ class Nomad:
         else:
             sd = weights
         self.engine = Engine(sd, dev_index)
+        self.engine.feature_grad_mult = find_feature_grad_mult() if feature_grad_mult is None else float(feature_grad_mult)
         self.model = TripletModel(self.engine)
         self.lossnet_layers = LossNetLayers(self.engine, SSL_OUT_DIM, EMB_DIM)
         self.nomad_loss = NomadLoss(self.engine)
@@ -257,8 +336,9 @@ class Nomad:
     def forward(self, estimate, clean):
         """NOMAD loss (nomad.py:142-146), differentiable w.r.t. ``estimate``.
 
-        The whole forward and backward run in the HIP engine (``torch.autograd.Function`` glue only).  The
-        backbone is frozen: the reference would also accumulate parameter gradients nobody reads
+        The whole forward and backward run in the HIP engine (``torch.autograd.Function`` glue only).  As in the
+        reference, the gradient that reaches ``estimate`` carries fairseq's ``feature_grad_mult`` (0.1 for wav2vec 2.0
+        BASE; ``Nomad(feature_grad_mult=...)`` / ``self.engine.feature_grad_mult``).  The backbone is frozen: the reference would also accumulate parameter gradients nobody reads
         (the freeze is commented out at nomad.py:74-76); ``clean`` receives no gradient."""
         return _NomadLossFn.apply(estimate, clean, self)
 
@@ -281,34 +361,37 @@ class Nomad:
 
         The reference embeds one file per iteration with a device sync each time (nomad.py:171-183).  Here files
         of arbitrary lengths are packed into ragged batches (``nomad_embed_ragged``: no padding enters the
-        arithmetic, results are bit-identical to per-file calls) of at most ``max_batch_samples`` samples."""
+        arithmetic, results are bit-identical to per-file calls) of at most ``max_batch_samples`` samples, as a
+        three-stage pipeline: a small thread pool decodes (and resamples) files ahead of need, a packer thread
+        copies each batch into a pinned staging buffer, and this thread only enqueues GPU work - batch k+1 is
+        decoded, packed and launched while the GPU still runs batch k, and results are fetched one batch late.
+        Like the reference, which holds one clip at a time, memory does not grow with the size of the directory:
+        never more than ``PIPELINE_BATCHES`` staged batches (plus the decode look-ahead) are alive."""
         file_names_arr = np.array(file_names)
         paths = []
         for row in file_names_arr:
             name = row[0] if isinstance(row, np.ndarray) else row
             paths.append(os.path.join(root, name) if root else name)
-        waves = [self.load_processing(p, trim=False) for p in paths]
-        embeddings = np.zeros((len(waves), EMB_DIM), dtype=np.float32)
-        batch, total = [], 0
-        batches = []
-        for i, w in enumerate(waves):
-            n = int(w.shape[1])
-            if batch and total + n > max_batch_samples:
-                batches.append(batch)
-                batch, total = [], 0
-            batch.append(i)
-            total += n
-        if batch:
-            batches.append(batch)
-        for idxs in batches:
+        embeddings = np.zeros((len(paths), EMB_DIM), dtype=np.float32)
+        pending = None                                   # (row indices, host copy in flight) of the previous batch
+        for idxs, packed in _staged_batches(paths, lambda p: self.load_processing(p, trim=False), self.engine.pack_ragged_host,
+                                            max_batch_samples, self.DECODE_THREADS, self.PIPELINE_BATCHES):
             prec = self.precision
-            if prec == "bf16x3" and sum(int(waves[i].shape[1]) for i in idxs) < BF16X3_MIN_SAMPLES:
+            if prec == "bf16x3" and sum(packed[1]) < BF16X3_MIN_SAMPLES:
                 prec = "fp32"   # a handful of files does not fill the 256 x 256 tiles: the exact path is also the faster one
-            emb = self.engine.embed_ragged([waves[i][0] for i in idxs], precision=prec)
-            embeddings[idxs] = emb.cpu().numpy()
+            emb = self.engine.embed_ragged(None, precision=prec, packed=packed)   # asynchronous
+            fetch = self.engine.fetch_async(emb)                                   # D2H enqueued right behind it
+            if pending is not None:
+                embeddings[pending[0]] = pending[1].result()                        # waits for the PREVIOUS batch only
+            pending = (idxs, fetch)
+        if pending is not None:
+            embeddings[pending[0]] = pending[1].result()
         emb_df = pd.DataFrame(embeddings)
         df_emb = pd.concat([file_names.reset_index(), emb_df], axis=1).drop("index", axis=1)
         return df_emb
+
+    DECODE_THREADS = int(os.environ.get("NOMAD_DECODE_THREADS", min(8, os.cpu_count() or 1)))
+    PIPELINE_BATCHES = 2      # staged batches alive at any time: one on the GPU, one being built / waiting
 
     def load_processing(self, filepath, target_sr=16000, trim=False):
         """file -> (1, N) fp32 mono tensor at 16 kHz, like the reference (nomad.py:192-212) but without torchaudio."""

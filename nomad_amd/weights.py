@@ -169,3 +169,41 @@ def find_checkpoint() -> Optional[str]:
         if cand and os.path.isfile(cand):
             return cand
     return None
+
+
+# fairseq wav2vec 2.0 BASE pre-training config (the cfg stored inside wav2vec_small.pt, which
+# load_model_ensemble_and_task keeps when the reference builds its model, nomad.py:58): the gradient entering the
+# conv feature extractor is scaled by this (GradMultiply on the extractor output, Wav2Vec2Model.forward)
+W2V_BASE_FEATURE_GRAD_MULT = 0.1
+
+
+def feature_grad_mult_of(obj) -> Optional[float]:
+    """``feature_grad_mult`` of a loaded fairseq checkpoint object (``{'cfg': {'model': {...}}}`` in fairseq >= 0.10.2,
+    ``{'args': Namespace}`` before), or None when the object carries no model config (a plain state dict)."""
+    if not isinstance(obj, dict):
+        return None
+    cfg = obj.get("cfg")
+    model = None
+    if cfg is not None:
+        model = cfg.get("model") if hasattr(cfg, "get") else getattr(cfg, "model", None)
+    if model is None:
+        model = obj.get("args")
+    if model is None:
+        return None
+    v = model.get("feature_grad_mult") if hasattr(model, "get") else getattr(model, "feature_grad_mult", None)
+    return None if v is None else float(v)
+
+
+def find_feature_grad_mult() -> float:
+    """The value the reference's model would carry: read from ``$NOMAD_W2V_CHECKPOINT`` or
+    ``./pt-models/wav2vec_small.pt`` (the reference's download location, nomad.py:21) when that file is present and
+    un-picklable here, else the wav2vec 2.0 BASE value 0.1."""
+    for cand in (os.environ.get("NOMAD_W2V_CHECKPOINT"), os.path.join("pt-models", "wav2vec_small.pt")):
+        if cand and os.path.isfile(cand):
+            try:
+                v = feature_grad_mult_of(torch.load(cand, map_location="cpu", weights_only=False))
+            except Exception:  # pickled fairseq / omegaconf classes that are not importable here
+                v = None
+            if v is not None:
+                return v
+    return W2V_BASE_FEATURE_GRAD_MULT

@@ -17,6 +17,11 @@ Fixtures written (data only):
   tests/golden/hf_tiny.npz         batch of 3 synthetic clips of 6000 samples: full 12 layer outputs + embeddings
   tests/golden/hf_loss.npz         nomad.forward() pins: two (2,1,16384) inputs -> loss and d loss/d estimate
                                    (HF layers + torch L1 + torch autograd)
+  tests/golden/hf_grad_fgm.npz     (``python oracle/make_golden.py fgm``) gradients with fairseq's
+                                   ``GradMultiply(features, feature_grad_mult)`` hooked onto the HF model's
+                                   feature-extractor output: d loss/d estimate of the hf_loss.npz inputs at 0.1, and
+                                   the gradient of a smooth functional of the 13 outputs of one 42 000-sample clip
+                                   (T = 131: three attention tiles) at 0.1 and 1.0
 """
 import os
 import shutil
@@ -158,5 +163,83 @@ def main():
     print("loss", float(loss))
 
 
+class _GradMultiply(torch.autograd.Function):
+    """fairseq/modules/grad_multiply.py (GradMultiply): identity forward, grad * scale backward."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.scale = scale
+        return x.new(x)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return grad * ctx.scale, None
+
+
+def smooth_functional_weights(B, T, seed):
+    """Upstream gradients of the smooth test functional sum_i <out_i, G_i>; tests regenerate them from the seed."""
+    g = torch.Generator().manual_seed(seed)
+    G_layers = torch.randn(12, B, T, 768, generator=g) / (B * T * 768)
+    G_emb = torch.randn(B, 256, generator=g) / (B * 256)
+    return G_layers, G_emb
+
+
+def main_fgm():
+    """Gradient pins with fairseq's feature_grad_mult: HF has no such knob, so the GradMultiply is attached as a
+    forward hook on HF's feature extractor (whose output is what fairseq calls ``features``)."""
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    sd = seeded_state_dict(0)
+    m = hf_model_from_state_dict(sd)
+    scale = {"v": 1.0}
+    m.feature_extractor.register_forward_hook(
+        lambda mod, inp, out: out if scale["v"] == 1.0 else _GradMultiply.apply(out, scale["v"]))
+
+    def hf_outputs(w):
+        o = m(w, output_hidden_states=True)
+        return list(o.hidden_states[1:]), o.last_hidden_state
+
+    # (a) the hf_loss.npz inputs (same generator sequence as main() section 4), feature_grad_mult = 0.1
+    g = torch.Generator().manual_seed(7)
+    clean = (0.1 * torch.randn(2, 1, 16384, generator=g)).clamp(-1, 1)
+    est = (clean + 0.02 * torch.randn(2, 1, 16384, generator=g)).clamp(-1, 1)
+    lw = (torch.rand(256, 768, generator=g) * 2 - 1) / 768 ** 0.5
+    lb = (torch.rand(256, generator=g) * 2 - 1) / 768 ** 0.5
+    old = np.load(os.path.join(GOLD, "hf_loss.npz"))
+    assert np.array_equal(old["estimate"], est.numpy()) and np.array_equal(old["emb_w"], lw.numpy())
+    est.requires_grad_(True)
+    scale["v"] = 0.1
+    outs = []
+    for w_ in (est, clean):
+        layers, last = hf_outputs(w_.squeeze(1))
+        outs.append(layers + [hf_head(last, lw, lb)])
+    loss = sum(torch.nn.functional.l1_loss(a, b) for a, b in zip(outs[0], outs[1]))
+    (grad_l1,) = torch.autograd.grad(loss, est)
+    assert abs(float(loss.detach()) - float(old["loss"])) < 1e-6
+    print("L1 loss grad at 0.1 vs 0.1 * stored grad: max rel",
+          float((grad_l1 - 0.1 * torch.from_numpy(old["grad"])).abs().max() / grad_l1.abs().max()))
+
+    # (b) one 42 000-sample clip (T = 131 frames: odd, three 64-key attention tiles), smooth functional
+    gen = torch.Generator().manual_seed(21)
+    wav = (0.1 * torch.randn(1, 42000, generator=gen)).clamp(-1, 1)
+    T = 131
+    G_layers, G_emb = smooth_functional_weights(1, T, 22)
+    grads = {}
+    for mult in (0.1, 1.0):
+        scale["v"] = mult
+        w = wav.clone().requires_grad_(True)
+        layers, last = hf_outputs(w)
+        assert layers[0].shape == (1, T, 768)
+        s = sum((layers[i] * G_layers[i]).sum() for i in range(12)) + (hf_head(last, lw, lb) * G_emb).sum()
+        (grads[mult],) = torch.autograd.grad(s, w)
+    print("smooth functional: grad(0.1) vs 0.1 * grad(1.0): max rel",
+          float((grads[0.1] - 0.1 * grads[1.0]).abs().max() / grads[0.1].abs().max()))
+    np.savez(os.path.join(GOLD, "hf_grad_fgm.npz"), grad_l1_fgm01=grad_l1.numpy(), long_wav=wav.numpy(),
+             long_grad_fgm01=grads[0.1].numpy(), long_grad_fgm1=grads[1.0].numpy(), g_seed=np.int64(22))  # head: emb_w / emb_b of hf_loss.npz
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "fgm":
+        main_fgm()
+    else:
+        main()

@@ -69,9 +69,11 @@ def feature_extractor(sd: Dict[str, torch.Tensor], wav: torch.Tensor, taps: Opti
 
 
 def encoder_layer(sd: Dict[str, torch.Tensor], l: int, x: torch.Tensor, taps: Optional[dict] = None,
-                  stoch: Optional["Stochastic"] = None) -> torch.Tensor:
+                  stoch: Optional["Stochastic"] = None, key_padding_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     """One post-LN TransformerSentenceEncoderLayer (layer_norm_first=False). x: (B,T,768).
-    stoch=None is eval mode; otherwise fairseq's train-mode dropouts with the engine's counter-based masks."""
+    stoch=None is eval mode; otherwise fairseq's train-mode dropouts with the engine's counter-based masks.
+    key_padding_mask (B,T) bool, True = padded key: fairseq MultiheadAttention fills those score columns with -inf
+    before the softmax (``attn_weights.masked_fill(key_padding_mask[:, None, None, :], -inf)``)."""
     q_ = P + f"encoder.layers.{l}."
     B, T, C = x.shape
     hd = C // NUM_HEADS
@@ -81,7 +83,10 @@ def encoder_layer(sd: Dict[str, torch.Tensor], l: int, x: torch.Tensor, taps: Op
     q = q.view(B, T, NUM_HEADS, hd).transpose(1, 2)
     k = k.view(B, T, NUM_HEADS, hd).transpose(1, 2)
     v = v.view(B, T, NUM_HEADS, hd).transpose(1, 2)
-    probs = torch.softmax(q @ k.transpose(-1, -2), dim=-1)
+    scores = q @ k.transpose(-1, -2)
+    if key_padding_mask is not None:
+        scores = scores.masked_fill(key_padding_mask[:, None, None, :], float("-inf"))
+    probs = torch.softmax(scores, dim=-1)
     if stoch is not None:
         probs = probs * stoch.mult(2 + 3 * l, probs.shape, stoch.attention_dropout)
     a = probs @ v
@@ -100,14 +105,47 @@ def encoder_layer(sd: Dict[str, torch.Tensor], l: int, x: torch.Tensor, taps: Op
     return x
 
 
+class GradMultiply(torch.autograd.Function):
+    """fairseq/modules/grad_multiply.py: identity in the forward, gradient times ``scale`` in the backward."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.scale = scale
+        return x.new(x)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return grad * ctx.scale, None
+
+
 def backbone(sd: Dict[str, torch.Tensor], wav: torch.Tensor, taps: Optional[dict] = None,
-             stoch: Optional["Stochastic"] = None) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+             stoch: Optional["Stochastic"] = None, feature_grad_mult: float = 1.0,
+             required_seq_len_multiple: int = 1) -> Tuple[torch.Tensor, List[torch.Tensor]]:
     """wav (B,N) -> (x (B,T,768), [12 layer outputs (B,T,768)]).
 
     The reference gets ``layer_results`` as (T,B,768) tuples and permutes them to (B,T,768)
     (nomad.py:248); the list returned here is already in that (B,T,768) form.
+
+    feature_grad_mult: fairseq ``Wav2Vec2Model.forward`` - ``features = self.feature_extractor(source)`` then, if
+    ``feature_grad_mult != 1.0``, ``features = GradMultiply.apply(features, self.feature_grad_mult)`` (train and eval
+    alike; with 0 the extractor runs under ``torch.no_grad()``).  wav2vec 2.0 BASE (wav2vec_small.pt): 0.1.  The
+    forward values do not depend on it; 1.0 (default here) is the plain chain rule.
+
+    required_seq_len_multiple: fairseq >= 0.12 ``TransformerEncoder.extract_features`` pads the frame axis with zero
+    frames to a multiple of this (config default 2) AFTER the positional conv and encoder LayerNorm, passes a
+    key-padding mask over the pad frames to every layer, and strips the pad frames from ``x`` and from every entry of
+    ``layer_results`` afterwards.  Real frames never attend to a pad frame (their score is -inf, exp(-inf) = 0 adds
+    exactly nothing to the softmax sum), so it changes no value on real frames: 1 (default, no padding) and 2 agree -
+    tests/test_oracle.py::test_pad_to_multiple_is_a_noop checks that.
     """
-    x = feature_extractor(sd, wav, taps)
+    if feature_grad_mult > 0:
+        x = feature_extractor(sd, wav, taps)
+        if feature_grad_mult != 1.0:
+            # fairseq multiplies the (B,512,T) tensor before the transpose; a transpose commutes with an elementwise scale
+            x = GradMultiply.apply(x, feature_grad_mult)
+    else:
+        with torch.no_grad():
+            x = feature_extractor(sd, wav, taps)
     x = F.layer_norm(x, (512,), sd[P + "layer_norm.weight"], sd[P + "layer_norm.bias"], 1e-5)
     x = F.linear(x, sd[P + "post_extract_proj.weight"], sd[P + "post_extract_proj.bias"])
     if stoch is not None:  # dropout_input
@@ -123,10 +161,18 @@ def backbone(sd: Dict[str, torch.Tensor], wav: torch.Tensor, taps: Optional[dict
         x = x * stoch.mult(1, x.shape, stoch.dropout)
     if taps is not None:
         taps["enc_in"] = x
+    T_real, kpm = x.shape[1], None
+    pad = (-T_real) % max(1, int(required_seq_len_multiple))
+    if pad:
+        if stoch is not None:
+            raise NotImplementedError("the padded variant restates the eval-mode call only")
+        x = F.pad(x, (0, 0, 0, pad), value=0.0)  # pad_to_multiple(x, multiple, dim=-2, value=0)
+        kpm = torch.zeros(x.shape[0], x.shape[1], dtype=torch.bool)
+        kpm[:, -pad:] = True
     layers = []
     for l in range(NUM_LAYERS):
         if stoch is None:
-            x = encoder_layer(sd, l, x, taps, stoch)
+            x = encoder_layer(sd, l, x, taps, stoch, kpm)
         elif stoch.branch_masks is None:
             if (stoch.layer_mask >> l) & 1:  # LayerDrop: a dropped layer is the identity
                 x = encoder_layer(sd, l, x, taps, stoch)
@@ -139,6 +185,9 @@ def backbone(sd: Dict[str, torch.Tensor], wav: torch.Tensor, taps: Optional[dict
                 keep_rows = keep.repeat_interleave(x.shape[0] // nb)[:, None, None]
                 x = torch.where(keep_rows, encoder_layer(sd, l, x, taps, stoch), x)
         layers.append(x)
+    if pad:  # "undo padding": x[:, :-pad_length] and every layer result likewise
+        x = x[:, :T_real]
+        layers = [y[:, :T_real] for y in layers]
     return x, layers
 
 
@@ -157,15 +206,18 @@ def triplet_forward(sd: Dict[str, torch.Tensor], wav: torch.Tensor, stoch: Optio
 
 
 def lossnet_forward(sd: Dict[str, torch.Tensor], wav: torch.Tensor,
-                    emb_w: torch.Tensor, emb_b: torch.Tensor) -> List[torch.Tensor]:
+                    emb_w: torch.Tensor, emb_b: torch.Tensor, feature_grad_mult: float = 1.0,
+                    required_seq_len_multiple: int = 1) -> List[torch.Tensor]:
     """``LossNetLayers.forward`` (nomad.py:243-258): 12 layer outputs (B,T,768) + embedding (B,256).
 
     ``emb_w/emb_b`` are LossNetLayers' OWN embedding layer (nomad.py:238-241), which the reference
     never loads from the checkpoint (it stays randomly initialised) - callers inject it.
+    ``feature_grad_mult`` / ``required_seq_len_multiple``: see ``backbone`` (the reference's model has 0.1 and,
+    with fairseq >= 0.12, 2).
     """
     if wav.dim() == 3:
         wav = wav.squeeze(1)
-    x, layers = backbone(sd, wav)
+    x, layers = backbone(sd, wav, feature_grad_mult=feature_grad_mult, required_seq_len_multiple=required_seq_len_multiple)
     return list(layers) + [head(x, emb_w, emb_b)]
 
 

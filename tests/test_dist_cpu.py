@@ -110,3 +110,35 @@ def test_allreduce_mean_gradients_world2():
         assert p.exitcode == 0
     want = [i * 1.5 for i in range(10)]  # mean of 1x and 2x
     assert res[0] == want and res[1] == want
+
+
+# ---- force_collective: a group of ONE rank still issues the collectives (what the 1-GPU RCCL test relies on) ----------
+def _ws1_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = {"n": 0}
+    real = dist.all_gather_into_tensor
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+    dist.all_gather_into_tensor = counting
+    g = torch.Generator().manual_seed(5)
+    deg, ref = torch.randn(5, 320, generator=g), torch.randn(3, 320, generator=g)
+    res = {}
+    for name, force, equal in (("skip", False, True), ("equal", True, True), ("sizes", True, False)):
+        calls["n"] = 0
+        sc = ShardedScorer(_fake_embed, _fake_pairwise, equal_shards=equal, force_collective=force)
+        mean, d, ref_all = sc.score(deg, ref, want_matrix=True)
+        res[name] = (calls["n"], mean.clone(), d.clone(), ref_all.clone())
+    np.savez(os.path.join(out_dir, "ws1.npz"), calls=np.array([res[k][0] for k in ("skip", "equal", "sizes")]),
+             same=np.array([all(torch.equal(res["skip"][i], res[k][i]) for i in (1, 2, 3)) for k in ("equal", "sizes")]))
+    dist.destroy_process_group()
+
+
+def test_force_collective_in_a_group_of_one(tmp_path):
+    mp.spawn(_ws1_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    out = np.load(os.path.join(tmp_path, "ws1.npz"))
+    assert out["calls"].tolist() == [0, 1, 2]     # none / the all-gather / size exchange + all-gather
+    assert out["same"].all()

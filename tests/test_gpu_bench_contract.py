@@ -33,6 +33,9 @@ def test_bench_line_contract():
         assert key in r, key
     assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert abs(out["value"] - 16 * 2 / (out["ms_per_step"] * 2e-3)) / out["value"] < 1e-3
+    assert out["config"]["collective"].startswith("none") and out["config"]["workload"].startswith("custom")
+    assert out["roofline"]["traffic"] is None and out["roofline"]["traffic_source"] is None   # only known for the full config
+    assert "also_measured_c5" not in out                                                     # only next to the headline workload
     also = out["also_measured"]
     assert also["unit"] == "clips/s" and also["value"] > 0 and also["max_abs_score_diff_vs_f32"] < 1e-4
 
@@ -43,3 +46,5 @@ def test_bench_under_the_distributed_launcher():
                launcher=("-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                          "--master-port", "29541"))
     assert out["n_gpus"] == 1 and out["steps"] == 1 and "also_measured" not in out
+    # under the launcher the RCCL process group exists at world size 1 too and the all-gather is really issued
+    assert out["config"]["collective"].startswith("RCCL all_gather_into_tensor executed")

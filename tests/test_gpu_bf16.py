@@ -77,7 +77,7 @@ def test_embed_bf16_vs_fp32_path(engine):
     d16, m16 = engine.pairwise(e16[:6].contiguous(), e16[6:].contiguous())
     serr = (d16 - d32).abs().max().item()
     print(f"bf16 vs fp32: embedding max|err| {err:.3e}, min cosine {cos:.6f}, score max|err| {serr:.3e}")
-    assert err < 2e-2 and cos > 0.999 and serr < 5e-2
+    assert err < 3e-3 and cos > 0.99997 and serr < 1.2e-3      # measured 9.5e-4 / 0.99999 / 3.6e-4
 
 
 def test_embed_bf16_long_form(engine):
@@ -87,7 +87,7 @@ def test_embed_bf16_long_form(engine):
     e32 = engine.embed(wav)
     e16 = engine.embed_bf16(wav)
     assert torch.isfinite(e16).all()
-    assert F.cosine_similarity(e16, e32, dim=1).min().item() > 0.999
+    assert (e16 - e32).abs().max().item() < 3e-3 and F.cosine_similarity(e16, e32, dim=1).min().item() > 0.99997
     one = engine.embed_bf16(wav[1:2].contiguous())
     assert torch.equal(one[0], e16[1])      # batch invariance holds in bf16 too
 

@@ -213,7 +213,8 @@ def test_predict_bf16x3_small_batches_take_the_fp32_path(built_lib, monkeypatch)
     import os
     import numpy as np
     from conftest import GOLD
-    import nomad_amd.nomad as NM
+    import importlib
+    NM = importlib.import_module("nomad_amd.nomad")
     nmr = os.path.join(GOLD, "wavs", "nmr-data")
     e32 = NM.Nomad(weights="seeded").get_embeddings(nmr).iloc[:, 1:].values.astype(np.float32)
     ex3 = NM.Nomad(weights="seeded", precision="bf16x3").get_embeddings(nmr).iloc[:, 1:].values.astype(np.float32)

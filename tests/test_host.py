@@ -158,3 +158,124 @@ def test_load_pretrained_accepts_a_fairseq_style_checkpoint(tmp_path):
     nomad_path = str(tmp_path / "nomad.pt")
     torch.save(sd, nomad_path)
     assert torch.equal(load_pretrained(nomad_path)["embedding_layer.1.weight"], sd["embedding_layer.1.weight"])
+
+
+# ---- the decode -> pack -> launch pipeline of Nomad.get_embeddings_csv (host logic, fake engine) ----------------------
+class _FakeEngine:
+    """Records what the pipeline asks of an Engine; "embeds" a clip as [length, first sample, ...]."""
+
+    def __init__(self):
+        self.alive = 0          # packed batches not yet dropped by the consumer
+        self.max_alive = 0
+        self.batches = []
+
+    def pack_ragged_host(self, waves):
+        import weakref
+        self.alive += 1
+        self.max_alive = max(self.max_alive, self.alive)
+        lens = [int(w.shape[0]) for w in waves]
+        host = np.zeros((len(waves), max(lens)), dtype=np.float32)
+        for i, w in enumerate(waves):
+            host[i, :lens[i]] = w
+
+        class Buf:                       # something that can carry a finalizer (a stand-in for the pinned tensor)
+            pass
+        b = Buf()
+        b.host = host
+        weakref.finalize(b, self._dropped)
+        return b, lens
+
+    def _dropped(self):
+        self.alive -= 1
+
+    def embed_ragged(self, waves, precision=None, packed=None):
+        assert waves is None
+        b, lens = packed
+        self.batches.append(list(lens))
+        out = np.zeros((len(lens), 256), dtype=np.float32)
+        out[:, 0] = lens
+        out[:, 1] = b.host[:, 0]
+        return out
+
+    def fetch_async(self, emb):
+        class F:
+            def result(self_inner):
+                return emb
+        return F()
+
+
+def _fake_nomad(eng, loads):
+    from nomad_amd.nomad import Nomad
+    n = Nomad.__new__(Nomad)            # no GPU: only the host pipeline is under test
+    n.engine, n.precision = eng, "fp32"
+    n.load_processing = lambda p, trim=False: loads(p)
+    return n
+
+
+def test_embedding_pipeline_order_batching_and_bounded_memory():
+    import pandas as pd
+    rng = np.random.default_rng(0)
+    lens = [int(x) for x in rng.integers(100, 4000, size=57)] + [9000] + [50, 60]   # one file longer than a whole batch
+    paths = [f"f{i}.wav" for i in range(len(lens))]
+
+    def load(p):
+        i = int(p[1:-4])
+        return np.full((1, lens[i]), float(i), dtype=np.float32)
+    eng = _FakeEngine()
+    n = _fake_nomad(eng, load)
+    df = n.get_embeddings_csv(None, pd.DataFrame({"filename": paths}), max_batch_samples=8000)
+    assert list(df["filename"]) == paths                                  # listing order kept
+    assert [int(x) for x in df[0]] == lens and [int(x) for x in df[1]] == list(range(len(lens)))
+    assert [l for b in eng.batches for l in b] == lens                    # consecutive files, every file exactly once
+    assert all(sum(b) <= 8000 or len(b) == 1 for b in eng.batches) and [9000] in eng.batches
+    assert len(eng.batches) > 5
+    assert eng.max_alive <= 2 + 1     # PIPELINE_BATCHES staged batches (+1 for the instant the consumer swaps batches)
+
+
+def test_embedding_pipeline_propagates_decode_errors_and_handles_empty():
+    import pandas as pd
+
+    def load(p):
+        if p == "bad.wav":
+            raise ValueError("bad.wav: not a RIFF/WAVE file")
+        return np.zeros((1, 500), dtype=np.float32)
+    n = _fake_nomad(_FakeEngine(), load)
+    with pytest.raises(ValueError, match="bad.wav"):
+        n.get_embeddings_csv(None, pd.DataFrame({"filename": ["a.wav"] * 40 + ["bad.wav"] + ["b.wav"] * 40}), max_batch_samples=2000)
+    df = n.get_embeddings_csv(None, pd.DataFrame({"filename": []}))
+    assert df.shape[0] == 0
+
+
+# ---- resampler parity: the product's form vs the separately written restatement of torchaudio's formulation -----------
+@pytest.mark.parametrize("sr", [8000, 22050, 44100, 48000, 11025, 32000])
+def test_resampler_matches_the_torchaudio_restatement(sr):
+    """nomad.py:203-205: torchaudio.transforms.Resample(sr, 16000).  wavio.resample (numpy, strided windows + einsum)
+    against oracle/resample_oracle.py (torch, per-phase kernels + conv1d(stride=orig), torchaudio's own formulation):
+    same length, samples within 1e-6 (fp32 summation order is the only difference)."""
+    import torch
+    from oracle import resample_oracle as R
+    rng = np.random.default_rng(sr)
+    x = (0.3 * rng.standard_normal((2, sr + 123))).astype(np.float32)       # 1 s + an awkward tail, two channels
+    y = wavio.resample(x, sr, 16000)
+    ref = R.resample(torch.from_numpy(x), sr, 16000).numpy()
+    assert y.shape == ref.shape == (2, math.ceil((sr + 123) * 16000 / sr))
+    assert np.abs(y - ref).max() < 1e-6, np.abs(y - ref).max()
+    # kernel itself: identical taps
+    k, w, orig, new = wavio._sinc_kernel(sr, 16000)
+    kref, wref = R.sinc_resample_kernel(orig, new)
+    assert w == wref and k.shape == tuple(kref.shape[::2]) and np.abs(k - kref[:, 0].numpy()).max() < 1e-7
+
+
+def test_load_processing_resamples_like_the_restatement(tmp_path):
+    """End of the front end: a 44.1 kHz stereo PCM-16 file through load_processing == mono mix then the restated
+    resampler (nomad.py:199-205 order: mix first, resample second)."""
+    import torch
+    from scipy.io import wavfile
+    from oracle import resample_oracle as R
+    rng = np.random.default_rng(7)
+    st = (rng.standard_normal((44100, 2)) * 4000).astype(np.int16)
+    wavfile.write(tmp_path / "s.wav", 44100, st)
+    w = wavio.load_processing(str(tmp_path / "s.wav"))
+    mono = (st[:, 0].astype(np.float32) / 32768.0 + st[:, 1].astype(np.float32) / 32768.0) / 2
+    ref = R.resample(torch.from_numpy(mono[None, :]), 44100, 16000).numpy()
+    assert w.shape == ref.shape == (1, 16000) and np.abs(w - ref).max() < 1e-6
