@@ -308,8 +308,11 @@ int nomad_diag_gemm_bf16x3(nomad_ctx* ctx, const void* A_dev, const void* W_dev,
  * waves per (clip, head). */
 int nomad_diag_attention_bf16x3(nomad_ctx* ctx, const void* qkv_dev, void* out_dev, int B, int T, int waves,
                                 nomad_stream_t stream);
-/* bf16 attention: qkv [B*T][2304] bf16 (q pre-scaled) -> out [B*T][768] bf16. */
-int nomad_diag_attention_bf16(nomad_ctx* ctx, const void* qkv_dev, void* out_dev, int B, int T, nomad_stream_t stream);
+/* bf16 attention: qkv [B*T][2304] bf16 (q pre-scaled by 64^-0.5) -> out [B*T][768] bf16.  q_has_log2e != 0: q is
+ * additionally scaled by log2(e), as the bf16 forward's QKV projection produces it (the kernel works in log2 units);
+ * 0: plain q, scaled (and re-rounded to bf16) inside the kernel. */
+int nomad_diag_attention_bf16(nomad_ctx* ctx, const void* qkv_dev, void* out_dev, int B, int T, int q_has_log2e,
+                              nomad_stream_t stream);
 /* out[M][N] = LayerNorm(in[M][N]) * gamma + beta, N in {512, 768}, eps 1e-5. */
 /* one wave spins for spin_ticks of the 100 MHz wall counter; out_dev[0] = shader-clock cycles elapsed, out_dev[1] = wall
  * ticks: run it on a second stream to read the clock a kernel under test actually gets */

@@ -78,7 +78,7 @@ SIGNATURES = {
     "nomad_diag_split_bf16": (C.c_int, [C.c_void_p, _fp, _fp, C.c_longlong, C.c_longlong, C.c_int, _fp]),
     "nomad_diag_gemm_bf16x3": (C.c_int, [C.c_void_p, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "nomad_diag_gemm_bf16": (C.c_int, [C.c_void_p, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
-    "nomad_diag_attention_bf16": (C.c_int, [C.c_void_p, _fp, _fp, C.c_int, C.c_int, _fp]),
+    "nomad_diag_attention_bf16": (C.c_int, [C.c_void_p, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     "nomad_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "nomad_profile_reset": (C.c_int, [C.c_void_p]),
     "nomad_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),

@@ -90,4 +90,20 @@ __global__ __launch_bounds__(256) void to_bf16_kernel(const float* __restrict__ 
         store4<bf16_t>(out + 4 * i, *reinterpret_cast<const float4*>(in + 4 * i));
 }
 
+// the same with the first `n4_scaled` float4 groups multiplied by `scale` (q rows of the fused QKV weight: log2 e)
+__global__ __launch_bounds__(256) void to_bf16_scaled_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long long n4,
+                                                             long long n4_scaled, float scale) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        float4 v = *reinterpret_cast<const float4*>(in + 4 * i);
+        if (i < n4_scaled) v = make_float4(v.x * scale, v.y * scale, v.z * scale, v.w * scale);
+        store4<bf16_t>(out + 4 * i, v);
+    }
+}
+// out[i] = in[i] * (i < n_scaled ? scale : 1)   (fp32 bias of the fused QKV projection, q part)
+__global__ __launch_bounds__(256) void scale_head_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int n_scaled,
+                                                         float scale) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = in[i] * (i < n_scaled ? scale : 1.0f);
+}
+
 }  // namespace nomad

@@ -24,6 +24,7 @@
 
 #include "../../include/nomad_hip.h"
 #include "attention.hip.h"
+#include "attention_bf16_v2.hip.h"
 #include "attention_bwd.hip.h"
 #include "backward.hip.h"
 #include "frontend.hip.h"
@@ -283,6 +284,9 @@ struct nomad_ctx {
     bf16_t *proj_w16 = nullptr, *pos_w16 = nullptr;
     bf16_t *qkv_w16[NOMAD_NUM_LAYERS] = {}, *o_w16[NOMAD_NUM_LAYERS] = {}, *fc1_w16[NOMAD_NUM_LAYERS] = {},
            *fc2_w16[NOMAD_NUM_LAYERS] = {};
+    // the bf16 path's q rows of the fused QKV weight and bias also carry log2(e): its attention kernel works in log2
+    // units (p = 2^(s - m), attention_bf16_v2.hip.h); qkv_b16 is the matching fp32 bias
+    float* qkv_b16[NOMAD_NUM_LAYERS] = {};
     // split (hi | lo bf16 planes) weight copies for the bf16x3 path (built by nomad_enable_bf16x3)
     bool x3_ready = false;
     bf16s_t* conv_wx[7] = {};
@@ -1103,6 +1107,16 @@ static int run_ln_bwd(nomad_ctx* c, const float* x, const float* g, const float*
 }
 
 // ---- bf16 path (config C5) -----------------------------------------------------------------------------
+// bf16 attention (attention_bf16_v2.hip.h).  T = frames per clip (the longest clip's with tpref).  256-query workgroups
+// when that still gives the chip >= 2 rounds of them, 128-query ones for small batches.  log2e: q carries log2(e).
+static hipError_t run_attention_bf16(const bf16_t* qkv, bf16_t* out, int B, int T, const int* tpref, bool log2e, hipStream_t s) {
+    const bool big = (long long)((T + 255) / 256) * B * 12 >= 1024;
+    if (log2e) return big ? launch_attention_bf16_v2<8, 64, 4, true>(qkv, out, B, T, tpref, s)
+                          : launch_attention_bf16_v2<4, 64, 4, true>(qkv, out, B, T, tpref, s);
+    return big ? launch_attention_bf16_v2<8, 64, 4, false>(qkv, out, B, T, tpref, s)
+               : launch_attention_bf16_v2<4, 64, 4, false>(qkv, out, B, T, tpref, s);
+}
+
 static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, int tile = -1) {
     const double flops = 2.0 * p.M * (double)p.n_valid * p.K * groups;  // bf16x3: the fp32-equivalent count, not 3x
     if (tile < 0) {
@@ -1316,11 +1330,11 @@ static int forward_bf16(nomad_ctx* c, const float* wav, int B, int n_samples, fl
     }
     for (int l = 0; l < NOMAD_NUM_LAYERS; ++l) {
         const LayerDev& d = c->layers[l];
-        if ((rc = run_gemm_bf16(c, dense(asf(x), 768, asf(c->qkv_w16[l]), d.qkv_b, nullptr, asfm(qkv), M, 2304, 768, 0), 1, s)))
+        if ((rc = run_gemm_bf16(c, dense(asf(x), 768, asf(c->qkv_w16[l]), c->qkv_b16[l], nullptr, asfm(qkv), M, 2304, 768, 0), 1, s)))
             return rc;
         {
             Scope sc(c, s, NOMAD_K_ATTN, 4.0 * B * 12.0 * (double)T * T * 64);
-            hipLaunchKernelGGL(attention_bf16_kernel, dim3((T + 63) / 64, B * 12), dim3(256), 0, s, qkv, ctxb, T);
+            HIP_TRY(run_attention_bf16(qkv, ctxb, B, T, nullptr, true, s));
         }
         if ((rc = run_gemm_bf16(c, dense(asf(ctxb), 768, asf(c->o_w16[l]), d.o_b, asf(x), asfm(y), M, 768, 768, 0), 1, s)))
             return rc;
@@ -1810,11 +1824,11 @@ static int forward_ragged_bf16(nomad_ctx* c, const float* wav, int B, int stride
     }
     for (int l = 0; l < NOMAD_NUM_LAYERS; ++l) {
         const LayerDev& d = c->layers[l];
-        if ((rc = run_gemm_bf16(c, dense(asf(x), 768, asf(c->qkv_w16[l]), d.qkv_b, nullptr, asfm(qkv), M, 2304, 768, 0), 1, s)))
+        if ((rc = run_gemm_bf16(c, dense(asf(x), 768, asf(c->qkv_w16[l]), c->qkv_b16[l], nullptr, asfm(qkv), M, 2304, 768, 0), 1, s)))
             return rc;
         {
             Scope sc(c, s, NOMAD_K_ATTN, attn_flops);
-            hipLaunchKernelGGL(attention_bf16_kernel, dim3((rs.max_t + 63) / 64, B * 12), dim3(256), 0, s, qkv, ctxb, 0, tpref);
+            HIP_TRY(run_attention_bf16(qkv, ctxb, B, rs.max_t, tpref, true, s));
         }
         if ((rc = run_gemm_bf16(c, dense(asf(ctxb), 768, asf(c->o_w16[l]), d.o_b, asf(x), asfm(y), M, 768, 768, 0), 1, s)))
             return rc;
@@ -1866,6 +1880,15 @@ int nomad_enable_bf16(nomad_ctx* c) {
     for (int l = 0; l < NOMAD_NUM_LAYERS; ++l) {
         const LayerDev& d = c->layers[l];
         if ((rc = conv(d.qkv_w, (size_t)2304 * 768, &c->qkv_w16[l]))) return rc;
+        hipLaunchKernelGGL(to_bf16_scaled_kernel, dim3(1024), dim3(256), 0, 0, d.qkv_w, c->qkv_w16[l], (long long)2304 * 768 / 4,
+                           (long long)768 * 768 / 4, kLog2e);  // q rows: q * 64^-0.5 * log2(e), rounded to bf16 once
+        if (!c->qkv_b16[l]) {
+            void* p = nullptr;
+            HIP_TRY(hipMalloc(&p, 2304 * sizeof(float)));
+            c->allocs.push_back(p);
+            c->qkv_b16[l] = static_cast<float*>(p);
+        }
+        hipLaunchKernelGGL(scale_head_kernel, dim3(9), dim3(256), 0, 0, d.qkv_b, c->qkv_b16[l], 2304, 768, kLog2e);
         if ((rc = conv(d.o_w, (size_t)768 * 768, &c->o_w16[l]))) return rc;
         if ((rc = conv(d.fc1_w, (size_t)3072 * 768, &c->fc1_w16[l]))) return rc;
         if ((rc = conv(d.fc2_w, (size_t)768 * 3072, &c->fc2_w16[l]))) return rc;
@@ -2939,13 +2962,11 @@ int nomad_diag_attention_bwd(nomad_ctx* c, const float* qkv, const float* dctx, 
     return 0;
 }
 
-int nomad_diag_attention_bf16(nomad_ctx* c, const void* qkv, void* out, int B, int T, nomad_stream_t stream) {
+int nomad_diag_attention_bf16(nomad_ctx* c, const void* qkv, void* out, int B, int T, int q_has_log2e, nomad_stream_t stream) {
     if (!c || !qkv || !out || B <= 0 || T <= 0) return fail(NOMAD_ERR_INVALID, "nomad_diag_attention_bf16: bad argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     Scope sc(c, s, NOMAD_K_ATTN, 4.0 * B * 12.0 * (double)T * T * 64);
-    hipLaunchKernelGGL(attention_bf16_kernel, dim3((T + 63) / 64, B * 12), dim3(256), 0, s,
-                       static_cast<const bf16_t*>(qkv), static_cast<bf16_t*>(out), T);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(run_attention_bf16(static_cast<const bf16_t*>(qkv), static_cast<bf16_t*>(out), B, T, nullptr, q_has_log2e != 0, s));
     return 0;
 }
 

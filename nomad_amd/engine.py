@@ -392,9 +392,11 @@ class Engine:
                    "nomad_diag_attention_bf16x3")
         return out
 
-    def diag_attention_bf16(self, qkv, B, T):
+    def diag_attention_bf16(self, qkv, B, T, q_has_log2e: bool = False):
+        """qkv (B*T, 2304) bf16 -> (B*T, 768) bf16.  q_has_log2e: the q columns already carry log2(e) (what the bf16
+        forward's QKV projection produces); otherwise the kernel scales q itself (one more bf16 rounding of q)."""
         out = torch.empty(B * T, 768, dtype=torch.bfloat16, device=self.device)
-        _lib.check(self.lib.nomad_diag_attention_bf16(self.ctx, qkv.data_ptr(), out.data_ptr(), B, T, self._stream()),
+        _lib.check(self.lib.nomad_diag_attention_bf16(self.ctx, qkv.data_ptr(), out.data_ptr(), B, T, int(q_has_log2e), self._stream()),
                    "nomad_diag_attention_bf16")
         return out
 

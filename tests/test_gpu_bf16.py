@@ -48,19 +48,58 @@ def test_gemm_bf16_epilogues(engine, tile, M, N, K, epi):
     assert err < 2 ** -7 * max(1.0, ref.abs().max().item()), err      # one bf16 rounding of the output
 
 
-@pytest.mark.parametrize("B,T", [(2, 50), (1, 64), (1, 65), (1, 199), (1, 330)])
+LOG2E = 1.4426950408889634
+
+
+def _attention_case(engine, qkv32, B, T, log2e):
+    """qkv32 fp32 (B*T, 2304) -> (kernel output, float64 reference from the bf16 values the kernel actually saw)."""
+    x = qkv32.clone()
+    if log2e:
+        x[:, :768] *= LOG2E          # what the bf16 forward's QKV projection hands the kernel: q * 64^-0.5 * log2(e)
+    x = x.bfloat16()
+    xd = x.double()
+    if log2e:
+        xd[:, :768] /= LOG2E
+    q, k, v = (xd[:, i * 768:(i + 1) * 768].view(B, T, 12, 64).transpose(1, 2) for i in range(3))
+    ref = (torch.softmax(q @ k.transpose(-1, -2), -1) @ v).transpose(1, 2).reshape(B * T, 768)
+    out = engine.diag_attention_bf16(x.cuda(), B, T, q_has_log2e=log2e).cpu()
+    return out, ref
+
+
+@pytest.mark.parametrize("B,T", [(2, 50), (1, 64), (1, 65), (1, 199), (1, 257), (1, 330), (90, 130)])
 @pytest.mark.parametrize("gain", [1.0, 6.0])
-def test_attention_bf16(engine, B, T, gain):
+@pytest.mark.parametrize("log2e", [True, False])
+def test_attention_bf16(engine, B, T, gain, log2e):
+    """Both workgroup shapes (128 / 256 queries: B = 90 crosses the switch), partial last key blocks and query blocks."""
     g = torch.Generator().manual_seed(T)
     qkv = torch.randn(B * T, 2304, generator=g)
     qkv[:, :1536] *= (gain ** 0.5) * 0.35
-    qkv = qkv.bfloat16()
-    q, k, v = (qkv[:, i * 768:(i + 1) * 768].double().view(B, T, 12, 64).transpose(1, 2) for i in range(3))
-    ref = (torch.softmax(q @ k.transpose(-1, -2), -1) @ v).transpose(1, 2).reshape(B * T, 768)
-    out = engine.diag_attention_bf16(qkv.cuda(), B, T).cpu()
+    out, ref = _attention_case(engine, qkv, B, T, log2e)
     assert torch.isfinite(out.float()).all()
-    # P is rounded to bf16 before the PV product and the output is stored in bf16: ~2^-8 relative each
-    assert (out.double() - ref).abs().max().item() < 2.5e-2 * max(1.0, ref.abs().max().item())
+    # P is rounded to bf16 before the PV product and the output is stored in bf16: ~2^-8 relative each; without the
+    # folded log2(e) the kernel also re-rounds q * log2(e) to bf16
+    tol = (1.2e-2 if log2e else 2.5e-2) * max(1.0, ref.abs().max().item())
+    assert (out.double() - ref).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("T,spike_key", [(1499, 700), (1499, 1498), (300, 64), (300, 299)])
+def test_attention_bf16_forced_late_rescale(engine, T, spike_key):
+    """The deferred rescale is a rare, data-dependent branch: force it.  One key late in the sequence whose logit
+    against every 7th query dwarfs the running reference maximum (all earlier blocks ran with the small one), in
+    head 3 only; full-tensor float64 reference."""
+    g = torch.Generator().manual_seed(T + spike_key)
+    qkv = torch.randn(T, 2304, generator=g) * 0.5
+    sign = torch.tensor([1.0 if d % 2 else -1.0 for d in range(64)])
+    qkv[spike_key, 768 + 3 * 64:768 + 4 * 64] = 4.0 * sign
+    qkv[::7, 3 * 64:4 * 64] = 0.6 * sign               # logit 0.6 * 4 * 64 = 154 against the spiked key
+    for log2e in (True, False):
+        out, ref = _attention_case(engine, qkv, 1, T, log2e)
+        assert torch.isfinite(out.float()).all()
+        err = (out.double() - ref).abs()
+        assert err.max().item() < 2.5e-2 * max(1.0, ref.abs().max().item()), err.max().item()
+        # the spiked rows of head 3 are (almost exactly) the spiked key's value row
+        vrow = qkv[spike_key, 1536 + 3 * 64:1536 + 4 * 64].bfloat16().double()
+        assert (out[::7, 3 * 64:4 * 64].double() - vrow).abs().max().item() < 2e-2
 
 
 def test_embed_bf16_vs_fp32_path(engine):
