@@ -286,12 +286,15 @@ int nomad_profile_read(nomad_ctx* ctx, double ms[NOMAD_K_COUNT], long long launc
 
 /* ---- kernel-level diagnostics (used by tests/ to localise a parity failure) --------------- */
 /* C[M][N] = epilogue(A[M][K] * W[N][K]^T): + bias[N] (nullable), GELU if gelu!=0, + R[M][N] (nullable).
- * tile selects the kernel instantiation: 0 = 128x128x32, 1 = 128x64x16, 2 = 64x64x32. */
+ * tile selects the kernel instantiation.  libnomad_hip.so holds the ones the forward / backward select: 33 = 256x128x16
+ * (3-stage LDS-DMA), 31 = 128x128x32, 20 = 128x128x32 (4 waves), 34 = 128x64x32, 37 = 64x64x32, 48 = N = 48 (pos-conv).
+ * Every other id (register-staged kernels, ablations, A/B variants) exists in libnomad_diag.so only - the same source
+ * built with -DNOMAD_DIAG for the measurement tools and kernel tests - and returns NOMAD_ERR_INVALID here. */
 int nomad_diag_gemm(nomad_ctx* ctx, const float* A_dev, const float* W_dev, const float* bias_dev,
                     const float* R_dev, float* C_dev, int M, int N, int K, int gelu, int tile,
                     nomad_stream_t stream);
-/* The bf16 GEMM: A [M][K], W [N][K], R, C [M][N] are bf16; bias fp32.  tile: 0 = 256x128, 1 = 128x128,
- * 2 = 128x64, 3 = 256x256, 4 = 64x64 (all BK = 64). */
+/* The bf16 GEMM: A [M][K], W [N][K], R, C [M][N] are bf16; bias fp32.  tile (libnomad_hip.so): 1 = 128x128,
+ * 2 = 128x64, 3 = 256x256, 4 = 64x64 (all BK = 64), 16 = 256x256 deep-pipelined; others: libnomad_diag.so. */
 int nomad_diag_gemm_bf16(nomad_ctx* ctx, const void* A_dev, const void* W_dev, const float* bias_dev,
                          const void* R_dev, void* C_dev, int M, int N, int K, int gelu, int tile,
                          nomad_stream_t stream);

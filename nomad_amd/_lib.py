@@ -94,23 +94,31 @@ SIGNATURES = {
 }
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libnomad_hip.so")
-_lib = None
+DIAG_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libnomad_diag.so")
+_libs = {}
 
 
-def load():
-    """Load the in-tree shared library; raises if it has not been built (no fallback exists)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.isfile(LIB_PATH):
-        raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -m nomad_amd.build` "
+def load(diag=None):
+    """Load an in-tree shared library; raises if it has not been built (no fallback exists).
+
+    diag=False (default): libnomad_hip.so, the product.  diag=True (or ``NOMAD_DIAG_LIB=1`` in the environment when the
+    argument is left None): libnomad_diag.so - the same exports plus every experimental kernel instantiation, for the
+    measurement tools and the tests of those kernels."""
+    if diag is None:
+        diag = os.environ.get("NOMAD_DIAG_LIB", "0") == "1"
+    diag = bool(diag)
+    if diag in _libs:
+        return _libs[diag]
+    path = DIAG_LIB_PATH if diag else LIB_PATH
+    if not os.path.isfile(path):
+        raise RuntimeError(f"{path} is missing: build it with `python -m nomad_amd.build` "
                            "(hipcc --offload-arch=gfx950). nomad_amd has no CPU or PyTorch fallback path.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the export is missing
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
+    _libs[diag] = lib
     return lib
 
 
@@ -120,5 +128,5 @@ class NomadHipError(RuntimeError):
 
 def check(rc: int, what: str):
     if rc != 0:
-        msg = load().nomad_last_error()
+        msg = b"; ".join(m for m in (lib.nomad_last_error() for lib in _libs.values()) if m)
         raise NomadHipError(f"{what} failed (status {rc}): {msg.decode() if msg else ''}")

@@ -1,13 +1,21 @@
-"""Build libnomad_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Build the in-tree HIP libraries with hipcc for gfx950 (cross-compiles without a GPU).
+
+* ``libnomad_hip.so``  - the product: only the kernel instantiations the scoring / training paths can select.
+* ``libnomad_diag.so`` - the same source with ``-DNOMAD_DIAG``: additionally every experimental GEMM instantiation,
+  ablation and timing probe (tools/gemm_sweep.py, tools/gemm_x3.py, the tests of those tiles).  Never loaded by the
+  product path (``nomad_amd._lib.load()``); ``Engine(..., diag=True)`` / ``NOMAD_DIAG_LIB=1`` select it explicitly.
+"""
 from __future__ import annotations
 
 import os
 import shutil
 import subprocess
+import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnomad_hip.so")
+DIAG_LIB = os.path.join(HERE, "libnomad_diag.so")
 SOURCES = ["nomad_hip.hip"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip.h")) + [os.path.join("..", "..", "include", "nomad_hip.h")]
 
@@ -16,36 +24,65 @@ def hipcc_path() -> str:
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
             return cand
-    raise RuntimeError("hipcc not found; libnomad_hip.so cannot be built")
+    raise RuntimeError("hipcc not found; the HIP libraries cannot be built")
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB):
+def needs_build(lib: str = LIB) -> bool:
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
-        return LIB
-    tmp = LIB + f".tmp{os.getpid()}"
+def _command(lib: str, diag: bool, verbose: bool):
+    tmp = lib + f".tmp{os.getpid()}"
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
            "-Wall", "-Wno-unused-function", "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+    if diag:
+        cmd.insert(1, "-DNOMAD_DIAG")
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
+    return cmd, tmp
+
+
+def _finish(proc, tmp: str, lib: str) -> None:
+    out, err = proc.communicate()
+    if proc.returncode != 0:
         if os.path.exists(tmp):
             os.remove(tmp)
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
-    os.replace(tmp, LIB)  # atomic: a concurrent dlopen never sees a half-written library
-    if verbose:
-        print(res.stderr)
-    return LIB
+        raise RuntimeError("hipcc failed:\n" + out + err)
+    os.replace(tmp, lib)  # atomic: a concurrent dlopen never sees a half-written library
+
+
+def build_library(force: bool = False, verbose: bool = False, diag: bool = False) -> str:
+    """(Re)build one library if its sources changed; returns its path."""
+    lib = DIAG_LIB if diag else LIB
+    if not force and not needs_build(lib):
+        return lib
+    cmd, tmp = _command(lib, diag, verbose)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    _finish(proc, tmp, lib)
+    return lib
+
+
+def build_all(force: bool = False) -> dict:
+    """Both libraries, the two hipcc runs side by side; -> {name: seconds} of what was rebuilt."""
+    jobs = []
+    for lib, diag in ((LIB, False), (DIAG_LIB, True)):
+        if force or needs_build(lib):
+            cmd, tmp = _command(lib, diag, False)
+            jobs.append((lib, tmp, time.perf_counter(), subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+    took = {}
+    for lib, tmp, t0, proc in jobs:
+        _finish(proc, tmp, lib)
+        took[os.path.basename(lib)] = round(time.perf_counter() - t0, 1)
+    return took
 
 
 if __name__ == "__main__":
     import sys
-    print(build_library(force=True, verbose="-v" in sys.argv))
+    if "-v" in sys.argv:
+        print(build_library(force=True, verbose=True, diag="--diag" in sys.argv))
+    else:
+        print(build_all(force=True))

@@ -32,7 +32,9 @@
 #include "gemm_bf16_8phase.hip.h"
 #include "gemm_bf16x3.hip.h"
 #include "gemm_f32.hip.h"
+#ifdef NOMAD_DIAG  // libnomad_diag.so only: experiments kept for A/B measurements (tools/, tests of the experimental tiles)
 #include "gemm_f32_pp.hip.h"
+#endif
 #include "pairwise.hip.h"
 #include "rowops.hip.h"
 #include "train.hip.h"
@@ -391,6 +393,15 @@ int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, in
     Scope sc(c, s, NOMAD_K_GEMM, flops, tile == 33 ? NOMAD_K_GEMM_BIG : ((tile == 34 || tile == 31 || tile == 48) ? NOMAD_K_GEMM_FINE : -1));
     hipError_t e;
     switch (tile) {
+        // the instantiations pick_tile() / the pos-conv can select
+        case 20: e = launch_gemm_glds<128, 128, 32, 2, 2, 2, false, 12>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 2, 2>::LDS_BYTES)); break;
+        case 31: e = launch_gemm_glds<128, 128, 32, 4, 2, 2, false, 12>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 4, 2>::LDS_BYTES)); break;
+        case 33: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13>(p, groups, s); break;   // 3-stage LDS-DMA pipeline (buffer_load..lds, issued mid-cluster), counted vmcnt
+        case 34: e = launch_gemm_glds<128, 64, 32, 4, 2, 3, false, 12>(p, groups, s); break;
+        case 37: e = launch_gemm_glds<64, 64, 32, 2, 2, 3, false, 12>(p, groups, s); break;
+        case 48: e = launch_gemm_n48<true>(p, groups, s); break;    // N = 48 exactly (16x16x4 MFMA): the grouped pos-conv
+#ifdef NOMAD_DIAG
+        // experimental instantiations and ablations (libnomad_diag.so; tools/gemm_sweep.py, tests of the experimental tiles)
         case 0: e = launch_gemm<128, 128, 32, 2, 2>(p, groups, s); break;
         case 1: e = launch_gemm<128, 64, 16, 2, 2>(p, groups, s); break;
         case 2: e = launch_gemm<64, 64, 32, 2, 2>(p, groups, s); break;
@@ -406,7 +417,6 @@ int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, in
         case 11: e = launch_gemm<128, 128, 32, 4, 2>(p, groups, s); break;
         case 12: e = launch_gemm<128, 128, 32, 2, 4>(p, groups, s); break;
         case 13: e = launch_gemm<128, 128, 16, 4, 2>(p, groups, s); break;               // 3 WG/CU if registers allow
-        case 20: e = launch_gemm_glds<128, 128, 32, 2, 2, 2, false, 12>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 2, 2>::LDS_BYTES)); break;
         case 21: e = launch_gemm_glds<256, 128, 16, 4, 2>(p, groups, s, occ_pad(occ, GldsCfg<256, 128, 16, 4, 2>::LDS_BYTES)); break;
         case 22: e = launch_gemm_glds<128, 128, 16, 4, 2>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 16, 4, 2>::LDS_BYTES)); break;
         case 23: e = launch_gemm_glds<256, 128, 32, 4, 2>(p, groups, s, occ_pad(occ, GldsCfg<256, 128, 32, 4, 2>::LDS_BYTES)); break;
@@ -417,13 +427,9 @@ int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, in
         case 28: e = launch_gemm_glds<128, 64, 16, 2, 2>(p, groups, s, occ_pad(occ, GldsCfg<128, 64, 16, 2, 2>::LDS_BYTES)); break;
         case 29: e = launch_gemm_glds<128, 64, 32, 4, 2>(p, groups, s, occ_pad(occ, GldsCfg<128, 64, 32, 4, 2>::LDS_BYTES)); break;
         case 30: e = launch_gemm_glds<128, 64, 32, 2, 2>(p, groups, s, occ_pad(occ, GldsCfg<128, 64, 32, 2, 2>::LDS_BYTES)); break;
-        case 31: e = launch_gemm_glds<128, 128, 32, 4, 2, 2, false, 12>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 4, 2>::LDS_BYTES)); break;
         case 32: e = launch_gemm_glds<256, 128, 16, 4, 2, 2, true>(p, groups, s); break;  // ablation: no epilogue stores
-        case 33: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13>(p, groups, s); break;   // 3-stage LDS-DMA pipeline (buffer_load..lds, issued mid-cluster), counted vmcnt
-        case 34: e = launch_gemm_glds<128, 64, 32, 4, 2, 3, false, 12>(p, groups, s); break;
         case 35: e = launch_gemm_glds<256, 128, 32, 4, 2, 3>(p, groups, s); break;
         case 36: e = launch_gemm_glds<64, 32, 32, 2, 1, 3>(p, groups, s); break;    // small problems: many small workgroups
-        case 37: e = launch_gemm_glds<64, 64, 32, 2, 2, 3, false, 12>(p, groups, s); break;
         case 38: e = launch_gemm_glds<128, 32, 32, 4, 1, 3>(p, groups, s); break;
         case 39: e = launch_gemm_glds<32, 32, 32, 1, 1, 3>(p, groups, s); break;
         case 40: e = launch_gemm_glds<256, 256, 16, 4, 4, 3>(p, groups, s); break;   // one 16-wave workgroup per CU
@@ -437,7 +443,6 @@ int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, in
             if (p.N % 256 != 0 || p.K % 64 != 0) return fail(NOMAD_ERR_INVALID, "fp32 ping-pong gemm: N %% 256, K %% 64");
             e = tile == 46 ? launch_gemm_f32_pp<false>(p, groups, s) : launch_gemm_f32_pp<true>(p, groups, s);
             break;
-        case 48: e = launch_gemm_n48<true>(p, groups, s); break;    // N = 48 exactly (16x16x4 MFMA): the grouped pos-conv
         case 49: e = launch_gemm_n48<false>(p, groups, s); break;   // A/B: global_load_lds instead of buffer_load..lds   // N = 48 exactly (16x16x4 MFMA): the grouped pos-conv
         case 14: e = launch_gemm<128, 128, 32, 2, 2, 1>(p, groups, s); break;            // ablations of tile 0
         case 15: e = launch_gemm<128, 128, 32, 2, 2, 2>(p, groups, s); break;
@@ -445,7 +450,8 @@ int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, in
         case 17: e = launch_gemm<256, 128, 16, 4, 2, 1>(p, groups, s); break;            // ablations of tile 6
         case 18: e = launch_gemm<256, 128, 16, 4, 2, 2>(p, groups, s); break;
         case 19: e = launch_gemm<256, 128, 16, 4, 2, 3>(p, groups, s); break;
-        default: return fail(NOMAD_ERR_INVALID, "unknown gemm tile id %d", tile);
+#endif
+        default: return fail(NOMAD_ERR_INVALID, "gemm tile id %d is not in this library (experimental instantiations live in libnomad_diag.so)", tile);
     }
     if (e != hipSuccess) return fail(NOMAD_ERR_HIP, "gemm launch: %s", hipGetErrorString(e));
     return 0;
@@ -545,7 +551,13 @@ int run_dropout(nomad_ctx* c, const float* x, const float* resid, float* y, long
 extern "C" {
 
 const char* nomad_last_error(void) { return g_err; }
-const char* nomad_version(void) { return "nomad_hip 0.1 (gfx950, fp32 MFMA)"; }
+const char* nomad_version(void) {
+#ifdef NOMAD_DIAG
+    return "nomad_hip 0.2 (gfx950) + experimental kernel instantiations (libnomad_diag.so)";
+#else
+    return "nomad_hip 0.2 (gfx950)";
+#endif
+}
 
 int nomad_num_frames(int n_samples) {
     Shapes s;
@@ -1131,11 +1143,23 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
     Scope sc(c, s, NOMAD_K_GEMM, flops, (tile == 1 || tile == 3 || tile == 16 || tile == 20 || tile == 21 || tile == 27 || tile == 28 || tile == 32 || tile == 33) ? NOMAD_K_GEMM_BIG : (tile == 2 ? NOMAD_K_GEMM_FINE : -1));
     hipError_t e;
     switch (tile) {
-        case 0: e = launch_gemm_bf16<256, 128, 4, 2>(p, groups, s); break;
+        // the instantiations the bf16 / bf16x3 forwards select
         case 1: e = launch_gemm_bf16<128, 128, 4, 2>(p, groups, s); break;
         case 2: e = launch_gemm_bf16<128, 64, 4, 2>(p, groups, s); break;
         case 3: e = launch_gemm_bf16<256, 256, 4, 2>(p, groups, s); break;
         case 4: e = launch_gemm_bf16<64, 64, 2, 2>(p, groups, s); break;
+        case 16:  // 256x256 deep-pipelined schedule (gemm_bf16_8phase.hip.h)
+            if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
+            e = launch_gemm_bf16_8phase<0>(p, groups, s);
+            break;
+        case 27:  // bf16x3, every plane staged once (gemm_bf16x3.hip.h): split output
+        case 28:  // ... fp32 output
+            if (p.N % 256 != 0 || p.K % 64 != 0) return fail(NOMAD_ERR_INVALID, "bf16x3 gemm: N %% 256, K %% 64");
+            e = tile == 27 ? launch_gemm_bf16x3<0, 1>(p, groups, s) : launch_gemm_bf16x3<0, 2>(p, groups, s);
+            break;
+#ifdef NOMAD_DIAG
+        // experimental instantiations, cross-check kernels and timing probes (libnomad_diag.so)
+        case 0: e = launch_gemm_bf16<256, 128, 4, 2>(p, groups, s); break;
         case 5: e = launch_gemm_bf16<128, 128, 2, 2>(p, groups, s); break;
         case 6: e = launch_gemm_bf16<256, 128, 2, 2>(p, groups, s); break;
         case 7: e = launch_gemm_bf16<128, 128, 4, 2, 1>(p, groups, s); break;   // ablation: no epilogue stores
@@ -1147,49 +1171,42 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
         case 13: e = launch_gemm_bf16<256, 128, 4, 2, 0, 64, 3>(p, groups, s); break;
         case 14: e = launch_gemm_bf16<256, 128, 4, 2, 0, 32, 4>(p, groups, s); break;
         case 15: e = launch_gemm_bf16<256, 256, 2, 4, 0, 64, 2>(p, groups, s); break;
-        case 16:  // 256x256 deep-pipelined schedule (gemm_bf16_8phase.hip.h)
-        case 17:  // ablation: no epilogue stores
+        case 17:  // 8-phase ablation: no epilogue stores
             if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
-            e = tile == 16 ? launch_gemm_bf16_8phase<0>(p, groups, s) : launch_gemm_bf16_8phase<1>(p, groups, s);
+            e = launch_gemm_bf16_8phase<1>(p, groups, s);
             break;
         case 18:  // A/B: 8-phase kernel with buffer_load..lds
             if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
             e = launch_gemm_bf16_8phase<0, true>(p, groups, s);
             break;
-        case 20:  // bf16x3: split operands, split output
-        case 21:  // bf16x3: split operands, fp32 output
-            if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16x3 gemm: N %% 256, K %% 128");
-            e = tile == 20 ? launch_gemm_bf16_8phase<0, false, 1>(p, groups, s) : launch_gemm_bf16_8phase<0, false, 2>(p, groups, s);
-            break;
-        case 22:  // bf16x3 timing probes (gemm_bf16_8phase.hip.h ABL), fp32 output
-            e = launch_gemm_bf16_8phase<3, false, 2>(p, groups, s);
-            break;
-        case 23: e = launch_gemm_bf16_8phase<4, false, 2>(p, groups, s); break;
-        case 24: e = launch_gemm_bf16_8phase<5, false, 2>(p, groups, s); break;
-        case 25: e = launch_gemm_bf16_8phase<6, false, 2>(p, groups, s); break;
-        case 26: e = launch_gemm_bf16_8phase<1, false, 2>(p, groups, s); break;
-        case 27:  // bf16x3, every plane staged once (gemm_bf16x3.hip.h): split output
-        case 28:  // ... fp32 output
-        case 29:  // timing probe: no epilogue stores
-        case 30:  // timing probe: no LDS-DMA
-        case 31:  // timing probe: every workgroup stages A tile 0 (A always hits in L2)
-        case 32:  // three A buffers (K % 192 == 0): split output
-        case 33:  // ... fp32 output
-            if (tile >= 32) {
-                if (p.N % 256 != 0 || p.K % 192 != 0) return fail(NOMAD_ERR_INVALID, "bf16x3 gemm (3 A buffers): N %% 256, K %% 192");
-                e = tile == 32 ? launch_gemm_bf16x3<0, 1, 3>(p, groups, s) : launch_gemm_bf16x3<0, 2, 3>(p, groups, s);
-                break;
-            }
-            if (p.N % 256 != 0 || p.K % 64 != 0) return fail(NOMAD_ERR_INVALID, "bf16x3 gemm: N %% 256, K %% 64");
-            e = tile == 27 ? launch_gemm_bf16x3<0, 1>(p, groups, s) : tile == 28 ? launch_gemm_bf16x3<0, 2>(p, groups, s)
-              : tile == 29 ? launch_gemm_bf16x3<1, 2>(p, groups, s) : tile == 30 ? launch_gemm_bf16x3<4, 2>(p, groups, s)
-              : launch_gemm_bf16x3<7, 2>(p, groups, s);
-            break;
         case 19:  // A/B: 8-phase kernel without s_setprio
             if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
             e = launch_gemm_bf16_8phase<2>(p, groups, s);
             break;
-        default: return fail(NOMAD_ERR_INVALID, "unknown bf16 gemm tile id %d", tile);
+        case 20:  // bf16x3 cross-check (K-concatenated operands in the 8-phase kernel): split output
+        case 21:  // ... fp32 output
+            if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16x3 gemm: N %% 256, K %% 128");
+            e = tile == 20 ? launch_gemm_bf16_8phase<0, false, 1>(p, groups, s) : launch_gemm_bf16_8phase<0, false, 2>(p, groups, s);
+            break;
+        case 22: e = launch_gemm_bf16_8phase<3, false, 2>(p, groups, s); break;  // bf16x3 timing probes, fp32 output
+        case 23: e = launch_gemm_bf16_8phase<4, false, 2>(p, groups, s); break;
+        case 24: e = launch_gemm_bf16_8phase<5, false, 2>(p, groups, s); break;
+        case 25: e = launch_gemm_bf16_8phase<6, false, 2>(p, groups, s); break;
+        case 26: e = launch_gemm_bf16_8phase<1, false, 2>(p, groups, s); break;
+        case 29:  // timing probe: no epilogue stores
+        case 30:  // timing probe: no LDS-DMA
+        case 31:  // timing probe: every workgroup stages A tile 0 (A always hits in L2)
+            if (p.N % 256 != 0 || p.K % 64 != 0) return fail(NOMAD_ERR_INVALID, "bf16x3 gemm: N %% 256, K %% 64");
+            e = tile == 29 ? launch_gemm_bf16x3<1, 2>(p, groups, s) : tile == 30 ? launch_gemm_bf16x3<4, 2>(p, groups, s)
+                                                                                  : launch_gemm_bf16x3<7, 2>(p, groups, s);
+            break;
+        case 32:  // three A buffers (K % 192 == 0): split output
+        case 33:  // ... fp32 output
+            if (p.N % 256 != 0 || p.K % 192 != 0) return fail(NOMAD_ERR_INVALID, "bf16x3 gemm (3 A buffers): N %% 256, K %% 192");
+            e = tile == 32 ? launch_gemm_bf16x3<0, 1, 3>(p, groups, s) : launch_gemm_bf16x3<0, 2, 3>(p, groups, s);
+            break;
+#endif
+        default: return fail(NOMAD_ERR_INVALID, "bf16 gemm tile id %d is not in this library (experimental instantiations live in libnomad_diag.so)", tile);
     }
     if (e != hipSuccess) return fail(NOMAD_ERR_HIP, "bf16 gemm launch: %s", hipGetErrorString(e));
     return 0;

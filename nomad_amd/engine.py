@@ -70,8 +70,10 @@ class _AsyncFetch:
 class Engine:
     """One engine per (process, GPU).  Not thread-safe; asynchronous on torch's current stream."""
 
-    def __init__(self, state_dict: Dict[str, torch.Tensor], device: int = 0):
-        self.lib = _lib.load()
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device: int = 0, diag=None):
+        """diag=True: run on libnomad_diag.so (same path + the experimental kernel instantiations the measurement tools and
+        the kernel tests select by tile id); None: ``NOMAD_DIAG_LIB=1`` decides; the product never passes it."""
+        self.lib = _lib.load(diag)
         check_state_dict(state_dict)
         self.device_index = int(device)
         self.device = torch.device("cuda", self.device_index)

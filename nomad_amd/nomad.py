@@ -165,6 +165,32 @@ class _NomadLossFn(torch.autograd.Function):
 BF16X3_MIN_SAMPLES = 8 * 64000
 
 
+def _write_rounded_csv(df: pd.DataFrame, path: str) -> None:
+    """``df.to_csv(path, index=False)`` for the scores table (first column = labels, the rest 3-decimal floats), byte for
+    byte, without pandas' per-cell float formatting: 10 000 x 1 000 scores take pandas 6-9 s to write and this 1 s.
+    A value rounded to 3 decimals is k / 1000 for an integer k, and pandas prints a float by its shortest round-trip
+    repr, so a table of ``repr(k / 1000.0)`` covers every cell.  Anything else (NaN, values off the grid, huge
+    values, labels that need CSV quoting) goes through pandas itself."""
+    vals = df.iloc[:, 1:].to_numpy(dtype=np.float64, copy=False) if df.shape[1] > 1 else np.zeros((len(df), 0))
+    labels = [str(x) for x in df.iloc[:, 0].tolist()]
+    header = [str(c) for c in df.columns]
+    special = set(',"\r\n')
+    ok = (vals.size > 0 and bool(np.isfinite(vals).all()) and not any(special & set(x) for x in labels + header)
+          and all(isinstance(x, str) for x in df.iloc[:, 0].tolist()))
+    if ok:
+        idx = np.rint(vals * 1000.0)
+        ok = bool(idx.min() >= 0 and idx.max() <= 100000 and np.array_equal(idx / 1000.0, vals))
+    if not ok:
+        df.to_csv(path, index=False)
+        return
+    lut = np.array([repr(k / 1000.0) for k in range(int(idx.max()) + 1)], dtype=object)
+    cells = lut[idx.astype(np.int64)]
+    with open(path, "w", newline="") as f:
+        f.write(",".join(header) + "\n")
+        f.write("\n".join(labels[i] + "," + ",".join(cells[i]) for i in range(len(labels))))
+        f.write("\n")
+
+
 def _staged_batches(paths, load, pack, max_batch_samples: int, decode_threads: int, max_alive: int):
     """Generator of (row indices, pack(waves)) batches over ``paths`` in order, built ahead of the consumer.
 
@@ -330,7 +356,7 @@ class Nomad:
             results_scores_path = os.path.join(results_path, "nomad_scores.csv")
 
         df_avg_nomad.reset_index().to_csv(results_avg_path, index=False)
-        df_dm.reset_index().to_csv(results_scores_path, index=False)
+        _write_rounded_csv(df_dm.reset_index(), results_scores_path)
         return df_avg_nomad, df_dm
 
     def forward(self, estimate, clean):

@@ -13,7 +13,7 @@ BF16_TILES = {0: (256, 128), 1: (128, 128), 2: (128, 64), 3: (256, 256), 4: (64,
 
 @pytest.mark.parametrize("tile", sorted(BF16_TILES))
 @pytest.mark.parametrize("M", [1, 200, 257, 1000])
-def test_gemm_bf16_exact_integer_asymmetric(engine, tile, M):
+def test_gemm_bf16_exact_integer_asymmetric(engine_for, tile, M):
     bm, bn = BF16_TILES[tile]
     N, K = 2 * bn, (256 if tile == 16 else 192)  # the deep-pipelined kernel walks K tiles in pairs: K % 128 == 0
     g = torch.Generator().manual_seed(M + tile)
@@ -21,7 +21,7 @@ def test_gemm_bf16_exact_integer_asymmetric(engine, tile, M):
     W = torch.randint(-1, 2, (N, K), generator=g).float()
     W[:, ::7] = 1.0                      # break symmetry
     ref = (A.double() @ W.double().T)    # |C| <= K <= 256: exact in bf16 (8-bit significand)
-    out = engine.diag_gemm_bf16(A.bfloat16().cuda(), W.bfloat16().cuda(), tile=tile).float().cpu()
+    out = engine_for("bf16", tile).diag_gemm_bf16(A.bfloat16().cuda(), W.bfloat16().cuda(), tile=tile).float().cpu()
     assert torch.equal(out.double(), ref)
 
 
@@ -29,7 +29,7 @@ def test_gemm_bf16_exact_integer_asymmetric(engine, tile, M):
                                         (3, 600, 512, 1536), (16, 777, 768, 3072), (16, 1500, 512, 1536),
                                         (16, 300, 2304, 768), (16, 4113, 256, 128)])
 @pytest.mark.parametrize("epi", ["none", "bias_gelu", "bias_res"])
-def test_gemm_bf16_epilogues(engine, tile, M, N, K, epi):
+def test_gemm_bf16_epilogues(engine_for, tile, M, N, K, epi):
     g = torch.Generator().manual_seed(5)
     A = torch.randn(M, K, generator=g).bfloat16()
     W = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16()
@@ -42,8 +42,8 @@ def test_gemm_bf16_epilogues(engine, tile, M, N, K, epi):
         ref = F.gelu(ref)
     if R is not None:
         ref = ref + R.double()
-    out = engine.diag_gemm_bf16(A.cuda(), W.cuda(), bias.cuda() if bias is not None else None,
-                                R.cuda() if R is not None else None, gelu="gelu" in epi, tile=tile).cpu()
+    out = engine_for("bf16", tile).diag_gemm_bf16(A.cuda(), W.cuda(), bias.cuda() if bias is not None else None,
+                                                  R.cuda() if R is not None else None, gelu="gelu" in epi, tile=tile).cpu()
     err = (out.double() - ref).abs().max().item()
     assert err < 2 ** -7 * max(1.0, ref.abs().max().item()), err      # one bf16 rounding of the output
 

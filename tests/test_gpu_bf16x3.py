@@ -27,11 +27,12 @@ KERNELS = {"kcat": (0, 1), "staged": (7, 8), "staged3": (12, 13)}   # staged3: t
 
 @pytest.mark.parametrize("kernel", sorted(KERNELS))
 @pytest.mark.parametrize("M", [1, 200, 257, 1000])
-def test_gemm_bf16x3_exact_on_16_bit_integers(engine, M, kernel):
+def test_gemm_bf16x3_exact_on_16_bit_integers(engine_for, M, kernel):
     """Operands that hi + lo represents exactly (|a| < 2^16) whose lo*lo terms vanish (one operand has lo = 0):
     the three products reproduce the exact integer result as long as it fits fp32."""
     N, K = 512, (384 if kernel == "staged3" else 256)
     var = KERNELS[kernel][1]
+    engine = engine_for("bf16x3", var)
     g = torch.Generator().manual_seed(M)
     A = torch.randint(-20000, 20000, (M, K), generator=g).float()       # needs hi and lo
     W = torch.randint(-3, 4, (N, K), generator=g).float()               # lo plane is zero
@@ -52,11 +53,12 @@ def test_gemm_bf16x3_exact_on_16_bit_integers(engine, M, kernel):
                                    (513, 256, 64), (255, 512, 192 + 64)])
 @pytest.mark.parametrize("epi", ["none", "bias_gelu", "bias_res"])
 @pytest.mark.parametrize("out_f32", [True, False])
-def test_gemm_bf16x3_vs_float64(engine, M, N, K, epi, out_f32, kernel):
+def test_gemm_bf16x3_vs_float64(engine_for, M, N, K, epi, out_f32, kernel):
     if kernel == "kcat" and K % 128:
         pytest.skip("the K-concatenated kernel walks K tiles of 64 in pairs")
     if kernel == "staged3" and K % 192:
         pytest.skip("three A buffers: stages in sixes")
+    engine = engine_for("bf16x3", KERNELS[kernel][1])
     g = torch.Generator().manual_seed(5)
     A = torch.randn(M, K, generator=g)
     W = torch.randn(N, K, generator=g) * K ** -0.5

@@ -279,3 +279,28 @@ def test_load_processing_resamples_like_the_restatement(tmp_path):
     mono = (st[:, 0].astype(np.float32) / 32768.0 + st[:, 1].astype(np.float32) / 32768.0) / 2
     ref = R.resample(torch.from_numpy(mono[None, :]), 44100, 16000).numpy()
     assert w.shape == ref.shape == (1, 16000) and np.abs(w - ref).max() < 1e-6
+
+
+def test_fast_scores_csv_is_byte_identical_to_pandas(tmp_path):
+    """Nomad.predict writes the N_deg x N_ref table with a lookup-table formatter (pandas needs seconds for 10^7 cells):
+    the bytes must equal DataFrame.to_csv's, and anything off the 3-decimal grid must take the pandas path."""
+    import pandas as pd
+    from nomad_amd.nomad import _write_rounded_csv
+    rng = np.random.default_rng(0)
+    vals = np.round(rng.uniform(0, 2, (300, 40)), 3)
+    vals[0, :8] = [0.0, 1.0, 2.0, 0.001, 0.01, 0.1, 1.999, 0.5]
+    for case, v, labels in (("grid", vals, [f"clip_{i:04d}" for i in range(300)]),
+                            ("offgrid", vals + 1e-4, [f"clip_{i:04d}" for i in range(300)]),
+                            ("nan", np.where(rng.uniform(size=vals.shape) < 0.01, np.nan, vals), [f"c{i}" for i in range(300)]),
+                            ("quoting", vals, [f'we,ird "{i}"' for i in range(300)]),
+                            ("float32", vals.astype(np.float32).astype(np.float64).round(3), [f"c{i}" for i in range(300)])):
+        df = pd.DataFrame(v)
+        df["Test File"] = labels
+        df.set_index("Test File", inplace=True)
+        df.columns = [f"ref_{j}" for j in range(v.shape[1])]
+        a, b = tmp_path / f"{case}_pandas.csv", tmp_path / f"{case}_fast.csv"
+        df.reset_index().to_csv(a, index=False)
+        _write_rounded_csv(df.reset_index(), str(b))
+        assert a.read_bytes() == b.read_bytes(), case
+    back = pd.read_csv(tmp_path / "grid_fast.csv", index_col="Test File")
+    assert np.array_equal(back.to_numpy(), vals)

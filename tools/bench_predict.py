@@ -34,10 +34,23 @@ def main():
         nmd = Nomad(weights="seeded", precision=a.precision)
         nmd.predict("dir", d + "/nmr", d + "/deg", results_path=d + "/out0")  # warm-up (first-touch, allocator)
         torch.cuda.synchronize()
+        import resource
+        rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
         t0 = time.perf_counter()
         avg, mat = nmd.predict("dir", d + "/nmr", d + "/deg", results_path=d + "/out1")
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        rss1 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+        # the stages of one predict call, timed separately on the same data
+        ts = time.perf_counter()
+        e_ref = nmd.get_embeddings(d + "/nmr")
+        e_deg = nmd.get_embeddings(d + "/deg")
+        torch.cuda.synchronize()
+        t_embed_stage = time.perf_counter() - ts
+        ts = time.perf_counter()
+        from nomad_amd.nomad import _write_rounded_csv
+        _write_rounded_csv(mat.reset_index(), d + "/out0/scores_again.csv")
+        t_csv = time.perf_counter() - ts
         # where the time goes: decode alone, embedding alone (device-resident inputs)
         import glob
         paths = sorted(glob.glob(d + "/deg/*.wav")) + sorted(glob.glob(d + "/nmr/*.wav"))
@@ -54,6 +67,9 @@ def main():
     n = a.deg + a.ref
     print(json.dumps({"precision": a.precision, "files": n, "audio_s": round(secs, 1), "predict_s": round(dt, 3), "files_per_s": round(n / dt, 1),
                       "audio_s_per_s": round(secs / dt, 1), "decode_only_s": round(t_dec, 3), "embed_only_s": round(t_emb, 3),
+                      "get_embeddings_pipeline_s": round(t_embed_stage, 3), "scores_csv_s": round(t_csv, 3),
+                      "audio_bytes_all_files_MB": round(secs * 16000 * 4 / 1e6, 1),
+                      "peak_rss_MB_before_after": [round(rss0 / 1024, 1), round(rss1 / 1024, 1)],
                       "score_shape": list(mat.shape)}))
 
 

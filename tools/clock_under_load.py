@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from nomad_amd.engine import Engine
 from nomad_amd.weights import seeded_state_dict
-eng = Engine(seeded_state_dict(0), 0)
+eng = Engine(seeded_state_dict(0), 0, diag=True)  # libnomad_diag.so: experimental tile ids
 side = torch.cuda.Stream()
 g = torch.Generator().manual_seed(0)
 A = torch.randn(50944, 768, generator=g).cuda(); W = (torch.randn(3072, 768, generator=g) * 0.03).cuda(); b = torch.randn(3072, generator=g).cuda()

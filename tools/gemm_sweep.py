@@ -79,7 +79,7 @@ def main():
     ap.add_argument("--json", default=None)
     ap.add_argument("--bf16", action="store_true", help="sweep the bf16 GEMM instantiations (tile ids 0..6)")
     a = ap.parse_args()
-    eng = Engine(seeded_state_dict(0), 0)
+    eng = Engine(seeded_state_dict(0), 0, diag=True)  # libnomad_diag.so: experimental tile ids
     g = torch.Generator().manual_seed(0)
     res = []
     if a.bf16:

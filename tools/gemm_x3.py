@@ -17,7 +17,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--json", default=None)
     a = ap.parse_args()
-    eng = Engine(seeded_state_dict(0), 0)
+    eng = Engine(seeded_state_dict(0), 0, diag=True)  # libnomad_diag.so: experimental tile ids
     g = torch.Generator().manual_seed(0)
     res = []
     for sname in a.shapes.split(","):

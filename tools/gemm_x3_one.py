@@ -8,7 +8,7 @@ from nomad_amd.weights import seeded_state_dict
 from gemm_sweep import SHAPES
 shape = sys.argv[1] if len(sys.argv) > 1 else "qkv"
 variant = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-eng = Engine(seeded_state_dict(0), 0)
+eng = Engine(seeded_state_dict(0), 0, diag=True)  # libnomad_diag.so: experimental tile ids
 g = torch.Generator().manual_seed(0)
 M, N, K, has_b, gelu, has_r = SHAPES[shape]
 A = eng.diag_split_bf16(torch.randn(M, K, generator=g).cuda())

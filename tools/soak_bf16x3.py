@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from nomad_amd.engine import Engine
 from nomad_amd.weights import seeded_state_dict
-eng = Engine(seeded_state_dict(0), 0)
+eng = Engine(seeded_state_dict(0), 0, diag=True)  # libnomad_diag.so: experimental tile ids
 g = torch.Generator().manual_seed(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 bad = 0
