@@ -20,26 +20,33 @@ namespace nomad {
 
 constexpr int kStatsPerClip = 65;  // 10 sums + 55 upper-triangular products
 
-// grid: B blocks of 256 threads.  stats[b][0..9] = S, stats[b][10..64] = R (j<=k, row-major).
-// Ragged batches: lens != nullptr gives each clip's sample count, clips are `n_samples` (the row stride) apart.
+// The 65 sums of a clip are taken in chunks of kStatsChunk conv-0 frames, one workgroup per (chunk, clip) - a 30 s clip
+// is 12 workgroups instead of one - and folded per clip in chunk order (wav_stats_fold_kernel): the order depends on the
+// clip's length only, so the statistics are batch-invariant and deterministic.
+// grid: (ceil(max L0 / kStatsChunk), B) blocks of 256 threads.  part[(b * gridDim.x + j)][0..9] = S, [10..64] = R
+// (j<=k, row-major) over frames [j * kStatsChunk, ...).  Ragged batches: lens != nullptr gives each clip's sample
+// count, clips are `n_samples` (the row stride) apart.
+constexpr int kStatsChunk = 8192;
 __global__ __launch_bounds__(256) void wav_stats_kernel(const float* __restrict__ wav, int n_samples, int L0,
-                                                        double* __restrict__ stats, const int* __restrict__ lens) {
-    const int b = blockIdx.x;
+                                                        double* __restrict__ part, const int* __restrict__ lens) {
+    const int b = blockIdx.y, j = blockIdx.x;
     const float* x = wav + (long long)b * n_samples;
     if (lens) L0 = (lens[b] - 10) / 5 + 1;
+    if (j * kStatsChunk >= L0) return;
+    const int t_end = min(L0, (j + 1) * kStatsChunk);
     double acc[kStatsPerClip];
 #pragma unroll
     for (int i = 0; i < kStatsPerClip; ++i) acc[i] = 0.0;
-    for (int t = threadIdx.x; t < L0; t += 256) {
+    for (int t = j * kStatsChunk + threadIdx.x; t < t_end; t += 256) {
         double v[10];
 #pragma unroll
-        for (int j = 0; j < 10; ++j) v[j] = (double)x[5 * t + j];
+        for (int q = 0; q < 10; ++q) v[q] = (double)x[5 * t + q];
         int idx = 10;
 #pragma unroll
-        for (int j = 0; j < 10; ++j) {
-            acc[j] += v[j];
+        for (int q = 0; q < 10; ++q) {
+            acc[q] += v[q];
 #pragma unroll
-            for (int k = j; k < 10; ++k) acc[idx++] += v[j] * v[k];
+            for (int k = q; k < 10; ++k) acc[idx++] += v[q] * v[k];
         }
     }
     __shared__ double red[4][kStatsPerClip];
@@ -53,8 +60,20 @@ __global__ __launch_bounds__(256) void wav_stats_kernel(const float* __restrict_
     }
     __syncthreads();
     if (threadIdx.x < kStatsPerClip)
-        stats[(long long)b * kStatsPerClip + threadIdx.x] =
+        part[((long long)b * gridDim.x + j) * kStatsPerClip + threadIdx.x] =
             (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// grid: B blocks of 128 threads.  stats[b][i] = sum over the clip's chunks, in chunk order.
+__global__ __launch_bounds__(128) void wav_stats_fold_kernel(const double* __restrict__ part, int nchunk_max, int L0,
+                                                             double* __restrict__ stats, const int* __restrict__ lens) {
+    const int b = blockIdx.x, i = threadIdx.x;
+    if (i >= kStatsPerClip) return;
+    if (lens) L0 = (lens[b] - 10) / 5 + 1;
+    const int nchunk = (L0 + kStatsChunk - 1) / kStatsChunk;
+    double s = 0.0;
+    for (int j = 0; j < nchunk; ++j) s += part[((long long)b * nchunk_max + j) * kStatsPerClip + i];
+    stats[(long long)b * kStatsPerClip + i] = s;
 }
 
 // grid: B blocks of 512 threads (one per channel).  scale = rstd*gamma, shift = beta - mean*rstd*gamma.

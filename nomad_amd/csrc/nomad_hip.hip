@@ -89,6 +89,18 @@ bool make_shapes(int B, int N, Shapes* s) {
 size_t align_up(size_t v) { return (v + 255) & ~size_t(255); }
 
 // Workspace carve.  With keep=false the conv stack ping-pongs between two buffers.
+// doubles in a forward's GroupNorm-statistics region: [B][65] final sums + [B][chunks][65] per-chunk partial sums
+size_t stats_doubles(int B, int max_l0) {
+    return (size_t)kStatsPerClip * B * (1 + (max_l0 + kStatsChunk - 1) / kStatsChunk);
+}
+// the two launches that fill it (frontend.hip.h); L0: conv-0 frames per clip (0 with lens), max_l0: the longest clip's
+void launch_wav_stats(const float* wav, int ld, int L0, int max_l0, int B, double* stats, const int* lens, hipStream_t s) {
+    const int nchunk = (max_l0 + kStatsChunk - 1) / kStatsChunk;
+    double* part = stats + (size_t)kStatsPerClip * B;
+    hipLaunchKernelGGL(wav_stats_kernel, dim3(nchunk, B), dim3(256), 0, s, wav, ld, L0, part, lens);
+    hipLaunchKernelGGL(wav_stats_fold_kernel, dim3(B), dim3(128), 0, s, part, nchunk, L0, stats, lens);
+}
+
 struct Layout {
     size_t stats, scale, shift, conv[7], featln, xpad, x, x2, y, qkv, ctxb, h, total;
 };
@@ -101,7 +113,7 @@ Layout make_layout(const Shapes& s, bool keep) {
         off += align_up(bytes);
         return o;
     };
-    l.stats = take(sizeof(double) * kStatsPerClip * s.B);
+    l.stats = take(sizeof(double) * stats_doubles(s.B, s.L[0]));
     l.scale = take(sizeof(float) * 512 * s.B);
     l.shift = take(sizeof(float) * 512 * s.B);
     auto conv_bytes = [&](int i) { return sizeof(float) * 512 * (size_t)s.B * s.L[i]; };
@@ -512,6 +524,18 @@ int run_layernorm(nomad_ctx* c, const float* in, const float* g, const float* b,
     return 0;
 }
 
+// mean/ReLU/Linear/normalise head in two stages (rowops.hip.h).  T: frames per clip (the longest clip's with tpref);
+// pool: scratch of at least (M / 64 + B) * 768 floats (M = total frames) - every caller passes its FFN hidden buffer.
+template <typename TIn>
+int run_head(nomad_ctx* c, const TIn* x, int B, int T, const float* w, const float* b, float* emb, const int* tpref,
+             float* pool, hipStream_t s) {
+    Scope sc(c, s, NOMAD_K_ROW, 2.0 * B * 768 * 256);
+    hipLaunchKernelGGL(head_pool_kernel<TIn>, dim3((T + kHeadChunk - 1) / kHeadChunk, B), dim3(256), 0, s, x, tpref ? 0 : T, pool, tpref);
+    hipLaunchKernelGGL(head_kernel, dim3(B), dim3(256), 0, s, pool, tpref ? 0 : T, w, b, emb, tpref);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 DropCfg make_drop(const nomad_ctx* c, float p) {
     DropCfg d{};
     d.seed_lo = (uint32_t)c->drop_seed;
@@ -740,7 +764,7 @@ static int forward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, co
     float* gn_shift = sv ? sv->gn_shift : F(lay.shift);
     {
         Scope sc(c, s, NOMAD_K_FRONT, 0.0);
-        hipLaunchKernelGGL(wav_stats_kernel, dim3(B), dim3(256), 0, s, wav, n_samples, sh.L[0], stats, kNoInts);
+        launch_wav_stats(wav, n_samples, sh.L[0], sh.L[0], B, stats, kNoInts, s);
         hipLaunchKernelGGL(gn_fold_kernel, dim3(B), dim3(512), 0, s, stats, c->conv0_w, c->gn_w, c->gn_b, sh.L[0],
                            gn_scale, gn_shift, sv ? sv->gn_mean : nullptr, sv ? sv->gn_rstd : nullptr, kNoInts);
     }
@@ -890,13 +914,8 @@ static int forward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, co
     }
 
     // ---- head -----------------------------------------------------------------------------------
-    {
-        Scope sc(c, s, NOMAD_K_ROW, 2.0 * B * 768 * 256);
-        hipLaunchKernelGGL(head_kernel<float>, dim3(B), dim3(256), 0, s, x, T, head_w ? head_w : c->emb_w,
-                           head_b ? head_b : c->emb_b, emb, kNoInts);
-    }
-    HIP_TRY(hipGetLastError());
-    return 0;
+    // the FFN hidden buffer is dead by now: scratch for the time sums
+    return run_head<float>(c, x, B, T, head_w ? head_w : c->emb_w, head_b ? head_b : c->emb_b, emb, kNoInts, F(lay.h), s);
 }
 
 // ---- ragged batches: clips of different lengths packed back to back ----------------------------------------
@@ -954,7 +973,7 @@ static RaggedLayout make_ragged_layout(const RaggedShapes& r) {
     };
     const size_t M = (size_t)r.rows[6];
     l.meta = take(sizeof(int) * r.meta.size());
-    l.stats = take(sizeof(double) * kStatsPerClip * r.B);
+    l.stats = take(sizeof(double) * stats_doubles(r.B, r.max_l0));
     l.scale = take(sizeof(float) * 512 * r.B);
     l.shift = take(sizeof(float) * 512 * r.B);
     l.conva = take(sizeof(float) * 512 * (size_t)r.rows[0]);
@@ -1000,7 +1019,7 @@ static int forward_ragged(nomad_ctx* c, const float* wav, int B, int stride, con
     float* cb[2] = {F(lay.conva), F(lay.convb)};
     {
         Scope sc(c, s, NOMAD_K_FRONT, 0.0);
-        hipLaunchKernelGGL(wav_stats_kernel, dim3(B), dim3(256), 0, s, wav, stride, 0, stats, lens);
+        launch_wav_stats(wav, stride, 0, rs.max_l0, B, stats, lens, s);
         hipLaunchKernelGGL(gn_fold_kernel, dim3(B), dim3(512), 0, s, stats, c->conv0_w, c->gn_w, c->gn_b, 0, scale, shift,
                            static_cast<float*>(nullptr), static_cast<float*>(nullptr), lens);
     }
@@ -1090,13 +1109,7 @@ static int forward_ragged(nomad_ctx* c, const float* wav, int B, int stride, con
             return rc;
         if ((rc = run_layernorm(c, y, d.ln2_w, d.ln2_b, x, nullptr, M, 768, s))) return rc;
     }
-    {
-        Scope sc(c, s, NOMAD_K_ROW, 2.0 * B * 768 * 256);
-        hipLaunchKernelGGL(head_kernel<float>, dim3(B), dim3(256), 0, s, x, 0, head_w ? head_w : c->emb_w,
-                           head_b ? head_b : c->emb_b, emb, tpref);
-    }
-    HIP_TRY(hipGetLastError());
-    return 0;
+    return run_head<float>(c, x, B, rs.max_t, head_w ? head_w : c->emb_w, head_b ? head_b : c->emb_b, emb, tpref, hbuf, s);
 }
 
 // One backward GEMM: C[M][N] = A[M][K] * Wt[N][K]^T (Wt = transposed forward weight), optional GELU' and residual.
@@ -1231,7 +1244,7 @@ static Bf16Layout make_bf16_layout(const Shapes& s) {
         return o;
     };
     const size_t e = sizeof(bf16_t), M = s.M;
-    l.stats = take(sizeof(double) * kStatsPerClip * s.B);
+    l.stats = take(sizeof(double) * stats_doubles(s.B, s.L[0]));
     l.scale = take(sizeof(float) * 512 * s.B);
     l.shift = take(sizeof(float) * 512 * s.B);
     l.conva = take(e * 512 * (size_t)s.B * s.L[0]);
@@ -1270,7 +1283,7 @@ static int forward_bf16(nomad_ctx* c, const float* wav, int B, int n_samples, fl
     bf16_t* cb[2] = {H(lay.conva), H(lay.convb)};
     {
         Scope sc(c, s, NOMAD_K_FRONT, 0.0);
-        hipLaunchKernelGGL(wav_stats_kernel, dim3(B), dim3(256), 0, s, wav, n_samples, sh.L[0], stats, kNoInts);
+        launch_wav_stats(wav, n_samples, sh.L[0], sh.L[0], B, stats, kNoInts, s);
         hipLaunchKernelGGL(gn_fold_kernel, dim3(B), dim3(512), 0, s, stats, c->conv0_w, c->gn_w, c->gn_b, sh.L[0], scale,
                            shift, static_cast<float*>(nullptr), static_cast<float*>(nullptr), kNoInts);
     }
@@ -1368,12 +1381,7 @@ static int forward_bf16(nomad_ctx* c, const float* wav, int B, int n_samples, fl
             launch_ln_bf16<3>(y, d.ln2_w, d.ln2_b, x, M, s);
         }
     }
-    {
-        Scope sc(c, s, NOMAD_K_ROW, 2.0 * B * 768 * 256);
-        hipLaunchKernelGGL(head_kernel<bf16_t>, dim3(B), dim3(256), 0, s, x, T, c->emb_w, c->emb_b, emb, kNoInts);
-    }
-    HIP_TRY(hipGetLastError());
-    return 0;
+    return run_head<bf16_t>(c, x, B, T, c->emb_w, c->emb_b, emb, kNoInts, reinterpret_cast<float*>(hb), s);
 }
 
 
@@ -1447,7 +1455,7 @@ static X3Layout make_x3_layout(const X3Geom& g) {
     l.capa = 512LL * g.rows[0];
     l.capb = 512LL * g.rows[1];
     l.meta = take(g.ragged ? sizeof(int) * g.ragged->meta.size() : 0);
-    l.stats = take(sizeof(double) * kStatsPerClip * g.B);
+    l.stats = take(sizeof(double) * stats_doubles(g.B, g.max_l0));
     l.scale = take(sizeof(float) * 512 * g.B);
     l.shift = take(sizeof(float) * 512 * g.B);
     l.conva = take(e * l.capa);
@@ -1546,7 +1554,7 @@ static int forward_x3_run(nomad_ctx* c, const float* wav, const X3Geom& g, const
     const long long cap[2] = {lay.capa, lay.capb};
     {
         Scope sc(c, s, NOMAD_K_FRONT, 0.0);
-        hipLaunchKernelGGL(wav_stats_kernel, dim3(B), dim3(256), 0, s, wav, g.wav_ld, g.L0, stats, lens);
+        launch_wav_stats(wav, g.wav_ld, g.L0, g.max_l0, B, stats, lens, s);
         hipLaunchKernelGGL(gn_fold_kernel, dim3(B), dim3(512), 0, s, stats, c->conv0_w, c->gn_w, c->gn_b, g.L0, scale,
                            shift, static_cast<float*>(nullptr), static_cast<float*>(nullptr), lens);
     }
@@ -1657,13 +1665,7 @@ static int forward_x3_run(nomad_ctx* c, const float* wav, const X3Geom& g, const
         if (l + 1 < NOMAD_NUM_LAYERS) ln(y, d.ln2_w, d.ln2_b, x);
         else if ((rc = run_layernorm(c, y, d.ln2_w, d.ln2_b, reinterpret_cast<float*>(x), nullptr, M, 768, s))) return rc;
     }
-    {
-        Scope sc(c, s, NOMAD_K_ROW, 2.0 * B * 768 * 256);
-        hipLaunchKernelGGL(head_kernel<float>, dim3(B), dim3(256), 0, s, reinterpret_cast<const float*>(x), g.T, c->emb_w,
-                           c->emb_b, emb, tpref);
-    }
-    HIP_TRY(hipGetLastError());
-    return 0;
+    return run_head<float>(c, reinterpret_cast<const float*>(x), B, g.max_t, c->emb_w, c->emb_b, emb, tpref, reinterpret_cast<float*>(hb), s);
 }
 
 static int forward_x3(nomad_ctx* c, const float* wav, int B, int n_samples, float* emb, void* workspace,
@@ -1711,7 +1713,7 @@ static size_t ragged_bf16_layout(const RaggedShapes& r, RaggedLayout* l) {
     };
     const size_t e = sizeof(bf16_t), M = (size_t)r.rows[6];
     l->meta = take(sizeof(int) * r.meta.size());
-    l->stats = take(sizeof(double) * kStatsPerClip * r.B);
+    l->stats = take(sizeof(double) * stats_doubles(r.B, r.max_l0));
     l->scale = take(sizeof(float) * 512 * r.B);
     l->shift = take(sizeof(float) * 512 * r.B);
     l->conva = take(e * 512 * (size_t)r.rows[0]);
@@ -1760,7 +1762,7 @@ static int forward_ragged_bf16(nomad_ctx* c, const float* wav, int B, int stride
     bf16_t* cb[2] = {H(lay.conva), H(lay.convb)};
     {
         Scope sc(c, s, NOMAD_K_FRONT, 0.0);
-        hipLaunchKernelGGL(wav_stats_kernel, dim3(B), dim3(256), 0, s, wav, stride, 0, stats, lens);
+        launch_wav_stats(wav, stride, 0, rs.max_l0, B, stats, lens, s);
         hipLaunchKernelGGL(gn_fold_kernel, dim3(B), dim3(512), 0, s, stats, c->conv0_w, c->gn_w, c->gn_b, 0, scale, shift,
                            static_cast<float*>(nullptr), static_cast<float*>(nullptr), lens);
     }
@@ -1862,12 +1864,7 @@ static int forward_ragged_bf16(nomad_ctx* c, const float* wav, int B, int stride
             launch_ln_bf16<3>(y, d.ln2_w, d.ln2_b, x, M, s);
         }
     }
-    {
-        Scope sc(c, s, NOMAD_K_ROW, 2.0 * B * 768 * 256);
-        hipLaunchKernelGGL(head_kernel<bf16_t>, dim3(B), dim3(256), 0, s, x, 0, c->emb_w, c->emb_b, emb, tpref);
-    }
-    HIP_TRY(hipGetLastError());
-    return 0;
+    return run_head<bf16_t>(c, x, B, rs.max_t, c->emb_w, c->emb_b, emb, tpref, reinterpret_cast<float*>(hb), s);
 }
 
 extern "C" {
