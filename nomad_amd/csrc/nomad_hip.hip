@@ -61,6 +61,7 @@ int fail(int code, const char* fmt, ...) {
 
 constexpr int kConvK[7] = {10, 3, 3, 3, 3, 2, 2};
 constexpr int kConvS[7] = {5, 2, 2, 2, 2, 2, 2};
+constexpr long long kPairScratchDoubles = 1 << 21;  // 16 MB: e.g. 16 ref tiles x 131 072 deg rows per launch pair
 constexpr int kEventChunk = 8192;  // the profiling event pool grows by this many events whenever it runs out
 const int* const kNoInts = nullptr;  // "uniform batch" for the kernels' optional ragged-metadata pointers
 
@@ -283,6 +284,7 @@ struct nomad_ctx {
     float *eln_w = nullptr, *eln_b = nullptr;
     LayerDev layers[NOMAD_NUM_LAYERS] = {};
     float *emb_w = nullptr, *emb_b = nullptr;
+    double* pair_scratch = nullptr;  // nomad_pairwise: row sums per (64-ref tile, deg row), kPairScratchDoubles doubles
     // transposed copies for the dX-only backward (built by nomad_enable_backward)
     bool bwd_ready = false;
     float* conv_bw_even[7] = {};  // k=3 layers 1..4: [512][1024] = [W_tap2^T | W_tap0^T]
@@ -671,6 +673,12 @@ int nomad_create(nomad_ctx** out, int device, const nomad_weights* w) {
     }
     up(w->emb_w, 256 * 768, &c->emb_w);
     up(w->emb_b, 256, &c->emb_b);
+    {
+        void* d = nullptr;
+        HIP_TRY(hipMalloc(&d, sizeof(double) * kPairScratchDoubles));
+        c->allocs.push_back(d);
+        c->pair_scratch = static_cast<double*>(d);
+    }
     if (rc != 0) {
         nomad_destroy(c);
         return rc;
@@ -2824,7 +2832,17 @@ int nomad_pairwise(nomad_ctx* c, const float* deg, int Nd, const float* ref, int
         return fail(NOMAD_ERR_INVALID, "nomad_pairwise: bad argument (Nd=%d, Nr=%d)", Nd, Nr);
     hipStream_t s = static_cast<hipStream_t>(stream);
     Scope sc(c, s, NOMAD_K_PAIR, 3.0 * 256 * (double)Nd * Nr);
-    hipLaunchKernelGGL(pairwise_f64_kernel, dim3((Nd + 31) / 32), dim3(256), 0, s, deg, Nd, ref, Nr, dist, mean);
+    // per-(ref tile, deg row) partial sums live in a context-owned scratch (allocated at nomad_create: entry points never
+    // allocate); deg rows are processed in slabs that fit it
+    const int ntiles = (Nr + kPairTile - 1) / kPairTile;
+    const long long slab_max = (kPairScratchDoubles / ntiles) / kPairTile * kPairTile;
+    if (slab_max < kPairTile) return fail(NOMAD_ERR_INVALID, "nomad_pairwise: Nr=%d is too large for the scratch", Nr);
+    for (long long d0 = 0; d0 < Nd; d0 += slab_max) {
+        const int nd = (int)std::min<long long>(slab_max, Nd - d0);
+        hipLaunchKernelGGL(pairwise_tile_kernel, dim3(ntiles, (nd + kPairTile - 1) / kPairTile), dim3(256), 0, s, deg + d0 * 256, nd,
+                           ref, Nr, dist ? dist + d0 * Nr : nullptr, c->pair_scratch);
+        hipLaunchKernelGGL(pairwise_mean_kernel, dim3((nd + 255) / 256), dim3(256), 0, s, c->pair_scratch, ntiles, nd, Nr, mean + d0);
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }
