@@ -150,7 +150,8 @@ def main():
     # bf16x3 embeds a batch as two halves on two streams (Engine.embed_bf16x3): launches overlap, so per-kernel event
     # durations no longer add up to wall time.  Its roofline comes from a second, profiled pass with the split off;
     # `value` from the un-profiled pass the product actually runs.
-    split_prof = profile and args.dtype == "bf16x3" and eng.X3_SPLIT_ROWS
+    split_attr = {"bf16x3": "X3_SPLIT_ROWS", "bf16": "BF16_SPLIT_ROWS"}.get(args.dtype)
+    split_prof = profile and split_attr is not None and getattr(eng, split_attr)
     if profile and not split_prof:
         eng.profile_enable(True)
         eng.profile_reset()
@@ -163,7 +164,8 @@ def main():
     if profile and not split_prof:
         eng.profile_enable(False)
     if split_prof:
-        keep, eng.X3_SPLIT_ROWS = eng.X3_SPLIT_ROWS, 0
+        keep = getattr(eng, split_attr)
+        setattr(eng, split_attr, 0)
         step()
         fence()
         eng.profile_enable(True)
@@ -173,7 +175,7 @@ def main():
         fence()
         prof = eng.profile_read()
         eng.profile_enable(False)
-        eng.X3_SPLIT_ROWS = keep
+        setattr(eng, split_attr, keep)
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if use_pg:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -305,7 +307,7 @@ def main():
                                "other_instantiation": {"achieved": round(rate(fine if dom is big else big), 2),
                                                        "launches": (fine if dom is big else big)["launches"]}}
             out["kernel_time_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in prof.items()}
-            if args.dtype == "bf16x3":
+            if split_prof:
                 out["roofline"]["note"] = ("per-kernel timings from a second pass with the two-stream batch split off "
                                            "(kernels run alone); value / ms_per_step from the pass with it on")
         if also:

@@ -95,6 +95,9 @@ __device__ __forceinline__ void attn_tile(const float* __restrict__ Ks, const fl
         }
 }
 
+// This is the kernel for SHORT clips (fewer than kAttnV2MinT frames: config C4's T = 50, short files of a ragged batch)
+// and for the training forward with attention dropout; longer clips take attention_f32_v2_kernel (attention_f32_v2.hip.h).
+// Which kernel a clip gets depends on ITS frame count only, never on the batch it is in.
 // lse (nullable): [B*12][T] log-sum-exp of every score row, saved for the backward pass.
 // T_ = storage type of qkv / out (fp32 or bf16); the arithmetic is fp32 MFMA either way.
 // tpref (nullable): ragged batches - clip b owns rows tpref[b] .. tpref[b+1]-1 of qkv / out.
@@ -104,7 +107,7 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const T_* __restrict
                                                             float* __restrict__ lse, int T,
                                                             const int* __restrict__ tpref = nullptr,
                                                             DropCfg dc = DropCfg{}, uint32_t site = 0, int bh0 = 0,
-                                                            long long out_plane = 0) {
+                                                            long long out_plane = 0, int t_below = 0) {
     __shared__ __attribute__((aligned(16))) float Ks[64 * kAttnLD];
     __shared__ __attribute__((aligned(16))) float Vs[64 * kAttnLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -115,6 +118,7 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const T_* __restrict
         row0 = tpref[b];
         T = tpref[b + 1] - tpref[b];
         if ((int)blockIdx.x * 64 >= T) return;  // whole workgroup: no barrier has been reached yet
+        if (t_below && T >= t_below) return;     // ragged batch: clips of t_below frames or more belong to attention_f32_v2_kernel
     }
     const long long base = row0 * 2304 + h * 64;
     const int q_row = blockIdx.x * 64 + wave * 16 + qi;

@@ -25,6 +25,7 @@
 #include "../../include/nomad_hip.h"
 #include "attention.hip.h"
 #include "attention_bf16_v2.hip.h"
+#include "attention_f32_v2.hip.h"
 #include "attention_bwd.hip.h"
 #include "backward.hip.h"
 #include "frontend.hip.h"
@@ -555,6 +556,8 @@ int run_attention(nomad_ctx* c, const float* qkv, float* out, float* lse, int B,
     const dim3 grid((T + 63) / 64, B * 12);
     if (dc && dc->threshold)
         hipLaunchKernelGGL((attention_f32_kernel<float, true>), grid, dim3(256), 0, s, qkv, out, lse, T, kNoInts, *dc, site, bh0);
+    else if (T >= kAttnV2MinT)  // by the clip's length only: the same clip takes the same kernel in every batch
+        HIP_TRY(launch_attention_f32_v2(qkv, out, lse, B, T, kNoInts, s));
     else
         hipLaunchKernelGGL((attention_f32_kernel<float, false>), grid, dim3(256), 0, s, qkv, out, lse, T, kNoInts, DropCfg{}, 0u, 0);
     HIP_TRY(hipGetLastError());
@@ -934,7 +937,7 @@ static int forward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, co
 // pos-conv buffer, attention, head) read per-clip prefix sums.  Each row goes through exactly the arithmetic it
 // would see at batch 1, so results are bit-identical to per-clip calls.
 struct RaggedShapes {
-    int B = 0, max_l0 = 0, max_t = 0;
+    int B = 0, max_l0 = 0, max_t = 0, min_t = 1 << 30;
     long long rows[7] = {};   // total frames per conv level
     long long P = 0;          // total padded pos-conv frames, sum (T_c + 128)
     long long blocks = 0;     // total pos-conv frame blocks, sum ceil(T_c / kPosBlk) (bf16x3 path)
@@ -963,6 +966,7 @@ static bool make_ragged(int B, const int* lens, RaggedShapes* r) {
         r->blocks += nb;
         r->max_l0 = sh.L[0] > r->max_l0 ? sh.L[0] : r->max_l0;
         r->max_t = sh.T > r->max_t ? sh.T : r->max_t;
+        r->min_t = sh.T < r->min_t ? sh.T : r->min_t;
     }
     return r->rows[0] < (1LL << 31) / 512 * 256;  // row counts stay well inside int
 }
@@ -1106,8 +1110,13 @@ static int forward_ragged(nomad_ctx* c, const float* wav, int B, int stride, con
             return rc;
         {
             Scope sc(c, s, NOMAD_K_ATTN, attn_flops);
-            hipLaunchKernelGGL(attention_f32_kernel<float>, dim3((rs.max_t + 63) / 64, B * 12), dim3(256), 0, s, qkv, ctxb,
-                               static_cast<float*>(nullptr), 0, tpref);
+            // clips of kAttnV2MinT frames or more: the 32x32x2 kernel; shorter ones: the 16x16x4 kernel (each skips the
+            // other's clips) - exactly the kernel the clip would get in a batch of its own
+            if (rs.max_t >= kAttnV2MinT)
+                HIP_TRY(launch_attention_f32_v2(qkv, ctxb, nullptr, B, rs.max_t, tpref, s, kAttnV2MinT));
+            if (rs.min_t < kAttnV2MinT)
+                hipLaunchKernelGGL(attention_f32_kernel<float>, dim3((std::min(rs.max_t, kAttnV2MinT - 1) + 63) / 64, B * 12), dim3(256), 0,
+                                   s, qkv, ctxb, static_cast<float*>(nullptr), 0, tpref, DropCfg{}, 0u, 0, 0LL, kAttnV2MinT);
         }
         if ((rc = run_gemm(c, dense(ctxb, 768, d.o_w, d.o_b, x, y, M, 768, 768, 0), 1, pick_tile(M, 768, 768), s))) return rc;
         if ((rc = run_layernorm(c, y, d.ln1_w, d.ln1_b, x2, nullptr, M, 768, s))) return rc;
@@ -1150,6 +1159,15 @@ static hipError_t run_attention_bf16(const bf16_t* qkv, bf16_t* out, int B, int 
                : launch_attention_bf16_v2<4, 64, 4, false>(qkv, out, B, T, tpref, s);
 }
 
+// smallest grid (in 256 x 256 tiles) that takes the deep-pipelined bf16 kernel; NOMAD_BF16_8PHASE_MIN_TILES overrides (A/B runs)
+static int p8_min_tiles() {
+    static const int v = [] {
+        const char* e = getenv("NOMAD_BF16_8PHASE_MIN_TILES");
+        return e ? atoi(e) : 256;
+    }();
+    return v;
+}
+
 static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, int tile = -1) {
     const double flops = 2.0 * p.M * (double)p.n_valid * p.K * groups;  // bf16x3: the fp32-equivalent count, not 3x
     if (tile < 0) {
@@ -1157,7 +1175,7 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
         // and very tall problems, 128x128 (8 waves) on the N = 768 / 512 transformer shapes
         if (p.N % 128 != 0) tile = p.M < 512 ? 4 : 2;
         else if (p.M < 512) tile = 4;
-        else if (p.N % 256 == 0 && p.K % 128 == 0 && groups == 1 && (long long)((p.M + 255) / 256) * (p.N / 256) >= 512)
+        else if (p.N % 256 == 0 && p.K % 128 == 0 && groups == 1 && (long long)((p.M + 255) / 256) * (p.N / 256) >= p8_min_tiles())
             tile = 16;  // deep-pipelined 256x256 kernel once there are >= 2 rounds of tiles (profiles/r01_gemm_sweep_bf16_8phase.json)
         else tile = (p.N % 256 == 0 && (p.N >= 1024 || p.M >= 100000)) ? 3 : 1;
     }

@@ -85,8 +85,8 @@ class Engine:
         self._state_dict = state_dict     # host copy: nomad_train_enable re-reads it for the master parameters
         self._train_segments = None
         self._ws: Optional[torch.Tensor] = None
-        self._ws_side: Optional[torch.Tensor] = None   # second workspace for a concurrent forward on a side stream
-        self._side_stream: Optional[torch.cuda.Stream] = None
+        self._ws_side: Dict[int, torch.Tensor] = {}     # further workspaces for concurrent forwards on side streams
+        self._side_streams: Dict[int, "torch.cuda.Stream"] = {}
         self._l1_scratch: Optional[torch.Tensor] = None
 
     def close(self):
@@ -109,21 +109,24 @@ class Engine:
         _lib.check(self.lib.nomad_workspace_bytes(self.ctx, B, n_samples, C.byref(n)), "nomad_workspace_bytes")
         return n.value
 
-    def _workspace(self, nbytes: int, side: bool = False) -> torch.Tensor:
-        if side:
-            if self._ws_side is None or self._ws_side.numel() < nbytes:
-                self._ws_side = None
-                self._ws_side = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-            return self._ws_side
+    def _workspace(self, nbytes: int, side=False) -> torch.Tensor:
+        """side: False / 0 = the main workspace, True / k >= 1 = the workspace of side stream k."""
+        k = int(side)
+        if k:
+            ws = self._ws_side.get(k)
+            if ws is None or ws.numel() < nbytes:
+                self._ws_side.pop(k, None)
+                ws = self._ws_side[k] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            return ws
         if self._ws is None or self._ws.numel() < nbytes:
             self._ws = None
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         return self._ws
 
-    def side_stream(self) -> "torch.cuda.Stream":
-        if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream(device=self.device)
-        return self._side_stream
+    def side_stream(self, k: int = 1) -> "torch.cuda.Stream":
+        if k not in self._side_streams:
+            self._side_streams[k] = torch.cuda.Stream(device=self.device)
+        return self._side_streams[k]
 
     def _check_dev(self, t: torch.Tensor, name: str):
         if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
@@ -258,6 +261,7 @@ class Engine:
         # depend on the batch it is in, so the split changes no bit
         rows = sum(num_frames(n) for n in lens)
         split = B >= 2 and ((precision == "bf16x3" and self.X3_SPLIT_ROWS and rows >= self.X3_SPLIT_ROWS) or
+                            (precision == "bf16" and self.BF16_SPLIT_ROWS and rows >= self.BF16_SPLIT_ROWS) or
                             (precision == "fp32" and self.F32_SPLIT_ROWS <= rows < self.F32_SPLIT_MAX_ROWS))
         if not split:
             run(0, B, False)
@@ -303,18 +307,47 @@ class Engine:
         return loss[0]
 
     # ---- bf16 path (long-form clips, config C5) -----------------------------------------------------
+    # Like the bf16x3 path below, bf16 batches with at least this many frames are embedded as two halves on two streams:
+    # every GEMM of the path runs one 256 x 256 workgroup per CU, so the partial last round of one half's tiles (the
+    # N = 768 GEMMs of 32 clips x 30 s are 2.2 rounds) and its per-tile prologue / epilogue are filled by the other
+    # half's kernels.  A clip's bits do not depend on the batch it is in, so the split changes no result.
+    # NOMAD_BF16_SPLIT_ROWS overrides; 0 disables.
+    BF16_SPLIT_ROWS = int(os.environ.get("NOMAD_BF16_SPLIT_ROWS", 4000))
+
+    def _embed_bf16_into(self, wav: torch.Tensor, emb: torch.Tensor, side: bool):
+        B, N = wav.shape
+        ws = self._workspace(self._size(self.lib.nomad_workspace_bytes_bf16, B, N, "nomad_workspace_bytes_bf16"), side=side)
+        _lib.check(self.lib.nomad_embed_bf16(self.ctx, wav.data_ptr(), B, N, emb.data_ptr(), ws.data_ptr(), ws.numel(),
+                                             self._stream()), "nomad_embed_bf16")
+
     def embed_bf16(self, wav: torch.Tensor) -> torch.Tensor:
         """Scoring forward with bf16 activations/weights (fp32 accumulation and statistics)."""
         if wav.dim() == 3:
             wav = wav.squeeze(1)
         self._check_dev(wav, "wav")
+        if not wav.is_contiguous():
+            wav = wav.contiguous()
         B, N = wav.shape
         _lib.check(self.lib.nomad_enable_bf16(self.ctx), "nomad_enable_bf16")
-        ws = self._workspace(self._size(self.lib.nomad_workspace_bytes_bf16, B, N, "nomad_workspace_bytes_bf16"))
         emb = torch.empty(B, 256, dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.nomad_embed_bf16(self.ctx, wav.data_ptr(), B, N, emb.data_ptr(), ws.data_ptr(), ws.numel(),
-                                             self._stream()), "nomad_embed_bf16")
+        rows = B * int(self.lib.nomad_num_frames(N))
+        ways = min(self.BF16_SPLIT_WAYS, B)
+        if ways < 2 or not self.BF16_SPLIT_ROWS or rows < self.BF16_SPLIT_ROWS:
+            self._embed_bf16_into(wav, emb, side=False)
+            return emb
+        cur = torch.cuda.current_stream(self.device)
+        cuts = [B * i // ways for i in range(ways + 1)]
+        for k in range(1, ways):
+            st = self.side_stream(k)
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                self._embed_bf16_into(wav[cuts[k]:cuts[k + 1]], emb[cuts[k]:cuts[k + 1]], side=k)
+        self._embed_bf16_into(wav[:cuts[1]], emb[:cuts[1]], side=False)
+        for k in range(1, ways):
+            cur.wait_stream(self.side_stream(k))
         return emb
+
+    BF16_SPLIT_WAYS = int(os.environ.get("NOMAD_BF16_SPLIT_WAYS", 2))
 
     # ---- bf16x3 path: fp32-class scores on the bf16 matrix cores ---------------------------------------
     # Batches with at least this many frames (rows of the encoder GEMMs) are embedded as two halves on two streams: the

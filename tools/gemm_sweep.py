@@ -48,6 +48,16 @@ SHAPES = {  # name: (M, N, K, bias, gelu, residual)
     # weight-gradient shapes (rows = out features, cols = in features, contraction = padded rows / split)
     "dw_fc1": (3072, 768, 2048, False, False, False),
     "dw_out": (768, 768, 512, False, False, False),
+    # config C5 (32 clips x 30 s, T = 1499): the encoder GEMMs and two conv layers
+    "c5_out": (47968, 768, 768, True, False, True),
+    "c5_qkv": (47968, 2304, 768, True, False, False),
+    "c5_fc1": (47968, 3072, 768, True, True, False),
+    "c5_fc2": (47968, 768, 3072, True, False, True),
+    "c5_conv2": (1535968, 512, 1536, False, True, False),
+    "c5_conv4": (383968, 512, 1536, False, True, False),
+    # large squares, for comparison with the guide's numbers for the 256x256 8-phase template (1320-1470 TFLOP/s)
+    "sq4096": (4096, 4096, 4096, False, False, False),
+    "sq8192": (8192, 8192, 8192, False, False, False),
 }
 TILE_NAMES = {0: "128x128x32 w2x2", 1: "128x64x16 w2x2", 2: "64x64x32 w2x2", 3: "128x128x16 w2x2",
               4: "256x128x32 w4x2", 5: "256x256x32 w4x2", 6: "256x128x16 w4x2", 7: "128x256x32 w2x2",
