@@ -195,6 +195,10 @@ int nomad_embed_backward(nomad_ctx* ctx, const float* wav_dev, int B, int n_samp
  *                             post_extract_proj) and LayerDrop (layer_mask bit l clear = layer l skipped).  Masks are a
  *                             counter-based hash of (seed, site, element): set the SAME values before a forward
  *                             and before its backward.  All zero + mask 0xFFF (the default) = eval-mode arithmetic.
+ *   nomad_train_set_frozen    freeze_encoder != 0: the reference's `freeze_all: True` (train_triplet.py:76-79) - the conv feature
+ *                             extractor AND the encoder (pos-conv, encoder LayerNorm, 12 layers) are frozen; gradients still
+ *                             flow through them to post_extract_proj and the feature LayerNorm, which stay trainable with
+ *                             the head.  Frozen parameters keep a zero gradient, so the Adam step leaves them untouched.
  *   nomad_train_set_branches  the batch of the following nomad_embed_train / nomad_train_backward calls is `branches`
  *                             equal groups of clips (anchor | positive | negative), each with its own LayerDrop mask -
  *                             as if each group had been its own forward call, but one launch sequence over all of
@@ -220,6 +224,7 @@ int nomad_train_set_step(nomad_ctx* ctx, long long step);
 int nomad_train_set_stochastic(nomad_ctx* ctx, float dropout, float attention_dropout, float dropout_input,
                                unsigned long long seed, unsigned layer_mask);
 int nomad_train_set_branches(nomad_ctx* ctx, int branches, const unsigned* layer_masks);
+int nomad_train_set_frozen(nomad_ctx* ctx, int freeze_encoder);
 
 /* ---- bf16 path (BASELINE config C5: long-form clips) ---------------------------------------- */
 /*

@@ -326,6 +326,7 @@ struct nomad_ctx {
     unsigned layer_mask = 0xFFFu;  // bit l set: encoder layer l runs (LayerDrop clears bits)
     // A training batch may be several equal groups of clips ("branches": anchor | positive | negative), each with
     // its own LayerDrop mask, as if each had been its own forward call (nomad_train_set_branches)
+    bool freeze_encoder = false;   // config freeze_all: the encoder's parameters get no gradient (nomad_train_set_frozen)
     int branches = 1;
     unsigned branch_mask[4] = {0xFFFu, 0xFFFu, 0xFFFu, 0xFFFu};
     std::vector<void*> allocs;
@@ -2285,6 +2286,9 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
         hipLaunchKernelGGL(ln_param_final_kernel, dim3(2 * N / 64), dim3(256), 0, s, lp, nblk, N, dgam, dbet);
     };
 
+    // parameter gradients of the ENCODER (pos-conv, encoder LayerNorm, the 12 layers): not with freeze_all, where only
+    // post_extract_proj, the feature LayerNorm and the head stay trainable (train_triplet.py:76-79)
+    const bool pg = train && !c->freeze_encoder;
     // ---- head -> d loss / d x_12 -------------------------------------------------------------------
     {
         Scope sc(c, s, NOMAD_K_ROW, 0.0);
@@ -2318,7 +2322,7 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
             if ((rc = run_dropout(c, dyas, nullptr, dmasks, acts, d_res, site_ffn(l), s, idx0))) return rc;
             dy2b = dmasks;
         }
-        if (train) {
+        if (pg) {
             ln_params(y2, gxs, dl, 768, G(lo.ln2_w), G(lo.ln2_b), Ms);
             tpose(dy2b, 768, TA, false, Ms, Mps);
             rowsum(TA, 768, G(lo.fc2_b), 1.0f, Mps);
@@ -2326,7 +2330,7 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
             if ((rc = dw_gemm(c, TA, TB, 768, 3072, Mps, part, G(lo.fc2_w), 0, 1.0f, s))) return rc;
         }
         if ((rc = bwd_gemm(c, dy2b, c->fc2_wT[l], dhs, Ms, 3072, 768, u, nullptr, s))) return rc;      // du = (dy2 W2) * gelu'(u)
-        if (train) {
+        if (pg) {
             tpose(dhs, 3072, TA, false, Ms, Mps);
             rowsum(TA, 3072, G(lo.fc1_b), 1.0f, Mps);
             // fc1's input = LayerNorm(y1), recomputed into gx (the upstream gradient it held has been consumed)
@@ -2336,13 +2340,13 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
         }
         if ((rc = bwd_gemm(c, dhs, c->fc1_wT[l], dybs, Ms, 768, 3072, nullptr, dyas, s))) return rc;   // dx1 = du W1 + dy2
         if ((rc = run_ln_bwd(c, y1, dybs, nullptr, d.ln1_w, dyas, Ms, 768, s))) return rc;             // dy1
-        if (train) ln_params(y1, dybs, nullptr, 768, G(lo.ln1_w), G(lo.ln1_b), Ms);
+        if (pg) ln_params(y1, dybs, nullptr, 768, G(lo.ln1_w), G(lo.ln1_b), Ms);
         const float* dy1b = dyas;  // dy1 through out_proj's dropout mask
         if (d_res.threshold) {
             if ((rc = run_dropout(c, dyas, nullptr, dmasks, acts, d_res, site_proj(l), s, idx0))) return rc;
             dy1b = dmasks;
         }
-        if (train) {
+        if (pg) {
             tpose(dy1b, 768, TA, false, Ms, Mps);
             rowsum(TA, 768, G(lo.o_b), 1.0f, Mps);
             tpose(ctx, 768, TB, false, Ms, Mps);
@@ -2353,7 +2357,7 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
             Scope sc(c, s, NOMAD_K_ATTN, 14.0 * nc * 12.0 * (double)T * T * 64);  // 7 T x T x 64 products (S, dP twice)
             HIP_TRY(launch_attention_bwd(qkv, ctx, dybs, lse, F(lay.attnd), dqkvs, nc, T, d_att, site_attn(l), s, c0 * 12));
         }
-        if (train) {
+        if (pg) {
             // the forward's fused weight holds q scaled by head_dim^-0.5: d q_proj = 0.125 * d fused rows 0..767
             tpose(dqkvs, 2304, TA, false, Ms, Mps);
             rowsum(TA, 768, G(lo.qkv_b), 0.125f, Mps);
@@ -2384,7 +2388,7 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
     // ---- encoder input: LayerNorm, x + gelu(pos_conv(x)) --------------------------------------------
     if (d_res.threshold && (rc = run_dropout(c, gx, nullptr, gx, act, d_res, kSiteEncoder, s))) return rc;
     if ((rc = run_ln_bwd(c, sv.y0, gx, nullptr, c->eln_w, dya, M, 768, s))) return rc;                   // dy0
-    if (train) ln_params(sv.y0, gx, nullptr, 768, G(po.eln_w), G(po.eln_b), M);
+    if (pg) ln_params(sv.y0, gx, nullptr, 768, G(po.eln_w), G(po.eln_b), M);
     const long long grp_stride = (long long)B * (T + 128) * 48;
     {
         float* dug = F(lay.dug);
@@ -2414,8 +2418,11 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
         if ((rc = run_gemm(c, p, 16, 48, s))) return rc;  // one instantiation for every batch size: same summation order
     }
     if (train) {
-        // ---- pos-conv parameters: bias, then weight_g / weight_v through the weight norm --------------------
         float *dug = F(lay.dug), *xg = F(lay.xg), *dwe = F(lay.dwe), *featln = F(lay.f2);
+        // post_extract_proj's input (LayerNorm of the extractor output) is recomputed, not saved
+        if ((rc = run_layernorm(c, sv.c6, c->fln_w, c->fln_b, featln, nullptr, M, 512, s))) return rc;
+        if (pg) {
+        // ---- pos-conv parameters: bias, then weight_g / weight_v through the weight norm --------------------
         {
             Scope sc(c, s, NOMAD_K_ROW, 0.0);
             hipLaunchKernelGGL(posconv_bias_partial_kernel, dim3(kPbChunks, 16), dim3(256), 0, s, dug, (long long)B * (T + 128),
@@ -2423,7 +2430,6 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
             hipLaunchKernelGGL(posconv_bias_final_kernel, dim3(1), dim3(768), 0, s, F(lay.lnpart), G(po.pos_b));
         }
         // the conv's input (post_extract_proj output, group-major, zero padded) is recomputed, not saved
-        if ((rc = run_layernorm(c, sv.c6, c->fln_w, c->fln_b, featln, nullptr, M, 512, s))) return rc;
         {
             Scope sc(c, s, NOMAD_K_ROW, 0.0);
             hipLaunchKernelGGL(zero_pad_rows_kernel<float>, dim3(16 * B), dim3(256), 0, s, xg, T, kNoInts, kNoInts, B);
@@ -2448,6 +2454,7 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
             hipLaunchKernelGGL(tap_sum_final_kernel, dim3(1), dim3(1024), 0, s, c->tap_partial, 576, c->tap_dot);
             hipLaunchKernelGGL(posconv_wn_bwd_kernel, dim3(768 * 48 * 128 / 256), dim3(256), 0, s, dwe, c->theta + po.pos_v,
                                c->theta + po.pos_g, c->pos_nrm2, c->tap_dot, G(po.pos_v), G(po.pos_g));
+        }
         }
         // ---- post_extract_proj parameters (its output went through dropout_input) ------------------------
         if (d_in.threshold && (rc = run_dropout(c, dyb, nullptr, dyb, act, d_in, kSiteInput, s))) return rc;
@@ -2835,6 +2842,12 @@ int nomad_train_set_branches(nomad_ctx* c, int branches, const unsigned* layer_m
         return fail(NOMAD_ERR_INVALID, "nomad_train_set_branches: 1..4 branches, one mask each");
     c->branches = branches;
     for (int i = 0; i < branches && layer_masks; ++i) c->branch_mask[i] = layer_masks[i] & 0xFFFu;
+    return 0;
+}
+
+int nomad_train_set_frozen(nomad_ctx* c, int freeze_encoder) {
+    if (!c) return fail(NOMAD_ERR_INVALID, "nomad_train_set_frozen: null ctx");
+    c->freeze_encoder = freeze_encoder != 0;
     return 0;
 }
 

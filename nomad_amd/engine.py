@@ -605,6 +605,11 @@ class Engine:
         arr = (C.c_uint * len(layer_masks))(*[int(m) & 0xFFF for m in layer_masks])
         _lib.check(self.lib.nomad_train_set_branches(self.ctx, len(layer_masks), arr), "nomad_train_set_branches")
 
+    def train_set_frozen(self, freeze_encoder: bool):
+        """``freeze_all: True`` of the reference's config: no parameter gradients for the encoder (the extractor is
+        always frozen); post_extract_proj, the feature LayerNorm and the head keep training."""
+        _lib.check(self.lib.nomad_train_set_frozen(self.ctx, int(bool(freeze_encoder))), "nomad_train_set_frozen")
+
     def train_set_step(self, step: int):
         _lib.check(self.lib.nomad_train_set_step(self.ctx, int(step)), "nomad_train_set_step")
 

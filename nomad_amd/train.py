@@ -148,10 +148,11 @@ class Training:
             if not self.config.get("freeze_convnet", True):
                 raise NotImplementedError("freeze_convnet: False - the conv feature extractor is frozen in this build "
                                           "(the reference's shipped config, src/config/train_triplet.yaml)")
-            if self.config.get("freeze_all"):
-                raise NotImplementedError("freeze_all: True (head-only training) is not implemented")
         self.engine = engine if engine is not None else Engine(load_pretrained(self.config["checkpoint_path"]), device)
         self.engine.train_enable()
+        # freeze_all (train_triplet.py:76-79): feature extractor and encoder frozen; what is left trainable is
+        # post_extract_proj, the feature LayerNorm and the embedding layer
+        self.engine.train_set_frozen(bool(self.config["experiment_name"] == "Training" and self.config.get("freeze_all")))
         self.reg = dict(W2V_BASE_REGULARISATION)
         self.reg.update(regularisation or {})
         self._rng = np.random.RandomState(SEED)  # LayerDrop draws + per-call dropout seeds

@@ -449,3 +449,53 @@ def test_train_step_with_branches_of_different_lengths(built_lib, sd_train):
             assert (got[k] - want).abs().max().item() < 2e-4 * want.abs().max().item() + 1e-6 * top, k
     finally:
         eng.close()
+
+
+# ---- freeze_all: True (train_triplet.py:76-79) ------------------------------------------------------------------------
+FREEZE_ALL_TRAINABLE = ("ssl_model.post_extract_proj.weight", "ssl_model.post_extract_proj.bias", "ssl_model.layer_norm.weight",
+                        "ssl_model.layer_norm.bias", "embedding_layer.1.weight", "embedding_layer.1.bias")
+
+
+def test_freeze_all_trains_only_what_the_reference_leaves_trainable(teng, sd_train):
+    """The reference's freeze_all freezes ssl_model.feature_extractor and ssl_model.encoder: post_extract_proj, the
+    feature LayerNorm and embedding_layer stay trainable and their gradients still flow THROUGH the frozen encoder.
+    Those gradients must equal the unfrozen run's (and the oracle's); every encoder gradient must be exactly zero; an
+    Adam step then moves only the trainable tensors."""
+    A, P, N = _triplet_batch(2, 8000, seed=3)
+    ref_loss, ref = O.triplet_step_grads(sd_train, A, P, N, 1.0)
+    _, flat_full = _gpu_step_grads(teng, A, P, N, 1.0)
+    full = teng.train_unflatten(flat_full)
+    teng.train_set_frozen(True)
+    try:
+        loss, flat = _gpu_step_grads(teng, A, P, N, 1.0)
+        got = teng.train_unflatten(flat)
+    finally:
+        teng.train_set_frozen(False)
+    assert abs(loss.item() - ref_loss.item()) < 2e-5
+    top = max(v.abs().max().item() for v in ref.values())
+    for k, v in got.items():
+        if k in FREEZE_ALL_TRAINABLE:
+            assert torch.equal(v, full[k]), k                       # the same kernels in the same order
+            assert (v - ref[k]).abs().max().item() < 2e-4 * ref[k].abs().max().item() + 1e-6 * top, k
+            assert v.abs().max().item() > 0, k
+        else:
+            assert torch.count_nonzero(v).item() == 0, k
+
+
+def test_freeze_all_through_the_training_class(tmp_path):
+    """Training(config with freeze_all: True).train_step: only the six trainable tensors change."""
+    from nomad_amd.train import Training
+    csv = _toy_dataset(tmp_path)
+    tr = Training(_config(tmp_path, csv, freeze_all=True), regularisation=dict(dropout=0.0, attention_dropout=0.0,
+                                                                              dropout_input=0.0, encoder_layerdrop=0.0))
+    try:
+        before = tr.engine.train_state_dict()
+        A, P, N = next(iter(tr.valid_loader))
+        loss = tr.train_step(A, P, N)
+        assert loss.item() > 0
+        after = tr.engine.train_state_dict()
+        changed = {k for k in before if not torch.equal(before[k], after[k])}
+        assert changed and changed <= set(FREEZE_ALL_TRAINABLE), changed
+        assert {"embedding_layer.1.weight", "ssl_model.post_extract_proj.weight"} <= changed
+    finally:
+        tr.engine.close()
