@@ -132,7 +132,11 @@ int nomad_l1_loss(nomad_ctx* ctx, const float* a_layers_dev, const float* b_laye
  * backbone parameters, which nobody uses: the freeze is commented out at nomad.py:74-76).  Here the
  * weights are frozen and only d loss / d waveform is computed.
  *
- *   nomad_enable_backward    builds the transposed weight copies once (allocates; call before training)
+ *   nomad_enable_backward    builds the transposed weight copies once and a 32 MB split-K scratch (allocates; call
+ *                            before training).  With it, nomad_embed_train / nomad_embed_backward cut the contraction
+ *                            of their small-M GEMMs (fewer than 512 tiles of 64 x 64, e.g. 32 clips of 1 s) into 2 or 4
+ *                            fixed slices summed in order - deterministic, but a different rounding than nomad_embed's,
+ *                            whose summation order never depends on the batch.  Not in fine-tuning mode.
  *   nomad_embed_train        = nomad_embed with layers_dev mandatory; additionally fills `saved_dev`
  *                              (nomad_saved_bytes) with what the backward needs
  *   nomad_l1_loss_backward   d NomadLoss / d a_layers, d a_emb  (sign(a-b)/numel, times *upstream_dev)

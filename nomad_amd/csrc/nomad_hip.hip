@@ -62,6 +62,7 @@ int fail(int code, const char* fmt, ...) {
 
 constexpr int kConvK[7] = {10, 3, 3, 3, 3, 2, 2};
 constexpr int kConvS[7] = {5, 2, 2, 2, 2, 2, 2};
+constexpr size_t kSplitKPartFloats = (size_t)4 * 512 * 64 * 64;  // 4 slices of the largest problem that is split (< 512 tiles of 64 x 64)
 constexpr long long kPairScratchDoubles = 1 << 21;  // 16 MB: e.g. 16 ref tiles x 131 072 deg rows per launch pair
 constexpr int kEventChunk = 8192;  // the profiling event pool grows by this many events whenever it runs out
 const int* const kNoInts = nullptr;  // "uniform batch" for the kernels' optional ragged-metadata pointers
@@ -285,6 +286,11 @@ struct nomad_ctx {
     float *eln_w = nullptr, *eln_b = nullptr;
     LayerDev layers[NOMAD_NUM_LAYERS] = {};
     float *emb_w = nullptr, *emb_b = nullptr;
+    // Split-K for the small-M GEMMs of Nomad.forward()'s loss forward / backward (config C4: M = 1600 rows): partial
+    // products of up to 4 K-slices, allocated by nomad_enable_backward; splitk_ok is raised for the duration of such a
+    // call only (never for scoring forwards, whose bits must not depend on the batch; never in fine-tuning mode)
+    float* splitk_part = nullptr;
+    bool splitk_ok = false;
     double* pair_scratch = nullptr;  // nomad_pairwise: row sums per (64-ref tile, deg row), kPairScratchDoubles doubles
     // transposed copies for the dX-only backward (built by nomad_enable_backward)
     bool bwd_ready = false;
@@ -403,7 +409,62 @@ int occ_pad(int occ, int lds) {
     return budget > lds ? budget - lds : 0;
 }
 
-int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, int occ = 0) {
+int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, int occ = 0);
+
+// Small-M dense GEMMs of the loss forward / backward (config C4: M = 1600): N = 768 is 300 tiles of 64 x 64 on 256 CUs,
+// 44 CUs get two tiles and the launch takes two tiles' time (fc2: 82 us where a balanced split would take 48).  The
+// contraction is cut into S fixed slices - S x as many, shorter workgroups - whose partial products are added in slice
+// order by splitk_epilogue_kernel together with bias / GELU / residual: deterministic, no atomics.
+struct SplitKScope {  // raises nomad_ctx::splitk_ok for the lifetime of one forward / backward call
+    nomad_ctx* c;
+    bool prev;
+    SplitKScope(nomad_ctx* c_, bool on) : c(c_), prev(c_->splitk_ok) { c->splitk_ok = on; }
+    ~SplitKScope() { c->splitk_ok = prev; }
+};
+
+static bool splitk_applies(const nomad_ctx* c, const GemmParams& p, int groups, int tile, int* S) {
+    if (!c->splitk_ok || !c->splitk_part || groups != 1 || tile != 37) return false;
+    if (p.DG || p.Upre || p.c_colblk || p.kchunk != p.K || p.n_valid != p.N || p.N % 64) return false;
+    const bool c_plain = p.cmap.clip_rows >= p.M && p.cmap.off == 0 && p.cmap.ld == p.N;
+    const bool r_plain = !p.R || (p.rmap.clip_rows >= p.M && p.rmap.off == 0 && p.rmap.ld == p.N);
+    if (!c_plain || !r_plain || p.amap.clip_rows < p.M) return false;
+    const long long tiles = (long long)((p.M + 63) / 64) * (p.N / 64);
+    if (tiles >= 512 || p.K < 768) return false;
+    *S = p.K >= 2304 ? 4 : 2;
+    return p.K % (*S * 32) == 0 && (size_t)*S * p.M * p.N <= kSplitKPartFloats;
+}
+
+static int run_gemm_splitk(nomad_ctx* c, const GemmParams& p, int S, hipStream_t s) {
+    GemmParams q = p;
+    q.K = p.K / S;
+    q.kchunk = q.K;
+    q.a_goff = q.K;
+    q.w_goff = q.K;
+    q.C = c->splitk_part;
+    q.cmap = plain_map(p.M, p.N);
+    q.c_goff = (long long)p.M * p.N;
+    q.bias = nullptr;
+    q.R = nullptr;
+    q.gelu = 0;
+    const bool keep = c->splitk_ok;
+    c->splitk_ok = false;  // the slices themselves are ordinary launches
+    const int rc = run_gemm(c, q, S, 37, s);
+    c->splitk_ok = keep;
+    if (rc) return rc;
+    Scope sc(c, s, NOMAD_K_ROW, 0.0);
+    const long long count4 = (long long)p.M * p.N / 4;
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((count4 + 255) / 256)), dim3(256), 0, s,
+                       reinterpret_cast<const float4*>(c->splitk_part), S, count4, p.N / 4, reinterpret_cast<const float4*>(p.bias),
+                       reinterpret_cast<const float4*>(p.R), reinterpret_cast<float4*>(p.C), p.gelu);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, int occ) {
+    {
+        int S = 0;
+        if (splitk_applies(c, p, groups, tile, &S)) return run_gemm_splitk(c, p, S, s);
+    }
     if (tile == 29 && occ == 0) occ = 4;  // measured: 4 workgroups/CU is the best residency for the 128x64x32 kernel
     const double flops = 2.0 * p.M * (double)p.n_valid * p.K * groups;
     Scope sc(c, s, NOMAD_K_GEMM, flops, tile == 33 ? NOMAD_K_GEMM_BIG : ((tile == 34 || tile == 31 || tile == 48) ? NOMAD_K_GEMM_FINE : -1));
@@ -755,6 +816,8 @@ static int forward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, co
     char* ws = static_cast<char*>(workspace);
     auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     const int T = sh.T, M = sh.M;
+    // the loss forward of Nomad.forward() (saving activations, not fine-tuning): small-M GEMMs may split K
+    const SplitKScope splitk(c, sv != nullptr && !c->train_ready);
     int rc;
     // model.train() regularisation: only in the training-mode forward, only when switched on
     const bool reg = sv != nullptr;
@@ -2171,6 +2234,12 @@ int nomad_enable_backward(nomad_ctx* c) {
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
+    if (!c->splitk_part) {
+        void* d = nullptr;
+        HIP_TRY(hipMalloc(&d, kSplitKPartFloats * sizeof(float)));
+        c->allocs.push_back(d);
+        c->splitk_part = static_cast<float*>(d);
+    }
     c->bwd_ready = true;
     return 0;
 }
@@ -2248,6 +2317,7 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
     char* ws = static_cast<char*>(workspace);
     auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     const int T = sh.T, M = sh.M;
+    const SplitKScope splitk(c, !train && !c->train_ready);  // d loss / d waveform of Nomad.forward(): small-M GEMMs may split K
     float *gx = F(lay.gx), *dya = F(lay.dya), *dyb = F(lay.dyb), *dh = F(lay.dh), *dqkv = F(lay.dqkv);
     int rc;
     // the regularisation of the forward this backward belongs to (the caller re-sets it: nomad_train_set_stochastic)

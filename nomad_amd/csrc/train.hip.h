@@ -63,6 +63,32 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float4* __rest
     out[i] = o;
 }
 
+// Epilogue of a split-K dense GEMM (run_gemm_splitk): C[m][n] = act(sum_s partial[s][m][n] + bias[n]) + R[m][n], s in
+// fixed order, plain row-major C / R with ld = N.  Float4 units: count4 = M * N / 4, n4 = N / 4.
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float4* __restrict__ partial, int S, long long count4, int n4,
+                                                              const float4* __restrict__ bias, const float4* __restrict__ R,
+                                                              float4* __restrict__ C, int gelu) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count4) return;
+    float4 a = partial[i];
+    for (int s = 1; s < S; ++s) {
+        const float4 b = partial[(long long)s * count4 + i];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    if (bias) {
+        const float4 b = bias[i % n4];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    if (gelu) {
+        a.x = gelu_erf(a.x); a.y = gelu_erf(a.y); a.z = gelu_erf(a.z); a.w = gelu_erf(a.w);
+    }
+    if (R) {
+        const float4 r = R[i];
+        a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
+    }
+    C[i] = a;
+}
+
 // Bias gradient from the transposed dY: out[r] += scale * sum_m in[r][m].  One wave per row; ld % 4 == 0.
 __global__ __launch_bounds__(256) void rowsum_acc_kernel(const float* __restrict__ in, int ld, int rows,
                                                          float* __restrict__ out, float scale) {

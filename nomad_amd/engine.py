@@ -471,6 +471,7 @@ class Engine:
         if wav.dim() == 3:
             wav = wav.squeeze(1)
         self._check_dev(wav, "wav")
+        self.enable_backward()   # also allocates the split-K scratch: the first call must run the same kernels as later ones
         B, N = wav.shape
         T = num_frames(N)
         emb = torch.empty(B, 256, dtype=torch.float32, device=self.device)

@@ -87,7 +87,9 @@ def test_embed_backward_vs_oracle_autograd(engine, sd0, case, mult, grad_mult):
     head = (hw.cuda(), hb.cuda())
     emb, layers, saved = engine.embed_train(wav.cuda(), head)
     emb2, layers2 = engine.embed(wav.cuda(), head=head, want_layers=True)
-    assert torch.equal(emb, emb2) and torch.equal(layers, layers2)      # training-mode forward == scoring forward
+    # the loss forward may split the contraction of its small-M GEMMs (a different summation order than the scoring
+    # forward, whose bits must not depend on the batch): equal to rounding, not bit for bit
+    assert (emb - emb2).abs().max().item() < 1e-6 and (layers - layers2).abs().max().item() < 2e-5
     dwav = engine.embed_backward(wav.cuda(), layers, saved, G_layers.cuda(), G_emb.cuda(), head).cpu()
     assert torch.isfinite(dwav).all()
     assert _rel(dwav, ref) < 1e-3, _rel(dwav, ref)
