@@ -12,6 +12,7 @@
  *                                  backbone (fairseq Wav2Vec2Model, call sites nomad.py:226,245)
  *                                  + mean/ReLU/Linear/L2-normalise head
  *   nomad_pairwise                 scipy cdist + np.mean(axis=1) (nomad.py:108-111)
+ *   nomad_wav_probe / _read_rows   torchaudio.load + channel mean of load_processing (nomad.py:196-200)
  *   nomad_l1_loss                  NomadLoss.forward (nomad.py:267-282)
  *
  * Conventions: every function returns 0 on success or a negative nomad_status; nothing throws.
@@ -40,7 +41,9 @@ typedef enum nomad_status {
     NOMAD_ERR_INVALID = -1,   /* bad argument */
     NOMAD_ERR_NO_DEVICE = -2, /* no usable gfx950 device */
     NOMAD_ERR_HIP = -3,       /* a HIP runtime call failed; see nomad_last_error() */
-    NOMAD_ERR_WORKSPACE = -4  /* workspace too small */
+    NOMAD_ERR_WORKSPACE = -4, /* workspace too small */
+    NOMAD_ERR_IO = -5,        /* a file could not be opened / read (nomad_wav_*) */
+    NOMAD_ERR_FORMAT = -6     /* not a RIFF/WAVE file, or an encoding nomad_wav_read_rows does not decode */
 } nomad_status;
 
 typedef struct nomad_ctx nomad_ctx;
@@ -271,6 +274,27 @@ int nomad_embed_bf16x3(nomad_ctx* ctx, const float* wav_dev, int B, int n_sample
 int nomad_workspace_bytes_ragged_bf16x3(const nomad_ctx* ctx, int B, const int* lengths_host, size_t* bytes);
 int nomad_embed_ragged_bf16x3(nomad_ctx* ctx, const float* wav_dev, int B, int stride, const int* lengths_host,
                               float* emb_dev, void* workspace_dev, size_t workspace_bytes, nomad_stream_t stream);
+
+/* ---- WAV front end of the file-scoring loop (host only, no GPU work) ------------------------
+ * Nomad.get_embeddings_csv (nomad.py:171-183) calls load_processing (nomad.py:192-212) per file:
+ * torchaudio.load -> fp32 in [-1, 1), mean of the first two channels, resample to 16 kHz.  These two
+ * entry points do the first two steps on plain host threads, straight into the rows of the (pinned)
+ * staging buffer nomad_embed_ragged* reads after one H2D copy; a file at another sample rate is
+ * reported by the probe and stays with the caller's resampler.
+ * Decoded: PCM 8/16/24/32 (x 2^-(bits-1)), IEEE float 32/64, WAVE_FORMAT_EXTENSIBLE of those. */
+typedef struct nomad_wav_info {
+    int sample_rate, channels, format_tag, bits;
+    long long frames;      /* per channel; a data chunk cut short by the end of the file counts what is there */
+    long long data_offset; /* byte offset of the sample data */
+} nomad_wav_info;
+/* Headers of n files on `threads` host threads.  status[i] = NOMAD_OK, NOMAD_ERR_IO or NOMAD_ERR_FORMAT per
+ * file (info[i] zeroed then); the return value is NOMAD_OK unless the arguments are bad. */
+int nomad_wav_probe(const char* const* paths, int n, nomad_wav_info* info, int* status, int threads);
+/* Sample data of n probed files -> dst[row[i] * stride + 0 .. info[i].frames) as mono fp32 (row == NULL:
+ * row[i] = i); the rest of a row is left untouched.  Needs info[i].frames <= stride.  status as above;
+ * returns the first non-zero status (all files are attempted). */
+int nomad_wav_read_rows(const char* const* paths, const nomad_wav_info* info, int n, const int* row,
+                        float* dst_host, long long stride, int* status, int threads);
 
 /* ---- measurement ------------------------------------------------------------------------- */
 /* Kernel classes for the in-library HIP-event timers. */

@@ -25,6 +25,11 @@ class Weights(C.Structure):
                 [("layers", LayerWeights * NUM_LAYERS), ("emb_w", _fp), ("emb_b", _fp)])
 
 
+class WavInfo(C.Structure):
+    _fields_ = [("sample_rate", C.c_int), ("channels", C.c_int), ("format_tag", C.c_int), ("bits", C.c_int),
+                ("frames", C.c_longlong), ("data_offset", C.c_longlong)]
+
+
 # name -> (restype, argtypes): the complete export list of include/nomad_hip.h
 SIGNATURES = {
     "nomad_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(Weights)]),
@@ -38,6 +43,9 @@ SIGNATURES = {
     "nomad_embed_ragged": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int, C.POINTER(C.c_int), _fp, _fp, _fp, _fp,
                                      C.c_size_t, _fp]),
     "nomad_pairwise": (C.c_int, [C.c_void_p, _fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp]),
+    "nomad_wav_probe": (C.c_int, [C.POINTER(C.c_char_p), C.c_int, C.POINTER(WavInfo), C.POINTER(C.c_int), C.c_int]),
+    "nomad_wav_read_rows": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(WavInfo), C.c_int, C.POINTER(C.c_int), _fp, C.c_longlong,
+                                      C.POINTER(C.c_int), C.c_int]),
     "nomad_l1_scratch_bytes": (C.c_size_t, []),
     "nomad_l1_loss": (C.c_int, [C.c_void_p, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp]),
     "nomad_enable_backward": (C.c_int, [C.c_void_p]),

@@ -38,7 +38,7 @@ def needs_build(lib: str = LIB) -> bool:
 def _command(lib: str, diag: bool, verbose: bool):
     tmp = lib + f".tmp{os.getpid()}"
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Wall", "-Wno-unused-function", "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-Wall", "-Wno-unused-function", "-pthread", "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
     if diag:
         cmd.insert(1, "-DNOMAD_DIAG")
     if verbose:

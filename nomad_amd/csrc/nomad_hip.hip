@@ -39,6 +39,7 @@
 #include "pairwise.hip.h"
 #include "rowops.hip.h"
 #include "train.hip.h"
+#include "wav_reader.h"
 
 using namespace nomad;
 
@@ -648,6 +649,37 @@ const char* nomad_version(void) {
 #else
     return "nomad_hip 0.2 (gfx950)";
 #endif
+}
+
+int nomad_wav_probe(const char* const* paths, int n, nomad_wav_info* info, int* status, int threads) {
+    if (n < 0 || (n > 0 && (!paths || !info || !status))) return fail(NOMAD_ERR_INVALID, "nomad_wav_probe: null argument");
+    try {
+        wav::parallel_for(n, threads, [&](int i, int) { status[i] = paths[i] ? wav::probe_one(paths[i], &info[i]) : NOMAD_ERR_INVALID; });
+    } catch (const std::exception& e) {
+        return fail(NOMAD_ERR_IO, "nomad_wav_probe: %s", e.what());
+    }
+    return NOMAD_OK;
+}
+
+int nomad_wav_read_rows(const char* const* paths, const nomad_wav_info* info, int n, const int* row, float* dst_host,
+                        long long stride, int* status, int threads) {
+    if (n < 0 || (n > 0 && (!paths || !info || !dst_host || !status)) || stride < 0)
+        return fail(NOMAD_ERR_INVALID, "nomad_wav_read_rows: bad argument");
+    for (int i = 0; i < n; ++i)
+        if (!paths[i] || info[i].frames > stride || (row && row[i] < 0))
+            return fail(NOMAD_ERR_INVALID, "nomad_wav_read_rows: file %d: %lld frames do not fit a row of %lld", i, info[i].frames, stride);
+    try {
+        const int nt = std::max(1, std::min(threads, n));
+        std::vector<std::vector<unsigned char>> raw((size_t)nt);
+        wav::parallel_for(n, nt, [&](int i, int t) {
+            status[i] = wav::read_one(paths[i], info[i], dst_host + (size_t)(row ? row[i] : i) * (size_t)stride, raw[(size_t)t]);
+        });
+    } catch (const std::exception& e) {
+        return fail(NOMAD_ERR_IO, "nomad_wav_read_rows: %s", e.what());
+    }
+    for (int i = 0; i < n; ++i)
+        if (status[i] != NOMAD_OK) return fail(status[i], "nomad_wav_read_rows: %s: %s", paths[i], status[i] == NOMAD_ERR_IO ? "read failed" : "unsupported encoding");
+    return NOMAD_OK;
 }
 
 int nomad_num_frames(int n_samples) {

@@ -1,0 +1,166 @@
+// Host-side WAV front end of the file-scoring loop: what stands in front of `self.model(wave, lengths)` in
+// Nomad.get_embeddings_csv (/root/reference/src/nomad_audio/nomad.py:171-183) is load_processing (nomad.py:192-212):
+// torchaudio.load -> fp32 in [-1, 1), first two channels averaged, 16 kHz.  The reference decodes one file per
+// iteration on the Python thread; here headers are probed and sample data is converted on plain host threads (no GIL),
+// straight into the rows of the pinned staging buffer that nomad_embed_ragged* reads after ONE H2D copy.
+// Resampling is not done here: a file that is not at the target rate is reported by the probe and stays on the
+// caller's path (nomad_amd/wavio.py).  Values are bit-identical to wavio.read_wav + the two-channel mean.
+#pragma once
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../../include/nomad_hip.h"
+
+namespace nomad {
+namespace wav {
+
+inline uint32_t le32(const unsigned char* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
+inline uint32_t le16(const unsigned char* p) { return p[0] | (p[1] << 8); }
+
+inline int bytes_per_sample(int tag, int bits) {
+    if (tag == 1 && (bits == 8 || bits == 16 || bits == 24 || bits == 32)) return bits / 8;
+    if (tag == 3 && (bits == 32 || bits == 64)) return bits / 8;
+    return 0;
+}
+
+// Walks the RIFF chunk list like wavio.read_wav: the first 'data' chunk after a 'fmt ' chunk is the audio; a chunk
+// that runs past the end of the file is cut at the end of the file; chunks are 2-byte aligned.
+inline int probe_one(const char* path, nomad_wav_info* out) {
+    memset(out, 0, sizeof(*out));
+    int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return NOMAD_ERR_IO;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) {
+        close(fd);
+        return NOMAD_ERR_IO;
+    }
+    const int64_t fsize = st.st_size;
+    unsigned char h[48];
+    int rc = NOMAD_ERR_FORMAT;
+    bool have_fmt = false;
+    if (fsize >= 12 && pread(fd, h, 12, 0) == 12 && !memcmp(h, "RIFF", 4) && !memcmp(h + 8, "WAVE", 4)) {
+        int64_t pos = 12;
+        while (pos + 8 <= fsize) {
+            if (pread(fd, h, 8, pos) != 8) break;
+            const int64_t size = le32(h + 4);
+            const int64_t avail = size < fsize - (pos + 8) ? size : fsize - (pos + 8);
+            if (!memcmp(h, "fmt ", 4)) {
+                if (avail < 16) break;
+                const int64_t take = avail < 40 ? avail : 40;
+                if (pread(fd, h + 8, (size_t)take, pos + 8) != take) break;
+                int tag = (int)le16(h + 8);
+                if (tag == 0xFFFE && take >= 26) tag = (int)le16(h + 8 + 24);  // WAVE_FORMAT_EXTENSIBLE: sub-format GUID
+                out->format_tag = tag;
+                out->channels = (int)le16(h + 10);
+                out->sample_rate = (int)le32(h + 12);
+                out->bits = (int)le16(h + 22);
+                have_fmt = true;
+            } else if (!memcmp(h, "data", 4)) {
+                if (!have_fmt) break;
+                const int bps = bytes_per_sample(out->format_tag, out->bits);
+                if (bps == 0 || out->channels < 1) break;
+                if (out->bits != 24 && avail % bps) break;  // wavio.read_wav rejects a ragged tail (np.frombuffer); 24-bit is cut
+                out->data_offset = pos + 8;
+                out->frames = avail / bps / out->channels;
+                rc = NOMAD_OK;
+                break;
+            }
+            pos += 8 + size + (size & 1);
+        }
+    }
+    close(fd);
+    return rc;
+}
+
+inline float sample_at(const unsigned char* p, int tag, int bits) {
+    if (tag == 1) {
+        switch (bits) {
+            case 8: return ((float)p[0] - 128.0f) / 128.0f;
+            case 16: return (float)(int16_t)le16(p) / 32768.0f;
+            case 24: {
+                int32_t v = (int32_t)(p[0] | (p[1] << 8) | (p[2] << 16));
+                if (v & 0x800000) v -= 0x1000000;
+                return (float)v / 8388608.0f;
+            }
+            default: return (float)((double)(int32_t)le32(p) / 2147483648.0);
+        }
+    }
+    if (bits == 32) {
+        float f;
+        memcpy(&f, p, 4);
+        return f;
+    }
+    double d;
+    memcpy(&d, p, 8);
+    return (float)d;
+}
+
+// One file -> `frames` mono samples at dst.  raw: a per-thread scratch vector.
+inline int read_one(const char* path, const nomad_wav_info& wi, float* dst, std::vector<unsigned char>& raw) {
+    const int bps = bytes_per_sample(wi.format_tag, wi.bits);
+    if (bps == 0 || wi.channels < 1 || wi.frames < 0) return NOMAD_ERR_FORMAT;
+    const int ch = wi.channels;
+    const size_t frame_bytes = (size_t)bps * ch;
+    int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return NOMAD_ERR_IO;
+    constexpr int64_t kBlockFrames = 1 << 16;  // converted block by block: the scratch stays in L2
+    int rc = NOMAD_OK;
+    for (int64_t f0 = 0; f0 < wi.frames && rc == NOMAD_OK; f0 += kBlockFrames) {
+        const int64_t nf = wi.frames - f0 < kBlockFrames ? wi.frames - f0 : kBlockFrames;
+        const size_t want = (size_t)nf * frame_bytes;
+        if (raw.size() < want) raw.resize(want);
+        size_t got = 0;
+        while (got < want) {
+            ssize_t r = pread(fd, raw.data() + got, want - got, wi.data_offset + f0 * (int64_t)frame_bytes + (int64_t)got);
+            if (r <= 0) break;
+            got += (size_t)r;
+        }
+        if (got != want) {  // the file shrank since the probe
+            rc = NOMAD_ERR_IO;
+            break;
+        }
+        const unsigned char* p = raw.data();
+        float* o = dst + f0;
+        if (ch == 1 && wi.format_tag == 1 && wi.bits == 16) {
+            for (int64_t i = 0; i < nf; ++i) o[i] = (float)(int16_t)le16(p + 2 * i) / 32768.0f;
+        } else if (ch == 1) {
+            for (int64_t i = 0; i < nf; ++i) o[i] = sample_at(p + (size_t)i * bps, wi.format_tag, wi.bits);
+        } else {  // the reference averages the first two channels only (nomad.py:199-200)
+            for (int64_t i = 0; i < nf; ++i) {
+                const unsigned char* q = p + (size_t)i * frame_bytes;
+                o[i] = (sample_at(q, wi.format_tag, wi.bits) + sample_at(q + bps, wi.format_tag, wi.bits)) / 2.0f;
+            }
+        }
+    }
+    close(fd);
+    return rc;
+}
+
+template <typename Fn>
+inline void parallel_for(int n, int threads, Fn fn) {
+    if (threads < 1) threads = 1;
+    if (threads > n) threads = n;
+    if (threads <= 1) {
+        for (int i = 0; i < n; ++i) fn(i, 0);
+        return;
+    }
+    std::atomic<int> next{0};
+    std::vector<std::thread> pool;
+    pool.reserve((size_t)threads);
+    for (int t = 0; t < threads; ++t)
+        pool.emplace_back([&, t] {
+            for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i, t);
+        });
+    for (auto& th : pool) th.join();
+}
+
+}  // namespace wav
+}  // namespace nomad

@@ -191,15 +191,57 @@ def _write_rounded_csv(df: pd.DataFrame, path: str) -> None:
         f.write("\n")
 
 
-def _staged_batches(paths, load, pack, max_batch_samples: int, decode_threads: int, max_alive: int):
-    """Generator of (row indices, pack(waves)) batches over ``paths`` in order, built ahead of the consumer.
+class _StagingRing:
+    """``slots`` pinned host buffers reused round-robin by the packer thread (grown on demand, never per batch).
 
-    ``load(path) -> (1, N) array`` runs on ``decode_threads`` worker threads with a bounded look-ahead; a packer thread
-    groups consecutive files into batches of at most ``max_batch_samples`` samples (a longer file is a batch of its
-    own) and calls ``pack(list of 1-D arrays)``.  At most ``max_alive`` packed batches exist between the packer and the
-    consumer: the packer takes a token before it starts a batch, and the token returns when the consumer asks for
-    the batch AFTER the next one (by then the consumer has fetched that batch's results).  Exceptions raised by
-    ``load`` / ``pack`` re-raise in the consumer."""
+    A slot is rewritten only after the H2D copy that read it last has completed: the consumer records an event right
+    after it enqueued the copy (``uploaded``), ``take`` waits for it.  With ``max_alive`` staged batches in flight and
+    ``max_alive + 1`` slots that wait is already over in practice (the batch three back has had its results fetched)."""
+
+    def __init__(self, slots: int):
+        self.bufs = [None] * slots
+        self.events = [None] * slots
+        self.taken = 0
+
+    def take(self, rows: int, stride: int):
+        slot = self.taken % len(self.bufs)
+        self.taken += 1
+        ev, self.events[slot] = self.events[slot], None
+        if ev is not None:
+            ev.synchronize()
+        need = rows * stride
+        if self.bufs[slot] is None or self.bufs[slot].numel() < need:
+            self.bufs[slot] = None
+            self.bufs[slot] = torch.empty(need, dtype=torch.float32, pin_memory=torch.cuda.is_available())
+        return slot, self.bufs[slot][:need].view(rows, stride)
+
+    def uploaded(self, slot: int) -> None:
+        if torch.cuda.is_available():
+            ev = torch.cuda.Event()
+            ev.record()
+            self.events[slot] = ev
+
+
+def _staged_batches(paths, load, pack, max_batch_samples: int, decode_threads: int, max_alive: int, native_threads: int = 0,
+                    target_sr: int = 16000):
+    """Generator of (row indices, (staging buffer, lengths), uploaded) batches over ``paths`` in order, built ahead of
+    the consumer; the consumer calls ``uploaded()`` once it has enqueued the H2D copy of the staging buffer.
+
+    A packer thread groups consecutive files into batches of at most ``max_batch_samples`` samples (a longer file is a
+    batch of its own; a batch also closes before rows x longest row would exceed twice that, which bounds the
+    staging buffer when one long file sits among short ones).
+
+    * ``native_threads > 0``: file headers are probed through the C ABI (``nomad_wav_probe``); files that are already at
+      ``target_sr`` are converted by ``nomad_wav_read_rows`` on that many plain host threads, straight into a slot of
+      a ring of pinned staging buffers - no per-file Python, no GIL, no second copy.
+    * every other file (another sample rate, an encoding or a header the native reader does not take, an unreadable
+      file) goes through ``load(path) -> (1, N) array`` on ``decode_threads`` Python worker threads with a bounded
+      look-ahead, so results and exceptions are those of ``load``.  A batch without native files is packed by
+      ``pack(list of 1-D arrays)``.
+
+    At most ``max_alive`` packed batches exist between the packer and the consumer: the packer takes a token before
+    it starts a batch, and the token returns when the consumer asks for the batch AFTER the next one (by then the
+    consumer has fetched that batch's results).  Exceptions raised by ``load`` / ``pack`` re-raise in the consumer."""
     import queue
     import threading
     from concurrent.futures import ThreadPoolExecutor
@@ -210,34 +252,70 @@ def _staged_batches(paths, load, pack, max_batch_samples: int, decode_threads: i
     out: "queue.Queue" = queue.Queue()
     stop = threading.Event()
     lookahead = max(4 * decode_threads, 16)
+    ring = _StagingRing(max_alive + 1) if native_threads > 0 else None
+    probe_chunk = 2048
 
     def packer():
         try:
             with ThreadPoolExecutor(max_workers=max(1, decode_threads)) as pool:
-                futs, nxt = {}, 0
+                infos, fast = {}, {}          # index -> WavInfo / frames of the files the native reader takes
+                probed = 0
+                futs, scan = {}, 0            # index -> future of load(path); next file to look at for submission
 
-                def top_up(upto):
-                    nonlocal nxt
-                    while nxt < len(paths) and nxt < upto:
-                        futs[nxt] = pool.submit(load, paths[nxt])
-                        nxt += 1
-                idxs, waves, total = [], [], 0
+                def probe_upto(upto):
+                    nonlocal probed
+                    while ring is not None and probed < min(upto, len(paths)):
+                        chunk = [str(p) for p in paths[probed:probed + probe_chunk]]
+                        inf, status = wavio.probe(chunk, native_threads)
+                        for k in range(len(chunk)):
+                            if status[k] == 0 and inf[k].sample_rate == target_sr and inf[k].frames > 0:
+                                infos[probed + k] = inf[k]
+                                fast[probed + k] = int(inf[k].frames)
+                        probed += len(chunk)
+
+                def top_up(i):                 # keep up to `lookahead` Python decodes in flight, in file order
+                    nonlocal scan
+                    scan = max(scan, i)
+                    while scan < len(paths) and len(futs) < lookahead and scan < i + probe_chunk:
+                        probe_upto(scan + 1)
+                        if scan not in fast:
+                            futs[scan] = pool.submit(load, paths[scan])
+                        scan += 1
+
+                def flush(idxs, items, lens):
+                    if not any(isinstance(it, int) for it in items):
+                        return idxs, pack(items), (lambda: None)
+                    stride = (max(lens) + 3) // 4 * 4
+                    slot, host = ring.take(len(idxs), stride)
+                    rows = [r for r, it in enumerate(items) if isinstance(it, int)]
+                    wavio.read_rows([str(paths[items[r]]) for r in rows], [infos.pop(items[r]) for r in rows], rows, host,
+                                    native_threads)
+                    for r, it in enumerate(items):
+                        if not isinstance(it, int):
+                            host[r, :lens[r]] = torch.as_tensor(it, dtype=torch.float32).reshape(-1)
+                    return idxs, (host, lens), (lambda: ring.uploaded(slot))
+
+                idxs, items, lens, total = [], [], [], 0
                 tokens.acquire()
                 for i in range(len(paths)):
                     if stop.is_set():
                         return
-                    top_up(i + lookahead)
-                    w = futs.pop(i).result()
-                    w = w[0] if getattr(w, "ndim", 1) == 2 else w
-                    n = int(w.shape[0])
-                    if idxs and total + n > max_batch_samples:
-                        out.put((idxs, pack(waves)))
-                        idxs, waves, total = [], [], 0
+                    top_up(i)
+                    if i in fast:
+                        item, n = i, fast.pop(i)                  # native: converted when the batch is flushed
+                    else:
+                        w = futs.pop(i).result()
+                        item = w[0] if getattr(w, "ndim", 1) == 2 else w
+                        n = int(item.shape[0])
+                    if idxs and (total + n > max_batch_samples or (len(idxs) + 1) * max(max(lens), n) > 2 * max_batch_samples):
+                        out.put(flush(idxs, items, lens))
+                        idxs, items, lens, total = [], [], [], 0
                         tokens.acquire()
                     idxs.append(i)
-                    waves.append(w)
+                    items.append(item)
+                    lens.append(n)
                     total += n
-                out.put((idxs, pack(waves)))
+                out.put(flush(idxs, items, lens))
             out.put(None)
         except BaseException as e:  # noqa: BLE001 - handed to the consumer
             out.put(e)
@@ -400,12 +478,14 @@ class Nomad:
             paths.append(os.path.join(root, name) if root else name)
         embeddings = np.zeros((len(paths), EMB_DIM), dtype=np.float32)
         pending = None                                   # (row indices, host copy in flight) of the previous batch
-        for idxs, packed in _staged_batches(paths, lambda p: self.load_processing(p, trim=False), self.engine.pack_ragged_host,
-                                            max_batch_samples, self.DECODE_THREADS, self.PIPELINE_BATCHES):
+        for idxs, packed, uploaded in _staged_batches(paths, lambda p: self.load_processing(p, trim=False),
+                                                      self.engine.pack_ragged_host, max_batch_samples, self.DECODE_THREADS,
+                                                      self.PIPELINE_BATCHES, self.NATIVE_WAV_THREADS):
             prec = self.precision
             if prec == "bf16x3" and sum(packed[1]) < BF16X3_MIN_SAMPLES:
                 prec = "fp32"   # a handful of files does not fill the 256 x 256 tiles: the exact path is also the faster one
             emb = self.engine.embed_ragged(None, precision=prec, packed=packed)   # asynchronous
+            uploaded()                                                             # the staging slot is free once the copy is done
             fetch = self.engine.fetch_async(emb)                                   # D2H enqueued right behind it
             if pending is not None:
                 embeddings[pending[0]] = pending[1].result()                        # waits for the PREVIOUS batch only
@@ -416,7 +496,11 @@ class Nomad:
         df_emb = pd.concat([file_names.reset_index(), emb_df], axis=1).drop("index", axis=1)
         return df_emb
 
-    DECODE_THREADS = int(os.environ.get("NOMAD_DECODE_THREADS", min(8, os.cpu_count() or 1)))
+    # 16 kHz files are converted by the C ABI's reader on plain host threads (0: everything through load_processing);
+    # files that need load_processing (resampling, unusual headers) are decoded on a few Python threads - more than
+    # two of those only fight over the interpreter lock
+    NATIVE_WAV_THREADS = int(os.environ.get("NOMAD_WAV_THREADS", min(4, os.cpu_count() or 1)))
+    DECODE_THREADS = int(os.environ.get("NOMAD_DECODE_THREADS", min(2, os.cpu_count() or 1)))
     PIPELINE_BATCHES = 2      # staged batches alive at any time: one on the GPU, one being built / waiting
 
     def load_processing(self, filepath, target_sr=16000, trim=False):

@@ -11,6 +11,7 @@ without torchaudio: RIFF/WAVE decode -> fp32 in [-1, 1) -> mono -> 16 kHz.
 from __future__ import annotations
 
 import math
+import os
 import struct
 from typing import Tuple
 
@@ -103,3 +104,39 @@ def load_processing(path, target_sr: int = 16000, trim: bool = False) -> np.ndar
     if trim and wave.shape[1] > sr * 10:
         wave = wave[:, :sr * 10]
     return np.ascontiguousarray(wave, dtype=np.float32)
+
+
+# ---- the C ABI's reader (include/nomad_hip.h: nomad_wav_probe / nomad_wav_read_rows) --------------------------------
+def probe(paths, threads: int = 4):
+    """Headers of many files on native threads -> (array of _lib.WavInfo, list of per-file status; 0 = decodable)."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    n = len(paths)
+    arr = (C.c_char_p * n)(*[os.fsencode(p) for p in paths])
+    info = (_lib.WavInfo * n)()
+    status = (C.c_int * n)()
+    _lib.check(lib.nomad_wav_probe(arr, n, info, status, int(threads)), "nomad_wav_probe")
+    return info, list(status)
+
+
+def read_rows(paths, infos, rows, host, threads: int = 4) -> None:
+    """Sample data of probed files -> ``host[rows[i], :frames_i]`` (a 2-D contiguous fp32 torch tensor or numpy array),
+    mono fp32 exactly as ``load_processing`` returns it for a file that needs no resampling."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    n = len(paths)
+    if n == 0:
+        return
+    if isinstance(host, np.ndarray):
+        assert host.dtype == np.float32 and host.ndim == 2 and host.flags.c_contiguous
+        ptr, stride = host.ctypes.data, host.shape[1]
+    else:
+        assert host.dtype.is_floating_point and host.element_size() == 4 and host.dim() == 2 and host.is_contiguous()
+        ptr, stride = host.data_ptr(), host.shape[1]
+    arr = (C.c_char_p * n)(*[os.fsencode(p) for p in paths])
+    inf = (_lib.WavInfo * n)(*infos)
+    row = (C.c_int * n)(*[int(r) for r in rows])
+    status = (C.c_int * n)()
+    _lib.check(lib.nomad_wav_read_rows(arr, inf, n, row, ptr, stride, status, int(threads)), "nomad_wav_read_rows")
