@@ -259,7 +259,8 @@ int nomad_embed_ragged_bf16(nomad_ctx* ctx, const float* wav_dev, int B, int str
  * bf16 MFMA products hi*hi + hi*lo + lo*hi with fp32 accumulation - the conv stack, every dense layer, the grouped
  * pos-conv (as a Toeplitz GEMM over 5-frame blocks) and both attention products; bias, GELU, residuals, LayerNorm,
  * softmax and the head are fp32.  Accuracy is measured against the fp32 path in tests/test_gpu_bf16x3.py
- * (NOMAD scores agree to ~1e-6).  Scoring only: no layer outputs, no backward.
+ * (NOMAD scores agree to ~1e-6).  Forward only: no backward (the branch of nomad.forward() that carries the gradient
+ * stays on nomad_embed_train).
  *   nomad_enable_bf16x3          builds the split weight copies (allocates once; call again after nomad_train_* /
  *                                weight updates)
  *   nomad_embed_bf16x3           wav [B][n_samples] fp32 -> emb [B][256] fp32
@@ -269,6 +270,13 @@ int nomad_enable_bf16x3(nomad_ctx* ctx);
 int nomad_workspace_bytes_bf16x3(const nomad_ctx* ctx, int B, int n_samples, size_t* bytes);
 int nomad_embed_bf16x3(nomad_ctx* ctx, const float* wav_dev, int B, int n_samples, float* emb_dev,
                        void* workspace_dev, size_t workspace_bytes, nomad_stream_t stream);
+/* LossNetLayers.forward (nomad.py:243-258) on the bf16x3 path - what the no-gradient `clean` branch of nomad.forward()
+ * runs on: like nomad_embed with layers_out, i.e. optional head override (both or neither), emb [B][256] and
+ * layers_out [12][B*T][768] fp32 (the fp32 LayerNorm output of every encoder layer).  Same workspace as
+ * nomad_embed_bf16x3. */
+int nomad_embed_layers_bf16x3(nomad_ctx* ctx, const float* wav_dev, int B, int n_samples, const float* head_w_dev,
+                              const float* head_b_dev, float* emb_dev, float* layers_out_dev, void* workspace_dev,
+                              size_t workspace_bytes, nomad_stream_t stream);
 /* bf16x3 counterpart of nomad_embed_ragged (files of different lengths in one launch sequence - what predict uses):
  * same arguments, no head override; every clip's result equals its own single-clip nomad_embed_bf16x3 call */
 int nomad_workspace_bytes_ragged_bf16x3(const nomad_ctx* ctx, int B, const int* lengths_host, size_t* bytes);

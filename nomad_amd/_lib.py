@@ -81,6 +81,7 @@ SIGNATURES = {
     "nomad_enable_bf16x3": (C.c_int, [C.c_void_p]),
     "nomad_workspace_bytes_bf16x3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     "nomad_embed_bf16x3": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int, _fp, _fp, C.c_size_t, _fp]),
+    "nomad_embed_layers_bf16x3": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_size_t, _fp]),
     "nomad_workspace_bytes_ragged_bf16x3": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
     "nomad_embed_ragged_bf16x3": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int, C.POINTER(C.c_int), _fp, _fp, C.c_size_t, _fp]),
     "nomad_diag_attention_bf16x3": (C.c_int, [C.c_void_p, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),

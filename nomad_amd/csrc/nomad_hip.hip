@@ -1659,7 +1659,8 @@ static GemmParams dense_x3(const bf16s_t* A, long long a_plane, int lda, const b
 constexpr int kX3Split = 27, kX3F32 = 28;
 
 static int forward_x3_run(nomad_ctx* c, const float* wav, const X3Geom& g, const X3Layout& lay, const int* meta, float* emb,
-                          char* ws, hipStream_t s) {
+                          char* ws, hipStream_t s, const float* head_w = nullptr, const float* head_b = nullptr,
+                          float* layers_out = nullptr) {
     auto S = [&](size_t off) { return reinterpret_cast<bf16s_t*>(ws + off); };
     auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     const int B = g.B, M = (int)g.rows[6];
@@ -1766,10 +1767,10 @@ static int forward_x3_run(nomad_ctx* c, const float* wav, const X3Geom& g, const
         p.gelu = 1;
         if ((rc = run_gemm_bf16(c, p, 16, s, kX3F32))) return rc;
     }
-    auto ln = [&](const float* in, const float* gm, const float* bt, bf16s_t* out) {
+    auto ln = [&](const float* in, const float* gm, const float* bt, bf16s_t* out, float* out2 = nullptr) {
         Scope sc(c, s, NOMAD_K_ROW, 0.0);
-        hipLaunchKernelGGL((layernorm_kernel<3, float, bf16s_t>), dim3((M + 3) / 4), dim3(256), 0, s, in, gm, bt, out,
-                           static_cast<float*>(nullptr), M, 0LL, pl768);
+        hipLaunchKernelGGL((layernorm_kernel<3, float, bf16s_t>), dim3((M + 3) / 4), dim3(256), 0, s, in, gm, bt, out, out2, M,
+                           0LL, pl768);
     };
     ln(y, c->eln_w, c->eln_b, x);
     for (int l = 0; l < NOMAD_NUM_LAYERS; ++l) {
@@ -1784,23 +1785,28 @@ static int forward_x3_run(nomad_ctx* c, const float* wav, const X3Geom& g, const
             return rc;
         if ((rc = run_gemm_bf16(c, dense_x3(hb, pl3072, 3072, c->fc2_wx[l], d.fc2_b, x2, pl768, y, 0, M, 768, 3072, 0), 1, s, kX3F32)))
             return rc;
-        if (l + 1 < NOMAD_NUM_LAYERS) ln(y, d.ln2_w, d.ln2_b, x);
-        else if ((rc = run_layernorm(c, y, d.ln2_w, d.ln2_b, reinterpret_cast<float*>(x), nullptr, M, 768, s))) return rc;
+        // layer_results (nomad.py:250-253): the fp32 LayerNorm output, written next to its split copy
+        float* lo = layers_out ? layers_out + (size_t)l * M * 768 : nullptr;
+        if (l + 1 < NOMAD_NUM_LAYERS) ln(y, d.ln2_w, d.ln2_b, x, lo);
+        else if ((rc = run_layernorm(c, y, d.ln2_w, d.ln2_b, reinterpret_cast<float*>(x), lo, M, 768, s))) return rc;
     }
-    return run_head<float>(c, reinterpret_cast<const float*>(x), B, g.max_t, c->emb_w, c->emb_b, emb, tpref, reinterpret_cast<float*>(hb), s);
+    return run_head<float>(c, reinterpret_cast<const float*>(x), B, g.max_t, head_w ? head_w : c->emb_w, head_b ? head_b : c->emb_b, emb,
+                           tpref, reinterpret_cast<float*>(hb), s);
 }
 
 static int forward_x3(nomad_ctx* c, const float* wav, int B, int n_samples, float* emb, void* workspace,
-                      size_t workspace_bytes, nomad_stream_t stream) {
+                      size_t workspace_bytes, nomad_stream_t stream, const float* head_w = nullptr, const float* head_b = nullptr,
+                      float* layers_out = nullptr) {
     Shapes sh;
-    if (!c || !wav || !emb || !workspace || B <= 0 || !make_shapes(B, n_samples, &sh))
+    if (!c || !wav || !emb || !workspace || B <= 0 || !make_shapes(B, n_samples, &sh) || (!head_w != !head_b))
         return fail(NOMAD_ERR_INVALID, "nomad_embed_bf16x3: bad argument (B=%d, n_samples=%d)", B, n_samples);
     if (!c->x3_ready) return fail(NOMAD_ERR_INVALID, "nomad_embed_bf16x3: call nomad_enable_bf16x3 first");
     const X3Geom g = x3_geom_fixed(sh);
     const X3Layout lay = make_x3_layout(g);
     if (workspace_bytes < lay.total)
         return fail(NOMAD_ERR_WORKSPACE, "nomad_embed_bf16x3: workspace %zu < required %zu", workspace_bytes, lay.total);
-    return forward_x3_run(c, wav, g, lay, nullptr, emb, static_cast<char*>(workspace), static_cast<hipStream_t>(stream));
+    return forward_x3_run(c, wav, g, lay, nullptr, emb, static_cast<char*>(workspace), static_cast<hipStream_t>(stream), head_w, head_b,
+                          layers_out);
 }
 
 static int forward_ragged_x3(nomad_ctx* c, const float* wav, int B, int stride, const int* lens_host, float* emb,
@@ -2119,6 +2125,12 @@ int nomad_embed_ragged_bf16x3(nomad_ctx* c, const float* wav, int B, int stride,
 int nomad_embed_bf16x3(nomad_ctx* c, const float* wav, int B, int n_samples, float* emb, void* workspace,
                        size_t workspace_bytes, nomad_stream_t stream) {
     return forward_x3(c, wav, B, n_samples, emb, workspace, workspace_bytes, stream);
+}
+
+int nomad_embed_layers_bf16x3(nomad_ctx* c, const float* wav, int B, int n_samples, const float* head_w, const float* head_b,
+                              float* emb, float* layers_out, void* workspace, size_t workspace_bytes, nomad_stream_t stream) {
+    if (!layers_out) return fail(NOMAD_ERR_INVALID, "nomad_embed_layers_bf16x3: layers_out is NULL");
+    return forward_x3(c, wav, B, n_samples, emb, workspace, workspace_bytes, stream, head_w, head_b, layers_out);
 }
 
 int nomad_diag_split_bf16(nomad_ctx* c, const float* in, void* out, long long plane, long long n, int inverse,

@@ -362,9 +362,12 @@ class Engine:
         _lib.check(self.lib.nomad_embed_bf16x3(self.ctx, wav.data_ptr(), B, N, emb.data_ptr(), ws.data_ptr(), ws.numel(),
                                                self._stream()), "nomad_embed_bf16x3")
 
-    def embed_bf16x3(self, wav: torch.Tensor) -> torch.Tensor:
-        """Scoring forward whose GEMMs run as three bf16 MFMA products over hi/lo-split operands (fp32 accumulation,
-        fp32 softmax / LayerNorm / head): NOMAD scores agree with the fp32 path to ~1e-6."""
+    def embed_bf16x3(self, wav: torch.Tensor, head: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+                     want_layers: bool = False, side: bool = False):
+        """Forward whose GEMMs run as three bf16 MFMA products over hi/lo-split operands (fp32 accumulation,
+        fp32 softmax / LayerNorm / head): NOMAD scores agree with the fp32 path to ~1e-6.
+        want_layers / head: as in ``embed`` -> (emb, layers (12,B,T,768)), the LossNetLayers outputs (no gradient:
+        the branch of ``forward()`` that needs one stays on ``embed_train``)."""
         if wav.dim() == 3:
             wav = wav.squeeze(1)
         self._check_dev(wav, "wav")
@@ -373,6 +376,25 @@ class Engine:
         B, N = wav.shape
         _lib.check(self.lib.nomad_enable_bf16x3(self.ctx), "nomad_enable_bf16x3")
         emb = torch.empty(B, 256, dtype=torch.float32, device=self.device)
+        if want_layers or head is not None:
+            T = num_frames(N)
+            if T < 1:
+                raise ValueError(f"clip of {N} samples is shorter than the conv stack's receptive field")
+            hw, hb = head if head is not None else (None, None)
+            for t, name in ((hw, "head weight"), (hb, "head bias")):
+                if t is not None:
+                    self._check_dev(t, name)
+            layers = torch.empty(12, B, T, 768, dtype=torch.float32, device=self.device)
+            ws = self._workspace(self._size(self.lib.nomad_workspace_bytes_bf16x3, B, N, "nomad_workspace_bytes_bf16x3"), side=side)
+            _lib.check(self.lib.nomad_embed_layers_bf16x3(self.ctx, wav.data_ptr(), B, N,
+                                                          hw.data_ptr() if hw is not None else None,
+                                                          hb.data_ptr() if hb is not None else None,
+                                                          emb.data_ptr(), layers.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                          self._stream()), "nomad_embed_layers_bf16x3")
+            return (emb, layers) if want_layers else emb
+        if side:
+            self._embed_bf16x3_into(wav, emb, side=True)
+            return emb
         rows = B * int(self.lib.nomad_num_frames(N))
         if B < 2 or not self.X3_SPLIT_ROWS or rows < self.X3_SPLIT_ROWS:
             self._embed_bf16x3_into(wav, emb, side=False)

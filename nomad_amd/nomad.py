@@ -66,6 +66,10 @@ class TripletModel:
         return self.engine.embed(wav.to(self.engine.device, torch.float32).contiguous())
 
 
+def _takes_bf16x3(precision: str, wav: torch.Tensor) -> bool:
+    return precision == "bf16x3" and wav.numel() >= BF16X3_MIN_SAMPLES
+
+
 class LossNetLayers:
     """``LossNetLayers.forward(wav)`` (nomad.py:243-258): 12 layer outputs (B,T,768) + embedding.
 
@@ -74,8 +78,9 @@ class LossNetLayers:
     that need reproducibility can set it.
     """
 
-    def __init__(self, engine: Engine, ssl_out_dim: int = SSL_OUT_DIM, emb_dim: int = EMB_DIM):
+    def __init__(self, engine: Engine, ssl_out_dim: int = SSL_OUT_DIM, emb_dim: int = EMB_DIM, precision: str = "fp32"):
         self.engine = engine
+        self.precision = precision     # "bf16x3": batches of at least BF16X3_MIN_SAMPLES samples take the split-bf16 forward
         lin = torch.nn.Linear(ssl_out_dim, emb_dim)
         self.embedding_weight = lin.weight.detach().to(engine.device).contiguous()
         self.embedding_bias = lin.bias.detach().to(engine.device).contiguous()
@@ -85,7 +90,8 @@ class LossNetLayers:
 
     def forward(self, wav: torch.Tensor) -> List[torch.Tensor]:
         wav = wav.to(self.engine.device, torch.float32).contiguous()
-        emb, layers = self.engine.embed(wav, head=(self.embedding_weight, self.embedding_bias), want_layers=True)
+        fwd = self.engine.embed_bf16x3 if _takes_bf16x3(self.precision, wav) else self.engine.embed
+        emb, layers = fwd(wav, head=(self.embedding_weight, self.embedding_bias), want_layers=True)
         return [layers[i] for i in range(12)] + [emb]
 
 
@@ -133,12 +139,15 @@ class _NomadLossFn(torch.autograd.Function):
         cur = torch.cuda.current_stream(eng.device)
         side = eng.side_stream()
         side.wait_stream(cur)
+        # precision="bf16x3": the branches that carry no gradient (always `clean`; `estimate` too under no_grad) run
+        # the split-bf16 forward (layer outputs within ~1e-5 of fp32); the branch that is differentiated stays fp32
+        fwd = eng.embed_bf16x3 if _takes_bf16x3(nomad.precision, cln) else eng.embed
         with torch.cuda.stream(side):
-            c_emb, c_layers = eng.embed(cln, head=head, want_layers=True, side=True)
+            c_emb, c_layers = fwd(cln, head=head, want_layers=True, side=True)
         if need_grad:
             e_emb, e_layers, saved = eng.embed_train(est, head)
         else:
-            e_emb, e_layers = eng.embed(est, head=head, want_layers=True)
+            e_emb, e_layers = fwd(est, head=head, want_layers=True)
             saved = None
         cur.wait_stream(side)
         for t in (c_emb, c_layers, cln):
@@ -379,7 +388,7 @@ class Nomad:
         self.engine = Engine(sd, dev_index)
         self.engine.feature_grad_mult = find_feature_grad_mult() if feature_grad_mult is None else float(feature_grad_mult)
         self.model = TripletModel(self.engine)
-        self.lossnet_layers = LossNetLayers(self.engine, SSL_OUT_DIM, EMB_DIM)
+        self.lossnet_layers = LossNetLayers(self.engine, SSL_OUT_DIM, EMB_DIM, precision)
         self.nomad_loss = NomadLoss(self.engine)
 
     # ------------------------------------------------------------------------------------------

@@ -240,3 +240,76 @@ def test_bf16x3_follows_weight_updates(built_lib, sd0):
     ref = eng.embed(wav)
     assert not torch.equal(before, after)
     assert (after - ref).abs().max().item() < 1e-5
+
+
+# ---- LossNetLayers outputs on the bf16x3 path (nomad_embed_layers_bf16x3): the no-gradient branch of nomad.forward() ----
+@pytest.mark.parametrize("B,N", [(2, 6000), (3, 16400), (8, 64000)])
+def test_layer_outputs_bf16x3_vs_fp32_path(engine, B, N):
+    gen = torch.Generator().manual_seed(B * 1000 + N)
+    wav = (0.1 * torch.randn(B, N, generator=gen)).clamp(-1, 1).cuda()
+    hw = (torch.randn(256, 768, generator=gen) / 768 ** 0.5).cuda()
+    hb = (0.01 * torch.randn(256, generator=gen)).cuda()
+    e32, l32 = engine.embed(wav, head=(hw, hb), want_layers=True)
+    ex3, lx3 = engine.embed_bf16x3(wav, head=(hw, hb), want_layers=True)
+    torch.cuda.synchronize()
+    assert lx3.shape == l32.shape and ex3.shape == e32.shape
+    rel = [((lx3[l] - l32[l]).abs().max() / l32[l].abs().max()).item() for l in range(12)]
+    print(f"bf16x3 layer outputs B={B} N={N}: max|err|/max|x| per layer {max(rel):.2e} (first {rel[0]:.2e}, last {rel[-1]:.2e}), "
+          f"emb {(ex3 - e32).abs().max().item():.2e}")
+    assert max(rel) < 5e-5 and (ex3 - e32).abs().max().item() < 1e-5     # measured 2.3e-5 / 1.9e-6
+    # the layer-output variant is the scoring forward plus extra stores: same embedding bits with the checkpoint's head
+    assert torch.equal(engine.embed_bf16x3(wav, want_layers=True)[0], engine.embed_bf16x3(wav))
+    # the last layer output is what the head pools
+    pooled = torch.relu(lx3[11].mean(dim=1)) @ hw.T + hb
+    assert (torch.nn.functional.normalize(pooled, dim=1) - ex3).abs().max().item() < 1e-5
+
+
+def test_layer_outputs_bf16x3_vs_oracle(engine, sd0):
+    from oracle import nomad_oracle as O
+    gen = torch.Generator().manual_seed(11)
+    wav = (0.1 * torch.randn(2, 6000, generator=gen)).clamp(-1, 1)
+    hw = torch.randn(256, 768, generator=gen) / 768 ** 0.5
+    hb = 0.01 * torch.randn(256, generator=gen)
+    with torch.no_grad():
+        ref = O.lossnet_forward(sd0, wav, hw, hb)
+    emb, layers = engine.embed_bf16x3(wav.cuda(), head=(hw.cuda(), hb.cuda()), want_layers=True)
+    rel = max(((layers[l].cpu() - ref[l]).abs().max() / ref[l].abs().max()).item() for l in range(12))
+    print(f"bf16x3 layer outputs vs oracle: {rel:.2e}, emb {(emb.cpu() - ref[12]).abs().max().item():.2e}")
+    assert rel < 5e-5 and (emb.cpu() - ref[12]).abs().max().item() < 2e-5
+
+
+def test_forward_loss_bf16x3_clean_branch(built_lib, sd0):
+    """nomad.forward() with precision="bf16x3": the clean branch (no gradient) runs the split-bf16 forward once the batch
+    is large enough; loss within 1e-5 (relative) of the fp32 engine's, gradient w.r.t. estimate too."""
+    from nomad_amd import nomad as NM
+    import importlib
+    NM = importlib.import_module("nomad_amd.nomad")
+    gen = torch.Generator().manual_seed(5)
+    clean = (0.1 * torch.randn(32, 1, 16384, generator=gen)).clamp(-1, 1).cuda()
+    est = (clean + 0.02 * torch.randn(32, 1, 16384, generator=gen).cuda()).clamp(-1, 1)
+    n32, nx3 = NM.Nomad(weights=sd0), NM.Nomad(weights=sd0, precision="bf16x3")
+    nx3.lossnet_layers.embedding_weight = n32.lossnet_layers.embedding_weight
+    nx3.lossnet_layers.embedding_bias = n32.lossnet_layers.embedding_bias
+    assert NM._takes_bf16x3("bf16x3", clean) and not NM._takes_bf16x3("bf16x3", clean[:4]) and not NM._takes_bf16x3("fp32", clean)
+    out = {}
+    for name, n in (("fp32", n32), ("bf16x3", nx3)):
+        e = est.clone().requires_grad_(True)
+        loss = n.forward(e, clean)
+        loss.backward()
+        out[name] = (loss.item(), e.grad.clone())
+        with torch.no_grad():
+            out[name + "_nograd"] = n.forward(est, clean).item()
+    l32, g32 = out["fp32"]
+    lx3, gx3 = out["bf16x3"]
+    print(f"forward() loss fp32 {l32:.7f} bf16x3-clean {lx3:.7f} (rel {abs(lx3 - l32) / l32:.2e}); no-grad both branches bf16x3 "
+          f"{out['bf16x3_nograd']:.7f}; grad rel {(gx3 - g32).abs().max().item() / g32.abs().max().item():.2e}")
+    assert abs(lx3 - l32) / l32 < 1e-5
+    assert abs(out["bf16x3_nograd"] - out["fp32_nograd"]) / l32 < 1e-5
+    # d|e - c|/de = sign(e - c) flips wherever the clean branch moved by more than |e - c|: a few elements per layer
+    l2 = ((gx3 - g32).norm() / g32.norm()).item()
+    print(f"grad: relative L2 difference {l2:.2e}")
+    assert (gx3 - g32).abs().max().item() / g32.abs().max().item() < 1e-2 and l2 < 1e-2
+    # small batches stay on the fp32 path entirely: same bits
+    a = n32.forward(est[:4], clean[:4]).item()
+    b = nx3.forward(est[:4], clean[:4]).item()
+    assert a == b

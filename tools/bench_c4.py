@@ -20,8 +20,9 @@ def main():
     ap.add_argument("--samples", type=int, default=16384)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--precision", default="fp32", help="bf16x3: the no-gradient branch(es) run the split-bf16 forward")
     a = ap.parse_args()
-    nmd = Nomad(weights="seeded")
+    nmd = Nomad(weights="seeded", precision=a.precision)
     g = torch.Generator().manual_seed(0)
     clean = (0.1 * torch.randn(a.batch, 1, a.samples, generator=g)).clamp(-1, 1).cuda()
     est0 = (clean + 0.02 * torch.randn(a.batch, 1, a.samples, generator=g).cuda()).clamp(-1, 1)
@@ -35,7 +36,7 @@ def main():
         loss.backward()
         return est.grad
 
-    out = {"config": f"C4: nomad.forward() on 2x({a.batch},1,{a.samples}), fp32, 1 GPU", "steps": a.steps}
+    out = {"config": f"C4: nomad.forward() on 2x({a.batch},1,{a.samples}), {a.precision}, 1 GPU", "steps": a.steps}
     for name, fn in (("forward_ms", fwd), ("forward_backward_ms", fwd_bwd)):
         for _ in range(a.warmup):
             fn()
