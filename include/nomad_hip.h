@@ -177,7 +177,7 @@ int nomad_embed_backward(nomad_ctx* ctx, const float* wav_dev, int B, int n_samp
 /*
  * The reference fine-tunes wav2vec 2.0 + head with A/P/N forwards, nn.TripletMarginLoss(margin),
  * loss.backward() and Adam (1e-5 on the backbone, `lr` on embedding_layer), conv feature extractor frozen
- * (freeze_convnet: True).  Here the trainable parameters live in ONE flat fp32 device vector (master copy in
+ * (freeze_convnet: True, the shipped config; False is supported too).  Here the trainable parameters live in ONE flat fp32 device vector (master copy in
  * checkpoint layout), with gradients and the two Adam moments in vectors of the same layout:
  *
  *   nomad_train_param_count   floats in the vector; head_begin = first float of embedding_layer (own lr)
@@ -188,7 +188,8 @@ int nomad_embed_backward(nomad_ctx* ctx, const float* wav_dev, int B, int n_samp
  *   nomad_embed_train         (above) forward that saves activations
  *   nomad_train_backward      given d loss / d emb [B][256]: ACCUMULATES d loss / d parameters into the gradient
  *                             vector (dW as MFMA GEMMs, split over the B*T contraction, fixed-order reduction);
- *                             scratch: nomad_train_workspace_bytes.  Stops at the frozen feature extractor.
+ *                             scratch: nomad_train_workspace_bytes.  Stops at the feature extractor unless
+ *                             nomad_train_set_convnet made it trainable.
  *   nomad_triplet_loss        loss [1] = mean_i max(||a-p+eps|| - ||a-n+eps|| + margin, 0), eps = 1e-6
  *                             (torch.pairwise_distance); da/dp/dn [B][256] nullable together (validation pass)
  *   nomad_train_adam_step     torch.optim.Adam update (amsgrad off, no weight decay) with the step count kept in
@@ -206,6 +207,11 @@ int nomad_embed_backward(nomad_ctx* ctx, const float* wav_dev, int B, int n_samp
  *                             extractor AND the encoder (pos-conv, encoder LayerNorm, 12 layers) are frozen; gradients still
  *                             flow through them to post_extract_proj and the feature LayerNorm, which stay trainable with
  *                             the head.  Frozen parameters keep a zero gradient, so the Adam step leaves them untouched.
+ *   nomad_train_set_convnet   trainable != 0: the reference's `freeze_convnet: False` (train_triplet.py:71-73) - the conv
+ *                             feature extractor's weights and its GroupNorm get gradients too (conv dW as split-K MFMA GEMMs
+ *                             over transposed im2col operands; scaled by feature_grad_mult like every gradient that
+ *                             enters the extractor); changes nomad_train_workspace_bytes.  Default 0: their slices of the
+ *                             gradient vector stay zero.
  *   nomad_train_set_branches  the batch of the following nomad_embed_train / nomad_train_backward calls is `branches`
  *                             equal groups of clips (anchor | positive | negative), each with its own LayerDrop mask -
  *                             as if each group had been its own forward call, but one launch sequence over all of
@@ -232,6 +238,7 @@ int nomad_train_set_stochastic(nomad_ctx* ctx, float dropout, float attention_dr
                                unsigned long long seed, unsigned layer_mask);
 int nomad_train_set_branches(nomad_ctx* ctx, int branches, const unsigned* layer_masks);
 int nomad_train_set_frozen(nomad_ctx* ctx, int freeze_encoder);
+int nomad_train_set_convnet(nomad_ctx* ctx, int trainable);
 
 /* ---- bf16 path (BASELINE config C5: long-form clips) ---------------------------------------- */
 /*

@@ -71,6 +71,7 @@ SIGNATURES = {
     "nomad_train_write": (C.c_int, [C.c_void_p, C.c_int, _fp, _fp]),
     "nomad_train_set_step": (C.c_int, [C.c_void_p, C.c_longlong]),
     "nomad_train_set_frozen": (C.c_int, [C.c_void_p, C.c_int]),
+    "nomad_train_set_convnet": (C.c_int, [C.c_void_p, C.c_int]),
     "nomad_train_set_branches": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint)]),
     "nomad_train_set_stochastic": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_ulonglong, C.c_uint]),
     "nomad_enable_bf16": (C.c_int, [C.c_void_p]),

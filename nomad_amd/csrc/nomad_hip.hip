@@ -191,11 +191,15 @@ struct BwdLayout {
     int nchunks;
     size_t ta, tb, kpart, xg, dwe, lnpart, headp, headdz, dmask;
     int Mp, pos_split, ln_blocks;
+    size_t h0, convtmp, c0part;  // trainable conv feature extractor: recomputed conv0 output, one layer's dW, conv0 partials
+    long long conv_cols;         // columns of the conv layers' transposed operands: B * ceil512(L_1)
 };
 
 constexpr size_t kSplitPartFloats = (size_t)16 * 2304 * 768;  // >= S * Nout * Kin for every split chosen below
 
-BwdLayout make_bwd_layout(const Shapes& s, bool train = false) {
+inline long long conv_lp(int L) { return ((long long)L + 511) / 512 * 512; }  // a clip's columns in the conv dW operands
+
+BwdLayout make_bwd_layout(const Shapes& s, bool train = false, bool train_conv = false) {
     BwdLayout l{};
     size_t off = 0;
     auto take = [&](size_t floats) {
@@ -221,8 +225,10 @@ BwdLayout make_bwd_layout(const Shapes& s, bool train = false) {
         l.Mp = (s.M + 511) / 512 * 512;  // contraction length of the dW GEMMs: any split S | 16 keeps K % 32 == 0
         l.pos_split = s.B < 4 ? s.B : 4;
         l.ln_blocks = (s.M + kLnRows - 1) / kLnRows;
-        l.ta = take((size_t)3072 * l.Mp);
-        l.tb = take((size_t)3072 * l.Mp);
+        // conv dW GEMMs (freeze_convnet: False): dU^T [512][cols] and the transposed im2col [taps * 512][cols]
+        l.conv_cols = train_conv ? (long long)s.B * conv_lp(s.L[1]) : 0;
+        l.ta = take(std::max((size_t)3072 * l.Mp, (size_t)(512 * l.conv_cols)));
+        l.tb = take(std::max((size_t)3072 * l.Mp, (size_t)(1536 * l.conv_cols)));
         const size_t pos_part = (size_t)l.pos_split * 16 * 128 * 2304;
         l.kpart = take(pos_part > kSplitPartFloats ? pos_part : kSplitPartFloats);
         l.xg = take(768 * (size_t)s.B * (s.T + 128));
@@ -231,6 +237,11 @@ BwdLayout make_bwd_layout(const Shapes& s, bool train = false) {
         l.headp = take((size_t)s.B * 768);
         l.headdz = take((size_t)s.B * 256);
         l.dmask = take(768 * M);
+        if (train_conv) {
+            l.h0 = take(512 * (size_t)s.B * s.L[0]);
+            l.convtmp = take((size_t)512 * 1536);
+            l.c0part = take((size_t)5120 * s.B * l.nchunks);
+        }
     }
     l.total = off;
     return l;
@@ -244,6 +255,8 @@ struct LayerOffsets {
 struct ParamOffsets {
     size_t fln_w, fln_b, proj_w, proj_b, pos_g, pos_v, pos_b, eln_w, eln_b;
     LayerOffsets L[NOMAD_NUM_LAYERS];
+    size_t conv0_w, gn_w, gn_b, conv_w[7];  // the conv feature extractor (checkpoint layout [co][ci][tap]); frozen unless
+                                            // nomad_train_set_convnet says otherwise
     size_t emb_w, emb_b, total;
 };
 
@@ -268,6 +281,8 @@ ParamOffsets make_param_offsets() {
         q.fc2_w = take((size_t)768 * 3072); q.fc2_b = take(768);
         q.ln2_w = take(768); q.ln2_b = take(768);
     }
+    o.conv0_w = take(512 * 10); o.gn_w = take(512); o.gn_b = take(512);
+    for (int i = 1; i < 7; ++i) o.conv_w[i] = take((size_t)512 * 512 * kConvK[i]);
     o.emb_w = take(256 * 768); o.emb_b = take(256);
     o.total = off;
     return o;
@@ -333,6 +348,7 @@ struct nomad_ctx {
     unsigned layer_mask = 0xFFFu;  // bit l set: encoder layer l runs (LayerDrop clears bits)
     // A training batch may be several equal groups of clips ("branches": anchor | positive | negative), each with
     // its own LayerDrop mask, as if each had been its own forward call (nomad_train_set_branches)
+    bool train_convnet = false;    // config freeze_convnet: False - the conv feature extractor's parameters get gradients (nomad_train_set_convnet)
     bool freeze_encoder = false;   // config freeze_all: the encoder's parameters get no gradient (nomad_train_set_frozen)
     int branches = 1;
     unsigned branch_mask[4] = {0xFFFu, 0xFFFu, 0xFFFu, 0xFFFu};
@@ -2235,6 +2251,12 @@ int nomad_embed_train(nomad_ctx* c, const float* wav, int B, int n_samples, cons
     return forward_impl(c, wav, B, n_samples, head_w, head_b, emb, layers_out, workspace, workspace_bytes, stream, &sv);
 }
 
+}  // extern "C"
+namespace {
+void rebuild_conv_bwd_weights(nomad_ctx* c, hipStream_t s);
+}
+extern "C" {
+
 int nomad_enable_backward(nomad_ctx* c) {
     if (!c) return fail(NOMAD_ERR_INVALID, "null ctx");
     if (c->bwd_ready) return 0;
@@ -2250,17 +2272,13 @@ int nomad_enable_backward(nomad_ctx* c) {
         hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(32, 8), 0, 0, in, ld_in, out, ld_out, R, C);
     };
     int rc;
-    for (int i = 1; i <= 4; ++i) {  // k = 3: forward repack is [n][tap*512 + c]
+    for (int i = 1; i <= 4; ++i) {
         if ((rc = alloc(512 * 1024, &c->conv_bw_even[i]))) return rc;
         if ((rc = alloc(512 * 512, &c->conv_bw_odd[i]))) return rc;
-        transpose(c->conv_w[i] + 2 * 512, 1536, c->conv_bw_even[i], 1024, 512, 512);        // tap 2 pairs with dU[t'-1]
-        transpose(c->conv_w[i], 1536, c->conv_bw_even[i] + 512, 1024, 512, 512);            // tap 0 pairs with dU[t']
-        transpose(c->conv_w[i] + 512, 1536, c->conv_bw_odd[i], 512, 512, 512);              // tap 1
     }
-    for (int i = 5; i <= 6; ++i) {  // k = 2: [n][tap*512 + c] -> [(tap*512 + c)][n]
+    for (int i = 5; i <= 6; ++i)
         if ((rc = alloc(1024 * 512, &c->conv_bw2[i]))) return rc;
-        transpose(c->conv_w[i], 1024, c->conv_bw2[i], 512, 512, 1024);
-    }
+    rebuild_conv_bwd_weights(c, 0);
     if ((rc = alloc(512 * 768, &c->proj_wT))) return rc;
     transpose(c->proj_w, 512, c->proj_wT, 768, 768, 512);
     if ((rc = alloc((size_t)16 * 64 * 6144, &c->pos_wb))) return rc;
@@ -2353,7 +2371,8 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
     if (!c->bwd_ready) return fail(NOMAD_ERR_INVALID, "nomad_embed_backward: call nomad_enable_backward first");
     if (train && !c->train_ready) return fail(NOMAD_ERR_INVALID, "nomad_train_backward: call nomad_train_enable first");
     const Saved sv = make_saved(sh, const_cast<void*>(saved));
-    const BwdLayout lay = make_bwd_layout(sh, train);
+    const bool conv_pg = train && c->train_convnet;  // parameter gradients of the conv feature extractor too
+    const BwdLayout lay = make_bwd_layout(sh, train, conv_pg);
     if (saved_bytes < sv.total || workspace_bytes < lay.total)
         return fail(NOMAD_ERR_WORKSPACE, "nomad_embed_backward: saved %zu/%zu, workspace %zu/%zu", saved_bytes, sv.total,
                     workspace_bytes, lay.total);
@@ -2581,11 +2600,36 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
     if ((rc = bwd_gemm(c, dyb, c->proj_wT, F(lay.f1), M, 512, 768, nullptr, nullptr, s))) return rc;
     if (train) ln_params(sv.c6, F(lay.f1), nullptr, 512, G(po.fln_w), G(po.fln_b), M);
     HIP_TRY(hipGetLastError());
-    if (!dwav) return 0;  // frozen conv feature extractor (freeze_convnet: True): nothing upstream needs a gradient
-    if (c->feature_grad_mult == 0.f) {  // fairseq runs the extractor under no_grad then: no gradient reaches the waveform
-        HIP_TRY(hipMemsetAsync(dwav, 0, sizeof(float) * (size_t)B * n_samples, s));
+    if (!dwav && !conv_pg) return 0;  // frozen conv feature extractor (freeze_convnet: True): nothing upstream needs a gradient
+    if (c->feature_grad_mult == 0.f) {  // fairseq runs the extractor under no_grad then: no gradient reaches it or the waveform
+        if (dwav) HIP_TRY(hipMemsetAsync(dwav, 0, sizeof(float) * (size_t)B * n_samples, s));
         return 0;
     }
+    // d W_i of conv layer i (freeze_convnet: False): dU_i^T x im2col(input)^T contracted over all frames, per-clip column
+    // blocks of conv_lp(L_i) (zero padded), the same split-K dW GEMM as the encoder's, then back to [co][ci][tap]
+    auto conv_dw = [&](int i, const float* dU, const float* in, long long in_clip, bool gelu_in) -> int {
+        const int Lout = sh.L[i], taps = kConvK[i], Kin = taps * 512;
+        const int Lp = (int)conv_lp(Lout);
+        const long long cols = (long long)B * Lp;
+        {
+            Scope sc(c, s, NOMAD_K_ROW, 0.0);
+            hipLaunchKernelGGL(transpose_clips_kernel<0>, dim3(Lp / 64, 8, B), dim3(256), 0, s, dU + 512, (long long)(Lout + 2) * 512, 512,
+                               TA, cols, Lp, Lout, 512);
+            const dim3 grid(Lp / 64, Kin / 64, B);
+            if (gelu_in)
+                hipLaunchKernelGGL(transpose_clips_kernel<1>, grid, dim3(256), 0, s, in, in_clip, kConvS[i] * 512, TB, cols, Lp, Lout, Kin);
+            else
+                hipLaunchKernelGGL(transpose_clips_kernel<0>, grid, dim3(256), 0, s, in, in_clip, kConvS[i] * 512, TB, cols, Lp, Lout, Kin);
+        }
+        float* tmp = F(lay.convtmp);
+        HIP_TRY(hipMemsetAsync(tmp, 0, sizeof(float) * 512 * (size_t)Kin, s));
+        int rc2;
+        if ((rc2 = dw_gemm(c, TA, TB, 512, Kin, (int)cols, part, tmp, 0, 1.0f, s))) return rc2;
+        Scope sc(c, s, NOMAD_K_ROW, 0.0);
+        const long long n = 512LL * Kin;
+        hipLaunchKernelGGL(conv_grad_permute_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, tmp, G(po.conv_w[i]), taps);
+        return 0;
+    };
     if ((rc = run_ln_bwd(c, sv.c6, F(lay.f1), nullptr, c->fln_w, F(lay.f2), M, 512, s))) return rc;
     float* bufs[2] = {F(lay.bufa), F(lay.bufb)};  // dU6 -> a, dU5 -> b, ..., dU1 -> b, G0 -> a
     {
@@ -2606,6 +2650,15 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
         const long long out_clip = to_g0 ? (long long)Lin * 512 : (long long)(Lin + 2) * 512;
         const long long out_off = to_g0 ? 0 : 512;
         HIP_TRY(hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * out_clip, s));
+        if (conv_pg) {  // input of layer i: gelu(u_{i-1}) recomputed in the transpose; for i = 1 conv0's output, recomputed whole
+            if (i == 1) {
+                Scope sc(c, s, NOMAD_K_FRONT, 0.0);
+                hipLaunchKernelGGL(conv0_gn_gelu_kernel<float>, dim3((sh.L[0] + kConv0Frames - 1) / kConv0Frames, B), dim3(256), 0, s, wav,
+                                   n_samples, sh.L[0], c->conv0_w, sv.gn_scale, sv.gn_shift, F(lay.h0), kNoInts, kNoInts, 0LL);
+            }
+            const float* in = i == 1 ? F(lay.h0) : sv.u[i - 1];
+            if ((rc = conv_dw(i, dU, in, (long long)Lin * 512, i != 1))) return rc;
+        }
         GemmParams p{};
         p.A = dU;
         p.C = out;
@@ -2648,13 +2701,20 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
     {
         const float* G0 = bufs[0];
         float* partial = F(lay.partial);
-        HIP_TRY(hipMemsetAsync(dwav, 0, sizeof(float) * (size_t)B * n_samples, s));
+        if (dwav) HIP_TRY(hipMemsetAsync(dwav, 0, sizeof(float) * (size_t)B * n_samples, s));
         Scope sc(c, s, NOMAD_K_FRONT, 0.0);
         const dim3 grid(lay.nchunks, B);
         hipLaunchKernelGGL(gn_bwd_stats_kernel, grid, dim3(256), 0, s, wav, n_samples, sh.L[0], c->conv0_w, sv.gn_scale,
                            sv.gn_shift, sv.gn_mean, sv.gn_rstd, G0, partial);
-        hipLaunchKernelGGL(conv0_bwd_kernel, grid, dim3(256), 0, s, wav, n_samples, sh.L[0], c->conv0_w, sv.gn_scale,
-                           sv.gn_shift, sv.gn_mean, sv.gn_rstd, G0, partial, lay.nchunks, dwav);
+        if (dwav)
+            hipLaunchKernelGGL(conv0_bwd_kernel, grid, dim3(256), 0, s, wav, n_samples, sh.L[0], c->conv0_w, sv.gn_scale,
+                               sv.gn_shift, sv.gn_mean, sv.gn_rstd, G0, partial, lay.nchunks, dwav);
+        if (conv_pg) {  // conv0 weight, GroupNorm gamma / beta
+            hipLaunchKernelGGL(conv0_param_partial_kernel, grid, dim3(256), 0, s, wav, n_samples, sh.L[0], c->conv0_w, sv.gn_scale,
+                               sv.gn_shift, sv.gn_mean, sv.gn_rstd, G0, partial, lay.nchunks, F(lay.c0part));
+            hipLaunchKernelGGL(conv0_param_final_kernel, dim3(24), dim3(256), 0, s, F(lay.c0part), partial, B, lay.nchunks,
+                               G(po.conv0_w), G(po.gn_w), G(po.gn_b));
+        }
     }
     HIP_TRY(hipGetLastError());
     return 0;
@@ -2668,8 +2728,9 @@ struct Segment {
     size_t offset, count;
 };
 
-// Checkpoint key -> slice of the flat parameter vector (the keys of nomad_best_model.pt that train_triplet.py
-// leaves trainable with freeze_convnet: True).
+// Checkpoint key -> slice of the flat parameter vector: every parameter of nomad_best_model.pt that train_triplet.py can
+// train (mask_emb gets no gradient with mask=False).  The conv feature extractor's slices keep a zero gradient unless
+// nomad_train_set_convnet(ctx, 1) (config freeze_convnet: False).
 const std::vector<Segment>& segments() {
     static const std::vector<Segment> segs = [] {
         std::vector<Segment> v;
@@ -2705,11 +2766,30 @@ const std::vector<Segment>& segments() {
             v.push_back({b + "final_layer_norm.weight", q.ln2_w, 768});
             v.push_back({b + "final_layer_norm.bias", q.ln2_b, 768});
         }
+        const std::string fe = p + "feature_extractor.conv_layers.";
+        v.push_back({fe + "0.0.weight", o.conv0_w, 512 * 10});
+        v.push_back({fe + "0.2.weight", o.gn_w, 512});
+        v.push_back({fe + "0.2.bias", o.gn_b, 512});
+        for (int i = 1; i < 7; ++i) v.push_back({fe + std::to_string(i) + ".0.weight", o.conv_w[i], (size_t)512 * 512 * kConvK[i]});
         v.push_back({"embedding_layer.1.weight", o.emb_w, 256 * 768});
         v.push_back({"embedding_layer.1.bias", o.emb_b, 256});
         return v;
     }();
     return segs;
+}
+
+// The transposed conv weights the dX chain of the backward contracts with (from the kernel-layout forward weights).
+void rebuild_conv_bwd_weights(nomad_ctx* c, hipStream_t s) {
+    auto transpose = [&](const float* in, int ld_in, float* out, int ld_out, int R, int C) {
+        hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(32, 8), 0, s, in, ld_in, out, ld_out, R, C);
+    };
+    for (int i = 1; i <= 4; ++i) {  // k = 3: forward repack is [n][tap*512 + c]
+        transpose(c->conv_w[i] + 2 * 512, 1536, c->conv_bw_even[i], 1024, 512, 512);        // tap 2 pairs with dU[t'-1]
+        transpose(c->conv_w[i], 1536, c->conv_bw_even[i] + 512, 1024, 512, 512);            // tap 0 pairs with dU[t']
+        transpose(c->conv_w[i] + 512, 1536, c->conv_bw_odd[i], 512, 512, 512);              // tap 1
+    }
+    for (int i = 5; i <= 6; ++i)  // k = 2: [n][tap*512 + c] -> [(tap*512 + c)][n]
+        transpose(c->conv_w[i], 1024, c->conv_bw2[i], 512, 512, 1024);
 }
 
 // Rebuild every kernel-layout weight that is not a plain alias of the master vector: the fused, q-scaled q/k/v
@@ -2726,6 +2806,12 @@ int refresh_weights(nomad_ctx* c, hipStream_t s) {
                        c->pos_nrm2, c->pos_w);
     hipLaunchKernelGGL(posconv_bwd_weight_kernel, dim3(16 * 64), dim3(256), 0, s, c->pos_w, c->pos_wb);
     transpose(c->proj_w, 512, c->proj_wT, 768, 768, 512);
+    for (int i = 1; i < 7; ++i) {  // conv feature extractor: kernel layout [co][tap * 512 + ci] and the dX GEMMs' copies
+        const long long n = 512LL * 512 * kConvK[i];
+        hipLaunchKernelGGL(conv_repack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c->theta + po.conv_w[i], c->conv_w[i],
+                           kConvK[i]);
+    }
+    rebuild_conv_bwd_weights(c, s);
     for (int l = 0; l < NOMAD_NUM_LAYERS; ++l) {
         const LayerDev& d = c->layers[l];
         const LayerOffsets& lo = po.L[l];
@@ -2832,6 +2918,8 @@ int nomad_train_enable(nomad_ctx* c, const nomad_weights* w) {
         put(lo.fc2_w, lw.fc2_w, (size_t)768 * 3072); put(lo.fc2_b, lw.fc2_b, 768);
         put(lo.ln2_w, lw.ln2_w, 768); put(lo.ln2_b, lw.ln2_b, 768);
     }
+    put(po.conv0_w, w->conv_w[0], 512 * 10); put(po.gn_w, w->gn_w, 512); put(po.gn_b, w->gn_b, 512);
+    for (int i = 1; i < 7; ++i) put(po.conv_w[i], w->conv_w[i], (size_t)512 * 512 * kConvK[i]);
     put(po.emb_w, w->emb_w, 256 * 768); put(po.emb_b, w->emb_b, 256);
     if (rc) return rc;
     // From here on the engine reads these parameters straight from the master vector (same layout as the
@@ -2851,6 +2939,7 @@ int nomad_train_enable(nomad_ctx* c, const nomad_weights* w) {
         d.ln2_w = th + lo.ln2_w; d.ln2_b = th + lo.ln2_b;
     }
     c->emb_w = th + po.emb_w; c->emb_b = th + po.emb_b;
+    c->conv0_w = th + po.conv0_w; c->gn_w = th + po.gn_w; c->gn_b = th + po.gn_b;  // conv1..6: derived copies (refresh_weights)
     if ((rc = refresh_weights(c, 0))) return rc;
     HIP_TRY(hipDeviceSynchronize());
     c->adam_t = 0;
@@ -2862,7 +2951,7 @@ int nomad_train_workspace_bytes(const nomad_ctx* c, int B, int n_samples, size_t
     Shapes sh;
     if (!c || !bytes || B <= 0 || !make_shapes(B, n_samples, &sh))
         return fail(NOMAD_ERR_INVALID, "nomad_train_workspace_bytes: bad shape B=%d N=%d", B, n_samples);
-    *bytes = make_bwd_layout(sh, true).total;
+    *bytes = make_bwd_layout(sh, true, c->train_convnet).total;
     return 0;
 }
 
@@ -2962,6 +3051,12 @@ int nomad_train_set_branches(nomad_ctx* c, int branches, const unsigned* layer_m
 int nomad_train_set_frozen(nomad_ctx* c, int freeze_encoder) {
     if (!c) return fail(NOMAD_ERR_INVALID, "nomad_train_set_frozen: null ctx");
     c->freeze_encoder = freeze_encoder != 0;
+    return 0;
+}
+
+int nomad_train_set_convnet(nomad_ctx* c, int trainable) {
+    if (!c) return fail(NOMAD_ERR_INVALID, "nomad_train_set_convnet: null ctx");
+    c->train_convnet = trainable != 0;
     return 0;
 }
 

@@ -13,6 +13,7 @@
 
 #include <cstdint>
 
+#include "backward.hip.h"
 #include "dropout.hip.h"
 #include "gemm_f32.hip.h"
 #include "rowops.hip.h"
@@ -485,6 +486,127 @@ __global__ __launch_bounds__(192) void dropout_groups_kernel(float* __restrict__
     v.x *= drop_mult(d, site, e); v.y *= drop_mult(d, site, e + 1);
     v.z *= drop_mult(d, site, e + 2); v.w *= drop_mult(d, site, e + 3);
     *p = v;
+}
+
+}  // namespace nomad
+
+// ---- parameter gradients of the conv feature extractor (freeze_convnet: False, train_triplet.py:71-73) --------------
+namespace nomad {
+
+// Per-clip transpose for the conv dW GEMMs: out[c][b * Lp + m] = f(in[b * in_clip + m * ld_in + c]) for m < L, 0 for
+// L <= m < Lp (Lp % 64 == 0, C % 4 == 0).  With ld_in = stride * 512 and C = taps * 512 the rows are the im2col rows
+// of a time-major activation (taps of consecutive frames are contiguous).  grid: (Lp/64, ceil(C/64), B), 256 threads.
+template <int ACT>
+__global__ __launch_bounds__(256) void transpose_clips_kernel(const float* __restrict__ in, long long in_clip, int ld_in,
+                                                              float* __restrict__ out, long long ld_out, int Lp, int L, int C) {
+    __shared__ float tile[64][65];
+    const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tid = threadIdx.x;
+    const int r = tid >> 4, q = (tid & 15) * 4;
+    in += (long long)blockIdx.z * in_clip;
+    out += (long long)blockIdx.z * Lp;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + r + 16 * i, c = c0 + q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < L && c < C) v = *reinterpret_cast<const float4*>(in + (long long)m * ld_in + c);
+        if (ACT == 1) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+        tile[r + 16 * i][q] = v.x; tile[r + 16 * i][q + 1] = v.y; tile[r + 16 * i][q + 2] = v.z; tile[r + 16 * i][q + 3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + r + 16 * i;
+        if (c < C) {
+            float4 v;
+            v.x = tile[q][r + 16 * i]; v.y = tile[q + 1][r + 16 * i]; v.z = tile[q + 2][r + 16 * i]; v.w = tile[q + 3][r + 16 * i];
+            *reinterpret_cast<float4*>(out + (long long)c * ld_out + m0 + q) = v;
+        }
+    }
+}
+
+// Checkpoint layout [co][ci][tap] -> kernel layout [co][tap * 512 + ci] (K taps).  grid: 512 * K * 2 blocks of 256.
+__global__ __launch_bounds__(256) void conv_repack_kernel(const float* __restrict__ w, float* __restrict__ out, int K) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // index into out
+    if (i >= 512LL * 512 * K) return;
+    const int ci = (int)(i & 511), tap = (int)((i >> 9) % K), co = (int)(i / (512LL * K));
+    out[i] = w[((long long)co * 512 + ci) * K + tap];
+}
+
+// grad[co][ci][tap] += dw[co][tap * 512 + ci]: the dW GEMM's output back into the checkpoint layout.
+__global__ __launch_bounds__(256) void conv_grad_permute_kernel(const float* __restrict__ dw, float* __restrict__ grad, int K) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // index into grad
+    if (i >= 512LL * 512 * K) return;
+    const int tap = (int)(i % K), ci = (int)((i / K) & 511), co = (int)(i / (512LL * K));
+    grad[i] += dw[((long long)co * K + tap) * 512 + ci];
+}
+
+// conv0 + GroupNorm parameter gradients, pass 2 (pass 1 = gn_bwd_stats_kernel, backward.hip.h): with
+//   dz = G gelu'(z), dy = gamma rstd (dz - s1/L0 - yhat s2/L0):   d w0[c][j] = sum_{b,t} dy[t,c] x[5t+j]
+// per (clip, frame chunk) partials cpart[b][chunk][512][10], folded in fixed order by conv0_param_final_kernel together
+// with d gamma[c] = sum_b s2[b][c], d beta[c] = sum_b s1[b][c] from pass 1's partials.  grid: (chunks, B), 256 threads.
+__global__ __launch_bounds__(256) void conv0_param_partial_kernel(const float* __restrict__ wav, int n_samples, int L0,
+                                                                  const float* __restrict__ w0, const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, const float* __restrict__ gmean,
+                                                                  const float* __restrict__ grstd, const float* __restrict__ G,
+                                                                  const float* __restrict__ partial, int nchunks,
+                                                                  float* __restrict__ cpart) {
+    __shared__ float xs[kGnChunk * 5 + 8];
+    const int b = blockIdx.y, t0 = blockIdx.x * kGnChunk, nfr = min(kGnChunk, L0 - t0), tid = threadIdx.x;
+    const float* x = wav + (long long)b * n_samples + 5 * t0;
+    for (int i = tid; i < 5 * nfr + 5; i += 256) xs[i] = x[i];
+    float w[2][10], sc[2], sh[2], mean[2], rstd[2], m1[2], m2[2], dw[2][10];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int c = tid + 256 * q;
+        sc[q] = scale[b * 512 + c]; sh[q] = shift[b * 512 + c];
+        mean[q] = gmean[b * 512 + c]; rstd[q] = grstd[b * 512 + c];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) { w[q][j] = w0[c * 10 + j]; dw[q][j] = 0.f; }
+        float a1 = 0.f, a2 = 0.f;
+        for (int k = 0; k < nchunks; ++k) {
+            const float* p = partial + ((long long)b * nchunks + k) * 1024;
+            a1 += p[c];
+            a2 += p[512 + c];
+        }
+        m1[q] = a1 / (float)L0;
+        m2[q] = a2 / (float)L0;
+    }
+    __syncthreads();
+    const float* g = G + ((long long)b * L0 + t0) * 512;
+    for (int t = 0; t < nfr; ++t) {
+        float z[2], yh[2];
+        conv0_frame(xs, t, w, sc, sh, mean, rstd, z, yh);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float dz = g[(long long)t * 512 + tid + 256 * q] * dgelu_erf(z[q]);
+            const float dy = sc[q] * (dz - m1[q] - yh[q] * m2[q]);
+#pragma unroll
+            for (int j = 0; j < 10; ++j) dw[q][j] = fmaf(dy, xs[5 * t + j], dw[q][j]);
+        }
+    }
+    float* o = cpart + ((long long)b * nchunks + blockIdx.x) * 5120;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j = 0; j < 10; ++j) o[(tid + 256 * q) * 10 + j] = dw[q][j];
+}
+
+// grid: 22 blocks of 256: elements 0..5119 = d w0, 5120..5631 = d gamma, 5632..6143 = d beta (accumulated into the
+// gradient vector; (b, chunk) folded in fixed order).
+__global__ __launch_bounds__(256) void conv0_param_final_kernel(const float* __restrict__ cpart, const float* __restrict__ partial,
+                                                                int B, int nchunks, float* __restrict__ dw0,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < 5120) {
+        float a = 0.f;
+        for (int k = 0; k < B * nchunks; ++k) a += cpart[(long long)k * 5120 + i];
+        dw0[i] += a;
+    } else if (i < 6144) {
+        const int c = (i - 5120) & 511, which = (i - 5120) >> 9;  // 0: gamma <- s2, 1: beta <- s1
+        float a = 0.f;
+        for (int k = 0; k < B * nchunks; ++k) a += partial[(long long)k * 1024 + (which == 0 ? 512 : 0) + c];
+        (which == 0 ? dgamma : dbeta)[c] += a;
+    }
 }
 
 }  // namespace nomad

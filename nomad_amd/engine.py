@@ -629,9 +629,14 @@ class Engine:
         _lib.check(self.lib.nomad_train_set_branches(self.ctx, len(layer_masks), arr), "nomad_train_set_branches")
 
     def train_set_frozen(self, freeze_encoder: bool):
-        """``freeze_all: True`` of the reference's config: no parameter gradients for the encoder (the extractor is
-        always frozen); post_extract_proj, the feature LayerNorm and the head keep training."""
+        """``freeze_all: True`` of the reference's config: no parameter gradients for the encoder (nor the extractor);
+        post_extract_proj, the feature LayerNorm and the head keep training."""
         _lib.check(self.lib.nomad_train_set_frozen(self.ctx, int(bool(freeze_encoder))), "nomad_train_set_frozen")
+
+    def train_set_convnet(self, trainable: bool):
+        """``freeze_convnet: False`` of the reference's config: the conv feature extractor's weights and GroupNorm get
+        gradients too (scaled by ``feature_grad_mult``, like everything that enters the extractor)."""
+        _lib.check(self.lib.nomad_train_set_convnet(self.ctx, int(bool(trainable))), "nomad_train_set_convnet")
 
     def train_set_step(self, step: int):
         _lib.check(self.lib.nomad_train_set_step(self.ctx, int(step)), "nomad_train_set_step")
@@ -643,12 +648,16 @@ class Engine:
         host = flat.detach().cpu()
         return {k: host[o:o + n].reshape(shapes[k]).clone() for k, o, n in self.train_segments()}
 
-    def train_flatten(self, tensors: Dict[str, torch.Tensor]) -> torch.Tensor:
-        """{checkpoint key: tensor} (every trainable key) -> flat device vector."""
+    def train_flatten(self, tensors: Dict[str, torch.Tensor], fill: Optional[float] = None) -> torch.Tensor:
+        """{checkpoint key: tensor} -> flat device vector.  A key that is missing raises, unless ``fill`` gives the value
+        its slice gets (e.g. 0.0 for gradient dicts that leave out frozen parameters)."""
         total, _ = self.train_param_count()
         host = torch.empty(total, dtype=torch.float32)
         for k, o, n in self.train_segments():
-            host[o:o + n] = tensors[k].detach().reshape(-1).to(torch.float32)
+            if k not in tensors and fill is not None:
+                host[o:o + n] = fill
+            else:
+                host[o:o + n] = tensors[k].detach().reshape(-1).to(torch.float32)
         return host.to(self.device)
 
     def train_state_dict(self) -> Dict[str, torch.Tensor]:

@@ -12,8 +12,9 @@ libnomad_hip.so (nomad_embed_train / nomad_triplet_loss / nomad_train_backward /
 is data loading, the epoch loop, the learning-rate schedule and checkpoint writing.
 
 Differences, on purpose:
-* ``freeze_convnet: True`` (the shipped config) is the supported mode: the conv feature extractor is frozen and no
-  gradient is computed for it.  ``freeze_convnet: False`` and ``freeze_all: True`` raise.
+* none in the freeze switches: ``freeze_convnet: True`` (the shipped config; backbone at 1e-5, head at ``lr``),
+  ``freeze_convnet: False`` (the conv feature extractor trains too, and - as in train_triplet.py:96 - ONE Adam group at
+  ``lr`` for every parameter) and ``freeze_all: True`` are all supported.
 * ``checkpoint_path`` may be a NOMAD-layout state dict (keys of nomad_best_model.pt), a fairseq ``wav2vec_small.pt``
   ({'model': state_dict}; the head is then initialised like ``nn.Linear`` under ``torch.manual_seed(0)``), or the word
   ``seeded`` (random weights, for tests).  fairseq itself is not needed.
@@ -144,15 +145,16 @@ class Training:
         torch.manual_seed(SEED)
         if self.config.get("eval_w2v"):
             raise NotImplementedError("eval_w2v (raw wav2vec features) is outside the NOMAD hot path")
-        if self.config["experiment_name"] == "Training":
-            if not self.config.get("freeze_convnet", True):
-                raise NotImplementedError("freeze_convnet: False - the conv feature extractor is frozen in this build "
-                                          "(the reference's shipped config, src/config/train_triplet.yaml)")
         self.engine = engine if engine is not None else Engine(load_pretrained(self.config["checkpoint_path"]), device)
         self.engine.train_enable()
         # freeze_all (train_triplet.py:76-79): feature extractor and encoder frozen; what is left trainable is
         # post_extract_proj, the feature LayerNorm and the embedding layer
-        self.engine.train_set_frozen(bool(self.config["experiment_name"] == "Training" and self.config.get("freeze_all")))
+        training = self.config["experiment_name"] == "Training"
+        self.engine.train_set_frozen(bool(training and self.config.get("freeze_all")))
+        # freeze_convnet: False (train_triplet.py:71-73): the conv feature extractor gets gradients too (unless freeze_all
+        # froze it again, :76-78)
+        self.train_convnet = bool(training and not self.config.get("freeze_convnet", True) and not self.config.get("freeze_all"))
+        self.engine.train_set_convnet(self.train_convnet)
         self.reg = dict(W2V_BASE_REGULARISATION)
         self.reg.update(regularisation or {})
         self._rng = np.random.RandomState(SEED)  # LayerDrop draws + per-call dropout seeds
@@ -176,8 +178,11 @@ class Training:
                 self.valid_set, batch_size=self.config["val_bs"], shuffle=False, num_workers=self.config["num_workers"],
                 collate_fn=self.valid_set.collate_fn, pin_memory=True)
             self.margin = float(self.config["margin"])
-            # train_triplet.py:98-107: Adam, pretrained parameters at 1e-5, embedding_layer at `lr`
-            self.lr_scheduler = ExponentialLR([1e-5, float(self.config["lr"])], float(self.config["lr_decay_factor"]))
+            # train_triplet.py:96-107: Adam; with freeze_convnet the pretrained parameters at 1e-5 and embedding_layer at
+            # `lr`, otherwise the optimiser is not overwritten and every parameter runs at `lr`
+            lr = float(self.config["lr"])
+            body_lr = 1e-5 if self.config.get("freeze_convnet", True) else lr
+            self.lr_scheduler = ExponentialLR([body_lr, lr], float(self.config["lr_decay_factor"]))
 
     # ---- one optimisation step (train_triplet.py:117-131) ---------------------------------------------
     def _draw(self) -> dict:

@@ -197,11 +197,13 @@ def head(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return F.normalize(e, dim=1)
 
 
-def triplet_forward(sd: Dict[str, torch.Tensor], wav: torch.Tensor, stoch: Optional["Stochastic"] = None) -> torch.Tensor:
-    """``TripletModel.forward`` (nomad.py:224-231): wav (B,1,N) or (B,N) -> (B,256) unit-norm."""
+def triplet_forward(sd: Dict[str, torch.Tensor], wav: torch.Tensor, stoch: Optional["Stochastic"] = None,
+                    feature_grad_mult: float = 1.0) -> torch.Tensor:
+    """``TripletModel.forward`` (nomad.py:224-231): wav (B,1,N) or (B,N) -> (B,256) unit-norm.
+    feature_grad_mult: see ``backbone`` (only matters for gradients that enter the conv feature extractor)."""
     if wav.dim() == 3:
         wav = wav.squeeze(1)
-    x, _ = backbone(sd, wav, stoch=stoch)
+    x, _ = backbone(sd, wav, stoch=stoch, feature_grad_mult=feature_grad_mult)
     return head(x, sd["embedding_layer.1.weight"], sd["embedding_layer.1.bias"])
 
 
@@ -281,10 +283,11 @@ def load_processing(path: str) -> torch.Tensor:
 # these lines (nn.TripletMarginLoss, loss.backward(), torch.optim.Adam); the backbone underneath is the restatement
 # above, with its pinning status.
 
-def trainable_keys(sd: Dict[str, torch.Tensor]) -> List[str]:
-    """Parameters train_triplet.py leaves trainable with freeze_convnet: True (src/config/train_triplet.yaml):
-    everything outside ``ssl_model.feature_extractor``.  ``mask_emb`` gets no gradient with mask=False."""
-    return [k for k in sd if "feature_extractor" not in k and not k.endswith("mask_emb")]
+def trainable_keys(sd: Dict[str, torch.Tensor], freeze_convnet: bool = True) -> List[str]:
+    """Parameters train_triplet.py leaves trainable: with freeze_convnet: True (src/config/train_triplet.yaml)
+    everything outside ``ssl_model.feature_extractor``, with False (train_triplet.py:71-73) those too.
+    ``mask_emb`` gets no gradient with mask=False."""
+    return [k for k in sd if (not freeze_convnet or "feature_extractor" not in k) and not k.endswith("mask_emb")]
 
 
 class Stochastic:
@@ -328,17 +331,21 @@ class Stochastic:
 
 
 def triplet_step_grads(sd: Dict[str, torch.Tensor], A: torch.Tensor, Pw: torch.Tensor, N: torch.Tensor,
-                       margin: float, stoch: Optional[Sequence[Optional[Stochastic]]] = None
+                       margin: float, stoch: Optional[Sequence[Optional[Stochastic]]] = None,
+                       freeze_convnet: bool = True, feature_grad_mult: float = 0.1
                        ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
     """One A/P/N forward + nn.TripletMarginLoss(margin) + backward (train_triplet.py:121-128).
     stoch: None = eval-mode arithmetic, or one Stochastic per branch (A, P, N).
+    freeze_convnet=False (train_triplet.py:71-73): the conv feature extractor's parameters are differentiated too, and
+    their gradients carry fairseq's ``feature_grad_mult`` (0.1 in wav2vec_small.pt's config).
     -> (loss, {key: d loss / d parameter})."""
     st = list(stoch) if stoch is not None else [None, None, None]
     sd = {k: v.clone() for k, v in sd.items()}
-    keys = trainable_keys(sd)
+    keys = trainable_keys(sd, freeze_convnet)
     for k in keys:
         sd[k].requires_grad_(True)
-    ea, ep, en = triplet_forward(sd, A, st[0]), triplet_forward(sd, Pw, st[1]), triplet_forward(sd, N, st[2])
+    fgm = 1.0 if freeze_convnet else feature_grad_mult
+    ea, ep, en = (triplet_forward(sd, A, st[0], fgm), triplet_forward(sd, Pw, st[1], fgm), triplet_forward(sd, N, st[2], fgm))
     loss = torch.nn.TripletMarginLoss(margin=margin)(ea, ep, en)
     grads = torch.autograd.grad(loss, [sd[k] for k in keys])
     return loss.detach(), dict(zip(keys, grads))

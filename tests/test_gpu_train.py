@@ -49,7 +49,7 @@ def test_segment_table_covers_trainable_keys(teng, sd_train):
     shapes = expected_shapes()
     segs = teng.train_segments()
     total, head = teng.train_param_count()
-    assert sorted(k for k, _, _ in segs) == sorted(O.trainable_keys(sd_train))
+    assert sorted(k for k, _, _ in segs) == sorted(O.trainable_keys(sd_train, freeze_convnet=False))   # every parameter the reference can train
     spans = sorted((o, n) for _, o, n in segs)
     assert spans[0][0] == 0 and all(a[0] + a[1] == b[0] for a, b in zip(spans, spans[1:]))
     assert spans[-1][0] + spans[-1][1] == total
@@ -94,7 +94,11 @@ def test_parameter_gradients_match_autograd(teng, sd_train, B, n, margin):
             worst = (k, err)
     assert worst[1] < 1.0, worst
     # global direction: cosine over the whole parameter vector
-    w = torch.cat([ref[k].reshape(-1) for k, _, _ in teng.train_segments()]).double()
+    # freeze_convnet: True (the default): the conv feature extractor's slices of the gradient vector stay exactly zero
+    for k, v in got.items():
+        if k not in ref:
+            assert "feature_extractor" in k and torch.count_nonzero(v).item() == 0, k
+    w = torch.cat([(ref[k] if k in ref else torch.zeros(n)).reshape(-1) for k, _, n in teng.train_segments()]).double()
     gflat = flat.cpu().double()
     cos = (w @ gflat / (w.norm() * gflat.norm())).item()
     assert cos > 0.999999, cos
@@ -132,7 +136,7 @@ def test_adam_matches_torch_and_weights_follow(built_lib, sd_train):
             for k, p in params.items():
                 p.grad = grads[k].clone()
             opt.step()
-            eng.train_write(1, eng.train_flatten(grads))
+            eng.train_write(1, eng.train_flatten(grads, fill=0.0))     # frozen conv feature extractor: zero gradient
             eng.adam_step(lr_body, lr)
         got = eng.train_unflatten(eng.train_read(0))
         for k, p in params.items():
@@ -449,6 +453,109 @@ def test_train_step_with_branches_of_different_lengths(built_lib, sd_train):
             assert (got[k] - want).abs().max().item() < 2e-4 * want.abs().max().item() + 1e-6 * top, k
     finally:
         eng.close()
+
+
+# ---- freeze_convnet: False (train_triplet.py:71-73): the conv feature extractor trains too --------------------------------
+@pytest.mark.parametrize("B,n,fgm", [(2, 8000, 0.1), (3, 5000, 1.0), (2, 33000, 0.1)])   # last: L_1 = 3299 > 6 column blocks of 512
+def test_convnet_gradients_match_autograd(teng, sd_train, B, n, fgm):
+    """Every parameter gradient with the conv feature extractor trainable - conv1..6 weights (dW as split-K GEMMs over
+    transposed im2col operands), conv0 weight and the GroupNorm affine - against the oracle's autograd, including
+    fairseq's feature_grad_mult on everything that enters the extractor; the other gradients must not change."""
+    A, P, N = _triplet_batch(B, n, seed=B + 40)
+    ref_loss, ref = O.triplet_step_grads(sd_train, A, P, N, 1.0, freeze_convnet=False, feature_grad_mult=fgm)
+    assert ref_loss.item() > 0
+    _, flat_frozen = _gpu_step_grads(teng, A, P, N, 1.0)
+    old = teng.feature_grad_mult
+    teng.train_set_convnet(True)
+    teng.feature_grad_mult = fgm
+    try:
+        loss, flat = _gpu_step_grads(teng, A, P, N, 1.0)
+        _, flat2 = _gpu_step_grads(teng, A, P, N, 1.0)
+    finally:
+        teng.train_set_convnet(False)
+        teng.feature_grad_mult = old
+    assert torch.equal(flat, flat2)                                  # deterministic
+    assert abs(loss.item() - ref_loss.item()) < 2e-5
+    got, frozen = teng.train_unflatten(flat), teng.train_unflatten(flat_frozen)
+    top = max(v.abs().max().item() for k, v in ref.items() if "feature_extractor" in k)
+    worst = ("", 0.0)
+    for k, want in ref.items():
+        if "feature_extractor" in k:
+            assert want.abs().max().item() > 0, k
+            err = (got[k] - want).abs().max().item() / (5e-5 * want.abs().max().item() + 1e-6 * top)   # measured: 1e-5
+            if err > worst[1]:
+                worst = (k, err)
+        else:
+            assert torch.equal(got[k], frozen[k]), k                  # same kernels, same order as with the extractor frozen
+    print(f"conv feature extractor gradients B={B} n={n} fgm={fgm}: worst {worst[0]} at {worst[1]:.2f} of its bound")
+    assert worst[1] < 1.0, worst
+
+
+def test_convnet_weights_follow_the_master_copy(built_lib, sd_train):
+    """An Adam step with the extractor trainable moves the conv weights, and the forward / dX kernels' derived copies
+    follow: the embedding afterwards equals the oracle's on the updated state dict."""
+    from nomad_amd.engine import Engine
+    eng = Engine({k: v.clone() for k, v in sd_train.items()}, 0)
+    try:
+        eng.train_enable()
+        eng.train_set_convnet(True)
+        A, P, N = _triplet_batch(2, 8000, seed=8)
+        _gpu_step_grads(eng, A, P, N, 1.0)
+        eng.adam_step(1e-3, 1e-3)
+        new_sd = eng.train_state_dict()
+        moved = [k for k in new_sd if "feature_extractor" in k and not torch.equal(new_sd[k], sd_train[k])]
+        assert len(moved) == 9, moved                                  # 7 conv weights + GroupNorm weight and bias
+        with torch.no_grad():
+            want = O.triplet_forward(new_sd, A)
+        got = eng.embed(A.cuda()).cpu()
+        assert (got - want).abs().max().item() < 2e-5
+        assert (eng.embed_bf16x3(A.cuda()).cpu() - want).abs().max().item() < 2e-5     # the split copies were rebuilt too
+        # the dX chain's transposed conv weights: gradient w.r.t. the waveform through the updated extractor
+        g32 = _wav_grad(eng, A)
+        ref = _wav_grad_oracle(new_sd, A, eng.feature_grad_mult)
+        assert (g32 - ref).abs().max().item() < 2e-3 * ref.abs().max().item()
+    finally:
+        eng.close()
+
+
+def _wav_grad(eng, wav):
+    """d sum(emb * fixed) / d wav through nomad_embed_train + nomad_embed_backward."""
+    g = torch.Generator().manual_seed(1)
+    d = torch.randn(wav.shape[0], 256, generator=g).cuda()
+    emb, layers, saved = eng.embed_train(wav.cuda())
+    return eng.embed_backward(wav.cuda(), layers, saved, None, d).cpu()
+
+
+def _wav_grad_oracle(sd, wav, fgm):
+    g = torch.Generator().manual_seed(1)
+    d = torch.randn(wav.shape[0], 256, generator=g)
+    w = wav.clone().requires_grad_(True)
+    emb = O.triplet_forward(sd, w, None, fgm)
+    (emb * d).sum().backward()
+    return w.grad
+
+
+def test_freeze_convnet_false_through_the_training_class(tmp_path):
+    """Training(config with freeze_convnet: False).train_step: the extractor's tensors change too, and - as in the
+    reference, which does not overwrite its optimiser then (train_triplet.py:96-107) - every parameter runs at `lr`."""
+    from nomad_amd.train import Training
+    csv = _toy_dataset(tmp_path)
+    tr = Training(_config(tmp_path, csv, freeze_convnet=False), regularisation=dict(dropout=0.0, attention_dropout=0.0,
+                                                                                   dropout_input=0.0, encoder_layerdrop=0.0))
+    try:
+        assert tr.train_convnet and tr.lr_scheduler.get_last_lr() == [1e-4, 1e-4]
+        before = tr.engine.train_state_dict()
+        A, P, N = next(iter(tr.valid_loader))
+        assert tr.train_step(A, P, N).item() > 0
+        after = tr.engine.train_state_dict()
+        changed = {k for k in before if not torch.equal(before[k], after[k])}
+        assert {k for k in before if "feature_extractor" in k} <= changed
+        assert "ssl_model.encoder.layers.0.fc1.weight" in changed and "embedding_layer.1.weight" in changed
+        k = "ssl_model.feature_extractor.conv_layers.3.0.weight"       # first Adam step: |update| ~ lr wherever g != 0
+        upd = (after[k] - before[k]).abs()
+        assert 0.5e-4 < upd.max().item() < 1.5e-4
+    finally:
+        tr.engine.close()
 
 
 # ---- freeze_all: True (train_triplet.py:76-79) ------------------------------------------------------------------------

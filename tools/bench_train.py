@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--eval-mode", action="store_true", help="no dropout / LayerDrop")
     ap.add_argument("--separate", action="store_true", help="three separate forward/backward calls (no merged batch)")
+    ap.add_argument("--train-convnet", action="store_true", help="freeze_convnet: False - the conv feature extractor trains too")
     ap.add_argument("--out", type=str, default="")
     args = ap.parse_args()
     from nomad_amd.train import Training
@@ -30,6 +31,7 @@ def main():
     from nomad_amd.train import ExponentialLR
     tr.margin, tr.lr_scheduler = 0.2, ExponentialLR([1e-5, 1e-4], 0.99)
     eng = tr.engine
+    eng.train_set_convnet(args.train_convnet)
     for _ in range(args.warmup):
         loss = tr.train_step(A, P, N)
     torch.cuda.synchronize()
@@ -46,6 +48,7 @@ def main():
     fwd_flop = 3 * args.bs * (56.925e9 * T / 199.0)  # ~linear in T except the T^2 attention term (small)
     res = {"workload": f"triplet step 3x({args.bs},1,{n}) T={T}", "mode": "eval-arith" if args.eval_mode else "train (dropout+layerdrop)",
            "branches": "separate calls" if args.separate else "merged 3B batch",
+           "conv_feature_extractor": "trainable" if args.train_convnet else "frozen",
            "ms_per_step": dt * 1e3, "triplets_per_s": args.bs / dt, "loss": loss.item(),
            "approx_model_tflops": 3 * fwd_flop / dt / 1e12,
            "classes_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
