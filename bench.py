@@ -272,7 +272,7 @@ def main():
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if args.dtype == "f32" and n_samples == 64000 and B == 256 and os.path.isfile(tfile):
             # HBM-side bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
-            # command (tools/gpu_round3.sh + tools/pmc_traffic.py); fabric-side counters, Infinity-Cache hits included
+            # command (tools/gpu_pmc_traffic.sh + tools/pmc_traffic.py); fabric-side counters, Infinity-Cache hits included
             traffic_tab = json.load(open(tfile))
         if prof:
             def rate(cls):
@@ -296,7 +296,7 @@ def main():
                                "achieved": round(ach, 2), "peak": round(peak / 1e12, 1), "unit": "TFLOP/s",
                                "frac": round(ach * 1e12 / peak, 4), "traffic": traffic,
                                "traffic_source": ("profiles/pmc_traffic.json (STATIC: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                                  "passes of this command taken earlier by tools/gpu_round3.sh, not measured "
+                                                  "passes of this command taken earlier (round 2) by tools/gpu_pmc_traffic.sh, not measured "
                                                   "in this run)" if traffic is not None else None),
                                "algorithmic_bytes_per_launch": alg_bytes,
                                "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4),

@@ -64,7 +64,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 alg, nl = algorithmic_gemm_bytes()
 out = {
     "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py "
-              "--steps 1 --warmup 1 --no-cpu-baseline --no-profile; MI355X (tools/gpu_round3.sh)",
+              "--steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-also; MI355X (tools/gpu_pmc_traffic.sh)",
     "units": "bytes per launch.  The counters sit on the fabric side of L2 and count Infinity-Cache hits: an upper "
              "bound on HBM bytes.",
     "calibration": "gfx950 FETCH_SIZE halves wide coalesced streaming reads (MI355X_MICROARCH.md, HBM): confirmed on "
@@ -94,7 +94,9 @@ for key, pats in (("gemm_256x128", ("<256, 128,",)), ("gemm_128x64", ("<128, 64,
     b = sum(v["launches"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) for v in sel)
     out[key] = {"launches": n, "hbm_bytes_per_launch": b / max(n, 1),
                 "algorithmic_bytes_per_launch": algorithmic_by_kernel()[0 if key == "gemm_256x128" else 1]}
-for dst in (os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json"), os.path.join(ROOT, "profiles", "pmc_traffic.json")):
+# also next to the passes: gpurun_out/ is what travels back from the GPU box, profiles/ on the box does not
+for dst in (os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json"), os.path.join(ROOT, "profiles", "pmc_traffic.json"),
+            os.path.join(src, "pmc_traffic_summary.json")):
     json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps(out["gemm_all_launches"]))
 for k, v in out["kernels"].items():
