@@ -141,10 +141,16 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p, const f32x4 (&a
 //   accumulators: a.w = (ah + al)(wh + wl) minus the al*wl term (2^-16 relative), i.e. the plain kernel run on
 //   operands concatenated along K, with no other change to the schedule.  X3 = 1 stores the result split
 //   (p.c_plane), X3 = 2 stores fp32.
+// timing probe ABL 7 (tools/gemm_timeline.py): per workgroup {entry, main loop start, main loop end, stores done} in 100 MHz
+// wall-clock ticks + HW_ID + XCC_ID
+constexpr int kTimelineSlots = 4096;
+__device__ unsigned long long g_timeline[kTimelineSlots * 6];
+
 template <int ABL = 0, bool BUFLD = false, int X3 = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams p) {
     using Cfg = P8Cfg;
     extern __shared__ __attribute__((aligned(16))) char smem8[];
+    const unsigned long long t_entry_ = ABL == 7 ? wall_clock64() : 0ull;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -248,6 +254,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    unsigned long long ts_[4] = {0, 0, 0, 0};
+    if (ABL == 7) {
+        ts_[0] = t_entry_;
+        ts_[1] = wall_clock64();
+    }
     if (wr == 1) __builtin_amdgcn_s_barrier();  // second wave row runs one barrier behind (ping-pong)
 
     // fragment addresses: this lane's row fr of a 16-row tile, chunk (4 kh + fq) ^ swizzle
@@ -328,7 +339,19 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
 #undef NOMAD_P8_DMA_A
 #undef NOMAD_P8_DMA_B
 
+    if (ABL == 7) ts_[2] = wall_clock64();
     p8_epilogue<ABL == 1, X3>(p, acc, smem8, grp, m0, n0, wave, wr, wc, lane, fr, fq);
+    if (ABL == 7) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the output stores have left the CU
+        ts_[3] = wall_clock64();
+        if (tid == 0 && blockIdx.x < kTimelineSlots) {
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned long long* o = g_timeline + (size_t)blockIdx.x * 6;
+            o[0] = ts_[0]; o[1] = ts_[1]; o[2] = ts_[2]; o[3] = ts_[3]; o[4] = hw; o[5] = xcc;
+        }
+    }
 }
 
 template <int ABL = 0, bool BUFLD = false, int X3 = 0>

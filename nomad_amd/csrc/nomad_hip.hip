@@ -1339,6 +1339,10 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
             if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16x3 gemm: N %% 256, K %% 128");
             e = tile == 20 ? launch_gemm_bf16_8phase<0, false, 1>(p, groups, s) : launch_gemm_bf16_8phase<0, false, 2>(p, groups, s);
             break;
+        case 36:  // timing probe: per-workgroup timeline (nomad_diag_timeline, tools/gemm_timeline.py)
+            if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
+            e = launch_gemm_bf16_8phase<7>(p, groups, s);
+            break;
         case 22: e = launch_gemm_bf16_8phase<3, false, 2>(p, groups, s); break;  // bf16x3 timing probes, fp32 output
         case 23: e = launch_gemm_bf16_8phase<4, false, 2>(p, groups, s); break;
         case 24: e = launch_gemm_bf16_8phase<5, false, 2>(p, groups, s); break;
@@ -2195,11 +2199,21 @@ int nomad_embed_ragged_bf16(nomad_ctx* c, const float* wav, int B, int stride, c
     return forward_ragged_bf16(c, wav, B, stride, lengths_host, emb, workspace, workspace_bytes, stream);
 }
 
+#ifdef NOMAD_DIAG
+// timeline of the last tile-36 GEMM: out_host[6 * n] = per workgroup {entry, loop start, loop end, stores done, HW_ID, XCC_ID}
+int nomad_diag_timeline(unsigned long long* out_host, int n) {
+    if (!out_host || n <= 0 || n > kTimelineSlots) return fail(NOMAD_ERR_INVALID, "nomad_diag_timeline: bad argument");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_timeline), sizeof(unsigned long long) * 6 * (size_t)n));
+    return 0;
+}
+#endif
+
 int nomad_diag_gemm_bf16(nomad_ctx* c, const void* A, const void* W, const float* bias, const void* R, void* C, int M,
                          int N, int K, int gelu, int tile, nomad_stream_t stream) {
     static const int kBN[] = {128, 128, 64, 256, 64, 128, 128, 128, 128, 256, 256, 128, 128, 128, 128, 256, 256, 256, 256, 256};
-    if (!c || !A || !W || !C || M <= 0 || tile < 0 || tile >= static_cast<int>(sizeof(kBN) / sizeof(kBN[0]))) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: bad argument");
-    if (N % kBN[tile] || K % 64) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: N %% %d or K %% 64 != 0", kBN[tile]);
+    if (!c || !A || !W || !C || M <= 0 || tile < 0 || (tile != 36 && tile >= static_cast<int>(sizeof(kBN) / sizeof(kBN[0])))) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: bad argument");
+    if (N % (tile == 36 ? 256 : kBN[tile]) || K % 64) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: N %% %d or K %% 64 != 0", kBN[tile]);
     GemmParams p = dense(static_cast<const float*>(A), K, static_cast<const float*>(W), bias, static_cast<const float*>(R),
                          static_cast<float*>(C), M, N, K, gelu);
     return run_gemm_bf16(c, p, 1, static_cast<hipStream_t>(stream), tile);

@@ -53,6 +53,12 @@ SHAPES = {  # name: (M, N, K, bias, gelu, residual)
     "c5_qkv": (47968, 2304, 768, True, False, False),
     "c5_fc1": (47968, 3072, 768, True, True, False),
     "c5_fc2": (47968, 768, 3072, True, False, True),
+    "one_tile": (256, 256, 128, True, False, False),        # a lone workgroup / one workgroup per XCD / one full round
+    "eight_tiles": (256, 2048, 128, True, False, False),
+    "one_round": (7168, 2304, 128, True, False, False),
+    "c5_k128": (47968, 2304, 128, True, False, False),      # per-tile constants: the same tiles with 2 / 4 / 8 K tiles only
+    "c5_k256": (47968, 2304, 256, True, False, False),
+    "c5_k512": (47968, 2304, 512, True, False, False),
     "c5_conv2": (1535968, 512, 1536, False, True, False),
     "c5_conv4": (383968, 512, 1536, False, True, False),
     # large squares, for comparison with the guide's numbers for the 256x256 8-phase template (1320-1470 TFLOP/s)
@@ -98,9 +104,9 @@ def main():
                  7: "bf16 128x128 ABL no-epilogue", 8: "bf16 128x128 ABL one-k-tile",
                  9: "bf16 256x256 w2x4 bk32 4st", 10: "bf16 256x256 w4x2 bk32 4st", 11: "bf16 128x128 w4x2 bk32 4st",
                  12: "bf16 128x128 w4x2 bk64 3st", 13: "bf16 256x128 w4x2 bk64 3st", 14: "bf16 256x128 w4x2 bk32 4st",
-                 15: "bf16 256x256 w2x4 bk64 2st", 16: "bf16 256x256 8-phase", 17: "bf16 256x256 8-phase ABL no-epilogue", 18: "bf16 256x256 8-phase buffer_load..lds", 19: "bf16 256x256 8-phase no setprio"}
+                 15: "bf16 256x256 w2x4 bk64 2st", 16: "bf16 256x256 8-phase", 17: "bf16 256x256 8-phase ABL no-epilogue", 18: "bf16 256x256 8-phase buffer_load..lds", 19: "bf16 256x256 8-phase no setprio", 36: "bf16 256x256 8-phase, timeline probe build"}
         bn = {0: 128, 1: 128, 2: 64, 3: 256, 4: 64, 5: 128, 6: 128, 7: 128, 8: 128, 9: 256, 10: 256, 11: 128, 12: 128,
-              13: 128, 14: 128, 15: 256, 16: 256, 17: 256, 18: 256, 19: 256}
+              13: 128, 14: 128, 15: 256, 16: 256, 17: 256, 18: 256, 19: 256, 36: 256}
         for sname in a.shapes.split(","):
             M, N, K, has_b, gelu, has_r = SHAPES[sname]
             A = torch.randn(M, K, generator=g).bfloat16().cuda()
@@ -109,7 +115,7 @@ def main():
             R = torch.randn(M, N, generator=g).bfloat16().cuda() if has_r else None
             first = None
             for t in (int(x) for x in a.tiles.split(",")):
-                if N % bn[t] or (t in (16, 17, 18, 19) and K % 128):
+                if N % bn[t] or (t in (16, 17, 18, 19, 36) and K % 128):
                     continue
                 out = eng.diag_gemm_bf16(A, W, b, R, gelu=gelu, tile=t).float()
                 if first is None:
