@@ -61,7 +61,7 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256) void k(float* out, int iters
             __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)(d * NT + tid) * 16), (lptr_t)(lds + stage * kStage + (d * NT + wave * 64) * 16), 16, 0, 0);
     };
     if (FLAGS & 2) dma(1);
-    rd(0, 0, 0);
+    if (!(FLAGS & 4)) rd(0, 0, 0);
     for (int it = 0; it < iters; ++it) {
         const int stage = it & 1;
         if (FLAGS & 2) {
@@ -69,12 +69,15 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256) void k(float* out, int iters
         }
         if (FLAGS & 1) __builtin_amdgcn_s_barrier();
         if (FLAGS & 2) dma(stage ^ 1);  // refill the stage consumed in the previous K tile
+        if (FLAGS & 4) rd(0, stage, 0);   // legal order: a K tile's first fragments only after its wait + barrier
 #pragma unroll
         for (int sub = 0; sub < SUB; ++sub) {
             if (sub + 1 < SUB) rd((sub + 1) & 1, stage, sub + 1);
-            else rd((sub + 1) & 1, stage ^ 1, 0);   // first fragments of the next K tile (model: no wait for its DMA)
+            else if (!(FLAGS & 4)) rd((sub + 1) & 1, stage ^ 1, 0);   // first fragments of the next K tile (model: no wait for its DMA)
             asm volatile("" ::: "memory");
+            if (FLAGS & 8) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_setprio(1); }
             mm(sub & 1);
+            if (FLAGS & 8) { __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_s_barrier(); }
         }
     }
     float s = 0.f;
@@ -177,6 +180,8 @@ int main() {
     run<0, 0>("8 waves, 64x128 wave tile, 16x16x32: reads + MFMA", out, src);
     run<0, 1>("8 waves, 64x128: + barrier per K tile", out, src);
     run<0, 3>("8 waves, 64x128: + barrier + 64 KB LDS-DMA per K tile", out, src);
+    run<0, 7>("8 waves, 64x128: barrier + DMA, LEGAL order (fragments after the barrier)", out, src);
+    run<0, 15>("8 waves, 64x128: legal order + 2 more barriers and setprio per sub-step", out, src);
     run<1, 0>("4 waves, 128x128 wave tile, 32x32x16: reads + MFMA", out, src);
     run<1, 1>("4 waves, 128x128: + barrier per K tile", out, src);
     run<1, 3>("4 waves, 128x128: + barrier + 64 KB LDS-DMA per K tile", out, src);
