@@ -12,7 +12,7 @@
  *                                  backbone (fairseq Wav2Vec2Model, call sites nomad.py:226,245)
  *                                  + mean/ReLU/Linear/L2-normalise head
  *   nomad_pairwise                 scipy cdist + np.mean(axis=1) (nomad.py:108-111)
- *   nomad_wav_probe / _read_rows   torchaudio.load + channel mean of load_processing (nomad.py:196-200)
+ *   nomad_wav_probe / _read_rows   torchaudio.load + channel mean + Resample of load_processing (nomad.py:196-205)
  *   nomad_l1_loss                  NomadLoss.forward (nomad.py:267-282)
  *
  * Conventions: every function returns 0 on success or a negative nomad_status; nothing throws.
@@ -294,8 +294,7 @@ int nomad_embed_ragged_bf16x3(nomad_ctx* ctx, const float* wav_dev, int B, int s
  * Nomad.get_embeddings_csv (nomad.py:171-183) calls load_processing (nomad.py:192-212) per file:
  * torchaudio.load -> fp32 in [-1, 1), mean of the first two channels, resample to 16 kHz.  These two
  * entry points do the first two steps on plain host threads, straight into the rows of the (pinned)
- * staging buffer nomad_embed_ragged* reads after one H2D copy; a file at another sample rate is
- * reported by the probe and stays with the caller's resampler.
+ * staging buffer nomad_embed_ragged* reads after one H2D copy; nomad_wav_read_rows also resamples.
  * Decoded: PCM 8/16/24/32 (x 2^-(bits-1)), IEEE float 32/64, WAVE_FORMAT_EXTENSIBLE of those. */
 typedef struct nomad_wav_info {
     int sample_rate, channels, format_tag, bits;
@@ -305,11 +304,15 @@ typedef struct nomad_wav_info {
 /* Headers of n files on `threads` host threads.  status[i] = NOMAD_OK, NOMAD_ERR_IO or NOMAD_ERR_FORMAT per
  * file (info[i] zeroed then); the return value is NOMAD_OK unless the arguments are bad. */
 int nomad_wav_probe(const char* const* paths, int n, nomad_wav_info* info, int* status, int threads);
-/* Sample data of n probed files -> dst[row[i] * stride + 0 .. info[i].frames) as mono fp32 (row == NULL:
- * row[i] = i); the rest of a row is left untouched.  Needs info[i].frames <= stride.  status as above;
- * returns the first non-zero status (all files are attempted). */
+/* Frames a probed file has at target_rate: its own count, or ceil(frames * target / rate) after resampling. */
+int nomad_wav_frames_at(const nomad_wav_info* info, int target_rate, long long* frames);
+/* Sample data of n probed files -> dst[row[i] * stride + 0 .. frames_at(info[i], target_rate)) as mono fp32 at target_rate
+ * (row == NULL: row[i] = i); the rest of a row is left untouched.  A file at another rate is resampled like
+ * torchaudio.transforms.Resample(rate, target_rate) with its defaults (Hann-windowed sinc, lowpass_filter_width 6, rolloff
+ * 0.99; nomad.py:203-205).  Needs frames_at <= stride.  status as above; returns the first non-zero status (all files are
+ * attempted). */
 int nomad_wav_read_rows(const char* const* paths, const nomad_wav_info* info, int n, const int* row,
-                        float* dst_host, long long stride, int* status, int threads);
+                        float* dst_host, long long stride, int target_rate, int* status, int threads);
 
 /* ---- measurement ------------------------------------------------------------------------- */
 /* Kernel classes for the in-library HIP-event timers. */

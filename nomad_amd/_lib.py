@@ -44,8 +44,9 @@ SIGNATURES = {
                                      C.c_size_t, _fp]),
     "nomad_pairwise": (C.c_int, [C.c_void_p, _fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp]),
     "nomad_wav_probe": (C.c_int, [C.POINTER(C.c_char_p), C.c_int, C.POINTER(WavInfo), C.POINTER(C.c_int), C.c_int]),
+    "nomad_wav_frames_at": (C.c_int, [C.POINTER(WavInfo), C.c_int, C.POINTER(C.c_longlong)]),
     "nomad_wav_read_rows": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(WavInfo), C.c_int, C.POINTER(C.c_int), _fp, C.c_longlong,
-                                      C.POINTER(C.c_int), C.c_int]),
+                                      C.c_int, C.POINTER(C.c_int), C.c_int]),
     "nomad_l1_scratch_bytes": (C.c_size_t, []),
     "nomad_l1_loss": (C.c_int, [C.c_void_p, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp]),
     "nomad_enable_backward": (C.c_int, [C.c_void_p]),

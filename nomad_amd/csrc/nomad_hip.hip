@@ -677,18 +677,44 @@ int nomad_wav_probe(const char* const* paths, int n, nomad_wav_info* info, int* 
     return NOMAD_OK;
 }
 
+int nomad_wav_frames_at(const nomad_wav_info* info, int target_rate, long long* frames) {
+    if (!info || !frames || target_rate <= 0 || info->sample_rate <= 0)
+        return fail(NOMAD_ERR_INVALID, "nomad_wav_frames_at: bad argument");
+    *frames = wav::resampled_frames(info->frames, info->sample_rate, target_rate);
+    return NOMAD_OK;
+}
+
 int nomad_wav_read_rows(const char* const* paths, const nomad_wav_info* info, int n, const int* row, float* dst_host,
-                        long long stride, int* status, int threads) {
-    if (n < 0 || (n > 0 && (!paths || !info || !dst_host || !status)) || stride < 0)
+                        long long stride, int target_rate, int* status, int threads) {
+    if (n < 0 || (n > 0 && (!paths || !info || !dst_host || !status)) || stride < 0 || target_rate <= 0)
         return fail(NOMAD_ERR_INVALID, "nomad_wav_read_rows: bad argument");
     for (int i = 0; i < n; ++i)
-        if (!paths[i] || info[i].frames > stride || (row && row[i] < 0))
-            return fail(NOMAD_ERR_INVALID, "nomad_wav_read_rows: file %d: %lld frames do not fit a row of %lld", i, info[i].frames, stride);
+        if (!paths[i] || info[i].sample_rate <= 0 || wav::resampled_frames(info[i].frames, info[i].sample_rate, target_rate) > stride ||
+            (row && row[i] < 0))
+            return fail(NOMAD_ERR_INVALID, "nomad_wav_read_rows: file %d: %lld frames at %d Hz do not fit a row of %lld", i, info[i].frames,
+                        info[i].sample_rate, stride);
     try {
         const int nt = std::max(1, std::min(threads, n));
         std::vector<std::vector<unsigned char>> raw((size_t)nt);
+        std::vector<std::vector<float>> mono((size_t)nt);      // a file at another rate is decoded here first
+        std::vector<wav::ResampleKernel> kern((size_t)nt);     // per-thread cache of the last kernel built
+        std::vector<int> kern_rate((size_t)nt, 0);
         wav::parallel_for(n, nt, [&](int i, int t) {
-            status[i] = wav::read_one(paths[i], info[i], dst_host + (size_t)(row ? row[i] : i) * (size_t)stride, raw[(size_t)t]);
+            float* dst = dst_host + (size_t)(row ? row[i] : i) * (size_t)stride;
+            if (info[i].sample_rate == target_rate) {
+                status[i] = wav::read_one(paths[i], info[i], dst, raw[(size_t)t]);
+                return;
+            }
+            std::vector<float>& m = mono[(size_t)t];
+            if ((long long)m.size() < info[i].frames) m.resize((size_t)info[i].frames);
+            status[i] = wav::read_one(paths[i], info[i], m.data(), raw[(size_t)t]);
+            if (status[i] != NOMAD_OK) return;
+            if (kern_rate[(size_t)t] != info[i].sample_rate) {
+                kern[(size_t)t] = wav::make_resample_kernel(info[i].sample_rate, target_rate);
+                kern_rate[(size_t)t] = info[i].sample_rate;
+            }
+            wav::resample_into(m.data(), info[i].frames, kern[(size_t)t], dst,
+                               wav::resampled_frames(info[i].frames, info[i].sample_rate, target_rate));
         });
     } catch (const std::exception& e) {
         return fail(NOMAD_ERR_IO, "nomad_wav_read_rows: %s", e.what());

@@ -3,8 +3,9 @@
 // torchaudio.load -> fp32 in [-1, 1), first two channels averaged, 16 kHz.  The reference decodes one file per
 // iteration on the Python thread; here headers are probed and sample data is converted on plain host threads (no GIL),
 // straight into the rows of the pinned staging buffer that nomad_embed_ragged* reads after ONE H2D copy.
-// Resampling is not done here: a file that is not at the target rate is reported by the probe and stays on the
-// caller's path (nomad_amd/wavio.py).  Values are bit-identical to wavio.read_wav + the two-channel mean.
+// A file at another rate is resampled here too (torchaudio.transforms.Resample defaults: Hann-windowed sinc, width 6,
+// rolloff 0.99, nomad.py:203-205).  Decoded values are bit-identical to wavio.read_wav + the two-channel mean; resampled
+// values agree with wavio.resample to fp32 summation order (~1e-7).
 #pragma once
 
 #include <fcntl.h>
@@ -12,8 +13,10 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <numeric>
 #include <thread>
 #include <vector>
 
@@ -142,6 +145,60 @@ inline int read_one(const char* path, const nomad_wav_info& wi, float* dst, std:
     }
     close(fd);
     return rc;
+}
+
+// torchaudio's sinc_interp_hann resampling kernel (functional._get_sinc_resample_kernel, lowpass_filter_width 6,
+// rolloff 0.99) for orig -> target Hz: `phases` rows of `taps` fp32 coefficients, built in double.
+struct ResampleKernel {
+    int orig = 1, phases = 1, width = 0, taps = 0;  // reduced rates orig : phases; taps = 2 width + orig
+    std::vector<float> k;                           // [phases][taps]
+};
+
+inline ResampleKernel make_resample_kernel(int orig_hz, int new_hz) {
+    ResampleKernel r;
+    const int g = std::gcd(orig_hz, new_hz);
+    r.orig = orig_hz / g;
+    r.phases = new_hz / g;
+    const double lowpass = 6.0, rolloff = 0.99, pi = 3.14159265358979323846;
+    const double base = (double)(r.orig < r.phases ? r.orig : r.phases) * rolloff;
+    r.width = (int)std::ceil(lowpass * r.orig / base);
+    r.taps = 2 * r.width + r.orig;
+    r.k.resize((size_t)r.phases * r.taps);
+    const double scale = base / r.orig;
+    for (int i = 0; i < r.phases; ++i)
+        for (int j = 0; j < r.taps; ++j) {
+            double t = ((double)(-i) / r.phases + (double)(j - r.width) / r.orig) * base;
+            t = t < -lowpass ? -lowpass : (t > lowpass ? lowpass : t);
+            const double c = std::cos(t * pi / lowpass / 2.0);
+            const double window = c * c;
+            t *= pi;
+            const double sinc = t == 0.0 ? 1.0 : std::sin(t) / t;
+            r.k[(size_t)i * r.taps + j] = (float)(sinc * window * scale);
+        }
+    return r;
+}
+
+inline long long resampled_frames(long long n, int orig_hz, int new_hz) {
+    if (orig_hz == new_hz) return n;
+    const int g = std::gcd(orig_hz, new_hz);
+    const long long o = orig_hz / g, w = new_hz / g;
+    return (w * n + o - 1) / o;  // ceil(new * n / orig), as torchaudio
+}
+
+// x[0 .. n) at the kernel's source rate -> dst[0 .. resampled_frames): frame f, phase i = sum_j xp[f orig + j] k[i][j] with
+// xp = x zero-padded by `width` in front (and behind).
+inline void resample_into(const float* x, long long n, const ResampleKernel& rk, float* dst, long long n_out) {
+    for (long long o = 0; o < n_out; ++o) {
+        const long long f = o / rk.phases;
+        const int i = (int)(o - f * rk.phases);
+        const float* kk = rk.k.data() + (size_t)i * rk.taps;
+        const long long x0 = f * rk.orig - rk.width;  // source index of tap 0
+        const int j0 = x0 < 0 ? (int)(-x0) : 0;
+        const long long j1 = n - x0 < rk.taps ? n - x0 : rk.taps;
+        double acc = 0.0;
+        for (long long j = j0; j < j1; ++j) acc += (double)x[x0 + j] * (double)kk[j];
+        dst[o] = (float)acc;
+    }
 }
 
 template <typename Fn>

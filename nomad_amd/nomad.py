@@ -240,11 +240,10 @@ def _staged_batches(paths, load, pack, max_batch_samples: int, decode_threads: i
     batch of its own; a batch also closes before rows x longest row would exceed twice that, which bounds the
     staging buffer when one long file sits among short ones).
 
-    * ``native_threads > 0``: file headers are probed through the C ABI (``nomad_wav_probe``); files that are already at
-      ``target_sr`` are converted by ``nomad_wav_read_rows`` on that many plain host threads, straight into a slot of
-      a ring of pinned staging buffers - no per-file Python, no GIL, no second copy.
-    * every other file (another sample rate, an encoding or a header the native reader does not take, an unreadable
-      file) goes through ``load(path) -> (1, N) array`` on ``decode_threads`` Python worker threads with a bounded
+    * ``native_threads > 0``: file headers are probed through the C ABI (``nomad_wav_probe``); the files it can decode are
+      converted - and, at another sample rate, resampled to ``target_sr`` - by ``nomad_wav_read_rows`` on that many plain
+      host threads, straight into a slot of a ring of pinned staging buffers - no per-file Python, no GIL, no second copy.
+    * every other file (an encoding or a header the native reader does not take, an unreadable file) goes through ``load(path) -> (1, N) array`` on ``decode_threads`` Python worker threads with a bounded
       look-ahead, so results and exceptions are those of ``load``.  A batch without native files is packed by
       ``pack(list of 1-D arrays)``.
 
@@ -277,9 +276,10 @@ def _staged_batches(paths, load, pack, max_batch_samples: int, decode_threads: i
                         chunk = [str(p) for p in paths[probed:probed + probe_chunk]]
                         inf, status = wavio.probe(chunk, native_threads)
                         for k in range(len(chunk)):
-                            if status[k] == 0 and inf[k].sample_rate == target_sr and inf[k].frames > 0:
+                            if status[k] == 0 and inf[k].sample_rate > 0 and inf[k].frames > 0:
                                 infos[probed + k] = inf[k]
-                                fast[probed + k] = int(inf[k].frames)
+                                fast[probed + k] = (int(inf[k].frames) if inf[k].sample_rate == target_sr
+                                                    else wavio.frames_at(inf[k], target_sr))
                         probed += len(chunk)
 
                 def top_up(i):                 # keep up to `lookahead` Python decodes in flight, in file order
@@ -298,7 +298,7 @@ def _staged_batches(paths, load, pack, max_batch_samples: int, decode_threads: i
                     slot, host = ring.take(len(idxs), stride)
                     rows = [r for r, it in enumerate(items) if isinstance(it, int)]
                     wavio.read_rows([str(paths[items[r]]) for r in rows], [infos.pop(items[r]) for r in rows], rows, host,
-                                    native_threads)
+                                    native_threads, target_sr)
                     for r, it in enumerate(items):
                         if not isinstance(it, int):
                             host[r, :lens[r]] = torch.as_tensor(it, dtype=torch.float32).reshape(-1)
@@ -508,7 +508,7 @@ class Nomad:
     # 16 kHz files are converted by the C ABI's reader on plain host threads (0: everything through load_processing);
     # files that need load_processing (resampling, unusual headers) are decoded on a few Python threads - more than
     # two of those only fight over the interpreter lock
-    NATIVE_WAV_THREADS = int(os.environ.get("NOMAD_WAV_THREADS", min(4, os.cpu_count() or 1)))
+    NATIVE_WAV_THREADS = int(os.environ.get("NOMAD_WAV_THREADS", min(8, os.cpu_count() or 1)))
     DECODE_THREADS = int(os.environ.get("NOMAD_DECODE_THREADS", min(2, os.cpu_count() or 1)))
     PIPELINE_BATCHES = 2      # staged batches alive at any time: one on the GPU, one being built / waiting
 

@@ -120,9 +120,19 @@ def probe(paths, threads: int = 4):
     return info, list(status)
 
 
-def read_rows(paths, infos, rows, host, threads: int = 4) -> None:
+def frames_at(info, target_sr: int = 16000) -> int:
+    """Samples a probed file has at ``target_sr`` (after resampling, if its rate differs)."""
+    import ctypes as C
+    from . import _lib
+    n = C.c_longlong()
+    _lib.check(_lib.load().nomad_wav_frames_at(C.byref(info), int(target_sr), C.byref(n)), "nomad_wav_frames_at")
+    return int(n.value)
+
+
+def read_rows(paths, infos, rows, host, threads: int = 4, target_sr: int = 16000) -> None:
     """Sample data of probed files -> ``host[rows[i], :frames_i]`` (a 2-D contiguous fp32 torch tensor or numpy array),
-    mono fp32 exactly as ``load_processing`` returns it for a file that needs no resampling."""
+    mono fp32 at ``target_sr`` as ``load_processing`` returns it (bit-identical without resampling, to fp32 summation
+    order with)."""
     import ctypes as C
     from . import _lib
     lib = _lib.load()
@@ -139,4 +149,4 @@ def read_rows(paths, infos, rows, host, threads: int = 4) -> None:
     inf = (_lib.WavInfo * n)(*infos)
     row = (C.c_int * n)(*[int(r) for r in rows])
     status = (C.c_int * n)()
-    _lib.check(lib.nomad_wav_read_rows(arr, inf, n, row, ptr, stride, status, int(threads)), "nomad_wav_read_rows")
+    _lib.check(lib.nomad_wav_read_rows(arr, inf, n, row, ptr, stride, int(target_sr), status, int(threads)), "nomad_wav_read_rows")

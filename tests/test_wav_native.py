@@ -89,6 +89,7 @@ def test_native_reader_takes_torch_tensors_and_checks_its_arguments(wav_dir):
     info, _ = wavio.probe(wav_dir[:2])
     host = torch.zeros(2, int(max(info[0].frames, info[1].frames)))
     wavio.read_rows(wav_dir[:2], [info[0], info[1]], [0, 1], host)
+    assert wavio.frames_at(info[0]) == info[0].frames and wavio.frames_at(info[0], 8000) == -(-info[0].frames // 2)
     assert np.array_equal(host[0, :info[0].frames].numpy(), wavio.load_processing(wav_dir[0])[0])
     with pytest.raises(_lib.NomadHipError, match="do not fit"):
         wavio.read_rows(wav_dir[:1], [info[0]], [0], torch.zeros(1, 10))
@@ -97,7 +98,7 @@ def test_native_reader_takes_torch_tensors_and_checks_its_arguments(wav_dir):
 def test_probe_reports_what_it_does_not_decode(tmp_path):
     x = np.zeros((800, 1))
     files = {
-        "ok8k.wav": _wav_bytes(x, 8000, 1, 16),                      # decodable, but the caller must resample
+        "ok8k.wav": _wav_bytes(x, 8000, 1, 16),                      # decodable; read_rows resamples it
         "alaw.wav": _wav_bytes(x, 16000, 1, 16).replace(struct.pack("<HH", 1, 1), struct.pack("<HH", 6, 1), 1),
         "ragged_tail.wav": _wav_bytes(x, 16000, 1, 16, cut=1),       # np.frombuffer rejects it: so does the probe
         "nodata.wav": _wav_bytes(x, 16000, 1, 16)[:36],
@@ -169,7 +170,7 @@ def test_file_pipeline_native_equals_python(tmp_path):
     rng = np.random.default_rng(3)
     paths = []
     for i in range(90):
-        sr = 8000 if i % 7 == 3 else 16000                         # every 7th file needs the resampler: Python path
+        sr = 8000 if i % 7 == 3 else 16000                         # every 7th file needs the resampler (native too)
         ch = 2 if i % 5 == 0 else 1
         bits = (16, 24, 32)[i % 3]
         x = np.clip(0.3 * rng.standard_normal((int(rng.integers(400, 6000)), ch)), -0.99, 0.99)
@@ -180,10 +181,42 @@ def test_file_pipeline_native_equals_python(tmp_path):
     e_py, e_nat = _Engine(), _Engine()
     ref = _nomad(e_py, 0).get_embeddings_csv(None, df, max_batch_samples=30_000)
     got = _nomad(e_nat, 3).get_embeddings_csv(None, df, max_batch_samples=30_000)
-    assert e_py.batches == e_nat.batches and len(e_py.batches) > 5      # same batching either way
-    assert set(e_py.kinds) == {"python"} and "native" in e_nat.kinds
-    assert np.array_equal(ref[list(range(256))].to_numpy().view(np.uint32), got[list(range(256))].to_numpy().view(np.uint32))
+    assert e_py.batches == e_nat.batches and len(e_py.batches) > 5      # same batching either way (resampled lengths too)
+    assert set(e_py.kinds) == {"python"} and set(e_nat.kinds) == {"native"}
+    a, b = ref[list(range(256))].to_numpy(), got[list(range(256))].to_numpy()
+    same_rate = np.array([i % 7 != 3 for i in range(90)])
+    assert np.array_equal(a[same_rate].view(np.uint32), b[same_rate].view(np.uint32))      # decode only: bit-identical
+    assert np.array_equal(a[:, 0], b[:, 0]) and np.allclose(a, b, rtol=0, atol=2e-5)        # resampled: fp32 summation order
     assert list(got["filename"]) == paths
+
+
+@pytest.mark.parametrize("sr", [8000, 11025, 22050, 32000, 44100, 48000, 96000])
+def test_native_resampler_matches_the_python_one_and_the_torchaudio_restatement(tmp_path, sr):
+    """nomad.py:203-205: torchaudio.transforms.Resample(sr, 16000) defaults.  nomad_wav_read_rows against wavio.resample
+    (numpy) and oracle/resample_oracle.py (torch conv1d over torchaudio's kernel): same length, samples within 1e-6."""
+    import torch
+    from oracle import resample_oracle as R
+    rng = np.random.default_rng(sr)
+    paths, raws = [], []
+    for k, (ch, bits, n) in enumerate([(1, 16, sr + 123), (2, 24, sr // 3 + 7), (1, 32, 5), (1, 16, 40_001)]):
+        x = np.clip(0.3 * rng.standard_normal((n, ch)), -0.99, 0.99)
+        p = str(tmp_path / f"{k}.wav")
+        open(p, "wb").write(_wav_bytes(x, sr, 1, bits))
+        paths.append(p)
+    info, status = wavio.probe(paths)
+    assert status == [0] * len(paths)
+    want = [wavio.load_processing(p)[0] for p in paths]                 # decode + mono + wavio.resample
+    assert [wavio.frames_at(i) for i in info] == [w.shape[0] for w in want]
+    host = np.zeros((len(paths), max(w.shape[0] for w in want) + 3), dtype=np.float32)
+    wavio.read_rows(paths, list(info), range(len(paths)), host, threads=2)
+    for r, (p, w) in enumerate(zip(paths, want)):
+        got = host[r, :w.shape[0]]
+        assert np.abs(got - w).max() < 1e-6, (sr, r)
+        assert np.all(host[r, w.shape[0]:] == 0)
+        raw, rate = wavio.read_wav(p)
+        mono = ((raw[0] + raw[1]) / 2)[None] if raw.shape[0] > 1 else raw
+        ref = R.resample(torch.from_numpy(mono), rate, 16000).numpy()[0]
+        assert ref.shape == got.shape and np.abs(got - ref).max() < 1e-6, (sr, r)
 
 
 def test_file_pipeline_native_raises_what_the_python_front_end_raises(tmp_path):

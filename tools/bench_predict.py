@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--deg", type=int, default=512)
     ap.add_argument("--ref", type=int, default=64)
     ap.add_argument("--precision", default="fp32", choices=("fp32", "bf16x3", "bf16"))
+    ap.add_argument("--sr", type=int, default=16000, help="sample rate of the files (other than 16000: the front end resamples)")
     a = ap.parse_args()
     from nomad_amd.nomad import Nomad
     rng = np.random.RandomState(0)
@@ -28,9 +29,9 @@ def main():
         secs = 0.0
         for sub, n in (("nmr", a.ref), ("deg", a.deg)):
             for i in range(n):
-                length = int(rng.uniform(1.0, 8.0) * 16000)
-                secs += length / 16000
-                write_wav(f"{d}/{sub}/f{i:05d}.wav", 0.1 * rng.randn(length))
+                length = int(rng.uniform(1.0, 8.0) * a.sr)
+                secs += length / a.sr
+                write_wav(f"{d}/{sub}/f{i:05d}.wav", 0.1 * rng.randn(length), a.sr)
         nmd = Nomad(weights="seeded", precision=a.precision)
         nmd.predict("dir", d + "/nmr", d + "/deg", results_path=d + "/out0")  # warm-up (first-touch, allocator)
         torch.cuda.synchronize()
@@ -65,7 +66,7 @@ def main():
         torch.cuda.synchronize()
         t_emb = time.perf_counter() - t2
     n = a.deg + a.ref
-    print(json.dumps({"precision": a.precision, "files": n, "audio_s": round(secs, 1), "predict_s": round(dt, 3), "files_per_s": round(n / dt, 1),
+    print(json.dumps({"precision": a.precision, "file_sample_rate": a.sr, "files": n, "audio_s": round(secs, 1), "predict_s": round(dt, 3), "files_per_s": round(n / dt, 1),
                       "audio_s_per_s": round(secs / dt, 1), "decode_only_s": round(t_dec, 3), "embed_only_s": round(t_emb, 3),
                       "get_embeddings_pipeline_s": round(t_embed_stage, 3), "scores_csv_s": round(t_csv, 3),
                       "audio_bytes_all_files_MB": round(secs * 16000 * 4 / 1e6, 1),
