@@ -33,6 +33,7 @@ import pandas as pd
 import torch
 
 from . import wavio
+from .dist import partition
 from .engine import Engine
 from .weights import find_checkpoint, find_feature_grad_mult, load_checkpoint, seeded_state_dict
 
@@ -231,6 +232,17 @@ class _StagingRing:
             self.events[slot] = ev
 
 
+def _dist_info(group=None):
+    """(world size, rank, use collectives) of the torch.distributed job this process belongs to - (1, 0, False) outside one.
+    NOMAD_FORCE_COLLECTIVE=1 runs the collectives in a group of one rank too (how the RCCL path is exercised on a
+    single-GPU box)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1, 0, False
+    world = dist.get_world_size(group)
+    return world, dist.get_rank(group), world > 1 or os.environ.get("NOMAD_FORCE_COLLECTIVE") == "1"
+
+
 def _staged_batches(paths, load, pack, max_batch_samples: int, decode_threads: int, max_alive: int, native_threads: int = 0,
                     target_sr: int = 16000):
     """Generator of (row indices, (staging buffer, lengths), uploaded) batches over ``paths`` in order, built ahead of
@@ -352,7 +364,7 @@ def _staged_batches(paths, load, pack, max_batch_samples: int, decode_threads: i
 
 class Nomad:
     def __init__(self, device=None, weights: Union[None, str, Dict[str, torch.Tensor]] = None, precision: str = "fp32",
-                 feature_grad_mult: Union[None, float] = None):
+                 feature_grad_mult: Union[None, float] = None, group=None):
         """feature_grad_mult: fairseq's ``Wav2Vec2Model.feature_grad_mult`` - ``forward()``'s gradient w.r.t. ``estimate``
         passes through ``GradMultiply(features, feature_grad_mult)`` at the conv feature extractor's output, exactly as
         in the reference's backbone (built from wav2vec_small.pt, whose config says 0.1; nomad.py:58).  None = the value
@@ -385,6 +397,7 @@ class Nomad:
             sd = load_checkpoint(weights)
         else:
             sd = weights
+        self.group = group   # torch.distributed group predict() shards its files over (None: the default group, if any)
         self.engine = Engine(sd, dev_index)
         self.engine.feature_grad_mult = find_feature_grad_mult() if feature_grad_mult is None else float(feature_grad_mult)
         self.model = TripletModel(self.engine)
@@ -420,7 +433,17 @@ class Nomad:
         # Pairwise distance matrix + average NOMAD score, on the GPU (cdist + np.mean, nomad.py:108-111)
         deg_t = torch.from_numpy(np.ascontiguousarray(test_embeddings.to_numpy(dtype=np.float32))).to(self.engine.device)
         ref_t = torch.from_numpy(np.ascontiguousarray(nmr_embeddings.to_numpy(dtype=np.float32))).to(self.engine.device)
-        dist, mean = self.engine.pairwise(deg_t, ref_t, want_matrix=True)
+        world, rank, collective = _dist_info(getattr(self, "group", None))
+        if collective:   # this rank's slab of the matrix (its slice of the degraded files x all references), then one gather
+            lo, hi = partition(deg_t.shape[0], world, rank)
+            if hi > lo:
+                dist, mean = self.engine.pairwise(deg_t[lo:hi].contiguous(), ref_t, want_matrix=True)
+            else:
+                dist = torch.zeros(0, ref_t.shape[0], dtype=torch.float64, device=deg_t.device)
+                mean = torch.zeros(0, dtype=torch.float64, device=deg_t.device)
+            dist, mean = self._all_gather_rows(dist), self._all_gather_rows(mean)
+        else:
+            dist, mean = self.engine.pairwise(deg_t, ref_t, want_matrix=True)
         distance_matrix = dist.cpu().numpy()
         avg_nomad = mean.cpu().numpy()
 
@@ -435,15 +458,17 @@ class Nomad:
         if results_path is None:
             dt_string = datetime.now().strftime("%d-%m-%Y_%H-%M-%S")
             out_dir = os.path.join("results-csv", dt_string)
-            os.makedirs(out_dir, exist_ok=True)
+            if rank == 0:
+                os.makedirs(out_dir, exist_ok=True)
             results_avg_path = os.path.join(out_dir, f"{dt_string}_nomad_avg.csv")
             results_scores_path = os.path.join(out_dir, f"{dt_string}_nomad_scores.csv")
         else:
             results_avg_path = os.path.join(results_path, "nomad_avg.csv")
             results_scores_path = os.path.join(results_path, "nomad_scores.csv")
 
-        df_avg_nomad.reset_index().to_csv(results_avg_path, index=False)
-        _write_rounded_csv(df_dm.reset_index(), results_scores_path)
+        if rank == 0:   # every rank returns the tables, one writes the files
+            df_avg_nomad.reset_index().to_csv(results_avg_path, index=False)
+            _write_rounded_csv(df_dm.reset_index(), results_scores_path)
         return df_avg_nomad, df_dm
 
     def forward(self, estimate, clean):
@@ -454,6 +479,14 @@ class Nomad:
         BASE; ``Nomad(feature_grad_mult=...)`` / ``self.engine.feature_grad_mult``).  The backbone is frozen: the reference would also accumulate parameter gradients nobody reads
         (the freeze is commented out at nomad.py:74-76); ``clean`` receives no gradient."""
         return _NomadLossFn.apply(estimate, clean, self)
+
+    def _all_gather_rows(self, x: torch.Tensor) -> torch.Tensor:
+        """Rows of every rank, in rank order, on every rank (nccl = RCCL needs device tensors, gloo takes host ones)."""
+        import torch.distributed as dist
+        from .dist import all_gather_rows
+        if dist.get_backend(getattr(self, "group", None)) == "nccl":
+            x = x.to(self.engine.device)
+        return all_gather_rows(x.contiguous(), getattr(self, "group", None), force_collective=True)
 
     def get_embeddings(self, path):
         if os.path.isdir(path):
@@ -475,19 +508,26 @@ class Nomad:
         The reference embeds one file per iteration with a device sync each time (nomad.py:171-183).  Here files
         of arbitrary lengths are packed into ragged batches (``nomad_embed_ragged``: no padding enters the
         arithmetic, results are bit-identical to per-file calls) of at most ``max_batch_samples`` samples, as a
-        three-stage pipeline: a small thread pool decodes (and resamples) files ahead of need, a packer thread
-        copies each batch into a pinned staging buffer, and this thread only enqueues GPU work - batch k+1 is
-        decoded, packed and launched while the GPU still runs batch k, and results are fetched one batch late.
+        pipeline (``_staged_batches``): a packer thread has the C ABI's reader decode (and resample) each batch on native
+        host threads straight into a pinned staging buffer, and this thread only enqueues GPU work - batch k+1 is
+        built and launched while the GPU still runs batch k, and results are fetched one batch late.
         Like the reference, which holds one clip at a time, memory does not grow with the size of the directory:
-        never more than ``PIPELINE_BATCHES`` staged batches (plus the decode look-ahead) are alive."""
+        never more than ``PIPELINE_BATCHES`` staged batches (plus the decode look-ahead) are alive.
+        Inside a ``torch.distributed`` job (one process per GPU) every rank embeds its contiguous slice of the list
+        and one all-gather gives every rank the whole table."""
         file_names_arr = np.array(file_names)
         paths = []
         for row in file_names_arr:
             name = row[0] if isinstance(row, np.ndarray) else row
             paths.append(os.path.join(root, name) if root else name)
-        embeddings = np.zeros((len(paths), EMB_DIM), dtype=np.float32)
+        # one process per GPU under torch.distributed: every rank embeds a contiguous slice of the file list, one
+        # all-gather (RCCL over xGMI; gloo on CPU) hands every rank all embeddings in listing order
+        world, rank, collective = _dist_info(getattr(self, "group", None))
+        lo, hi = partition(len(paths), world, rank) if collective else (0, len(paths))
+        mine = paths[lo:hi]
+        embeddings = np.zeros((len(mine), EMB_DIM), dtype=np.float32)
         pending = None                                   # (row indices, host copy in flight) of the previous batch
-        for idxs, packed, uploaded in _staged_batches(paths, lambda p: self.load_processing(p, trim=False),
+        for idxs, packed, uploaded in _staged_batches(mine, lambda p: self.load_processing(p, trim=False),
                                                       self.engine.pack_ragged_host, max_batch_samples, self.DECODE_THREADS,
                                                       self.PIPELINE_BATCHES, self.NATIVE_WAV_THREADS):
             prec = self.precision
@@ -501,13 +541,15 @@ class Nomad:
             pending = (idxs, fetch)
         if pending is not None:
             embeddings[pending[0]] = pending[1].result()
+        if collective:
+            embeddings = self._all_gather_rows(torch.from_numpy(embeddings)).cpu().numpy()
         emb_df = pd.DataFrame(embeddings)
         df_emb = pd.concat([file_names.reset_index(), emb_df], axis=1).drop("index", axis=1)
         return df_emb
 
-    # 16 kHz files are converted by the C ABI's reader on plain host threads (0: everything through load_processing);
-    # files that need load_processing (resampling, unusual headers) are decoded on a few Python threads - more than
-    # two of those only fight over the interpreter lock
+    # files are decoded (and resampled) by the C ABI's reader on plain host threads (0: everything through load_processing);
+    # files it does not take (unusual headers / encodings) are decoded on a few Python threads - more than two of those
+    # only fight over the interpreter lock
     NATIVE_WAV_THREADS = int(os.environ.get("NOMAD_WAV_THREADS", min(8, os.cpu_count() or 1)))
     DECODE_THREADS = int(os.environ.get("NOMAD_DECODE_THREADS", min(2, os.cpu_count() or 1)))
     PIPELINE_BATCHES = 2      # staged batches alive at any time: one on the GPU, one being built / waiting

@@ -5,7 +5,8 @@ Checks, with the real Engine:
   * the sharded scorer with the all-gather really issued (force_collective) equals the unsharded result bit for bit;
   * the same on a non-default stream, with fresh inputs every iteration: the collective must be ordered after the
     engine's embedding kernels and before its distance kernel on whatever stream the engine launches on;
-  * the unequal-shard path (size exchange + padded all-gather) and the final gather of the scores.
+  * the unequal-shard path (size exchange + padded all-gather) and the final gather of the scores;
+  * Nomad.predict on the shipped example files with its file sharding forced on: same tables, byte-identical CSV files.
 Prints RCCL_WS1_OK on success.
 """
 import os
@@ -68,11 +69,30 @@ def main():
         x = x * 1.0001 + k
         y = all_gather_rows(x, equal=True, force_collective=True)
         assert y.data_ptr() != x.data_ptr() and torch.equal(y, x)
+    # Nomad.predict on the shipped example files with its file sharding switched on in this group of one rank
+    # (NOMAD_FORCE_COLLECTIVE=1): the embedding tables and the distance slab go through RCCL all-gathers and must come back
+    # identical to the run without a collective
+    import tempfile
+    from nomad_amd.nomad import Nomad
+    wavs = os.path.join(ROOT, "tests", "golden", "wavs")
+    nmd = Nomad(weights=seeded_state_dict(0), device=local_rank)
+    with tempfile.TemporaryDirectory() as d:
+        os.makedirs(d + "/a")
+        os.makedirs(d + "/b")
+        os.environ.pop("NOMAD_FORCE_COLLECTIVE", None)
+        avg0, dm0 = nmd.predict("dir", os.path.join(wavs, "nmr-data"), os.path.join(wavs, "test-data"), results_path=d + "/a")
+        os.environ["NOMAD_FORCE_COLLECTIVE"] = "1"
+        avg1, dm1 = nmd.predict("dir", os.path.join(wavs, "nmr-data"), os.path.join(wavs, "test-data"), results_path=d + "/b")
+        os.environ.pop("NOMAD_FORCE_COLLECTIVE", None)
+        assert avg1.equals(avg0) and dm1.equals(dm0) and dm1.shape == (2, 4)
+        for name in ("nomad_avg.csv", "nomad_scores.csv"):
+            assert open(f"{d}/a/{name}", "rb").read() == open(f"{d}/b/{name}", "rb").read()
+    nmd.engine.close()
     dist.barrier()
     torch.cuda.synchronize()
     dist.destroy_process_group()
     eng.close()
-    print(f"RCCL_WS1_OK collectives={n_coll + 8}", flush=True)
+    print(f"RCCL_WS1_OK collectives={n_coll + 8} predict_sharded=ok", flush=True)
 
 
 if __name__ == "__main__":

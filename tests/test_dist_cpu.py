@@ -142,3 +142,90 @@ def test_force_collective_in_a_group_of_one(tmp_path):
     out = np.load(os.path.join(tmp_path, "ws1.npz"))
     assert out["calls"].tolist() == [0, 1, 2]     # none / the all-gather / size exchange + all-gather
     assert out["same"].all()
+
+
+# ---- Nomad.predict inside a torch.distributed job: files shard across ranks ------------------------------------------
+class _FileEngine:
+    """CPU stand-in for nomad_amd.engine.Engine: a clip's "embedding" is a deterministic function of its samples."""
+    device = torch.device("cpu")
+
+    def pack_ragged_host(self, waves):
+        lens = [int(w.shape[0]) for w in waves]
+        host = np.zeros((len(waves), max(lens)), dtype=np.float32)
+        for i, w in enumerate(waves):
+            host[i, :lens[i]] = np.asarray(w)
+        return host, lens
+
+    def embed_ragged(self, waves, precision=None, packed=None):
+        host, lens = packed
+        host = host.numpy() if not isinstance(host, np.ndarray) else host
+        out = np.zeros((len(lens), 256), dtype=np.float32)
+        for i, n in enumerate(lens):
+            x = host[i, :n].astype(np.float64)
+            out[i, :3] = n / 1e4, x.sum(), np.abs(x).mean()
+        return out
+
+    def fetch_async(self, emb):
+        class F:
+            def result(self_inner):
+                return emb
+        return F()
+
+    def pairwise(self, deg, ref, want_matrix=False):
+        d = torch.cdist(deg.double(), ref.double())
+        return (d if want_matrix else None), d.mean(dim=1)
+
+
+def _file_nomad():
+    from nomad_amd import wavio
+    from nomad_amd.nomad import Nomad
+    n = Nomad.__new__(Nomad)
+    n.engine, n.precision, n.group, n.model = _FileEngine(), "fp32", None, None
+    n.load_processing = lambda p, trim=False: torch.from_numpy(wavio.load_processing(p, 16000, trim))
+    return n
+
+
+def _write_dirs(root, n_deg, n_ref):
+    import struct
+    rng = np.random.default_rng(5)
+    for sub, n in (("nmr", n_ref), ("deg", n_deg)):
+        os.makedirs(os.path.join(root, sub))
+        for i in range(n):
+            x = (0.2 * rng.standard_normal(int(rng.integers(300, 3000))) * 32767).astype("<i2").tobytes()
+            with open(os.path.join(root, sub, f"{sub}{i:03d}.wav"), "wb") as f:
+                f.write(b"RIFF" + struct.pack("<I", 36 + len(x)) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 1, 16000, 32000, 2, 16) +
+                        b"data" + struct.pack("<I", len(x)) + x)
+
+
+def _predict_worker(rank, world, port, root):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = os.path.join(root, "out_dist")
+    avg, dm = _file_nomad().predict("dir", os.path.join(root, "nmr"), os.path.join(root, "deg"), results_path=out)
+    avg.to_pickle(os.path.join(root, f"avg_rank{rank}.pkl"))     # every rank returns the full tables
+    dm.to_pickle(os.path.join(root, f"dm_rank{rank}.pkl"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_predict_shards_files_across_ranks(tmp_path):
+    """world_size 2 (gloo): each rank embeds its slice of both directories, the all-gathers put the tables back in
+    listing order, each rank computes its slab of the distance matrix, rank 0 writes the CSV files - byte-identical to
+    the single-process run; 7 degraded files do not divide evenly, 1 reference file leaves a rank with none."""
+    import pandas as pd
+    for n_deg, n_ref in ((7, 4), (3, 1)):
+        root = str(tmp_path / f"d{n_deg}_{n_ref}")
+        os.makedirs(root)
+        _write_dirs(root, n_deg, n_ref)
+        os.makedirs(os.path.join(root, "out_dist"))
+        os.makedirs(os.path.join(root, "out_single"))
+        mp.spawn(_predict_worker, args=(2, _free_port(), root), nprocs=2, join=True)
+        avg, dm = _file_nomad().predict("dir", os.path.join(root, "nmr"), os.path.join(root, "deg"),
+                                        results_path=os.path.join(root, "out_single"))
+        assert avg.shape == (n_deg, 1) and dm.shape == (n_deg, n_ref)
+        for r in range(2):
+            assert pd.read_pickle(os.path.join(root, f"avg_rank{r}.pkl")).equals(avg)
+            assert pd.read_pickle(os.path.join(root, f"dm_rank{r}.pkl")).equals(dm)
+        for name in ("nomad_avg.csv", "nomad_scores.csv"):
+            assert open(os.path.join(root, "out_dist", name), "rb").read() == open(os.path.join(root, "out_single", name), "rb").read()
