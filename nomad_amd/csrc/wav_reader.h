@@ -17,6 +17,7 @@
 #include <cstdint>
 #include <cstring>
 #include <numeric>
+#include <stdexcept>
 #include <thread>
 #include <vector>
 
@@ -212,11 +213,18 @@ inline void parallel_for(int n, int threads, Fn fn) {
     std::atomic<int> next{0};
     std::vector<std::thread> pool;
     pool.reserve((size_t)threads);
+    std::atomic<bool> failed{false};  // an exception must not leave a worker thread (std::terminate): remember it, re-throw here
     for (int t = 0; t < threads; ++t)
         pool.emplace_back([&, t] {
-            for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i, t);
+            try {
+                for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i, t);
+            } catch (...) {
+                failed.store(true);
+                next.store(n);
+            }
         });
     for (auto& th : pool) th.join();
+    if (failed.load()) throw std::runtime_error("a reader thread ran out of memory or failed");
 }
 
 }  // namespace wav

@@ -243,3 +243,46 @@ def test_staging_bound_closes_a_batch_when_one_long_file_sits_among_short_ones(t
     _nomad(eng, 2).get_embeddings_csv(None, pd.DataFrame({"filename": paths}), max_batch_samples=40_000)
     assert [l for b in eng.batches for l in b] == lens
     assert all(len(b) * max(b) <= 80_000 for b in eng.batches)           # rows x stride of every staging buffer
+
+
+def test_reader_under_address_and_ub_sanitizers(tmp_path, wav_dir):
+    """The host code of the reader (probe, decode, resample) built with g++ -fsanitize=address,undefined and run over the
+    format zoo, truncated / malformed files and other sample rates, every output in an exactly-sized heap buffer; its
+    sums must match the Python front end's."""
+    import shutil
+    import subprocess
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "wav_reader_driver")
+    subprocess.run([gxx, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-pthread",
+                    os.path.join(root, "tests", "native", "wav_reader_driver.cpp"), "-o", exe], check=True, timeout=300)
+    rng = np.random.default_rng(11)
+    extra = []
+    for k, (sr, ch, bits, n) in enumerate([(48000, 2, 16, 4801), (8000, 1, 24, 3), (44100, 1, 32, 12345), (22050, 3, 16, 1)]):
+        p = str(tmp_path / f"r{k}.wav")
+        open(p, "wb").write(_wav_bytes(np.clip(0.3 * rng.standard_normal((n, ch)), -0.99, 0.99), sr, 1, bits))
+        extra.append(p)
+    bad = []
+    good = _wav_bytes(np.zeros((700, 2)), 16000, 1, 16)
+    for k, data in enumerate([good[:50], good[:45], good[:13], b"RIFF\xff\xff\xff\xffWAVEfmt \xff\xff\xff\x7f", good[:len(good) - 3],
+                              good.replace(b"data", b"dat_"), b""]):
+        p = str(tmp_path / f"bad{k}.wav")
+        open(p, "wb").write(data)
+        bad.append(p)
+    files = list(wav_dir) + extra + bad
+    res = subprocess.run([exe] + files, capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1"))
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = res.stdout.strip().split("\n")
+    assert len(lines) == len(files)
+    for path, line in zip(files, lines):
+        st, rate, ch, frames, n16, total = line.split()
+        try:
+            want = wavio.load_processing(path)[0]
+        except (ValueError, struct.error):
+            assert int(st) != 0, path
+            continue
+        assert int(st) == 0 and int(n16) == want.shape[0], (path, line)
+        assert abs(float(total) - float(want.astype(np.float64).sum())) < 1e-3 + 1e-6 * want.shape[0], (path, line)
