@@ -2747,8 +2747,8 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
         hipLaunchKernelGGL(gn_bwd_stats_kernel, grid, dim3(256), 0, s, wav, n_samples, sh.L[0], c->conv0_w, sv.gn_scale,
                            sv.gn_shift, sv.gn_mean, sv.gn_rstd, G0, partial);
         if (dwav)
-            hipLaunchKernelGGL(conv0_bwd_kernel, grid, dim3(256), 0, s, wav, n_samples, sh.L[0], c->conv0_w, sv.gn_scale,
-                               sv.gn_shift, sv.gn_mean, sv.gn_rstd, G0, partial, lay.nchunks, dwav);
+            hipLaunchKernelGGL(conv0_bwd_kernel, dim3((sh.L[0] + kC0Frames - 1) / kC0Frames, B), dim3(256), 0, s, wav, n_samples, sh.L[0],
+                               c->conv0_w, sv.gn_scale, sv.gn_shift, sv.gn_mean, sv.gn_rstd, G0, partial, lay.nchunks, dwav);
         if (conv_pg) {  // conv0 weight, GroupNorm gamma / beta
             hipLaunchKernelGGL(conv0_param_partial_kernel, grid, dim3(256), 0, s, wav, n_samples, sh.L[0], c->conv0_w, sv.gn_scale,
                                sv.gn_shift, sv.gn_mean, sv.gn_rstd, G0, partial, lay.nchunks, F(lay.c0part));
