@@ -145,13 +145,23 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ poo
     float p[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) p[i] = pooled[lane + 64 * i];
-    for (int o = wave * 64; o < wave * 64 + 64; ++o) {
-        const float* wr = w + (long long)o * 768;
-        float d = 0.f;
+    // 8 output rows per trip: their 96 loads are in flight together (one row at a time, each trip waited ~0.7 us for its own
+    // 12 loads: 76 us for the 64 rows of a wave); every row's own sum keeps its order
+#pragma unroll 1
+    for (int o0 = wave * 64; o0 < wave * 64 + 64; o0 += 8) {
+        float wv[8][12];
 #pragma unroll
-        for (int i = 0; i < 12; ++i) d = fmaf(wr[lane + 64 * i], p[i], d);
-        d = wave_sum(d);
-        if (lane == 0) e[o] = d + bias[o];
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int i = 0; i < 12; ++i) wv[u][i] = w[(long long)(o0 + u) * 768 + lane + 64 * i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            float d = 0.f;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) d = fmaf(wv[u][i], p[i], d);
+            d = wave_sum(d);
+            if (lane == 0) e[o0 + u] = d + bias[o0 + u];
+        }
     }
     __syncthreads();
     const float v = e[tid];
