@@ -115,6 +115,11 @@ def main():
     # exercises the same collective path the 2/4/8-GPU runs take.  A plain `python bench.py` has no process group.
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     use_pg = world > 1 or launched
+    # RCCL prints a version banner on this process's stdout when its communicator comes up (at init or at the first
+    # collective); the contract is ONE JSON line on rank 0's stdout, so fd 1 points at stderr until that line is printed
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     if use_pg:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if rank == 0:
@@ -316,7 +321,10 @@ def main():
             out["also_measured_c5"] = also_c5
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, n_samples)
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if use_pg:
         dist.barrier()
         dist.destroy_process_group()

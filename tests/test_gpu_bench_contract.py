@@ -15,8 +15,8 @@ def _run(args, launcher=()):
     res = subprocess.run([sys.executable, *launcher, os.path.join(ROOT, "bench.py"), *args], cwd=ROOT, env=env,
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
-    lines = [ln for ln in res.stdout.splitlines() if ln.strip().startswith("{")]
-    assert len(lines) == 1, res.stdout
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), res.stdout      # ONE JSON line and nothing else on stdout (RCCL's banner too)
     return json.loads(lines[0])
 
 
