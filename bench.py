@@ -27,6 +27,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL otherwise fails with hipIpcGetMemHandle: invalid argument); the
+# boxes export it already - this only covers a shell that lost it
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 FLOP_PER_CLIP_4S = 56.925e9      # BASELINE.md section 2 (2*MAC, no recompute)
 FLOP_LAYERS_4S = 35.264e9        # the 12 encoder layers ("attention-GEMM" subset)
