@@ -155,10 +155,10 @@ def main():
         step()
     fence()
     profile = not args.no_profile
-    # bf16x3 embeds a batch as two halves on two streams (Engine.embed_bf16x3): launches overlap, so per-kernel event
+    # Every precision embeds a batch as two halves on two streams (Engine.embed*): launches overlap, so per-kernel event
     # durations no longer add up to wall time.  Its roofline comes from a second, profiled pass with the split off;
     # `value` from the un-profiled pass the product actually runs.
-    split_attr = {"bf16x3": "X3_SPLIT_ROWS", "bf16": "BF16_SPLIT_ROWS"}.get(args.dtype)
+    split_attr = {"bf16x3": "X3_SPLIT_ROWS", "bf16": "BF16_SPLIT_ROWS", "f32": "F32_SPLIT_ROWS"}.get(args.dtype)
     split_prof = profile and split_attr is not None and getattr(eng, split_attr)
     if profile and not split_prof:
         eng.profile_enable(True)

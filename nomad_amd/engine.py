@@ -162,7 +162,7 @@ class Engine:
                                             e.data_ptr(), layers.data_ptr() if layers is not None else None,
                                             ws.data_ptr(), ws.numel(), self._stream()), "nomad_embed")
 
-        if side or want_layers or B < 2 or not (self.F32_SPLIT_ROWS <= B * T < self.F32_SPLIT_MAX_ROWS):
+        if side or want_layers or B < 2 or not self.F32_SPLIT_ROWS or not (self.F32_SPLIT_ROWS <= B * T < self.F32_SPLIT_MAX_ROWS):
             run(wav, emb, side)
         else:
             # two halves on two streams: each half's kernels fill the CUs the other's partial last round of tiles leaves
@@ -176,12 +176,13 @@ class Engine:
             cur.wait_stream(ss)
         return (emb, layers) if want_layers else emb
 
-    # Plain scoring batches of F32_SPLIT_ROWS <= frames < F32_SPLIT_MAX_ROWS run as two halves on two streams:
-    # +7.6 % at 32 clips of 4 s, +4 % at 64, +5 % at 128 (profiles/r01_f32_two_streams.txt).  At 256 clips (the bench
-    # workload, 50 944 frames) the gain is 0.75 % and the overlapping launches would blur the per-kernel timings the
-    # roofline is computed from, so full batches stay on one stream.  NOMAD_F32_SPLIT_ROWS / _MAX_ROWS override.
+    # Plain scoring batches of at least F32_SPLIT_ROWS frames run as two halves on two streams: each half's kernels fill the
+    # CUs the other's partial last round of tiles leaves idle: +7.6 % at 32 clips of 4 s, +4 % at 64, +5 % at 128
+    # (profiles/r01_f32_two_streams.txt), +0.7 % at 256 (the bench workload, 50 944 frames: 2253-2260 vs 2238-2245 clips/s
+    # alternating in one run).  bench.py takes its per-kernel timings (roofline) from a second pass with the split off
+    # (F32_SPLIT_ROWS = 0), where kernels run alone.  NOMAD_F32_SPLIT_ROWS / _MAX_ROWS override.
     F32_SPLIT_ROWS = int(os.environ.get("NOMAD_F32_SPLIT_ROWS", 4000))
-    F32_SPLIT_MAX_ROWS = int(os.environ.get("NOMAD_F32_SPLIT_MAX_ROWS", 40000))
+    F32_SPLIT_MAX_ROWS = int(os.environ.get("NOMAD_F32_SPLIT_MAX_ROWS", 1 << 30))
 
     def fetch_async(self, dev: torch.Tensor) -> _AsyncFetch:
         """Start copying a result to the host; ``.result()`` (numpy) later waits for this copy alone."""
@@ -262,7 +263,7 @@ class Engine:
         rows = sum(num_frames(n) for n in lens)
         split = B >= 2 and ((precision == "bf16x3" and self.X3_SPLIT_ROWS and rows >= self.X3_SPLIT_ROWS) or
                             (precision == "bf16" and self.BF16_SPLIT_ROWS and rows >= self.BF16_SPLIT_ROWS) or
-                            (precision == "fp32" and self.F32_SPLIT_ROWS <= rows < self.F32_SPLIT_MAX_ROWS))
+                            (precision == "fp32" and self.F32_SPLIT_ROWS and self.F32_SPLIT_ROWS <= rows < self.F32_SPLIT_MAX_ROWS))
         if not split:
             run(0, B, False)
             return emb
