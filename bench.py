@@ -95,6 +95,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the extra bf16x3 measurement after the fp32 one")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with hipEvents")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="no two-stream batch split: kernels run alone, as in the pass the roofline is timed in - the command "
+                         "the rocprofv3 kernel summaries under profiles/ are taken with")
     args = ap.parse_args()
 
     import torch
@@ -133,6 +136,8 @@ def main():
     ckpt = find_checkpoint()
     sd = load_checkpoint(ckpt) if ckpt else seeded_state_dict(0)
     eng = Engine(sd, local_rank)
+    if args.single_stream:
+        eng.F32_SPLIT_ROWS = eng.X3_SPLIT_ROWS = eng.BF16_SPLIT_ROWS = 0
     embed_fn = {"f32": eng.embed, "bf16": eng.embed_bf16, "bf16x3": eng.embed_bf16x3}[args.dtype]
     scorer = ShardedScorer(embed_fn, eng.pairwise, equal_shards=True, force_collective=use_pg)
 

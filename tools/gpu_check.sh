@@ -11,7 +11,7 @@ tail -n 40 $OUT/pytest_gpu.log
 timeout 900 python bench.py --steps 5 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?" | tee -a $OUT/summary.txt
 cat $OUT/bench.json
 ROOTDIR=$(pwd)
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOTDIR/$OUT/prof -o prof -- python3 $ROOTDIR/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-also > $ROOTDIR/$OUT/prof_bench.json 2> $ROOTDIR/$OUT/prof.err); echo "rocprof exit $?" | tee -a $OUT/summary.txt
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOTDIR/$OUT/prof -o prof -- python3 $ROOTDIR/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --single-stream --no-also > $ROOTDIR/$OUT/prof_bench.json 2> $ROOTDIR/$OUT/prof.err); echo "rocprof exit $?" | tee -a $OUT/summary.txt
 find $OUT/prof -name "*kernel_stats*.csv" | head -1 | xargs -r head -n 30
 # keep only the small summaries (gpurun_out merge limit is 64 MiB)
 find $OUT/prof -name "*kernel_trace*.csv" -size +8M -delete

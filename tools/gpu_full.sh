@@ -11,6 +11,6 @@ import json
 d = json.load(open("$OUT/bench.json"))
 print({k: d[k] for k in ("value", "ms_per_step", "kernel_time_ms_per_step")}, d["roofline"]["frac"], d.get("also_measured", {}).get("value"), d.get("also_measured_c5", {}).get("value"))
 PY
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o prof -- python3 $ROOTDIR/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-also > $OUT/prof_bench.json 2> $OUT/prof.err); echo "rocprof exit $?" | tee -a $OUT/summary.txt
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o prof -- python3 $ROOTDIR/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --single-stream --no-also > $OUT/prof_bench.json 2> $OUT/prof.err); echo "rocprof exit $?" | tee -a $OUT/summary.txt
 f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/kernel_stats.csv && head -12 $OUT/kernel_stats.csv | cut -c1-180
 find $OUT/prof -type f ! -name "*stats*" -delete 2>/dev/null
