@@ -162,18 +162,22 @@ class Engine:
                                             e.data_ptr(), layers.data_ptr() if layers is not None else None,
                                             ws.data_ptr(), ws.numel(), self._stream()), "nomad_embed")
 
-        if side or want_layers or B < 2 or not self.F32_SPLIT_ROWS or not (self.F32_SPLIT_ROWS <= B * T < self.F32_SPLIT_MAX_ROWS):
+        ways = min(self.F32_SPLIT_WAYS, B)
+        if side or want_layers or ways < 2 or not self.F32_SPLIT_ROWS or not (self.F32_SPLIT_ROWS <= B * T < self.F32_SPLIT_MAX_ROWS):
             run(wav, emb, side)
         else:
-            # two halves on two streams: each half's kernels fill the CUs the other's partial last round of tiles leaves
-            # idle (every instantiation contracts k in the same order, so the halves' bits equal the whole batch's)
-            h = B // 2
-            cur, ss = torch.cuda.current_stream(self.device), self.side_stream()
-            ss.wait_stream(cur)
-            with torch.cuda.stream(ss):
-                run(wav[h:], emb[h:], True)
-            run(wav[:h], emb[:h], False)
-            cur.wait_stream(ss)
+            # parts of the batch on separate streams: each part's kernels fill the CUs the others' partial last rounds of tiles
+            # leave idle (every instantiation contracts k in the same order, so the parts' bits equal the whole batch's)
+            cur = torch.cuda.current_stream(self.device)
+            cuts = [B * i // ways for i in range(ways + 1)]
+            for k in range(1, ways):
+                st = self.side_stream(k)
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    run(wav[cuts[k]:cuts[k + 1]], emb[cuts[k]:cuts[k + 1]], k)
+            run(wav[:cuts[1]], emb[:cuts[1]], False)
+            for k in range(1, ways):
+                cur.wait_stream(self.side_stream(k))
         return (emb, layers) if want_layers else emb
 
     # Plain scoring batches of at least F32_SPLIT_ROWS frames run as two halves on two streams: each half's kernels fill the
@@ -183,6 +187,7 @@ class Engine:
     # (F32_SPLIT_ROWS = 0), where kernels run alone.  NOMAD_F32_SPLIT_ROWS / _MAX_ROWS override.
     F32_SPLIT_ROWS = int(os.environ.get("NOMAD_F32_SPLIT_ROWS", 4000))
     F32_SPLIT_MAX_ROWS = int(os.environ.get("NOMAD_F32_SPLIT_MAX_ROWS", 1 << 30))
+    F32_SPLIT_WAYS = int(os.environ.get("NOMAD_F32_SPLIT_WAYS", 2))
 
     def fetch_async(self, dev: torch.Tensor) -> _AsyncFetch:
         """Start copying a result to the host; ``.result()`` (numpy) later waits for this copy alone."""
