@@ -434,7 +434,13 @@ class Nomad:
         deg_t = torch.from_numpy(np.ascontiguousarray(test_embeddings.to_numpy(dtype=np.float32))).to(self.engine.device)
         ref_t = torch.from_numpy(np.ascontiguousarray(nmr_embeddings.to_numpy(dtype=np.float32))).to(self.engine.device)
         world, rank, collective = _dist_info(getattr(self, "group", None))
-        if collective:   # this rank's slab of the matrix (its slice of the degraded files x all references), then one gather
+        if deg_t.shape[0] == 0 or ref_t.shape[0] == 0:
+            # an empty directory: what cdist + np.mean(axis=1) give the reference - an empty matrix, and NaN means when
+            # there is no reference to average over (the engine's kernels take no empty operands)
+            collective = False
+            dist = torch.zeros(deg_t.shape[0], ref_t.shape[0], dtype=torch.float64)
+            mean = torch.full((deg_t.shape[0],), float("nan"), dtype=torch.float64)
+        elif collective:   # this rank's slab of the matrix (its slice of the degraded files x all references), then one gather
             lo, hi = partition(deg_t.shape[0], world, rank)
             if hi > lo:
                 dist, mean = self.engine.pairwise(deg_t[lo:hi].contiguous(), ref_t, want_matrix=True)

@@ -229,3 +229,24 @@ def test_predict_shards_files_across_ranks(tmp_path):
             assert pd.read_pickle(os.path.join(root, f"dm_rank{r}.pkl")).equals(dm)
         for name in ("nomad_avg.csv", "nomad_scores.csv"):
             assert open(os.path.join(root, "out_dist", name), "rb").read() == open(os.path.join(root, "out_single", name), "rb").read()
+
+
+def test_predict_with_an_empty_file_list(tmp_path):
+    """csv mode with no rows (an empty directory already fails in get_embeddings, exactly like the reference's
+    nomad.py:148-151): cdist + np.mean(axis=1) of the reference give an empty matrix for no degraded files and NaN means for
+    no references; the engine's kernels take no empty operands, so predict answers that itself."""
+    import pandas as pd
+    root = str(tmp_path)
+    _write_dirs(root, 3, 2)
+    full = lambda sub: pd.DataFrame({"filename": sorted(os.path.join(root, sub, f) for f in os.listdir(os.path.join(root, sub)))})
+    empty = pd.DataFrame({"filename": []})
+    for name, df in (("nmr.csv", full("nmr")), ("deg.csv", full("deg")), ("none.csv", empty)):
+        df.to_csv(os.path.join(root, name), index=False)
+    os.makedirs(os.path.join(root, "o1"))
+    os.makedirs(os.path.join(root, "o2"))
+    n = _file_nomad()
+    avg, dm = n.predict("csv", os.path.join(root, "nmr.csv"), os.path.join(root, "none.csv"), results_path=os.path.join(root, "o1"))
+    assert avg.shape == (0, 1) and dm.shape == (0, 2)
+    avg, dm = n.predict("csv", os.path.join(root, "none.csv"), os.path.join(root, "deg.csv"), results_path=os.path.join(root, "o2"))
+    assert avg.shape == (3, 1) and dm.shape == (3, 0) and avg["NOMAD"].isna().all()
+    assert open(os.path.join(root, "o2", "nomad_avg.csv")).read().count("\n") == 4
