@@ -255,9 +255,9 @@ def _staged_batches(paths, load, pack, max_batch_samples: int, decode_threads: i
     * ``native_threads > 0``: file headers are probed through the C ABI (``nomad_wav_probe``); the files it can decode are
       converted - and, at another sample rate, resampled to ``target_sr`` - by ``nomad_wav_read_rows`` on that many plain
       host threads, straight into a slot of a ring of pinned staging buffers - no per-file Python, no GIL, no second copy.
-    * every other file (an encoding or a header the native reader does not take, an unreadable file) goes through ``load(path) -> (1, N) array`` on ``decode_threads`` Python worker threads with a bounded
-      look-ahead, so results and exceptions are those of ``load``.  A batch without native files is packed by
-      ``pack(list of 1-D arrays)``.
+    * every other file (an encoding or a header the native reader does not take, an unreadable file) goes through
+      ``load(path) -> (1, N) array`` on ``decode_threads`` Python worker threads with a bounded look-ahead, so results
+      and exceptions are those of ``load``.  A batch without native files is packed by ``pack(list of 1-D arrays)``.
 
     At most ``max_alive`` packed batches exist between the packer and the consumer: the packer takes a token before
     it starts a batch, and the token returns when the consumer asks for the batch AFTER the next one (by then the
