@@ -508,6 +508,24 @@ class Nomad:
             raise Exception(f"Path {path} does not exist")
         return self.get_embeddings_csv(self.model, data)
 
+    def _embed_files_into(self, paths, embeddings: np.ndarray, max_batch_samples: int) -> None:
+        """The file pipeline over ``paths`` -> rows of ``embeddings`` (same order)."""
+        pending = None                                   # (row indices, host copy in flight) of the previous batch
+        for idxs, packed, uploaded in _staged_batches(paths, lambda p: self.load_processing(p, trim=False),
+                                                      self.engine.pack_ragged_host, max_batch_samples, self.DECODE_THREADS,
+                                                      self.PIPELINE_BATCHES, self.NATIVE_WAV_THREADS):
+            prec = self.precision
+            if prec == "bf16x3" and sum(packed[1]) < BF16X3_MIN_SAMPLES:
+                prec = "fp32"   # a handful of files does not fill the 256 x 256 tiles: the exact path is also the faster one
+            emb = self.engine.embed_ragged(None, precision=prec, packed=packed)   # asynchronous
+            uploaded()                                                             # the staging slot is free once the copy is done
+            fetch = self.engine.fetch_async(emb)                                   # D2H enqueued right behind it
+            if pending is not None:
+                embeddings[pending[0]] = pending[1].result()                        # waits for the PREVIOUS batch only
+            pending = (idxs, fetch)
+        if pending is not None:
+            embeddings[pending[0]] = pending[1].result()
+
     def get_embeddings_csv(self, model, file_names, root=False, max_batch_samples: int = 256 * 64000):
         """Embeddings for every row of ``file_names`` (a DataFrame with the path in column 0).
 
@@ -532,21 +550,20 @@ class Nomad:
         lo, hi = partition(len(paths), world, rank) if collective else (0, len(paths))
         mine = paths[lo:hi]
         embeddings = np.zeros((len(mine), EMB_DIM), dtype=np.float32)
-        pending = None                                   # (row indices, host copy in flight) of the previous batch
-        for idxs, packed, uploaded in _staged_batches(mine, lambda p: self.load_processing(p, trim=False),
-                                                      self.engine.pack_ragged_host, max_batch_samples, self.DECODE_THREADS,
-                                                      self.PIPELINE_BATCHES, self.NATIVE_WAV_THREADS):
-            prec = self.precision
-            if prec == "bf16x3" and sum(packed[1]) < BF16X3_MIN_SAMPLES:
-                prec = "fp32"   # a handful of files does not fill the 256 x 256 tiles: the exact path is also the faster one
-            emb = self.engine.embed_ragged(None, precision=prec, packed=packed)   # asynchronous
-            uploaded()                                                             # the staging slot is free once the copy is done
-            fetch = self.engine.fetch_async(emb)                                   # D2H enqueued right behind it
-            if pending is not None:
-                embeddings[pending[0]] = pending[1].result()                        # waits for the PREVIOUS batch only
-            pending = (idxs, fetch)
-        if pending is not None:
-            embeddings[pending[0]] = pending[1].result()
+        failure = None
+        try:
+            self._embed_files_into(mine, embeddings, max_batch_samples)
+        except Exception as e:  # noqa: BLE001 - inside a job the other ranks must hear about it before anybody raises
+            if not collective:
+                raise
+            failure = e
+        if collective:
+            # a rank that failed (an unreadable file in its slice) must not leave the others waiting in the all-gather
+            flags = self._all_gather_rows(torch.tensor([0 if failure is None else 1], dtype=torch.int32)).cpu().tolist()
+            if any(flags):
+                if failure is not None:
+                    raise failure
+                raise RuntimeError(f"get_embeddings_csv: rank(s) {[r for r, f in enumerate(flags) if f]} failed on their files")
         if collective:
             embeddings = self._all_gather_rows(torch.from_numpy(embeddings)).cpu().numpy()
         emb_df = pd.DataFrame(embeddings)

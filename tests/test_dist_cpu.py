@@ -250,3 +250,36 @@ def test_predict_with_an_empty_file_list(tmp_path):
     avg, dm = n.predict("csv", os.path.join(root, "none.csv"), os.path.join(root, "deg.csv"), results_path=os.path.join(root, "o2"))
     assert avg.shape == (3, 1) and dm.shape == (3, 0) and avg["NOMAD"].isna().all()
     assert open(os.path.join(root, "o2", "nomad_avg.csv")).read().count("\n") == 4
+
+
+def _predict_bad_worker(rank, world, port, root):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _file_nomad().predict("dir", os.path.join(root, "nmr"), os.path.join(root, "deg"), results_path=os.path.join(root, "out"))
+        outcome = "no error"
+    except ValueError as e:
+        outcome = f"ValueError: {e}"
+    except RuntimeError as e:
+        outcome = f"RuntimeError: {e}"
+    with open(os.path.join(root, f"outcome{rank}.txt"), "w") as f:
+        f.write(outcome)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_bad_file_on_one_rank_fails_every_rank_instead_of_hanging(tmp_path):
+    """The last degraded file (rank 1's slice) is not a wav: rank 1 raises the front end's ValueError, rank 0 - whose own
+    files were fine - raises too instead of waiting in the all-gather."""
+    root = str(tmp_path)
+    _write_dirs(root, 6, 2)
+    os.makedirs(os.path.join(root, "out"))
+    bad = sorted(os.listdir(os.path.join(root, "deg")))[-1]
+    open(os.path.join(root, "deg", bad), "wb").write(b"RIFFxxxxWAVEnope")
+    listing = os.listdir(os.path.join(root, "deg"))
+    mp.spawn(_predict_bad_worker, args=(2, _free_port(), root), nprocs=2, join=True)
+    outcomes = [open(os.path.join(root, f"outcome{r}.txt")).read() for r in range(2)]
+    owner = 0 if listing.index(bad) < 3 else 1                        # os.listdir order decides whose slice it is in
+    assert outcomes[owner].startswith("ValueError") and bad in outcomes[owner]
+    assert outcomes[1 - owner].startswith("RuntimeError") and f"[{owner}]" in outcomes[1 - owner]
