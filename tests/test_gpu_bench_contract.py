@@ -51,10 +51,9 @@ def test_bench_under_the_distributed_launcher():
 
 
 def test_bench_line_bf16_long_form():
-    """configs[4] (bf16, 30 s clips) through the same contract, small batch: the value comes from the two-stream pass, the
-    roofline from a second pass with the split off."""
+    """configs[4] (bf16, 30 s clips) through the same contract, small batch."""
     out = _run(["--dtype", "bf16", "--seconds", "30", "--batch", "4", "--refs", "1", "--steps", "2", "--warmup", "1",
                 "--no-cpu-baseline"])
     assert out["dtype"] == "bf16" and out["config"]["workload"].startswith("configs[4]")
-    assert out["roofline"]["peak"] == 2500.0 and out["roofline"]["achieved"] > 0 and "note" in out["roofline"]
+    assert out["roofline"]["peak"] == 2500.0 and out["roofline"]["achieved"] > 0
     assert "also_measured" not in out and out["value"] > 0

@@ -274,6 +274,7 @@ def test_repeat_runs_are_bit_identical(engine):
     wav = (0.1 * torch.randn(64, 64000, generator=gen)).clamp(-1, 1).cuda()
     ref = engine.embed(wav).clone()
     ref16 = engine.embed_bf16(wav).clone()
+    refx3 = engine.embed_bf16x3(wav).clone()
     side = torch.cuda.Stream()
     junk = torch.randn(4096, 4096, device="cuda")
     for it in range(12):
@@ -281,8 +282,24 @@ def test_repeat_runs_are_bit_identical(engine):
             for _ in range(4):
                 junk = junk @ junk * 1e-3          # uneven background load on the other queue
         assert torch.equal(engine.embed(wav), ref), it
+        if it % 4 == 2:
+            outx3 = engine.embed_bf16x3(wav)           # two halves on two streams (Engine.X3_SPLIT_ROWS)
+            if not torch.equal(outx3, refx3):
+                rows = torch.nonzero((outx3 != refx3).any(dim=1)).flatten().tolist()
+                pytest.fail(f"iteration {it}: embed_bf16x3 differs from its first result in clips {rows} "
+                            f"(max|diff| {(outx3 - refx3).abs().max().item():.3e})")
         if it % 4 == 0:
-            assert torch.equal(engine.embed_bf16(wav), ref16), it
+            out16 = engine.embed_bf16(wav)
+            if not torch.equal(out16, ref16):     # say what differs before failing: which clips, by how much, and whether it repeats
+                rows = torch.nonzero((out16 != ref16).any(dim=1)).flatten().tolist()
+                again = engine.embed_bf16(wav)
+                torch.cuda.synchronize()
+                stale = [r for r in rows if torch.equal(out16[r], ref[r])]      # rows that hold the fp32 result of the call before?
+                pytest.fail(f"iteration {it}: embed_bf16 differs from its first result in clips {rows} "
+                            f"[of these equal to the fp32 embedding bit for bit: {stale}] "
+                            f"(max|diff| {(out16 - ref16).abs().max().item():.3e}, finite {bool(torch.isfinite(out16).all())}); "
+                            f"the next call {'equals' if torch.equal(again, ref16) else 'differs from'} the first result"
+                            f"{'' if torch.equal(again, ref16) else ' in clips ' + str(torch.nonzero((again != ref16).any(dim=1)).flatten().tolist())}")
     torch.cuda.synchronize()
 
 
