@@ -16,6 +16,18 @@ if len(sys.argv) > 2:
 if len(sys.argv) > 3:
     eng.F32_SPLIT_ROWS = int(sys.argv[3])
 gen = torch.Generator().manual_seed(33)
+if os.environ.get("HUNT_BIG_FIRST") == "1":   # what the suite does before the screen: a 512-clip batch (a main workspace of tens of GB),
+    big = (0.1 * torch.randn(512, 64000, generator=gen)).clamp(-1, 1).cuda()   # long clips, ragged batches, many streams
+    eng.embed(big)
+    eng.embed_bf16(big[:64])
+    eng.embed_bf16x3(big[:64])
+    del big
+    long_ = (0.1 * torch.randn(2, 480000, generator=gen)).clamp(-1, 1).cuda()
+    eng.embed(long_); eng.embed_bf16(long_)
+    eng.embed_ragged([long_[0, :50000], long_[1, :123456], long_[0, :8000]], precision="bf16")
+    del long_
+    _streams = [torch.cuda.Stream() for _ in range(40)]
+    torch.cuda.synchronize()
 wav = (0.1 * torch.randn(64, 64000, generator=gen)).clamp(-1, 1).cuda()
 ref = eng.embed(wav).clone()
 ref16 = eng.embed_bf16(wav).clone()
