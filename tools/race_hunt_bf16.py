@@ -28,6 +28,26 @@ if os.environ.get("HUNT_BIG_FIRST") == "1":   # what the suite does before the s
     del long_
     _streams = [torch.cuda.Stream() for _ in range(40)]
     torch.cuda.synchronize()
+parts = set(filter(None, os.environ.get("HUNT_PARTS", "").split(",")))  # what else of the parity file's life before the screen:
+if parts:                                                                 # a = second engine, b = predict (threads), c = autograd, d = degenerate inputs
+    import tempfile
+    from nomad_amd.nomad import Nomad
+    if "a" in parts:
+        eng2 = Engine(seeded_state_dict(1, qk_gain=6.0), 0)
+        eng2.embed((0.1 * torch.randn(4, 30000, generator=gen)).clamp(-1, 1).cuda())
+    if "b" in parts or "c" in parts:
+        nmd = Nomad(weights=seeded_state_dict(0))
+    if "b" in parts:
+        wavs = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "wavs")
+        with tempfile.TemporaryDirectory() as d:
+            nmd.predict("dir", os.path.join(wavs, "nmr-data"), os.path.join(wavs, "test-data"), results_path=d)
+    if "c" in parts:
+        est = (0.1 * torch.randn(2, 1, 16384, generator=gen)).cuda().requires_grad_(True)
+        nmd.forward(est, (0.1 * torch.randn(2, 1, 16384, generator=gen)).cuda()).backward()
+    if "d" in parts:
+        for kind in (torch.zeros(2, 16000), torch.full((2, 16000), 0.5), torch.ones(2, 16000)):
+            eng.embed(kind.cuda())
+    torch.cuda.synchronize()
 wav = (0.1 * torch.randn(64, 64000, generator=gen)).clamp(-1, 1).cuda()
 ref = eng.embed(wav).clone()
 ref16 = eng.embed_bf16(wav).clone()
