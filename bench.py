@@ -2,8 +2,13 @@
 """NOMAD scoring throughput on MI355X: clips/s embedded + N x M NOMAD distances.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus N --steps K --warmup W        # N > 1 from a plain shell: spawns the N ranks itself (below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+
+Started WITHOUT the launcher's environment (no RANK) and with --gpus N > 1, this process touches no GPU: it starts
+`python -m torch.distributed.run --nproc-per-node N ... bench.py <same arguments>` as a child (one rank per GPU, RCCL),
+relays rank 0's single JSON line and exits with the child's status.
 
 One "step" (per rank) = one pass of the hot path over one batch of synthetic input (BASELINE.json
 configs[1]): 256 clips of 16 kHz x 4 s (224 degraded + 32 non-matching references) through the
@@ -80,6 +85,94 @@ PRECISION_NOTE = {"f32": "fp32", "bf16": "bf16 storage / fp32 accumulate",
                   "bf16x3": "bf16x3 (hi/lo-split operands, 3 bf16 MFMA products, fp32 accumulate; fp32 attention / norms)"}
 
 
+def spawn_ranks(n: int, argv) -> int:
+    """Parent of a multi-GPU run started from a plain shell: N fresh rank processes under torch.distributed.run (this
+    process has not touched the GPU and never will - no exec of an initialised process), rank 0's stdout relayed."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + [a for a in argv if a != "--spawn"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    if res.returncode != 0:
+        print(f"bench.py: the {n}-rank run failed (status {res.returncode}); does this box have {n} GPUs?", file=sys.stderr)
+    return res.returncode if res.returncode != 0 or lines else 1
+
+
+def time_c3(eng, world, rank, use_pg, fence, n_deg=10000, n_ref=1000, batch=256):
+    """BASELINE.json configs[2]: 10 000 degraded x 1 000 non-matching references (16 kHz x 4 s, fp32), clips sharded over the
+    ranks, ONE all-gather of the reference embeddings, each rank's distance slab + row means, one gather of the scores.
+    Strong scaling (the total is fixed); waveforms resident in HBM before the timed region."""
+    import torch
+    from nomad_amd.dist import all_gather_rows, partition
+    (ds, de), (rs, re_) = partition(n_deg, world, rank), partition(n_ref, world, rank)
+    g = torch.Generator(device="cuda").manual_seed(3000 + rank)
+    wav = (0.1 * torch.randn(de - ds + re_ - rs, 64000, generator=g, device="cuda")).clamp(-1, 1)
+
+    def run():
+        emb = torch.cat([eng.embed(wav[i:i + batch]) for i in range(0, wav.shape[0], batch)])
+        ref_all = all_gather_rows(emb[de - ds:].contiguous(), force_collective=use_pg)     # the one data-path collective
+        d, mean = eng.pairwise(emb[:de - ds].contiguous(), ref_all, want_matrix=True)
+        return all_gather_rows(mean, force_collective=use_pg), ref_all, d
+
+    eng.embed(wav[:batch])
+    fence()
+    t0 = time.perf_counter()
+    scores, ref_all, d = run()
+    fence()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    if use_pg:
+        import torch.distributed as dist
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    ok = bool(scores.shape[0] == n_deg and ref_all.shape[0] == n_ref and torch.isfinite(scores).all().item())
+    dt = float(dt.item())
+    return {"workload": f"configs[2]: {n_deg} deg x {n_ref} ref clips of 64000 samples, fp32, clip-sharded x{world}, one all-gather of "
+                        f"the ref embeddings, {n_deg}x{n_ref} float64 distances + means, end to end",
+            "dtype": "f32", "value": round((n_deg + n_ref) / dt, 2), "unit": "clips/s", "seconds": round(dt, 3), "pairs": n_deg * n_ref,
+            "scaling": "strong", "finite": ok}
+
+
+def time_c4(sd, device, steps=10, warmup=3, batch=32, samples=16384):
+    """BASELINE.json configs[3]: nomad.forward() as an auxiliary loss (nomad_loss_test.py:60-79 shapes: 2 x (32,1,16384),
+    T = 50) - per-step latency of the loss forward and of forward + backward to `estimate`, one GPU."""
+    import torch
+    from nomad_amd.nomad import Nomad
+    nmd = Nomad(device=device, weights=sd)
+    g = torch.Generator().manual_seed(0)
+    clean = (0.1 * torch.randn(batch, 1, samples, generator=g)).clamp(-1, 1).to(nmd.DEVICE)
+    est0 = (clean + 0.02 * torch.randn(batch, 1, samples, generator=g).to(nmd.DEVICE)).clamp(-1, 1)
+
+    def fwd():
+        return nmd.forward(est0, clean)
+
+    def fwd_bwd():
+        est = est0.clone().requires_grad_(True)
+        nmd.forward(est, clean).backward()
+        return est.grad
+
+    out = {"workload": f"configs[3]: nomad.forward() on 2 x ({batch},1,{samples}) (T=50), fp32, feature_grad_mult "
+                       f"{nmd.engine.feature_grad_mult:g}, d loss / d estimate through the whole backbone",
+           "dtype": "f32", "steps": steps, "warmup": warmup}
+    for name, fn in (("forward_ms", fwd), ("forward_backward_ms", fwd_bwd)):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = fn()
+        torch.cuda.synchronize()
+        out[name] = round(1e3 * (time.perf_counter() - t0) / steps, 3)
+        out["finite"] = bool(torch.isfinite(r).all().item()) and out.get("finite", True)
+    nmd.engine.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,10 +188,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the extra bf16x3 measurement after the fp32 one")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with hipEvents")
+    ap.add_argument("--weights", choices=("seeded", "peaky"), default="seeded",
+                    help="without a real checkpoint: seeded = PyTorch-default-style random init (near-zero attention logits); "
+                         "peaky = the same with q/k gain 6 (logit sigma ~ 6: softmax rows with a few dominant keys, as "
+                         "trained models have) - the attention kernels are data dependent")
+    ap.add_argument("--spawn", action="store_true",
+                    help="start the ranks through torch.distributed.run even for --gpus 1 (what --gpus N > 1 does by itself)")
     ap.add_argument("--single-stream", action="store_true",
                     help="no two-stream batch split: kernels run alone, as in the pass the roofline is timed in - the command "
                          "the rocprofv3 kernel summaries under profiles/ are taken with")
     args = ap.parse_args()
+    if "RANK" not in os.environ and (args.gpus > 1 or args.spawn):
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))   # before anything touches the GPU in this process
 
     import torch
     import torch.distributed as dist
@@ -115,6 +216,8 @@ def main():
                          f"--nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: nomad_amd has no CPU path")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}, this box has {torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)
     # Under the distributed launcher (RANK / WORLD_SIZE in the environment) the RCCL process group is created at EVERY
     # world size, 1 included, and the all-gather of the reference embeddings is really issued - so a 1-GPU box
@@ -134,7 +237,8 @@ def main():
         dist.barrier()
 
     ckpt = find_checkpoint()
-    sd = load_checkpoint(ckpt) if ckpt else seeded_state_dict(0)
+    peaky = dict(seed=1, qk_gain=6.0)
+    sd = load_checkpoint(ckpt) if ckpt else (seeded_state_dict(**peaky) if args.weights == "peaky" else seeded_state_dict(0))
     eng = Engine(sd, local_rank)
     if args.single_stream:
         eng.F32_SPLIT_ROWS = eng.X3_SPLIT_ROWS = eng.BF16_SPLIT_ROWS = 0
@@ -245,6 +349,54 @@ def main():
             del wav5
         except Exception as e:
             also_c5 = {"workload": "configs[4]", "error": str(e)[:200]}
+    # ... BASELINE.json configs[2] (10 000 x 1 000, end to end, sharded over the ranks of this run) and configs[3]
+    # (nomad.forward() latency, one GPU: rank 0), and the attention kernels' sensitivity to the weights: the headline
+    # workload and configs[4] once more on the "peaky" seeded weights.  All after the headline, never part of `value`.
+    also_c3 = also_c4 = also_peaky = None
+    headline = args.dtype == "f32" and not args.no_also and n_samples == 64000 and B == 256
+    if headline:
+        try:
+            also_c3 = time_c3(eng, world, rank, use_pg, fence)
+        except Exception as e:
+            also_c3 = {"workload": "configs[2]", "error": str(e)[:200]}
+        if rank == 0:
+            try:
+                also_c4 = time_c4(sd, local_rank)
+            except Exception as e:
+                also_c4 = {"workload": "configs[3]", "error": str(e)[:200]}
+    if headline and not ckpt and args.weights == "seeded":
+        try:
+            engp = Engine(seeded_state_dict(**peaky), local_rank)
+            engp.F32_SPLIT_ROWS = engp.BF16_SPLIT_ROWS = 0    # kernels run alone: the per-kernel times below are theirs
+            scp = ShardedScorer(engp.embed, engp.pairwise, equal_shards=True, force_collective=use_pg)
+            res = {"weights": "seeded_state_dict(seed=1, qk_gain=6.0): attention logits with sigma ~ 6 instead of ~ 0"}
+            g5 = torch.Generator().manual_seed(2000 + rank)
+            wav5 = (0.1 * torch.randn(32, 480000, generator=g5)).clamp(-1, 1).cuda()
+            sc5 = ShardedScorer(engp.embed_bf16, engp.pairwise, equal_shards=True, force_collective=use_pg)
+            for key, fn, n_clips, k in (("c2", lambda: scp.score(deg_wav, ref_wav, want_matrix=True), B, args.steps),
+                                        ("c5", lambda: sc5.score(wav5[:28], wav5[28:], want_matrix=True), 32, 5)):
+                for _ in range(2):
+                    fn()
+                fence()
+                engp.profile_enable(True)
+                engp.profile_reset()
+                t1 = time.perf_counter()
+                for _ in range(k):
+                    fn()
+                fence()
+                tp = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
+                pp = engp.profile_read()
+                engp.profile_enable(False)
+                if use_pg:
+                    dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+                res[key] = {"value": round(world * n_clips * k / float(tp.item()), 2), "unit": "clips/s",
+                            "ms_per_step": round(1e3 * float(tp.item()) / k, 3),
+                            "attention_ms_per_step": round(pp["attention_mfma"]["ms"] / k, 3), "single_stream": True}
+            del wav5
+            engp.close()
+            also_peaky = res
+        except Exception as e:
+            also_peaky = {"error": str(e)[:200]}
 
     if rank == 0:
         clips = world * B * args.steps
@@ -266,7 +418,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic (0.1*randn waveforms, seed 1000+rank; " +
-                    ("real nomad_best_model.pt" if ckpt else "seeded random-init wav2vec2-base + head weights") + ")",
+                    ("real nomad_best_model.pt" if ckpt else f"{args.weights} random-init wav2vec2-base + head weights") + ")",
             "config": {"workload": f"{cfg_name}: batch={B} x {n_samples} samples (T={T}) per GPU, wav2vec2-base + "
                                    f"projection head {PRECISION_NOTE[args.dtype]}, {B - n_ref} deg x {n_ref}*N "
                                    f"ref float64 distances + means",
@@ -327,6 +479,12 @@ def main():
             out["also_measured"] = also
         if also_c5:
             out["also_measured_c5"] = also_c5
+        if also_c3:
+            out["also_measured_c3"] = also_c3
+        if also_c4:
+            out["also_measured_c4"] = also_c4
+        if also_peaky:
+            out["also_measured_peaky"] = also_peaky
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, n_samples)
         sys.stdout.flush()

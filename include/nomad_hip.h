@@ -115,6 +115,9 @@ int nomad_embed_ragged(nomad_ctx* ctx, const float* wav_dev, int B, int stride, 
  * sqrt(sum_k (a_k - b_k)^2) like scipy's cdist on float32 inputs promoted to double.
  *   deg_dev [Nd][256] fp32, ref_dev [Nr][256] fp32
  *   dist_dev  optional [Nd][Nr] float64 (out) or NULL;  mean_dev [Nd] float64 (out)
+ * Scratch (row sums per 64-reference tile, 16 MB) is owned by the context, one block PER LAUNCH STREAM: calls on
+ * different streams of one context may be in flight together; the first call on a stream the context has not seen
+ * allocates that stream's block (the only entry point that may allocate after nomad_create).
  */
 int nomad_pairwise(nomad_ctx* ctx, const float* deg_dev, int Nd, const float* ref_dev, int Nr,
                    double* dist_dev, double* mean_dev, nomad_stream_t stream);

@@ -17,7 +17,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnomad_hip.so")
 DIAG_LIB = os.path.join(HERE, "libnomad_diag.so")
 SOURCES = ["nomad_hip.hip"]
-HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip.h")) + [os.path.join("..", "..", "include", "nomad_hip.h")]
+# every header the one translation unit includes: *.hip.h kernels AND plain *.h host code (wav_reader.h)
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "nomad_hip.h")]
 
 
 def hipcc_path() -> str:

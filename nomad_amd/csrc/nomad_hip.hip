@@ -307,7 +307,11 @@ struct nomad_ctx {
     // call only (never for scoring forwards, whose bits must not depend on the batch; never in fine-tuning mode)
     float* splitk_part = nullptr;
     bool splitk_ok = false;
-    double* pair_scratch = nullptr;  // nomad_pairwise: row sums per (64-ref tile, deg row), kPairScratchDoubles doubles
+    // nomad_pairwise: row sums per (64-ref tile, deg row), kPairScratchDoubles doubles PER LAUNCH STREAM - calls on
+    // different streams of one context may be in flight together (Engine / ShardedScorer are driven from side streams), so
+    // each stream gets its own block: the first at nomad_create, further ones on a stream's first call
+    std::vector<std::pair<hipStream_t, double*>> pair_scratch;
+    bool pair_first_bound = false;   // the block allocated at nomad_create has been given to a stream
     // transposed copies for the dX-only backward (built by nomad_enable_backward)
     bool bwd_ready = false;
     float* conv_bw_even[7] = {};  // k=3 layers 1..4: [512][1024] = [W_tap2^T | W_tap0^T]
@@ -367,6 +371,13 @@ struct nomad_ctx {
     double p_fl[NOMAD_K_COUNT] = {};
     bool ev_ready = false;
     bool prof_overflow = false;   // an event could not be created: the counters are incomplete and profile_read says so
+    // libnomad_diag.so only (nomad_diag_set_cksum): per-stage, per-clip checksums of the NEXT bf16 forward's intermediates
+    unsigned long long* cksum = nullptr;
+    int cksum_stages = 0, cksum_segs = 0;
+    // ... and device-to-device copies of up to 4 of those stages' buffers (nomad_diag_set_snapshot)
+    int snap_stage[4] = {-1, -1, -1, -1};
+    void* snap_dst[4] = {};
+    size_t snap_cap[4] = {};
 };
 
 namespace {
@@ -814,11 +825,14 @@ int nomad_create(nomad_ctx** out, int device, const nomad_weights* w) {
     }
     up(w->emb_w, 256 * 768, &c->emb_w);
     up(w->emb_b, 256, &c->emb_b);
-    {
+    if (rc == 0) {
         void* d = nullptr;
-        HIP_TRY(hipMalloc(&d, sizeof(double) * kPairScratchDoubles));
-        c->allocs.push_back(d);
-        c->pair_scratch = static_cast<double*>(d);
+        const hipError_t e = hipMalloc(&d, sizeof(double) * kPairScratchDoubles);
+        if (e != hipSuccess) rc = fail(NOMAD_ERR_HIP, "nomad_create: pairwise scratch: %s", hipGetErrorString(e));
+        else {
+            c->allocs.push_back(d);
+            c->pair_scratch.emplace_back(static_cast<hipStream_t>(nullptr), static_cast<double*>(d));
+        }
     }
     if (rc != 0) {
         nomad_destroy(c);
@@ -1395,6 +1409,60 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
     return 0;
 }
 
+#ifdef NOMAD_DIAG
+// Race hunting (tools/race_hunt_bf16.py): order-independent checksum of `nseg` equal byte segments of a buffer -
+// out[seg] += sum_i word[i] * ((i & 1023) + 1) mod 2^64 (integer adds commute: the value does not depend on scheduling).
+__global__ __launch_bounds__(256) void cksum_kernel(const uint32_t* __restrict__ p, long long words, unsigned long long* __restrict__ out) {
+    const uint32_t* s = p + (long long)blockIdx.y * words;
+    unsigned long long acc = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < words; i += (long long)gridDim.x * 256)
+        acc += (unsigned long long)s[i] * (unsigned long long)((i & 1023) + 1);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out + blockIdx.y, acc);
+}
+// One stage of a forward: segment `seg` of the buffer goes to slot [stage][seg] of the context's checksum table.
+struct CkSum {
+    nomad_ctx* c;
+    hipStream_t s;
+    unsigned long long* tab;
+    int stages, segs, stage = 0;
+    int snap[4];
+    void* sdst[4];
+    size_t scap[4];
+    CkSum(nomad_ctx* c_, hipStream_t s_) : c(c_), s(s_), tab(c_->cksum), stages(c_->cksum_stages), segs(c_->cksum_segs) {
+        for (int k = 0; k < 4; ++k) {
+            snap[k] = c->snap_stage[k];
+            sdst[k] = c->snap_dst[k];
+            scap[k] = c->snap_cap[k];
+            c->snap_stage[k] = -1;
+        }
+        c->cksum = nullptr;  // one forward per nomad_diag_set_cksum / nomad_diag_set_snapshot
+        if (tab) (void)hipMemsetAsync(tab, 0, sizeof(unsigned long long) * stages * segs, s);
+    }
+    void operator()(const void* p, int nseg, size_t seg_bytes) {
+        if (!tab) return;
+        for (int k = 0; k < 4; ++k)
+            if (snap[k] == stage && sdst[k]) {
+                const size_t n = std::min(scap[k], (size_t)nseg * seg_bytes);
+                (void)hipMemcpyAsync(sdst[k], p, n, hipMemcpyDeviceToDevice, s);
+            }
+        if (stage < stages && nseg <= segs && seg_bytes % 4 == 0) {
+            const long long words = (long long)(seg_bytes / 4);
+            const int gx = (int)((words + 256 * 16 - 1) / (256 * 16));
+            hipLaunchKernelGGL(cksum_kernel, dim3(gx < 1 ? 1 : (gx > 256 ? 256 : gx), nseg), dim3(256), 0, s,
+                               static_cast<const uint32_t*>(p), words, tab + (size_t)stage * segs);
+        }
+        ++stage;
+    }
+};
+#else
+struct CkSum {
+    CkSum(nomad_ctx*, hipStream_t) {}
+    void operator()(const void*, int, size_t) {}
+};
+#endif
+
 template <int VPT>
 static void launch_ln_bf16(const bf16_t* in, const float* g, const float* b, bf16_t* out, int M, hipStream_t s) {
     hipLaunchKernelGGL((layernorm_kernel<VPT, bf16_t, bf16_t>), dim3((M + 3) / 4), dim3(256), 0, s, in, g, b, out,
@@ -1451,17 +1519,22 @@ static int forward_bf16(nomad_ctx* c, const float* wav, int B, int n_samples, fl
     float* scale = reinterpret_cast<float*>(ws + lay.scale);
     float* shift = reinterpret_cast<float*>(ws + lay.shift);
     bf16_t* cb[2] = {H(lay.conva), H(lay.convb)};
+    CkSum CK(c, s);  // no-op in the product library
     {
         Scope sc(c, s, NOMAD_K_FRONT, 0.0);
         launch_wav_stats(wav, n_samples, sh.L[0], sh.L[0], B, stats, kNoInts, s);
         hipLaunchKernelGGL(gn_fold_kernel, dim3(B), dim3(512), 0, s, stats, c->conv0_w, c->gn_w, c->gn_b, sh.L[0], scale,
                            shift, static_cast<float*>(nullptr), static_cast<float*>(nullptr), kNoInts);
     }
+    CK(stats, B, sizeof(double) * kStatsPerClip);
+    CK(scale, B, sizeof(float) * 512);
+    CK(shift, B, sizeof(float) * 512);
     {
         Scope sc(c, s, NOMAD_K_FRONT, 2.0 * B * (double)sh.L[0] * 512 * 10);
         hipLaunchKernelGGL(conv0_gn_gelu_kernel<bf16_t>, dim3((sh.L[0] + kConv0Frames - 1) / kConv0Frames, B), dim3(256), 0,
                            s, wav, n_samples, sh.L[0], c->conv0_w, scale, shift, cb[0], kNoInts, kNoInts);
     }
+    CK(cb[0], B, sizeof(bf16_t) * 512 * (size_t)sh.L[0]);
     for (int i = 1; i < 7; ++i) {
         GemmParams p{};
         p.A = asf(cb[(i - 1) % 2]);
@@ -1478,6 +1551,7 @@ static int forward_bf16(nomad_ctx* c, const float* wav, int B, int n_samples, fl
         p.rmap = p.cmap;
         p.gelu = 1;
         if ((rc = run_gemm_bf16(c, p, 1, s))) return rc;
+        CK(cb[i % 2], B, sizeof(bf16_t) * 512 * (size_t)sh.L[i]);
     }
     bf16_t* conv6 = cb[0];
     bf16_t* featln = cb[1];
@@ -1485,6 +1559,7 @@ static int forward_bf16(nomad_ctx* c, const float* wav, int B, int n_samples, fl
         Scope sc(c, s, NOMAD_K_ROW, 0.0);
         launch_ln_bf16<2>(conv6, c->fln_w, c->fln_b, featln, M, s);
     }
+    CK(featln, B, sizeof(bf16_t) * 512 * (size_t)T);
     bf16_t* xpad = H(lay.xpad);
     const long long grp_stride = (long long)B * (T + 128) * 48;
     const RowMap pad_map{64LL * 48, (long long)(T + 128) * 48, T, 48};
@@ -1499,6 +1574,7 @@ static int forward_bf16(nomad_ctx* c, const float* wav, int B, int n_samples, fl
         p.c_colblk_stride = grp_stride;
         if ((rc = run_gemm_bf16(c, p, 1, s))) return rc;
     }
+    CK(xpad, 16 * B, sizeof(bf16_t) * 48 * (size_t)(T + 128));
     bf16_t *x = H(lay.x), *x2 = H(lay.x2), *y = H(lay.y), *qkv = H(lay.qkv), *ctxb = H(lay.ctxb), *hb = H(lay.h);
     {
         GemmParams p{};
@@ -1524,34 +1600,46 @@ static int forward_bf16(nomad_ctx* c, const float* wav, int B, int n_samples, fl
         p.gelu = 1;
         if ((rc = run_gemm_bf16(c, p, 16, s))) return rc;
     }
+    const size_t clip768 = sizeof(bf16_t) * 768 * (size_t)T;
+    CK(y, B, clip768);
     {
         Scope sc(c, s, NOMAD_K_ROW, 0.0);
         launch_ln_bf16<3>(y, c->eln_w, c->eln_b, x, M, s);
     }
+    CK(x, B, clip768);
     for (int l = 0; l < NOMAD_NUM_LAYERS; ++l) {
         const LayerDev& d = c->layers[l];
         if ((rc = run_gemm_bf16(c, dense(asf(x), 768, asf(c->qkv_w16[l]), c->qkv_b16[l], nullptr, asfm(qkv), M, 2304, 768, 0), 1, s)))
             return rc;
+        CK(qkv, B, clip768 * 3);
         {
             Scope sc(c, s, NOMAD_K_ATTN, 4.0 * B * 12.0 * (double)T * T * 64);
             HIP_TRY(run_attention_bf16(qkv, ctxb, B, T, nullptr, true, s));
         }
+        CK(ctxb, B, clip768);
         if ((rc = run_gemm_bf16(c, dense(asf(ctxb), 768, asf(c->o_w16[l]), d.o_b, asf(x), asfm(y), M, 768, 768, 0), 1, s)))
             return rc;
+        CK(y, B, clip768);
         {
             Scope sc(c, s, NOMAD_K_ROW, 0.0);
             launch_ln_bf16<3>(y, d.ln1_w, d.ln1_b, x2, M, s);
         }
+        CK(x2, B, clip768);
         if ((rc = run_gemm_bf16(c, dense(asf(x2), 768, asf(c->fc1_w16[l]), d.fc1_b, nullptr, asfm(hb), M, 3072, 768, 1), 1, s)))
             return rc;
+        CK(hb, B, clip768 * 4);
         if ((rc = run_gemm_bf16(c, dense(asf(hb), 3072, asf(c->fc2_w16[l]), d.fc2_b, asf(x2), asfm(y), M, 768, 3072, 0), 1, s)))
             return rc;
+        CK(y, B, clip768);
         {
             Scope sc(c, s, NOMAD_K_ROW, 0.0);
             launch_ln_bf16<3>(y, d.ln2_w, d.ln2_b, x, M, s);
         }
+        CK(x, B, clip768);
     }
-    return run_head<bf16_t>(c, x, B, T, c->emb_w, c->emb_b, emb, kNoInts, reinterpret_cast<float*>(hb), s);
+    rc = run_head<bf16_t>(c, x, B, T, c->emb_w, c->emb_b, emb, kNoInts, reinterpret_cast<float*>(hb), s);
+    CK(emb, B, sizeof(float) * 256);
+    return rc;
 }
 
 
@@ -2226,6 +2314,45 @@ int nomad_embed_ragged_bf16(nomad_ctx* c, const float* wav, int B, int stride, c
                             void* workspace, size_t workspace_bytes, nomad_stream_t stream) {
     return forward_ragged_bf16(c, wav, B, stride, lengths_host, emb, workspace, workspace_bytes, stream);
 }
+
+#ifdef NOMAD_DIAG
+/* Race hunting: the NEXT nomad_embed_bf16 call on this context writes table[stage][seg] (stages x segs 64-bit sums, device
+ * memory) - stage order: GroupNorm sums, scale, shift, conv0..6, feature LN, padded projection (16 x B segments), pos-conv,
+ * encoder LN, then per layer qkv / ctx / out_proj+res / LN1 / fc1 / fc2+res / LN2, last the embeddings; seg = clip. */
+int nomad_diag_set_cksum(nomad_ctx* c, unsigned long long* table_dev, int stages, int segs) {
+    if (!c) return fail(NOMAD_ERR_INVALID, "null ctx");
+    c->cksum = table_dev;
+    c->cksum_stages = stages;
+    c->cksum_segs = segs;
+    return 0;
+}
+/* ... and copies the buffer of stage `stage` (up to cap bytes) to dst_dev on the forward's stream; slot 0..3. */
+int nomad_diag_set_snapshot(nomad_ctx* c, int slot, int stage, void* dst_dev, size_t cap) {
+    if (!c || slot < 0 || slot > 3) return fail(NOMAD_ERR_INVALID, "nomad_diag_set_snapshot: bad argument");
+    c->snap_stage[slot] = stage;
+    c->snap_dst[slot] = dst_dev;
+    c->snap_cap[slot] = cap;
+    return 0;
+}
+/* The bf16 forward's front end alone: waveform statistics -> GroupNorm scale / shift -> conv0 + GroupNorm + GELU as bf16
+ * out_dev [B][L0][512]; scratch_dev: 8 * 65 * B * (1 + chunks) + 2 * 4 * 512 * B bytes (race hunting: the victim kernel). */
+int nomad_diag_conv0_bf16(nomad_ctx* c, const float* wav, int B, int n_samples, void* out_dev, void* scratch_dev,
+                          nomad_stream_t stream) {
+    Shapes sh;
+    if (!c || !wav || !out_dev || !scratch_dev || !make_shapes(B, n_samples, &sh)) return fail(NOMAD_ERR_INVALID, "nomad_diag_conv0_bf16");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    double* stats = static_cast<double*>(scratch_dev);
+    float* scale = reinterpret_cast<float*>(stats + stats_doubles(B, sh.L[0]));
+    float* shift = scale + 512 * (size_t)B;
+    launch_wav_stats(wav, n_samples, sh.L[0], sh.L[0], B, stats, kNoInts, s);
+    hipLaunchKernelGGL(gn_fold_kernel, dim3(B), dim3(512), 0, s, stats, c->conv0_w, c->gn_w, c->gn_b, sh.L[0], scale, shift,
+                       static_cast<float*>(nullptr), static_cast<float*>(nullptr), kNoInts);
+    hipLaunchKernelGGL(conv0_gn_gelu_kernel<bf16_t>, dim3((sh.L[0] + kConv0Frames - 1) / kConv0Frames, B), dim3(256), 0, s, wav,
+                       n_samples, sh.L[0], c->conv0_w, scale, shift, static_cast<bf16_t*>(out_dev), kNoInts, kNoInts);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+#endif
 
 #ifdef NOMAD_DIAG
 // timeline of the last tile-36 GEMM: out_host[6 * n] = per workgroup {entry, loop start, loop end, stores done, HW_ID, XCC_ID}
@@ -3113,17 +3240,44 @@ int nomad_pairwise(nomad_ctx* c, const float* deg, int Nd, const float* ref, int
     if (!c || !deg || !ref || !mean || Nd <= 0 || Nr <= 0)
         return fail(NOMAD_ERR_INVALID, "nomad_pairwise: bad argument (Nd=%d, Nr=%d)", Nd, Nr);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // per-(ref tile, deg row) partial sums live in a context-owned scratch, one block per launch stream (calls on the same
+    // stream are ordered, calls on different streams must not share it): the block of nomad_create goes to the first
+    // stream that calls, any further stream allocates its own on its first call
+    double* scratch = nullptr;
+    if (!c->pair_first_bound) {
+        c->pair_scratch[0].first = s;
+        c->pair_first_bound = true;
+    }
+    for (const auto& e : c->pair_scratch)
+        if (e.first == s) {
+            scratch = e.second;
+            break;
+        }
+    if (!scratch) {
+        if (c->pair_scratch.size() >= 64) {  // stream handles come and go: recycle the oldest block once everything has drained
+            HIP_TRY(hipDeviceSynchronize());
+            c->pair_scratch.resize(1);
+            c->pair_scratch[0].first = s;
+            scratch = c->pair_scratch[0].second;   // (the dropped blocks stay in allocs and are freed by nomad_destroy)
+        } else {
+            void* d = nullptr;
+            HIP_TRY(hipSetDevice(c->device));
+            HIP_TRY(hipMalloc(&d, sizeof(double) * kPairScratchDoubles));
+            c->allocs.push_back(d);
+            c->pair_scratch.emplace_back(s, static_cast<double*>(d));
+            scratch = static_cast<double*>(d);
+        }
+    }
     Scope sc(c, s, NOMAD_K_PAIR, 3.0 * 256 * (double)Nd * Nr);
-    // per-(ref tile, deg row) partial sums live in a context-owned scratch (allocated at nomad_create: entry points never
-    // allocate); deg rows are processed in slabs that fit it
+    // deg rows are processed in slabs that fit the scratch
     const int ntiles = (Nr + kPairTile - 1) / kPairTile;
     const long long slab_max = (kPairScratchDoubles / ntiles) / kPairTile * kPairTile;
     if (slab_max < kPairTile) return fail(NOMAD_ERR_INVALID, "nomad_pairwise: Nr=%d is too large for the scratch", Nr);
     for (long long d0 = 0; d0 < Nd; d0 += slab_max) {
         const int nd = (int)std::min<long long>(slab_max, Nd - d0);
         hipLaunchKernelGGL(pairwise_tile_kernel, dim3(ntiles, (nd + kPairTile - 1) / kPairTile), dim3(256), 0, s, deg + d0 * 256, nd,
-                           ref, Nr, dist ? dist + d0 * Nr : nullptr, c->pair_scratch);
-        hipLaunchKernelGGL(pairwise_mean_kernel, dim3((nd + 255) / 256), dim3(256), 0, s, c->pair_scratch, ntiles, nd, Nr, mean + d0);
+                           ref, Nr, dist ? dist + d0 * Nr : nullptr, scratch);
+        hipLaunchKernelGGL(pairwise_mean_kernel, dim3((nd + 255) / 256), dim3(256), 0, s, scratch, ntiles, nd, Nr, mean + d0);
     }
     HIP_TRY(hipGetLastError());
     return 0;

@@ -208,10 +208,11 @@ class _StagingRing:
     after it enqueued the copy (``uploaded``), ``take`` waits for it.  With ``max_alive`` staged batches in flight and
     ``max_alive + 1`` slots that wait is already over in practice (the batch three back has had its results fetched)."""
 
-    def __init__(self, slots: int):
+    def __init__(self, slots: int, device=None):
         self.bufs = [None] * slots
         self.events = [None] * slots
         self.taken = 0
+        self.device = device   # the engine's device: the H2D copy runs on ITS current stream, whatever device is current
 
     def take(self, rows: int, stride: int):
         slot = self.taken % len(self.bufs)
@@ -228,7 +229,7 @@ class _StagingRing:
     def uploaded(self, slot: int) -> None:
         if torch.cuda.is_available():
             ev = torch.cuda.Event()
-            ev.record()
+            ev.record(torch.cuda.current_stream(self.device))
             self.events[slot] = ev
 
 
@@ -244,7 +245,7 @@ def _dist_info(group=None):
 
 
 def _staged_batches(paths, load, pack, max_batch_samples: int, decode_threads: int, max_alive: int, native_threads: int = 0,
-                    target_sr: int = 16000):
+                    target_sr: int = 16000, device=None):
     """Generator of (row indices, (staging buffer, lengths), uploaded) batches over ``paths`` in order, built ahead of
     the consumer; the consumer calls ``uploaded()`` once it has enqueued the H2D copy of the staging buffer.
 
@@ -272,7 +273,7 @@ def _staged_batches(paths, load, pack, max_batch_samples: int, decode_threads: i
     out: "queue.Queue" = queue.Queue()
     stop = threading.Event()
     lookahead = max(4 * decode_threads, 16)
-    ring = _StagingRing(max_alive + 1) if native_threads > 0 else None
+    ring = _StagingRing(max_alive + 1, device) if native_threads > 0 else None
     probe_chunk = 2048
 
     def packer():
@@ -367,8 +368,9 @@ class Nomad:
                  feature_grad_mult: Union[None, float] = None, group=None):
         """feature_grad_mult: fairseq's ``Wav2Vec2Model.feature_grad_mult`` - ``forward()``'s gradient w.r.t. ``estimate``
         passes through ``GradMultiply(features, feature_grad_mult)`` at the conv feature extractor's output, exactly as
-        in the reference's backbone (built from wav2vec_small.pt, whose config says 0.1; nomad.py:58).  None = the value
-        in ``pt-models/wav2vec_small.pt`` if that file is present, else 0.1; 1.0 = plain chain rule.
+        in the reference's backbone (built from wav2vec_small.pt, whose config says 0.1; nomad.py:58).  None = 0.1, or
+        the value in the fairseq checkpoint ``$NOMAD_W2V_CHECKPOINT`` names (read with ``weights_only=True``; nothing is
+        unpickled that the caller did not name); 1.0 = plain chain rule.
 
         precision of the embeddings of ``predict`` / ``get_embeddings*``:
         "fp32"   the reference's arithmetic (fp32 MFMA), scores within 1e-4 of the reference;
@@ -513,7 +515,8 @@ class Nomad:
         pending = None                                   # (row indices, host copy in flight) of the previous batch
         for idxs, packed, uploaded in _staged_batches(paths, lambda p: self.load_processing(p, trim=False),
                                                       self.engine.pack_ragged_host, max_batch_samples, self.DECODE_THREADS,
-                                                      self.PIPELINE_BATCHES, self.NATIVE_WAV_THREADS):
+                                                      self.PIPELINE_BATCHES, self.NATIVE_WAV_THREADS,
+                                                      device=getattr(self.engine, "device", None)):
             prec = self.precision
             if prec == "bf16x3" and sum(packed[1]) < BF16X3_MIN_SAMPLES:
                 prec = "fp32"   # a handful of files does not fill the 256 x 256 tiles: the exact path is also the faster one

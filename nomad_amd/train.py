@@ -83,7 +83,10 @@ def load_pretrained(path: str) -> Dict[str, torch.Tensor]:
     """State dict in the NOMAD checkpoint layout from ``checkpoint_path`` (see module docstring)."""
     if path == "seeded":
         return seeded_state_dict(0)
-    obj = torch.load(path, map_location="cpu", weights_only=False)
+    try:  # tensors-only unpickling first; a fairseq checkpoint that pickles its config objects needs the full unpickler,
+        obj = torch.load(path, map_location="cpu", weights_only=True)   # which runs only for this explicitly named file
+    except Exception:
+        obj = torch.load(path, map_location="cpu", weights_only=False)  # (the reference does the same: nomad.py:58)
     if isinstance(obj, dict) and "model" in obj and isinstance(obj["model"], dict):  # fairseq checkpoint
         want = expected_shapes()
         sd = {}

@@ -194,16 +194,19 @@ def feature_grad_mult_of(obj) -> Optional[float]:
     return None if v is None else float(v)
 
 
-def find_feature_grad_mult() -> float:
-    """The value the reference's model would carry: read from ``$NOMAD_W2V_CHECKPOINT`` or
-    ``./pt-models/wav2vec_small.pt`` (the reference's download location, nomad.py:21) when that file is present and
-    un-picklable here, else the wav2vec 2.0 BASE value 0.1."""
-    for cand in (os.environ.get("NOMAD_W2V_CHECKPOINT"), os.path.join("pt-models", "wav2vec_small.pt")):
-        if cand and os.path.isfile(cand):
-            try:
-                v = feature_grad_mult_of(torch.load(cand, map_location="cpu", weights_only=False))
-            except Exception:  # pickled fairseq / omegaconf classes that are not importable here
-                v = None
-            if v is not None:
-                return v
+def find_feature_grad_mult(checkpoint: Optional[str] = None) -> float:
+    """The value the reference's model would carry.  The wav2vec 2.0 BASE constant 0.1 unless the caller names a fairseq
+    checkpoint EXPLICITLY (argument, or ``$NOMAD_W2V_CHECKPOINT``): that file is then read with ``weights_only=True``
+    (no code in the pickle is ever executed) and its ``feature_grad_mult`` used when the restricted unpickler can
+    reach it - fairseq checkpoints that pickle omegaconf / argparse objects cannot be read that way and give 0.1 too.
+    Nothing is read from the working directory implicitly: constructing ``Nomad()`` never unpickles a file the caller
+    did not name."""
+    cand = checkpoint or os.environ.get("NOMAD_W2V_CHECKPOINT")
+    if cand and os.path.isfile(cand):
+        try:
+            v = feature_grad_mult_of(torch.load(cand, map_location="cpu", weights_only=True))
+        except Exception:  # classes the restricted unpickler refuses: fall back to the published BASE value
+            v = None
+        if v is not None:
+            return v
     return W2V_BASE_FEATURE_GRAD_MULT

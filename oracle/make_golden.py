@@ -11,12 +11,20 @@ fairseq->HF key map, runs the reference's head (nomad.py:228-230) and SciPy's ``
 ``np.mean`` (nomad.py:108-111) on top, and stores inputs/outputs as small fixtures.  Neither
 ``transformers`` nor anything under /root/reference travels with the fixtures.
 
+The one piece of the reference's OWN Python that imports with plain torch is ``src/models/networks.py`` (``TripletModel``,
+the twin of nomad.py:214-231, and ``Origw2v``): the embedding fixtures below are produced by THAT class's forward, built
+around the HF backbone through an adapter that answers fairseq's call ``ssl_model(wav, mask=False, features_only=True)``
+with ``{'x': last_hidden_state}`` (``reference_models``).  So squeeze -> mean over time -> ReLU -> Linear -> normalize
+ are pinned to the reference's code, the backbone (a2) to HF.
+
 Fixtures written (data only):
   tests/golden/wavs/*.wav          the reference's six example clips (data/nmr-data, data/test-data)
   tests/golden/hf_example_wavs.npz embeddings (6,256), 2x4 distance matrix + means, per-layer checksums
   tests/golden/hf_tiny.npz         batch of 3 synthetic clips of 6000 samples: full 12 layer outputs + embeddings
   tests/golden/hf_loss.npz         nomad.forward() pins: two (2,1,16384) inputs -> loss and d loss/d estimate
                                    (HF layers + torch L1 + torch autograd)
+  tests/golden/ref_networks.npz    (``python oracle/make_golden.py refnet``) reference TripletModel / Origw2v outputs on the tiny
+                                   batch (both weight sets) and on the six example clips
   tests/golden/hf_grad_fgm.npz     (``python oracle/make_golden.py fgm``) gradients with fairseq's
                                    ``GradMultiply(features, feature_grad_mult)`` hooked onto the HF model's
                                    feature-extractor output: d loss/d estimate of the hf_loss.npz inputs at 0.1, and
@@ -82,6 +90,34 @@ def hf_forward(m, wav):
     return out.last_hidden_state, list(out.hidden_states[1:])
 
 
+class _FairseqCallAdapter(torch.nn.Module):
+    """What the reference's wrappers call (networks.py:16,31; nomad.py:226): ``ssl_model(wav, mask=False,
+    features_only=True)['x']`` - answered by the HF model's last hidden state."""
+
+    def __init__(self, hf):
+        super().__init__()
+        self.hf = hf
+
+    def forward(self, wav, mask=False, features_only=True):
+        assert mask is False and features_only is True
+        return {"x": self.hf(wav).last_hidden_state}
+
+
+def reference_models(hf, sd):
+    """(TripletModel, Origw2v) of /root/reference/src/models/networks.py:4-34, imported from the reference tree (build
+    container only), around ``hf``; the seeded head goes into ``embedding_layer.1`` as nomad.py:63-65 loads it."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("reference_networks", os.path.join(REF, "src", "models", "networks.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ssl = _FairseqCallAdapter(hf)
+    tm = mod.TripletModel(ssl, 768, 256).eval()
+    with torch.no_grad():
+        tm.embedding_layer[1].weight.copy_(sd["embedding_layer.1.weight"])
+        tm.embedding_layer[1].bias.copy_(sd["embedding_layer.1.bias"])
+    return tm, mod.Origw2v(ssl, 768).eval()
+
+
 def hf_head(x, w, b):
     e = torch.nn.functional.linear(torch.relu(x.mean(1)), w, b)
     return torch.nn.functional.normalize(e, dim=1)
@@ -109,6 +145,11 @@ def main():
     sd = seeded_state_dict(0)
     m = hf_model_from_state_dict(sd)
     we, be = sd["embedding_layer.1.weight"], sd["embedding_layer.1.bias"]
+    ref_tm, _ = reference_models(m, sd)   # embeddings come from the reference's TripletModel.forward (networks.py:14-21)
+
+    def ref_embed(model, w):              # (B, N) -> (B, 256): the reference takes (B, 1, N) and squeezes it itself
+        with torch.no_grad():
+            return model(w[:, None, :])
 
     # 1. the reference's own example: 2 deg x 4 ref
     embs, checks = {}, {}
@@ -116,7 +157,8 @@ def main():
         for n in ns:
             wav = read_wav(os.path.join(GOLD, "wavs", d, n + ".wav"))
             x, layers = hf_forward(m, wav)
-            embs[n] = hf_head(x, we, be)[0].numpy()
+            embs[n] = ref_embed(ref_tm, wav)[0].numpy()
+            assert np.abs(embs[n] - hf_head(x, we, be)[0].numpy()).max() < 1e-7
             checks[n] = np.array([[float(l.double().sum()), float(l.double().abs().sum())] for l in layers])
     nmr = np.stack([embs[n] for n in names["nmr-data"]])
     deg = np.stack([embs[n] for n in names["test-data"]])
@@ -132,7 +174,7 @@ def main():
     wav = (0.1 * torch.randn(3, 6000, generator=g)).clamp(-1, 1)
     x, layers = hf_forward(m, wav)
     np.savez(os.path.join(GOLD, "hf_tiny.npz"), wav=wav.numpy(),
-             layers=torch.stack(layers).numpy(), emb=hf_head(x, we, be).numpy())
+             layers=torch.stack(layers).numpy(), emb=ref_embed(ref_tm, wav).numpy())
 
     # 3. peaky-attention variant (qk_gain 6) on the same tiny batch
     sd2 = seeded_state_dict(1, qk_gain=6.0)
@@ -140,7 +182,7 @@ def main():
     x, layers = hf_forward(m2, wav)
     np.savez(os.path.join(GOLD, "hf_tiny_peaky.npz"), wav=wav.numpy(),
              last=x.numpy(), layer0=layers[0].numpy(),
-             emb=hf_head(x, sd2["embedding_layer.1.weight"], sd2["embedding_layer.1.bias"]).numpy())
+             emb=ref_embed(reference_models(m2, sd2)[0], wav).numpy())
 
     # 4. nomad.forward() pins (LossNetLayers' own embedding layer is seeded explicitly)
     g = torch.Generator().manual_seed(7)
@@ -161,6 +203,30 @@ def main():
              emb_w=lw.numpy(), emb_b=lb.numpy(), loss=np.float64(loss.detach()), grad=grad.numpy(),
              terms=np.array([float(torch.nn.functional.l1_loss(a, b)) for a, b in zip(outs[0], outs[1])]))
     print("loss", float(loss))
+
+
+def main_refnet():
+    """tests/golden/ref_networks.npz: outputs of the reference's own TripletModel / Origw2v (networks.py) - the pin of SURVEY.md
+    section 8 rows a1 / a3 / a4 to reference code."""
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    g = torch.Generator().manual_seed(123)
+    wav = (0.1 * torch.randn(3, 6000, generator=g)).clamp(-1, 1)      # the hf_tiny.npz batch
+    out = {"wav": wav.numpy()}
+    for tag, sd in (("seed0", seeded_state_dict(0)), ("peaky", seeded_state_dict(1, qk_gain=6.0))):
+        tm, ow = reference_models(hf_model_from_state_dict(sd), sd)
+        with torch.no_grad():
+            out[f"emb_{tag}"] = tm(wav[:, None, :]).numpy()            # TripletModel.forward: (B,1,N) -> (B,256)
+            out[f"pooled_{tag}"] = ow(wav[:, None, :]).numpy()         # Origw2v.forward: (B,1,N) -> (B,768), mean over time
+            if tag == "seed0":
+                names = [("nmr-data", n) for n in ("FI53_04", "FL67_01", "MJ57_01", "MJ60_10")] + \
+                        [("test-data", n) for n in ("445-123860-0012_NOISE_15", "6563-285357-0042_OPUS_64k")]
+                out["example_names"] = np.array([n for _, n in names])
+                out["example_emb"] = np.stack([tm(read_wav(os.path.join(GOLD, "wavs", d, n + ".wav"))[:, None, :])[0].numpy()
+                                               for d, n in names])
+    np.savez(os.path.join(GOLD, "ref_networks.npz"), **out)
+    old = np.load(os.path.join(GOLD, "hf_tiny.npz"))
+    print("ref TripletModel vs hf_tiny.npz emb: max|diff|", float(np.abs(out["emb_seed0"] - old["emb"]).max()))
 
 
 class _GradMultiply(torch.autograd.Function):
@@ -241,5 +307,7 @@ def main_fgm():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "fgm":
         main_fgm()
+    elif len(sys.argv) > 1 and sys.argv[1] == "refnet":
+        main_refnet()
     else:
         main()

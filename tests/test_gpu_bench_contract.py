@@ -50,6 +50,36 @@ def test_bench_under_the_distributed_launcher():
     assert out["config"]["collective"].startswith("RCCL all_gather_into_tensor executed")
 
 
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus N` from a plain shell (no launcher): the parent starts the ranks under torch.distributed.run
+    and relays rank 0's line - exercised here with one rank (--spawn), and N = 2 on this one-GPU box must fail cleanly."""
+    out = _run(["--gpus", "1", "--spawn", "--steps", "1", "--warmup", "1", "--batch", "8", "--refs", "2", "--no-cpu-baseline", "--no-also"])
+    assert out["n_gpus"] == 1 and out["config"]["collective"].startswith("RCCL all_gather_into_tensor executed")
+    import torch
+    if torch.cuda.device_count() < 2:
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                              "--no-cpu-baseline", "--no-also"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode != 0 and res.stdout.strip() == "" and "2-rank run failed" in res.stderr
+
+
+def test_bench_headline_extras_small():
+    """The extra legs of the default line (configs[2] / configs[3] / peaky weights) through their helper functions at
+    reduced sizes: keys and sanity only."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import bench
+    from nomad_amd.engine import Engine
+    from nomad_amd.weights import seeded_state_dict
+    sd = seeded_state_dict(0)
+    eng = Engine(sd, 0)
+    c3 = bench.time_c3(eng, 1, 0, False, torch.cuda.synchronize, n_deg=40, n_ref=8, batch=16)
+    assert c3["finite"] and c3["pairs"] == 320 and c3["scaling"] == "strong" and c3["value"] > 0
+    c4 = bench.time_c4(sd, 0, steps=2, warmup=1, batch=4)
+    assert c4["finite"] and 0 < c4["forward_ms"] < c4["forward_backward_ms"]
+    eng.close()
+
+
 def test_bench_line_bf16_long_form():
     """configs[4] (bf16, 30 s clips) through the same contract, small batch."""
     out = _run(["--dtype", "bf16", "--seconds", "30", "--batch", "4", "--refs", "1", "--steps", "2", "--warmup", "1",

@@ -160,6 +160,38 @@ def test_load_pretrained_accepts_a_fairseq_style_checkpoint(tmp_path):
     assert torch.equal(load_pretrained(nomad_path)["embedding_layer.1.weight"], sd["embedding_layer.1.weight"])
 
 
+def test_feature_grad_mult_is_never_read_from_an_unnamed_file(tmp_path, monkeypatch):
+    """Nomad() construction must not unpickle ./pt-models/wav2vec_small.pt behind the caller's back: the
+    constant 0.1 unless a checkpoint is NAMED, and then only through the restricted unpickler."""
+    import torch
+    from nomad_amd import weights as W
+    (tmp_path / "pt-models").mkdir()
+    torch.save({"cfg": {"model": {"feature_grad_mult": 0.5}}}, str(tmp_path / "pt-models" / "wav2vec_small.pt"))
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.delenv("NOMAD_W2V_CHECKPOINT", raising=False)
+    calls = []
+    real_load = torch.load
+
+    def spy(*a, **k):
+        calls.append(k.get("weights_only"))
+        return real_load(*a, **k)
+    monkeypatch.setattr(torch, "load", spy)
+    assert W.find_feature_grad_mult() == 0.1 and calls == []
+    named = str(tmp_path / "named.pt")
+    torch.save({"cfg": {"model": {"feature_grad_mult": 0.25}}}, named)
+    assert W.find_feature_grad_mult(named) == 0.25
+    monkeypatch.setenv("NOMAD_W2V_CHECKPOINT", named)
+    assert W.find_feature_grad_mult() == 0.25
+    assert calls == [True, True]                      # never the full unpickler
+
+    class Evil:                                       # a pickle that would run code: refused, constant returned
+        def __reduce__(self):
+            return (os.system, ("true",))
+    evil = str(tmp_path / "evil.pt")
+    torch.save({"cfg": Evil()}, evil)
+    assert W.find_feature_grad_mult(evil) == 0.1
+
+
 # ---- the decode -> pack -> launch pipeline of Nomad.get_embeddings_csv (host logic, fake engine) ----------------------
 class _FakeEngine:
     """Records what the pipeline asks of an Engine; "embeds" a clip as [length, first sample, ...]."""
