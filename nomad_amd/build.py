@@ -36,10 +36,24 @@ def needs_build(lib: str = LIB) -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+# Device code is generated without the packed-FP32 VALU instructions (DESIGN.md "The packed-FP32 hazard": a v_pk_fma_f32 can
+# lose a product while a bf16 MFMA kernel of another stream shares its SIMD).  The flag reaches the host pass too, which
+# prints "not a recognized feature for this target (ignoring feature)" - harmless, and swallowed with the rest of hipcc's
+# stderr on success.  NOMAD_PACKED_FP32=1 builds WITH those instructions (A/B measurements, the reproducer of the hazard).
+NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+
+
+def pk_path(lib: str) -> str:
+    """Where the A/B build WITH packed FP32 of a library goes (tools/race_hunt_*.py, NOMAD_LIB_VARIANT=pk)."""
+    return lib[:-3] + "_pk.so"
+
+
 def _command(lib: str, diag: bool, verbose: bool):
     tmp = lib + f".tmp{os.getpid()}"
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
            "-Wall", "-Wno-unused-function", "-pthread", "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+    if os.environ.get("NOMAD_PACKED_FP32", "0") != "1" and not lib.endswith("_pk.so"):
+        cmd[2:2] = NO_PACKED_FP32
     if diag:
         cmd.insert(1, "-DNOMAD_DIAG")
     if verbose:
@@ -81,9 +95,24 @@ def build_all(force: bool = False) -> dict:
     return took
 
 
+def build_pk_variants() -> dict:
+    """libnomad_hip_pk.so / libnomad_diag_pk.so: the same libraries WITH the packed-FP32 instructions, for A/B runs."""
+    jobs = []
+    for lib, diag in ((pk_path(LIB), False), (pk_path(DIAG_LIB), True)):
+        cmd, tmp = _command(lib, diag, False)
+        jobs.append((lib, tmp, time.perf_counter(), subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+    took = {}
+    for lib, tmp, t0, proc in jobs:
+        _finish(proc, tmp, lib)
+        took[os.path.basename(lib)] = round(time.perf_counter() - t0, 1)
+    return took
+
+
 if __name__ == "__main__":
     import sys
-    if "-v" in sys.argv:
+    if "--pk" in sys.argv:
+        print(build_pk_variants())
+    elif "-v" in sys.argv:
         print(build_library(force=True, verbose=True, diag="--diag" in sys.argv))
     else:
         print(build_all(force=True))

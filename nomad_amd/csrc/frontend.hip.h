@@ -115,7 +115,10 @@ __global__ __launch_bounds__(512) void gn_fold_kernel(const double* __restrict__
 // grid: (ceil(L0/FR), B), 256 threads.  Thread = (4 channels) x (frame parity); samples staged in LDS.
 // out[b][t][c] time-major, c contiguous: each frame is one 2 KB coalesced row.
 constexpr int kConv0Frames = 64;
-template <typename TOut>
+// VAR (libnomad_diag.so, nomad_diag_conv0_bf16 / tools/race_hunt_conv0.py; 0 everywhere else): variants of the kernel that
+// located the packed-FP32 hazard in a build WITH those instructions - bit 0: samples straight from global memory
+// (no LDS: still fails), bit 1: the tap loop kept scalar (no v_pk_fma_f32: never fails).
+template <typename TOut, int VAR = 0>
 __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restrict__ wav, int n_samples, int L0,
                                                             const float* __restrict__ w0, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, TOut* __restrict__ out,
@@ -149,14 +152,17 @@ __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restr
     for (int t = par; t < nfr; t += 2) {
         float xv[10];
 #pragma unroll
-        for (int j = 0; j < 10; ++j) xv[j] = xs[5 * t + j];
+        for (int j = 0; j < 10; ++j) xv[j] = (VAR & 1) ? x[5 * t + j] : xs[5 * t + j];   // VAR bit 0: race-hunt variant without LDS reads
         float4 r;
         float* rp = reinterpret_cast<float*>(&r);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float y = 0.f;
 #pragma unroll
-            for (int j = 0; j < 10; ++j) y = fmaf(w[q][j], xv[j], y);
+            for (int j = 0; j < 10; ++j) {
+                y = fmaf(w[q][j], xv[j], y);
+                if (VAR & 2) asm volatile("" : "+v"(y));   // VAR bit 1: keeps the compiler from pairing channels into v_pk_fma_f32
+            }
             rp[q] = gelu_erf(fmaf(y, sc[q], sh[q]));
         }
         store4p<TOut>(o + (long long)t * 512, out_plane, r);

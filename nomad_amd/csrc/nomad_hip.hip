@@ -23,6 +23,13 @@
 #include <vector>
 
 #include "../../include/nomad_hip.h"
+
+// The device pass of this file is compiled WITHOUT the packed-FP32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 /
+// v_pk_add_f32 / v_pk_mov_b32: nomad_amd/build.py passes -target-feature -packed-fp32-ops).  DESIGN.md, "The packed-FP32
+// hazard": on MI355X a v_pk_fma_f32 whose low half reads the HIGH register of a source pair (op_sel) can lose that product
+// in lanes 48-63 while waves of a bf16 32x32x16-MFMA GEMM from ANOTHER kernel share its SIMD - the cause of the round-2
+// "bf16 nondeterminism".  Those instructions are the compiler's choice (SLP vectorisation of scalar source), so the
+// target feature is off for every kernel rather than relying on kernels never being co-scheduled.
 #include "attention.hip.h"
 #include "attention_bf16_v2.hip.h"
 #include "attention_f32_v2.hip.h"
@@ -2335,9 +2342,10 @@ int nomad_diag_set_snapshot(nomad_ctx* c, int slot, int stage, void* dst_dev, si
     return 0;
 }
 /* The bf16 forward's front end alone: waveform statistics -> GroupNorm scale / shift -> conv0 + GroupNorm + GELU as bf16
- * out_dev [B][L0][512]; scratch_dev: 8 * 65 * B * (1 + chunks) + 2 * 4 * 512 * B bytes (race hunting: the victim kernel). */
+ * out_dev [B][L0][512]; scratch_dev: 8 * 65 * B * (1 + chunks) + 2 * 4 * 512 * B bytes (race hunting: the victim kernel).
+ * variant: conv0_gn_gelu_kernel's VAR (0 = the forward's kernel, bit 0 no LDS, bit 1 scalar tap loop). */
 int nomad_diag_conv0_bf16(nomad_ctx* c, const float* wav, int B, int n_samples, void* out_dev, void* scratch_dev,
-                          nomad_stream_t stream) {
+                          nomad_stream_t stream, int variant) {
     Shapes sh;
     if (!c || !wav || !out_dev || !scratch_dev || !make_shapes(B, n_samples, &sh)) return fail(NOMAD_ERR_INVALID, "nomad_diag_conv0_bf16");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -2347,8 +2355,18 @@ int nomad_diag_conv0_bf16(nomad_ctx* c, const float* wav, int B, int n_samples, 
     launch_wav_stats(wav, n_samples, sh.L[0], sh.L[0], B, stats, kNoInts, s);
     hipLaunchKernelGGL(gn_fold_kernel, dim3(B), dim3(512), 0, s, stats, c->conv0_w, c->gn_w, c->gn_b, sh.L[0], scale, shift,
                        static_cast<float*>(nullptr), static_cast<float*>(nullptr), kNoInts);
-    hipLaunchKernelGGL(conv0_gn_gelu_kernel<bf16_t>, dim3((sh.L[0] + kConv0Frames - 1) / kConv0Frames, B), dim3(256), 0, s, wav,
-                       n_samples, sh.L[0], c->conv0_w, scale, shift, static_cast<bf16_t*>(out_dev), kNoInts, kNoInts);
+    const dim3 grid((sh.L[0] + kConv0Frames - 1) / kConv0Frames, B);
+    bf16_t* out = static_cast<bf16_t*>(out_dev);
+#define NOMAD_C0(V)                                                                                                             \
+    case V:                                                                                                                     \
+        hipLaunchKernelGGL((conv0_gn_gelu_kernel<bf16_t, V>), grid, dim3(256), 0, s, wav, n_samples, sh.L[0], c->conv0_w, scale, \
+                           shift, out, kNoInts, kNoInts, 0LL);                                                                  \
+        break;
+    switch (variant) {
+        NOMAD_C0(0) NOMAD_C0(1) NOMAD_C0(2) NOMAD_C0(3)
+        default: return fail(NOMAD_ERR_INVALID, "nomad_diag_conv0_bf16: variant %d", variant);
+    }
+#undef NOMAD_C0
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -316,15 +316,12 @@ class Engine:
     # Like the bf16x3 path below, bf16 batches with at least this many frames are embedded as two halves on two streams:
     # every GEMM of the path runs one 256 x 256 workgroup per CU, so the partial last round of one half's tiles (the
     # N = 768 GEMMs of 32 clips x 30 s are 2.2 rounds) and its per-tile prologue / epilogue are filled by the other
-    # half's kernels.  A clip's bits do not depend on the batch it is in, so the split changes no result - in principle.
-    # OFF by default since the end of round 2: with the split on, the race screen of tests/test_gpu_parity.py
-    # (test_repeat_runs_are_bit_identical, inside a long pytest session) saw embed_bf16 return slightly different values
-    # (max|diff| 4-6e-4, a bf16 rounding somewhere) for some clips of the FIRST half - the one on the caller's stream - in
-    # about one run of ten; 0 of 40 runs with the split off, 0 of 1 600 calls in a fresh process either way
-    # (tools/race_hunt_bf16.py), and the fp32 and bf16x3 splits never tripped it.  Two bf16 forwards running
-    # concurrently expose a hazard that is not understood yet; until it is, NOMAD_BF16_SPLIT_ROWS=4000
-    # buys +2.7 % on config C5 at that price.
-    BF16_SPLIT_ROWS = int(os.environ.get("NOMAD_BF16_SPLIT_ROWS", 0))
+    # half's kernels.  A clip's bits do not depend on the batch it is in, so the split changes no result.
+    # (Round 2 switched this off because embed_bf16 then differed run to run in ~1 % of the calls.  Round 3 found the cause -
+    # not the split: v_pk_fma_f32 in conv0 lost products while the other half's 128 x 128 bf16 GEMM shared its SIMD, DESIGN.md
+    # "The packed-FP32 hazard" - and the library is now built without packed-FP32 instructions; tests/test_gpu_race_screen.py
+    # holds every precision to bit-identical results with the split on.)  NOMAD_BF16_SPLIT_ROWS overrides; 0 disables.
+    BF16_SPLIT_ROWS = int(os.environ.get("NOMAD_BF16_SPLIT_ROWS", 4000))
 
     def _embed_bf16_into(self, wav: torch.Tensor, emb: torch.Tensor, side: bool):
         B, N = wav.shape

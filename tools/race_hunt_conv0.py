@@ -21,7 +21,8 @@ which = (sys.argv[2] if len(sys.argv) > 2 else "none,forward,gemm1,gemm3,gemm16,
 eng = Engine(seeded_state_dict(0), 0, diag=True)
 lib = eng.lib
 lib.nomad_diag_conv0_bf16.restype = C.c_int
-lib.nomad_diag_conv0_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+lib.nomad_diag_conv0_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+VARIANT = int(os.environ.get("HUNT_VARIANT", 0))   # conv0_gn_gelu_kernel's VAR: bit 0 no LDS, bit 1 scalar tap loop (no v_pk_fma_f32)
 lib.nomad_enable_bf16(eng.ctx)
 gen = torch.Generator().manual_seed(33)
 if os.environ.get("HUNT_PARTS"):   # prior activity in the process, as in tools/race_hunt_stages.py ("d": degenerate inputs)
@@ -34,7 +35,7 @@ wav = wav_all[:B]
 
 
 def conv0(w, out, scratch):
-    rc = lib.nomad_diag_conv0_bf16(eng.ctx, w.data_ptr(), w.shape[0], N, out.data_ptr(), scratch.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    rc = lib.nomad_diag_conv0_bf16(eng.ctx, w.data_ptr(), w.shape[0], N, out.data_ptr(), scratch.data_ptr(), torch.cuda.current_stream().cuda_stream, VARIANT)
     assert rc == 0
 
 
@@ -53,6 +54,7 @@ W768 = (torch.randn(768, 768, generator=gen) * 0.03).to(torch.bfloat16).cuda()
 A1536 = (torch.randn(B * 6399 // 8, 1536, generator=gen) * 0.5).to(torch.bfloat16).cuda()
 W512 = (torch.randn(512, 1536, generator=gen) * 0.03).to(torch.bfloat16).cuda()
 qkv = (torch.randn(M, 2304, generator=gen) * 0.5).to(torch.bfloat16).cuda()
+A768f, W768f = A768.float(), W768.float()
 junk = torch.randn(4096, 4096, device="cuda")
 out2 = torch.empty_like(out)
 scratch2 = torch.empty_like(scratch)
@@ -71,6 +73,12 @@ def aggress(kind):
         elif kind == "gemm1":
             for _ in range(6):
                 eng.diag_gemm_bf16(A768, W768, tile=1)
+        elif kind.startswith("bt"):      # bt<N>: bf16 GEMM diag tile N on the N = 768 shape (0 256x128, 4 64x64, 5 128x128 4 waves,
+            for _ in range(6):           # 6 256x128 4 waves, 7 = gemm1 without its stores, 8 = gemm1 with one K tile, 11 / 12 BK 32 / 3-stage)
+                eng.diag_gemm_bf16(A768, W768, tile=int(kind[2:]))
+        elif kind.startswith("ft"):      # ft<N>: fp32 GEMM diag tile N (31 = 128x128x32 8 waves, 20 = 4 waves, 37 = 64x64, 34 = 128x64)
+            for _ in range(2):
+                eng.diag_gemm(A768f, W768f, tile=int(kind[2:]))
         elif kind == "gemm3":
             for _ in range(3):
                 eng.diag_gemm_bf16(A768, W2304, tile=3)
@@ -108,6 +116,44 @@ def describe(o):
           f"median {float(rel.median()):.2e} max {float(rel.max()):.2e}; zeros among the differing: {int((o[d] == 0).sum())}", flush=True)
 
 
+def gelu64(z):
+    import math
+    return 0.5 * z * (1.0 + math.erf(z / math.sqrt(2.0)))
+
+
+def provenance(o, limit=6):
+    """For a few differing elements: invert the GELU (z >= -0.75 branch) to the conv sum y the kernel must have had, and list
+    A(j0) = y_obs - sum_{j > j0} w_j x_j for every j0 - the value the accumulator held after tap j0 IF the taps after it were
+    applied correctly - next to the ten samples, to see what replaced the accumulator."""
+    import numpy as np
+    sd = eng._state_dict
+    w0 = sd["ssl_model.feature_extractor.conv_layers.0.0.weight"].double().reshape(512, 10).numpy()
+    sc_sh = scratch.cpu()
+    nst = 65 * B * (1 + (L0 + 8191) // 8192)
+    f = sc_sh[8 * nst:8 * nst + 8 * 512 * B].view(torch.float32).double().numpy()
+    scale, shift = f[:512 * B].reshape(B, 512), f[512 * B:].reshape(B, 512)
+    d = torch.nonzero(o.view(torch.int16) != ref_i)[:limit].tolist()
+    wv = wav.double().cpu().numpy()
+    for b, t, c in d:
+        x = wv[b, 5 * t:5 * t + 10]
+        y_ref = float((w0[c] * x).sum())
+        o_obs, o_ref = float(o[b, t, c].float()), float(ref[b, t, c].float())
+        lo, hi = -0.75, 30.0
+        for _ in range(80):
+            mid = 0.5 * (lo + hi)
+            if gelu64(mid) < o_obs:
+                lo = mid
+            else:
+                hi = mid
+        z = 0.5 * (lo + hi)
+        y_obs = (z - shift[b, c]) / scale[b, c]
+        tail = np.cumsum((w0[c] * x)[::-1])[::-1]          # tail[j] = sum_{k >= j} w_k x_k
+        A = [y_obs - (tail[j0 + 1] if j0 + 1 < 10 else 0.0) for j0 in range(-1, 10)]
+        print(f"      elem (clip {b}, frame {t}, ch {c} = lane {(c // 4) % 64} q {c % 4}): out {o_obs:+.4f} ref {o_ref:+.4f}; y_ref {y_ref:+.5f} y_obs~{y_obs:+.5f} "
+              f"(scale {scale[b, c]:.3f} shift {shift[b, c]:+.3f})\n        A(j0=-1..9) = {[round(a, 4) for a in A]}\n        x = {[round(float(v), 4) for v in x]}\n"
+              f"        w = {[round(float(v), 4) for v in w0[c]]}", flush=True)
+
+
 for kind in which:
     t_end = time.time() + secs
     calls = bad = 0
@@ -122,5 +168,7 @@ for kind in which:
                 if bad <= 3:
                     print(f"  [{kind}] call {calls}: conv0 output differs", flush=True)
                     describe(out)
+                    if bad <= 2 and os.environ.get("HUNT_PROVENANCE", "1") == "1":
+                        provenance(out)
     torch.cuda.synchronize()
-    print(f"aggressor {kind}: conv0 mismatches {bad}/{calls}", flush=True)
+    print(f"variant {VARIANT} aggressor {kind}: conv0 mismatches {bad}/{calls}", flush=True)
