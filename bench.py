@@ -140,36 +140,47 @@ def time_c3(eng, world, rank, use_pg, fence, n_deg=10000, n_ref=1000, batch=256)
 
 def time_c4(sd, device, steps=10, warmup=3, batch=32, samples=16384):
     """BASELINE.json configs[3]: nomad.forward() as an auxiliary loss (nomad_loss_test.py:60-79 shapes: 2 x (32,1,16384),
-    T = 50) - per-step latency of the loss forward and of forward + backward to `estimate`, one GPU."""
+    T = 50) - per-step latency of the loss forward and of forward + backward to `estimate`, one GPU.  fp32 (the reference's
+    arithmetic) and, next to it, Nomad(precision="bf16x3") (three bf16 MFMA products per fp32 product in every GEMM)."""
     import torch
     from nomad_amd.nomad import Nomad
-    nmd = Nomad(device=device, weights=sd)
     g = torch.Generator().manual_seed(0)
-    clean = (0.1 * torch.randn(batch, 1, samples, generator=g)).clamp(-1, 1).to(nmd.DEVICE)
-    est0 = (clean + 0.02 * torch.randn(batch, 1, samples, generator=g).to(nmd.DEVICE)).clamp(-1, 1)
+    clean_h = (0.1 * torch.randn(batch, 1, samples, generator=g)).clamp(-1, 1)
+    noise_h = 0.02 * torch.randn(batch, 1, samples, generator=g)
+    out = {"workload": f"configs[3]: nomad.forward() on 2 x ({batch},1,{samples}) (T=50), d loss / d estimate through the whole "
+                       f"backbone (feature_grad_mult 0.1)", "dtype": "f32", "steps": steps, "warmup": warmup, "finite": True}
+    losses = {}
+    for prec in ("fp32", "bf16x3"):
+        nmd = Nomad(device=device, weights=sd, precision=prec)
+        clean = clean_h.to(nmd.DEVICE)
+        est0 = (clean + noise_h.to(nmd.DEVICE)).clamp(-1, 1)
 
-    def fwd():
-        return nmd.forward(est0, clean)
+        def fwd():
+            return nmd.forward(est0, clean)
 
-    def fwd_bwd():
-        est = est0.clone().requires_grad_(True)
-        nmd.forward(est, clean).backward()
-        return est.grad
+        def fwd_bwd():
+            est = est0.clone().requires_grad_(True)
+            nmd.forward(est, clean).backward()
+            return est.grad
 
-    out = {"workload": f"configs[3]: nomad.forward() on 2 x ({batch},1,{samples}) (T=50), fp32, feature_grad_mult "
-                       f"{nmd.engine.feature_grad_mult:g}, d loss / d estimate through the whole backbone",
-           "dtype": "f32", "steps": steps, "warmup": warmup}
-    for name, fn in (("forward_ms", fwd), ("forward_backward_ms", fwd_bwd)):
-        for _ in range(warmup):
-            fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            r = fn()
-        torch.cuda.synchronize()
-        out[name] = round(1e3 * (time.perf_counter() - t0) / steps, 3)
-        out["finite"] = bool(torch.isfinite(r).all().item()) and out.get("finite", True)
-    nmd.engine.close()
+        res = {}
+        for name, fn in (("forward_ms", fwd), ("forward_backward_ms", fwd_bwd)):
+            for _ in range(warmup):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                r = fn()
+            torch.cuda.synchronize()
+            res[name] = round(1e3 * (time.perf_counter() - t0) / steps, 3)
+            out["finite"] = bool(torch.isfinite(r).all().item()) and out["finite"]
+        losses[prec] = float(fwd())
+        nmd.engine.close()
+        if prec == "fp32":
+            out.update(res)
+        else:
+            res["loss_rel_diff_vs_f32"] = abs(losses["bf16x3"] - losses["fp32"]) / abs(losses["fp32"])
+            out["precision_bf16x3"] = res
     return out
 
 
@@ -460,9 +471,9 @@ def main():
             out["roofline"] = {"bound": "mfma", "kernel": kname,
                                "achieved": round(ach, 2), "peak": round(peak / 1e12, 1), "unit": "TFLOP/s",
                                "frac": round(ach * 1e12 / peak, 4), "traffic": traffic,
-                               "traffic_source": ("profiles/pmc_traffic.json (STATIC: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                                  "passes of this command taken earlier (round 2) by tools/gpu_pmc_traffic.sh, not measured "
-                                                  "in this run)" if traffic is not None else None),
+                               "traffic_source": (f"profiles/pmc_traffic.json (STATIC: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                                  f"passes of this command taken earlier ({traffic_tab.get('taken', 'round 2')}) by "
+                                                  f"tools/gpu_pmc_traffic.sh, not measured in this run)" if traffic is not None else None),
                                "algorithmic_bytes_per_launch": alg_bytes,
                                "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4),
                                "algorithmic_gflop_per_launch": round(dom["flops"] / max(dom["launches"], 1) / 1e9, 3),

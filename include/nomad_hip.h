@@ -161,6 +161,17 @@ int nomad_enable_backward(nomad_ctx* ctx);
  * Applies to nomad_embed_backward only (the fine-tuning step never reaches the frozen extractor).
  */
 int nomad_set_feature_grad_mult(nomad_ctx* ctx, float mult);
+/*
+ * Arithmetic of the fp32-layout GEMMs (nomad_embed, nomad_embed_ragged, nomad_embed_train, nomad_embed_backward,
+ * nomad_train_backward): mode 0 (default) exact fp32 MFMA (v_mfma_f32_32x32x2_f32, the reference's arithmetic); mode 1
+ * "bf16x3 products": every product a*w as a_hi*w_hi + a_hi*w_lo + a_lo*w_hi on the bf16 matrix cores, hi = bf16(x),
+ * lo = bf16(x - hi) made in registers, fp32 accumulation - all buffers, epilogues and every other kernel unchanged.  A GEMM
+ * is then within ~3e-5 (relative) of the fp32 one and its K loop ~5x shorter: for the small-M problems of Nomad.forward()
+ * (nomad.py:142-146 at the shapes of nomad_loss_test.py:60-79) and of the fine-tuning step.  Opt-in: Nomad(precision=
+ * "bf16x3").  The pos-conv and attention kernels stay fp32.
+ */
+int nomad_set_gemm_precision(nomad_ctx* ctx, int mode);
+int nomad_get_gemm_precision(const nomad_ctx* ctx, int* mode);
 int nomad_get_feature_grad_mult(const nomad_ctx* ctx, float* mult);
 int nomad_saved_bytes(const nomad_ctx* ctx, int B, int n_samples, size_t* bytes);
 int nomad_backward_workspace_bytes(const nomad_ctx* ctx, int B, int n_samples, size_t* bytes);

@@ -52,6 +52,8 @@ SIGNATURES = {
     "nomad_enable_backward": (C.c_int, [C.c_void_p]),
     "nomad_set_feature_grad_mult": (C.c_int, [C.c_void_p, C.c_float]),
     "nomad_get_feature_grad_mult": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "nomad_set_gemm_precision": (C.c_int, [C.c_void_p, C.c_int]),
+    "nomad_get_gemm_precision": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "nomad_saved_bytes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     "nomad_backward_workspace_bytes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     "nomad_embed_train": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_size_t, _fp,

@@ -16,6 +16,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "dtypes.hip.h"
+
 namespace nomad {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -343,6 +345,42 @@ __device__ __forceinline__ void dma16_buffer(const float* base, lptr_t dst, int 
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voff, soff, 0, 0);
 }
 
+// X3 variant of the kernel below: hi = bf16(x), lo = bf16(x - hi) of 8 consecutive k values held by one lane - the operand
+// fragments of v_mfma_f32_32x32x16_bf16, made in registers from the fp32 LDS image (nothing is stored split).
+// The low halves x - hi come from v_dot2c_f32_bf16 (acc += a.lo * b.lo + a.hi * b.hi on packed bf16 pairs) with the constant
+// pairs (-1, 0) / (0, -1) and x as the accumulator: one instruction per value instead of unpack + subtract (the difference is
+// exactly representable, so the dot unit's internal rounding cannot matter).  16 VALU instructions per 8 values instead of 24:
+// the kernel is VALU-bound on this split at one 32 x 32 accumulator per wave.
+// The two constant pairs live in VGPRs filled from 32-bit literals (split_consts): written as compile-time constants the
+// compiler encodes (-1, 0) as the INLINE constant -1.0, which the instruction reads as an fp16 -1.0 (0xBC00) in a bf16 operand
+// - measured: embeddings off by 0.25.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+struct SplitConsts {
+    bf16x2_t m0, m1;   // (-1, 0) and (0, -1)
+};
+__device__ __forceinline__ SplitConsts split_consts() {
+    unsigned a, b;
+    asm volatile("v_mov_b32 %0, 0x0000bf80\n\tv_mov_b32 %1, 0xbf800000" : "=v"(a), "=v"(b));
+    SplitConsts c;
+    c.m0 = __builtin_bit_cast(bf16x2_t, a);
+    c.m1 = __builtin_bit_cast(bf16x2_t, b);
+    return c;
+}
+__device__ __forceinline__ void split_frag8(const f32x4& a, const f32x4& b, const SplitConsts& k, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; e += 2) {
+        bf16x2_t ha, hb;
+        ha[0] = (bf16_t)a[e]; ha[1] = (bf16_t)a[e + 1];
+        hb[0] = (bf16_t)b[e]; hb[1] = (bf16_t)b[e + 1];
+        hi[e] = ha[0]; hi[e + 1] = ha[1];
+        hi[4 + e] = hb[0]; hi[4 + e + 1] = hb[1];
+        lo[e] = (bf16_t)__builtin_amdgcn_fdot2_f32_bf16(ha, k.m0, a[e], false);
+        lo[e + 1] = (bf16_t)__builtin_amdgcn_fdot2_f32_bf16(ha, k.m1, a[e + 1], false);
+        lo[4 + e] = (bf16_t)__builtin_amdgcn_fdot2_f32_bf16(hb, k.m0, b[e], false);
+        lo[4 + e + 1] = (bf16_t)__builtin_amdgcn_fdot2_f32_bf16(hb, k.m1, b[e + 1], false);
+    }
+}
+
 // STAGES = 2: double-buffered LDS, __syncthreads() (vmcnt(0) + barrier) once per K tile.
 // STAGES = 3: the DMA of tile kt+2 is issued while tile kt is multiplied; the wait before the barrier is a
 //             COUNTED vmcnt that leaves tile kt+1's loads in flight, and the barrier is the raw s_barrier
@@ -350,7 +388,13 @@ __device__ __forceinline__ void dma16_buffer(const float* base, lptr_t dst, int 
 // NOEPI: timing-only ablation (no epilogue stores).
 // OPT (experiments, results unchanged): bit 0 = epilogue slabs fenced per wave (lgkmcnt) instead of per workgroup
 //      (__syncthreads also waits for the previous slab's global stores); bit 1 = s_setprio(1) around the MFMA cluster.
-template <int BM, int BN, int BK, int WM, int WN, int STAGES = 2, bool NOEPI = false, int OPT = 0>
+// X3 ("bf16x3 products on fp32 buffers"): same operands, staging, LDS image and epilogue, but every fp32 product a*w is
+//      formed as a_hi*w_hi + a_hi*w_lo + a_lo*w_hi on v_mfma_f32_32x32x16_bf16 (fp32 accumulate; the dropped a_lo*w_lo is
+//      2^-16 relative), the hi / lo halves made in registers from the fp32 fragments.  Per 32-deep K tile a 32 x 32
+//      accumulator costs 6 MFMAs of 32 cycles instead of 16 of 64: the K loop of the small-M problems (config C4:
+//      M = 1600 rows, one round of 64 x 64 tiles, where one wave's serial K loop IS the launch time) is ~5x shorter.
+//      Every X3 instantiation contracts k in the same order, so the tile choice changes no result bit, as in fp32.
+template <int BM, int BN, int BK, int WM, int WN, int STAGES = 2, bool NOEPI = false, int OPT = 0, bool X3 = false>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_glds_kernel(const GemmParams p) {
     using Cfg = GldsCfg<BM, BN, BK, WM, WN, STAGES>;
     constexpr int TM = Cfg::TM, TN = Cfg::TN, NT = Cfg::THREADS, KC = Cfg::KC, RB = Cfg::RB;
@@ -442,6 +486,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_glds_kernel(const GemmPa
     const int a_row_off = (wm * Cfg::WTM + frag_row) * BK;
     const int b_row_off = (wn * Cfg::WTN + frag_row) * BK;
 
+    SplitConsts sk{};
+    if (X3) sk = split_consts();
     int cur = 0;  // LDS buffer of tile kt
     for (int kt = 0; kt < nk; ++kt) {
         if (STAGES == 2) {
@@ -461,6 +507,29 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_glds_kernel(const GemmPa
         if (!(OPT & 8) && nxt < nk) NOMAD_GLDS_TILE(nxt, nb)
         const float* as = As + cur * BM * BK + a_row_off;
         const float* bs = Bs + cur * BN * BK + b_row_off;
+        if (X3) {
+            static_assert(!X3 || BK % 16 == 0, "X3 needs 16-deep k steps");
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {   // lane (row, h) holds k = 16 ks + 8 h .. + 7: logical chunks 4 ks + 2 h, + 1
+                if ((OPT & 8) && ks == (BK / 16) - 1 && nxt < nk) NOMAD_GLDS_TILE(nxt, nb)
+                const int c0 = ((4 * ks + 2 * h) ^ swz) * 4, c1 = ((4 * ks + 2 * h + 1) ^ swz) * 4;
+                bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    split_frag8(*reinterpret_cast<const f32x4*>(as + i * 32 * BK + c0), *reinterpret_cast<const f32x4*>(as + i * 32 * BK + c1), sk, ah[i], al[i]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    split_frag8(*reinterpret_cast<const f32x4*>(bs + j * 32 * BK + c0), *reinterpret_cast<const f32x4*>(bs + j * 32 * BK + c1), sk, bh[j], bl[j]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+        } else
 #pragma unroll
         for (int kq = 0; kq < BK / 8; ++kq) {
             if ((OPT & 8) && kq == 1 && nxt < nk) NOMAD_GLDS_TILE(nxt, nb)
@@ -554,14 +623,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_glds_kernel(const GemmPa
 }
 
 // persist_blocks > 0: launch at most that many workgroups, each walking several tiles (see the kernel)
-template <int BM, int BN, int BK, int WM, int WN, int STAGES = 2, bool NOEPI = false, int OPT = 0>
+template <int BM, int BN, int BK, int WM, int WN, int STAGES = 2, bool NOEPI = false, int OPT = 0, bool X3 = false>
 inline hipError_t launch_gemm_glds(GemmParams p, int groups, hipStream_t s, int extra_lds = 0, int persist_blocks = 0) {
     using Cfg = GldsCfg<BM, BN, BK, WM, WN, STAGES>;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = p.N / BN;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_glds_kernel<BM, BN, BK, WM, WN, STAGES, NOEPI, OPT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_glds_kernel<BM, BN, BK, WM, WN, STAGES, NOEPI, OPT, X3>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -569,7 +638,7 @@ inline hipError_t launch_gemm_glds(GemmParams p, int groups, hipStream_t s, int 
     int gx = p.tiles_m * p.tiles_n;
     if (persist_blocks > 0 && gx > persist_blocks) gx = persist_blocks;
     dim3 grid(gx, groups);
-    hipLaunchKernelGGL((gemm_f32_glds_kernel<BM, BN, BK, WM, WN, STAGES, NOEPI, OPT>), grid, dim3(Cfg::THREADS),
+    hipLaunchKernelGGL((gemm_f32_glds_kernel<BM, BN, BK, WM, WN, STAGES, NOEPI, OPT, X3>), grid, dim3(Cfg::THREADS),
                        Cfg::LDS_BYTES + extra_lds, s, p);
     return hipGetLastError();
 }

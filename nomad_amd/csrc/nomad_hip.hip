@@ -355,6 +355,9 @@ struct nomad_ctx {
     // fairseq Wav2Vec2Model.feature_grad_mult: the gradient entering the conv feature extractor is scaled by this
     // (GradMultiply on the extractor's output); 0.1 in the wav2vec 2.0 BASE config that wav2vec_small.pt carries
     float feature_grad_mult = 0.1f;
+    // nomad_set_gemm_precision: 1 = the fp32-layout GEMMs (forward, nomad_embed_train, backward, dW) form their products as
+    // three bf16 MFMA products over hi / lo halves split in registers (gemm_f32_glds_kernel<..., X3>); buffers stay fp32
+    int gemm_x3 = 0;
     unsigned long long drop_seed = 0;
     unsigned layer_mask = 0xFFFu;  // bit l set: encoder layer l runs (LayerDrop clears bits)
     // A training batch may be several equal groups of clips ("branches": anchor | positive | negative), each with
@@ -504,6 +507,18 @@ int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, in
     const double flops = 2.0 * p.M * (double)p.n_valid * p.K * groups;
     Scope sc(c, s, NOMAD_K_GEMM, flops, tile == 33 ? NOMAD_K_GEMM_BIG : ((tile == 34 || tile == 31 || tile == 48) ? NOMAD_K_GEMM_FINE : -1));
     hipError_t e;
+    if (c->gemm_x3 && (tile == 20 || tile == 31 || tile == 33 || tile == 34 || tile == 37)) {
+        // bf16x3 products on the same fp32 operands (nomad_set_gemm_precision): same tiles, staging and epilogues
+        switch (tile) {
+            case 20: e = launch_gemm_glds<128, 128, 32, 2, 2, 2, false, 12, true>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 2, 2>::LDS_BYTES)); break;
+            case 31: e = launch_gemm_glds<128, 128, 32, 4, 2, 2, false, 12, true>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 4, 2>::LDS_BYTES)); break;
+            case 33: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13, true>(p, groups, s); break;
+            case 34: e = launch_gemm_glds<128, 64, 32, 4, 2, 3, false, 12, true>(p, groups, s); break;
+            default: e = launch_gemm_glds<64, 64, 32, 2, 2, 3, false, 12, true>(p, groups, s); break;
+        }
+        if (e != hipSuccess) return fail(NOMAD_ERR_HIP, "gemm (bf16x3 products) launch: %s", hipGetErrorString(e));
+        return 0;
+    }
     switch (tile) {
         // the instantiations pick_tile() / the pos-conv can select
         case 20: e = launch_gemm_glds<128, 128, 32, 2, 2, 2, false, 12>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 2, 2>::LDS_BYTES)); break;
@@ -3021,6 +3036,18 @@ int refresh_weights(nomad_ctx* c, hipStream_t s) {
 }  // namespace
 
 extern "C" {
+
+int nomad_set_gemm_precision(nomad_ctx* c, int mode) {
+    if (!c || (mode != 0 && mode != 1)) return fail(NOMAD_ERR_INVALID, "nomad_set_gemm_precision: mode must be 0 (fp32 MFMA) or 1 (bf16x3 products)");
+    c->gemm_x3 = mode;
+    return 0;
+}
+
+int nomad_get_gemm_precision(const nomad_ctx* c, int* mode) {
+    if (!c || !mode) return fail(NOMAD_ERR_INVALID, "nomad_get_gemm_precision: null argument");
+    *mode = c->gemm_x3;
+    return 0;
+}
 
 int nomad_set_feature_grad_mult(nomad_ctx* c, float mult) {
     if (!c || !(mult >= 0.f)) return fail(NOMAD_ERR_INVALID, "nomad_set_feature_grad_mult: bad argument");

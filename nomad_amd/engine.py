@@ -489,6 +489,21 @@ class Engine:
     def feature_grad_mult(self, mult: float):
         _lib.check(self.lib.nomad_set_feature_grad_mult(self.ctx, float(mult)), "nomad_set_feature_grad_mult")
 
+    @property
+    def gemm_precision(self) -> str:
+        """"fp32" (exact fp32 MFMA, the default) or "bf16x3" (three bf16 MFMA products over hi / lo halves split in
+        registers, fp32 accumulation) for the GEMMs of ``embed`` / ``embed_ragged`` / ``embed_train`` / the backward passes;
+        buffers and every other kernel stay fp32 (``nomad_set_gemm_precision``)."""
+        v = C.c_int()
+        _lib.check(self.lib.nomad_get_gemm_precision(self.ctx, C.byref(v)), "nomad_get_gemm_precision")
+        return "bf16x3" if v.value else "fp32"
+
+    @gemm_precision.setter
+    def gemm_precision(self, mode: str):
+        if mode not in ("fp32", "bf16x3"):
+            raise ValueError("gemm_precision must be 'fp32' or 'bf16x3'")
+        _lib.check(self.lib.nomad_set_gemm_precision(self.ctx, int(mode == "bf16x3")), "nomad_set_gemm_precision")
+
     def enable_backward(self):
         _lib.check(self.lib.nomad_enable_backward(self.ctx), "nomad_enable_backward")
 

@@ -170,9 +170,12 @@ class _NomadLossFn(torch.autograd.Function):
         return dwav.reshape(ctx.shape), None, None
 
 
-# precision="bf16x3" pays off from about 8 clips of 4 s per batch (measured on MI355X, profiles/r01_bf16x3_small_batch.txt:
-# 2 clips 5.1 ms vs 3.2 ms in fp32, 8 clips 5.4 vs 6.1 ms, 32 clips 8.1 vs 17.3 ms); smaller batches take the fp32 path.
-BF16X3_MIN_SAMPLES = 8 * 64000
+# precision="bf16x3": from about 2 500 frames per batch (12 clips of 4 s, 50 of 1 s) the split-storage forward (256 x 256 tiles,
+# embed_bf16x3) is the fastest; below that the batch stays on fp32 buffers with the same three-product arithmetic in its
+# small-tile GEMMs (Engine.gemm_precision = "bf16x3").  Measured on MI355X (tools/bench_small_batch.py,
+# profiles/r03_small_batch.jsonl; fp32 / x3 products on fp32 buffers / split storage, ms): 8 clips of 4 s 5.96 / 4.33 / 5.32,
+# 16 clips 9.44 / 6.64 / 5.84, 32 clips of 1 s (config C4's branch) 5.75 / 4.18 / 5.22, 64 clips of 1 s 9.15 / 6.38 / 5.77.
+BF16X3_MIN_SAMPLES = 800_000
 
 
 def _write_rounded_csv(df: pd.DataFrame, path: str) -> None:
@@ -376,9 +379,11 @@ class Nomad:
         "fp32"   the reference's arithmetic (fp32 MFMA), scores within 1e-4 of the reference;
         "bf16x3" GEMM operands split into hi + lo bf16 planes, three bf16 MFMA products per fp32 product, fp32
                  accumulation / softmax / norms: scores within ~1e-6 of the fp32 path, 2.7x as fast on full batches
-                 (batches of fewer than BF16X3_MIN_SAMPLES samples run the fp32 path, which is faster there);
+                 (batches of fewer than BF16X3_MIN_SAMPLES samples stay on fp32 buffers, with the same three-product
+                 arithmetic in their GEMMs: ``Engine.gemm_precision``); ``forward()``'s differentiated branch and its
+                 backward run that way too;
         "bf16"   bf16 storage, fp32 accumulation: scores within ~5e-4 of fp32, fastest on long recordings.
-        ``forward()`` (the training loss) is always fp32."""
+        ``forward()`` (the training loss) is fp32 unless precision is "bf16x3"."""
         if precision not in ("fp32", "bf16x3", "bf16"):
             raise ValueError("precision must be 'fp32', 'bf16x3' or 'bf16'")
         self.precision = precision
@@ -402,6 +407,11 @@ class Nomad:
         self.group = group   # torch.distributed group predict() shards its files over (None: the default group, if any)
         self.engine = Engine(sd, dev_index)
         self.engine.feature_grad_mult = find_feature_grad_mult() if feature_grad_mult is None else float(feature_grad_mult)
+        if precision == "bf16x3":
+            # everything that stays on fp32 buffers in this mode - batches too small for the split-storage path, and the
+            # differentiated branch of forward() with its backward - forms its GEMM products as three bf16 MFMA products
+            # as well (hi / lo halves split in registers): ~1e-6 on scores, ~5x shorter K loops on the small-M problems
+            self.engine.gemm_precision = "bf16x3"
         self.model = TripletModel(self.engine)
         self.lossnet_layers = LossNetLayers(self.engine, SSL_OUT_DIM, EMB_DIM, precision)
         self.nomad_loss = NomadLoss(self.engine)

@@ -149,6 +149,9 @@ class Training:
         if self.config.get("eval_w2v"):
             raise NotImplementedError("eval_w2v (raw wav2vec features) is outside the NOMAD hot path")
         self.engine = engine if engine is not None else Engine(load_pretrained(self.config["checkpoint_path"]), device)
+        # gemm_precision (not a reference key; default fp32): "bf16x3" forms the products of every GEMM of the step - forward,
+        # dX and the split-K dW - as three bf16 MFMA products over hi / lo halves, accumulated in fp32 (Engine.gemm_precision)
+        self.engine.gemm_precision = self.config.get("gemm_precision", "fp32")
         self.engine.train_enable()
         # freeze_all (train_triplet.py:76-79): feature extractor and encoder frozen; what is left trainable is
         # post_extract_proj, the feature LayerNorm and the embedding layer

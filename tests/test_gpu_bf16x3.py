@@ -209,21 +209,27 @@ def test_predict_in_bf16x3_precision(built_lib):
     assert abs(ax3.values[:, -1].astype(float) - a32.values[:, -1].astype(float)).max() <= 1e-3 + 1e-9
 
 
-def test_predict_bf16x3_small_batches_take_the_fp32_path(built_lib, monkeypatch):
-    """Six example files are far below BF16X3_MIN_SAMPLES: Nomad(precision='bf16x3') embeds them on the fp32 path (bit-equal
-    embeddings); with the threshold lowered the same call runs the split-operand kernels (close, not equal)."""
+def test_predict_bf16x3_small_batches_stay_on_fp32_buffers(built_lib, monkeypatch):
+    """Six example files are far below BF16X3_MIN_SAMPLES: Nomad(precision='bf16x3') embeds them on fp32 buffers with
+    three-product GEMMs (Engine.gemm_precision = "bf16x3": close to the fp32 embeddings, bit-equal to that engine mode); with
+    the threshold lowered the same call runs the split-storage kernels (close to both, equal to neither)."""
     import os
     import numpy as np
     from conftest import GOLD
     import importlib
     NM = importlib.import_module("nomad_amd.nomad")
     nmr = os.path.join(GOLD, "wavs", "nmr-data")
-    e32 = NM.Nomad(weights="seeded").get_embeddings(nmr).iloc[:, 1:].values.astype(np.float32)
-    ex3 = NM.Nomad(weights="seeded", precision="bf16x3").get_embeddings(nmr).iloc[:, 1:].values.astype(np.float32)
-    assert np.array_equal(e32, ex3)
+    n32 = NM.Nomad(weights="seeded")
+    e32 = n32.get_embeddings(nmr).iloc[:, 1:].values.astype(np.float32)
+    nx3 = NM.Nomad(weights="seeded", precision="bf16x3")
+    assert nx3.engine.gemm_precision == "bf16x3" and n32.engine.gemm_precision == "fp32"
+    ex3 = nx3.get_embeddings(nmr).iloc[:, 1:].values.astype(np.float32)
+    assert not np.array_equal(e32, ex3) and np.abs(e32 - ex3).max() < 1e-5
+    n32.engine.gemm_precision = "bf16x3"                      # the same engine mode by hand: the same bits
+    assert np.array_equal(n32.get_embeddings(nmr).iloc[:, 1:].values.astype(np.float32), ex3)
     monkeypatch.setattr(NM, "BF16X3_MIN_SAMPLES", 0)
-    ex3b = NM.Nomad(weights="seeded", precision="bf16x3").get_embeddings(nmr).iloc[:, 1:].values.astype(np.float32)
-    assert not np.array_equal(e32, ex3b) and np.abs(e32 - ex3b).max() < 1e-5
+    ex3b = nx3.get_embeddings(nmr).iloc[:, 1:].values.astype(np.float32)
+    assert not np.array_equal(ex3, ex3b) and np.abs(e32 - ex3b).max() < 1e-5
 
 
 def test_bf16x3_follows_weight_updates(built_lib, sd0):
@@ -278,19 +284,23 @@ def test_layer_outputs_bf16x3_vs_oracle(engine, sd0):
     assert rel < 5e-5 and (emb.cpu() - ref[12]).abs().max().item() < 2e-5
 
 
-def test_forward_loss_bf16x3_clean_branch(built_lib, sd0):
-    """nomad.forward() with precision="bf16x3": the clean branch (no gradient) runs the split-bf16 forward once the batch
-    is large enough; loss within 1e-5 (relative) of the fp32 engine's, gradient w.r.t. estimate too."""
+@pytest.mark.parametrize("reps", [1, 2], ids=["c4_shape_fp32_buffers", "64_clips_split_storage_clean_branch"])
+def test_forward_loss_bf16x3_clean_branch(built_lib, sd0, reps):
+    """nomad.forward() with precision="bf16x3": every GEMM of both branches and of the backward on three bf16 products; the
+    clean branch (no gradient) on the split-storage forward once the batch is large enough; loss within 1e-5 (relative) of
+    the fp32 engine's, gradient w.r.t. estimate too."""
     from nomad_amd import nomad as NM
     import importlib
     NM = importlib.import_module("nomad_amd.nomad")
     gen = torch.Generator().manual_seed(5)
-    clean = (0.1 * torch.randn(32, 1, 16384, generator=gen)).clamp(-1, 1).cuda()
-    est = (clean + 0.02 * torch.randn(32, 1, 16384, generator=gen).cuda()).clamp(-1, 1)
+    clean = (0.1 * torch.randn(32 * reps, 1, 16384, generator=gen)).clamp(-1, 1).cuda()
+    est = (clean + 0.02 * torch.randn(32 * reps, 1, 16384, generator=gen).cuda()).clamp(-1, 1)
     n32, nx3 = NM.Nomad(weights=sd0), NM.Nomad(weights=sd0, precision="bf16x3")
     nx3.lossnet_layers.embedding_weight = n32.lossnet_layers.embedding_weight
     nx3.lossnet_layers.embedding_bias = n32.lossnet_layers.embedding_bias
-    assert NM._takes_bf16x3("bf16x3", clean) and not NM._takes_bf16x3("bf16x3", clean[:4]) and not NM._takes_bf16x3("fp32", clean)
+    # 32 x 16384 samples (1 600 frames) per branch stay on fp32 buffers with three-product GEMMs; from ~2 500 frames on the
+    # no-gradient branch takes the split-storage forward
+    assert NM._takes_bf16x3("bf16x3", clean) == (reps == 2) and not NM._takes_bf16x3("fp32", clean)
     out = {}
     for name, n in (("fp32", n32), ("bf16x3", nx3)):
         e = est.clone().requires_grad_(True)
@@ -309,7 +319,7 @@ def test_forward_loss_bf16x3_clean_branch(built_lib, sd0):
     l2 = ((gx3 - g32).norm() / g32.norm()).item()
     print(f"grad: relative L2 difference {l2:.2e}")
     assert (gx3 - g32).abs().max().item() / g32.abs().max().item() < 1e-2 and l2 < 1e-2
-    # small batches stay on the fp32 path entirely: same bits
+    # small batches stay on fp32 buffers, with three-product GEMMs in this mode: close, not bit-equal
     a = n32.forward(est[:4], clean[:4]).item()
     b = nx3.forward(est[:4], clean[:4]).item()
-    assert a == b
+    assert a != b and abs(a - b) / a < 1e-5

@@ -41,7 +41,7 @@ def test_predict_on_resampled_and_stereo_files_vs_oracle(built_lib, sd0, tmp_pat
     from nomad_amd.nomad import Nomad
     rng = np.random.default_rng(11)
     nmr, deg = tmp_path / "nmr", tmp_path / "deg"
-    nmr.mkdir(), deg.mkdir()
+    nmr.mkdir(), deg.mkdir(), (tmp_path / "out").mkdir()   # like the reference, predict() writes into an EXISTING results_path
     t = lambda n, sr: np.arange(n) / sr                                                       # noqa: E731
 
     def tone(n, sr, ch, f0):     # band-limited content (below 3.5 kHz: representable at every rate used) + a little noise

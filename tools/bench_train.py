@@ -16,6 +16,8 @@ def main():
     ap.add_argument("--eval-mode", action="store_true", help="no dropout / LayerDrop")
     ap.add_argument("--separate", action="store_true", help="three separate forward/backward calls (no merged batch)")
     ap.add_argument("--train-convnet", action="store_true", help="freeze_convnet: False - the conv feature extractor trains too")
+    ap.add_argument("--gemm-precision", choices=("fp32", "bf16x3"), default="fp32",
+                    help="bf16x3: every GEMM of the step as three bf16 MFMA products over hi / lo halves (Engine.gemm_precision)")
     ap.add_argument("--out", type=str, default="")
     args = ap.parse_args()
     from nomad_amd.train import Training
@@ -24,7 +26,8 @@ def main():
     n = int(args.seconds * 16000)
     g = torch.Generator().manual_seed(0)
     A, P, N = [(0.1 * torch.randn(args.bs, 1, n, generator=g)).clamp(-1, 1).cuda() for _ in range(3)]
-    cfg = dict(experiment_name="bench", checkpoint_path="seeded", margin=0.2, lr=1e-4, lr_decay_factor=0.99)
+    cfg = dict(experiment_name="bench", checkpoint_path="seeded", margin=0.2, lr=1e-4, lr_decay_factor=0.99,
+               gemm_precision=args.gemm_precision)
     reg = dict(dropout=0.0, attention_dropout=0.0, dropout_input=0.0, encoder_layerdrop=0.0) if args.eval_mode else None
     sd = seeded_state_dict(0)
     tr = Training(cfg, engine=Engine(sd, 0), regularisation=reg, merge_branches=not args.separate)
@@ -48,7 +51,7 @@ def main():
     fwd_flop = 3 * args.bs * (56.925e9 * T / 199.0)  # ~linear in T except the T^2 attention term (small)
     res = {"workload": f"triplet step 3x({args.bs},1,{n}) T={T}", "mode": "eval-arith" if args.eval_mode else "train (dropout+layerdrop)",
            "branches": "separate calls" if args.separate else "merged 3B batch",
-           "conv_feature_extractor": "trainable" if args.train_convnet else "frozen",
+           "conv_feature_extractor": "trainable" if args.train_convnet else "frozen", "gemm_precision": args.gemm_precision,
            "ms_per_step": dt * 1e3, "triplets_per_s": args.bs / dt, "loss": loss.item(),
            "approx_model_tflops": 3 * fwd_flop / dt / 1e12,
            "classes_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},

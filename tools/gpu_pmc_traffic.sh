@@ -7,7 +7,7 @@ ROOTDIR=$(pwd)
 export TMPDIR=/tmp
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $ROOTDIR/$OUT/pmc_$c -o p -- python3 $ROOTDIR/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-also > $ROOTDIR/$OUT/pmc_$c.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $ROOTDIR/$OUT/pmc_$c -o p -- python3 $ROOTDIR/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-also --single-stream > $ROOTDIR/$OUT/pmc_$c.log 2>&1
   echo "pmc $c exit $?" | tee -a $ROOTDIR/$OUT/summary.txt
 done
 cd $ROOTDIR

@@ -63,8 +63,9 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
                 agg[name + " grid=" + r["Grid_Size"]][c].append(float(r["Counter_Value"]) * 1024.0)
 alg, nl = algorithmic_gemm_bytes()
 out = {
+    "taken": tag,
     "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py "
-              "--steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-also; MI355X (tools/gpu_pmc_traffic.sh)",
+              "--steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-also --single-stream; MI355X (tools/gpu_pmc_traffic.sh)",
     "units": "bytes per launch.  The counters sit on the fabric side of L2 and count Infinity-Cache hits: an upper "
              "bound on HBM bytes.",
     "calibration": "gfx950 FETCH_SIZE halves wide coalesced streaming reads (MI355X_MICROARCH.md, HBM): confirmed on "
