@@ -507,6 +507,10 @@ int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, in
     const double flops = 2.0 * p.M * (double)p.n_valid * p.K * groups;
     Scope sc(c, s, NOMAD_K_GEMM, flops, tile == 33 ? NOMAD_K_GEMM_BIG : ((tile == 34 || tile == 31 || tile == 48) ? NOMAD_K_GEMM_FINE : -1));
     hipError_t e;
+    if (c->gemm_x3 && (tile == 31 || tile == 34 || tile == 37) && p.N % 128 == 0 &&
+        (long long)((p.M + 127) / 128) * (p.N / 128) >= 512)
+        tile = 20;  // bf16x3 products: a 64 x 64 wave tile (128 x 128, 4 waves) does 12 MFMAs per 4 fragment splits where the
+                    // 32 x 32 one does 3 per 2 - the split is VALU work - so it is taken as soon as it fills two rounds of CUs
     if (c->gemm_x3 && (tile == 20 || tile == 31 || tile == 33 || tile == 34 || tile == 37)) {
         // bf16x3 products on the same fp32 operands (nomad_set_gemm_precision): same tiles, staging and epilogues
         switch (tile) {
@@ -2534,10 +2538,12 @@ static int dw_gemm(nomad_ctx* c, const float* TA, const float* TB, int Nout, int
                    int rows_scaled, float scale, hipStream_t s) {
     // 128x64 tiles; enough splits for ~1500 workgroups (measured on the training shapes: 512 -> 1536 workgroups
     // is 4 % of a step, beyond that nothing)
-    const int tile = 34;
-    const int tiles = (Nout / 128) * (Kin / 64);
+    // (bf16x3 products, nomad_set_gemm_precision: 128x128 tiles of four 64x64 wave tiles - 12 MFMAs per 4 fragment splits)
+    const bool wide = c->gemm_x3 && Kin % 128 == 0;
+    const int tile = wide ? 20 : 34;
+    const int tiles = (Nout / 128) * (Kin / (wide ? 128 : 64));
     int S = 1;
-    while (S < 16 && tiles * S < 1536) S *= 2;
+    while (S < 16 && tiles * S < 1536 && (size_t)(2 * S) * Nout * Kin <= kSplitPartFloats) S *= 2;
     if ((size_t)S * Nout * Kin > kSplitPartFloats) return fail(NOMAD_ERR_INVALID, "dw_gemm: partial buffer too small");
     const int Kc = Mp / S;
     GemmParams p = dense(TA, Mp, TB, nullptr, nullptr, part, Nout, Kin, Kc, 0);
