@@ -384,25 +384,38 @@ def main():
             g5 = torch.Generator().manual_seed(2000 + rank)
             wav5 = (0.1 * torch.randn(32, 480000, generator=g5)).clamp(-1, 1).cuda()
             sc5 = ShardedScorer(engp.embed_bf16, engp.pairwise, equal_shards=True, force_collective=use_pg)
-            for key, fn, n_clips, k in (("c2", lambda: scp.score(deg_wav, ref_wav, want_matrix=True), B, args.steps),
-                                        ("c5", lambda: sc5.score(wav5[:28], wav5[28:], want_matrix=True), 32, 5)):
-                for _ in range(2):
-                    fn()
-                fence()
-                engp.profile_enable(True)
-                engp.profile_reset()
-                t1 = time.perf_counter()
-                for _ in range(k):
-                    fn()
-                fence()
-                tp = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
-                pp = engp.profile_read()
-                engp.profile_enable(False)
-                if use_pg:
-                    dist.all_reduce(tp, op=dist.ReduceOp.MAX)
-                res[key] = {"value": round(world * n_clips * k / float(tp.item()), 2), "unit": "clips/s",
-                            "ms_per_step": round(1e3 * float(tp.item()) / k, 3),
-                            "attention_ms_per_step": round(pp["attention_mfma"]["ms"] / k, 3), "single_stream": True}
+            # the same loops on the headline's (seeded) engine with its batch split off: the like-for-like reference
+            keep = (eng.F32_SPLIT_ROWS, eng.BF16_SPLIT_ROWS)
+            eng.F32_SPLIT_ROWS = eng.BF16_SPLIT_ROWS = 0
+            sc5s = ShardedScorer(eng.embed_bf16, eng.pairwise, equal_shards=True, force_collective=use_pg)
+            sc2s = ShardedScorer(eng.embed, eng.pairwise, equal_shards=True, force_collective=use_pg)
+            for tag, e_, loops in (("peaky", engp, (("c2", lambda: scp.score(deg_wav, ref_wav, want_matrix=True), B, args.steps),
+                                                   ("c5", lambda: sc5.score(wav5[:28], wav5[28:], want_matrix=True), 32, 5))),
+                                   ("seeded", eng, (("c2", lambda: sc2s.score(deg_wav, ref_wav, want_matrix=True), B, args.steps),
+                                                    ("c5", lambda: sc5s.score(wav5[:28], wav5[28:], want_matrix=True), 32, 5)))):
+                for key, fn, n_clips, k in loops:
+                    for _ in range(2):
+                        fn()
+                    fence()
+                    e_.profile_enable(True)
+                    e_.profile_reset()
+                    t1 = time.perf_counter()
+                    for _ in range(k):
+                        fn()
+                    fence()
+                    tp = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
+                    pp = e_.profile_read()
+                    e_.profile_enable(False)
+                    if use_pg:
+                        dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+                    row = {"value": round(world * n_clips * k / float(tp.item()), 2), "unit": "clips/s",
+                           "ms_per_step": round(1e3 * float(tp.item()) / k, 3),
+                           "attention_ms_per_step": round(pp["attention_mfma"]["ms"] / k, 3), "single_stream": True}
+                    if tag == "peaky":
+                        res[key] = row
+                    else:
+                        res[key]["seeded_weights_same_loop"] = row
+            eng.F32_SPLIT_ROWS, eng.BF16_SPLIT_ROWS = keep
             del wav5
             engp.close()
             also_peaky = res
