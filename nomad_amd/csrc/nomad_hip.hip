@@ -508,6 +508,9 @@ int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, in
     const double flops = 2.0 * p.M * (double)p.n_valid * p.K * groups;
     Scope sc(c, s, NOMAD_K_GEMM, flops, tile == 33 ? NOMAD_K_GEMM_BIG : ((tile == 34 || tile == 31 || tile == 48) ? NOMAD_K_GEMM_FINE : -1));
     hipError_t e;
+    if (c->gemm_x3 && tile == 48 && p.N == 64)
+        tile = 37;  // bf16x3 products: the grouped pos-conv on the generic 64 x 64 tile (N padded 48 -> 64: a quarter of the MFMAs
+                    // wasted, but 6 bf16 MFMAs of 32 cycles per 32-deep k range instead of 48 fp32 ones of 32 in the N = 48 kernel)
     if (c->gemm_x3 && (tile == 31 || tile == 34 || tile == 37) && p.N % 128 == 0 &&
         (long long)((p.M + 127) / 128) * (p.N / 128) >= 512)
         tile = 20;  // bf16x3 products: a 64 x 64 wave tile (128 x 128, 4 waves) does 12 MFMAs per 4 fragment splits where the

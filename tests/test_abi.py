@@ -89,7 +89,7 @@ def test_shipped_libraries_have_no_packed_fp32_instructions(built_lib):
             with tempfile.NamedTemporaryFile(suffix=".co") as f:
                 f.write(data[i + o:i + o + sz])
                 f.flush()
-                asm = subprocess.run([objdump, "-d", f.name], capture_output=True, text=True, check=True).stdout
+                asm = subprocess.run([objdump, "-d", "--no-show-raw-insn", f.name], capture_output=True, text=True, check=True).stdout
             found += 1
             assert asm.count("s_endpgm") > 50, "disassembly looks empty"
             assert not re.search(r"v_pk_(fma|mul|add)_f32|v_pk_mov_b32", asm), f"{os.path.basename(lib)} contains packed-FP32 instructions"

@@ -111,3 +111,51 @@ def test_conv0_under_the_strongest_reproducer(built_lib, sd0):
     torch.cuda.synchronize()
     eng.close()
     assert bad == 0, f"conv0 differed from its reference in {bad} of 400 calls"
+
+
+@pytest.mark.parametrize("tile", [37, 20, 31, 33])
+def test_x3_product_gemm_repeats_bit_identically_under_its_own_kind_of_load(engine, tile):
+    """The bf16x3-products GEMM (gemm_f32_glds_kernel<..., X3>) is itself a 32x32x16-bf16-MFMA kernel with two workgroups per CU
+    whose waves spend half their time on VALU work (the hi / lo split: v_cvt_pk_bf16_f32, v_dot2c_f32_bf16) - the very
+    co-residency that made v_pk_fma_f32 lose products.  300 launches on a fine-tuning-size problem, with the 128 x 128 bf16
+    GEMM running on another stream as well: every result equal to the first, bit for bit."""
+    engine.gemm_precision = "bf16x3"
+    try:
+        g = torch.Generator().manual_seed(tile)
+        A = torch.randn(11976, 768, generator=g).cuda()
+        W = (torch.randn(768, 768, generator=g) * 0.03).cuda()
+        bias = torch.randn(768, generator=g).cuda()
+        ref = engine.diag_gemm(A, W, bias=bias, gelu=True, tile=tile).clone()
+        Ab, Wb = _aggressor_operands(32, 199)
+        side = torch.cuda.Stream()
+        bad = 0
+        for it in range(300):
+            if it % 3 == 0:
+                with torch.cuda.stream(side):
+                    engine.diag_gemm_bf16(Ab, Wb, tile=1)
+            bad += int(not torch.equal(engine.diag_gemm(A, W, bias=bias, gelu=True, tile=tile), ref))
+        torch.cuda.synchronize()
+        assert bad == 0, f"tile {tile}: {bad} of 300 results differ"
+    finally:
+        engine.gemm_precision = "fp32"
+
+
+def test_forward_backward_bf16x3_products_repeat_bit_identically(built_lib, sd0):
+    """Nomad(precision="bf16x3").forward() + backward at config C4's shape, 30 times: the loss and d loss / d estimate are the
+    same bits every time (two branches on two streams, every GEMM on three bf16 products)."""
+    from nomad_amd.nomad import Nomad
+    nmd = Nomad(weights=sd0, precision="bf16x3")
+    gen = torch.Generator().manual_seed(12)
+    clean = (0.1 * torch.randn(32, 1, 16384, generator=gen)).clamp(-1, 1).cuda()
+    est0 = (clean + 0.02 * torch.randn(32, 1, 16384, generator=gen).cuda()).clamp(-1, 1)
+    first = None
+    for it in range(30):
+        est = est0.clone().requires_grad_(True)
+        loss = nmd.forward(est, clean)
+        loss.backward()
+        cur = (loss.detach().clone(), est.grad.clone())
+        if first is None:
+            first = cur
+        else:
+            assert torch.equal(cur[0], first[0]) and torch.equal(cur[1], first[1]), it
+    nmd.engine.close()
