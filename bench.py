@@ -105,26 +105,31 @@ def spawn_ranks(n: int, argv) -> int:
     return res.returncode if res.returncode != 0 or lines else 1
 
 
+def c3_sharded_scores(embed_fn, pairwise_fn, wav, n_deg_local, batch, use_pg):
+    """One rank's part of configs[2]: embed this rank's clips (its slice of the degraded set, then its slice of the references)
+    in batches, ONE all-gather of the reference embeddings, this rank's distance slab + row means, one gather of the scores
+    -> (all scores in global order, all reference embeddings, this rank's slab).  Shard sizes may differ between ranks."""
+    import torch
+    from nomad_amd.dist import all_gather_rows
+    emb = torch.cat([embed_fn(wav[i:i + batch]) for i in range(0, wav.shape[0], batch)])
+    ref_all = all_gather_rows(emb[n_deg_local:].contiguous(), force_collective=use_pg)     # the one data-path collective
+    d, mean = pairwise_fn(emb[:n_deg_local].contiguous(), ref_all, True)
+    return all_gather_rows(mean, force_collective=use_pg), ref_all, d
+
+
 def time_c3(eng, world, rank, use_pg, fence, n_deg=10000, n_ref=1000, batch=256):
     """BASELINE.json configs[2]: 10 000 degraded x 1 000 non-matching references (16 kHz x 4 s, fp32), clips sharded over the
     ranks, ONE all-gather of the reference embeddings, each rank's distance slab + row means, one gather of the scores.
     Strong scaling (the total is fixed); waveforms resident in HBM before the timed region."""
     import torch
-    from nomad_amd.dist import all_gather_rows, partition
+    from nomad_amd.dist import partition
     (ds, de), (rs, re_) = partition(n_deg, world, rank), partition(n_ref, world, rank)
     g = torch.Generator(device="cuda").manual_seed(3000 + rank)
     wav = (0.1 * torch.randn(de - ds + re_ - rs, 64000, generator=g, device="cuda")).clamp(-1, 1)
-
-    def run():
-        emb = torch.cat([eng.embed(wav[i:i + batch]) for i in range(0, wav.shape[0], batch)])
-        ref_all = all_gather_rows(emb[de - ds:].contiguous(), force_collective=use_pg)     # the one data-path collective
-        d, mean = eng.pairwise(emb[:de - ds].contiguous(), ref_all, want_matrix=True)
-        return all_gather_rows(mean, force_collective=use_pg), ref_all, d
-
     eng.embed(wav[:batch])
     fence()
     t0 = time.perf_counter()
-    scores, ref_all, d = run()
+    scores, ref_all, d = c3_sharded_scores(eng.embed, eng.pairwise, wav, de - ds, batch, use_pg)
     fence()
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
     if use_pg:

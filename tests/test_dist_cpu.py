@@ -72,6 +72,40 @@ def test_sharded_equals_unsharded_ragged(tmp_path):
     _run(13, 5, tmp_path)  # unequal shards: 7+6 deg, 3+2 ref
 
 
+# ---- bench.py's configs[2] leg (10 000 x 1 000 sharded over the ranks of the run) at world size 4, unequal shards ----------
+def _c3_worker(rank, world, port, n_deg, n_ref, out_dir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(99)
+    deg = torch.randn(n_deg, 320, generator=g)
+    ref = torch.randn(n_ref, 320, generator=g)
+    (ds, de), (rs, re_) = partition(n_deg, world, rank), partition(n_ref, world, rank)
+    wav = torch.cat([deg[ds:de], ref[rs:re_]])
+    pw = lambda a, b, m: _fake_pairwise(a, b, m)                                               # noqa: E731
+    scores, ref_all, slab = bench.c3_sharded_scores(_fake_embed, pw, wav, de - ds, 2, True)   # batches of 2 clips
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "c3.npz"), scores=scores.numpy(), ref=ref_all.numpy())
+    assert slab.shape == (de - ds, n_ref)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_c3_leg_sharded_over_four_ranks_equals_unsharded(tmp_path):
+    n_deg, n_ref, world = 10, 7, 4                      # shards 3+3+2+2 degraded, 2+2+2+1 references
+    mp.spawn(_c3_worker, args=(world, _free_port(), n_deg, n_ref, str(tmp_path)), nprocs=world, join=True)
+    out = np.load(os.path.join(tmp_path, "c3.npz"))
+    g = torch.Generator().manual_seed(99)
+    deg = torch.randn(n_deg, 320, generator=g)
+    ref = torch.randn(n_ref, 320, generator=g)
+    _, m = _fake_pairwise(_fake_embed(deg), _fake_embed(ref), True)
+    assert np.array_equal(out["ref"], _fake_embed(ref).numpy())
+    assert out["scores"].shape == (n_deg,) and np.abs(out["scores"] - m.numpy()).max() < 1e-12
+
+
 # ---- data-parallel fine-tuning: gradient averaging across ranks (gloo, world_size 2) ------------------------------
 def _ddp_worker(rank, world, port, out):
     import os
