@@ -152,11 +152,17 @@ def time_c4(sd, device, steps=10, warmup=3, batch=32, samples=16384):
     g = torch.Generator().manual_seed(0)
     clean_h = (0.1 * torch.randn(batch, 1, samples, generator=g)).clamp(-1, 1)
     noise_h = 0.02 * torch.randn(batch, 1, samples, generator=g)
+    # LossNetLayers owns a freshly initialised, never loaded Linear(768, 256) (nomad.py:238-241): seeded here and shared by the
+    # two Nomad objects below, so that their losses are comparable
+    head_w = (torch.rand(256, 768, generator=g) * 2 - 1) / 768 ** 0.5
+    head_b = (torch.rand(256, generator=g) * 2 - 1) / 768 ** 0.5
     out = {"workload": f"configs[3]: nomad.forward() on 2 x ({batch},1,{samples}) (T=50), d loss / d estimate through the whole "
                        f"backbone (feature_grad_mult 0.1)", "dtype": "f32", "steps": steps, "warmup": warmup, "finite": True}
     losses = {}
     for prec in ("fp32", "bf16x3"):
         nmd = Nomad(device=device, weights=sd, precision=prec)
+        nmd.lossnet_layers.embedding_weight = head_w.to(nmd.DEVICE).contiguous()
+        nmd.lossnet_layers.embedding_bias = head_b.to(nmd.DEVICE).contiguous()
         clean = clean_h.to(nmd.DEVICE)
         est0 = (clean + noise_h.to(nmd.DEVICE)).clamp(-1, 1)
 

@@ -75,6 +75,7 @@ constexpr size_t kSplitKPartFloats = (size_t)4 * 512 * 64 * 64;  // 4 slices of 
 constexpr long long kPairScratchDoubles = 1 << 21;  // 16 MB: e.g. 16 ref tiles x 131 072 deg rows per launch pair
 constexpr int kEventChunk = 8192;  // the profiling event pool grows by this many events whenever it runs out
 const int* const kNoInts = nullptr;  // "uniform batch" for the kernels' optional ragged-metadata pointers
+const hipStream_t kNoStream = reinterpret_cast<hipStream_t>(~uintptr_t(0));  // nomad_pairwise: a scratch block bound to no stream
 
 struct LayerDev {
     float *qkv_w, *qkv_b, *o_w, *o_b, *ln1_w, *ln1_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b, *ln2_w, *ln2_b;
@@ -318,8 +319,7 @@ struct nomad_ctx {
     // nomad_pairwise: row sums per (64-ref tile, deg row), kPairScratchDoubles doubles PER LAUNCH STREAM - calls on
     // different streams of one context may be in flight together (Engine / ShardedScorer are driven from side streams), so
     // each stream gets its own block: the first at nomad_create, further ones on a stream's first call
-    std::vector<std::pair<hipStream_t, double*>> pair_scratch;
-    bool pair_first_bound = false;   // the block allocated at nomad_create has been given to a stream
+    std::vector<std::pair<hipStream_t, double*>> pair_scratch;   // (kNoStream: block not bound to a stream)
     // transposed copies for the dX-only backward (built by nomad_enable_backward)
     bool bwd_ready = false;
     float* conv_bw_even[7] = {};  // k=3 layers 1..4: [512][1024] = [W_tap2^T | W_tap0^T]
@@ -861,7 +861,7 @@ int nomad_create(nomad_ctx** out, int device, const nomad_weights* w) {
         if (e != hipSuccess) rc = fail(NOMAD_ERR_HIP, "nomad_create: pairwise scratch: %s", hipGetErrorString(e));
         else {
             c->allocs.push_back(d);
-            c->pair_scratch.emplace_back(static_cast<hipStream_t>(nullptr), static_cast<double*>(d));
+            c->pair_scratch.emplace_back(kNoStream, static_cast<double*>(d));
         }
     }
     if (rc != 0) {
@@ -3308,21 +3308,27 @@ int nomad_pairwise(nomad_ctx* c, const float* deg, int Nd, const float* ref, int
     // stream are ordered, calls on different streams must not share it): the block of nomad_create goes to the first
     // stream that calls, any further stream allocates its own on its first call
     double* scratch = nullptr;
-    if (!c->pair_first_bound) {
-        c->pair_scratch[0].first = s;
-        c->pair_first_bound = true;
-    }
     for (const auto& e : c->pair_scratch)
         if (e.first == s) {
             scratch = e.second;
             break;
         }
     if (!scratch) {
-        if (c->pair_scratch.size() >= 64) {  // stream handles come and go: recycle the oldest block once everything has drained
+        // a block whose stream slot was released by an earlier recycle (first == kNoStream) is taken before anything new is
+        // allocated; at most 64 blocks (1 GB) ever exist, whatever the number of stream handles a long-lived process goes through
+        for (auto& e : c->pair_scratch)
+            if (e.first == kNoStream) {
+                e.first = s;
+                scratch = e.second;
+                break;
+            }
+    }
+    if (!scratch) {
+        if (c->pair_scratch.size() >= 64) {  // every block is bound: drain the device once and release all bindings but this one
             HIP_TRY(hipDeviceSynchronize());
-            c->pair_scratch.resize(1);
+            for (auto& e : c->pair_scratch) e.first = kNoStream;
             c->pair_scratch[0].first = s;
-            scratch = c->pair_scratch[0].second;   // (the dropped blocks stay in allocs and are freed by nomad_destroy)
+            scratch = c->pair_scratch[0].second;
         } else {
             void* d = nullptr;
             HIP_TRY(hipSetDevice(c->device));

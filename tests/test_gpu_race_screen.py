@@ -159,3 +159,26 @@ def test_forward_backward_bf16x3_products_repeat_bit_identically(built_lib, sd0)
         else:
             assert torch.equal(cur[0], first[0]) and torch.equal(cur[1], first[1]), it
     nmd.engine.close()
+
+
+def test_pairwise_calls_on_different_streams_do_not_share_scratch(engine):
+    """Round-2 advice: nomad_pairwise kept its per-tile row sums in ONE context-owned scratch, so two calls in flight on different
+    streams of one context raced.  The scratch is per launch stream now (64 blocks at most, rebound after a drain): 70 streams,
+    four calls in flight at a time on different operands, every result bit-equal to its single-stream value."""
+    g = torch.Generator().manual_seed(4)
+    sets = []
+    for k in range(4):
+        deg = torch.nn.functional.normalize(torch.randn(900 + 37 * k, 256, generator=g), dim=1).cuda()
+        ref = torch.nn.functional.normalize(torch.randn(300 + 11 * k, 256, generator=g), dim=1).cuda()
+        d, m = engine.pairwise(deg, ref)
+        sets.append((deg, ref, d.clone(), m.clone()))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(70)]
+    for base in range(0, 68, 4):
+        outs = []
+        for k in range(4):
+            with torch.cuda.stream(streams[base + k]):
+                outs.append(engine.pairwise(sets[k][0], sets[k][1]))
+        torch.cuda.synchronize()
+        for k in range(4):
+            assert torch.equal(outs[k][0], sets[k][2]) and torch.equal(outs[k][1], sets[k][3]), (base, k)
