@@ -124,13 +124,15 @@ __device__ __forceinline__ float dgelu_erf_(float u) {
 __device__ __forceinline__ float gelu_erf(float x) {
     const float ax = fabsf(x);
     const float t = __builtin_amdgcn_rcpf(fmaf(0.23164189f, ax, 1.0f));  // p / sqrt(2), p = 0.3275911
-    float poly = fmaf(t, 1.061405429f, -1.453152027f);
-    poly = fmaf(t, poly, 1.421413741f);
-    poly = fmaf(t, poly, -0.284496736f);
-    poly = fmaf(t, poly, 0.254829592f);
+    // the polynomial carries the factor 0.5 (halved coefficients: exact scalings, the same bits as 0.5 * poly) and the positive
+    // part is max(x, 0) == 0.5 (x + |x|) exactly: two instructions fewer per activation, results unchanged bit for bit
+    float poly = fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);
+    poly = fmaf(t, poly, 0.5f * 1.421413741f);
+    poly = fmaf(t, poly, 0.5f * -0.284496736f);
+    poly = fmaf(t, poly, 0.5f * 0.254829592f);
     poly *= t;
     const float e = __builtin_amdgcn_exp2f(-0.72134752044f * x * x);  // exp(-x^2/2) = 2^(-x^2 log2(e) / 2)
-    return fmaf(-0.5f * ax, poly * e, 0.5f * (x + ax));
+    return fmaf(-ax, poly * e, fmaxf(x, 0.0f));
 }
 
 // XCD-aware bijective remap of a 1-D grid: blocks b and b+8 share an XCD (round-robin dispatch),
