@@ -15,6 +15,8 @@ sname = sys.argv[2] if len(sys.argv) > 2 else "fc1"
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 M, N, K, has_b, gelu, has_r = SHAPES[sname]
 eng = Engine(seeded_state_dict(0), 0, diag=True)  # libnomad_diag.so: experimental tile ids
+if os.environ.get("GEMM_X3") == "1":   # bf16x3 products on fp32 buffers (gemm_f32_glds_kernel<..., X3>)
+    eng.gemm_precision = "bf16x3"
 g = torch.Generator().manual_seed(0)
 A = torch.randn(M, K, generator=g).cuda()
 W = (torch.randn(N, K, generator=g) * K ** -0.5).cuda()
