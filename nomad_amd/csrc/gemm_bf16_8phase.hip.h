@@ -41,7 +41,8 @@ struct P8Cfg {
 // Epilogue shared by the 256 x 256 kernels (8 waves as 2 x 4, wave tile 128 x 64 = acc[8][4], accumulator: column fr,
 // rows 4 fq + r of each 16 x 16 tile): 32-row fp32 slabs through LDS, bias / GELU / residual in fp32, 16-byte stores.
 // OUT: 0 = bf16, 1 = split planes (p.c_plane; R split too), 2 = fp32 (R split).  NOSTORE: timing ablation.
-template <bool NOSTORE, int X3>
+// NT: bit 0 = output stores, bit 1 = residual loads carry the non-temporal hint (streamed through L2).
+template <bool NOSTORE, int X3, int NT = 0>
 __device__ __forceinline__ void p8_epilogue(const GemmParams& p, const f32x4 (&acc)[8][4], char* smem8, int grp, int m0, int n0,
                                             int wave, int wr, int wc, int lane, int fr, int fq) {
     using Cfg = P8Cfg;
@@ -94,7 +95,7 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p, const f32x4 (&a
                     float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     if (Rg) {
                         const bf16_t* rp = Rg + (r_plain ? p.rmap.off + (long long)m * p.rmap.ld : row_addr(p.rmap, m)) + n;
-                        const bf16x8 rv = *reinterpret_cast<const bf16x8*>(rp);
+                        const bf16x8 rv = (NT & 2) ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(rp)) : *reinterpret_cast<const bf16x8*>(rp);
                         if (X3) {
                             const bf16x8 rl = *reinterpret_cast<const bf16x8*>(rp + p.r_plane);
 #pragma unroll
@@ -111,18 +112,25 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p, const f32x4 (&a
                     }
                     const long long ci = (c_plain ? p.cmap.off + (long long)m * p.cmap.ld : row_addr(p.cmap, m)) + c_col;
                     if (X3 == 2) {
-                        *reinterpret_cast<f32x4*>(Cf + ci) = (f32x4){v[0], v[1], v[2], v[3]};
-                        *reinterpret_cast<f32x4*>(Cf + ci + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+                        if (NT & 1) {
+                            __builtin_nontemporal_store((f32x4){v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(Cf + ci));
+                            __builtin_nontemporal_store((f32x4){v[4], v[5], v[6], v[7]}, reinterpret_cast<f32x4*>(Cf + ci + 4));
+                        } else {
+                            *reinterpret_cast<f32x4*>(Cf + ci) = (f32x4){v[0], v[1], v[2], v[3]};
+                            *reinterpret_cast<f32x4*>(Cf + ci + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+                        }
                     } else {
                         bf16x8 ov;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) ov[e] = (bf16_t)v[e];
-                        *reinterpret_cast<bf16x8*>(Cg + ci) = ov;
+                        if (NT & 1) __builtin_nontemporal_store(ov, reinterpret_cast<bf16x8*>(Cg + ci));
+                        else *reinterpret_cast<bf16x8*>(Cg + ci) = ov;
                         if (X3 == 1) {
                             bf16x8 ol;
 #pragma unroll
                             for (int e = 0; e < 8; ++e) ol[e] = (bf16_t)(v[e] - (float)ov[e]);
-                            *reinterpret_cast<bf16x8*>(Cg + ci + p.c_plane) = ol;
+                            if (NT & 1) __builtin_nontemporal_store(ol, reinterpret_cast<bf16x8*>(Cg + ci + p.c_plane));
+                            else *reinterpret_cast<bf16x8*>(Cg + ci + p.c_plane) = ol;
                         }
                     }
                 }
@@ -141,6 +149,7 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p, const f32x4 (&a
 //   accumulators: a.w = (ah + al)(wh + wl) minus the al*wl term (2^-16 relative), i.e. the plain kernel run on
 //   operands concatenated along K, with no other change to the schedule.  X3 = 1 stores the result split
 //   (p.c_plane), X3 = 2 stores fp32.
+//      8 / 9 / 10 = non-temporal output stores / stores + residual loads / residual loads only (A/B).
 // timing probe ABL 7 (tools/gemm_timeline.py): per workgroup {entry, main loop start, main loop end, stores done} in 100 MHz
 // wall-clock ticks + HW_ID + XCC_ID
 constexpr int kTimelineSlots = 4096;
@@ -340,7 +349,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
 #undef NOMAD_P8_DMA_B
 
     if (ABL == 7) ts_[2] = wall_clock64();
-    p8_epilogue<ABL == 1, X3>(p, acc, smem8, grp, m0, n0, wave, wr, wc, lane, fr, fq);
+    p8_epilogue<ABL == 1, X3, (ABL == 8 ? 1 : ABL == 9 ? 3 : ABL == 10 ? 2 : 0)>(p, acc, smem8, grp, m0, n0, wave, wr, wc, lane, fr, fq);
     if (ABL == 7) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the output stores have left the CU
         ts_[3] = wall_clock64();

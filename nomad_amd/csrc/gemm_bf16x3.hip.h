@@ -231,7 +231,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_kernel(const GemmParams p) {
 #undef NOMAD_X3_DMA_A
 #undef NOMAD_X3_DMA_B
 
-    p8_epilogue<ABL == 1, X3>(p, acc, smem8, grp, m0, n0, wave, wr, wc, lane, fr, fq);
+    p8_epilogue<ABL == 1, X3, (ABL == 8 ? 1 : 0)>(p, acc, smem8, grp, m0, n0, wave, wr, wc, lane, fr, fq);
 }
 
 template <int ABL, int X3, int NA = 2>

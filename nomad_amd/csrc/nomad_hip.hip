@@ -1352,6 +1352,15 @@ static int p8_min_tiles() {
     return v;
 }
 
+// output stores of the deep-pipelined bf16 kernel carry the non-temporal hint; NOMAD_BF16_NT_STORES=0 switches it off (A/B runs)
+static bool p8_nt_stores() {
+    static const bool v = [] {
+        const char* e = getenv("NOMAD_BF16_NT_STORES");
+        return e ? atoi(e) != 0 : true;
+    }();
+    return v;
+}
+
 static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, int tile = -1) {
     const double flops = 2.0 * p.M * (double)p.n_valid * p.K * groups;  // bf16x3: the fp32-equivalent count, not 3x
     if (tile < 0) {
@@ -1363,7 +1372,7 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
             tile = 16;  // deep-pipelined 256x256 kernel once there are >= 2 rounds of tiles (profiles/r01_gemm_sweep_bf16_8phase.json)
         else tile = (p.N % 256 == 0 && (p.N >= 1024 || p.M >= 100000)) ? 3 : 1;
     }
-    Scope sc(c, s, NOMAD_K_GEMM, flops, (tile == 1 || tile == 3 || tile == 16 || tile == 40 || tile == 41 || tile == 20 || tile == 21 || tile == 27 || tile == 28 || tile == 32 || tile == 33) ? NOMAD_K_GEMM_BIG : (tile == 2 ? NOMAD_K_GEMM_FINE : -1));
+    Scope sc(c, s, NOMAD_K_GEMM, flops, (tile == 1 || tile == 3 || tile == 16 || tile == 40 || tile == 41 || tile == 42 || tile == 43 || tile == 44 || tile == 20 || tile == 21 || tile == 27 || tile == 28 || tile == 32 || tile == 33) ? NOMAD_K_GEMM_BIG : (tile == 2 ? NOMAD_K_GEMM_FINE : -1));
     hipError_t e;
     switch (tile) {
         // the instantiations the bf16 / bf16x3 forwards select
@@ -1373,12 +1382,13 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
         case 4: e = launch_gemm_bf16<64, 64, 2, 2>(p, groups, s); break;
         case 16:  // 256x256 deep-pipelined schedule (gemm_bf16_8phase.hip.h)
             if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
-            e = launch_gemm_bf16_8phase<0>(p, groups, s);
+            e = p8_nt_stores() ? launch_gemm_bf16_8phase<8>(p, groups, s) : launch_gemm_bf16_8phase<0>(p, groups, s);
             break;
         case 27:  // bf16x3, every plane staged once (gemm_bf16x3.hip.h): split output
         case 28:  // ... fp32 output
             if (p.N % 256 != 0 || p.K % 64 != 0) return fail(NOMAD_ERR_INVALID, "bf16x3 gemm: N %% 256, K %% 64");
-            e = tile == 27 ? launch_gemm_bf16x3<0, 1>(p, groups, s) : launch_gemm_bf16x3<0, 2>(p, groups, s);
+            if (p8_nt_stores()) e = tile == 27 ? launch_gemm_bf16x3<8, 1>(p, groups, s) : launch_gemm_bf16x3<8, 2>(p, groups, s);
+            else e = tile == 27 ? launch_gemm_bf16x3<0, 1>(p, groups, s) : launch_gemm_bf16x3<0, 2>(p, groups, s);
             break;
 #ifdef NOMAD_DIAG
         // experimental instantiations, cross-check kernels and timing probes (libnomad_diag.so)
@@ -1418,6 +1428,12 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
         case 41:  // 32x32x16 8-phase kernel without its epilogue stores (timing ablation)
             if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
             e = launch_gemm_bf16_8phase32<true>(p, groups, s);
+            break;
+        case 42:  // A/B: 8-phase kernel with non-temporal output stores / + residual loads / residual loads only
+        case 43:
+        case 44:
+            if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
+            e = tile == 42 ? launch_gemm_bf16_8phase<8>(p, groups, s) : tile == 43 ? launch_gemm_bf16_8phase<9>(p, groups, s) : launch_gemm_bf16_8phase<10>(p, groups, s);
             break;
         case 36:  // timing probe: per-workgroup timeline (nomad_diag_timeline, tools/gemm_timeline.py)
             if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
@@ -2416,7 +2432,7 @@ int nomad_diag_timeline(unsigned long long* out_host, int n) {
 int nomad_diag_gemm_bf16(nomad_ctx* c, const void* A, const void* W, const float* bias, const void* R, void* C, int M,
                          int N, int K, int gelu, int tile, nomad_stream_t stream) {
     static const int kBN[] = {128, 128, 64, 256, 64, 128, 128, 128, 128, 256, 256, 128, 128, 128, 128, 256, 256, 256, 256, 256};
-    const bool big256 = tile == 36 || tile == 40 || tile == 41;
+    const bool big256 = tile == 36 || (tile >= 40 && tile <= 44);
     if (!c || !A || !W || !C || M <= 0 || tile < 0 || (!big256 && tile >= static_cast<int>(sizeof(kBN) / sizeof(kBN[0])))) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: bad argument");
     if (N % (big256 ? 256 : kBN[tile]) || K % 64) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: N %% %d or K %% 64 != 0", big256 ? 256 : kBN[tile]);
     GemmParams p = dense(static_cast<const float*>(A), K, static_cast<const float*>(W), bias, static_cast<const float*>(R),

@@ -53,6 +53,8 @@ SHAPES = {  # name: (M, N, K, bias, gelu, residual)
     "c5_qkv": (47968, 2304, 768, True, False, False),
     "c5_fc1": (47968, 3072, 768, True, True, False),
     "c5_fc2": (47968, 768, 3072, True, False, True),
+    "c5_fc1_nogelu": (47968, 3072, 768, True, False, False),          # what the GELU epilogue costs on the bf16 tiles
+    "c5_conv4_nogelu": (383968, 512, 1536, False, False, False),
     "one_tile": (256, 256, 128, True, False, False),        # a lone workgroup / one workgroup per XCD / one full round
     "eight_tiles": (256, 2048, 128, True, False, False),
     "one_round": (7168, 2304, 128, True, False, False),
@@ -105,9 +107,9 @@ def main():
                  9: "bf16 256x256 w2x4 bk32 4st", 10: "bf16 256x256 w4x2 bk32 4st", 11: "bf16 128x128 w4x2 bk32 4st",
                  12: "bf16 128x128 w4x2 bk64 3st", 13: "bf16 256x128 w4x2 bk64 3st", 14: "bf16 256x128 w4x2 bk32 4st",
                  15: "bf16 256x256 w2x4 bk64 2st", 16: "bf16 256x256 8-phase", 17: "bf16 256x256 8-phase ABL no-epilogue", 18: "bf16 256x256 8-phase buffer_load..lds", 19: "bf16 256x256 8-phase no setprio", 36: "bf16 256x256 8-phase, timeline probe build",
-                 40: "bf16 256x256 8-phase on 32x32x16 MFMA", 41: "bf16 256x256 8-phase 32x32x16 ABL no-epilogue"}
+                 42: "bf16 256x256 8-phase, non-temporal C stores", 43: "bf16 256x256 8-phase, non-temporal C stores + R loads", 44: "bf16 256x256 8-phase, non-temporal R loads", 40: "bf16 256x256 8-phase on 32x32x16 MFMA", 41: "bf16 256x256 8-phase 32x32x16 ABL no-epilogue"}
         bn = {0: 128, 1: 128, 2: 64, 3: 256, 4: 64, 5: 128, 6: 128, 7: 128, 8: 128, 9: 256, 10: 256, 11: 128, 12: 128,
-              13: 128, 14: 128, 15: 256, 16: 256, 17: 256, 18: 256, 19: 256, 36: 256, 40: 256, 41: 256}
+              13: 128, 14: 128, 15: 256, 16: 256, 17: 256, 18: 256, 19: 256, 36: 256, 40: 256, 41: 256, 42: 256, 43: 256, 44: 256}
         for sname in a.shapes.split(","):
             M, N, K, has_b, gelu, has_r = SHAPES[sname]
             A = torch.randn(M, K, generator=g).bfloat16().cuda()
@@ -116,7 +118,7 @@ def main():
             R = torch.randn(M, N, generator=g).bfloat16().cuda() if has_r else None
             first = None
             for t in (int(x) for x in a.tiles.split(",")):
-                if N % bn[t] or (t in (16, 17, 18, 19, 36, 40, 41) and K % 128):
+                if N % bn[t] or (t in (16, 17, 18, 19, 36, 40, 41, 42, 43, 44) and K % 128):
                     continue
                 out = eng.diag_gemm_bf16(A, W, b, R, gelu=gelu, tile=t).float()
                 if first is None:
