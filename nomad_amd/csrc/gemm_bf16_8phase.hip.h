@@ -150,6 +150,7 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p, const f32x4 (&a
 //   operands concatenated along K, with no other change to the schedule.  X3 = 1 stores the result split
 //   (p.c_plane), X3 = 2 stores fp32.
 //      8 / 9 / 10 = non-temporal output stores / stores + residual loads / residual loads only (A/B).
+//      11 = timing probe: every workgroup stages A tile 0 (A always hits in L2; wrong results).
 // timing probe ABL 7 (tools/gemm_timeline.py): per workgroup {entry, main loop start, main loop end, stores done} in 100 MHz
 // wall-clock ticks + HW_ID + XCC_ID
 constexpr int kTimelineSlots = 4096;
@@ -179,7 +180,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
     // Instruction i of a half-tile covers rows (tid + 512 i) / 8, physical chunk (tid + 512 i) % 8.
     // The 32-bit offsets are relative to the tile's FIRST row (row addresses grow with the row index, a 256-row tile
     // spans far less than 4 GB); the tensor itself may be larger than 4 GB (conv1 input at batch 512: 6.7 GB).
-    const long long tile_row0 = row_addr(p.amap, m0 < p.M ? m0 : p.M - 1);  // wave-uniform
+    const int m0_ld = ABL == 11 ? 0 : m0;  // ABL 11 (timing probe): every workgroup stages A tile 0 - always an L2 hit
+    const long long tile_row0 = row_addr(p.amap, m0_ld < p.M ? m0_ld : p.M - 1);  // wave-uniform
     unsigned a_off[2][2], b_off[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
         b_off[i] = (unsigned)(((long long)row * p.ldw + sw) * 2);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            int m = m0 + h * 128 + row;
+            int m = m0_ld + h * 128 + row;
             m = m < p.M ? m : p.M - 1;
             a_off[h][i] = (unsigned)((row_addr(p.amap, m) - tile_row0 + sw) * 2);
         }
