@@ -138,6 +138,10 @@ def load(diag=None):
     return lib
 
 
+# nomad_status (include/nomad_hip.h)
+NOMAD_OK, NOMAD_ERR_INVALID, NOMAD_ERR_NO_DEVICE, NOMAD_ERR_HIP, NOMAD_ERR_WORKSPACE, NOMAD_ERR_IO, NOMAD_ERR_FORMAT = 0, -1, -2, -3, -4, -5, -6
+
+
 class NomadHipError(RuntimeError):
     pass
 

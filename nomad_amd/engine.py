@@ -337,6 +337,8 @@ class Engine:
         if not wav.is_contiguous():
             wav = wav.contiguous()
         B, N = wav.shape
+        if num_frames(N) < 1:
+            raise ValueError(f"clip of {N} samples is shorter than the conv stack's receptive field")
         _lib.check(self.lib.nomad_enable_bf16(self.ctx), "nomad_enable_bf16")
         emb = torch.empty(B, 256, dtype=torch.float32, device=self.device)
         rows = B * int(self.lib.nomad_num_frames(N))
@@ -383,12 +385,12 @@ class Engine:
         if not wav.is_contiguous():
             wav = wav.contiguous()
         B, N = wav.shape
+        T = num_frames(N)
+        if T < 1:
+            raise ValueError(f"clip of {N} samples is shorter than the conv stack's receptive field")
         _lib.check(self.lib.nomad_enable_bf16x3(self.ctx), "nomad_enable_bf16x3")
         emb = torch.empty(B, 256, dtype=torch.float32, device=self.device)
         if want_layers or head is not None:
-            T = num_frames(N)
-            if T < 1:
-                raise ValueError(f"clip of {N} samples is shorter than the conv stack's receptive field")
             hw, hb = head if head is not None else (None, None)
             for t, name in ((hw, "head weight"), (hb, "head bias")):
                 if t is not None:
