@@ -41,8 +41,6 @@
 #include "gemm_bf16x3.hip.h"
 #include "gemm_f32.hip.h"
 #ifdef NOMAD_DIAG  // libnomad_diag.so only: experiments kept for A/B measurements (tools/, tests of the experimental tiles)
-#include "gemm_bf16_8phase32.hip.h"
-#include "gemm_f32_pp.hip.h"
 #endif
 #include "pairwise.hip.h"
 #include "rowops.hip.h"
@@ -573,11 +571,6 @@ int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, in
         case 43: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 3>(p, groups, s); break;   // t33 + s_setprio around the MFMAs (-4 %)
         case 44: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 1>(p, groups, s); break;            // t33 with global_load_lds (64-bit per-lane pointers)
         case 45: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 5>(p, groups, s); break;            // t33 with the DMA issued right behind the barrier
-        case 46:  // 256x256, one workgroup/CU, ping-pong wave rows (gemm_f32_pp.hip.h)
-        case 47:  // ablation: no epilogue stores
-            if (p.N % 256 != 0 || p.K % 64 != 0) return fail(NOMAD_ERR_INVALID, "fp32 ping-pong gemm: N %% 256, K %% 64");
-            e = tile == 46 ? launch_gemm_f32_pp<false>(p, groups, s) : launch_gemm_f32_pp<true>(p, groups, s);
-            break;
         case 49: e = launch_gemm_n48<false>(p, groups, s); break;   // A/B: global_load_lds instead of buffer_load..lds   // N = 48 exactly (16x16x4 MFMA): the grouped pos-conv
         case 14: e = launch_gemm<128, 128, 32, 2, 2, 1>(p, groups, s); break;            // ablations of tile 0
         case 15: e = launch_gemm<128, 128, 32, 2, 2, 2>(p, groups, s); break;
@@ -1372,7 +1365,7 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
             tile = 16;  // deep-pipelined 256x256 kernel once there are >= 2 rounds of tiles (profiles/r01_gemm_sweep_bf16_8phase.json)
         else tile = (p.N % 256 == 0 && (p.N >= 1024 || p.M >= 100000)) ? 3 : 1;
     }
-    Scope sc(c, s, NOMAD_K_GEMM, flops, (tile == 1 || tile == 3 || tile == 16 || tile == 40 || tile == 41 || tile == 42 || tile == 43 || tile == 44 || tile == 45 || tile == 20 || tile == 21 || tile == 27 || tile == 28 || tile == 32 || tile == 33) ? NOMAD_K_GEMM_BIG : (tile == 2 ? NOMAD_K_GEMM_FINE : -1));
+    Scope sc(c, s, NOMAD_K_GEMM, flops, (tile == 1 || tile == 3 || tile == 16 || tile == 42 || tile == 43 || tile == 44 || tile == 45 || tile == 20 || tile == 21 || tile == 27 || tile == 28 || tile == 32 || tile == 33) ? NOMAD_K_GEMM_BIG : (tile == 2 ? NOMAD_K_GEMM_FINE : -1));
     hipError_t e;
     switch (tile) {
         // the instantiations the bf16 / bf16x3 forwards select
@@ -1420,14 +1413,6 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
         case 21:  // ... fp32 output
             if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16x3 gemm: N %% 256, K %% 128");
             e = tile == 20 ? launch_gemm_bf16_8phase<0, false, 1>(p, groups, s) : launch_gemm_bf16_8phase<0, false, 2>(p, groups, s);
-            break;
-        case 40:  // the 8-phase schedule on v_mfma_f32_32x32x16_bf16 (gemm_bf16_8phase32.hip.h): bit-identical, not faster
-            if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
-            e = launch_gemm_bf16_8phase32<false>(p, groups, s);
-            break;
-        case 41:  // 32x32x16 8-phase kernel without its epilogue stores (timing ablation)
-            if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
-            e = launch_gemm_bf16_8phase32<true>(p, groups, s);
             break;
         case 42:  // A/B: 8-phase kernel with non-temporal output stores / + residual loads / residual loads only
         case 43:
@@ -2436,7 +2421,7 @@ int nomad_diag_timeline(unsigned long long* out_host, int n) {
 int nomad_diag_gemm_bf16(nomad_ctx* c, const void* A, const void* W, const float* bias, const void* R, void* C, int M,
                          int N, int K, int gelu, int tile, nomad_stream_t stream) {
     static const int kBN[] = {128, 128, 64, 256, 64, 128, 128, 128, 128, 256, 256, 128, 128, 128, 128, 256, 256, 256, 256, 256};
-    const bool big256 = tile == 36 || (tile >= 40 && tile <= 45);
+    const bool big256 = tile == 36 || (tile >= 42 && tile <= 45);
     if (!c || !A || !W || !C || M <= 0 || tile < 0 || (!big256 && tile >= static_cast<int>(sizeof(kBN) / sizeof(kBN[0])))) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: bad argument");
     if (N % (big256 ? 256 : kBN[tile]) || K % 64) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: N %% %d or K %% 64 != 0", big256 ? 256 : kBN[tile]);
     GemmParams p = dense(static_cast<const float*>(A), K, static_cast<const float*>(W), bias, static_cast<const float*>(R),

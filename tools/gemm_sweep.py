@@ -83,9 +83,9 @@ TILE_NAMES.update({32: "glds 256x128x16 ABL no-epilogue", 33: "glds 256x128x16 w
                    38: "glds 128x32x32 w4x1 3-stage", 39: "glds 32x32x32 w1x1 3-stage",
                    40: "glds 256x256x16 w4x4 3-stage", 41: "glds 256x256x16 w4x4 2-stage",
                    42: "t33 with workgroup barriers in the epilogue", 43: "t33 + setprio", 44: "t33 with global_load_lds", 45: "t33 with DMA right behind the barrier",
-                   46: "ping-pong 256x256x32 1wg/cu", 47: "ping-pong 256x256x32 ABL no-epilogue",
+                   
                    48: "n48 16x16x4 buffer_load..lds", 49: "n48 16x16x4 global_load_lds"})
-BN.update({32: 128, 33: 128, 34: 64, 35: 128, 36: 32, 37: 64, 38: 32, 39: 32, 40: 256, 41: 256, 42: 128, 43: 128, 44: 128, 45: 128, 46: 256, 47: 256, 48: 48, 49: 48})
+BN.update({32: 128, 33: 128, 34: 64, 35: 128, 36: 32, 37: 64, 38: 32, 39: 32, 40: 256, 41: 256, 42: 128, 43: 128, 44: 128, 45: 128, 48: 48, 49: 48})
 TILE_NAMES.update({28: "glds 128x64x16 w2x2", 29: "glds 128x64x32 w4x2", 30: "glds 128x64x32 w2x2", 31: "glds 128x128x32 w4x2"})
 
 
@@ -107,9 +107,9 @@ def main():
                  9: "bf16 256x256 w2x4 bk32 4st", 10: "bf16 256x256 w4x2 bk32 4st", 11: "bf16 128x128 w4x2 bk32 4st",
                  12: "bf16 128x128 w4x2 bk64 3st", 13: "bf16 256x128 w4x2 bk64 3st", 14: "bf16 256x128 w4x2 bk32 4st",
                  15: "bf16 256x256 w2x4 bk64 2st", 16: "bf16 256x256 8-phase", 17: "bf16 256x256 8-phase ABL no-epilogue", 18: "bf16 256x256 8-phase buffer_load..lds", 19: "bf16 256x256 8-phase no setprio", 36: "bf16 256x256 8-phase, timeline probe build",
-                 42: "bf16 256x256 8-phase, non-temporal C stores", 43: "bf16 256x256 8-phase, non-temporal C stores + R loads", 44: "bf16 256x256 8-phase, non-temporal R loads", 45: "bf16 256x256 8-phase, probe: A tile 0 for every workgroup", 40: "bf16 256x256 8-phase on 32x32x16 MFMA", 41: "bf16 256x256 8-phase 32x32x16 ABL no-epilogue"}
+                 42: "bf16 256x256 8-phase, non-temporal C stores", 43: "bf16 256x256 8-phase, non-temporal C stores + R loads", 44: "bf16 256x256 8-phase, non-temporal R loads", 45: "bf16 256x256 8-phase, probe: A tile 0 for every workgroup",}
         bn = {0: 128, 1: 128, 2: 64, 3: 256, 4: 64, 5: 128, 6: 128, 7: 128, 8: 128, 9: 256, 10: 256, 11: 128, 12: 128,
-              13: 128, 14: 128, 15: 256, 16: 256, 17: 256, 18: 256, 19: 256, 36: 256, 40: 256, 41: 256, 42: 256, 43: 256, 44: 256, 45: 256}
+              13: 128, 14: 128, 15: 256, 16: 256, 17: 256, 18: 256, 19: 256, 36: 256, 42: 256, 43: 256, 44: 256, 45: 256}
         for sname in a.shapes.split(","):
             M, N, K, has_b, gelu, has_r = SHAPES[sname]
             A = torch.randn(M, K, generator=g).bfloat16().cuda()
@@ -118,7 +118,7 @@ def main():
             R = torch.randn(M, N, generator=g).bfloat16().cuda() if has_r else None
             first = None
             for t in (int(x) for x in a.tiles.split(",")):
-                if N % bn[t] or (t in (16, 17, 18, 19, 36, 40, 41, 42, 43, 44, 45) and K % 128):
+                if N % bn[t] or (t in (16, 17, 18, 19, 36, 42, 43, 44, 45) and K % 128):
                     continue
                 out = eng.diag_gemm_bf16(A, W, b, R, gelu=gelu, tile=t).float()
                 if first is None:
