@@ -156,9 +156,18 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p, const f32x4 (&a
 constexpr int kTimelineSlots = 4096;
 __device__ unsigned long long g_timeline[kTimelineSlots * 6];
 
-template <int ABL = 0, bool BUFLD = false, int X3 = 0>
+// NB = 3 (plain bf16 only): THREE B buffers.  With two, B of tile t+1 can only be issued in phases 1 / 2 of tile t (its buffer
+//   is read until phase 3 of tile t-1) and is waited for in phase 4 of the same tile: 2-3 phases of lead, less than an L2
+//   round trip under load once the loop runs near the MFMA rate.  With three, B of tile t+2 is issued in phases 1 / 2 of tile t
+//   and waited for in phase 4 of tile t+1 (vmcnt(8): B and A of tile t+2 may be outstanding) - 1.75 K tiles of lead; A keeps
+//   its two buffers and one tile of lead.  LDS: A0 A1 (32 KB each) | B0 B1 B2 = 160 KB; the B buffer of a K tile rotates
+//   (t mod 3, a scalar offset).  Same MFMA order, same results.
+template <int ABL = 0, bool BUFLD = false, int X3 = 0, int NB = 2>
 __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams p) {
     using Cfg = P8Cfg;
+    static_assert(NB == 2 || (NB == 3 && X3 == 0 && !BUFLD), "three B buffers: plain bf16, global_load_lds");
+    constexpr bool B3 = NB == 3;
+    constexpr int A_BUF = 2 * Cfg::HALF_BYTES;   // B3 layout: A buffers at 0 / 32 KB, B buffers from 64 KB on
     extern __shared__ __attribute__((aligned(16))) char smem8[];
     const unsigned long long t_entry_ = ABL == 7 ? wall_clock64() : 0ull;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -217,7 +226,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
         const int k0_ = kt_ * 64;                                                                               \
         const int kq_ = k0_ / p.kchunk;                                                                         \
         const unsigned ko_ = (unsigned)((kq_ * p.kstride + (k0_ - kq_ * p.kchunk)) * 2);                        \
-        char* d_ = dma_dst + ((KT)&1) * Cfg::BUF_BYTES + (H)*Cfg::HALF_BYTES;                                   \
+        char* d_ = dma_dst + ((KT)&1) * (B3 ? A_BUF : Cfg::BUF_BYTES) + (H)*Cfg::HALF_BYTES;                    \
         if (ABL == 4 || ABL == 5) {                                                                             \
         } else if (BUFLD) {                                                                                            \
             dma16_buffer(reinterpret_cast<const float*>(ab_), (lptr_t)(d_), (int)a_off[H][0], (int)ko_);          \
@@ -237,7 +246,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
             kt_ = kk_;                                                                                          \
         }                                                                                                       \
         const unsigned ko_ = (unsigned)(kt_ * 128);                                                             \
-        char* d_ = dma_dst + ((KT)&1) * Cfg::BUF_BYTES + (2 + (H)) * Cfg::HALF_BYTES;                           \
+        char* d_ = B3 ? dma_dst + 2 * A_BUF + b3_dst_ + (H)*Cfg::HALF_BYTES                                    \
+                      : dma_dst + ((KT)&1) * Cfg::BUF_BYTES + (2 + (H)) * Cfg::HALF_BYTES;                      \
         if (ABL == 4 || ABL == 5) {                                                                             \
         } else if (BUFLD) {                                                                                            \
             dma16_buffer(reinterpret_cast<const float*>(bb_), (lptr_t)(d_), (int)b_off[0], (int)ko_);             \
@@ -256,13 +266,22 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
 
     const int nk = (X3 ? 3 : 1) * (p.K / 64);  // even
     // prologue: tile 0 complete, A of tile 1 on its way
+    int b3_cur = 0;    // B3: byte offset of the B buffer of the current K tile (t mod 3) ...
+    int b3_dst_ = 0;   // ... and of the buffer a NOMAD_P8_DMA_B fills
     NOMAD_P8_DMA_A(0, 0)
     NOMAD_P8_DMA_A(0, 1)
     NOMAD_P8_DMA_B(0, 0)
     NOMAD_P8_DMA_B(0, 1)
     NOMAD_P8_DMA_A(1, 0)
     NOMAD_P8_DMA_A(1, 1)
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (B3) {  // tile 1 complete too: B of tile t+1 is never issued inside the loop
+        b3_dst_ = A_BUF;
+        NOMAD_P8_DMA_B(1, 0)
+        NOMAD_P8_DMA_B(1, 1)
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     unsigned long long ts_[4] = {0, 0, 0, 0};
@@ -276,7 +295,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
     const int sw = (fr >> 1) & 7;
     const int koff0 = ((0 + fq) ^ sw) * 16, koff1 = ((4 + fq) ^ sw) * 16;
     const int a_frag = wr * Cfg::HALF_BYTES + fr * 128;                                         // + i * 2048
-    const int b_frag = (2 + (wc >> 1)) * Cfg::HALF_BYTES + ((wc & 1) * 64 + fr) * 128;          // + j * 2048
+    const int b_frag = (B3 ? 2 * A_BUF + (wc >> 1) * Cfg::HALF_BYTES : (2 + (wc >> 1)) * Cfg::HALF_BYTES) + ((wc & 1) * 64 + fr) * 128;  // + j * 2048
 
     bf16x8 af[8][2], bf[2][2];
     if (ABL >= 3) {  // timing probes may skip fragment loads: keep the registers defined
@@ -302,8 +321,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
     // one K tile (buffer BUF = KT & 1, a compile-time constant per call site)
 #define NOMAD_P8_KTILE(KT, BUF)                                                                            \
     {                                                                                                      \
-        const char* la_ = smem8 + (BUF)*Cfg::BUF_BYTES + a_frag;                                           \
-        const char* lb_ = smem8 + (BUF)*Cfg::BUF_BYTES + b_frag;                                           \
+        const char* la_ = smem8 + (BUF) * (B3 ? A_BUF : Cfg::BUF_BYTES) + a_frag;                          \
+        const char* lb_ = smem8 + (B3 ? b3_cur : (BUF)*Cfg::BUF_BYTES) + b_frag;                           \
+        if (B3) b3_dst_ = b3_cur >= A_BUF ? b3_cur - A_BUF : b3_cur + 2 * A_BUF; /* buffer of tile t+2 */  \
         /* phase 1: B columns 0..31, A rows 0..63 */                                                       \
         if (ABL != 5 && ABL != 6) _Pragma("unroll") for (int j = 0; j < 2; ++j) {                          \
             bf[j][0] = *reinterpret_cast<const bf16x8*>(lb_ + j * 2048 + koff0);                           \
@@ -313,14 +333,18 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
             af[i][0] = *reinterpret_cast<const bf16x8*>(la_ + i * 2048 + koff0);                           \
             af[i][1] = *reinterpret_cast<const bf16x8*>(la_ + i * 2048 + koff1);                           \
         }                                                                                                  \
-        if ((KT) + 1 < nk) NOMAD_P8_DMA_B((KT) + 1, 0)                                                     \
+        if (B3) {                                                                                          \
+            if ((KT) + 2 < nk) NOMAD_P8_DMA_B((KT) + 2, 0)                                                 \
+        } else if ((KT) + 1 < nk) NOMAD_P8_DMA_B((KT) + 1, 0)                                              \
         NOMAD_P8_SYNC_COMPUTE(0, 0)                                                                        \
         /* phase 2: A rows 64..127 */                                                                      \
         if (!(ABL == 3 && (KT) % 3 == 1) && ABL != 5 && ABL != 6) _Pragma("unroll") for (int i = 4; i < 8; ++i) {                  \
             af[i][0] = *reinterpret_cast<const bf16x8*>(la_ + i * 2048 + koff0);                           \
             af[i][1] = *reinterpret_cast<const bf16x8*>(la_ + i * 2048 + koff1);                           \
         }                                                                                                  \
-        if ((KT) + 1 < nk) NOMAD_P8_DMA_B((KT) + 1, 1)                                                     \
+        if (B3) {                                                                                          \
+            if ((KT) + 2 < nk) NOMAD_P8_DMA_B((KT) + 2, 1)                                                 \
+        } else if ((KT) + 1 < nk) NOMAD_P8_DMA_B((KT) + 1, 1)                                              \
         NOMAD_P8_SYNC_COMPUTE(4, 0)                                                                        \
         /* phase 3: B columns 32..63 */                                                                    \
         if (ABL != 5 && ABL != 6) _Pragma("unroll") for (int j = 0; j < 2; ++j) {                          \
@@ -332,11 +356,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
         if ((KT) + 2 < nk) {                                                                               \
             NOMAD_P8_DMA_A((KT) + 2, 0)                                                                    \
             NOMAD_P8_DMA_A((KT) + 2, 1)                                                                    \
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                               \
+            if (B3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                       \
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                          \
         } else {                                                                                           \
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                               \
         }                                                                                                  \
         NOMAD_P8_SYNC_COMPUTE(4, 2)                                                                        \
+        if (B3) b3_cur = b3_cur >= 2 * A_BUF ? 0 : b3_cur + A_BUF;                                         \
     }
 
     for (int kt = 0; kt < nk; kt += 2) {
@@ -365,18 +391,19 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
     }
 }
 
-template <int ABL = 0, bool BUFLD = false, int X3 = 0>
+template <int ABL = 0, bool BUFLD = false, int X3 = 0, int NB = 2>
 inline hipError_t launch_gemm_bf16_8phase(GemmParams p, int groups, hipStream_t s) {
     p.tiles_m = (p.M + P8Cfg::BM - 1) / P8Cfg::BM;
     p.tiles_n = p.N / P8Cfg::BN;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_8phase_kernel<ABL, BUFLD, X3>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_8phase_kernel<ABL, BUFLD, X3, NB>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_8phase_kernel<ABL, BUFLD, X3>), dim3(p.tiles_m * p.tiles_n, groups), dim3(P8Cfg::THREADS), P8Cfg::LDS_BYTES, s, p);
+    hipLaunchKernelGGL((gemm_bf16_8phase_kernel<ABL, BUFLD, X3, NB>), dim3(p.tiles_m * p.tiles_n, groups), dim3(P8Cfg::THREADS),
+                       NB == 3 ? 160 * 1024 : P8Cfg::LDS_BYTES, s, p);
     return hipGetLastError();
 }
 
