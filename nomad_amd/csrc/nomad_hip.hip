@@ -38,7 +38,6 @@
 #include "frontend.hip.h"
 #include "gemm_bf16.hip.h"
 #include "gemm_bf16_8phase.hip.h"
-#include "gemm_bf16_p2.hip.h"
 #include "gemm_bf16x3.hip.h"
 #include "gemm_f32.hip.h"
 #ifdef NOMAD_DIAG  // libnomad_diag.so only: experiments kept for A/B measurements (tools/, tests of the experimental tiles)
@@ -1355,6 +1354,15 @@ static bool p8_nt_stores() {
     return v;
 }
 
+// three B buffers in the deep-pipelined bf16 kernel (B staged 1.75 K tiles ahead, 160 KB of LDS); NOMAD_BF16_B3=0: two (A/B runs)
+static bool p8_three_b() {
+    static const bool v = [] {
+        const char* e = getenv("NOMAD_BF16_B3");
+        return e ? atoi(e) != 0 : true;
+    }();
+    return v;
+}
+
 static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, int tile = -1) {
     const double flops = 2.0 * p.M * (double)p.n_valid * p.K * groups;  // bf16x3: the fp32-equivalent count, not 3x
     if (tile < 0) {
@@ -1366,7 +1374,7 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
             tile = 16;  // deep-pipelined 256x256 kernel once there are >= 2 rounds of tiles (profiles/r01_gemm_sweep_bf16_8phase.json)
         else tile = (p.N % 256 == 0 && (p.N >= 1024 || p.M >= 100000)) ? 3 : 1;
     }
-    Scope sc(c, s, NOMAD_K_GEMM, flops, (tile == 1 || tile == 3 || tile == 16 || tile == 42 || tile == 43 || tile == 44 || tile == 45 || tile == 46 || tile == 47 || tile == 48 || tile == 49 || tile == 50 || tile == 51 || tile == 52 || tile == 20 || tile == 21 || tile == 27 || tile == 28 || tile == 32 || tile == 33) ? NOMAD_K_GEMM_BIG : (tile == 2 ? NOMAD_K_GEMM_FINE : -1));
+    Scope sc(c, s, NOMAD_K_GEMM, flops, (tile == 1 || tile == 3 || tile == 16 || tile == 42 || tile == 43 || tile == 44 || tile == 45 || tile == 46 || tile == 47 || tile == 48 || tile == 49 || tile == 20 || tile == 21 || tile == 27 || tile == 28 || tile == 32 || tile == 33) ? NOMAD_K_GEMM_BIG : (tile == 2 ? NOMAD_K_GEMM_FINE : -1));
     hipError_t e;
     switch (tile) {
         // the instantiations the bf16 / bf16x3 forwards select
@@ -1376,7 +1384,8 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
         case 4: e = launch_gemm_bf16<64, 64, 2, 2>(p, groups, s); break;
         case 16:  // 256x256 deep-pipelined schedule (gemm_bf16_8phase.hip.h)
             if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
-            e = p8_nt_stores() ? launch_gemm_bf16_8phase<8>(p, groups, s) : launch_gemm_bf16_8phase<0>(p, groups, s);
+            e = !p8_nt_stores() ? launch_gemm_bf16_8phase<0>(p, groups, s)
+                : p8_three_b()  ? launch_gemm_bf16_8phase<8, false, 0, 3>(p, groups, s) : launch_gemm_bf16_8phase<8>(p, groups, s);
             break;
         case 27:  // bf16x3, every plane staged once (gemm_bf16x3.hip.h): split output
         case 28:  // ... fp32 output
@@ -1430,12 +1439,6 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
         case 49:
             if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
             e = tile == 47 ? launch_gemm_bf16_8phase<4>(p, groups, s) : tile == 48 ? launch_gemm_bf16_8phase<5>(p, groups, s) : launch_gemm_bf16_8phase<6>(p, groups, s);
-            break;
-        case 50:  // two 32-MFMA phases per K tile, three B buffers (gemm_bf16_p2.hip.h)
-        case 51:  // ... without its epilogue stores / with neither DMA nor LDS reads (timing probes)
-        case 52:
-            if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 p2 gemm: N %% 256, K %% 128");
-            e = tile == 50 ? launch_gemm_bf16_p2<0>(p, groups, s) : tile == 51 ? launch_gemm_bf16_p2<1>(p, groups, s) : launch_gemm_bf16_p2<5>(p, groups, s);
             break;
         case 45:  // timing probe: every workgroup stages A tile 0 (wrong results)
             if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
@@ -2438,7 +2441,7 @@ int nomad_diag_timeline(unsigned long long* out_host, int n) {
 int nomad_diag_gemm_bf16(nomad_ctx* c, const void* A, const void* W, const float* bias, const void* R, void* C, int M,
                          int N, int K, int gelu, int tile, nomad_stream_t stream) {
     static const int kBN[] = {128, 128, 64, 256, 64, 128, 128, 128, 128, 256, 256, 128, 128, 128, 128, 256, 256, 256, 256, 256};
-    const bool big256 = tile == 36 || (tile >= 42 && tile <= 52);
+    const bool big256 = tile == 36 || (tile >= 42 && tile <= 49);
     if (!c || !A || !W || !C || M <= 0 || tile < 0 || (!big256 && tile >= static_cast<int>(sizeof(kBN) / sizeof(kBN[0])))) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: bad argument");
     if (N % (big256 ? 256 : kBN[tile]) || K % 64) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: N %% %d or K %% 64 != 0", big256 ? 256 : kBN[tile]);
     GemmParams p = dense(static_cast<const float*>(A), K, static_cast<const float*>(W), bias, static_cast<const float*>(R),

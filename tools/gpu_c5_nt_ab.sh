@@ -1,6 +1,7 @@
 #!/bin/bash
-# same-box alternating A/B of NOMAD_BF16_NT_STORES: config C5 (bf16) and the bf16x3 line of the headline config
+# same-box alternating A/B of an environment switch of the bf16 GEMM on config C5 end to end
+# Usage: bash tools/gpu_c5_nt_ab.sh [VAR]      (NOMAD_BF16_NT_STORES, NOMAD_BF16_B3)
+VAR=${1:-NOMAD_BF16_B3}
 for i in 1 2 3; do for v in 0 1; do
-  NOMAD_BF16_NT_STORES=$v python bench.py --dtype bf16 --seconds 30 --batch 32 --refs 4 --steps 10 --warmup 3 --no-cpu-baseline --no-profile 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('c5 nt=$v', d['value'], d['ms_per_step'])"
-  NOMAD_BF16_NT_STORES=$v python bench.py --dtype bf16x3 --steps 6 --warmup 2 --no-cpu-baseline --no-profile 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('bf16x3 nt=$v', d['value'], d['ms_per_step'])"
+  env $VAR=$v python bench.py --dtype bf16 --seconds 30 --batch 32 --refs 4 --steps 10 --warmup 3 --no-cpu-baseline --no-profile 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('c5 $VAR=$v', d['value'], d['ms_per_step'])"
 done; done
