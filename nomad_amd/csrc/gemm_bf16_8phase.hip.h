@@ -151,6 +151,7 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p, const f32x4 (&a
 //   (p.c_plane), X3 = 2 stores fp32.
 //      8 / 9 / 10 = non-temporal output stores / stores + residual loads / residual loads only (A/B).
 //      11 = timing probe: every workgroup stages A tile 0 (A always hits in L2; wrong results).
+//      12 = timing probe: as 5 (no DMA, no LDS reads) and no barriers in the loop either - both wave rows issue MFMAs freely.
 // timing probe ABL 7 (tools/gemm_timeline.py): per workgroup {entry, main loop start, main loop end, stores done} in 100 MHz
 // wall-clock ticks + HW_ID + XCC_ID
 constexpr int kTimelineSlots = 4096;
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
         const int kq_ = k0_ / p.kchunk;                                                                         \
         const unsigned ko_ = (unsigned)((kq_ * p.kstride + (k0_ - kq_ * p.kchunk)) * 2);                        \
         char* d_ = dma_dst + ((KT)&1) * (B3 ? A_BUF : Cfg::BUF_BYTES) + (H)*Cfg::HALF_BYTES;                    \
-        if (ABL == 4 || ABL == 5) {                                                                             \
+        if (ABL == 4 || ABL == 5 || ABL == 12) {                                                                             \
         } else if (BUFLD) {                                                                                            \
             dma16_buffer(reinterpret_cast<const float*>(ab_), (lptr_t)(d_), (int)a_off[H][0], (int)ko_);          \
             dma16_buffer(reinterpret_cast<const float*>(ab_), (lptr_t)(d_ + 8192), (int)a_off[H][1], (int)ko_);   \
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
         const unsigned ko_ = (unsigned)(kt_ * 128);                                                             \
         char* d_ = B3 ? dma_dst + 2 * A_BUF + b3_dst_ + (H)*Cfg::HALF_BYTES                                    \
                       : dma_dst + ((KT)&1) * Cfg::BUF_BYTES + (2 + (H)) * Cfg::HALF_BYTES;                      \
-        if (ABL == 4 || ABL == 5) {                                                                             \
+        if (ABL == 4 || ABL == 5 || ABL == 12) {                                                                             \
         } else if (BUFLD) {                                                                                            \
             dma16_buffer(reinterpret_cast<const float*>(bb_), (lptr_t)(d_), (int)b_off[0], (int)ko_);             \
             dma16_buffer(reinterpret_cast<const float*>(bb_), (lptr_t)(d_ + 8192), (int)b_off[1], (int)ko_);      \
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
         ts_[0] = t_entry_;
         ts_[1] = wall_clock64();
     }
-    if (wr == 1) __builtin_amdgcn_s_barrier();  // second wave row runs one barrier behind (ping-pong)
+    if (wr == 1 && ABL != 12) __builtin_amdgcn_s_barrier();  // second wave row runs one barrier behind (ping-pong)
 
     // fragment addresses: this lane's row fr of a 16-row tile, chunk (4 kh + fq) ^ swizzle
     const int sw = (fr >> 1) & 7;
@@ -310,12 +311,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                  \
                 acc[(I0) + i][(J0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[(I0) + i][kh], bf[j][kh], acc[(I0) + i][(J0) + j], 0, 0, 0);
 #define NOMAD_P8_SYNC_COMPUTE(I0, J0)                   \
-    __builtin_amdgcn_s_barrier();                       \
+    if (ABL != 12) __builtin_amdgcn_s_barrier();        \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
-    if (ABL != 2) __builtin_amdgcn_s_setprio(1);        \
+    if (ABL != 2 && ABL != 12) __builtin_amdgcn_s_setprio(1);        \
     NOMAD_P8_MMA(I0, J0)                                \
-    if (ABL != 2) __builtin_amdgcn_s_setprio(0);        \
-    __builtin_amdgcn_s_barrier();                       \
+    if (ABL != 2 && ABL != 12) __builtin_amdgcn_s_setprio(0);        \
+    if (ABL != 12) __builtin_amdgcn_s_barrier();        \
     asm volatile("" ::: "memory");
 
     // one K tile (buffer BUF = KT & 1, a compile-time constant per call site)
@@ -325,11 +326,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
         const char* lb_ = smem8 + (B3 ? b3_cur : (BUF)*Cfg::BUF_BYTES) + b_frag;                           \
         if (B3) b3_dst_ = b3_cur >= A_BUF ? b3_cur - A_BUF : b3_cur + 2 * A_BUF; /* buffer of tile t+2 */  \
         /* phase 1: B columns 0..31, A rows 0..63 */                                                       \
-        if (ABL != 5 && ABL != 6) _Pragma("unroll") for (int j = 0; j < 2; ++j) {                          \
+        if (ABL != 5 && ABL != 6 && ABL != 12) _Pragma("unroll") for (int j = 0; j < 2; ++j) {                          \
             bf[j][0] = *reinterpret_cast<const bf16x8*>(lb_ + j * 2048 + koff0);                           \
             bf[j][1] = *reinterpret_cast<const bf16x8*>(lb_ + j * 2048 + koff1);                           \
         }                                                                                                  \
-        if (!(ABL == 3 && (KT) % 3 == 1) && ABL != 5 && ABL != 6) _Pragma("unroll") for (int i = 0; i < 4; ++i) {                  \
+        if (!(ABL == 3 && (KT) % 3 == 1) && ABL != 5 && ABL != 6 && ABL != 12) _Pragma("unroll") for (int i = 0; i < 4; ++i) {                  \
             af[i][0] = *reinterpret_cast<const bf16x8*>(la_ + i * 2048 + koff0);                           \
             af[i][1] = *reinterpret_cast<const bf16x8*>(la_ + i * 2048 + koff1);                           \
         }                                                                                                  \
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
         } else if ((KT) + 1 < nk) NOMAD_P8_DMA_B((KT) + 1, 0)                                              \
         NOMAD_P8_SYNC_COMPUTE(0, 0)                                                                        \
         /* phase 2: A rows 64..127 */                                                                      \
-        if (!(ABL == 3 && (KT) % 3 == 1) && ABL != 5 && ABL != 6) _Pragma("unroll") for (int i = 4; i < 8; ++i) {                  \
+        if (!(ABL == 3 && (KT) % 3 == 1) && ABL != 5 && ABL != 6 && ABL != 12) _Pragma("unroll") for (int i = 4; i < 8; ++i) {                  \
             af[i][0] = *reinterpret_cast<const bf16x8*>(la_ + i * 2048 + koff0);                           \
             af[i][1] = *reinterpret_cast<const bf16x8*>(la_ + i * 2048 + koff1);                           \
         }                                                                                                  \
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
         } else if ((KT) + 1 < nk) NOMAD_P8_DMA_B((KT) + 1, 1)                                              \
         NOMAD_P8_SYNC_COMPUTE(4, 0)                                                                        \
         /* phase 3: B columns 32..63 */                                                                    \
-        if (ABL != 5 && ABL != 6) _Pragma("unroll") for (int j = 0; j < 2; ++j) {                          \
+        if (ABL != 5 && ABL != 6 && ABL != 12) _Pragma("unroll") for (int j = 0; j < 2; ++j) {                          \
             bf[j][0] = *reinterpret_cast<const bf16x8*>(lb_ + (2 + j) * 2048 + koff0);                     \
             bf[j][1] = *reinterpret_cast<const bf16x8*>(lb_ + (2 + j) * 2048 + koff1);                     \
         }                                                                                                  \
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
         NOMAD_P8_KTILE(kt, 0)
         NOMAD_P8_KTILE(kt + 1, 1)
     }
-    if (wr == 0) __builtin_amdgcn_s_barrier();  // re-join the two wave rows
+    if (wr == 0 && ABL != 12) __builtin_amdgcn_s_barrier();  // re-join the two wave rows
 #undef NOMAD_P8_KTILE
 #undef NOMAD_P8_SYNC_COMPUTE
 #undef NOMAD_P8_MMA

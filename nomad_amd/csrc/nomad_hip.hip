@@ -1374,7 +1374,7 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
             tile = 16;  // deep-pipelined 256x256 kernel once there are >= 2 rounds of tiles (profiles/r01_gemm_sweep_bf16_8phase.json)
         else tile = (p.N % 256 == 0 && (p.N >= 1024 || p.M >= 100000)) ? 3 : 1;
     }
-    Scope sc(c, s, NOMAD_K_GEMM, flops, (tile == 1 || tile == 3 || tile == 16 || tile == 42 || tile == 43 || tile == 44 || tile == 45 || tile == 46 || tile == 47 || tile == 48 || tile == 49 || tile == 20 || tile == 21 || tile == 27 || tile == 28 || tile == 32 || tile == 33) ? NOMAD_K_GEMM_BIG : (tile == 2 ? NOMAD_K_GEMM_FINE : -1));
+    Scope sc(c, s, NOMAD_K_GEMM, flops, (tile == 1 || tile == 3 || tile == 16 || tile == 42 || tile == 43 || tile == 44 || tile == 45 || tile == 46 || tile == 47 || tile == 48 || tile == 49 || tile == 50 || tile == 20 || tile == 21 || tile == 27 || tile == 28 || tile == 32 || tile == 33) ? NOMAD_K_GEMM_BIG : (tile == 2 ? NOMAD_K_GEMM_FINE : -1));
     hipError_t e;
     switch (tile) {
         // the instantiations the bf16 / bf16x3 forwards select
@@ -1439,6 +1439,9 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
         case 49:
             if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
             e = tile == 47 ? launch_gemm_bf16_8phase<4>(p, groups, s) : tile == 48 ? launch_gemm_bf16_8phase<5>(p, groups, s) : launch_gemm_bf16_8phase<6>(p, groups, s);
+            break;
+        case 50:  // timing probe: no loads and no barriers in the loop (both wave rows issue MFMAs at once)
+            e = launch_gemm_bf16_8phase<12>(p, groups, s);
             break;
         case 45:  // timing probe: every workgroup stages A tile 0 (wrong results)
             if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
@@ -2441,7 +2444,7 @@ int nomad_diag_timeline(unsigned long long* out_host, int n) {
 int nomad_diag_gemm_bf16(nomad_ctx* c, const void* A, const void* W, const float* bias, const void* R, void* C, int M,
                          int N, int K, int gelu, int tile, nomad_stream_t stream) {
     static const int kBN[] = {128, 128, 64, 256, 64, 128, 128, 128, 128, 256, 256, 128, 128, 128, 128, 256, 256, 256, 256, 256};
-    const bool big256 = tile == 36 || (tile >= 42 && tile <= 49);
+    const bool big256 = tile == 36 || (tile >= 42 && tile <= 50);
     if (!c || !A || !W || !C || M <= 0 || tile < 0 || (!big256 && tile >= static_cast<int>(sizeof(kBN) / sizeof(kBN[0])))) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: bad argument");
     if (N % (big256 ? 256 : kBN[tile]) || K % 64) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: N %% %d or K %% 64 != 0", big256 ? 256 : kBN[tile]);
     GemmParams p = dense(static_cast<const float*>(A), K, static_cast<const float*>(W), bias, static_cast<const float*>(R),
