@@ -8,14 +8,14 @@ pytestmark = pytest.mark.gpu
 
 BF16_TILES = {0: (256, 128), 1: (128, 128), 2: (128, 64), 3: (256, 256), 4: (64, 64), 5: (128, 128), 6: (256, 128),
               9: (256, 256), 10: (256, 256), 11: (128, 128), 12: (128, 128), 13: (256, 128), 14: (256, 128), 15: (256, 256),
-              16: (256, 256), 40: (256, 256)}    # 16 / 40: the deep-pipelined kernel on 16x16x32 / 32x32x16 MFMA
+              16: (256, 256), 42: (256, 256)}    # 16: the deep-pipelined kernel as shipped (three B buffers); 42: with two (NOMAD_BF16_B3=0)
 
 
 @pytest.mark.parametrize("tile", sorted(BF16_TILES))
 @pytest.mark.parametrize("M", [1, 200, 257, 1000])
 def test_gemm_bf16_exact_integer_asymmetric(engine_for, tile, M):
     bm, bn = BF16_TILES[tile]
-    N, K = 2 * bn, (256 if tile in (16, 40) else 192)  # the deep-pipelined kernels walk K tiles in pairs: K % 128 == 0
+    N, K = 2 * bn, (256 if tile in (16, 42) else 192)  # the deep-pipelined kernels walk K tiles in pairs: K % 128 == 0
     g = torch.Generator().manual_seed(M + tile)
     A = torch.randint(-1, 2, (M, K), generator=g).float()
     W = torch.randint(-1, 2, (N, K), generator=g).float()
@@ -27,7 +27,7 @@ def test_gemm_bf16_exact_integer_asymmetric(engine_for, tile, M):
 
 @pytest.mark.parametrize("tile,M,N,K", [(0, 1500, 256, 768), (1, 700, 768, 3072), (2, 260, 64, 6144), (4, 84, 768, 512),
                                         (3, 600, 512, 1536), (16, 777, 768, 3072), (16, 1500, 512, 1536),
-                                        (16, 300, 2304, 768), (16, 4113, 256, 128)])
+                                        (16, 300, 2304, 768), (16, 4113, 256, 128), (42, 777, 768, 3072), (42, 300, 2304, 768)])
 @pytest.mark.parametrize("epi", ["none", "bias_gelu", "bias_res"])
 def test_gemm_bf16_epilogues(engine_for, tile, M, N, K, epi):
     g = torch.Generator().manual_seed(5)
