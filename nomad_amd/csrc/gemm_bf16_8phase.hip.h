@@ -168,6 +168,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
     using Cfg = P8Cfg;
     static_assert(NB == 2 || (NB == 3 && X3 == 0 && !BUFLD), "three B buffers: plain bf16, global_load_lds");
     constexpr bool B3 = NB == 3;
+    // cache-policy probes of the LDS-DMA (aux: 1 = sc0, 2 = nt, 16 = sc1): ABL 13 / 14 / 15 = nt on A / on B / on both, 16 = sc1 on both
+    constexpr int AUX_A = (ABL == 13 || ABL == 15) ? 2 : ABL == 16 ? 16 : 0, AUX_B = (ABL == 14 || ABL == 15) ? 2 : ABL == 16 ? 16 : 0;
     constexpr int A_BUF = 2 * Cfg::HALF_BYTES;   // B3 layout: A buffers at 0 / 32 KB, B buffers from 64 KB on
     extern __shared__ __attribute__((aligned(16))) char smem8[];
     const unsigned long long t_entry_ = ABL == 7 ? wall_clock64() : 0ull;
@@ -233,8 +235,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
             dma16_buffer(reinterpret_cast<const float*>(ab_), (lptr_t)(d_), (int)a_off[H][0], (int)ko_);          \
             dma16_buffer(reinterpret_cast<const float*>(ab_), (lptr_t)(d_ + 8192), (int)a_off[H][1], (int)ko_);   \
         } else {                                                                                                \
-            __builtin_amdgcn_global_load_lds((gptr_t)(ab_ + (a_off[H][0] + ko_)), (lptr_t)(d_), 16, 0, 0);         \
-            __builtin_amdgcn_global_load_lds((gptr_t)(ab_ + (a_off[H][1] + ko_)), (lptr_t)(d_ + 8192), 16, 0, 0);  \
+            __builtin_amdgcn_global_load_lds((gptr_t)(ab_ + (a_off[H][0] + ko_)), (lptr_t)(d_), 16, 0, AUX_A);         \
+            __builtin_amdgcn_global_load_lds((gptr_t)(ab_ + (a_off[H][1] + ko_)), (lptr_t)(d_ + 8192), 16, 0, AUX_A);  \
         }                                                                                                       \
     }
 #define NOMAD_P8_DMA_B(KT, H)                                                                                   \
@@ -254,8 +256,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
             dma16_buffer(reinterpret_cast<const float*>(bb_), (lptr_t)(d_), (int)b_off[0], (int)ko_);             \
             dma16_buffer(reinterpret_cast<const float*>(bb_), (lptr_t)(d_ + 8192), (int)b_off[1], (int)ko_);      \
         } else {                                                                                                \
-            __builtin_amdgcn_global_load_lds((gptr_t)(bb_ + (b_off[0] + ko_)), (lptr_t)(d_), 16, 0, 0);            \
-            __builtin_amdgcn_global_load_lds((gptr_t)(bb_ + (b_off[1] + ko_)), (lptr_t)(d_ + 8192), 16, 0, 0);     \
+            __builtin_amdgcn_global_load_lds((gptr_t)(bb_ + (b_off[0] + ko_)), (lptr_t)(d_), 16, 0, AUX_B);            \
+            __builtin_amdgcn_global_load_lds((gptr_t)(bb_ + (b_off[1] + ko_)), (lptr_t)(d_ + 8192), 16, 0, AUX_B);     \
         }                                                                                                       \
     }
 
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
 #undef NOMAD_P8_DMA_B
 
     if (ABL == 7) ts_[2] = wall_clock64();
-    p8_epilogue<ABL == 1, X3, (ABL == 8 ? 1 : ABL == 9 ? 3 : ABL == 10 ? 2 : 0)>(p, acc, smem8, grp, m0, n0, wave, wr, wc, lane, fr, fq);
+    p8_epilogue<ABL == 1, X3, (ABL == 8 || (ABL >= 13 && ABL <= 16) ? 1 : ABL == 9 ? 3 : ABL == 10 ? 2 : 0)>(p, acc, smem8, grp, m0, n0, wave, wr, wc, lane, fr, fq);
     if (ABL == 7) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the output stores have left the CU
         ts_[3] = wall_clock64();

@@ -1374,7 +1374,7 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
             tile = 16;  // deep-pipelined 256x256 kernel once there are >= 2 rounds of tiles (profiles/r01_gemm_sweep_bf16_8phase.json)
         else tile = (p.N % 256 == 0 && (p.N >= 1024 || p.M >= 100000)) ? 3 : 1;
     }
-    Scope sc(c, s, NOMAD_K_GEMM, flops, (tile == 1 || tile == 3 || tile == 16 || tile == 42 || tile == 43 || tile == 44 || tile == 45 || tile == 46 || tile == 47 || tile == 48 || tile == 49 || tile == 50 || tile == 20 || tile == 21 || tile == 27 || tile == 28 || tile == 32 || tile == 33) ? NOMAD_K_GEMM_BIG : (tile == 2 ? NOMAD_K_GEMM_FINE : -1));
+    Scope sc(c, s, NOMAD_K_GEMM, flops, (tile == 1 || tile == 3 || tile == 16 || tile == 42 || tile == 43 || tile == 44 || tile == 45 || tile == 46 || tile == 47 || tile == 48 || tile == 49 || tile == 50 || tile == 51 || tile == 52 || tile == 53 || tile == 54 || tile == 20 || tile == 21 || tile == 27 || tile == 28 || tile == 32 || tile == 33) ? NOMAD_K_GEMM_BIG : (tile == 2 ? NOMAD_K_GEMM_FINE : -1));
     hipError_t e;
     switch (tile) {
         // the instantiations the bf16 / bf16x3 forwards select
@@ -1385,7 +1385,7 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
         case 16:  // 256x256 deep-pipelined schedule (gemm_bf16_8phase.hip.h)
             if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
             e = !p8_nt_stores() ? launch_gemm_bf16_8phase<0>(p, groups, s)
-                : p8_three_b()  ? launch_gemm_bf16_8phase<8, false, 0, 3>(p, groups, s) : launch_gemm_bf16_8phase<8>(p, groups, s);
+                : !p8_three_b() ? launch_gemm_bf16_8phase<8>(p, groups, s) : launch_gemm_bf16_8phase<8, false, 0, 3>(p, groups, s);
             break;
         case 27:  // bf16x3, every plane staged once (gemm_bf16x3.hip.h): split output
         case 28:  // ... fp32 output
@@ -1439,6 +1439,14 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
         case 49:
             if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
             e = tile == 47 ? launch_gemm_bf16_8phase<4>(p, groups, s) : tile == 48 ? launch_gemm_bf16_8phase<5>(p, groups, s) : launch_gemm_bf16_8phase<6>(p, groups, s);
+            break;
+        case 51:  // cache-policy probes of the LDS-DMA on the shipped kernel (three B buffers, nt stores): nt on A / B / both, sc1 on both
+        case 52:
+        case 53:
+        case 54:
+            if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
+            e = tile == 51 ? launch_gemm_bf16_8phase<13, false, 0, 3>(p, groups, s) : tile == 52 ? launch_gemm_bf16_8phase<14, false, 0, 3>(p, groups, s)
+              : tile == 53 ? launch_gemm_bf16_8phase<15, false, 0, 3>(p, groups, s) : launch_gemm_bf16_8phase<16, false, 0, 3>(p, groups, s);
             break;
         case 50:  // timing probe: no loads and no barriers in the loop (both wave rows issue MFMAs at once)
             e = launch_gemm_bf16_8phase<12>(p, groups, s);
@@ -2444,7 +2452,7 @@ int nomad_diag_timeline(unsigned long long* out_host, int n) {
 int nomad_diag_gemm_bf16(nomad_ctx* c, const void* A, const void* W, const float* bias, const void* R, void* C, int M,
                          int N, int K, int gelu, int tile, nomad_stream_t stream) {
     static const int kBN[] = {128, 128, 64, 256, 64, 128, 128, 128, 128, 256, 256, 128, 128, 128, 128, 256, 256, 256, 256, 256};
-    const bool big256 = tile == 36 || (tile >= 42 && tile <= 50);
+    const bool big256 = tile == 36 || (tile >= 42 && tile <= 54);
     if (!c || !A || !W || !C || M <= 0 || tile < 0 || (!big256 && tile >= static_cast<int>(sizeof(kBN) / sizeof(kBN[0])))) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: bad argument");
     if (N % (big256 ? 256 : kBN[tile]) || K % 64) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: N %% %d or K %% 64 != 0", big256 ? 256 : kBN[tile]);
     GemmParams p = dense(static_cast<const float*>(A), K, static_cast<const float*>(W), bias, static_cast<const float*>(R),
