@@ -42,22 +42,25 @@ struct P8Cfg {
 // rows 4 fq + r of each 16 x 16 tile): 32-row fp32 slabs through LDS, bias / GELU / residual in fp32, 16-byte stores.
 // OUT: 0 = bf16, 1 = split planes (p.c_plane; R split too), 2 = fp32 (R split).  NOSTORE: timing ablation.
 // NT: bit 0 = output stores, bit 1 = residual loads carry the non-temporal hint (streamed through L2).
-template <bool NOSTORE, int X3, int NT = 0>
-__device__ __forceinline__ void p8_epilogue(const GemmParams& p, const f32x4 (&acc)[8][4], char* smem8, int grp, int m0, int n0,
+// NJ: 16-column accumulator tiles per wave (wave tile 128 x 16 NJ; 4 = the 256-column workgroup tile, 3 = the 192-column one).
+template <bool NOSTORE, int X3, int NT = 0, int NJ = 4>
+__device__ __forceinline__ void p8_epilogue(const GemmParams& p, const f32x4 (&acc)[8][NJ], char* smem8, int grp, int m0, int n0,
                                             int wave, int wr, int wc, int lane, int fr, int fq) {
     using Cfg = P8Cfg;
+    static_assert(NJ == 4 || NJ == 3, "wave tile of 64 or 48 columns");
     constexpr int ABL = NOSTORE ? 1 : 0;
+    constexpr int WTN = 16 * NJ;  // columns of a wave tile
     bf16_t* Cg = reinterpret_cast<bf16_t*>(p.C) + grp * p.c_goff;
     float* Cf = p.C + grp * p.c_goff;  // X3 == 2: fp32 output
     const bf16_t* Rg = p.R ? reinterpret_cast<const bf16_t*>(p.R) + grp * p.r_goff : nullptr;
     const float* biasg = p.bias ? p.bias + grp * p.bias_goff : nullptr;
     const bool c_plain = p.cmap.clip_rows >= p.M, r_plain = p.rmap.clip_rows >= p.M;
-    constexpr int ELD = Cfg::ELD;
+    constexpr int ELD = WTN + 4;
     float* slab = reinterpret_cast<float*>(smem8) + wave * (32 * ELD);
-    float bv[4];
+    float bv[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wc * 64 + j * 16 + fr;
+    for (int j = 0; j < NJ; ++j) {
+        const int n = n0 + wc * WTN + j * 16 + fr;
         bv[j] = (biasg && n < p.n_valid) ? biasg[n] : 0.f;
     }
     __syncthreads();  // every wave is done with the staging buffers
@@ -69,7 +72,7 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p, const f32x4 (&a
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float v = acc[2 * s4 + ii][j][r] + bv[j];
@@ -79,10 +82,10 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p, const f32x4 (&a
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (ABL != 1) {
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {  // 32 rows x 8 groups of 8 columns
-                const int id = lane + 64 * it, row = id >> 3, cg = id & 7;
+            for (int it = 0; it < NJ; ++it) {  // 32 rows x 2 NJ groups of 8 columns
+                const int id = lane + 64 * it, row = NJ == 4 ? id >> 3 : id / 6, cg = NJ == 4 ? id & 7 : id - 6 * row;
                 const int m = m0 + wr * 128 + s4 * 32 + row;
-                const int n = n0 + wc * 64 + cg * 8;
+                const int n = n0 + wc * WTN + cg * 8;
                 bool live = m < p.M && n < p.n_valid;
                 if (live && p.c_blk_step > 0 && p.c_colblk > 0) {  // column blocks are frames: drop those past the clip's end
                     int li, frames;
@@ -163,10 +166,17 @@ __device__ unsigned long long g_timeline[kTimelineSlots * 6];
 //   and waited for in phase 4 of tile t+1 (vmcnt(8): B and A of tile t+2 may be outstanding) - 1.75 K tiles of lead; A keeps
 //   its two buffers and one tile of lead.  LDS: A0 A1 (32 KB each) | B0 B1 B2 = 160 KB; the B buffer of a K tile rotates
 //   (t mod 3, a scalar offset).  Same MFMA order, same results.
-template <int ABL = 0, bool BUFLD = false, int X3 = 0, int NB = 2>
+// NJ = 3: a 256 x 192 workgroup tile (wave tile 128 x 48) for the N = 768 GEMMs (out_proj, fc2) whose 256 x 256 grids are a
+//   little over two rounds of the 256 CUs (C5: 564 tiles = 2.2 rounds, so the launch takes three rounds for 2.2 rounds of work;
+//   752 tiles of 256 x 192 = 2.94 rounds).  Same schedule: B tiles are 192 rows (the second B half is 64 rows = ONE DMA
+//   instruction per thread), phases 3 / 4 multiply the third 16-column tile only (16 + 16 + 8 + 8 MFMAs per K tile), the counted
+//   waits allow one DMA less.  Same MFMA order per output element, same results.
+template <int ABL = 0, bool BUFLD = false, int X3 = 0, int NB = 2, int NJ = 4>
 __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams p) {
     using Cfg = P8Cfg;
     static_assert(NB == 2 || (NB == 3 && X3 == 0 && !BUFLD), "three B buffers: plain bf16, global_load_lds");
+    static_assert(NJ == 4 || (NJ == 3 && X3 == 0 && !BUFLD), "192-column tiles: plain bf16, global_load_lds");
+    constexpr int BN = 64 * NJ;
     constexpr bool B3 = NB == 3;
     // cache-policy probes of the LDS-DMA (aux: 1 = sc0, 2 = nt, 16 = sc1): ABL 13 / 14 / 15 = nt on A / on B / on both, 16 = sc1 on both
     constexpr int AUX_A = (ABL == 13 || ABL == 15) ? 2 : ABL == 16 ? 16 : 0, AUX_B = (ABL == 14 || ABL == 15) ? 2 : ABL == 16 ? 16 : 0;
@@ -181,7 +191,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
     const int wg = xcd_remap(blockIdx.x, nwg);
     int tile_m, tile_n;
     tile_coords(wg, p.tiles_m, p.tiles_n, p.group_m, tile_m, tile_n);
-    const int m0 = tile_m * Cfg::BM, n0 = tile_n * Cfg::BN;
+    const int m0 = tile_m * Cfg::BM, n0 = tile_n * BN;
     const int grp = blockIdx.y;
     const bf16_t* Ag = reinterpret_cast<const bf16_t*>(p.A) + grp * p.a_goff;
     const bf16_t* Wg = reinterpret_cast<const bf16_t*>(p.W) + grp * p.w_goff;
@@ -257,15 +267,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
             dma16_buffer(reinterpret_cast<const float*>(bb_), (lptr_t)(d_ + 8192), (int)b_off[1], (int)ko_);      \
         } else {                                                                                                \
             __builtin_amdgcn_global_load_lds((gptr_t)(bb_ + (b_off[0] + ko_)), (lptr_t)(d_), 16, 0, AUX_B);            \
-            __builtin_amdgcn_global_load_lds((gptr_t)(bb_ + (b_off[1] + ko_)), (lptr_t)(d_ + 8192), 16, 0, AUX_B);     \
+            if (NJ == 4 || (H) == 0)                                                                            \
+                __builtin_amdgcn_global_load_lds((gptr_t)(bb_ + (b_off[1] + ko_)), (lptr_t)(d_ + 8192), 16, 0, AUX_B); \
         }                                                                                                       \
     }
 
-    f32x4 acc[8][4];
+    f32x4 acc[8][NJ];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = (X3 ? 3 : 1) * (p.K / 64);  // even
     // prologue: tile 0 complete, A of tile 1 on its way
@@ -281,7 +292,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
         b3_dst_ = A_BUF;
         NOMAD_P8_DMA_B(1, 0)
         NOMAD_P8_DMA_B(1, 1)
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (NJ == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // A and B of tile 1 may be outstanding
+        else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     }
@@ -298,7 +310,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
     const int sw = (fr >> 1) & 7;
     const int koff0 = ((0 + fq) ^ sw) * 16, koff1 = ((4 + fq) ^ sw) * 16;
     const int a_frag = wr * Cfg::HALF_BYTES + fr * 128;                                         // + i * 2048
-    const int b_frag = (B3 ? 2 * A_BUF + (wc >> 1) * Cfg::HALF_BYTES : (2 + (wc >> 1)) * Cfg::HALF_BYTES) + ((wc & 1) * 64 + fr) * 128;  // + j * 2048
+    // B rows (= output columns) are contiguous over the two halves: row 16 NJ wc + 16 j + fr of the workgroup tile
+    const int b_frag = (B3 ? 2 * A_BUF : 2 * Cfg::HALF_BYTES) + (wc * (16 * NJ) + fr) * 128;  // + j * 2048
 
     bf16x8 af[8][2], bf[2][2];
     if (ABL >= 3) {  // timing probes may skip fragment loads: keep the registers defined
@@ -311,7 +324,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
     _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                       \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                  \
-                acc[(I0) + i][(J0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[(I0) + i][kh], bf[j][kh], acc[(I0) + i][(J0) + j], 0, 0, 0);
+                if ((J0) + j < NJ)                                                                         \
+                    acc[(I0) + i][(J0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[(I0) + i][kh], bf[j][kh], acc[(I0) + i][(J0) + j], 0, 0, 0);
 #define NOMAD_P8_SYNC_COMPUTE(I0, J0)                   \
     if (ABL != 12) __builtin_amdgcn_s_barrier();        \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
@@ -350,7 +364,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
         } else if ((KT) + 1 < nk) NOMAD_P8_DMA_B((KT) + 1, 1)                                              \
         NOMAD_P8_SYNC_COMPUTE(4, 0)                                                                        \
         /* phase 3: B columns 32..63 */                                                                    \
-        if (ABL != 5 && ABL != 6 && ABL != 12) _Pragma("unroll") for (int j = 0; j < 2; ++j) {                          \
+        if (ABL != 5 && ABL != 6 && ABL != 12) _Pragma("unroll") for (int j = 0; j < NJ - 2; ++j) {                     \
             bf[j][0] = *reinterpret_cast<const bf16x8*>(lb_ + (2 + j) * 2048 + koff0);                     \
             bf[j][1] = *reinterpret_cast<const bf16x8*>(lb_ + (2 + j) * 2048 + koff1);                     \
         }                                                                                                  \
@@ -359,7 +373,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
         if ((KT) + 2 < nk) {                                                                               \
             NOMAD_P8_DMA_A((KT) + 2, 0)                                                                    \
             NOMAD_P8_DMA_A((KT) + 2, 1)                                                                    \
-            if (B3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                       \
+            if (B3 && NJ == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                            \
+            else if (B3) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");                                  \
             else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                          \
         } else {                                                                                           \
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                               \
@@ -380,7 +395,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
 #undef NOMAD_P8_DMA_B
 
     if (ABL == 7) ts_[2] = wall_clock64();
-    p8_epilogue<ABL == 1, X3, (ABL == 8 || (ABL >= 13 && ABL <= 16) ? 1 : ABL == 9 ? 3 : ABL == 10 ? 2 : 0)>(p, acc, smem8, grp, m0, n0, wave, wr, wc, lane, fr, fq);
+    p8_epilogue<ABL == 1, X3, (ABL == 8 || (ABL >= 13 && ABL <= 16) ? 1 : ABL == 9 ? 3 : ABL == 10 ? 2 : 0), NJ>(p, acc, smem8, grp, m0, n0, wave, wr, wc, lane, fr, fq);
     if (ABL == 7) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the output stores have left the CU
         ts_[3] = wall_clock64();
@@ -394,18 +409,18 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
     }
 }
 
-template <int ABL = 0, bool BUFLD = false, int X3 = 0, int NB = 2>
+template <int ABL = 0, bool BUFLD = false, int X3 = 0, int NB = 2, int NJ = 4>
 inline hipError_t launch_gemm_bf16_8phase(GemmParams p, int groups, hipStream_t s) {
     p.tiles_m = (p.M + P8Cfg::BM - 1) / P8Cfg::BM;
-    p.tiles_n = p.N / P8Cfg::BN;
+    p.tiles_n = p.N / (64 * NJ);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_8phase_kernel<ABL, BUFLD, X3, NB>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_8phase_kernel<ABL, BUFLD, X3, NB, NJ>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_8phase_kernel<ABL, BUFLD, X3, NB>), dim3(p.tiles_m * p.tiles_n, groups), dim3(P8Cfg::THREADS),
+    hipLaunchKernelGGL((gemm_bf16_8phase_kernel<ABL, BUFLD, X3, NB, NJ>), dim3(p.tiles_m * p.tiles_n, groups), dim3(P8Cfg::THREADS),
                        NB == 3 ? 160 * 1024 : P8Cfg::LDS_BYTES, s, p);
     return hipGetLastError();
 }

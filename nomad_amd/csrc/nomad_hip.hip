@@ -1363,6 +1363,24 @@ static bool p8_three_b() {
     return v;
 }
 
+// 256 x 192 instead of 256 x 256 tiles in the deep-pipelined bf16 kernel (gemm_bf16_8phase.hip.h, NJ = 3) for the N = 768 GEMMs
+// of config C5 (out_proj, fc2: 188 row tiles x 3 = 2.2 rounds of the 256 CUs, 2.94 with 192-column tiles).  Bit-identical
+// results.  OFF by default: in isolation fc2 runs 19 % and out_proj 12 % faster (hipBLASLt picks MT256x192 there too), but inside
+// the C5 forward the other GEMMs slow down by more than that - the chip holds 2130 instead of 2157 MHz (2400 nominal) with
+// them, 19.25 vs 18.98 ms per forward (profiles/r03_n192_null.txt).  NOMAD_BF16_N192=1 takes them wherever they save a round
+// (a 192-column tile costs ~0.78 of a 256-column one), =2 wherever N % 192 == 0.
+static bool p8_use_n192(int M, int N) {
+    static const int mode = [] {
+        const char* e = getenv("NOMAD_BF16_N192");
+        return e ? atoi(e) : 0;
+    }();
+    if (N % 192 != 0 || mode <= 0) return false;
+    if (mode >= 2) return true;
+    const long long tm = (M + 255) / 256;
+    const long long r256 = (tm * (N / 256) + 255) / 256, r192 = (tm * (N / 192) + 255) / 256;
+    return 0.78 * (double)r192 < 0.97 * (double)r256;
+}
+
 static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, int tile = -1) {
     const double flops = 2.0 * p.M * (double)p.n_valid * p.K * groups;  // bf16x3: the fp32-equivalent count, not 3x
     if (tile < 0) {
@@ -1371,10 +1389,10 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
         if (p.N % 128 != 0) tile = p.M < 512 ? 4 : 2;
         else if (p.M < 512) tile = 4;
         else if (p.N % 256 == 0 && p.K % 128 == 0 && groups == 1 && (long long)((p.M + 255) / 256) * (p.N / 256) >= p8_min_tiles())
-            tile = 16;  // deep-pipelined 256x256 kernel once there are >= 2 rounds of tiles (profiles/r01_gemm_sweep_bf16_8phase.json)
+            tile = (p8_three_b() && p8_nt_stores() && p8_use_n192(p.M, p.N)) ? 55 : 16;  // deep-pipelined 256x256 / 256x192 kernel once there are >= 2 rounds of tiles (profiles/r01_gemm_sweep_bf16_8phase.json)
         else tile = (p.N % 256 == 0 && (p.N >= 1024 || p.M >= 100000)) ? 3 : 1;
     }
-    Scope sc(c, s, NOMAD_K_GEMM, flops, (tile == 1 || tile == 3 || tile == 16 || tile == 42 || tile == 43 || tile == 44 || tile == 45 || tile == 46 || tile == 47 || tile == 48 || tile == 49 || tile == 50 || tile == 51 || tile == 52 || tile == 53 || tile == 54 || tile == 20 || tile == 21 || tile == 27 || tile == 28 || tile == 32 || tile == 33) ? NOMAD_K_GEMM_BIG : (tile == 2 ? NOMAD_K_GEMM_FINE : -1));
+    Scope sc(c, s, NOMAD_K_GEMM, flops, (tile == 1 || tile == 3 || tile == 16 || tile == 55 || tile == 56 || tile == 42 || tile == 43 || tile == 44 || tile == 45 || tile == 46 || tile == 47 || tile == 48 || tile == 49 || tile == 50 || tile == 51 || tile == 52 || tile == 53 || tile == 54 || tile == 20 || tile == 21 || tile == 27 || tile == 28 || tile == 32 || tile == 33) ? NOMAD_K_GEMM_BIG : (tile == 2 ? NOMAD_K_GEMM_FINE : -1));
     hipError_t e;
     switch (tile) {
         // the instantiations the bf16 / bf16x3 forwards select
@@ -1386,6 +1404,10 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
             if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
             e = !p8_nt_stores() ? launch_gemm_bf16_8phase<0>(p, groups, s)
                 : !p8_three_b() ? launch_gemm_bf16_8phase<8>(p, groups, s) : launch_gemm_bf16_8phase<8, false, 0, 3>(p, groups, s);
+            break;
+        case 55:  // 256x192 tiles of the same schedule (three B buffers, nt stores)
+            if (p.N % 192 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm, 192-column tiles: N %% 192, K %% 128");
+            e = launch_gemm_bf16_8phase<8, false, 0, 3, 3>(p, groups, s);
             break;
         case 27:  // bf16x3, every plane staged once (gemm_bf16x3.hip.h): split output
         case 28:  // ... fp32 output
@@ -1429,6 +1451,10 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
         case 44:
             if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
             e = tile == 42 ? launch_gemm_bf16_8phase<8>(p, groups, s) : tile == 43 ? launch_gemm_bf16_8phase<9>(p, groups, s) : launch_gemm_bf16_8phase<10>(p, groups, s);
+            break;
+        case 56:  // 256x192 tiles with two B buffers (A/B against 55)
+            if (p.N % 192 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm, 192-column tiles: N %% 192, K %% 128");
+            e = launch_gemm_bf16_8phase<8, false, 0, 2, 3>(p, groups, s);
             break;
         case 46:  // three B buffers: B staged 1.75 K tiles ahead (non-temporal stores as tile 16 ships them)
             if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
@@ -2453,6 +2479,13 @@ int nomad_diag_gemm_bf16(nomad_ctx* c, const void* A, const void* W, const float
                          int N, int K, int gelu, int tile, nomad_stream_t stream) {
     static const int kBN[] = {128, 128, 64, 256, 64, 128, 128, 128, 128, 256, 256, 128, 128, 128, 128, 256, 256, 256, 256, 256};
     const bool big256 = tile == 36 || (tile >= 42 && tile <= 54);
+    if (tile == 55 || tile == 56) {  // 256 x 192 tiles of the deep-pipelined kernel
+        if (!c || !A || !W || !C || M <= 0) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: bad argument");
+        if (N % 192 || K % 128) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: N %% 192 or K %% 128 != 0");
+        GemmParams p192 = dense(static_cast<const float*>(A), K, static_cast<const float*>(W), bias, static_cast<const float*>(R),
+                                static_cast<float*>(C), M, N, K, gelu);
+        return run_gemm_bf16(c, p192, 1, static_cast<hipStream_t>(stream), tile);
+    }
     if (!c || !A || !W || !C || M <= 0 || tile < 0 || (!big256 && tile >= static_cast<int>(sizeof(kBN) / sizeof(kBN[0])))) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: bad argument");
     if (N % (big256 ? 256 : kBN[tile]) || K % 64) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: N %% %d or K %% 64 != 0", big256 ? 256 : kBN[tile]);
     GemmParams p = dense(static_cast<const float*>(A), K, static_cast<const float*>(W), bias, static_cast<const float*>(R),

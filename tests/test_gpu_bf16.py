@@ -8,14 +8,15 @@ pytestmark = pytest.mark.gpu
 
 BF16_TILES = {0: (256, 128), 1: (128, 128), 2: (128, 64), 3: (256, 256), 4: (64, 64), 5: (128, 128), 6: (256, 128),
               9: (256, 256), 10: (256, 256), 11: (128, 128), 12: (128, 128), 13: (256, 128), 14: (256, 128), 15: (256, 256),
-              16: (256, 256), 42: (256, 256)}    # 16: the deep-pipelined kernel as shipped (three B buffers); 42: with two (NOMAD_BF16_B3=0)
+              16: (256, 256), 42: (256, 256),    # 16: the deep-pipelined kernel as shipped (three B buffers); 42: with two (NOMAD_BF16_B3=0)
+              55: (256, 192), 56: (256, 192)}    # the same schedule on 256 x 192 tiles (N = 768 GEMMs of config C5): three / two B buffers
 
 
 @pytest.mark.parametrize("tile", sorted(BF16_TILES))
 @pytest.mark.parametrize("M", [1, 200, 257, 1000])
 def test_gemm_bf16_exact_integer_asymmetric(engine_for, tile, M):
     bm, bn = BF16_TILES[tile]
-    N, K = 2 * bn, (256 if tile in (16, 42) else 192)  # the deep-pipelined kernels walk K tiles in pairs: K % 128 == 0
+    N, K = 2 * bn, (256 if tile in (16, 42, 55, 56) else 192)  # the deep-pipelined kernels walk K tiles in pairs: K % 128 == 0
     g = torch.Generator().manual_seed(M + tile)
     A = torch.randint(-1, 2, (M, K), generator=g).float()
     W = torch.randint(-1, 2, (N, K), generator=g).float()
@@ -27,7 +28,9 @@ def test_gemm_bf16_exact_integer_asymmetric(engine_for, tile, M):
 
 @pytest.mark.parametrize("tile,M,N,K", [(0, 1500, 256, 768), (1, 700, 768, 3072), (2, 260, 64, 6144), (4, 84, 768, 512),
                                         (3, 600, 512, 1536), (16, 777, 768, 3072), (16, 1500, 512, 1536),
-                                        (16, 300, 2304, 768), (16, 4113, 256, 128), (42, 777, 768, 3072), (42, 300, 2304, 768)])
+                                        (16, 300, 2304, 768), (16, 4113, 256, 128), (42, 777, 768, 3072), (42, 300, 2304, 768),
+                                        (55, 777, 768, 3072), (55, 1500, 768, 768), (55, 300, 2304, 768), (55, 4113, 192, 128),
+                                        (56, 777, 768, 3072), (56, 300, 192, 256)])
 @pytest.mark.parametrize("epi", ["none", "bias_gelu", "bias_res"])
 def test_gemm_bf16_epilogues(engine_for, tile, M, N, K, epi):
     g = torch.Generator().manual_seed(5)
@@ -46,6 +49,20 @@ def test_gemm_bf16_epilogues(engine_for, tile, M, N, K, epi):
                                                   R.cuda() if R is not None else None, gelu="gelu" in epi, tile=tile).cpu()
     err = (out.double() - ref).abs().max().item()
     assert err < 2 ** -7 * max(1.0, ref.abs().max().item()), err      # one bf16 rounding of the output
+
+
+@pytest.mark.parametrize("M,N,K", [(4000, 768, 3072), (2999, 768, 768), (513, 2304, 768), (255, 768, 128)])
+@pytest.mark.parametrize("epi", ["none", "bias_gelu", "bias_res"])
+def test_gemm_bf16_192_column_tiles_are_bit_identical(engine_for, M, N, K, epi):
+    """The 256 x 192 tiles (run_gemm_bf16 takes them where they save a round of CUs) change no bit: same k order per element."""
+    g = torch.Generator().manual_seed(M)
+    A = torch.randn(M, K, generator=g).bfloat16().cuda()
+    W = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16().cuda()
+    bias = torch.randn(N, generator=g).cuda() if "bias" in epi else None
+    R = torch.randn(M, N, generator=g).bfloat16().cuda() if "res" in epi else None
+    outs = [engine_for("bf16", t).diag_gemm_bf16(A, W, bias, R, gelu="gelu" in epi, tile=t) for t in (16, 55, 56, 1)]
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
 
 
 LOG2E = 1.4426950408889634

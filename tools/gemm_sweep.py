@@ -53,6 +53,8 @@ SHAPES = {  # name: (M, N, K, bias, gelu, residual)
     "c5_qkv": (47968, 2304, 768, True, False, False),
     "c5_fc1": (47968, 3072, 768, True, True, False),
     "c5_fc2": (47968, 768, 3072, True, False, True),
+    "c5h_out": (23984, 768, 768, True, False, True),      # one half of the two-stream split of config C5
+    "c5h_fc2": (23984, 768, 3072, True, False, True),
     "c5_fc1_nogelu": (47968, 3072, 768, True, False, False),          # what the GELU epilogue costs on the bf16 tiles
     "c5_conv4_nogelu": (383968, 512, 1536, False, False, False),
     "one_tile": (256, 256, 128, True, False, False),        # a lone workgroup / one workgroup per XCD / one full round
