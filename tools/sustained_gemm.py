@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Burst vs sustained rate of one bf16 GEMM instantiation: the same launch repeated for ~1.5 s (long enough for the chip's clock
 management to settle) with the shader clock read by the one-wave probe on a side stream, next to the median of a burst of 8.
-Usage: python3 tools/sustained_gemm.py [shape,...] [tile,...]"""
+Usage: python3 tools/sustained_gemm.py [shape,...] [tile,...]      (tile -1 = torch.matmul, i.e. hipBLASLt)"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -25,7 +25,11 @@ for name in shapes:
     for tile in tiles:
         if tile in (55, 56) and N % 192:
             continue
-        fn = lambda: _lib.check(eng.lib.nomad_diag_gemm_bf16(eng.ctx, ptr(A), ptr(W), ptr(b), ptr(R), ptr(C), M, N, K, int(gelu), tile, eng._stream()), "gemm")
+        if tile == -1:   # the vendor library on the same operands (plain A W^T)
+            Wt = W.t()
+            fn = lambda: torch.matmul(A, Wt, out=C)
+        else:
+            fn = lambda: _lib.check(eng.lib.nomad_diag_gemm_bf16(eng.ctx, ptr(A), ptr(W), ptr(b), ptr(R), ptr(C), M, N, K, int(gelu), tile, eng._stream()), "gemm")
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
