@@ -1369,16 +1369,18 @@ static bool p8_three_b() {
 // the C5 forward the other GEMMs slow down by more than that - the chip holds 2130 instead of 2157 MHz (2400 nominal) with
 // them, 19.25 vs 18.98 ms per forward (profiles/r03_n192_null.txt).  NOMAD_BF16_N192=1 takes them wherever they save a round
 // (a 192-column tile costs ~0.78 of a 256-column one), =2 wherever N % 192 == 0.
-static bool p8_use_n192(int M, int N) {
+static bool p8_use_n192(int M, int N, int K) {
     static const int mode = [] {
         const char* e = getenv("NOMAD_BF16_N192");
         return e ? atoi(e) : 0;
     }();
     if (N % 192 != 0 || mode <= 0) return false;
-    if (mode >= 2) return true;
+    if (mode == 2) return true;
+    if (mode == 3 && K < 2048) return false;   // A/B: the long-K problems only (fc2)
+    if (mode == 4 && K >= 2048) return false;  // A/B: the short-K problems only (out_proj, proj)
     const long long tm = (M + 255) / 256;
     const long long r256 = (tm * (N / 256) + 255) / 256, r192 = (tm * (N / 192) + 255) / 256;
-    return 0.78 * (double)r192 < 0.97 * (double)r256;
+    return 0.80 * (double)r192 < 0.95 * (double)r256;
 }
 
 static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, int tile = -1) {
@@ -1389,7 +1391,7 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
         if (p.N % 128 != 0) tile = p.M < 512 ? 4 : 2;
         else if (p.M < 512) tile = 4;
         else if (p.N % 256 == 0 && p.K % 128 == 0 && groups == 1 && (long long)((p.M + 255) / 256) * (p.N / 256) >= p8_min_tiles())
-            tile = (p8_three_b() && p8_nt_stores() && p8_use_n192(p.M, p.N)) ? 55 : 16;  // deep-pipelined 256x256 / 256x192 kernel once there are >= 2 rounds of tiles (profiles/r01_gemm_sweep_bf16_8phase.json)
+            tile = (p8_three_b() && p8_nt_stores() && p8_use_n192(p.M, p.N, p.K)) ? 55 : 16;  // deep-pipelined 256x256 / 256x192 kernel once there are >= 2 rounds of tiles (profiles/r01_gemm_sweep_bf16_8phase.json)
         else tile = (p.N % 256 == 0 && (p.N >= 1024 || p.M >= 100000)) ? 3 : 1;
     }
     Scope sc(c, s, NOMAD_K_GEMM, flops, (tile == 1 || tile == 3 || tile == 16 || tile == 55 || tile == 56 || tile == 42 || tile == 43 || tile == 44 || tile == 45 || tile == 46 || tile == 47 || tile == 48 || tile == 49 || tile == 50 || tile == 51 || tile == 52 || tile == 53 || tile == 54 || tile == 20 || tile == 21 || tile == 27 || tile == 28 || tile == 32 || tile == 33) ? NOMAD_K_GEMM_BIG : (tile == 2 ? NOMAD_K_GEMM_FINE : -1));
