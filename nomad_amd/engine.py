@@ -117,11 +117,16 @@ class Engine:
             if ws is None or ws.numel() < nbytes:
                 self._ws_side.pop(k, None)
                 ws = self._ws_side[k] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-            return ws
-        if self._ws is None or self._ws.numel() < nbytes:
-            self._ws = None
-            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        return self._ws
+        else:
+            if self._ws is None or self._ws.numel() < nbytes:
+                self._ws = None
+                self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            ws = self._ws
+        if ws.is_cuda:
+            # the caller's stream may differ from the one the block was allocated on: when the block is replaced by a larger one
+            # the caching allocator must not hand it out again before this stream's kernels are done with it
+            ws.record_stream(torch.cuda.current_stream(self.device))
+        return ws
 
     def side_stream(self, k: int = 1) -> "torch.cuda.Stream":
         if k not in self._side_streams:
