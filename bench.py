@@ -367,7 +367,10 @@ def main():
                        "dtype": "bf16", "value": round(v5, 2), "unit": "clips/s", "steps": 5, "warmup": 2,
                        "ms_per_step": round(1e3 * float(t5.item()) / 5, 3),
                        "model_frac_of_mfma_peak": round(v5 * 500.044e9 / world / 2.5e15, 4),
-                       "finite": bool(torch.isfinite(m5).all().item())}
+                       "finite": bool(torch.isfinite(m5).all().item()),
+                       "context": "STATIC notes, not measured in this run: this forward holds a shader clock of 2015-2160 MHz of the "
+                                  "2400 nominal (profiles/r03_n192_null.txt, r03_clock_c5.jsonl); sustained on its GEMM shapes hipBLASLt "
+                                  "reaches 725-1205 TFLOP/s, the shipped kernels 658-1086 (profiles/r03_vendor_yardstick.txt)"}
             del wav5
         except Exception as e:
             also_c5 = {"workload": "configs[4]", "error": str(e)[:200]}
