@@ -214,6 +214,9 @@ def main():
                     help="without a real checkpoint: seeded = PyTorch-default-style random init (near-zero attention logits); "
                          "peaky = the same with q/k gain 6 (logit sigma ~ 6: softmax rows with a few dominant keys, as "
                          "trained models have) - the attention kernels are data dependent")
+    ap.add_argument("--live-traffic", choices=("auto", "off"), default="auto",
+                    help="auto: a 1-GPU headline run takes the two rocprofv3 --pmc passes behind roofline.traffic itself (child "
+                         "processes, ~15 s); off: replay profiles/pmc_traffic.json")
     ap.add_argument("--spawn", action="store_true",
                     help="start the ranks through torch.distributed.run even for --gpus 1 (what --gpus N > 1 does by itself)")
     ap.add_argument("--single-stream", action="store_true",
@@ -472,11 +475,30 @@ def main():
             if n_samples == 64000:
                 out["encoder_layers_frac_of_mfma_peak"] = round(value * FLOP_LAYERS_4S / world / peak, 4)
         traffic_tab = None
+        traffic_live = None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if args.dtype == "f32" and n_samples == 64000 and B == 256 and os.path.isfile(tfile):
-            # HBM-side bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
-            # command (tools/gpu_pmc_traffic.sh + tools/pmc_traffic.py); fabric-side counters, Infinity-Cache hits included
-            traffic_tab = json.load(open(tfile))
+        if args.dtype == "f32" and n_samples == 64000 and B == 256:
+            # HBM-side bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
+            # (fabric-side counters, Infinity-Cache hits included).  On a 1-GPU headline run the two passes are taken NOW, as
+            # child processes (tools/pmc_traffic.py:collect, ~15 s; this process is idle meanwhile); otherwise, or if that
+            # fails, the table committed under profiles/ (same passes, taken by tools/gpu_pmc_traffic.sh) is replayed and says so.
+            if world == 1 and prof and args.live_traffic != "off":
+                try:
+                    sys.path.insert(0, os.path.join(ROOT, "tools"))
+                    import pmc_traffic
+                    scratch = os.path.join(ROOT, "gpurun_out", "bench_live_pmc")
+                    try:
+                        os.makedirs(scratch, exist_ok=True)
+                    except OSError:
+                        import tempfile
+                        scratch = tempfile.mkdtemp(prefix="bench_live_pmc_")
+                    traffic_tab = pmc_traffic.collect(scratch)
+                    traffic_live = "measured in this run"
+                except Exception as e:  # noqa: BLE001 - any failure falls back to the committed table, labelled
+                    traffic_live = f"live passes failed ({str(e)[:120]})"
+                    traffic_tab = None
+            if traffic_tab is None and os.path.isfile(tfile):
+                traffic_tab = json.load(open(tfile))
         if prof:
             def rate(cls):
                 return cls["flops"] / (cls["ms"] * 1e-3) / 1e12 if cls["ms"] > 0 else 0.0
@@ -498,9 +520,14 @@ def main():
             out["roofline"] = {"bound": "mfma", "kernel": kname,
                                "achieved": round(ach, 2), "peak": round(peak / 1e12, 1), "unit": "TFLOP/s",
                                "frac": round(ach * 1e12 / peak, 4), "traffic": traffic,
-                               "traffic_source": (f"profiles/pmc_traffic.json (STATIC: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                                  f"passes of this command taken earlier ({traffic_tab.get('taken', 'round 2')}) by "
-                                                  f"tools/gpu_pmc_traffic.sh, not measured in this run)" if traffic is not None else None),
+                               "traffic_source": (None if traffic is None else
+                                                  "LIVE: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE, two separate passes of "
+                                                  "`bench.py --steps 1 --warmup 1 --single-stream` run as child processes at the end of this run "
+                                                  "(tools/pmc_traffic.py:collect); fabric-side bytes per launch of the dominant kernel"
+                                                  if traffic_live == "measured in this run" else
+                                                  f"profiles/pmc_traffic.json (STATIC: the same two passes taken earlier "
+                                                  f"({traffic_tab.get('taken', 'round 2')}) by tools/gpu_pmc_traffic.sh, not measured in this run"
+                                                  f"{'; ' + traffic_live if traffic_live else ''})"),
                                "algorithmic_bytes_per_launch": alg_bytes,
                                "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4),
                                "algorithmic_gflop_per_launch": round(dom["flops"] / max(dom["launches"], 1) / 1e9, 3),

@@ -89,3 +89,20 @@ def test_bench_line_bf16_long_form():
     assert out["dtype"] == "bf16" and out["config"]["workload"].startswith("configs[4]")
     assert out["roofline"]["peak"] == 2500.0 and out["roofline"]["achieved"] > 0
     assert "also_measured" not in out and out["value"] > 0
+
+
+def test_live_pmc_traffic(tmp_path):
+    """roofline.traffic of a 1-GPU headline run is measured inside that run: the two rocprofv3 --pmc passes bench.py starts as
+    child processes (tools/pmc_traffic.py:collect) produce HBM-side bytes per launch of the dominant GEMM close to the
+    algorithmic A + W + C (+ residual) bytes."""
+    import shutil
+    if not (shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3")):
+        pytest.skip("rocprofv3 not available")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_traffic
+    tab = pmc_traffic.collect(str(tmp_path))
+    big = tab["gemm_256x128"]
+    assert big["launches"] >= 40
+    ratio = big["hbm_bytes_per_launch"] / big["algorithmic_bytes_per_launch"]
+    assert 0.9 < ratio < 1.6, ratio                       # 1.16-1.19 measured: no wasted re-reads
+    assert 0.9 < tab["gemm_all_launches"]["ratio"] < 1.6
