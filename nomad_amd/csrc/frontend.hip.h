@@ -169,6 +169,133 @@ __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restr
     }
 }
 
+// conv0 on the matrix cores, for the bf16 output path (config C5): the 10-tap, 1-input-channel convolution is a GEMM with K = 10,
+// too thin for MFMA in bf16 alone - but K = 32 of v_mfma_f32_16x16x32_bf16 holds the THREE bf16 products of the hi / lo split
+// at once: k 0..9 = x_hi w_hi, 10..19 = x_hi w_lo, 20..29 = x_lo w_hi (x_lo w_lo, 2^-16 relative, dropped; 30, 31 zero), fp32
+// accumulation - an fp32-class conv for ONE matrix instruction per 16 channels x 16 frames, where conv0_gn_gelu_kernel spends
+// 40 of its 110 vector instructions per 4 outputs on the taps (the rest - GroupNorm affine, GELU, convert - stays on the VALU).
+// Computed transposed, D[channel][frame] = W[channel][k] X[k][frame], with the channel rows of the four MFMAs of a 64-channel
+// group interleaved (row 4q + r of MFMA j = channel 64 g + 16 q + 4 j + r) so that a lane (frame lane & 15, q = lane >> 4) ends
+// up with 16 CONSECUTIVE channels: two 16-byte stores per group, four lanes fill a 128-byte line of the time-major output.
+// wfrag: the A operands in fragment order [8 groups][4][64 lanes][8 bf16] (conv0_wfrag_kernel).  grid: (ceil(L0 / 256), B),
+// 256 threads = 4 waves x 64 frames (four 16-frame B operands per wave share every A fragment).
+constexpr int kConv0MfmaFrames = 256;   // per workgroup: 4 waves x 4 B operands of 16 frames
+constexpr int kConv0MfmaOcc = 4, kConv0MfmaUf = 1;   // the instantiation the forward uses (tools/conv0_time.py)
+__global__ __launch_bounds__(256) void conv0_wfrag_kernel(const float* __restrict__ w0, bf16_t* __restrict__ wfrag) {
+    // one thread per (group g, j, lane): blockIdx.x = g * 4 + j, threadIdx.x = lane (64)
+    const int g = blockIdx.x >> 2, j = blockIdx.x & 3, lane = threadIdx.x;
+    const int row = lane & 15, kb = lane >> 4;
+    const int c = 64 * g + 16 * (row >> 2) + 4 * j + (row & 3);
+    bf16x8 a;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = 8 * kb + e, seg = k / 10, tap = k - 10 * seg;
+        const float w = k < 30 ? w0[c * 10 + tap] : 0.f;
+        const bf16_t hi = (bf16_t)w;
+        a[e] = (k >= 30) ? (bf16_t)0.f : (seg == 1 ? (bf16_t)(w - (float)hi) : hi);
+    }
+    *reinterpret_cast<bf16x8*>(wfrag + ((size_t)blockIdx.x * 64 + lane) * 8) = a;
+}
+
+// OCC: waves per SIMD the register allocation must allow; UF: 16-frame tiles whose 16 GELUs each are issued together (more
+// independent rcp / exp chains in flight per wave, more registers) - measured in tools/conv0_time.py.
+// ABL (libnomad_diag.so timing probe): 2 = no GELU (the affine result is stored): 0.68 ms of the kernel's 0.88 at 32 x 30 s are
+// its 3.1 GB of output, the GELU adds the rest (gpurun_out/conv0mfma4; the VALU kernel: 1.02-1.13 ms).
+template <int OCC, int UF, int ABL = 0>
+__global__ __launch_bounds__(256, OCC) void conv0_mfma_gn_gelu_kernel(const float* __restrict__ wav, int n_samples, int L0,
+                                                                      const bf16_t* __restrict__ wfrag, const float* __restrict__ scale,
+                                                                      const float* __restrict__ shift, bf16_t* __restrict__ out,
+                                                                      const int* __restrict__ lens, const int* __restrict__ pref0) {
+    constexpr int NFT = kConv0MfmaFrames / 64;                            // 16-frame B operands per wave
+    static_assert(NFT % UF == 0, "tiles per wave must divide by the unroll factor");
+    __shared__ __attribute__((aligned(16))) float scs[512], shs[512];
+    __shared__ float xs[kConv0MfmaFrames * 5 + 8];
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * kConv0MfmaFrames;
+    long long out_row0 = (long long)b * L0;
+    if (lens) {  // ragged: this clip's own frame count and packed output position
+        L0 = (lens[b] - 10) / 5 + 1;
+        out_row0 = pref0[b];
+        if (t0 >= L0) return;
+    }
+    const int nfr = min(kConv0MfmaFrames, L0 - t0);
+    const float* x = wav + (long long)b * n_samples + 5 * t0;
+    const int nx = 5 * nfr + 5;
+    for (int i = threadIdx.x; i < kConv0MfmaFrames * 5 + 8; i += 256) xs[i] = i < nx ? x[i] : 0.f;
+    for (int i = threadIdx.x; i < 512; i += 256) {
+        scs[i] = scale[b * 512 + i];
+        shs[i] = shift[b * 512 + i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, q = lane >> 4;
+    const int f_base = wave * (16 * NFT);         // this wave's first frame inside the block
+    if (f_base >= nfr) return;                    // wave-uniform, after the only barrier
+    // B operands: frame f_base + 16 ft + col, k = 8 q + e
+    bf16x8 xb[NFT];
+#pragma unroll
+    for (int ft = 0; ft < NFT; ++ft) {
+        const float* xp = xs + 5 * (f_base + 16 * ft + col);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 8 * q + e, seg = k / 10, tap = k - 10 * seg;
+            const float v = xp[k < 30 ? tap : 0];
+            const bf16_t hi = (bf16_t)v;
+            xb[ft][e] = (k >= 30) ? (bf16_t)0.f : (seg == 2 ? (bf16_t)(v - (float)hi) : hi);
+        }
+    }
+    bf16_t* const o_lane = out + (out_row0 + t0 + f_base + col) * 512 + 16 * q;
+    // A fragments straight from global memory (32 KB for the whole layer: L1 / L2 hits), the next group's loaded one group ahead;
+    // staging them in LDS (32 KB per workgroup) capped the kernel at 3 waves per SIMD
+    const bf16_t* wl = wfrag + lane * 8;
+    bf16x8 an[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) an[j] = *reinterpret_cast<const bf16x8*>(wl + j * 512);
+    for (int g = 0; g < 8; ++g) {
+        bf16x8 a[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = an[j];
+        if (g < 7) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) an[j] = *reinterpret_cast<const bf16x8*>(wl + ((g + 1) * 4 + j) * 512);
+        }
+        f32x4 sc4[4], sh4[4];   // this lane's 16 channels of the group
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sc4[j] = *reinterpret_cast<const f32x4*>(scs + 64 * g + 16 * q + 4 * j);
+            sh4[j] = *reinterpret_cast<const f32x4*>(shs + 64 * g + 16 * q + 4 * j);
+        }
+#pragma unroll
+        for (int f0 = 0; f0 < NFT; f0 += UF) {
+            if (f_base + 16 * f0 >= nfr) break;   // wave-uniform
+            f32x4 acc[UF][4];
+#pragma unroll
+            for (int u = 0; u < UF; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], xb[f0 + u], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < UF; ++u) {
+                bf16x8 lo, hi;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float z = fmaf(acc[u][j][r], sc4[j][r], sh4[j][r]);
+                        const float y = ABL == 2 ? z : gelu_erf(z);
+                        if (j < 2) lo[4 * j + r] = (bf16_t)y;
+                        else hi[4 * (j - 2) + r] = (bf16_t)y;
+                    }
+                if (f_base + 16 * (f0 + u) + col < nfr) {
+                    bf16_t* o = o_lane + (long long)(f0 + u) * (16 * 512) + 64 * g;
+                    *reinterpret_cast<bf16x8*>(o) = lo;
+                    *reinterpret_cast<bf16x8*>(o + 8) = hi;
+                }
+            }
+        }
+    }
+}
+
 // Pos-conv input buffer, GROUP-MAJOR: xg[16 groups][B clips][T+128 frames][48 channels], 64 zero frames on
 // each side of every clip (SamePad of the k=128 grouped conv).  With 192-B rows a group's K vector
 // (128 taps x 48 channels) for output frame t is 6144 CONTIGUOUS floats starting at frame t, so the

@@ -330,6 +330,7 @@ struct nomad_ctx {
     // bf16 weight copies for the bf16 path (built by nomad_enable_bf16); biases and norm parameters stay fp32
     bool bf16_ready = false;
     bf16_t* conv_w16[7] = {};
+    bf16_t* conv0_wfrag = nullptr;       // conv0's MFMA A operands [8][4][64][8] (conv0_wfrag_kernel): bf16 path
     bf16_t *proj_w16 = nullptr, *pos_w16 = nullptr;
     bf16_t *qkv_w16[NOMAD_NUM_LAYERS] = {}, *o_w16[NOMAD_NUM_LAYERS] = {}, *fc1_w16[NOMAD_NUM_LAYERS] = {},
            *fc2_w16[NOMAD_NUM_LAYERS] = {};
@@ -1336,6 +1337,25 @@ static hipError_t run_attention_bf16(const bf16_t* qkv, bf16_t* out, int B, int 
                : launch_attention_bf16_v2<4, 64, 4, false>(qkv, out, B, T, tpref, s);
 }
 
+// conv0 of the bf16 path on the matrix cores (conv0_mfma_gn_gelu_kernel); NOMAD_BF16_CONV0_MFMA=0: the VALU kernel (A/B runs)
+static bool bf16_conv0_mfma() {
+    static const bool v = [] {
+        const char* e = getenv("NOMAD_BF16_CONV0_MFMA");
+        return e ? atoi(e) != 0 : true;
+    }();
+    return v;
+}
+// wav rows `stride` apart; lens == nullptr: every clip has l0 frames, else ragged (max_l0 = the longest clip's, pref0 = packed rows)
+static void launch_conv0_bf16(nomad_ctx* c, const float* wav, int stride, int l0, int max_l0, int B, const float* scale,
+                              const float* shift, bf16_t* out, const int* lens, const int* pref0, hipStream_t s) {
+    if (bf16_conv0_mfma() && c->conv0_wfrag)
+        hipLaunchKernelGGL((conv0_mfma_gn_gelu_kernel<kConv0MfmaOcc, kConv0MfmaUf>), dim3((max_l0 + kConv0MfmaFrames - 1) / kConv0MfmaFrames, B), dim3(256), 0, s, wav,
+                           stride, l0, c->conv0_wfrag, scale, shift, out, lens, pref0);
+    else
+        hipLaunchKernelGGL(conv0_gn_gelu_kernel<bf16_t>, dim3((max_l0 + kConv0Frames - 1) / kConv0Frames, B), dim3(256), 0, s, wav,
+                           stride, l0, c->conv0_w, scale, shift, out, lens, pref0, 0LL);
+}
+
 // smallest grid (in 256 x 256 tiles) that takes the deep-pipelined bf16 kernel; NOMAD_BF16_8PHASE_MIN_TILES overrides (A/B runs)
 static int p8_min_tiles() {
     static const int v = [] {
@@ -1633,8 +1653,7 @@ static int forward_bf16(nomad_ctx* c, const float* wav, int B, int n_samples, fl
     CK(shift, B, sizeof(float) * 512);
     {
         Scope sc(c, s, NOMAD_K_FRONT, 2.0 * B * (double)sh.L[0] * 512 * 10);
-        hipLaunchKernelGGL(conv0_gn_gelu_kernel<bf16_t>, dim3((sh.L[0] + kConv0Frames - 1) / kConv0Frames, B), dim3(256), 0,
-                           s, wav, n_samples, sh.L[0], c->conv0_w, scale, shift, cb[0], kNoInts, kNoInts);
+        launch_conv0_bf16(c, wav, n_samples, sh.L[0], sh.L[0], B, scale, shift, cb[0], kNoInts, kNoInts, s);
     }
     CK(cb[0], B, sizeof(bf16_t) * 512 * (size_t)sh.L[0]);
     for (int i = 1; i < 7; ++i) {
@@ -2134,8 +2153,7 @@ static int forward_ragged_bf16(nomad_ctx* c, const float* wav, int B, int stride
     }
     {
         Scope sc(c, s, NOMAD_K_FRONT, 2.0 * (double)rs.rows[0] * 512 * 10);
-        hipLaunchKernelGGL(conv0_gn_gelu_kernel<bf16_t>, dim3((rs.max_l0 + kConv0Frames - 1) / kConv0Frames, B), dim3(256), 0,
-                           s, wav, stride, 0, c->conv0_w, scale, shift, cb[0], lens, pref(0));
+        launch_conv0_bf16(c, wav, stride, 0, rs.max_l0, B, scale, shift, cb[0], lens, pref(0), s);
     }
     for (int i = 1; i < 7; ++i) {
         GemmParams p{};
@@ -2253,6 +2271,13 @@ int nomad_enable_bf16(nomad_ctx* c) {
         return 0;
     };
     int rc;
+    if (!c->conv0_wfrag) {
+        void* d = nullptr;
+        HIP_TRY(hipMalloc(&d, (size_t)8 * 4 * 64 * 8 * sizeof(bf16_t)));
+        c->allocs.push_back(d);
+        c->conv0_wfrag = static_cast<bf16_t*>(d);
+    }
+    hipLaunchKernelGGL(conv0_wfrag_kernel, dim3(32), dim3(64), 0, 0, c->conv0_w, c->conv0_wfrag);
     for (int i = 1; i < 7; ++i)
         if ((rc = conv(c->conv_w[i], (size_t)512 * kConvK[i] * 512, &c->conv_w16[i]))) return rc;
     if ((rc = conv(c->proj_w, (size_t)768 * 512, &c->proj_w16))) return rc;
@@ -2459,6 +2484,16 @@ int nomad_diag_conv0_bf16(nomad_ctx* c, const float* wav, int B, int n_samples, 
         break;
     switch (variant) {
         NOMAD_C0(0) NOMAD_C0(1) NOMAD_C0(2) NOMAD_C0(3)
+#define NOMAD_C0M(V, OCC, UF, ABL)                                                                                                \
+    case V:                                                                                                                     \
+        if (!c->conv0_wfrag) return fail(NOMAD_ERR_INVALID, "nomad_diag_conv0_bf16: variant %d needs nomad_enable_bf16", V);    \
+        hipLaunchKernelGGL((conv0_mfma_gn_gelu_kernel<OCC, UF, ABL>), dim3((sh.L[0] + kConv0MfmaFrames - 1) / kConv0MfmaFrames, B), \
+                           dim3(256), 0, s, wav, n_samples, sh.L[0], c->conv0_wfrag, scale, shift, out, kNoInts, kNoInts);      \
+        break;
+        NOMAD_C0M(4, kConv0MfmaOcc, kConv0MfmaUf, 0)   // the matrix-core kernel as the bf16 forward launches it (needs nomad_enable_bf16)
+        NOMAD_C0M(5, 3, 2, 0) NOMAD_C0M(6, 3, 1, 0) NOMAD_C0M(7, 3, 4, 0)   // other budgets / unrolls (tools/conv0_time.py)
+        NOMAD_C0M(9, 4, 1, 2)                                             // timing probe: no GELU
+#undef NOMAD_C0M
         default: return fail(NOMAD_ERR_INVALID, "nomad_diag_conv0_bf16: variant %d", variant);
     }
 #undef NOMAD_C0

@@ -180,3 +180,49 @@ def test_predict_in_bf16_precision(built_lib):
     assert abs(m16.values - m32.values).max() < 2e-3
     with pytest.raises(ValueError):
         Nomad(weights="seeded", precision="fp16")
+
+
+@pytest.mark.parametrize("B,N", [(3, 64000), (2, 400), (1, 16395), (5, 3335), (2, 1375), (1, 2090)])
+def test_conv0_on_the_matrix_cores(built_lib, sd0, B, N):
+    """conv0 + GroupNorm + GELU of the bf16 path as one v_mfma_f32_16x16x32_bf16 per 16 channels x 16 frames (hi / lo split of
+    waveform and weights along K, frontend.hip.h): against a float64 reference to one bf16 rounding, and against the VALU kernel
+    it replaces (at most one bf16 ulp apart, almost everywhere equal).  N covers full blocks of 256 frames, a single short block,
+    and tails that end inside different 16-frame tiles of a wave."""
+    import ctypes as C
+    from nomad_amd import _lib
+    from nomad_amd.engine import Engine
+    eng = Engine(sd0, 0, diag=True)
+    lib = eng.lib
+    _lib.check(lib.nomad_enable_bf16(eng.ctx), "nomad_enable_bf16")
+    lib.nomad_diag_conv0_bf16.restype = C.c_int
+    lib.nomad_diag_conv0_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L0 = (N - 10) // 5 + 1
+    gen = torch.Generator().manual_seed(N)
+    wav = (0.1 * torch.randn(B, N, generator=gen)).clamp(-1, 1)
+    wav_dev = wav.cuda()
+    outs = []
+    for variant in (0, 4):
+        out = torch.full((B, L0, 512), float("nan"), dtype=torch.bfloat16, device="cuda")
+        scratch = torch.empty(8 * 65 * B * 16 + 8 * 512 * B + 4096, dtype=torch.uint8, device="cuda")
+        assert lib.nomad_diag_conv0_bf16(eng.ctx, wav_dev.data_ptr(), B, N, out.data_ptr(), scratch.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream, variant) == 0
+        torch.cuda.synchronize()
+        outs.append(out.float().cpu())
+    eng.close()
+    w = sd0["ssl_model.feature_extractor.conv_layers.0.0.weight"].double()                  # (512, 1, 10)
+    y = F.conv1d(wav.double().unsqueeze(1), w, stride=5)                           # (B, 512, L0)
+    y = F.group_norm(y, 512, sd0["ssl_model.feature_extractor.conv_layers.0.2.weight"].double(), sd0["ssl_model.feature_extractor.conv_layers.0.2.bias"].double(), 1e-5)
+    ref = F.gelu(y).transpose(1, 2)                                                # (B, L0, 512)
+    for name, out in zip(("VALU kernel", "matrix-core kernel"), outs):
+        assert torch.isfinite(out).all(), name
+        err = (out.double() - ref).abs()
+        # one bf16 rounding of the output (half an ulp is 2^-8 |x| at the bottom of a binade) + the fp32-class conv
+        # (the matrix-core kernel drops the x_lo w_lo products: 2^-16 of the tap magnitudes, an absolute 1e-5 next to O(1) values)
+        bad = err > 1.02 * 2 ** -8 * ref.abs() + (4e-5 if name.startswith("matrix") else 1e-6)
+        if bad.any():
+            i = torch.nonzero(bad)[0].tolist()
+            raise AssertionError(f"{name}: {int(bad.sum())} elements off, first at {i}: out {out[tuple(i)].item()!r} ref {ref[tuple(i)].item()!r}")
+    diff = (outs[0] - outs[1]).abs()
+    assert (diff <= 2 ** -7 * outs[0].abs() + 8e-5).all(), diff.max().item()      # never more than one bf16 ulp apart (outputs near zero: the absolute 2^-16 floor)
+    frac = (diff > 0).float().mean().item()
+    assert frac < 0.05, frac                                                        # and different in a few per cent of the elements only
