@@ -322,4 +322,9 @@ def test_forward_loss_bf16x3_clean_branch(built_lib, sd0, reps):
     # small batches stay on fp32 buffers, with three-product GEMMs in this mode: close, not bit-equal
     a = n32.forward(est[:4], clean[:4]).item()
     b = nx3.forward(est[:4], clean[:4]).item()
-    assert a != b and abs(a - b) / a < 1e-5
+    assert abs(a - b) / a < 1e-5
+    # "not bit-equal" is checked on the embeddings, not on the loss: the two losses are about one fp32 ulp apart and the head is
+    # initialised at random per process, so they round to the same float in a good share of the runs (seen on the GPU box)
+    assert n32.engine.gemm_precision == "fp32" and nx3.engine.gemm_precision == "bf16x3"
+    ea, eb = n32.engine.embed(est[:4].squeeze(1)), nx3.engine.embed(est[:4].squeeze(1))
+    assert not torch.equal(ea, eb) and (ea - eb).abs().max().item() < 1e-4
