@@ -20,7 +20,8 @@
 //   * keys past the end of the clip are set to -1e30 in the one partial block only (a wave-uniform branch): no masked
 //     copy of the block code;
 //   * K / V tiles of KT keys are double-buffered in LDS with ONE barrier per tile: the next tile's global loads are in
-//     flight during the whole compute phase and are written to the other buffer just before the barrier.  Rows are
+//     flight during the whole compute phase and are written to the other buffer just before the barrier (DMA = false), or go
+//     straight into it by LDS-DMA (DMA = true: what the forward uses since round 3, with KT = 128).  Rows are
 //     128 B, unpadded, with the 16-byte chunk index XOR-swizzled by the row ((row>>1)&7 for K, 4*((row>>1)&1) for V):
 //     the ds_read_b128 lane groups of the K fragments and the 4-row x 64-B blocks of the transposing V reads each
 //     cover all 64 banks once.
@@ -71,7 +72,11 @@ __device__ __forceinline__ void a2_halves(float x, float& lo, float& hi) {
 // OCC: waves per SIMD the register allocation must allow (__launch_bounds__' second argument).
 // LOG2E: q already carries the factor log2(e) (folded into the bf16 q weights: nomad_enable_bf16); otherwise the Q
 // fragments are scaled (and re-rounded to bf16) when they are loaded.
-template <int NW, int KT, int OCC, bool LOG2E>
+// DMA: K / V tiles go global -> LDS by global_load_lds (no VGPR round trip, no ds_write): a wave's instruction fills 1 KB = 8 rows
+// linearly, so lane (row l >> 3, physical chunk l & 7) fetches the LOGICAL chunk the swizzle maps there; the next tile's DMA is
+// issued at the top of an iteration into the buffer the previous iteration's barrier released and waited for (vmcnt(0)) just
+// before this iteration's barrier.
+template <int NW, int KT, int OCC, bool LOG2E, bool DMA = false>
 __global__ __launch_bounds__(64 * NW, OCC) void attention_bf16_v2_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                                          int T, int nqblk, const int* __restrict__ tpref) {
     extern __shared__ __attribute__((aligned(16))) char a2_lds[];
@@ -146,12 +151,23 @@ __global__ __launch_bounds__(64 * NW, OCC) void attention_bf16_v2_kernel(const b
             const int cid = tid + i * NT, row = cid >> 3, ch = cid & 7;
             int key = kt * KT + row;
             key = key < T ? key : T - 1;
-            const bf16_t* src = src_bh + (long long)key * 2304 + ch * 8;
-            kreg[i] = *reinterpret_cast<const bf16x8*>(src + 768);
-            vreg[i] = *reinterpret_cast<const bf16x8*>(src + 1536);
+            if (DMA) {   // ch is the PHYSICAL chunk of this lane's 16 bytes; destination: wave-uniform base + lane * 16
+                const bf16_t* src = src_bh + (long long)key * 2304;
+                char* dk = a2_lds + ((kt & 1) * (KT * 256)) + (i * NT + wave * 64) * 16;
+                __builtin_amdgcn_global_load_lds((gptr_t)(src + 768 + 8 * (ch ^ ((row >> 1) & 7))), (lptr_t)dk, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(src + 1536 + 8 * (ch ^ (4 * ((row >> 1) & 1)))), (lptr_t)(dk + KT * 128), 16, 0, 0);
+            } else {
+                const bf16_t* src = src_bh + (long long)key * 2304 + ch * 8;
+                kreg[i] = *reinterpret_cast<const bf16x8*>(src + 768);
+                vreg[i] = *reinterpret_cast<const bf16x8*>(src + 1536);
+            }
         }
     };
     auto stage = [&](int buf) {
+        if (DMA) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the next tile has landed
+            return;
+        }
         char* B0 = a2_lds + buf * (KT * 256);
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
@@ -293,10 +309,10 @@ __global__ __launch_bounds__(64 * NW, OCC) void attention_bf16_v2_kernel(const b
 }
 
 // host-side launcher of one instantiation.  Returns the hipError of the launch.
-template <int NW, int KT, int OCC, bool LOG2E>
+template <int NW, int KT, int OCC, bool LOG2E, bool DMA = false>
 inline hipError_t launch_attention_bf16_v2(const bf16_t* qkv, bf16_t* out, int B, int T, const int* tpref, hipStream_t s) {
     static bool configured = false;
-    auto kern = attention_bf16_v2_kernel<NW, KT, OCC, LOG2E>;
+    auto kern = attention_bf16_v2_kernel<NW, KT, OCC, LOG2E, DMA>;
     constexpr int lds = attn_bf16_v2_lds(KT);
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -1329,8 +1329,24 @@ static int run_ln_bwd(nomad_ctx* c, const float* x, const float* g, const float*
 // ---- bf16 path (config C5) -----------------------------------------------------------------------------
 // bf16 attention (attention_bf16_v2.hip.h).  T = frames per clip (the longest clip's with tpref).  256-query workgroups
 // when that still gives the chip >= 2 rounds of them, 128-query ones for small batches.  log2e: q carries log2(e).
+// The forward's (log2e) kernels stage K / V by LDS-DMA, 128-key tiles for the 256-query workgroups: attention 3.33 -> 3.05 ms per
+// C5 step, 1637-1646 -> 1676-1679 clips/s, bit-identical (gpurun_out/attndma).  NOMAD_BF16_ATTN_DMA = 0: staging through registers,
+// 1: LDS-DMA with 64-key tiles (A/B runs).
+static int bf16_attn_dma() {
+    static const int v = [] {
+        const char* e = getenv("NOMAD_BF16_ATTN_DMA");
+        return e ? atoi(e) : 2;
+    }();
+    return v;
+}
 static hipError_t run_attention_bf16(const bf16_t* qkv, bf16_t* out, int B, int T, const int* tpref, bool log2e, hipStream_t s) {
     const bool big = (long long)((T + 255) / 256) * B * 12 >= 1024;
+    if (log2e && bf16_attn_dma() == 1)
+        return big ? launch_attention_bf16_v2<8, 64, 4, true, true>(qkv, out, B, T, tpref, s)
+                   : launch_attention_bf16_v2<4, 64, 4, true, true>(qkv, out, B, T, tpref, s);
+    if (log2e && bf16_attn_dma() == 2)
+        return big ? launch_attention_bf16_v2<8, 128, 4, true, true>(qkv, out, B, T, tpref, s)
+                   : launch_attention_bf16_v2<4, 64, 4, true, true>(qkv, out, B, T, tpref, s);
     if (log2e) return big ? launch_attention_bf16_v2<8, 64, 4, true>(qkv, out, B, T, tpref, s)
                           : launch_attention_bf16_v2<4, 64, 4, true>(qkv, out, B, T, tpref, s);
     return big ? launch_attention_bf16_v2<8, 64, 4, false>(qkv, out, B, T, tpref, s)

@@ -52,6 +52,9 @@ int main(int argc, char** argv) {
     const Variant variants[] = {
         {"NW8 KT64 occ4", launch_attention_bf16_v2<8, 64, 4, false>},
         {"NW4 KT64 occ4", launch_attention_bf16_v2<4, 64, 4, false>},
+        {"NW8 KT64 occ4 LDS-DMA", launch_attention_bf16_v2<8, 64, 4, false, true>},
+        {"NW8 KT128 occ4 LDS-DMA", launch_attention_bf16_v2<8, 128, 4, false, true>},
+        {"NW4 KT64 occ4 LDS-DMA", launch_attention_bf16_v2<4, 64, 4, false, true>},
     };
     const int nvar = sizeof(variants) / sizeof(variants[0]);
     const int pick = getenv("VARIANT") ? atoi(getenv("VARIANT")) : 0;
