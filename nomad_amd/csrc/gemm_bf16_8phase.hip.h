@@ -43,7 +43,14 @@ struct P8Cfg {
 // OUT: 0 = bf16, 1 = split planes (p.c_plane; R split too), 2 = fp32 (R split).  NOSTORE: timing ablation.
 // NT: bit 0 = output stores, bit 1 = residual loads carry the non-temporal hint (streamed through L2).
 // NJ: 16-column accumulator tiles per wave (wave tile 128 x 16 NJ; 4 = the 256-column workgroup tile, 3 = the 192-column one).
-template <bool NOSTORE, int X3, int NT = 0, int NJ = 4>
+// RPRE: residual prefetch (see below).
+// PLAIN: C and R are plain row-major matrices (the caller checked: no ragged row maps, no column blocks) - the address arithmetic
+//   of the general case (a binary search per row for ragged maps, two integer divisions for column blocks and frame limits),
+//   unrolled over the 16 chunks of a lane, is 45 KB of the kernel's 58 KB of code; the plain epilogue is a fifth of that.  Code
+//   size matters here: two large instantiations ALTERNATING between launches cost the launch after each switch 12-17 us
+//   (instruction cache; gpurun_out/rpreprof2), which is what ate the isolated gains of the 256 x 192 tiles and of the residual
+//   prefetch until every GEMM of the transformer layers ran the SAME instantiation.
+template <bool NOSTORE, int X3, int NT = 0, int NJ = 4, bool RPRE = false, bool PLAIN = false>
 __device__ __forceinline__ void p8_epilogue(const GemmParams& p, const f32x4 (&acc)[8][NJ], char* smem8, int grp, int m0, int n0,
                                             int wave, int wr, int wc, int lane, int fr, int fq) {
     using Cfg = P8Cfg;
@@ -62,6 +69,28 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p, const f32x4 (&a
     for (int j = 0; j < NJ; ++j) {
         const int n = n0 + wc * WTN + j * 16 + fr;
         bv[j] = (biasg && n < p.n_valid) ? biasg[n] : 0.f;
+    }
+    // Residual prefetch (plain bf16): C and R are not restrict-qualified (R may BE C), so the compiler keeps every residual load
+    // behind the previous chunk's store and waits for it at once - 16 serial memory round trips per lane and tile (llvm-objdump:
+    // global_load_dwordx4, s_waitcnt vmcnt(0), ..., global_store_dwordx4, 16 times).  A lane only ever stores the elements it
+    // loaded, so all 16 loads can be issued up front, into the registers the operand fragments have just vacated; the counted
+    // waits the compiler then places never cover a store.
+    bf16x8 rpre[4][NJ];
+    if (RPRE && X3 == 0 && Rg) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int it = 0; it < NJ; ++it) {
+                const int id = lane + 64 * it, row = NJ == 4 ? id >> 3 : id / 6, cg = NJ == 4 ? id & 7 : id - 6 * row;
+                const int m = m0 + wr * 128 + s4 * 32 + row;
+                const int n = n0 + wc * WTN + cg * 8;
+                if (m < p.M && n < p.n_valid) {
+                    const bf16_t* rp = Rg + ((PLAIN || r_plain) ? p.rmap.off + (long long)m * p.rmap.ld : row_addr(p.rmap, m)) + n;
+                    rpre[s4][it] = (NT & 2) ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(rp)) : *reinterpret_cast<const bf16x8*>(rp);
+                } else {
+                    rpre[s4][it] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                }
+            }
     }
     __syncthreads();  // every wave is done with the staging buffers
     // The slab is private to the wave and a wave's LDS operations execute in order, so inside the loop only the
@@ -87,7 +116,7 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p, const f32x4 (&a
                 const int m = m0 + wr * 128 + s4 * 32 + row;
                 const int n = n0 + wc * WTN + cg * 8;
                 bool live = m < p.M && n < p.n_valid;
-                if (live && p.c_blk_step > 0 && p.c_colblk > 0) {  // column blocks are frames: drop those past the clip's end
+                if (!PLAIN && live && p.c_blk_step > 0 && p.c_colblk > 0) {  // column blocks are frames: drop those past the clip's end
                     int li, frames;
                     clip_pos(p.cmap, m, p.c_clip_frames, li, frames);
                     live = li * p.c_blk_step + n / p.c_colblk < frames;
@@ -96,8 +125,11 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p, const f32x4 (&a
                     const f32x4 lo = *reinterpret_cast<const f32x4*>(slab + row * ELD + cg * 8);
                     const f32x4 hi = *reinterpret_cast<const f32x4*>(slab + row * ELD + cg * 8 + 4);
                     float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    if (Rg) {
-                        const bf16_t* rp = Rg + (r_plain ? p.rmap.off + (long long)m * p.rmap.ld : row_addr(p.rmap, m)) + n;
+                    if (RPRE && X3 == 0 && Rg) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += (float)rpre[s4][it][e];
+                    } else if (Rg) {
+                        const bf16_t* rp = Rg + ((PLAIN || r_plain) ? p.rmap.off + (long long)m * p.rmap.ld : row_addr(p.rmap, m)) + n;
                         const bf16x8 rv = (NT & 2) ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(rp)) : *reinterpret_cast<const bf16x8*>(rp);
                         if (X3) {
                             const bf16x8 rl = *reinterpret_cast<const bf16x8*>(rp + p.r_plane);
@@ -109,11 +141,11 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p, const f32x4 (&a
                         }
                     }
                     long long c_col = n;
-                    if (p.c_colblk > 0) {
+                    if (!PLAIN && p.c_colblk > 0) {
                         const int blk = n / p.c_colblk;
                         c_col = (long long)blk * p.c_colblk_stride + (n - blk * p.c_colblk);
                     }
-                    const long long ci = (c_plain ? p.cmap.off + (long long)m * p.cmap.ld : row_addr(p.cmap, m)) + c_col;
+                    const long long ci = ((PLAIN || c_plain) ? p.cmap.off + (long long)m * p.cmap.ld : row_addr(p.cmap, m)) + c_col;
                     if (X3 == 2) {
                         if (NT & 1) {
                             __builtin_nontemporal_store((f32x4){v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(Cf + ci));
@@ -171,7 +203,7 @@ __device__ unsigned long long g_timeline[kTimelineSlots * 6];
 //   752 tiles of 256 x 192 = 2.94 rounds).  Same schedule: B tiles are 192 rows (the second B half is 64 rows = ONE DMA
 //   instruction per thread), phases 3 / 4 multiply the third 16-column tile only (16 + 16 + 8 + 8 MFMAs per K tile), the counted
 //   waits allow one DMA less.  Same MFMA order per output element, same results.
-template <int ABL = 0, bool BUFLD = false, int X3 = 0, int NB = 2, int NJ = 4>
+template <int ABL = 0, bool BUFLD = false, int X3 = 0, int NB = 2, int NJ = 4, bool RPRE = false, bool PLAIN = false>
 __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams p) {
     using Cfg = P8Cfg;
     static_assert(NB == 2 || (NB == 3 && X3 == 0 && !BUFLD), "three B buffers: plain bf16, global_load_lds");
@@ -395,7 +427,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
 #undef NOMAD_P8_DMA_B
 
     if (ABL == 7) ts_[2] = wall_clock64();
-    p8_epilogue<ABL == 1, X3, (ABL == 8 || (ABL >= 13 && ABL <= 16) ? 1 : ABL == 9 ? 3 : ABL == 10 ? 2 : 0), NJ>(p, acc, smem8, grp, m0, n0, wave, wr, wc, lane, fr, fq);
+    p8_epilogue<ABL == 1, X3, (ABL == 8 || (ABL >= 13 && ABL <= 16) ? 1 : ABL == 9 ? 3 : ABL == 10 ? 2 : 0), NJ, RPRE, PLAIN>(p, acc, smem8, grp, m0, n0, wave, wr, wc, lane, fr, fq);
     if (ABL == 7) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the output stores have left the CU
         ts_[3] = wall_clock64();
@@ -409,18 +441,18 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
     }
 }
 
-template <int ABL = 0, bool BUFLD = false, int X3 = 0, int NB = 2, int NJ = 4>
+template <int ABL = 0, bool BUFLD = false, int X3 = 0, int NB = 2, int NJ = 4, bool RPRE = false, bool PLAIN = false>
 inline hipError_t launch_gemm_bf16_8phase(GemmParams p, int groups, hipStream_t s) {
     p.tiles_m = (p.M + P8Cfg::BM - 1) / P8Cfg::BM;
     p.tiles_n = p.N / (64 * NJ);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_8phase_kernel<ABL, BUFLD, X3, NB, NJ>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_8phase_kernel<ABL, BUFLD, X3, NB, NJ, RPRE, PLAIN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_8phase_kernel<ABL, BUFLD, X3, NB, NJ>), dim3(p.tiles_m * p.tiles_n, groups), dim3(P8Cfg::THREADS),
+    hipLaunchKernelGGL((gemm_bf16_8phase_kernel<ABL, BUFLD, X3, NB, NJ, RPRE, PLAIN>), dim3(p.tiles_m * p.tiles_n, groups), dim3(P8Cfg::THREADS),
                        NB == 3 ? 160 * 1024 : P8Cfg::LDS_BYTES, s, p);
     return hipGetLastError();
 }

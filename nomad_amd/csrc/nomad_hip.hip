@@ -1390,6 +1390,21 @@ static bool p8_nt_stores() {
     return v;
 }
 
+// residual prefetch in the epilogue of the deep-pipelined bf16 kernel (p8_epilogue, RPRE); NOMAD_BF16_RPRE=0 / 1 (A/B runs)
+// 0 = off, 1 = the RPRE instantiation for GEMMs with a residual only (alternates with the plain one: slower, kept for A/B),
+// 2 = for every GEMM (one code object), 3 (default) = 2 + the small epilogue for plain C / R matrices
+static int p8_residual_prefetch() {
+    static const int v = [] {
+        const char* e = getenv("NOMAD_BF16_RPRE");
+        return e ? atoi(e) : 3;
+    }();
+    return v;
+}
+static bool p8_plain_cr(const GemmParams& p) {
+    return p.cmap.clip_rows >= p.M && !p.cmap.pref && p.c_colblk == 0 && p.c_blk_step == 0 &&
+           (!p.R || (p.rmap.clip_rows >= p.M && !p.rmap.pref));
+}
+
 // three B buffers in the deep-pipelined bf16 kernel (B staged 1.75 K tiles ahead, 160 KB of LDS); NOMAD_BF16_B3=0: two (A/B runs)
 static bool p8_three_b() {
     static const bool v = [] {
@@ -1430,7 +1445,7 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
             tile = (p8_three_b() && p8_nt_stores() && p8_use_n192(p.M, p.N, p.K)) ? 55 : 16;  // deep-pipelined 256x256 / 256x192 kernel once there are >= 2 rounds of tiles (profiles/r01_gemm_sweep_bf16_8phase.json)
         else tile = (p.N % 256 == 0 && (p.N >= 1024 || p.M >= 100000)) ? 3 : 1;
     }
-    Scope sc(c, s, NOMAD_K_GEMM, flops, (tile == 1 || tile == 3 || tile == 16 || tile == 55 || tile == 56 || tile == 42 || tile == 43 || tile == 44 || tile == 45 || tile == 46 || tile == 47 || tile == 48 || tile == 49 || tile == 50 || tile == 51 || tile == 52 || tile == 53 || tile == 54 || tile == 20 || tile == 21 || tile == 27 || tile == 28 || tile == 32 || tile == 33) ? NOMAD_K_GEMM_BIG : (tile == 2 ? NOMAD_K_GEMM_FINE : -1));
+    Scope sc(c, s, NOMAD_K_GEMM, flops, (tile == 1 || tile == 3 || tile == 16 || tile == 55 || tile == 56 || tile == 57 || tile == 58 || tile == 42 || tile == 43 || tile == 44 || tile == 45 || tile == 46 || tile == 47 || tile == 48 || tile == 49 || tile == 50 || tile == 51 || tile == 52 || tile == 53 || tile == 54 || tile == 20 || tile == 21 || tile == 27 || tile == 28 || tile == 32 || tile == 33) ? NOMAD_K_GEMM_BIG : (tile == 2 ? NOMAD_K_GEMM_FINE : -1));
     hipError_t e;
     switch (tile) {
         // the instantiations the bf16 / bf16x3 forwards select
@@ -1441,7 +1456,16 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
         case 16:  // 256x256 deep-pipelined schedule (gemm_bf16_8phase.hip.h)
             if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
             e = !p8_nt_stores() ? launch_gemm_bf16_8phase<0>(p, groups, s)
-                : !p8_three_b() ? launch_gemm_bf16_8phase<8>(p, groups, s) : launch_gemm_bf16_8phase<8, false, 0, 3>(p, groups, s);
+                : !p8_three_b() ? launch_gemm_bf16_8phase<8>(p, groups, s)
+                : (p8_residual_prefetch() == 3 && p8_plain_cr(p)) ? launch_gemm_bf16_8phase<8, false, 0, 3, 4, true, true>(p, groups, s)
+                : ((p.R && p8_residual_prefetch() == 1) || p8_residual_prefetch() >= 2) ? launch_gemm_bf16_8phase<8, false, 0, 3, 4, true>(p, groups, s)
+                                                  : launch_gemm_bf16_8phase<8, false, 0, 3>(p, groups, s);
+            break;
+        case 57:  // the deep-pipelined kernel with the residual prefetch in the epilogue, general C / R addressing
+        case 58:  // ... with the small epilogue for plain C / R matrices (what tile 16 resolves to for them)
+            if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
+            if (tile == 58 && !p8_plain_cr(p)) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm, plain epilogue: C / R are not plain matrices");
+            e = tile == 57 ? launch_gemm_bf16_8phase<8, false, 0, 3, 4, true>(p, groups, s) : launch_gemm_bf16_8phase<8, false, 0, 3, 4, true, true>(p, groups, s);
             break;
         case 55:  // 256x192 tiles of the same schedule (three B buffers, nt stores)
             if (p.N % 192 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm, 192-column tiles: N %% 192, K %% 128");
@@ -2531,7 +2555,7 @@ int nomad_diag_timeline(unsigned long long* out_host, int n) {
 int nomad_diag_gemm_bf16(nomad_ctx* c, const void* A, const void* W, const float* bias, const void* R, void* C, int M,
                          int N, int K, int gelu, int tile, nomad_stream_t stream) {
     static const int kBN[] = {128, 128, 64, 256, 64, 128, 128, 128, 128, 256, 256, 128, 128, 128, 128, 256, 256, 256, 256, 256};
-    const bool big256 = tile == 36 || (tile >= 42 && tile <= 54);
+    const bool big256 = tile == 36 || (tile >= 42 && tile <= 54) || tile == 57 || tile == 58;
     if (tile == 55 || tile == 56) {  // 256 x 192 tiles of the deep-pipelined kernel
         if (!c || !A || !W || !C || M <= 0) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: bad argument");
         if (N % 192 || K % 128) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: N %% 192 or K %% 128 != 0");

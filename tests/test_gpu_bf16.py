@@ -60,7 +60,7 @@ def test_gemm_bf16_192_column_tiles_are_bit_identical(engine_for, M, N, K, epi):
     W = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16().cuda()
     bias = torch.randn(N, generator=g).cuda() if "bias" in epi else None
     R = torch.randn(M, N, generator=g).bfloat16().cuda() if "res" in epi else None
-    outs = [engine_for("bf16", t).diag_gemm_bf16(A, W, bias, R, gelu="gelu" in epi, tile=t) for t in (16, 55, 56, 1)]
+    outs = [engine_for("bf16", t).diag_gemm_bf16(A, W, bias, R, gelu="gelu" in epi, tile=t) for t in (16, 55, 56, 57, 58, 1)]   # 57 / 58: the residual prefetch, general / plain epilogue (16 resolves to one of them)
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
 

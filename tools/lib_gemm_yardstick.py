@@ -69,6 +69,11 @@ for dtype, names in (("bf16", args.bf16), ("f32", args.f32)):
         if t_ours:
             rec["ours_ms"] = min(t_ours)
             rec["ours_tflops"] = fl / min(t_ours) / 1e9
+        if dtype == "bf16" and has_r and N % 256 == 0:   # tile 16 with the residual prefetch in the epilogue
+            alt = lambda: _lib.check(fn(eng.ctx, ptr(A), ptr(W), ptr(b), ptr(R), ptr(Co), M, N, K, int(gelu), 57, eng._stream()), "diag_gemm")
+            t = min(timed(alt, args.iters) for _ in range(3))
+            rec["rpre_ms"] = t
+            rec["rpre_tflops"] = fl / t / 1e9
         if dtype == "bf16" and N % 192 == 0 and K % 128 == 0:   # the 256 x 192 tiles of the same schedule
             for tname, tid in (("n192", 55), ("n192_two_b", 56)):
                 alt = lambda: _lib.check(fn(eng.ctx, ptr(A), ptr(W), ptr(b), ptr(R), ptr(Co), M, N, K, int(gelu), tid, eng._stream()), "diag_gemm")
