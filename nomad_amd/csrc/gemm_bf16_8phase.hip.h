@@ -146,7 +146,7 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p, const f32x4 (&a
                         c_col = (long long)blk * p.c_colblk_stride + (n - blk * p.c_colblk);
                     }
                     const long long ci = ((PLAIN || c_plain) ? p.cmap.off + (long long)m * p.cmap.ld : row_addr(p.cmap, m)) + c_col;
-                    if (X3 == 2) {
+                    if (X3 == 2 || (X3 == 3 && p.c_plane == 0)) {   // fp32 output (X3 = 3: decided per problem)
                         if (NT & 1) {
                             __builtin_nontemporal_store((f32x4){v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(Cf + ci));
                             __builtin_nontemporal_store((f32x4){v[4], v[5], v[6], v[7]}, reinterpret_cast<f32x4*>(Cf + ci + 4));
@@ -160,7 +160,7 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p, const f32x4 (&a
                         for (int e = 0; e < 8; ++e) ov[e] = (bf16_t)v[e];
                         if (NT & 1) __builtin_nontemporal_store(ov, reinterpret_cast<bf16x8*>(Cg + ci));
                         else *reinterpret_cast<bf16x8*>(Cg + ci) = ov;
-                        if (X3 == 1) {
+                        if (X3 == 1 || X3 == 3) {
                             bf16x8 ol;
 #pragma unroll
                             for (int e = 0; e < 8; ++e) ol[e] = (bf16_t)(v[e] - (float)ov[e]);

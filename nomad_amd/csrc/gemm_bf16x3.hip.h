@@ -51,7 +51,10 @@ struct X3Cfg {
 };
 
 // LDS: [NA buffers of (A_hi, A_lo)] [2 buffers of (W_hi, W_lo)]
-template <int ABL, int X3, int NA>
+// X3 = 3: the output format is a run-time property of the problem (p.c_plane != 0: split planes, else fp32) and PLAIN = the small
+// epilogue for plain C / R matrices (gemm_bf16_8phase.hip.h): ONE instantiation for every GEMM of the bf16x3 transformer layers
+// instead of two 60 KB ones alternating four times per layer.
+template <int ABL, int X3, int NA, bool PLAIN = false>
 __global__ __launch_bounds__(512) void gemm_bf16x3_kernel(const GemmParams p) {
     using Cfg = X3Cfg;
     extern __shared__ __attribute__((aligned(16))) char smem8[];
@@ -231,21 +234,21 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_kernel(const GemmParams p) {
 #undef NOMAD_X3_DMA_A
 #undef NOMAD_X3_DMA_B
 
-    p8_epilogue<ABL == 1, X3, (ABL == 8 ? 1 : 0)>(p, acc, smem8, grp, m0, n0, wave, wr, wc, lane, fr, fq);
+    p8_epilogue<ABL == 1, X3, (ABL == 8 ? 1 : 0), 4, false, PLAIN>(p, acc, smem8, grp, m0, n0, wave, wr, wc, lane, fr, fq);
 }
 
-template <int ABL, int X3, int NA = 2>
+template <int ABL, int X3, int NA = 2, bool PLAIN = false>
 inline hipError_t launch_gemm_bf16x3(GemmParams p, int groups, hipStream_t s) {
     p.tiles_m = (p.M + X3Cfg::BM - 1) / X3Cfg::BM;
     p.tiles_n = p.N / X3Cfg::BN;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel<ABL, X3, NA>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel<ABL, X3, NA, PLAIN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_bf16x3_kernel<ABL, X3, NA>), dim3(p.tiles_m * p.tiles_n, groups), dim3(X3Cfg::THREADS), (NA + 2) * X3Cfg::PAIR_BYTES, s, p);
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<ABL, X3, NA, PLAIN>), dim3(p.tiles_m * p.tiles_n, groups), dim3(X3Cfg::THREADS), (NA + 2) * X3Cfg::PAIR_BYTES, s, p);
     return hipGetLastError();
 }
 

@@ -397,7 +397,7 @@ __device__ __forceinline__ void split_frag8(const f32x4& a, const f32x4& b, cons
 //      M = 1600 rows, one round of 64 x 64 tiles, where one wave's serial K loop IS the launch time) is ~5x shorter.
 //      Every X3 instantiation contracts k in the same order, so the tile choice changes no result bit, as in fp32.
 template <int BM, int BN, int BK, int WM, int WN, int STAGES = 2, bool NOEPI = false, int OPT = 0, bool X3 = false>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_f32_glds_kernel(const GemmParams p) {
+__global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : 1) void gemm_f32_glds_kernel(const GemmParams p) {   // OPT bit 16: two 8-wave workgroups per CU = 128 VGPRs
     using Cfg = GldsCfg<BM, BN, BK, WM, WN, STAGES>;
     constexpr int TM = Cfg::TM, TN = Cfg::TN, NT = Cfg::THREADS, KC = Cfg::KC, RB = Cfg::RB;
     static_assert(BK == 8 || BK == 16 || BK == 32, "swizzle is written for 32-, 64- and 128-B rows");
@@ -566,6 +566,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_glds_kernel(const GemmPa
     float* Ug = p.Upre ? p.Upre + grp * p.c_goff : nullptr;
     const bool c_plain = p.cmap.clip_rows >= p.M, r_plain = p.rmap.clip_rows >= p.M;
     constexpr int ELD = Cfg::WTN + 4, CG = Cfg::WTN / 4;
+    // OPT bit 16: the epilogue for PLAIN C / R matrices (the caller checked: no ragged row maps, no column blocks, no Upre / DG
+    // side outputs) with the residual PREFETCHED per slab.  (1) The general epilogue's address arithmetic - a binary search per
+    // row for ragged maps, integer divisions for column blocks - unrolled over 16 chunks is most of this kernel's 70 KB of code,
+    // and two such instantiations alternating between launches cost the launch after each switch 12-17 us of instruction-cache
+    // misses (measured on the bf16 twin, gemm_bf16_8phase.hip.h); (2) C and R are not restrict-qualified, so the compiler keeps
+    // every residual load behind the previous chunk's store and waits for it at once - a lane only stores what it loaded, so the
+    // loads of a slab can all be issued before its first store.  Same arithmetic, same results.
+    constexpr bool PL = (OPT & 16) != 0;
+    constexpr int NIT = 32 * CG / 64;
     float* slab = smem + wave * (32 * ELD);
     float bv[TN];
 #pragma unroll
@@ -577,6 +586,20 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_glds_kernel(const GemmPa
     for (int i = 0; i < TM; ++i) {
         // the slab is private to the wave: after the first barrier (main loop done with the staging LDS) a wave-local
         // fence is enough, LDS operations of one wave execute in order
+        // (in groups of NIT / 4 chunks: the kernel must stay within 128 VGPRs for two workgroups per CU)
+        constexpr int NH = NIT >= 4 ? NIT / 4 : NIT;
+        f32x4 rpre[NH];
+        auto prefetch = [&](int it0) {
+#pragma unroll
+            for (int it = it0; it < it0 + NH; ++it) {
+                const int id = lane + 64 * it, row = id / CG, cg = id - row * CG;
+                const int m = m0 + wm * Cfg::WTM + i * 32 + row;
+                const int n = n0 + wn * Cfg::WTN + cg * 4;
+                rpre[it - it0] = (m < p.M && n < p.n_valid) ? *reinterpret_cast<const f32x4*>(Rg + p.rmap.off + (long long)m * p.rmap.ld + n)
+                                                            : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        };
+        if (PL && Rg) prefetch(0);
         if (!(OPT & 1) || i == 0) __syncthreads();
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -592,7 +615,18 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_glds_kernel(const GemmPa
                 const int id = lane + 64 * it, row = id / CG, cg = id - row * CG;
                 const int m = m0 + wm * Cfg::WTM + i * 32 + row;
                 const int n = n0 + wn * Cfg::WTN + cg * 4;
-                if (m < p.M && n < p.n_valid) {
+                if (PL) {
+                    if (NH < NIT && it > 0 && it % NH == 0 && Rg) prefetch(it);   // next group: after the previous group's stores have been issued
+                    if (m < p.M && n < p.n_valid) {
+                        f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * ELD + cg * 4);
+                        if (p.gelu) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                        }
+                        if (Rg) v += rpre[it % NH];
+                        *reinterpret_cast<f32x4*>(Cg + p.cmap.off + (long long)m * p.cmap.ld + n) = v;
+                    }
+                } else if (m < p.M && n < p.n_valid) {
                     f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * ELD + cg * 4);
                     long long c_col = n;
                     if (p.c_colblk > 0) {

@@ -526,6 +526,19 @@ int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, in
         if (e != hipSuccess) return fail(NOMAD_ERR_HIP, "gemm (bf16x3 products) launch: %s", hipGetErrorString(e));
         return 0;
     }
+    // plain C / R matrices (every GEMM of the scoring forward but the pos-conv's neighbours): the instantiations with the small,
+    // residual-prefetching epilogue (gemm_f32.hip.h, OPT bit 16).  NOMAD_F32_PLAIN_EPI=0: the general epilogue (A/B runs)
+    static const bool plain_epi = [] {
+        const char* e = getenv("NOMAD_F32_PLAIN_EPI");
+        return e ? atoi(e) != 0 : true;
+    }();
+    if (plain_epi && (tile == 33 || tile == 31) && !p.Upre && !p.DG && p.c_colblk == 0 && p.cmap.clip_rows >= p.M && !p.cmap.pref &&
+        (!p.R || (p.rmap.clip_rows >= p.M && !p.rmap.pref))) {
+        e = tile == 33 ? launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16>(p, groups, s)
+                       : launch_gemm_glds<128, 128, 32, 4, 2, 2, false, 12 | 16>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 4, 2>::LDS_BYTES));
+        if (e != hipSuccess) return fail(NOMAD_ERR_HIP, "gemm launch: %s", hipGetErrorString(e));
+        return 0;
+    }
     switch (tile) {
         // the instantiations pick_tile() / the pos-conv can select
         case 20: e = launch_gemm_glds<128, 128, 32, 2, 2, 2, false, 12>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 2, 2>::LDS_BYTES)); break;
@@ -1400,6 +1413,15 @@ static int p8_residual_prefetch() {
     }();
     return v;
 }
+// bf16x3 GEMMs on plain C / R matrices: one instantiation with a run-time output format and the small epilogue
+// (gemm_bf16x3.hip.h); NOMAD_X3_PLAIN_EPI=0: the two templated ones (A/B runs)
+static bool x3_plain_epilogue() {
+    static const bool v = [] {
+        const char* e = getenv("NOMAD_X3_PLAIN_EPI");
+        return e ? atoi(e) != 0 : true;
+    }();
+    return v;
+}
 static bool p8_plain_cr(const GemmParams& p) {
     return p.cmap.clip_rows >= p.M && !p.cmap.pref && p.c_colblk == 0 && p.c_blk_step == 0 &&
            (!p.R || (p.rmap.clip_rows >= p.M && !p.rmap.pref));
@@ -1474,7 +1496,9 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
         case 27:  // bf16x3, every plane staged once (gemm_bf16x3.hip.h): split output
         case 28:  // ... fp32 output
             if (p.N % 256 != 0 || p.K % 64 != 0) return fail(NOMAD_ERR_INVALID, "bf16x3 gemm: N %% 256, K %% 64");
-            if (p8_nt_stores()) e = tile == 27 ? launch_gemm_bf16x3<8, 1>(p, groups, s) : launch_gemm_bf16x3<8, 2>(p, groups, s);
+            if (p8_nt_stores() && x3_plain_epilogue() && p8_plain_cr(p) && (tile == 27) == (p.c_plane != 0))
+                e = launch_gemm_bf16x3<8, 3, 2, true>(p, groups, s);   // one instantiation for both output formats, small epilogue
+            else if (p8_nt_stores()) e = tile == 27 ? launch_gemm_bf16x3<8, 1>(p, groups, s) : launch_gemm_bf16x3<8, 2>(p, groups, s);
             else e = tile == 27 ? launch_gemm_bf16x3<0, 1>(p, groups, s) : launch_gemm_bf16x3<0, 2>(p, groups, s);
             break;
 #ifdef NOMAD_DIAG
