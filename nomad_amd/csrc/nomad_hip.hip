@@ -1491,7 +1491,8 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
             break;
         case 55:  // 256x192 tiles of the same schedule (three B buffers, nt stores)
             if (p.N % 192 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm, 192-column tiles: N %% 192, K %% 128");
-            e = launch_gemm_bf16_8phase<8, false, 0, 3, 3>(p, groups, s);
+            e = (p8_residual_prefetch() == 3 && p8_plain_cr(p)) ? launch_gemm_bf16_8phase<8, false, 0, 3, 3, true, true>(p, groups, s)
+                                                                : launch_gemm_bf16_8phase<8, false, 0, 3, 3>(p, groups, s);
             break;
         case 27:  // bf16x3, every plane staged once (gemm_bf16x3.hip.h): split output
         case 28:  // ... fp32 output
