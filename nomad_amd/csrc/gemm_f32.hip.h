@@ -397,7 +397,7 @@ __device__ __forceinline__ void split_frag8(const f32x4& a, const f32x4& b, cons
 //      M = 1600 rows, one round of 64 x 64 tiles, where one wave's serial K loop IS the launch time) is ~5x shorter.
 //      Every X3 instantiation contracts k in the same order, so the tile choice changes no result bit, as in fp32.
 template <int BM, int BN, int BK, int WM, int WN, int STAGES = 2, bool NOEPI = false, int OPT = 0, bool X3 = false>
-__global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : 1) void gemm_f32_glds_kernel(const GemmParams p) {   // OPT bit 16: two 8-wave workgroups per CU = 128 VGPRs
+__global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : 1) void gemm_f32_glds_kernel(const GemmParams p) {   // OPT bit 16: two 8-wave workgroups per CU = 128 VGPRs (8 values computed in the prologue for the epilogue are spilled over the K loop, none inside it)
     using Cfg = GldsCfg<BM, BN, BK, WM, WN, STAGES>;
     constexpr int TM = Cfg::TM, TN = Cfg::TN, NT = Cfg::THREADS, KC = Cfg::KC, RB = Cfg::RB;
     static_assert(BK == 8 || BK == 16 || BK == 32, "swizzle is written for 32-, 64- and 128-B rows");
