@@ -566,8 +566,8 @@ __global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : 1) 
     float* Ug = p.Upre ? p.Upre + grp * p.c_goff : nullptr;
     const bool c_plain = p.cmap.clip_rows >= p.M, r_plain = p.rmap.clip_rows >= p.M;
     constexpr int ELD = Cfg::WTN + 4, CG = Cfg::WTN / 4;
-    // OPT bit 16: the epilogue for PLAIN C / R matrices (the caller checked: no ragged row maps, no column blocks, no Upre / DG
-    // side outputs) with the residual PREFETCHED per slab.  (1) The general epilogue's address arithmetic - a binary search per
+    // OPT bit 16: the epilogue for PLAIN C / R matrices (the caller checked: no ragged row maps, no column blocks; Upre / DG side
+    // operands only with bit 32, plain too) with the residual PREFETCHED per slab.  (1) The general epilogue's address arithmetic - a binary search per
     // row for ragged maps, integer divisions for column blocks - unrolled over 16 chunks is most of this kernel's 70 KB of code,
     // and two such instantiations alternating between launches cost the launch after each switch 12-17 us of instruction-cache
     // misses (measured on the bf16 twin, gemm_bf16_8phase.hip.h); (2) C and R are not restrict-qualified, so the compiler keeps
@@ -619,12 +619,19 @@ __global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : 1) 
                     if (NH < NIT && it > 0 && it % NH == 0 && Rg) prefetch(it);   // next group: after the previous group's stores have been issued
                     if (m < p.M && n < p.n_valid) {
                         f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * ELD + cg * 4);
+                        const long long c_idx = p.cmap.off + (long long)m * p.cmap.ld + n;
+                        if ((OPT & 32) && Ug) *reinterpret_cast<f32x4*>(Ug + c_idx) = v;   // OPT bit 32, training forward: the pre-activation copy
                         if (p.gelu) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
                         }
+                        if ((OPT & 32) && DGg) {                              // OPT bit 32, backward: GELU' of the saved pre-activation (plain map)
+                            const f32x4 u = *reinterpret_cast<const f32x4*>(DGg + p.dgmap.off + (long long)m * p.dgmap.ld + n);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] *= dgelu_erf_(u[e]);
+                        }
                         if (Rg) v += rpre[it % NH];
-                        *reinterpret_cast<f32x4*>(Cg + p.cmap.off + (long long)m * p.cmap.ld + n) = v;
+                        *reinterpret_cast<f32x4*>(Cg + c_idx) = v;
                     }
                 } else if (m < p.M && n < p.n_valid) {
                     f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * ELD + cg * 4);

@@ -532,10 +532,20 @@ int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, in
         const char* e = getenv("NOMAD_F32_PLAIN_EPI");
         return e ? atoi(e) != 0 : true;
     }();
-    if (plain_epi && (tile == 33 || tile == 31) && !p.Upre && !p.DG && p.c_colblk == 0 && p.cmap.clip_rows >= p.M && !p.cmap.pref &&
-        (!p.R || (p.rmap.clip_rows >= p.M && !p.rmap.pref))) {
-        e = tile == 33 ? launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16>(p, groups, s)
-                       : launch_gemm_glds<128, 128, 32, 4, 2, 2, false, 12 | 16>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 4, 2>::LDS_BYTES));
+    const bool plain_cr = plain_epi && p.c_colblk == 0 && p.cmap.clip_rows >= p.M && !p.cmap.pref &&
+                          (!p.R || (p.rmap.clip_rows >= p.M && !p.rmap.pref)) && (!p.DG || (p.dgmap.clip_rows >= p.M && !p.dgmap.pref));
+    if (plain_cr && (tile == 33 || tile == 31 || tile == 37 || tile == 34 || tile == 20)) {
+        constexpr int P = 16, T = 16 | 32;   // plain epilogue; + the training side operands (Upre / DG)
+        const bool tr = p.Upre || p.DG;
+        switch (tile) {
+            case 33: e = tr ? launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | T>(p, groups, s) : launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | P>(p, groups, s); break;
+            case 31: e = tr ? launch_gemm_glds<128, 128, 32, 4, 2, 2, false, 12 | T>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 4, 2>::LDS_BYTES))
+                            : launch_gemm_glds<128, 128, 32, 4, 2, 2, false, 12 | P>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 4, 2>::LDS_BYTES)); break;
+            case 20: e = tr ? launch_gemm_glds<128, 128, 32, 2, 2, 2, false, 12 | T>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 2, 2>::LDS_BYTES))
+                            : launch_gemm_glds<128, 128, 32, 2, 2, 2, false, 12 | P>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 2, 2>::LDS_BYTES)); break;
+            case 34: e = tr ? launch_gemm_glds<128, 64, 32, 4, 2, 3, false, 12 | T>(p, groups, s) : launch_gemm_glds<128, 64, 32, 4, 2, 3, false, 12 | P>(p, groups, s); break;
+            default: e = tr ? launch_gemm_glds<64, 64, 32, 2, 2, 3, false, 12 | T>(p, groups, s) : launch_gemm_glds<64, 64, 32, 2, 2, 3, false, 12 | P>(p, groups, s); break;
+        }
         if (e != hipSuccess) return fail(NOMAD_ERR_HIP, "gemm launch: %s", hipGetErrorString(e));
         return 0;
     }
