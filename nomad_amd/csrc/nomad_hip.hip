@@ -514,6 +514,26 @@ int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, in
         (long long)((p.M + 127) / 128) * (p.N / 128) >= 512)
         tile = 20;  // bf16x3 products: a 64 x 64 wave tile (128 x 128, 4 waves) does 12 MFMAs per 4 fragment splits where the
                     // 32 x 32 one does 3 per 2 - the split is VALU work - so it is taken as soon as it fills two rounds of CUs
+    // plain C / R (/ Upre / DG) matrices: the instantiations with the small, residual-prefetching epilogue (gemm_f32.hip.h, OPT bits
+    // 16 / 32) - every GEMM of the uniform scoring forward but the pos-conv's neighbours.  NOMAD_F32_PLAIN_EPI=0: the general
+    // epilogue (A/B runs)
+    static const bool plain_epi = [] {
+        const char* e = getenv("NOMAD_F32_PLAIN_EPI");
+        return e ? atoi(e) != 0 : true;
+    }();
+    const bool plain_cr = plain_epi && p.c_colblk == 0 && p.cmap.clip_rows >= p.M && !p.cmap.pref &&
+                          (!p.R || (p.rmap.clip_rows >= p.M && !p.rmap.pref)) && (!p.DG || (p.dgmap.clip_rows >= p.M && !p.dgmap.pref));
+    if (c->gemm_x3 && plain_cr && (tile == 20 || tile == 31 || tile == 34 || tile == 37)) {   // (not 33: its X3 form needs 146 VGPRs)
+        constexpr int T = 16 | 32;   // one plain instantiation per tile for scoring and training alike (this mode is the small-batch / training one)
+        switch (tile) {
+            case 20: e = launch_gemm_glds<128, 128, 32, 2, 2, 2, false, 12 | T, true>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 2, 2>::LDS_BYTES)); break;
+            case 31: e = launch_gemm_glds<128, 128, 32, 4, 2, 2, false, 12 | T, true>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 4, 2>::LDS_BYTES)); break;
+            case 34: e = launch_gemm_glds<128, 64, 32, 4, 2, 3, false, 12 | T, true>(p, groups, s); break;
+            default: e = launch_gemm_glds<64, 64, 32, 2, 2, 3, false, 12 | T, true>(p, groups, s); break;
+        }
+        if (e != hipSuccess) return fail(NOMAD_ERR_HIP, "gemm (bf16x3 products) launch: %s", hipGetErrorString(e));
+        return 0;
+    }
     if (c->gemm_x3 && (tile == 20 || tile == 31 || tile == 33 || tile == 34 || tile == 37)) {
         // bf16x3 products on the same fp32 operands (nomad_set_gemm_precision): same tiles, staging and epilogues
         switch (tile) {
@@ -526,14 +546,6 @@ int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, in
         if (e != hipSuccess) return fail(NOMAD_ERR_HIP, "gemm (bf16x3 products) launch: %s", hipGetErrorString(e));
         return 0;
     }
-    // plain C / R matrices (every GEMM of the scoring forward but the pos-conv's neighbours): the instantiations with the small,
-    // residual-prefetching epilogue (gemm_f32.hip.h, OPT bit 16).  NOMAD_F32_PLAIN_EPI=0: the general epilogue (A/B runs)
-    static const bool plain_epi = [] {
-        const char* e = getenv("NOMAD_F32_PLAIN_EPI");
-        return e ? atoi(e) != 0 : true;
-    }();
-    const bool plain_cr = plain_epi && p.c_colblk == 0 && p.cmap.clip_rows >= p.M && !p.cmap.pref &&
-                          (!p.R || (p.rmap.clip_rows >= p.M && !p.rmap.pref)) && (!p.DG || (p.dgmap.clip_rows >= p.M && !p.dgmap.pref));
     if (plain_cr && (tile == 33 || tile == 31 || tile == 37 || tile == 34 || tile == 20)) {
         constexpr int P = 16, T = 16 | 32;   // plain epilogue; + the training side operands (Upre / DG)
         const bool tr = p.Upre || p.DG;
