@@ -574,25 +574,30 @@ __global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : 1) 
     // every residual load behind the previous chunk's store and waits for it at once - a lane only stores what it loaded, so the
     // loads of a slab can all be issued before its first store.  Same arithmetic, same results.
     constexpr bool PL = (OPT & 16) != 0;
+    // the lane index is laundered through an empty asm so that the per-lane row / column indices of the epilogue are computed HERE:
+    // hoisted above the K loop they stayed live across it and were spilled to scratch in the 128-register instantiations (8 dwords
+    // per lane and tile: +12 % on WRITE_SIZE of conv1, seen in the live traffic counters)
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
     constexpr int NIT = 32 * CG / 64;
     float* slab = smem + wave * (32 * ELD);
     float bv[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * Cfg::WTN + j * 32 + (lane & 31);
+        const int n = n0 + wn * Cfg::WTN + j * 32 + (lane_e & 31);
         bv[j] = (biasg && n < p.n_valid) ? biasg[n] : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         // the slab is private to the wave: after the first barrier (main loop done with the staging LDS) a wave-local
         // fence is enough, LDS operations of one wave execute in order
-        // (in groups of NIT / 4 chunks: the kernel must stay within 128 VGPRs for two workgroups per CU)
-        constexpr int NH = NIT >= 4 ? NIT / 4 : NIT;
+        // (in groups of NIT / 2 chunks, NIT / 4 with the training operands: the kernel must stay within 128 VGPRs for two workgroups per CU)
+        constexpr int NH = (OPT & 32) ? (NIT >= 4 ? NIT / 4 : NIT) : (NIT >= 2 ? NIT / 2 : NIT);
         f32x4 rpre[NH];
         auto prefetch = [&](int it0) {
 #pragma unroll
             for (int it = it0; it < it0 + NH; ++it) {
-                const int id = lane + 64 * it, row = id / CG, cg = id - row * CG;
+                const int id = lane_e + 64 * it, row = id / CG, cg = id - row * CG;
                 const int m = m0 + wm * Cfg::WTM + i * 32 + row;
                 const int n = n0 + wn * Cfg::WTN + cg * 4;
                 rpre[it - it0] = (m < p.M && n < p.n_valid) ? *reinterpret_cast<const f32x4*>(Rg + p.rmap.off + (long long)m * p.rmap.ld + n)
@@ -606,13 +611,13 @@ __global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : 1) 
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                slab[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * ELD + j * 32 + (lane & 31)] = acc[i][j][r] + bv[j];
+                slab[((r & 3) + 8 * (r >> 2) + 4 * (lane_e >> 5)) * ELD + j * 32 + (lane_e & 31)] = acc[i][j][r] + bv[j];
         if (!(OPT & 1)) __syncthreads();
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (!NOEPI) {
 #pragma unroll
             for (int it = 0; it < 32 * CG / 64; ++it) {
-                const int id = lane + 64 * it, row = id / CG, cg = id - row * CG;
+                const int id = lane_e + 64 * it, row = id / CG, cg = id - row * CG;
                 const int m = m0 + wm * Cfg::WTM + i * 32 + row;
                 const int n = n0 + wn * Cfg::WTN + cg * 4;
                 if (PL) {
