@@ -373,7 +373,8 @@ def main():
                        "finite": bool(torch.isfinite(m5).all().item()),
                        "context": "STATIC notes, not measured in this run: this forward holds a shader clock of 2015-2160 MHz of the "
                                   "2400 nominal (profiles/r03_n192_null.txt, r03_clock_c5.jsonl); sustained on its GEMM shapes hipBLASLt "
-                                  "reaches 725-1205 TFLOP/s, the shipped kernels 658-1086 (profiles/r03_vendor_yardstick.txt)"}
+                                  "reaches 725-1205 TFLOP/s, the shipped kernels 715-1086 (profiles/r03_vendor_yardstick.txt; out_proj / fc2 with the "
+                                  "prefetching epilogue: profiles/NOTEBOOK.md, last section)"}
             del wav5
         except Exception as e:
             also_c5 = {"workload": "configs[4]", "error": str(e)[:200]}
