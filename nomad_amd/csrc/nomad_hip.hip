@@ -663,8 +663,13 @@ int pick_tile(int M, int N, int K) {
     // (profiles/r01_gemm_sweep_train_m.json)
     if (N >= 2048 && N % 128 == 0 && tiles256 < 2048) return 20;
     // out_proj, conv5/6 at full batch (K = 768 / 1024, N = 768 / 512): 128x128x32 tiles, 8 waves, 2 stages: +2..5 % over
-    // 128x64 (profiles/r01_gemm_sweep_n768_128x128.json)
-    return N % 128 == 0 ? 31 : 34;
+    // 128x64 (profiles/r01_gemm_sweep_n768_128x128.json).  NOMAD_F32_MID_TILE=33 (A/B): the 256x128 kernel there too, so that the
+    // transformer layers run ONE GEMM instantiation (no alternation)
+    static const int mid = [] {
+        const char* e = getenv("NOMAD_F32_MID_TILE");
+        return e ? atoi(e) : 31;
+    }();
+    return N % 128 == 0 ? mid : 34;
 }
 
 int run_layernorm(nomad_ctx* c, const float* in, const float* g, const float* b, float* out, float* out2, int M, int N,
