@@ -5,6 +5,11 @@
 
 namespace nomad {
 
+// per-workgroup timeline of the GEMM timing probes (gemm_bf16_8phase.hip.h ABL 7, gemm_f32.hip.h OPT bit 128; nomad_diag_timeline)
+constexpr int kTimelineSlots = 4096;
+__device__ unsigned long long g_timeline[kTimelineSlots * 6];
+
+
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));

@@ -189,8 +189,7 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p, const f32x4 (&a
 //      12 = timing probe: as 5 (no DMA, no LDS reads) and no barriers in the loop either - both wave rows issue MFMAs freely.
 // timing probe ABL 7 (tools/gemm_timeline.py): per workgroup {entry, main loop start, main loop end, stores done} in 100 MHz
 // wall-clock ticks + HW_ID + XCC_ID
-constexpr int kTimelineSlots = 4096;
-__device__ unsigned long long g_timeline[kTimelineSlots * 6];
+// (kTimelineSlots / g_timeline live in dtypes.hip.h: the fp32 GEMM's probe writes the same buffer)
 
 // NB = 3 (plain bf16 only): THREE B buffers.  With two, B of tile t+1 can only be issued in phases 1 / 2 of tile t (its buffer
 //   is read until phase 3 of tile t-1) and is waited for in phase 4 of the same tile: 2-3 phases of lead, less than an L2

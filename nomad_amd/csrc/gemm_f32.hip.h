@@ -340,6 +340,16 @@ struct GldsCfg {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// A pointer every lane of the wave holds the same value of, moved to SGPRs.  The tile base addresses below are uniform by
+// construction but come out of 64-bit VALU arithmetic (row_addr's ragged branch loads through the vector memory path), and a
+// buffer descriptor built from VGPRs makes the compiler wrap EVERY buffer_load ... lds in a waterfall loop (4 v_readfirstlane,
+// 2 v_cmp_eq_u64, s_and_saveexec, a branch) - found in round 4 in the K loop of every fp32 GEMM, on the A operand.
+__device__ __forceinline__ const float* uniform_ptr(const float* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+}
+
 // 16 bytes per lane from `base + voff + soff` (bytes) straight into LDS through a raw buffer descriptor
 // (buffer_load_dwordx4 ... offen lds): the base is wave-uniform (SGPRs), the per-lane part is one 32-bit VGPR.
 __device__ __forceinline__ void dma16_buffer(const float* base, lptr_t dst, int voff, int soff) {
@@ -397,7 +407,7 @@ __device__ __forceinline__ void split_frag8(const f32x4& a, const f32x4& b, cons
 //      M = 1600 rows, one round of 64 x 64 tiles, where one wave's serial K loop IS the launch time) is ~5x shorter.
 //      Every X3 instantiation contracts k in the same order, so the tile choice changes no result bit, as in fp32.
 template <int BM, int BN, int BK, int WM, int WN, int STAGES = 2, bool NOEPI = false, int OPT = 0, bool X3 = false>
-__global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : 1) void gemm_f32_glds_kernel(const GemmParams p) {   // OPT bit 16: two 8-wave workgroups per CU = 128 VGPRs (8 values computed in the prologue for the epilogue are spilled over the K loop, none inside it)
+__global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : (((OPT & 16) && WM * WN == 4 && BM * BN == 256 * 128) ? 2 : 1)) void gemm_f32_glds_kernel(const GemmParams p) {   // OPT bit 16: two 8-wave workgroups per CU = 128 VGPRs (8 values computed in the prologue for the epilogue are spilled over the K loop, none inside it)
     using Cfg = GldsCfg<BM, BN, BK, WM, WN, STAGES>;
     constexpr int TM = Cfg::TM, TN = Cfg::TN, NT = Cfg::THREADS, KC = Cfg::KC, RB = Cfg::RB;
     static_assert(BK == 8 || BK == 16 || BK == 32, "swizzle is written for 32-, 64- and 128-B rows");
@@ -411,6 +421,12 @@ __global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : 1) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave - wm * WN;
     const int nwg = p.tiles_m * p.tiles_n;
+#ifdef NOMAD_DIAG
+    // OPT bit 128 (timing probe, tools/gemm_timeline_f32.py): wave 0 stamps {entry, first barrier passed, K loop done, epilogue stores
+    // issued, stores acknowledged} in 100 MHz wall-clock ticks + HW_ID | XCC_ID << 32 into g_timeline[6 * blockIdx.x]
+    unsigned long long ts_[5] = {0, 0, 0, 0, 0};
+    if (OPT & 128) ts_[0] = wall_clock64();
+#endif
     // Persistent launch (gridDim.x < nwg): a workgroup walks tiles blockIdx.x, + gridDim.x, ...; its output stores
     // drain under the next tile's prologue instead of holding the wave slots until they are acknowledged.
     for (int t_ = blockIdx.x; t_ < nwg; t_ += gridDim.x) {
@@ -444,8 +460,8 @@ __global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : 1) 
         b_src[i] = Wg + (long long)(n0 + row) * p.ldw + ((pc ^ ((row / RB) % KC)) * 4);
         b_voff[i] = (int)(((long long)row * p.ldw + ((pc ^ ((row / RB) % KC)) * 4)) * 4);
     }
-    const float* const a_tile = Ag + tile_row0;
-    const float* const b_tile = Wg + (long long)n0 * p.ldw;
+    const float* const a_tile = (OPT & 4) ? uniform_ptr(Ag + tile_row0) : Ag + tile_row0;
+    const float* const b_tile = (OPT & 4) ? uniform_ptr(Wg + (long long)n0 * p.ldw) : Wg + (long long)n0 * p.ldw;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -456,11 +472,20 @@ __global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : 1) 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = p.K / BK;
+    // K tiles are staged strictly in order, so the chunked-K map (logical k -> (k / kchunk) * kstride + k % kchunk) is walked
+    // with three running scalars instead of an integer division per tile (KT only documents which tile a call stages)
+    int ld_k0 = 0, ld_in = 0;
+    long long ld_chunk = 0;
 #define NOMAD_GLDS_TILE(KT, BUF)                                                                         \
     {                                                                                                    \
-        const int k0_ = (KT)*BK;                                                                         \
-        const int kq_ = k0_ / p.kchunk;                                                                  \
-        const long long a_koff_ = (long long)kq_ * p.kstride + (k0_ - kq_ * p.kchunk);                   \
+        const int k0_ = ld_k0;                                                                           \
+        const long long a_koff_ = ld_chunk + ld_in;                                                      \
+        ld_k0 += BK;                                                                                     \
+        ld_in += BK;                                                                                     \
+        if (ld_in >= p.kchunk) {                                                                         \
+            ld_in = 0;                                                                                   \
+            ld_chunk += p.kstride;                                                                       \
+        }                                                                                                \
         float* as_ = As + (BUF)*BM * BK + wave * 256;                                                    \
         float* bs_ = Bs + (BUF)*BN * BK + wave * 256;                                                    \
         if (OPT & 4) {                                                                                   \
@@ -491,6 +516,77 @@ __global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : 1) 
     SplitConsts sk{};
     if (X3) sk = split_consts();
     int cur = 0;  // LDS buffer of tile kt
+    if constexpr ((OPT & 64) != 0) {
+        // OPT bit 64 (round 4): the skewed schedule.  All three stages are kept in flight; the fragments of k-step s+1 are read before
+        // the MFMAs of step s, and the per-tile vmcnt + barrier sits in front of a tile's LAST step, so the first fragments of tile
+        // kt+1 are read behind it under that step's MFMAs and the DMA of tile kt+3 refills the buffer the barrier has just released.
+        // A wave waits for the barrier and for nothing else.  Same contraction order per accumulator (kq ascending, c ascending):
+        // bit-identical to the straight schedule.
+        static_assert(STAGES == 3 && !X3 && (BK / 8) % 2 == 0, "skewed schedule: 3 stages, fp32 products, an even number of k-steps");
+        constexpr int NKQ = BK / 8, D = Cfg::A_CHUNKS + Cfg::B_CHUNKS;
+#define NOMAD_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+        if (nk > 2) {
+            NOMAD_GLDS_TILE(2, 2)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * D) : "memory");
+        } else if (nk > 1) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        NOMAD_FENCE();
+        f32x4 af[2][TM], bf[2][TN];
+        auto rd = [&](int buf, int st, int kq) {
+            const float* as = As + st * BM * BK + a_row_off;
+            const float* bs = Bs + st * BN * BK + b_row_off;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[buf][i] = *reinterpret_cast<const f32x4*>(as + i * 32 * BK + koff[kq]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[buf][j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * BK + koff[kq]);
+        };
+        auto mm = [&](int buf, int c0, int c1) {
+#pragma unroll
+            for (int c = c0; c < c1; ++c)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[buf][i][c], bf[buf][j][c], acc[i][j], 0, 0, 0);
+        };
+        rd(0, 0, 0);
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+#pragma unroll
+            for (int kq = 0; kq + 1 < NKQ; ++kq) {
+                rd((kq + 1) & 1, cur, kq + 1);
+                NOMAD_FENCE();
+                mm(kq & 1, 0, 4);
+                NOMAD_FENCE();
+            }
+            const int nxt = cur + 1 == STAGES ? 0 : cur + 1;
+            // this wave has read all of tile kt, and its share of tile kt+1 has landed (tile kt+2 may still be in flight)
+            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(D) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            NOMAD_FENCE();
+            rd(0, nxt, 0);
+            NOMAD_FENCE();
+            mm((NKQ - 1) & 1, 0, 1);
+            NOMAD_FENCE();
+            if (kt + 3 < nk) NOMAD_GLDS_TILE(kt + 3, cur)
+            NOMAD_FENCE();
+            mm((NKQ - 1) & 1, 1, 4);
+            NOMAD_FENCE();
+            cur = nxt;
+        }
+#pragma unroll
+        for (int kq = 0; kq < NKQ; ++kq) {   // the last tile
+            if (kq + 1 < NKQ) rd((kq + 1) & 1, cur, kq + 1);
+            NOMAD_FENCE();
+            mm(kq & 1, 0, 4);
+            NOMAD_FENCE();
+        }
+#undef NOMAD_FENCE
+    } else
     for (int kt = 0; kt < nk; ++kt) {
         if (STAGES == 2) {
             __syncthreads();  // tile kt has landed (vmcnt(0)) and every wave is done with the other buffer
@@ -500,6 +596,9 @@ __global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : 1) 
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();  // every wave's share of tile kt has landed; buffer of tile kt-1 is free
             asm volatile("" ::: "memory");
+#ifdef NOMAD_DIAG
+            if ((OPT & 128) && kt == 0) ts_[1] = wall_clock64();
+#endif
         }
         const int nxt = kt + STAGES - 1;
         int nb = cur + STAGES - 1;
@@ -553,6 +652,9 @@ __global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : 1) 
         cur = cur + 1 == STAGES ? 0 : cur + 1;
     }
 #undef NOMAD_GLDS_TILE
+#ifdef NOMAD_DIAG
+    if (OPT & 128) ts_[2] = wall_clock64();
+#endif
 
     // Epilogue through LDS: an accumulator holds one output column per lane (4-byte stores, 64 per lane and
     // tile).  Each wave parks a 32-row slab (acc + bias) in LDS, then every lane owns 4 consecutive columns of
@@ -638,6 +740,10 @@ __global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : 1) 
                         if (Rg) v += rpre[it % NH];
                         *reinterpret_cast<f32x4*>(Cg + c_idx) = v;
                     }
+                    // OPT bits 256 / 512 (experiment): pace the output stores (s_sleep 4 / 16 = 256 / 1024 cycles after each) so that the
+                    // CU's vector memory pipe never holds a long queue of them in front of the other workgroup's operand loads
+                    if (OPT & 256) __builtin_amdgcn_s_sleep(4);
+                    if (OPT & 512) __builtin_amdgcn_s_sleep(16);
                 } else if (m < p.M && n < p.n_valid) {
                     f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * ELD + cg * 4);
                     long long c_col = n;
@@ -668,6 +774,20 @@ __global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : 1) 
     }
     if (t_ + (int)gridDim.x < nwg) __syncthreads();  // every wave has read its slab: the staging LDS may be refilled
     }
+#ifdef NOMAD_DIAG
+    if (OPT & 128) {
+        ts_[3] = wall_clock64();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the output stores have been acknowledged
+        ts_[4] = wall_clock64();
+        if (tid == 0 && blockIdx.x < kTimelineSlots) {
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned long long* o = g_timeline + (size_t)blockIdx.x * 6;
+            o[0] = ts_[0]; o[1] = ts_[1]; o[2] = ts_[2]; o[3] = ts_[3]; o[4] = ts_[4]; o[5] = hw | ((unsigned long long)xcc << 32);
+        }
+    }
+#endif
 }
 
 // persist_blocks > 0: launch at most that many workgroups, each walking several tiles (see the kernel)
@@ -723,7 +843,7 @@ __global__ __launch_bounds__(512) void gemm_f32_n48_kernel(const GemmParams p) {
 
     // LDS-DMA through buffer descriptors (see dma16_buffer): base = this tile's first row, 32-bit lane offsets
     const long long tile_row0 = row_addr(p.amap, m0 < p.M ? m0 : p.M - 1);
-    const float* const a_tile = Ag + tile_row0;
+    const float* const a_tile = uniform_ptr(Ag + tile_row0);
     int a_voff[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {

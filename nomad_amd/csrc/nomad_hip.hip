@@ -608,6 +608,19 @@ int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, in
         case 44: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 1>(p, groups, s); break;            // t33 with global_load_lds (64-bit per-lane pointers)
         case 45: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 5>(p, groups, s); break;            // t33 with the DMA issued right behind the barrier
         case 49: e = launch_gemm_n48<false>(p, groups, s); break;   // A/B: global_load_lds instead of buffer_load..lds   // N = 48 exactly (16x16x4 MFMA): the grouped pos-conv
+        // round 4: fewer, fatter waves and the skewed schedule (OPT bit 64); plain C / R operands only (nomad_diag_gemm's are)
+        case 60: e = launch_gemm_glds<256, 128, 16, 2, 2, 3, false, 13 | 16>(p, groups, s); break;        // 4 waves of 128 x 64, straight schedule
+        case 61: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, true, 13 | 16>(p, groups, s); break;         // production tile 33 without its epilogue stores
+        case 62: e = launch_gemm_glds<128, 128, 16, 2, 2, 3, false, 13 | 16>(p, groups, s); break;        // 4 waves of 64 x 64, 48 KB: 3 workgroups / CU
+        case 63: e = launch_gemm_glds<256, 128, 16, 2, 2, 3, true, 13 | 16 | 64>(p, groups, s); break;    // tile 65 without its epilogue stores
+        case 64: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 64>(p, groups, s); break;   // production tile, skewed schedule
+        case 65: e = launch_gemm_glds<256, 128, 16, 2, 2, 3, false, 13 | 16 | 64>(p, groups, s); break;   // 4 waves of 128 x 64, skewed schedule
+        case 66: e = launch_gemm_glds<128, 128, 16, 2, 2, 3, false, 13 | 16 | 64>(p, groups, s); break;   // 4 waves of 64 x 64, skewed, 3 workgroups / CU
+        case 67: e = launch_gemm_glds<128, 256, 16, 2, 2, 3, false, 13 | 16 | 64>(p, groups, s); break;   // 4 waves of 64 x 128, skewed
+        case 68: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 128>(p, groups, s); break;  // production tile + per-workgroup timeline stamps (nomad_diag_timeline)
+        case 69: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, true, 13 | 16 | 128>(p, groups, s); break;   // ... without the epilogue stores
+        case 70: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 256>(p, groups, s); break;  // production tile, output stores paced (s_sleep 4)
+        case 71: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 512>(p, groups, s); break;  // ... s_sleep 16
         case 14: e = launch_gemm<128, 128, 32, 2, 2, 1>(p, groups, s); break;            // ablations of tile 0
         case 15: e = launch_gemm<128, 128, 32, 2, 2, 2>(p, groups, s); break;
         case 16: e = launch_gemm<128, 128, 32, 2, 2, 3>(p, groups, s); break;
@@ -3641,8 +3654,8 @@ int nomad_diag_gemm(nomad_ctx* c, const float* A, const float* W, const float* b
         GemmParams p48 = dense(A, K, W, bias, R, C, M, N, K, gelu);
         return run_gemm(c, p48, 1, tile, static_cast<hipStream_t>(stream));
     }
-    if (tile < 0 || tile > 47) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile id %d", tile);
-    const int bn = kBN[tile], bk = kBK[tile];
+    if (tile < 0 || (tile > 47 && (tile < 60 || tile > 71))) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile id %d", tile);
+    const int bn = tile >= 60 ? (tile == 67 ? 256 : 128) : kBN[tile], bk = tile >= 60 ? 16 : kBK[tile];
     if (N % bn || K % bk) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: N %% %d or K %% %d != 0", bn, bk);
     GemmParams p = dense(A, K, W, bias, R, C, M, N, K, gelu);
     p.group_m = group_m;

@@ -25,6 +25,11 @@ Fixtures written (data only):
                                    (HF layers + torch L1 + torch autograd)
   tests/golden/ref_networks.npz    (``python oracle/make_golden.py refnet``) reference TripletModel / Origw2v outputs on the tiny
                                    batch (both weight sets) and on the six example clips
+  tests/golden/ref_nomad_classes.npz (``python oracle/make_golden.py refnomad``) outputs of the reference's OWN ``LossNetLayers``,
+                                   ``NomadLoss``, ``Nomad.forward`` / ``predict`` / ``get_embeddings(_csv)`` (nomad.py:82-189,
+                                   233-282), compiled from the file's ClassDef nodes without importing the module: 13 layer
+                                   outputs + loss + gradients on the hf_loss.npz inputs; DataFrames, CSV bytes (dir and csv
+                                   mode), default result paths and exception messages of ``predict`` on the example clips
   tests/golden/hf_grad_fgm.npz     (``python oracle/make_golden.py fgm``) gradients with fairseq's
                                    ``GradMultiply(features, feature_grad_mult)`` hooked onto the HF model's
                                    feature-extractor output: d loss/d estimate of the hf_loss.npz inputs at 0.1, and
@@ -304,8 +309,208 @@ def main_fgm():
              long_grad_fgm01=grads[0.1].numpy(), long_grad_fgm1=grads[1.0].numpy(), g_seed=np.int64(22))  # head: emb_w / emb_b of hf_loss.npz
 
 
+class _FairseqFullAdapter(torch.nn.Module):
+    """fairseq's ``Wav2Vec2Model.forward(wav, mask=False, features_only=True)`` result as nomad.py:226-248 reads it: ``x`` (B,T,C)
+    and ``layer_results`` - one tuple per encoder layer whose element 0 is that layer's output in fairseq's (T,B,C) layout."""
+
+    def __init__(self, hf):
+        super().__init__()
+        self.hf = hf
+
+    def forward(self, wav, mask=False, features_only=True):
+        assert mask is False and features_only is True
+        o = self.hf(wav, output_hidden_states=True)
+        return {"x": o.last_hidden_state, "layer_results": [(h.transpose(0, 1), None) for h in o.hidden_states[1:]]}
+
+
+def reference_nomad_namespace(fixed_now=None):
+    """The reference's OWN classes ``Nomad``, ``TripletModel``, ``LossNetLayers``, ``NomadLoss`` (nomad.py:35-282), compiled from
+    the ClassDef nodes of /root/reference/src/nomad_audio/nomad.py WITHOUT importing the module - so none of its import-time
+    side effects (``import fairseq`` / ``torchaudio``, the two ``urlretrieve`` downloads) run.  Build container only; no text of
+    the file is stored anywhere.  The namespace holds what the class bodies name: torch, nn, F, np, pd, cdist, tqdm, an ``os``
+    whose ``listdir`` is sorted (the reference lists directories in file-system order; a fixture needs a defined one) and a
+    ``datetime`` whose ``now()`` is fixed (the default ``results-csv/<timestamp>/`` paths)."""
+    import ast
+    import datetime as _dt
+    import pandas as pd
+    from scipy.spatial.distance import cdist
+
+    class _SortedOS:
+        def __getattr__(self, name):
+            return getattr(os, name)
+
+        @staticmethod
+        def listdir(path):
+            return sorted(os.listdir(path))
+
+    class _FixedDatetime:
+        @staticmethod
+        def now():
+            return fixed_now or _dt.datetime(2024, 1, 2, 3, 4, 5)
+
+    with open(os.path.join(REF, "src", "nomad_audio", "nomad.py")) as f:
+        tree = ast.parse(f.read())
+    wanted = ("Nomad", "TripletModel", "LossNetLayers", "NomadLoss")
+    body = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name in wanted]
+    assert sorted(n.name for n in body) == sorted(wanted)
+    ns = {"torch": torch, "nn": torch.nn, "F": torch.nn.functional, "np": np, "pd": pd, "cdist": cdist,
+          "tqdm": (lambda it: it), "os": _SortedOS(), "datetime": _FixedDatetime}
+    exec(compile(ast.Module(body=body, type_ignores=[]), "<classes of the reference nomad.py>", "exec"), ns)
+    return ns
+
+
+def reference_nomad(ns, hf, sd, loss_head=None):
+    """An instance of the reference's ``Nomad`` without its ``__init__`` (which loads fairseq checkpoints): the attributes
+    ``__init__`` sets (nomad.py:39-80) built from the same classes around the HF backbone, and ``load_processing`` - the one
+    method that needs torchaudio - replaced by a PCM-16 reader that returns what ``torchaudio.load`` returns for such a file."""
+    ssl = _FairseqFullAdapter(hf)
+    n = ns["Nomad"].__new__(ns["Nomad"])
+    n.DEVICE = "cpu"
+    n.model = ns["TripletModel"](ssl, 768, 256)
+    with torch.no_grad():
+        n.model.embedding_layer[1].weight.copy_(sd["embedding_layer.1.weight"])
+        n.model.embedding_layer[1].bias.copy_(sd["embedding_layer.1.bias"])
+    n.model.eval()
+    n.lossnet_layers = ns["LossNetLayers"](ssl, 768, 256)
+    if loss_head is not None:
+        with torch.no_grad():
+            n.lossnet_layers.embedding_layer[1].weight.copy_(loss_head[0])
+            n.lossnet_layers.embedding_layer[1].bias.copy_(loss_head[1])
+    n.nomad_loss = ns["NomadLoss"]()
+    n.nomad_loss.eval()
+
+    def load_processing(filepath, target_sr=16000, trim=False):
+        if isinstance(filepath, np.ndarray):     # nomad.py:194-195
+            filepath = filepath[0]
+        return read_wav(filepath)
+    n.load_processing = load_processing
+    return n
+
+
+def _bytes(path):
+    with open(path, "rb") as f:
+        return np.frombuffer(f.read(), dtype=np.uint8)
+
+
+def main_refnomad():
+    """tests/golden/ref_nomad_classes.npz: what the reference's own ``LossNetLayers.forward`` / ``NomadLoss.forward`` /
+    ``Nomad.forward`` (nomad.py:142-146, 233-282) return on the hf_loss.npz inputs, and what its own ``Nomad.predict`` /
+    ``get_embeddings`` / ``get_embeddings_csv`` (nomad.py:82-189) return and WRITE for the example directories - DataFrames, the
+    bytes of both CSV files in both modes, the default result paths, and every exception message of the argument checks."""
+    import tempfile
+    import pandas as pd
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    sd = seeded_state_dict(0)
+    hf = hf_model_from_state_dict(sd)
+    scale = {"v": 1.0}
+    hf.feature_extractor.register_forward_hook(
+        lambda mod, inp, out: out if scale["v"] == 1.0 else _GradMultiply.apply(out, scale["v"]))
+    old = np.load(os.path.join(GOLD, "hf_loss.npz"))
+    est, clean = torch.from_numpy(old["estimate"]), torch.from_numpy(old["clean"])
+    lw, lb = torch.from_numpy(old["emb_w"]), torch.from_numpy(old["emb_b"])
+    ns = reference_nomad_namespace()
+    n = reference_nomad(ns, hf, sd, loss_head=(lw, lb))
+    out = {}
+
+    # ---- LossNetLayers.forward, NomadLoss.forward, Nomad.forward + autograd -------------------------------------------
+    with torch.no_grad():
+        a = n.lossnet_layers(est)            # (B,1,N) -> 12 x (B,T,768) + (B,256)
+        b = n.lossnet_layers(clean)
+        loss = n.nomad_loss(b, a)
+    assert len(a) == 13 and a[0].shape == (2, 50, 768) and a[12].shape == (2, 256)
+    out["loss"] = np.float64(loss)
+    out["terms"] = np.array([float(torch.nn.functional.l1_loss(x, y)) for x, y in zip(a, b)])
+    for tag, lst in (("est", a), ("clean", b)):
+        out[f"checks_{tag}"] = np.array([[float(t.double().sum()), float(t.double().abs().sum())] for t in lst])
+        out[f"emb_{tag}"] = lst[12].numpy()
+        out[f"layers_{tag}_sample"] = np.stack([t.reshape(-1)[::97].numpy() for t in lst[:12]])
+    n.nomad_loss.only_embedding = True       # the reference's other branch indexes element 13 of a 13-element list (nomad.py:271-272)
+    try:
+        n.nomad_loss(b, a)
+        out["only_embedding_error"] = np.array("")
+    except Exception as e:  # noqa: BLE001
+        out["only_embedding_error"] = np.array(type(e).__name__)
+    n.nomad_loss.only_embedding = False
+    for mult, key in ((1.0, "grad_fgm1"), (0.1, "grad_fgm01")):
+        scale["v"] = mult
+        e = est.clone().requires_grad_(True)
+        l = n.forward(e, clean)              # Nomad.forward (nomad.py:142-146)
+        (g,) = torch.autograd.grad(l, e)
+        out[key] = g.numpy()
+        assert abs(float(l.detach()) - float(out["loss"])) < 1e-6
+    scale["v"] = 1.0
+    print("reference NomadLoss", float(out["loss"]), "hf_loss.npz", float(old["loss"]),
+          "| terms max diff", float(np.abs(out["terms"] - old["terms"]).max()),
+          "| grad max rel diff", float(np.abs(out["grad_fgm1"] - old["grad"]).max() / np.abs(old["grad"]).max()),
+          "| only_embedding ->", str(out["only_embedding_error"]))
+
+    # ---- Nomad.predict / get_embeddings / get_embeddings_csv on the example directories ------------------------------
+    nmr_dir, deg_dir = os.path.join(GOLD, "wavs", "nmr-data"), os.path.join(GOLD, "wavs", "test-data")
+    with tempfile.TemporaryDirectory() as tmp:
+        df_avg, df_dm = n.predict("dir", nmr_dir, deg_dir, results_path=tmp)
+        out["dir_avg_csv"], out["dir_scores_csv"] = _bytes(os.path.join(tmp, "nomad_avg.csv")), _bytes(os.path.join(tmp, "nomad_scores.csv"))
+        out["avg_index"], out["avg_values"] = np.array(list(df_avg.index)), df_avg["NOMAD"].to_numpy()
+        out["avg_index_name"], out["avg_columns"] = np.array(df_avg.index.name), np.array(list(df_avg.columns))
+        out["dm_index"], out["dm_columns"], out["dm_values"] = np.array(list(df_dm.index)), np.array(list(df_dm.columns)), df_dm.to_numpy()
+        emb = n.get_embeddings(deg_dir)      # the embeddings table itself (nomad.py:148-163)
+        out["emb_columns"] = np.array([str(c) for c in emb.columns])
+        out["emb_filenames_rel"] = np.array([os.path.relpath(p, GOLD) for p in emb["filename"]])
+        out["emb_values"] = emb.drop("filename", axis=1).to_numpy(dtype=np.float32)
+        # csv mode: the same files listed in two csv files, in REVERSE order (the listing order must be kept)
+        lists = {}
+        for tag, d in (("nmr", nmr_dir), ("deg", deg_dir)):
+            lists[tag] = os.path.join(tmp, f"{tag}.csv")
+            pd.DataFrame({"filename": [os.path.join(d, f) for f in sorted(os.listdir(d), reverse=True)]}).to_csv(lists[tag], index=False)
+        os.makedirs(os.path.join(tmp, "csvmode"))
+        n.predict("csv", lists["nmr"], lists["deg"], results_path=os.path.join(tmp, "csvmode"))
+        out["csv_avg_csv"] = _bytes(os.path.join(tmp, "csvmode", "nomad_avg.csv"))
+        out["csv_scores_csv"] = _bytes(os.path.join(tmp, "csvmode", "nomad_scores.csv"))
+        # default result paths (results_path=None) under the fixed clock, relative to the working directory
+        cwd = os.getcwd()
+        os.makedirs(os.path.join(tmp, "cwd"))
+        os.chdir(os.path.join(tmp, "cwd"))
+        try:
+            n.predict("dir", nmr_dir, deg_dir)
+            made = sorted(os.path.join(r, f) for r, _, fs in os.walk(".") for f in fs)
+        finally:
+            os.chdir(cwd)
+        out["default_paths"] = np.array([p[2:] for p in made])
+        out["fixed_now"] = np.array("2024-01-02 03:04:05")
+        # the argument checks (nomad.py:83-99) and the csv without a 'filename' column (nomad.py:157-158)
+        bad = os.path.join(tmp, "bad.csv")
+        pd.DataFrame({"file": ["a.wav"]}).to_csv(bad, index=False)
+        cases = {"nmr_none": ("dir", None, deg_dir), "deg_none": ("dir", nmr_dir, None),
+                 "dir_nmr_missing": ("dir", "/nonexistent/nmr", deg_dir), "dir_deg_missing": ("dir", nmr_dir, "/nonexistent/deg"),
+                 "csv_nmr_missing": ("csv", "/nonexistent/nmr.csv", lists["deg"]), "csv_deg_missing": ("csv", lists["nmr"], "/nonexistent/deg.csv"),
+                 "bad_mode": ("zip", nmr_dir, deg_dir)}
+        msgs = {}
+        for key, args in cases.items():
+            try:
+                n.predict(*args)
+                msgs[key] = None
+            except Exception as e:  # noqa: BLE001
+                msgs[key] = [type(e).__name__, str(e)]
+        try:
+            n.get_embeddings(bad)
+            msgs["csv_without_filename_column"] = None
+        except Exception as e:  # noqa: BLE001
+            msgs["csv_without_filename_column"] = [type(e).__name__, str(e)]
+    import json
+    out["messages_json"] = np.array(json.dumps(msgs))
+    np.savez(os.path.join(GOLD, "ref_nomad_classes.npz"), **out)
+    g = np.load(os.path.join(GOLD, "hf_example_wavs.npz"))
+    print("reference predict table vs hf_example_wavs.npz: max |diff|",
+          float(np.abs(out["dm_values"] - np.round(g["dist"], 3)).max()), float(np.abs(out["avg_values"] - np.round(g["mean"], 3)).max()))
+    print(out["dir_scores_csv"].tobytes().decode())
+    print(out["dir_avg_csv"].tobytes().decode())
+    print(out["default_paths"], msgs)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "fgm":
+    if len(sys.argv) > 1 and sys.argv[1] == "refnomad":
+        main_refnomad()
+    elif len(sys.argv) > 1 and sys.argv[1] == "fgm":
         main_fgm()
     elif len(sys.argv) > 1 and sys.argv[1] == "refnet":
         main_refnet()
