@@ -16,6 +16,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "dtypes.hip.h"
 
 namespace nomad {
@@ -90,7 +92,22 @@ struct GemmParams {
     // local_row * c_blk_step + b, stored only while that is < the clip's frame count (c_clip_frames for uniform
     // batches, cmap.base[c + 1] - cmap.base[c] for ragged ones).
     int c_blk_step, c_clip_frames;
+    // persistent kernel (gemm_f32_pers_kernel): exact division by amap.clip_rows and by tiles_n as mulhi + shift
+    // (fast_div_magic; magic 0 = quotient 0 / divisor 1)
+    unsigned a_clip_magic, tn_magic;
+    int a_clip_shift, tn_shift;
 };
+
+// q = n / d for 0 <= n < 2^31 as (n * magic) >> (32 + shift): magic = ceil(2^(31 + l) / d), l = ceil(log2 d), shift = l - 1
+// (Granlund & Montgomery 1994, theorem 4.2 for 31-bit dividends: the magic number fits 32 bits).  d >= 2.
+inline void fast_div_magic(unsigned d, unsigned* magic, int* shift) {
+    int l = 0;
+    while ((1ull << l) < d) ++l;
+    const unsigned long long num = 1ull << (31 + l);
+    *magic = (unsigned)((num + d - 1) / d);
+    *shift = l - 1;
+}
+__device__ __forceinline__ int fast_div(int n, unsigned magic, int shift) { return (int)(__umulhi((unsigned)n, magic) >> shift); }
 
 // (local row, frames of its clip) of logical row m under map r - see GemmParams::c_blk_step
 __device__ __forceinline__ void clip_pos(const RowMap& r, int m, int uniform_frames, int& local, int& frames) {
@@ -407,9 +424,17 @@ __device__ __forceinline__ void split_frag8(const f32x4& a, const f32x4& b, cons
 //      M = 1600 rows, one round of 64 x 64 tiles, where one wave's serial K loop IS the launch time) is ~5x shorter.
 //      Every X3 instantiation contracts k in the same order, so the tile choice changes no result bit, as in fp32.
 template <int BM, int BN, int BK, int WM, int WN, int STAGES = 2, bool NOEPI = false, int OPT = 0, bool X3 = false>
-__global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : (((OPT & 16) && WM * WN == 4 && BM * BN == 256 * 128) ? 2 : 1)) void gemm_f32_glds_kernel(const GemmParams p) {   // OPT bit 16: two 8-wave workgroups per CU = 128 VGPRs (8 values computed in the prologue for the epilogue are spilled over the K loop, none inside it)
+__global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : (((OPT & 16) && WM * WN == 4 && BM * BN == 256 * 128) ? (BK == 8 ? 3 : 2) : 1)) void gemm_f32_glds_kernel(const GemmParams p) {   // OPT bit 16: two 8-wave workgroups per CU = 128 VGPRs (8 values computed in the prologue for the epilogue are spilled over the K loop, none inside it)
     using Cfg = GldsCfg<BM, BN, BK, WM, WN, STAGES>;
     constexpr int TM = Cfg::TM, TN = Cfg::TN, NT = Cfg::THREADS, KC = Cfg::KC, RB = Cfg::RB;
+    // OPT bit 1024 (round 4): TRANSPOSED accumulators + direct epilogue.  The two operands of v_mfma_f32_32x32x2_f32 have the same
+    // lane layout, so passing W as the first and A as the second operand leaves D^T in the same registers: a lane then owns ONE
+    // output row (lane & 31) and, per accumulator, four runs of four CONSECUTIVE columns - 16-byte stores straight from the
+    // accumulators, no LDS slab, no barrier between the K loop and the stores, no per-store address arithmetic (buffer
+    // descriptors: per-lane offset + scalar row-block offset + immediate).  Products and their order per output element are
+    // unchanged (a*w == w*a): bit-identical results.  Plain C / R matrices only (with bit 16).
+    constexpr bool TR = (OPT & 1024) != 0;
+    static_assert(!TR || ((OPT & 16) && !X3 && !(OPT & 32)), "transposed accumulators: plain scoring epilogue only");
     static_assert(BK == 8 || BK == 16 || BK == 32, "swizzle is written for 32-, 64- and 128-B rows");
     static_assert(BM * KC % NT == 0 && BN * KC % NT == 0 && TM >= 1 && TN >= 1, "bad tile");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -430,13 +455,41 @@ __global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : (((
     // Persistent launch (gridDim.x < nwg): a workgroup walks tiles blockIdx.x, + gridDim.x, ...; its output stores
     // drain under the next tile's prologue instead of holding the wave slots until they are acknowledged.
     for (int t_ = blockIdx.x; t_ < nwg; t_ += gridDim.x) {
+    // OPT bit 4096 (round 4): the address set-up and the epilogue run at raised wave priority.  The timeline probe shows the
+    // set-up of a workgroup that starts next to a peer in its K loop taking 13 us instead of 2 (its scalar / vector instructions
+    // queue behind the peer's MFMA stream), and the lone peer fills only ~3/4 of the matrix pipe meanwhile.
+    if (OPT & 4096) __builtin_amdgcn_s_setprio(3);
+    // OPT bit 16384 (round 4): LEAN set-up.  Vector instructions of a freshly launched workgroup are starved by the older
+    // peer workgroup's MFMA stream (tools/micro/issue_starve.hip: a dependent v_add chain next to two MFMA-streaming waves on
+    // its SIMD makes NO progress until they stop - issue is oldest-wave-first, s_setprio does not change it - while scalar
+    // ALU and scalar loads run at full speed), and the general set-up is ~250 vector instructions, most of them the
+    // float-reciprocal sequences of four integer divisions.  Lean: every division is mulhi + shift with magic numbers from the
+    // host (fast_div), the tile coordinates and bases stay on the scalar unit, ~60 vector instructions remain.  Uniform clip
+    // maps only (no ragged prefix sums), tiles walked n-fastest (group_m == 0); the caller checks and fills the magic numbers.
+    constexpr bool LEAN = (OPT & 16384) != 0;
+    static_assert(!LEAN || (OPT & 4), "lean set-up: buffer-descriptor DMA only");
     const int wg = xcd_remap(t_, nwg);
     int tile_m, tile_n;
-    tile_coords(wg, p.tiles_m, p.tiles_n, p.group_m, tile_m, tile_n);
+    if (LEAN) {
+        tile_m = p.tn_magic ? fast_div(wg, p.tn_magic, p.tn_shift) : wg;
+        tile_n = wg - tile_m * p.tiles_n;
+    } else {
+        tile_coords(wg, p.tiles_m, p.tiles_n, p.group_m, tile_m, tile_n);
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    auto row_addr_lean = [&](int m) -> long long {
+        const int c = p.a_clip_magic ? fast_div(m, p.a_clip_magic, p.a_clip_shift) : 0;
+        return p.amap.off + (long long)c * p.amap.clip_stride + (long long)(m - c * p.amap.clip_rows) * p.amap.ld;
+    };
     const int grp = blockIdx.y;
     const float* Ag = p.A + grp * p.a_goff;
     const float* Wg = p.W + grp * p.w_goff;
+#ifdef NOMAD_DIAG
+    if ((OPT & 128) && (OPT & 8192)) {   // set-up detail: kernel arguments read, tile coordinates known
+        asm volatile("" :: "s"(m0), "s"(n0));
+        ts_[1] = wall_clock64();
+    }
+#endif
 
     // Per-lane DMA sources; LDS chunk id = tid + i*NT is linear in the lane within each wave-instruction.
     // OPT & 4: buffer_load ... lds - an SGPR resource descriptor per operand (base = this tile's first row, so the
@@ -445,14 +498,19 @@ __global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : (((
     const float* a_src[Cfg::A_CHUNKS];
     const float* b_src[Cfg::B_CHUNKS];
     int a_voff[Cfg::A_CHUNKS], b_voff[Cfg::B_CHUNKS];
-    const long long tile_row0 = (OPT & 4) ? row_addr(p.amap, m0 < p.M ? m0 : p.M - 1) : 0;
+    const long long tile_row0 = LEAN ? row_addr_lean(m0 < p.M ? m0 : p.M - 1) : (OPT & 4) ? row_addr(p.amap, m0 < p.M ? m0 : p.M - 1) : 0;
 #pragma unroll
     for (int i = 0; i < Cfg::A_CHUNKS; ++i) {
         const int id = tid + i * NT, row = id / KC, pc = id - row * KC;
         int m = m0 + row;
         m = m < p.M ? m : p.M - 1;
-        a_src[i] = Ag + row_addr(p.amap, m) + ((pc ^ ((row / RB) % KC)) * 4);
-        a_voff[i] = (int)((row_addr(p.amap, m) - tile_row0 + ((pc ^ ((row / RB) % KC)) * 4)) * 4);
+        if (LEAN) {
+            a_src[i] = nullptr;
+            a_voff[i] = (int)((row_addr_lean(m) - tile_row0 + ((pc ^ ((row / RB) % KC)) * 4)) * 4);
+        } else {
+            a_src[i] = Ag + row_addr(p.amap, m) + ((pc ^ ((row / RB) % KC)) * 4);
+            a_voff[i] = (int)((row_addr(p.amap, m) - tile_row0 + ((pc ^ ((row / RB) % KC)) * 4)) * 4);
+        }
     }
 #pragma unroll
     for (int i = 0; i < Cfg::B_CHUNKS; ++i) {
@@ -462,6 +520,12 @@ __global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : (((
     }
     const float* const a_tile = (OPT & 4) ? uniform_ptr(Ag + tile_row0) : Ag + tile_row0;
     const float* const b_tile = (OPT & 4) ? uniform_ptr(Wg + (long long)n0 * p.ldw) : Wg + (long long)n0 * p.ldw;
+#ifdef NOMAD_DIAG
+    if ((OPT & 128) && (OPT & 8192)) {   // set-up detail: per-lane offsets and tile bases done
+        asm volatile("" :: "v"(a_voff[0]), "v"(b_voff[0]), "s"(a_tile), "s"(b_tile));
+        ts_[2] = wall_clock64();
+    }
+#endif
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -501,8 +565,13 @@ __global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : (((
         }                                                                                                \
     }
 
+#ifdef NOMAD_DIAG
+    if ((OPT & 128) && (OPT & 2048)) ts_[1] = wall_clock64();   // prologue detail: address set-up done, first DMA about to be issued
+    if ((OPT & 128) && (OPT & 8192)) ts_[3] = wall_clock64();   // set-up detail: accumulators zeroed, first DMA about to be issued
+#endif
     NOMAD_GLDS_TILE(0, 0)
     if (STAGES == 3 && nk > 1) NOMAD_GLDS_TILE(1, 1)
+    if (OPT & 4096) __builtin_amdgcn_s_setprio(0);
 
     // fragment read offsets (floats): row R, logical chunk 2*kq + h -> physical chunk ^ swz(R)
     const int frag_row = lane & 31, h = lane >> 5;
@@ -551,7 +620,8 @@ __global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : (((
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[buf][i][c], bf[buf][j][c], acc[i][j], 0, 0, 0);
+                        acc[i][j] = TR ? __builtin_amdgcn_mfma_f32_32x32x2f32(bf[buf][j][c], af[buf][i][c], acc[i][j], 0, 0, 0)
+                                       : __builtin_amdgcn_mfma_f32_32x32x2f32(af[buf][i][c], bf[buf][j][c], acc[i][j], 0, 0, 0);
         };
         rd(0, 0, 0);
         for (int kt = 0; kt + 1 < nk; ++kt) {
@@ -594,10 +664,13 @@ __global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : (((
             // this wave's loads of tile kt are done once at most one newer tile (kt+1) is still outstanding
             if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::A_CHUNKS + Cfg::B_CHUNKS) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef NOMAD_DIAG
+            if ((OPT & 128) && (OPT & 2048) && kt == 0) ts_[2] = wall_clock64();   // prologue detail: this wave's share of tile 0 has landed
+#endif
             __builtin_amdgcn_s_barrier();  // every wave's share of tile kt has landed; buffer of tile kt-1 is free
             asm volatile("" ::: "memory");
 #ifdef NOMAD_DIAG
-            if ((OPT & 128) && kt == 0) ts_[1] = wall_clock64();
+            if ((OPT & 128) && kt == 0) ts_[(OPT & 8192) ? 4 : (OPT & 2048) ? 3 : 1] = wall_clock64();
 #endif
         }
         const int nxt = kt + STAGES - 1;
@@ -646,16 +719,75 @@ __global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : (((
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][c], bf[j][c], acc[i][j], 0, 0, 0);
+                        acc[i][j] = TR ? __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][c], af[i][c], acc[i][j], 0, 0, 0)
+                                       : __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][c], bf[j][c], acc[i][j], 0, 0, 0);
             if (OPT & 2) __builtin_amdgcn_s_setprio(0);
         }
         cur = cur + 1 == STAGES ? 0 : cur + 1;
     }
 #undef NOMAD_GLDS_TILE
 #ifdef NOMAD_DIAG
-    if (OPT & 128) ts_[2] = wall_clock64();
+    if ((OPT & 128) && !(OPT & 8192)) ts_[(OPT & 2048) ? 4 : 2] = wall_clock64();
 #endif
+    if (OPT & 4096) __builtin_amdgcn_s_setprio(3);
 
+    if constexpr (TR) {
+        // ---- direct epilogue from transposed accumulators (see TR above) ----
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));   // keep the per-lane offsets below out of the K loop's live ranges
+        const int mw = m0 + wm * Cfg::WTM, nw = n0 + wn * Cfg::WTN;   // this wave's first output row / column (uniform)
+        const int mrow = lane_e & 31, hh = lane_e >> 5;
+        auto clamp_bytes = [](long long v) { return (unsigned)(v < 0 ? 0 : (v > (1ll << 30) ? (1ll << 30) : v)); };
+        // rows >= M lie beyond num_records and are dropped (stores) / read as zero (loads) by the buffer addressing itself
+        const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(uniform_ptr(p.C + grp * p.c_goff + p.cmap.off + (long long)mw * p.cmap.ld + nw)), 0,
+            clamp_bytes((long long)(p.M - mw) * p.cmap.ld * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(uniform_ptr(p.R ? p.R + grp * p.r_goff + p.rmap.off + (long long)mw * p.rmap.ld + nw : p.C)), 0,
+            p.R ? clamp_bytes((long long)(p.M - mw) * p.rmap.ld * 4) : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(uniform_ptr(p.bias ? p.bias + grp * p.bias_goff + nw : p.C)), 0, p.bias ? (unsigned)(Cfg::WTN * 4) : 0u, 0x00020000);
+        const int c_voff = (mrow * p.cmap.ld + 4 * hh) * 4, r_voff = (mrow * p.rmap.ld + 4 * hh) * 4, b_voff = 16 * hh;
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        // steps (j, i), the residual of step s + 1 loaded before step s is computed: 2 x 16 registers whatever TM is
+        f32x4 rres[2][4];
+        auto load_r = [&](int buf, int j, int i) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                rres[buf][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, r_voff + i * 32 * p.rmap.ld * 4 + (j * 32 + 8 * g) * 4, 0, 0));
+        };
+        if (p.R) load_r(0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            f32x4 b4[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)   // a zero-length descriptor (no bias) reads as 0.0f
+                b4[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, b_voff + (j * 32 + 8 * g) * 4, 0, 0));
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int st = j * TM + i;
+                if (p.R && st + 1 < TN * TM) load_r((st + 1) & 1, (st + 1) / TM, (st + 1) % TM);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + b4[g][e];
+                    if (p.gelu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                    }
+                    if (p.R) v += rres[st & 1][g];
+                    // The row-block offset goes into the VGPR offset, NOT the scalar offset: with an SGPR soffset the compiler's
+                    // hazard recogniser (LLVM GCNHazardRecognizer, "VMEM store of more than 8 bytes followed by a VALU write of
+                    // the data registers") emits no wait state, and on gfx950 the v_add of the next chunk, issued right behind
+                    // buffer_store_dwordx4 ... s53 offen, then corrupted element 0 of lanes 12-15 / 28-31 / 44-47 / 60-63
+                    // (measured: tools/dbg_tr.py, gpurun_out/r4d/dbg_tr.txt)
+                    if (!NOEPI || p.M < 0)   // (NOEPI, a timing probe: the never-true condition keeps the arithmetic alive)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rc, c_voff + i * 32 * p.cmap.ld * 4 + (j * 32 + 8 * g) * 4, 0, 0);
+                }
+            }
+        }
+    } else {
     // Epilogue through LDS: an accumulator holds one output column per lane (4-byte stores, 64 per lane and
     // tile).  Each wave parks a 32-row slab (acc + bias) in LDS, then every lane owns 4 consecutive columns of
     // one row and does the rest - pre-activation copy, GELU, GELU' factor, residual - on 16-byte vectors:
@@ -772,13 +904,14 @@ __global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : (((
             }
         }
     }
+    }   // !TR
     if (t_ + (int)gridDim.x < nwg) __syncthreads();  // every wave has read its slab: the staging LDS may be refilled
     }
 #ifdef NOMAD_DIAG
     if (OPT & 128) {
-        ts_[3] = wall_clock64();
+        if (!(OPT & (2048 | 8192))) ts_[3] = wall_clock64();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the output stores have been acknowledged
-        ts_[4] = wall_clock64();
+        if (!(OPT & (2048 | 8192))) ts_[4] = wall_clock64();
         if (tid == 0 && blockIdx.x < kTimelineSlots) {
             unsigned hw, xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -796,6 +929,12 @@ inline hipError_t launch_gemm_glds(GemmParams p, int groups, hipStream_t s, int 
     using Cfg = GldsCfg<BM, BN, BK, WM, WN, STAGES>;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = p.N / BN;
+    if (OPT & 16384) {   // lean set-up: division magic (the caller has checked: no ragged A map, group_m == 0)
+        p.a_clip_magic = p.tn_magic = 0;
+        p.a_clip_shift = p.tn_shift = 0;
+        if (p.amap.clip_rows < p.M) fast_div_magic((unsigned)p.amap.clip_rows, &p.a_clip_magic, &p.a_clip_shift);
+        if (p.tiles_n > 1) fast_div_magic((unsigned)p.tiles_n, &p.tn_magic, &p.tn_shift);
+    }
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_glds_kernel<BM, BN, BK, WM, WN, STAGES, NOEPI, OPT, X3>),
@@ -808,6 +947,231 @@ inline hipError_t launch_gemm_glds(GemmParams p, int groups, hipStream_t s, int 
     dim3 grid(gx, groups);
     hipLaunchKernelGGL((gemm_f32_glds_kernel<BM, BN, BK, WM, WN, STAGES, NOEPI, OPT, X3>), grid, dim3(Cfg::THREADS),
                        Cfg::LDS_BYTES + extra_lds, s, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Persistent 256 x 128 kernel (round 4).  The per-workgroup timeline of the kernel above (tools/gemm_timeline_f32.py,
+// profiles/r04_gemm_timeline_f32.txt) shows a QKV tile spending 176 us in its K loop and 46 us around it - 13 us of address
+// set-up that crawls next to a peer workgroup's MFMA stream, 9 us until the first K tile has landed and the first barrier is
+// passed, 19 us of LDS-staged epilogue, 5 us until the slot is taken again - and the lone peer fills only ~3/4 of the matrix
+// pipe meanwhile: two workgroups are inside their K loops for 58 % of a CU's time.  Here a workgroup stays resident and walks
+// tiles blockIdx.x, + gridDim.x, ... (two workgroups per CU):
+//  * the LDS-DMA stream never drains: while K tiles nk-2 and nk-1 of an output tile are multiplied, K tiles 0 and 1 of the NEXT
+//    output tile are staged (its three per-lane offsets overwrite the current tile's after their last use, its bases are a few
+//    scalar instructions with precomputed division magic), so the next K loop starts on data that is already in LDS;
+//  * the epilogue is the direct one from transposed accumulators (OPT bit 1024 above): no LDS, so it cannot collide with the
+//    staged K tiles, no barrier, and its vector-memory operations are accounted for in the counted vmcnt of the next two K tiles;
+//  * nothing is recomputed per tile but ~40 scalar and ~20 vector instructions.
+// Same tile, same K loop, same contraction order: bit-identical to every other fp32 instantiation.  Plain C / R matrices,
+// one group, contiguous K (the caller checks); A may be a per-clip RowMap (the conv stack).
+template <bool NOEPI = false, int OPT = 0>
+__global__ __launch_bounds__(512, 4) void gemm_f32_pers_kernel(const GemmParams p) {
+    constexpr int BM = 256, BN = 128, BK = 16, WN = 2, ST = 3, NT = 512, KC = 4, RB = 4, WTM = 64, WTN = 64, TM = 2, TN = 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                  // [ST][BM][BK]
+    float* Bs = smem + ST * BM * BK;   // [ST][BN][BK]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int nwg = p.tiles_m * p.tiles_n, nk = p.K / BK;
+
+    // tile-independent per-lane DMA geometry: LDS chunk id = tid + i * NT, source chunk swizzled (see the kernel above)
+    int a_rowl[2], a_sw[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int id = tid + i * NT, row = id / KC, pc = id - row * KC;
+        a_rowl[i] = row;
+        a_sw[i] = (pc ^ ((row / RB) % KC)) * 4;
+    }
+    const int b_voff = [&] {
+        const int row = tid / KC, pc = tid - row * KC;
+        return (int)(((long long)row * p.ldw + ((pc ^ ((row / RB) % KC)) * 4)) * 4);
+    }();
+    // fragment read offsets
+    const int frag_row = lane & 31, h = lane >> 5;
+    const int swz = (frag_row / RB) % KC;
+    int koff[2];
+#pragma unroll
+    for (int kq = 0; kq < 2; ++kq) koff[kq] = ((kq * 2 + h) ^ swz) * 4;
+    const int a_row_off = (wm * WTM + frag_row) * BK, b_row_off = (wn * WTN + frag_row) * BK;
+
+    auto row_addr_fast = [&](int m) -> long long {
+        const int c = p.a_clip_magic ? fast_div(m, p.a_clip_magic, p.a_clip_shift) : 0;
+        return p.amap.off + (long long)c * p.amap.clip_stride + (long long)(m - c * p.amap.clip_rows) * p.amap.ld;
+    };
+    // tile t -> (m0, n0), scalar tile bases, per-lane A offsets
+    auto setup = [&](int t, int& m0_, int& n0_, const float*& at, const float*& bt, int (&av)[2]) {
+        const int wg = xcd_remap(t, nwg);
+        const int tm = p.tn_magic ? fast_div(wg, p.tn_magic, p.tn_shift) : wg;
+        m0_ = tm * BM;
+        n0_ = (wg - tm * p.tiles_n) * BN;
+        const long long row0 = row_addr_fast(m0_);
+        at = uniform_ptr(p.A + row0);
+        bt = uniform_ptr(p.W + (long long)n0_ * p.ldw);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int m = m0_ + a_rowl[i];
+            m = m < p.M ? m : p.M - 1;
+            av[i] = (int)((row_addr_fast(m) - row0 + a_sw[i]) * 4);
+        }
+    };
+    auto issue = [&](const float* at, const float* bt, const int (&av)[2], int k_off_bytes, int stage) {
+        float* as_ = As + stage * BM * BK + wave * 256;
+        float* bs_ = Bs + stage * BN * BK + wave * 256;
+        dma16_buffer(at, (lptr_t)(as_), av[0], k_off_bytes);
+        dma16_buffer(at, (lptr_t)(as_ + NT * 4), av[1], k_off_bytes);
+        dma16_buffer(bt, (lptr_t)(bs_), b_voff, k_off_bytes);
+    };
+
+    // Two cursors walk the same sequence of (output tile, K tile): the LOAD side (a_tile / b_tile / a_voff / k_ld) runs two K
+    // tiles ahead of the multiply side and crosses into the next output tile first - its bases and per-lane offsets are
+    // recomputed in place right after the current tile's last K tile has been issued.  The last output tile of a workgroup
+    // "crosses" into itself: two K tiles are staged that nobody reads (no has-next special case anywhere in the loop).
+    int tile = blockIdx.x;
+    int m0, n0, m0_ld, n0_ld, a_voff[2];
+    const float *a_tile, *b_tile;
+    setup(tile, m0_ld, n0_ld, a_tile, b_tile, a_voff);
+    m0 = m0_ld;
+    n0 = n0_ld;
+    int k_ld = 0;         // byte offset of the next K tile to stage, within the load side's output tile
+    const int k_bytes = p.K * 4;
+    issue(a_tile, b_tile, a_voff, k_ld, 0);
+    k_ld += BK * 4;
+    issue(a_tile, b_tile, a_voff, k_ld, 1);
+    k_ld += BK * 4;
+    int cur = 0;          // LDS stage of the K tile being multiplied
+    int fresh = 2;        // K tiles to go before an epilogue's vector-memory operations no longer sit between the DMA groups
+    const bool has_r = p.R != nullptr;
+    while (true) {
+        const bool has_next = tile + (int)gridDim.x < nwg;
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int kt = 0; kt < nk; ++kt) {
+            // this wave's share of K tile kt has landed once only NEWER vector-memory operations are outstanding: the next K
+            // tile's three DMA instructions and, for the first two K tiles after an epilogue, that epilogue's 8 bias loads, 16
+            // stores and (with a residual) 16 residual loads, which were issued between the two DMA groups
+            if (fresh < 2) {
+                if (NOEPI) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+                else if (has_r) asm volatile("s_waitcnt vmcnt(43)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(27)" ::: "memory");
+                ++fresh;
+            } else {
+                asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            int nb = cur + 2;
+            nb = nb >= ST ? nb - ST : nb;
+            const float* as = As + cur * BM * BK + a_row_off;
+            const float* bs = Bs + cur * BN * BK + b_row_off;
+#pragma unroll
+            for (int kq = 0; kq < 2; ++kq) {
+                if (kq == 1) {   // stage the K tile two ahead in the stream, behind the first k-step's MFMAs
+                    __builtin_amdgcn_sched_barrier(0);   // (unconditional here: without the fence the compiler hoists the DMA to the barrier)
+                    issue(a_tile, b_tile, a_voff, k_ld, nb);
+                    __builtin_amdgcn_sched_barrier(0);
+                    k_ld += BK * 4;
+                    if (k_ld == k_bytes) {   // the load side crosses into the next output tile
+                        k_ld = 0;
+                        setup(has_next ? tile + (int)gridDim.x : tile, m0_ld, n0_ld, a_tile, b_tile, a_voff);
+                    }
+                }
+                f32x4 af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * BK + koff[kq]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * BK + koff[kq]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][c], af[i][c], acc[i][j], 0, 0, 0);   // transposed: D^T
+            }
+            cur = cur + 1 == ST ? 0 : cur + 1;
+        }
+        fresh = 0;
+        // ---- direct epilogue from transposed accumulators (as OPT bit 1024 of the kernel above) ----
+        {
+            int lane_e = lane;
+            asm volatile("" : "+v"(lane_e));
+            const int mw = m0 + wm * WTM, nw = n0 + wn * WTN;
+            const int mrow = lane_e & 31, hh = lane_e >> 5;
+            auto clamp_bytes = [](long long v) { return (unsigned)(v < 0 ? 0 : (v > (1ll << 30) ? (1ll << 30) : v)); };
+            const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(uniform_ptr(p.C + p.cmap.off + (long long)mw * p.cmap.ld + nw)), 0, clamp_bytes((long long)(p.M - mw) * p.cmap.ld * 4), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(uniform_ptr(has_r ? p.R + p.rmap.off + (long long)mw * p.rmap.ld + nw : p.C)), 0,
+                has_r ? clamp_bytes((long long)(p.M - mw) * p.rmap.ld * 4) : 0u, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(uniform_ptr(p.bias ? p.bias + nw : p.C)), 0, p.bias ? (unsigned)(WTN * 4) : 0u, 0x00020000);
+            const int c_voff = (mrow * p.cmap.ld + 4 * hh) * 4, r_voff = (mrow * p.rmap.ld + 4 * hh) * 4, b_off = 16 * hh;
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                f32x4 rres[TM][4], b4[4];
+                if (has_r) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            rres[i][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, r_voff + i * 32 * p.rmap.ld * 4 + (j * 32 + 8 * g) * 4, 0, 0));
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) b4[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, b_off + (j * 32 + 8 * g) * 4, 0, 0));
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + b4[g][e];
+                        if (p.gelu) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                        }
+                        if (has_r) v += rres[i][g];
+                        // (VGPR offset only - see the store-data hazard note at OPT bit 1024)
+                        if (!NOEPI || p.M < 0)   // (NOEPI, a timing probe: the never-true condition keeps the arithmetic alive)
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rc, c_voff + i * 32 * p.cmap.ld * 4 + (j * 32 + 8 * g) * 4, 0, 0);
+                    }
+            }
+        }
+        if (!has_next) break;
+        tile += (int)gridDim.x;
+        m0 = m0_ld;
+        n0 = n0_ld;
+    }
+}
+
+// workgroups: two per CU (the kernel's residency), never more than there are tiles
+inline hipError_t launch_gemm_pers(GemmParams p, hipStream_t s, int num_cus, bool noepi = false, bool one_tile_each = false) {
+    p.tiles_m = (p.M + 255) / 256;
+    p.tiles_n = p.N / 128;
+    p.a_clip_magic = p.tn_magic = 0;
+    p.a_clip_shift = p.tn_shift = 0;
+    if (p.amap.clip_rows < p.M) fast_div_magic((unsigned)p.amap.clip_rows, &p.a_clip_magic, &p.a_clip_shift);
+    if (p.tiles_n > 1) fast_div_magic((unsigned)p.tiles_n, &p.tn_magic, &p.tn_shift);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_pers_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_pers_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const long long nwg = (long long)p.tiles_m * p.tiles_n;
+    // one_tile_each: the same kernel launched with one workgroup per tile - no tile loop, only its lean set-up and direct epilogue
+    const int grid = (int)((one_tile_each || nwg < 2ll * num_cus) ? nwg : 2ll * num_cus);
+    constexpr int lds = 3 * (256 + 128) * 16 * 4;
+    if (noepi) hipLaunchKernelGGL(gemm_f32_pers_kernel<true>, dim3(grid), dim3(512), lds, s, p);
+    else hipLaunchKernelGGL(gemm_f32_pers_kernel<false>, dim3(grid), dim3(512), lds, s, p);
     return hipGetLastError();
 }
 

@@ -299,6 +299,7 @@ ParamOffsets make_param_offsets() {
 
 struct nomad_ctx {
     int device = 0;
+    int num_cus = 256;   // multiProcessorCount (the persistent GEMM launches two workgroups per CU)
     bool keep = false;
     // repacked weights (device)
     float* conv0_w = nullptr;            // [512][10]
@@ -549,6 +550,30 @@ int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, in
     if (plain_cr && (tile == 33 || tile == 31 || tile == 37 || tile == 34 || tile == 20)) {
         constexpr int P = 16, T = 16 | 32;   // plain epilogue; + the training side operands (Upre / DG)
         const bool tr = p.Upre || p.DG;
+        // Round 4 (gemm_f32.hip.h OPT bits 16384 / 64 / 1024; profiles/r04_gemm_f32_variants.txt): the scoring GEMMs on uniform
+        // clip maps take the lean set-up (magic-number divisions on the scalar unit), the 256 x 128 tile also the skewed K
+        // loop, and GEMMs without a residual the direct epilogue from transposed accumulators.  All bit-identical to the plain
+        // instantiations.  NOMAD_F32_LEAN=0 / NOMAD_F32_DIRECT_EPI=0 / NOMAD_F32_SKEW=0 switch them off (A/B runs).
+        static const int variants = [] {
+            auto on = [](const char* name) { const char* v = getenv(name); return !v || atoi(v) != 0; };
+            return (on("NOMAD_F32_LEAN") ? 1 : 0) | (on("NOMAD_F32_DIRECT_EPI") ? 2 : 0) | (on("NOMAD_F32_SKEW") ? 4 : 0);
+        }();
+        const bool lean = (variants & 1) && !tr && !p.amap.pref && p.group_m == 0 && p.kchunk >= p.K;
+        const bool direct = lean && (variants & 2) && !p.R && p.n_valid == p.N;
+        const bool skew = lean && (variants & 4);
+        constexpr int L = 16384, D = 1024, S = 64;
+        if (lean && tile == 33) {
+            e = direct ? (skew ? launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | P | L | S | D>(p, groups, s) : launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | P | L | D>(p, groups, s))
+                       : (skew ? launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | P | L | S>(p, groups, s) : launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | P | L>(p, groups, s));
+            if (e != hipSuccess) return fail(NOMAD_ERR_HIP, "gemm launch: %s", hipGetErrorString(e));
+            return 0;
+        }
+        if (lean && tile == 31) {
+            e = direct ? launch_gemm_glds<128, 128, 32, 4, 2, 2, false, 12 | P | L | D>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 4, 2>::LDS_BYTES))
+                       : launch_gemm_glds<128, 128, 32, 4, 2, 2, false, 12 | P | L>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 4, 2>::LDS_BYTES));
+            if (e != hipSuccess) return fail(NOMAD_ERR_HIP, "gemm launch: %s", hipGetErrorString(e));
+            return 0;
+        }
         switch (tile) {
             case 33: e = tr ? launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | T>(p, groups, s) : launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | P>(p, groups, s); break;
             case 31: e = tr ? launch_gemm_glds<128, 128, 32, 4, 2, 2, false, 12 | T>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 4, 2>::LDS_BYTES))
@@ -621,6 +646,17 @@ int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, in
         case 69: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, true, 13 | 16 | 128>(p, groups, s); break;   // ... without the epilogue stores
         case 70: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 256>(p, groups, s); break;  // production tile, output stores paced (s_sleep 4)
         case 71: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 512>(p, groups, s); break;  // ... s_sleep 16
+        case 72: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 1024>(p, groups, s); break;        // transposed accumulators + direct epilogue
+        case 73: e = launch_gemm_glds<128, 128, 32, 4, 2, 2, false, 12 | 16 | 1024>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 4, 2>::LDS_BYTES)); break;
+        case 74: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, true, 13 | 16 | 1024>(p, groups, s); break;         // ... without its stores
+        case 75: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 1024 | 128>(p, groups, s); break;  // ... with timeline stamps
+        case 76: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 128 | 2048>(p, groups, s); break;  // production tile, prologue-detail stamps
+        case 77: e = launch_gemm_glds<256, 128, 16, 2, 2, 3, false, 13 | 16 | 64 | 1024>(p, groups, s); break;   // 4 waves of 128 x 64, skewed, direct epilogue
+        case 78: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 4096>(p, groups, s); break;          // production tile, set-up and epilogue at raised priority
+        case 79: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 1024 | 4096>(p, groups, s); break;   // direct epilogue + raised priority
+        case 80: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 1024 | 4096 | 128>(p, groups, s); break;   // ... with timeline stamps
+        case 81: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 4096 | 128 | 2048>(p, groups, s); break;   // production + raised priority, prologue detail
+        case 86: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 128 | 8192>(p, groups, s); break;   // production, set-up detail stamps
         case 14: e = launch_gemm<128, 128, 32, 2, 2, 1>(p, groups, s); break;            // ablations of tile 0
         case 15: e = launch_gemm<128, 128, 32, 2, 2, 2>(p, groups, s); break;
         case 16: e = launch_gemm<128, 128, 32, 2, 2, 3>(p, groups, s); break;
@@ -667,6 +703,21 @@ int pick_tile(int M, int N, int K) {
     const long long tiles256 = (long long)((M + 255) / 256) * (N / 128);
     // 1500, not 2048: a half of the bench batch (Engine.embed runs the batch as two halves on two streams) has 1800 tiles in
     // QKV and 1600 in conv4 - the 256x128 kernel there is worth +0.5 % of the step (2230-2235 vs 2219-2222 clips/s, alternating)
+    // 256 x 128 or 128 x 128 (round 4)?  Two workgroups share a CU and a lone one runs about twice as fast, so what a launch costs
+    // is the largest number of tiles any CU gets: ceil(tiles / CUs) big tiles against ceil(2 tiles / CUs) half-size ones, the latter
+    // ~3 % dearer per flop (more operand traffic per MFMA).  conv5 at the bench batch is 1596 big tiles = 6.2 per CU -> 7, or 3192
+    // small ones = 12.5 -> 13 halves = 6.5: 135 vs 127 TFLOP/s measured (profiles/r04_gemm_f32_variants.txt).  NOMAD_F32_QUANT_TILE=0:
+    // the round-3 rule.
+    static const bool quant = [] {
+        const char* e = getenv("NOMAD_F32_QUANT_TILE");
+        return !e || atoi(e) != 0;
+    }();
+    if (quant && N % 128 == 0 && tiles256 >= 1024) {
+        const long long per_cu_256 = (tiles256 + 255) / 256;
+        const long long tiles128 = (long long)((M + 127) / 128) * (N / 128);
+        const double cost128 = (double)((tiles128 + 255) / 256) * 0.5 * 1.03;
+        return cost128 < (double)per_cu_256 ? 31 : 33;
+    }
     if (N % 128 == 0 && tiles256 >= 1500) return 33;
     if (N % 128 == 0 && tiles256 >= 512 && (K >= 2048 || K <= 512)) return 33;
     // less than one round of 256x128 tiles (batch 1 .. a few dozen short clips, config C4): 64x64 tiles keep the
@@ -833,6 +884,7 @@ int nomad_create(nomad_ctx** out, int device, const nomad_weights* w) {
     HIP_TRY(hipSetDevice(device));
     nomad_ctx* c = new nomad_ctx();
     c->device = device;
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     int rc = 0;
     auto up = [&](const float* h, size_t n, float** d) {
         if (rc == 0) rc = upload(c, h, n, d);
@@ -3654,8 +3706,39 @@ int nomad_diag_gemm(nomad_ctx* c, const float* A, const float* W, const float* b
         GemmParams p48 = dense(A, K, W, bias, R, C, M, N, K, gelu);
         return run_gemm(c, p48, 1, tile, static_cast<hipStream_t>(stream));
     }
-    if (tile < 0 || (tile > 47 && (tile < 60 || tile > 71))) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile id %d", tile);
-    const int bn = tile >= 60 ? (tile == 67 ? 256 : 128) : kBN[tile], bk = tile >= 60 ? 16 : kBK[tile];
+    if (tile >= 88 && tile <= 93) {   // lean set-up (OPT bit 16384) on: 88 production tile, 89 + direct epilogue, 90 + skewed + direct, 91 + skewed (LDS epilogue), 92 128x128x32 tile, 93 128x128x32 + direct
+        if (N % 128 || K % 32) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: N %% 128 or K %% 32 != 0");
+        GemmParams pp = dense(A, K, W, bias, R, C, M, N, K, gelu);
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        Scope sc(c, st, NOMAD_K_GEMM, 2.0 * M * (double)N * K, NOMAD_K_GEMM_BIG);
+        constexpr int L = 16384;
+        switch (tile) {
+            case 88: HIP_TRY((launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | L>(pp, 1, st))); break;
+            case 89: HIP_TRY((launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 1024 | L>(pp, 1, st))); break;
+            case 90: HIP_TRY((launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 64 | 1024 | L>(pp, 1, st))); break;
+            case 91: HIP_TRY((launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 64 | L>(pp, 1, st))); break;
+            case 92: HIP_TRY((launch_gemm_glds<128, 128, 32, 4, 2, 2, false, 12 | 16 | L>(pp, 1, st, occ_pad(0, GldsCfg<128, 128, 32, 4, 2>::LDS_BYTES)))); break;
+            default: HIP_TRY((launch_gemm_glds<128, 128, 32, 4, 2, 2, false, 12 | 16 | 1024 | L>(pp, 1, st, occ_pad(0, GldsCfg<128, 128, 32, 4, 2>::LDS_BYTES)))); break;
+        }
+        return 0;
+    }
+    if (tile == 84 || tile == 85) {   // 84: production tile, skewed schedule + direct epilogue; 85: 4 waves of 128 x 64, BK = 8 (36 KB: three workgroups / CU)
+        if (N % 128 || K % 16) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: N %% 128 or K %% 16 != 0");
+        GemmParams pp = dense(A, K, W, bias, R, C, M, N, K, gelu);
+        Scope sc(c, static_cast<hipStream_t>(stream), NOMAD_K_GEMM, 2.0 * M * (double)N * K, NOMAD_K_GEMM_BIG);
+        HIP_TRY(tile == 84 ? (launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 64 | 1024>(pp, 1, static_cast<hipStream_t>(stream)))
+                           : (launch_gemm_glds<256, 128, 8, 2, 2, 3, false, 1 | 4 | 16 | 1024>(pp, 1, static_cast<hipStream_t>(stream))));
+        return 0;
+    }
+    if (tile == 82 || tile == 83 || tile == 87) {   // the persistent 256 x 128 kernel (83: without its output stores; 87: one workgroup per tile)
+        if (N % 128 || K % 16 || K < 64) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: persistent kernel needs N %% 128 == 0, K %% 16 == 0, K >= 64");
+        GemmParams pp = dense(A, K, W, bias, R, C, M, N, K, gelu);
+        Scope sc(c, static_cast<hipStream_t>(stream), NOMAD_K_GEMM, 2.0 * M * (double)N * K, NOMAD_K_GEMM_BIG);
+        HIP_TRY(launch_gemm_pers(pp, static_cast<hipStream_t>(stream), c->num_cus, tile == 83, tile == 87));
+        return 0;
+    }
+    if (tile < 0 || (tile > 47 && (tile < 60 || tile > 81) && tile != 86)) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile id %d", tile);
+    const int bn = tile >= 60 ? (tile == 67 ? 256 : 128) : kBN[tile], bk = tile >= 60 ? (tile == 73 ? 32 : 16) : kBK[tile];
     if (N % bn || K % bk) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: N %% %d or K %% %d != 0", bn, bk);
     GemmParams p = dense(A, K, W, bias, R, C, M, N, K, gelu);
     p.group_m = group_m;

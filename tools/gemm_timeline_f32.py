@@ -39,6 +39,20 @@ def main():
                 os.makedirs(a.dump, exist_ok=True)
                 np.save(os.path.join(a.dump, f"timeline_{sname}_{tile}.npy"), t)
             us = (t[:, :5] - t[:, 0].min()) / 100.0                    # 100 MHz ticks -> us
+            if tile == 86:   # set-up detail build: {entry, tile coordinates known, offsets + bases done, accumulators zeroed (first DMA next), first barrier passed}
+                later = us[:, 0] >= 1.0
+                seg = {"entry_to_tile_coords_us": us[:, 1] - us[:, 0], "coords_to_offsets_done_us": us[:, 2] - us[:, 1],
+                       "offsets_to_first_dma_us": us[:, 3] - us[:, 2], "first_dma_to_barrier_passed_us": us[:, 4] - us[:, 3]}
+                print(json.dumps({"shape": sname, "tile": tile, "setup_detail": {k: {"first_round": round(float(v[~later].mean()), 2), "later": round(float(v[later].mean()), 2),
+                                  "later_p90": round(float(np.percentile(v[later], 90)), 2)} for k, v in seg.items()}}), flush=True)
+                continue
+            if tile in (76, 81):   # prologue-detail build: {entry, address set-up done, own share of K tile 0 landed, first barrier passed, K loop done}
+                later = us[:, 0] >= 1.0
+                seg = {"entry_to_setup_done_us": us[:, 1] - us[:, 0], "first_dma_issue_to_landed_us": us[:, 2] - us[:, 1],
+                       "landed_to_barrier_passed_us": us[:, 3] - us[:, 2], "k_loop_us": us[:, 4] - us[:, 3]}
+                print(json.dumps({"shape": sname, "tile": tile, "prologue_detail": {k: {"first_round": round(float(v[~later].mean()), 2), "later": round(float(v[later].mean()), 2),
+                                  "later_p90": round(float(np.percentile(v[later], 90)), 2)} for k, v in seg.items()}}), flush=True)
+                continue
             pro, loop, epi, ack = us[:, 1] - us[:, 0], us[:, 2] - us[:, 1], us[:, 3] - us[:, 2], us[:, 4] - us[:, 3]
             hw, xcc = t[:, 5] & 0xFFFFFFFF, (t[:, 5] >> 32) & 0xF
             cu = (xcc << 16) | (((hw >> 13) & 7) << 12) | (((hw >> 12) & 1) << 8) | ((hw >> 8) & 0xF)   # (xcc, se, sh, cu)
