@@ -75,7 +75,38 @@ def cpu_baseline(sd, n_samples, budget_s=20.0, max_clips=256):
         half = max(1, n // 8)
         O.pairwise(e[half:], e[:half])
         dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 3), "unit": "clips/s", "cores": best_threads, "kind": "port",
+        # the batched leg SURVEY.md section 8(d) asks for: the same oracle on batches of 8 clips (what a user who batches the
+        # reference's per-file loop by hand would get), bounded to a few seconds, threads re-calibrated for the larger GEMMs
+        batched = None
+        try:
+            bt, bdt = None, None
+            for c in [c for c in (16, 32, 64) if c <= ncpu] or [ncpu]:
+                torch.set_num_threads(c)
+                O.triplet_forward(sd, wav[:8])
+                t1 = time.perf_counter()
+                O.triplet_forward(sd, wav[:8])
+                d1 = time.perf_counter() - t1
+                if bdt is None or d1 < bdt:
+                    bt, bdt = c, d1
+            torch.set_num_threads(bt)
+            t1, nb = time.perf_counter(), 0
+            while nb + 8 <= max_clips and (nb < 16 or time.perf_counter() - t1 < budget_s / 3):
+                O.triplet_forward(sd, wav[nb:nb + 8])
+                nb += 8
+            batched = {"value": round(nb / (time.perf_counter() - t1), 3), "unit": "clips/s", "batch": 8, "cores": bt, "clips": nb}
+        except Exception as ex:  # noqa: BLE001
+            batched = {"error": str(ex)[:120]}
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": round(n / dt, 3), "unit": "clips/s", "cores": best_threads, "kind": "port", "cpu_model": cpu_model,
+            "batched_b8": batched,
             "sample": f"{n} clips of {n_samples} samples, batch-1 loop (as nomad.py:171-183) + float64 cdist "
                       f"{n - half}x{half}, {dt:.1f} s wall; host has {ncpu} logical CPUs, thread count calibrated "
                       f"over 8/16/32/64"}
@@ -105,16 +136,30 @@ def spawn_ranks(n: int, argv) -> int:
     return res.returncode if res.returncode != 0 or lines else 1
 
 
-def c3_sharded_scores(embed_fn, pairwise_fn, wav, n_deg_local, batch, use_pg):
+def c3_sharded_scores(embed_fn, pairwise_fn, wav, n_deg_local, batch, use_pg, stage_ms=None):
     """One rank's part of configs[2]: embed this rank's clips (its slice of the degraded set, then its slice of the references)
     in batches, ONE all-gather of the reference embeddings, this rank's distance slab + row means, one gather of the scores
-    -> (all scores in global order, all reference embeddings, this rank's slab).  Shard sizes may differ between ranks."""
+    -> (all scores in global order, all reference embeddings, this rank's slab).  Shard sizes may differ between ranks.
+    stage_ms (dict, optional): receives the device times of the all-gather, the distance stage and the score gather (events on the
+    current stream; BASELINE.md section 4, row C3: "all-gather + distance time")."""
     import torch
     from nomad_amd.dist import all_gather_rows
     emb = torch.cat([embed_fn(wav[i:i + batch]) for i in range(0, wav.shape[0], batch)])
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if stage_ms is not None else None
+    if ev:
+        ev[0].record()
     ref_all = all_gather_rows(emb[n_deg_local:].contiguous(), force_collective=use_pg)     # the one data-path collective
+    if ev:
+        ev[1].record()
     d, mean = pairwise_fn(emb[:n_deg_local].contiguous(), ref_all, True)
-    return all_gather_rows(mean, force_collective=use_pg), ref_all, d
+    if ev:
+        ev[2].record()
+    scores = all_gather_rows(mean, force_collective=use_pg)
+    if ev:
+        ev[3].record()
+        ev[3].synchronize()
+        stage_ms.update(allgather_ms=ev[0].elapsed_time(ev[1]), pairwise_ms=ev[1].elapsed_time(ev[2]), scores_gather_ms=ev[2].elapsed_time(ev[3]))
+    return scores, ref_all, d
 
 
 def time_c3(eng, world, rank, use_pg, fence, n_deg=10000, n_ref=1000, batch=256):
@@ -125,21 +170,42 @@ def time_c3(eng, world, rank, use_pg, fence, n_deg=10000, n_ref=1000, batch=256)
     from nomad_amd.dist import partition
     (ds, de), (rs, re_) = partition(n_deg, world, rank), partition(n_ref, world, rank)
     g = torch.Generator(device="cuda").manual_seed(3000 + rank)
-    wav = (0.1 * torch.randn(de - ds + re_ - rs, 64000, generator=g, device="cuda")).clamp(-1, 1)
-    eng.embed(wav[:batch])
+    # everything that can fail on ONE rank only (the 2.8 GB of waveforms, the first embed) happens before the ranks agree to go
+    # on: a rank that failed here must not leave the others waiting inside the all-gather
+    err = None
+    try:
+        wav = (0.1 * torch.randn(de - ds + re_ - rs, 64000, generator=g, device="cuda")).clamp(-1, 1)
+        eng.embed(wav[:batch])
+    except Exception as e:  # noqa: BLE001
+        err = e
+    if use_pg:
+        import torch.distributed as dist
+        bad = torch.tensor([0 if err is None else 1], dtype=torch.int32, device="cuda")
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if int(bad.item()) and err is None:
+            err = RuntimeError("configs[2]: another rank could not set the leg up")
+    if err is not None:
+        raise err
     fence()
     t0 = time.perf_counter()
-    scores, ref_all, d = c3_sharded_scores(eng.embed, eng.pairwise, wav, de - ds, batch, use_pg)
+    stage_ms = {}
+    scores, ref_all, d = c3_sharded_scores(eng.embed, eng.pairwise, wav, de - ds, batch, use_pg, stage_ms)
     fence()
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    st = torch.tensor([stage_ms.get("allgather_ms", 0.0), stage_ms.get("pairwise_ms", 0.0), stage_ms.get("scores_gather_ms", 0.0)], dtype=torch.float64, device="cuda")
     if use_pg:
         import torch.distributed as dist
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(st, op=dist.ReduceOp.MAX)
     ok = bool(scores.shape[0] == n_deg and ref_all.shape[0] == n_ref and torch.isfinite(scores).all().item())
     dt = float(dt.item())
     return {"workload": f"configs[2]: {n_deg} deg x {n_ref} ref clips of 64000 samples, fp32, clip-sharded x{world}, one all-gather of "
                         f"the ref embeddings, {n_deg}x{n_ref} float64 distances + means, end to end",
             "dtype": "f32", "value": round((n_deg + n_ref) / dt, 2), "unit": "clips/s", "seconds": round(dt, 3), "pairs": n_deg * n_ref,
+            "allgather_ms": round(float(st[0].item()), 3), "pairwise_ms": round(float(st[1].item()), 3),
+            "scores_gather_ms": round(float(st[2].item()), 3),
+            "stage_note": "device time (events on the launch stream, max over ranks) of the all-gather of the reference embeddings, of this "
+                          "rank's distance slab + row means, and of the gather of the scores; the rest of `seconds` is the embedding of the clips",
             "scaling": "strong", "finite": ok}
 
 
@@ -365,12 +431,45 @@ def main():
             if use_pg:
                 dist.all_reduce(t5, op=dist.ReduceOp.MAX)
             v5 = world * 32 * 5 / float(t5.item())
+            # the same 32 x 480 000 batch through bf16x3 (fp32-class scores from the bf16 matrix cores) and, once, through fp32:
+            # what long-form scores within the north star's 1e-4 cost next to the bf16 figure
+            c5_x3 = None
+            try:
+                sc5x = ShardedScorer(eng.embed_bf16x3, eng.pairwise, equal_shards=True, force_collective=use_pg)
+                for _ in range(2):
+                    m5x, _, _ = sc5x.score(wav5[:28], wav5[28:], want_matrix=True)
+                fence()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    m5x, _, _ = sc5x.score(wav5[:28], wav5[28:], want_matrix=True)
+                fence()
+                t5x = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
+                sc5f = ShardedScorer(eng.embed, eng.pairwise, equal_shards=True, force_collective=use_pg)
+                m5f, _, _ = sc5f.score(wav5[:28], wav5[28:], want_matrix=True)
+                fence()
+                t1 = time.perf_counter()
+                m5f, _, _ = sc5f.score(wav5[:28], wav5[28:], want_matrix=True)
+                fence()
+                t5f = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
+                if use_pg:
+                    dist.all_reduce(t5x, op=dist.ReduceOp.MAX)
+                    dist.all_reduce(t5f, op=dist.ReduceOp.MAX)
+                c5_x3 = {"precision": "bf16x3 (hi/lo-split bf16 operands, 3 bf16 MFMA products per fp32 product, fp32 accumulate)",
+                         "value": round(world * 32 * 3 / float(t5x.item()), 2), "unit": "clips/s", "steps": 3,
+                         "ms_per_step": round(1e3 * float(t5x.item()) / 3, 3),
+                         "max_abs_score_diff_vs_f32": float((m5x - m5f).abs().max().item()),
+                         "bf16_max_abs_score_diff_vs_f32": float((m5 - m5f).abs().max().item()),
+                         "f32_same_batch": {"value": round(world * 32 / float(t5f.item()), 2), "unit": "clips/s", "steps": 1,
+                                            "ms_per_step": round(1e3 * float(t5f.item()), 3)}}
+            except Exception as e:
+                c5_x3 = {"precision": "bf16x3", "error": str(e)[:200]}
             also_c5 = {"workload": "configs[4]: batch=32 x 480000 samples (T=1499) per GPU, bf16 storage / fp32 accumulate, "
                                    "28 deg x 4*N ref float64 distances + means",
                        "dtype": "bf16", "value": round(v5, 2), "unit": "clips/s", "steps": 5, "warmup": 2,
                        "ms_per_step": round(1e3 * float(t5.item()) / 5, 3),
                        "model_frac_of_mfma_peak": round(v5 * 500.044e9 / world / 2.5e15, 4),
                        "finite": bool(torch.isfinite(m5).all().item()),
+                       "fp32_class_scores_same_batch": c5_x3,
                        "context": "STATIC notes, not measured in this run: this forward holds a shader clock of 2015-2160 MHz of the "
                                   "2400 nominal (profiles/r03_n192_null.txt, r03_clock_c5.jsonl); sustained on its GEMM shapes hipBLASLt "
                                   "reaches 725-1205 TFLOP/s, the shipped kernels 715-1086 (profiles/r03_vendor_yardstick.txt; out_proj / fc2 with the "
@@ -394,6 +493,8 @@ def main():
             except Exception as e:
                 also_c4 = {"workload": "configs[3]", "error": str(e)[:200]}
     if headline and not ckpt and args.weights == "seeded":
+        engp = None
+        keep = (eng.F32_SPLIT_ROWS, eng.BF16_SPLIT_ROWS)
         try:
             engp = Engine(seeded_state_dict(**peaky), local_rank)
             engp.F32_SPLIT_ROWS = engp.BF16_SPLIT_ROWS = 0    # kernels run alone: the per-kernel times below are theirs
@@ -403,7 +504,6 @@ def main():
             wav5 = (0.1 * torch.randn(32, 480000, generator=g5)).clamp(-1, 1).cuda()
             sc5 = ShardedScorer(engp.embed_bf16, engp.pairwise, equal_shards=True, force_collective=use_pg)
             # the same loops on the headline's (seeded) engine with its batch split off: the like-for-like reference
-            keep = (eng.F32_SPLIT_ROWS, eng.BF16_SPLIT_ROWS)
             eng.F32_SPLIT_ROWS = eng.BF16_SPLIT_ROWS = 0
             sc5s = ShardedScorer(eng.embed_bf16, eng.pairwise, equal_shards=True, force_collective=use_pg)
             sc2s = ShardedScorer(eng.embed, eng.pairwise, equal_shards=True, force_collective=use_pg)
@@ -433,12 +533,15 @@ def main():
                         res[key] = row
                     else:
                         res[key]["seeded_weights_same_loop"] = row
-            eng.F32_SPLIT_ROWS, eng.BF16_SPLIT_ROWS = keep
             del wav5
-            engp.close()
             also_peaky = res
         except Exception as e:
             also_peaky = {"error": str(e)[:200]}
+        finally:   # whatever happened above: the headline engine gets its split back, the second engine is released
+            eng.F32_SPLIT_ROWS, eng.BF16_SPLIT_ROWS = keep
+            if engp is not None:
+                engp.profile_enable(False)
+                engp.close()
 
     if rank == 0:
         clips = world * B * args.steps
@@ -483,7 +586,10 @@ def main():
             # (fabric-side counters, Infinity-Cache hits included).  On a 1-GPU headline run the two passes are taken NOW, as
             # child processes (tools/pmc_traffic.py:collect, ~15 s; this process is idle meanwhile); otherwise, or if that
             # fails, the table committed under profiles/ (same passes, taken by tools/gpu_pmc_traffic.sh) is replayed and says so.
-            if world == 1 and prof and args.live_traffic != "off":
+            # (never from inside a profiler: a bench.py that is itself the target of rocprofv3 would start nested profiled runs)
+            under_profiler = any(k in os.environ for k in ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_METRICS_PATH")) or \
+                "rocprof" in os.environ.get("LD_PRELOAD", "")
+            if world == 1 and prof and args.live_traffic != "off" and not under_profiler:
                 try:
                     sys.path.insert(0, os.path.join(ROOT, "tools"))
                     import pmc_traffic

@@ -54,6 +54,8 @@ def _command(lib: str, diag: bool, verbose: bool):
            "-Wall", "-Wno-unused-function", "-pthread", "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
     if os.environ.get("NOMAD_PACKED_FP32", "0") != "1" and not lib.endswith("_pk.so"):
         cmd[2:2] = NO_PACKED_FP32
+    else:
+        cmd.insert(1, "-DNOMAD_PACKED_FP32_BUILD=1")   # nomad_build_flags() reports it; Engine then keeps its two-stream split off
     if diag:
         cmd.insert(1, "-DNOMAD_DIAG")
     if verbose:

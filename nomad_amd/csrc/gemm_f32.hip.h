@@ -604,6 +604,9 @@ __global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : (((
         }
         __builtin_amdgcn_s_barrier();
         NOMAD_FENCE();
+#ifdef NOMAD_DIAG
+        if (OPT & 128) ts_[(OPT & 8192) ? 4 : (OPT & 2048) ? 3 : 1] = wall_clock64();
+#endif
         f32x4 af[2][TM], bf[2][TN];
         auto rd = [&](int buf, int st, int kq) {
             const float* as = As + st * BM * BK + a_row_off;
@@ -1028,6 +1031,12 @@ __global__ __launch_bounds__(512, 4) void gemm_f32_pers_kernel(const GemmParams 
     // tiles ahead of the multiply side and crosses into the next output tile first - its bases and per-lane offsets are
     // recomputed in place right after the current tile's last K tile has been issued.  The last output tile of a workgroup
     // "crosses" into itself: two K tiles are staged that nobody reads (no has-next special case anywhere in the loop).
+    // OPT bit 1 (experiment): the second workgroup of every CU starts half a tile late, so that the two do not reach their
+    // epilogues together for the rest of the launch (they process equal tiles at equal speed from a common start otherwise)
+    if ((OPT & 1) && blockIdx.x >= gridDim.x / 2) {
+        const int naps = nk / 4;   // ~ half a K loop: a K tile takes ~3.5 us when two workgroups share the CU, s_sleep 127 ~ 3.4 us
+        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     int tile = blockIdx.x;
     int m0, n0, m0_ld, n0_ld, a_voff[2];
     const float *a_tile, *b_tile;
@@ -1152,7 +1161,7 @@ __global__ __launch_bounds__(512, 4) void gemm_f32_pers_kernel(const GemmParams 
 }
 
 // workgroups: two per CU (the kernel's residency), never more than there are tiles
-inline hipError_t launch_gemm_pers(GemmParams p, hipStream_t s, int num_cus, bool noepi = false, bool one_tile_each = false) {
+inline hipError_t launch_gemm_pers(GemmParams p, hipStream_t s, int num_cus, bool noepi = false, bool one_tile_each = false, bool stagger = false) {
     p.tiles_m = (p.M + 255) / 256;
     p.tiles_n = p.N / 128;
     p.a_clip_magic = p.tn_magic = 0;
@@ -1170,7 +1179,15 @@ inline hipError_t launch_gemm_pers(GemmParams p, hipStream_t s, int num_cus, boo
     // one_tile_each: the same kernel launched with one workgroup per tile - no tile loop, only its lean set-up and direct epilogue
     const int grid = (int)((one_tile_each || nwg < 2ll * num_cus) ? nwg : 2ll * num_cus);
     constexpr int lds = 3 * (256 + 128) * 16 * 4;
-    if (noepi) hipLaunchKernelGGL(gemm_f32_pers_kernel<true>, dim3(grid), dim3(512), lds, s, p);
+    if (stagger) {
+        static bool attr2 = false;
+        if (!attr2) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_pers_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr2 = true;
+        }
+        hipLaunchKernelGGL((gemm_f32_pers_kernel<false, 1>), dim3(grid), dim3(512), lds, s, p);
+    } else if (noepi) hipLaunchKernelGGL(gemm_f32_pers_kernel<true>, dim3(grid), dim3(512), lds, s, p);
     else hipLaunchKernelGGL(gemm_f32_pers_kernel<false>, dim3(grid), dim3(512), lds, s, p);
     return hipGetLastError();
 }

@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -319,6 +320,7 @@ struct nomad_ctx {
     // different streams of one context may be in flight together (Engine / ShardedScorer are driven from side streams), so
     // each stream gets its own block: the first at nomad_create, further ones on a stream's first call
     std::vector<std::pair<hipStream_t, double*>> pair_scratch;   // (kNoStream: block not bound to a stream)
+    std::mutex pair_mu;   // guards pair_scratch: nomad_pairwise may be called from several host threads (one stream each)
     // transposed copies for the dX-only backward (built by nomad_enable_backward)
     bool bwd_ready = false;
     float* conv_bw_even[7] = {};  // k=3 layers 1..4: [512][1024] = [W_tap2^T | W_tap0^T]
@@ -3562,6 +3564,17 @@ int nomad_train_set_step(nomad_ctx* c, long long step) {
     return 0;
 }
 
+int nomad_build_flags(void) {
+    int f = 0;
+#ifdef NOMAD_PACKED_FP32_BUILD
+    f |= NOMAD_BUILD_PACKED_FP32;
+#endif
+#ifdef NOMAD_DIAG
+    f |= NOMAD_BUILD_DIAG;
+#endif
+    return f;
+}
+
 int nomad_pairwise(nomad_ctx* c, const float* deg, int Nd, const float* ref, int Nr, double* dist, double* mean,
                    nomad_stream_t stream) {
     if (!c || !deg || !ref || !mean || Nd <= 0 || Nr <= 0)
@@ -3571,6 +3584,7 @@ int nomad_pairwise(nomad_ctx* c, const float* deg, int Nd, const float* ref, int
     // stream are ordered, calls on different streams must not share it): the block of nomad_create goes to the first
     // stream that calls, any further stream allocates its own on its first call
     double* scratch = nullptr;
+    std::unique_lock<std::mutex> pair_lock(c->pair_mu);   // look-up, binding and allocation of a stream's block: one thread at a time
     for (const auto& e : c->pair_scratch)
         if (e.first == s) {
             scratch = e.second;
@@ -3601,6 +3615,7 @@ int nomad_pairwise(nomad_ctx* c, const float* deg, int Nd, const float* ref, int
             scratch = static_cast<double*>(d);
         }
     }
+    pair_lock.unlock();
     Scope sc(c, s, NOMAD_K_PAIR, 3.0 * 256 * (double)Nd * Nr);
     // deg rows are processed in slabs that fit the scratch
     const int ntiles = (Nr + kPairTile - 1) / kPairTile;
@@ -3706,6 +3721,14 @@ int nomad_diag_gemm(nomad_ctx* c, const float* A, const float* W, const float* b
         GemmParams p48 = dense(A, K, W, bias, R, C, M, N, K, gelu);
         return run_gemm(c, p48, 1, tile, static_cast<hipStream_t>(stream));
     }
+    if (tile == 94 || tile == 95) {   // the shipped lean + skewed + direct-epilogue instantiation with timeline stamps (94) / set-up detail stamps (95)
+        if (N % 128 || K % 32) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: N %% 128 or K %% 32 != 0");
+        GemmParams pp = dense(A, K, W, bias, R, C, M, N, K, gelu);
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        if (tile == 94) HIP_TRY((launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 64 | 1024 | 16384 | 128>(pp, 1, st)));
+        else HIP_TRY((launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 64 | 1024 | 16384 | 128 | 8192>(pp, 1, st)));
+        return 0;
+    }
     if (tile >= 88 && tile <= 93) {   // lean set-up (OPT bit 16384) on: 88 production tile, 89 + direct epilogue, 90 + skewed + direct, 91 + skewed (LDS epilogue), 92 128x128x32 tile, 93 128x128x32 + direct
         if (N % 128 || K % 32) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: N %% 128 or K %% 32 != 0");
         GemmParams pp = dense(A, K, W, bias, R, C, M, N, K, gelu);
@@ -3730,11 +3753,12 @@ int nomad_diag_gemm(nomad_ctx* c, const float* A, const float* W, const float* b
                            : (launch_gemm_glds<256, 128, 8, 2, 2, 3, false, 1 | 4 | 16 | 1024>(pp, 1, static_cast<hipStream_t>(stream))));
         return 0;
     }
-    if (tile == 82 || tile == 83 || tile == 87) {   // the persistent 256 x 128 kernel (83: without its output stores; 87: one workgroup per tile)
+    if (tile == 82 || tile == 83 || tile == 87 || tile == 96) {   // (96: persistent, second workgroup of a CU starts half a tile late)
+   // the persistent 256 x 128 kernel (83: without its output stores; 87: one workgroup per tile)
         if (N % 128 || K % 16 || K < 64) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: persistent kernel needs N %% 128 == 0, K %% 16 == 0, K >= 64");
         GemmParams pp = dense(A, K, W, bias, R, C, M, N, K, gelu);
         Scope sc(c, static_cast<hipStream_t>(stream), NOMAD_K_GEMM, 2.0 * M * (double)N * K, NOMAD_K_GEMM_BIG);
-        HIP_TRY(launch_gemm_pers(pp, static_cast<hipStream_t>(stream), c->num_cus, tile == 83, tile == 87));
+        HIP_TRY(launch_gemm_pers(pp, static_cast<hipStream_t>(stream), c->num_cus, tile == 83, tile == 87, tile == 96));
         return 0;
     }
     if (tile < 0 || (tile > 47 && (tile < 60 || tile > 81) && tile != 86)) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile id %d", tile);

@@ -146,7 +146,9 @@ class _NomadLossFn(torch.autograd.Function):
         side = eng.side_stream()
         side.wait_stream(cur)
         # precision="bf16x3": the branches that carry no gradient (always `clean`; `estimate` too under no_grad) run
-        # the split-bf16 forward (layer outputs within ~1e-5 of fp32); the branch that is differentiated stays fp32
+        # the split-bf16 forward (layer outputs within ~1e-5 of fp32); the branch that is differentiated stays on fp32 BUFFERS
+        # (embed_train), its GEMM products in whatever Engine.gemm_precision says - "bf16x3" when the Nomad was made with
+        # precision="bf16x3", exact fp32 otherwise
         fwd = eng.embed_bf16x3 if _takes_bf16x3(nomad.precision, cln) else eng.embed
         with torch.cuda.stream(side):
             c_emb, c_layers = fwd(cln, head=head, want_layers=True, side=True)
@@ -534,7 +536,10 @@ class Nomad:
                                                       device=getattr(self.engine, "device", None)):
             prec = self.precision
             if prec == "bf16x3" and sum(packed[1]) < BF16X3_MIN_SAMPLES:
-                prec = "fp32"   # a handful of files does not fill the 256 x 256 tiles: the exact path is also the faster one
+                # a handful of files does not fill the 256 x 256 tiles of the split-storage path: they take the fp32-buffer forward,
+                # which is the faster one there.  Its GEMM products follow Engine.gemm_precision, and Nomad(precision="bf16x3") has
+                # set that to "bf16x3" - so these embeddings are bf16x3-class (~1e-6 from fp32) too, not exact fp32
+                prec = "fp32"
             emb = self.engine.embed_ragged(None, precision=prec, packed=packed)   # asynchronous
             uploaded()                                                             # the staging slot is free once the copy is done
             fetch = self.engine.fetch_async(emb)                                   # D2H enqueued right behind it

@@ -79,14 +79,25 @@ class TripletDataset(torch.utils.data.Dataset):
         return torch.stack([torch.nn.functional.pad(w, (0, max_len - w.shape[1]), "constant", 0) for w in wavs], dim=0)
 
 
-def load_pretrained(path: str) -> Dict[str, torch.Tensor]:
-    """State dict in the NOMAD checkpoint layout from ``checkpoint_path`` (see module docstring)."""
+def load_pretrained(path: str, allow_unsafe_pickle: bool = None) -> Dict[str, torch.Tensor]:
+    """State dict in the NOMAD checkpoint layout from ``checkpoint_path`` (see module docstring).
+
+    The file is read with the tensors-only unpickler.  A fairseq checkpoint that pickles its config objects needs the full
+    unpickler - which executes whatever the file contains - so that is used only when the caller asks for it
+    (``allow_unsafe_pickle=True``, config key ``allow_unsafe_pickle``, or ``NOMAD_ALLOW_UNSAFE_PICKLE=1``); otherwise the
+    restricted loader's error is re-raised with that hint.  (The reference always uses the full one: nomad.py:58.)"""
     if path == "seeded":
         return seeded_state_dict(0)
-    try:  # tensors-only unpickling first; a fairseq checkpoint that pickles its config objects needs the full unpickler,
-        obj = torch.load(path, map_location="cpu", weights_only=True)   # which runs only for this explicitly named file
-    except Exception:
-        obj = torch.load(path, map_location="cpu", weights_only=False)  # (the reference does the same: nomad.py:58)
+    if allow_unsafe_pickle is None:
+        allow_unsafe_pickle = os.environ.get("NOMAD_ALLOW_UNSAFE_PICKLE", "0") == "1"
+    try:
+        obj = torch.load(path, map_location="cpu", weights_only=True)
+    except Exception as e:
+        if not allow_unsafe_pickle:
+            raise RuntimeError(f"{path}: not loadable with torch.load(weights_only=True) ({type(e).__name__}: {str(e)[:200]}).  If this is a "
+                               "trusted fairseq checkpoint with pickled config objects, pass allow_unsafe_pickle=True (config key "
+                               "'allow_unsafe_pickle', or NOMAD_ALLOW_UNSAFE_PICKLE=1) to load it with the full unpickler.") from e
+        obj = torch.load(path, map_location="cpu", weights_only=False)
     if isinstance(obj, dict) and "model" in obj and isinstance(obj["model"], dict):  # fairseq checkpoint
         want = expected_shapes()
         sd = {}
@@ -148,10 +159,13 @@ class Training:
         torch.manual_seed(SEED)
         if self.config.get("eval_w2v"):
             raise NotImplementedError("eval_w2v (raw wav2vec features) is outside the NOMAD hot path")
-        self.engine = engine if engine is not None else Engine(load_pretrained(self.config["checkpoint_path"]), device)
-        # gemm_precision (not a reference key; default fp32): "bf16x3" forms the products of every GEMM of the step - forward,
-        # dX and the split-K dW - as three bf16 MFMA products over hi / lo halves, accumulated in fp32 (Engine.gemm_precision)
-        self.engine.gemm_precision = self.config.get("gemm_precision", "fp32")
+        self.engine = engine if engine is not None else Engine(
+            load_pretrained(self.config["checkpoint_path"], self.config.get("allow_unsafe_pickle")), device)
+        # gemm_precision (not a reference key): "bf16x3" forms the products of every GEMM of the step - forward, dX and the
+        # split-K dW - as three bf16 MFMA products over hi / lo halves, accumulated in fp32 (Engine.gemm_precision).  Only set
+        # when the config names it: an engine handed in by the caller (shared with a Nomad(precision="bf16x3"), say) keeps its mode
+        if "gemm_precision" in self.config:
+            self.engine.gemm_precision = self.config["gemm_precision"]
         self.engine.train_enable()
         # freeze_all (train_triplet.py:76-79): feature extractor and encoder frozen; what is left trainable is
         # post_extract_proj, the feature LayerNorm and the embedding layer

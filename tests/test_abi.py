@@ -33,6 +33,10 @@ def test_shape_helpers(built_lib):
     for n in (9, 400, 16384, 27225, 64000, 223840, 480000):
         assert lib.nomad_num_frames(n) == max(num_frames(n), 0)
     assert lib.nomad_l1_scratch_bytes() > 0
+    # the shipped library reports a build without packed-FP32 instructions and without the diagnostic instantiations; the
+    # diagnostic one says so (nomad_build_flags: Engine keys its two-stream splits on bit 0)
+    assert lib.nomad_build_flags() == 0
+    assert _lib.load(diag=True).nomad_build_flags() == 2
 
 
 def test_create_fails_loudly_without_gpu(built_lib, sd0):

@@ -160,6 +160,30 @@ def test_load_pretrained_accepts_a_fairseq_style_checkpoint(tmp_path):
     assert torch.equal(load_pretrained(nomad_path)["embedding_layer.1.weight"], sd["embedding_layer.1.weight"])
 
 
+def test_load_pretrained_never_falls_back_to_the_full_unpickler_on_its_own(tmp_path, monkeypatch):
+    """a file the restricted loader rejects is exactly the file that must not reach pickle's full machinery
+    unless the caller says so."""
+    import pickle
+    import torch
+    from nomad_amd.train import load_pretrained
+    from nomad_amd.weights import seeded_state_dict
+    marker = tmp_path / "executed"
+
+    class Evil:
+        def __reduce__(self):
+            return (open, (str(marker), "w"))
+    path = str(tmp_path / "evil.pt")
+    sd = seeded_state_dict(4)
+    model = {k[len("ssl_model."):]: v for k, v in sd.items() if k.startswith("ssl_model.")}
+    torch.save({"model": model, "cfg": Evil()}, path, pickle_protocol=pickle.DEFAULT_PROTOCOL)
+    monkeypatch.delenv("NOMAD_ALLOW_UNSAFE_PICKLE", raising=False)
+    with pytest.raises(RuntimeError, match="allow_unsafe_pickle"):
+        load_pretrained(path)
+    assert not marker.exists()
+    got = load_pretrained(path, allow_unsafe_pickle=True)      # the caller's explicit decision
+    assert marker.exists() and "ssl_model.layer_norm.weight" in got
+
+
 def test_feature_grad_mult_is_never_read_from_an_unnamed_file(tmp_path, monkeypatch):
     """Nomad() construction must not unpickle ./pt-models/wav2vec_small.pt behind the caller's back: the
     constant 0.1 unless a checkpoint is NAMED, and then only through the restricted unpickler."""

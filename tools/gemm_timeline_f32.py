@@ -39,7 +39,7 @@ def main():
                 os.makedirs(a.dump, exist_ok=True)
                 np.save(os.path.join(a.dump, f"timeline_{sname}_{tile}.npy"), t)
             us = (t[:, :5] - t[:, 0].min()) / 100.0                    # 100 MHz ticks -> us
-            if tile == 86:   # set-up detail build: {entry, tile coordinates known, offsets + bases done, accumulators zeroed (first DMA next), first barrier passed}
+            if tile in (86, 95):   # set-up detail build: {entry, tile coordinates known, offsets + bases done, accumulators zeroed (first DMA next), first barrier passed}
                 later = us[:, 0] >= 1.0
                 seg = {"entry_to_tile_coords_us": us[:, 1] - us[:, 0], "coords_to_offsets_done_us": us[:, 2] - us[:, 1],
                        "offsets_to_first_dma_us": us[:, 3] - us[:, 2], "first_dma_to_barrier_passed_us": us[:, 4] - us[:, 3]}

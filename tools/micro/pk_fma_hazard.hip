@@ -1,0 +1,135 @@
+// Library-free reproducer ATTEMPT of the packed-FP32 hazard.
+// Round 3 localised a run-to-run difference of the bf16 forward to conv0_gn_gelu_kernel<bf16>: with the library's 128 x 128 bf16
+// GEMM (v_mfma_f32_32x32x16_bf16, two workgroups per CU) running on another stream, a v_pk_fma_f32 ... op_sel:[0,1,0] of the tap
+// loop retired with its LOW result unchanged in lanes 48-63 (one tap's product missing) - 6 % of the calls, 97 % with the 3/4-stage
+// variants of that GEMM.  Victim and aggressor were the library's own kernels; this file has no dependency on the library:
+//   victim    (stream A): every lane accumulates 10 taps for a channel pair with v_pk_fma_f32 (op_sel forms as in conv0's loop),
+//             repeated over many "frames"; a per-lane integer checksum of the result bits is written out;
+//   aggressor (stream B): two 8-wave workgroups per CU in a GEMM-like K loop: global_load_lds_dwordx4 staging, ds_read_b128 fragments,
+//             16 v_mfma_f32_32x32x16_bf16 per K tile, one barrier per K tile (64 KB LDS each).
+// The victim runs alone first (reference checksums), then repeatedly while the aggressor loops; any differing checksum is reported
+// with its lane and whether the low or the high channel of the pair differs.
+// Build+run: hipcc --offload-arch=gfx950 -O3 -o /tmp/pk_fma_hazard tools/micro/pk_fma_hazard.hip && /tmp/pk_fma_hazard
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// ---- victim: 256 threads, each lane one channel pair, `frames` outputs of 10 taps ------------------------------------------
+__global__ __launch_bounds__(256) void victim(const float* __restrict__ x, const float* __restrict__ w, unsigned* __restrict__ cks, int frames) {
+    const int tid = threadIdx.x;
+    f32x2 wt[10];
+    for (int t = 0; t < 10; ++t) wt[t] = (f32x2){w[(tid * 2) * 10 + t], w[(tid * 2 + 1) * 10 + t]};
+    const float* xp = x + (size_t)blockIdx.x * (frames * 5 + 16);
+    unsigned c_lo = 0, c_hi = 0;
+    for (int f = 0; f < frames; ++f) {
+        // taps as five (even, odd) pairs, like a stride-5 window of the waveform read as float2
+        f32x2 xs[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) xs[q] = (f32x2){xp[f * 5 + 2 * q], xp[f * 5 + 2 * q + 1]};
+        f32x2 acc = (f32x2){0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            // both channels times the EVEN tap (low half of xs broadcast), then times the ODD tap (high half broadcast)
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(wt[2 * q]), "v"(xs[q]));
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(wt[2 * q + 1]), "v"(xs[q]));
+        }
+        c_lo = c_lo * 1664525u + __float_as_uint(acc[0]);
+        c_hi = c_hi * 1664525u + __float_as_uint(acc[1]);
+    }
+    cks[((size_t)blockIdx.x * 256 + tid) * 2] = c_lo;
+    cks[((size_t)blockIdx.x * 256 + tid) * 2 + 1] = c_hi;
+}
+
+// ---- aggressor: GEMM-like K loop on bf16 MFMAs, 512 threads, 64 KB LDS, two workgroups per CU --------------------------------
+__global__ __launch_bounds__(512, 2) void aggressor(const __bf16* __restrict__ src, float* __restrict__ sink, int ktiles) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];   // 2 stages x 32 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const char* g = reinterpret_cast<const char*>(src) + ((size_t)blockIdx.x * 4096 + tid * 16) % (1 << 22);
+    for (int kt = 0; kt < ktiles; ++kt) {
+        char* stage = lds + (kt & 1) * 32768;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)   // 4 x 8 KB per K tile by LDS-DMA
+            __builtin_amdgcn_global_load_lds((gptr_t)(g + (size_t)(kt & 255) * 32768 + c * 8192), (lptr_t)(stage + c * 8192 + wave * 1024), 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const char* rd = lds + (kt & 1) * 32768 + (lane & 31) * 128 + (lane >> 5) * 16;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(rd + ks * 32), a1 = *reinterpret_cast<const bf16x8*>(rd + 4096 + ks * 32);
+            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(rd + 8192 + ks * 32), b1 = *reinterpret_cast<const bf16x8*>(rd + 12288 + ks * 32);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[3], 0, 0, 0);
+        }
+    }
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    if (s == 1234.5f) sink[0] = s;
+    // stores, as a GEMM's epilogue has them
+    sink[16 + (size_t)blockIdx.x * 512 + tid] = s;
+}
+
+int main() {
+    const int vblocks = 2048, frames = 4000, rounds = 60;
+    float *x, *w, *sink;
+    unsigned* cks;
+    __bf16* src;
+    hipMalloc(&x, sizeof(float) * (size_t)vblocks * (frames * 5 + 16));
+    hipMalloc(&w, sizeof(float) * 512 * 10);
+    hipMalloc(&cks, sizeof(unsigned) * (size_t)vblocks * 512);
+    hipMalloc(&src, (1 << 22) + 256 * 32768 + 65536);
+    hipMalloc(&sink, sizeof(float) * (16 + 1024 * 512));
+    std::vector<float> hx((size_t)vblocks * (frames * 5 + 16)), hw(5120);
+    unsigned seed = 12345;
+    auto rnd = [&] { seed = seed * 1664525u + 1013904223u; return ((seed >> 8) & 0xffff) / 65536.0f - 0.5f; };
+    for (auto& v : hx) v = rnd();
+    for (auto& v : hw) v = rnd();
+    hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
+    hipMemset(src, 0x3c, (1 << 22) + 256 * 32768 + 65536);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(aggressor), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipStream_t sa, sb;
+    hipStreamCreate(&sa);
+    hipStreamCreate(&sb);
+    std::vector<unsigned> ref((size_t)vblocks * 512), got(ref.size());
+    hipLaunchKernelGGL(victim, dim3(vblocks), dim3(256), 0, sa, x, w, cks, frames);
+    hipStreamSynchronize(sa);
+    hipMemcpy(ref.data(), cks, ref.size() * 4, hipMemcpyDeviceToHost);
+    // alone, repeated: the victim must reproduce itself
+    long long alone_bad = 0;
+    for (int r = 0; r < 5; ++r) {
+        hipLaunchKernelGGL(victim, dim3(vblocks), dim3(256), 0, sa, x, w, cks, frames);
+        hipStreamSynchronize(sa);
+        hipMemcpy(got.data(), cks, got.size() * 4, hipMemcpyDeviceToHost);
+        for (size_t i = 0; i < got.size(); ++i) alone_bad += got[i] != ref[i];
+    }
+    printf("victim alone, 5 repeats: %lld of %zu checksums differ\n", alone_bad, got.size() * 5);
+    long long bad = 0, bad_lo = 0, lanes_hi48 = 0;
+    for (int r = 0; r < rounds; ++r) {
+        hipLaunchKernelGGL(aggressor, dim3(512 * 6), dim3(512), 65536, sb, src, sink, 400);
+        hipLaunchKernelGGL(victim, dim3(vblocks), dim3(256), 0, sa, x, w, cks, frames);
+        hipStreamSynchronize(sa);
+        hipMemcpy(got.data(), cks, got.size() * 4, hipMemcpyDeviceToHost);
+        for (size_t i = 0; i < got.size(); ++i)
+            if (got[i] != ref[i]) {
+                ++bad;
+                if ((i & 1) == 0) ++bad_lo;
+                if (((i >> 1) & 63) >= 48) ++lanes_hi48;
+            }
+        hipStreamSynchronize(sb);
+    }
+    printf("victim next to the GEMM-like bf16 aggressor, %d rounds: %lld of %zu checksums differ (%lld in the LOW channel of a pair, %lld in lanes 48-63)\n",
+           rounds, bad, got.size() * (size_t)rounds, bad_lo, lanes_hi48);
+    return 0;
+}
