@@ -315,6 +315,14 @@ struct nomad_ctx {
     // products of up to 4 K-slices, allocated by nomad_enable_backward; splitk_ok is raised for the duration of such a
     // call only (never for scoring forwards, whose bits must not depend on the batch; never in fine-tuning mode)
     float* splitk_part = nullptr;
+    // further blocks for the no-gradient branch(es) of Nomad.forward() (layer outputs wanted, nothing saved): they run concurrently
+    // with the differentiated branch - and, under no_grad, with each other - on different streams, so each launch stream binds
+    // its own block on first use (two exist; a third stream simply does not split).  splitk_cur: the block of the call being enqueued.
+    float* splitk_extra[2] = {nullptr, nullptr};
+    hipStream_t splitk_extra_stream[2] = {nullptr, nullptr};
+    bool splitk_extra_bound[2] = {false, false};
+    hipEvent_t splitk_extra_done[2] = {nullptr, nullptr};   // recorded behind the last forward that used the block: a block whose event
+    float* splitk_cur = nullptr;                            // has completed may be re-bound to another stream
     bool splitk_ok = false;
     // nomad_pairwise: row sums per (64-ref tile, deg row), kPairScratchDoubles doubles PER LAUNCH STREAM - calls on
     // different streams of one context may be in flight together (Engine / ShardedScorer are driven from side streams), so
@@ -464,7 +472,7 @@ struct SplitKScope {  // raises nomad_ctx::splitk_ok for the lifetime of one for
 };
 
 static bool splitk_applies(const nomad_ctx* c, const GemmParams& p, int groups, int tile, int* S) {
-    if (!c->splitk_ok || !c->splitk_part || groups != 1 || tile != 37) return false;
+    if (!c->splitk_ok || !c->splitk_cur || groups != 1 || tile != 37) return false;
     if (p.DG || p.Upre || p.c_colblk || p.kchunk != p.K || p.n_valid != p.N || p.N % 64) return false;
     const bool c_plain = p.cmap.clip_rows >= p.M && p.cmap.off == 0 && p.cmap.ld == p.N;
     const bool r_plain = !p.R || (p.rmap.clip_rows >= p.M && p.rmap.off == 0 && p.rmap.ld == p.N);
@@ -481,7 +489,7 @@ static int run_gemm_splitk(nomad_ctx* c, const GemmParams& p, int S, hipStream_t
     q.kchunk = q.K;
     q.a_goff = q.K;
     q.w_goff = q.K;
-    q.C = c->splitk_part;
+    q.C = c->splitk_cur;
     q.cmap = plain_map(p.M, p.N);
     q.c_goff = (long long)p.M * p.N;
     q.bias = nullptr;
@@ -495,7 +503,7 @@ static int run_gemm_splitk(nomad_ctx* c, const GemmParams& p, int S, hipStream_t
     Scope sc(c, s, NOMAD_K_ROW, 0.0);
     const long long count4 = (long long)p.M * p.N / 4;
     hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((count4 + 255) / 256)), dim3(256), 0, s,
-                       reinterpret_cast<const float4*>(c->splitk_part), S, count4, p.N / 4, reinterpret_cast<const float4*>(p.bias),
+                       reinterpret_cast<const float4*>(c->splitk_cur), S, count4, p.N / 4, reinterpret_cast<const float4*>(p.bias),
                        reinterpret_cast<const float4*>(p.R), reinterpret_cast<float4*>(p.C), p.gelu);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -560,7 +568,9 @@ int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, in
             auto on = [](const char* name) { const char* v = getenv(name); return !v || atoi(v) != 0; };
             return (on("NOMAD_F32_LEAN") ? 1 : 0) | (on("NOMAD_F32_DIRECT_EPI") ? 2 : 0) | (on("NOMAD_F32_SKEW") ? 4 : 0);
         }();
-        const bool lean = (variants & 1) && !tr && !p.amap.pref && p.group_m == 0 && p.kchunk >= p.K;
+        // (a divisor of 1 - clips of ONE row, the shortest legal input - has no 32-bit magic number: those stay on the general set-up)
+        const bool lean = (variants & 1) && !tr && !p.amap.pref && p.group_m == 0 && p.kchunk >= p.K &&
+                          (p.amap.clip_rows >= p.M || p.amap.clip_rows >= 2);
         const bool direct = lean && (variants & 2) && !p.R && p.n_valid == p.N;
         const bool skew = lean && (variants & 4);
         constexpr int L = 16384, D = 1024, S = 64;
@@ -573,6 +583,16 @@ int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, in
         if (lean && tile == 31) {
             e = direct ? launch_gemm_glds<128, 128, 32, 4, 2, 2, false, 12 | P | L | D>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 4, 2>::LDS_BYTES))
                        : launch_gemm_glds<128, 128, 32, 4, 2, 2, false, 12 | P | L>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 4, 2>::LDS_BYTES));
+            if (e != hipSuccess) return fail(NOMAD_ERR_HIP, "gemm launch: %s", hipGetErrorString(e));
+            return 0;
+        }
+        if (lean && (tile == 37 || tile == 34 || tile == 20)) {   // the small-problem tiles (batch 1 .. config C4): one round of workgroups, the set-up is a visible part of each
+            switch (tile) {
+                case 37: e = direct ? launch_gemm_glds<64, 64, 32, 2, 2, 3, false, 12 | P | L | D>(p, groups, s) : launch_gemm_glds<64, 64, 32, 2, 2, 3, false, 12 | P | L>(p, groups, s); break;
+                case 34: e = direct ? launch_gemm_glds<128, 64, 32, 4, 2, 3, false, 12 | P | L | D>(p, groups, s) : launch_gemm_glds<128, 64, 32, 4, 2, 3, false, 12 | P | L>(p, groups, s); break;
+                default: e = direct ? launch_gemm_glds<128, 128, 32, 2, 2, 2, false, 12 | P | L | D>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 2, 2>::LDS_BYTES))
+                                    : launch_gemm_glds<128, 128, 32, 2, 2, 2, false, 12 | P | L>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 2, 2>::LDS_BYTES)); break;
+            }
             if (e != hipSuccess) return fail(NOMAD_ERR_HIP, "gemm launch: %s", hipGetErrorString(e));
             return 0;
         }
@@ -964,6 +984,17 @@ int nomad_create(nomad_ctx** out, int device, const nomad_weights* w) {
             c->allocs.push_back(d);
             c->pair_scratch.emplace_back(kNoStream, static_cast<double*>(d));
         }
+        // the split-K blocks of the layer-output forward (LossNetLayers) exist from the start: whether that forward splits must
+        // not depend on whether a backward has been enabled meanwhile (its bits would change between two calls of a process)
+        for (int i = 0; i < 2 && rc == 0; ++i) {
+            void* b = nullptr;
+            const hipError_t e2 = hipMalloc(&b, kSplitKPartFloats * sizeof(float));
+            if (e2 != hipSuccess) rc = fail(NOMAD_ERR_HIP, "nomad_create: split-K block: %s", hipGetErrorString(e2));
+            else {
+                c->allocs.push_back(b);
+                c->splitk_extra[i] = static_cast<float*>(b);
+            }
+        }
     }
     if (rc != 0) {
         nomad_destroy(c);
@@ -978,6 +1009,8 @@ void nomad_destroy(nomad_ctx* c) {
     (void)hipSetDevice(c->device);
     for (void* p : c->allocs) (void)hipFree(p);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->splitk_extra_done)
+        if (e) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -1037,8 +1070,42 @@ static int forward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, co
     char* ws = static_cast<char*>(workspace);
     auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     const int T = sh.T, M = sh.M;
-    // the loss forward of Nomad.forward() (saving activations, not fine-tuning): small-M GEMMs may split K
-    const SplitKScope splitk(c, sv != nullptr && !c->train_ready);
+    // the loss forward of Nomad.forward() (saving activations, not fine-tuning): small-M GEMMs may split K.  Round 4: so may the
+    // other branch of that loss - a forward that returns the 12 layer outputs (LossNetLayers: `clean`, or `estimate` under
+    // no_grad) on fewer than 4096 frames.  The split is a function of the GEMM shape only (fixed slices, ordered fold): the
+    // results are deterministic, but they are the loss path's bits, not the scoring path's - nomad_embed WITHOUT layer outputs
+    // (TripletModel / predict) never splits, whatever the batch.  NOMAD_SPLITK_LAYERS=0 switches the new case off (A/B).
+    static const bool splitk_layers = [] {
+        const char* e = getenv("NOMAD_SPLITK_LAYERS");
+        return !e || atoi(e) != 0;
+    }();
+    float* loss_block = nullptr;
+    if (sv == nullptr && layers_out != nullptr && M < 4096 && splitk_layers && c->splitk_extra[0]) {
+        for (int i = 0; i < 2 && !loss_block; ++i)
+            if (c->splitk_extra_bound[i] && c->splitk_extra_stream[i] == s) loss_block = c->splitk_extra[i];
+        for (int i = 0; i < 2 && !loss_block; ++i)   // an unbound block, or one whose last user has finished (a third stream takes it over)
+            if (!c->splitk_extra_bound[i] || (c->splitk_extra_done[i] && hipEventQuery(c->splitk_extra_done[i]) == hipSuccess)) {
+                c->splitk_extra_bound[i] = true;
+                c->splitk_extra_stream[i] = s;
+                loss_block = c->splitk_extra[i];
+            }
+        (void)hipGetLastError();   // (hipEventQuery's hipErrorNotReady is not an error of this call)
+    }
+    struct BlockDone {   // behind everything this forward enqueues: the block's "last user finished" event
+        nomad_ctx* c; float* blk; hipStream_t st;
+        ~BlockDone() {
+            if (!blk) return;
+            for (int i = 0; i < 2; ++i)
+                if (c->splitk_extra[i] == blk) {
+                    if (!c->splitk_extra_done[i] && hipEventCreateWithFlags(&c->splitk_extra_done[i], hipEventDisableTiming) != hipSuccess) c->splitk_extra_done[i] = nullptr;
+                    if (c->splitk_extra_done[i]) (void)hipEventRecord(c->splitk_extra_done[i], st);
+                }
+        }
+    } block_done{c, loss_block, s};
+    const SplitKScope splitk(c, (sv != nullptr || loss_block != nullptr) && !c->train_ready);
+    float* const prev_cur = c->splitk_cur;
+    c->splitk_cur = sv != nullptr ? c->splitk_part : loss_block;
+    struct CurRestore { nomad_ctx* c; float* v; ~CurRestore() { c->splitk_cur = v; } } cur_restore{c, prev_cur};
     int rc;
     // model.train() regularisation: only in the training-mode forward, only when switched on
     const bool reg = sv != nullptr;
@@ -2786,6 +2853,7 @@ int nomad_enable_backward(nomad_ctx* c) {
         c->allocs.push_back(d);
         c->splitk_part = static_cast<float*>(d);
     }
+
     c->bwd_ready = true;
     return 0;
 }
@@ -2867,6 +2935,9 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
     auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     const int T = sh.T, M = sh.M;
     const SplitKScope splitk(c, !train && !c->train_ready);  // d loss / d waveform of Nomad.forward(): small-M GEMMs may split K
+    float* const prev_cur_b = c->splitk_cur;
+    c->splitk_cur = c->splitk_part;
+    struct CurRestoreB { nomad_ctx* c; float* v; ~CurRestoreB() { c->splitk_cur = v; } } cur_restore_b{c, prev_cur_b};
     float *gx = F(lay.gx), *dya = F(lay.dya), *dyb = F(lay.dyb), *dh = F(lay.dh), *dqkv = F(lay.dqkv);
     int rc;
     // the regularisation of the forward this backward belongs to (the caller re-sets it: nomad_train_set_stochastic)

@@ -161,6 +161,34 @@ def test_forward_backward_bf16x3_products_repeat_bit_identically(built_lib, sd0)
     nmd.engine.close()
 
 
+def test_forward_backward_fp32_splitk_repeats_bit_identically(built_lib, sd0):
+    """Config C4 at the reference's precision (round 4: the no-gradient branch splits K too, on its own per-stream block):
+    loss and d loss / d estimate are the same bits on every repeat, the loss under no_grad is the same bits before and
+    after a backward has been enabled in the process, and a scoring embed of the same clips never changes."""
+    from nomad_amd.nomad import Nomad
+    nmd = Nomad(weights=sd0)
+    gen = torch.Generator().manual_seed(13)
+    clean = (0.1 * torch.randn(32, 1, 16384, generator=gen)).clamp(-1, 1).cuda()
+    est0 = (clean + 0.02 * torch.randn(32, 1, 16384, generator=gen).cuda()).clamp(-1, 1)
+    emb_before = nmd.model(est0).clone()
+    with torch.no_grad():
+        loss_nograd_before = nmd.forward(est0, clean).clone()       # both branches on the layer-output forward, two streams
+    first = None
+    for it in range(12):
+        est = est0.clone().requires_grad_(True)
+        loss = nmd.forward(est, clean)
+        loss.backward()
+        cur = (loss.detach().clone(), est.grad.clone())
+        if first is None:
+            first = cur
+        else:
+            assert torch.equal(cur[0], first[0]) and torch.equal(cur[1], first[1]), it
+    with torch.no_grad():
+        assert torch.equal(nmd.forward(est0, clean), loss_nograd_before)
+    assert torch.equal(nmd.model(est0), emb_before)
+    nmd.engine.close()
+
+
 def test_pairwise_calls_on_different_streams_do_not_share_scratch(engine):
     """Round-2 advice: nomad_pairwise kept its per-tile row sums in ONE context-owned scratch, so two calls in flight on different
     streams of one context raced.  The scratch is per launch stream now (64 blocks at most, rebound after a drain): 70 streams,

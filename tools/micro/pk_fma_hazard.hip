@@ -77,7 +77,7 @@ __global__ __launch_bounds__(512, 2) void aggressor(const __bf16* __restrict__ s
         for (int r = 0; r < 16; ++r) s += acc[i][r];
     if (s == 1234.5f) sink[0] = s;
     // stores, as a GEMM's epilogue has them
-    sink[16 + (size_t)blockIdx.x * 512 + tid] = s;
+    sink[16 + ((size_t)blockIdx.x * 512 + tid) % (1024 * 512)] = s;
 }
 
 int main() {
