@@ -72,29 +72,28 @@ __global__ __launch_bounds__(256, 3) void attention_f32_v2_kernel(const float* _
     const int ntiles = (T + kF2KT - 1) / kF2KT;
 
     // ---- staging: thread -> (key row, float4 chunk) x 2 of the 32 x 64 tile, for K and for V ----
-    float4 kreg[2], vreg[2];
-    int st_k[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int cid = tid + i * 256, row = cid >> 4, c16 = cid & 15;
-        st_k[i] = row * 256 + 16 * (c16 ^ (row & 15));
-    }
+    // Round 4: K goes global -> LDS by LDS-DMA (the instruction fills 1 KB per wave linearly, so the thread fetches the LOGICAL chunk
+    // that the XOR swizzle maps to its slot: chunk ^ (row & 15)); only V, which is stored transposed, still passes through registers.
+    // Before, the eight staging registers of K pushed the loop over its 168-register budget: the compiler spilled and reloaded 8
+    // registers through scratch in every key tile (llvm-objdump of the round-3 kernel: scratch_store / scratch_load_dwordx4 x 2).
+    float4 vreg[2];
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     auto fetch = [&](int kt) {
+        char* B0 = f2_lds + (kt & 1) * kF2Buf;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int cid = tid + i * 256, row = cid >> 4, c16 = cid & 15;
+            const int cid = tid + i * 256, row = cid >> 4, pc = cid & 15;
             int key = kt * kF2KT + row;
             key = key < T ? key : T - 1;
-            const float* src = src_bh + (long long)key * 2304 + c16 * 4;
-            kreg[i] = *reinterpret_cast<const float4*>(src + 768);
-            vreg[i] = *reinterpret_cast<const float4*>(src + 1536);
+            const float* src = src_bh + (long long)key * 2304;
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + 768 + 4 * (pc ^ (row & 15))), (lptr_t)(B0 + i * 4096 + wave_u * 1024), 16, 0, 0);
+            vreg[i] = *reinterpret_cast<const float4*>(src + 1536 + pc * 4);
         }
     };
     auto stage = [&](int buf) {
         char* B0 = f2_lds + buf * kF2Buf;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            *reinterpret_cast<float4*>(B0 + st_k[i]) = kreg[i];
             // V[key = row][d = 4*c16 + c] -> V^T[d][key]: row d is 128 B, chunk (key >> 2) ^ ((d >> 1) & 7), element key & 3
             const int cid = tid + i * 256, row = cid >> 4, c16 = cid & 15;
             const int kq = row >> 2, ke = row & 3;

@@ -221,8 +221,20 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
     const int nwg = p.tiles_m * p.tiles_n;
     const int wg = xcd_remap(blockIdx.x, nwg);
     int tile_m, tile_n;
-    tile_coords(wg, p.tiles_m, p.tiles_n, p.group_m, tile_m, tile_n);
+    if (PLAIN) {   // round 4, as gemm_f32.hip.h OPT bit 16384: the set-up's integer divisions as mulhi + shift with host-made magic numbers
+        tile_m = p.tn_magic ? fast_div(wg, p.tn_magic, p.tn_shift) : wg;   // (the caller checks: uniform clip map, n-fastest tile walk)
+        tile_n = wg - tile_m * p.tiles_n;
+    } else {
+        tile_coords(wg, p.tiles_m, p.tiles_n, p.group_m, tile_m, tile_n);
+    }
     const int m0 = tile_m * Cfg::BM, n0 = tile_n * BN;
+    auto row_addr_a = [&](int m) -> long long {
+        if (PLAIN) {
+            const int c = p.a_clip_magic ? fast_div(m, p.a_clip_magic, p.a_clip_shift) : 0;
+            return p.amap.off + (long long)c * p.amap.clip_stride + (long long)(m - c * p.amap.clip_rows) * p.amap.ld;
+        }
+        return row_addr(p.amap, m);
+    };
     const int grp = blockIdx.y;
     const bf16_t* Ag = reinterpret_cast<const bf16_t*>(p.A) + grp * p.a_goff;
     const bf16_t* Wg = reinterpret_cast<const bf16_t*>(p.W) + grp * p.w_goff;
@@ -234,7 +246,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
     // The 32-bit offsets are relative to the tile's FIRST row (row addresses grow with the row index, a 256-row tile
     // spans far less than 4 GB); the tensor itself may be larger than 4 GB (conv1 input at batch 512: 6.7 GB).
     const int m0_ld = ABL == 11 ? 0 : m0;  // ABL 11 (timing probe): every workgroup stages A tile 0 - always an L2 hit
-    const long long tile_row0 = row_addr(p.amap, m0_ld < p.M ? m0_ld : p.M - 1);  // wave-uniform
+    const long long tile_row0 = row_addr_a(m0_ld < p.M ? m0_ld : p.M - 1);  // wave-uniform
     unsigned a_off[2][2], b_off[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -245,7 +257,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(const GemmParams 
         for (int h = 0; h < 2; ++h) {
             int m = m0_ld + h * 128 + row;
             m = m < p.M ? m : p.M - 1;
-            a_off[h][i] = (unsigned)((row_addr(p.amap, m) - tile_row0 + sw) * 2);
+            a_off[h][i] = (unsigned)((row_addr_a(m) - tile_row0 + sw) * 2);
         }
     }
     const char* const a_base = reinterpret_cast<const char*>(Ag + tile_row0);
@@ -444,6 +456,12 @@ template <int ABL = 0, bool BUFLD = false, int X3 = 0, int NB = 2, int NJ = 4, b
 inline hipError_t launch_gemm_bf16_8phase(GemmParams p, int groups, hipStream_t s) {
     p.tiles_m = (p.M + P8Cfg::BM - 1) / P8Cfg::BM;
     p.tiles_n = p.N / (64 * NJ);
+    if (PLAIN) {
+        p.a_clip_magic = p.tn_magic = 0;
+        p.a_clip_shift = p.tn_shift = 0;
+        if (p.amap.clip_rows < p.M) fast_div_magic((unsigned)p.amap.clip_rows, &p.a_clip_magic, &p.a_clip_shift);
+        if (p.tiles_n > 1) fast_div_magic((unsigned)p.tiles_n, &p.tn_magic, &p.tn_shift);
+    }
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_8phase_kernel<ABL, BUFLD, X3, NB, NJ, RPRE, PLAIN>),

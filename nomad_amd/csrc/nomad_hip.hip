@@ -1583,9 +1583,12 @@ static bool x3_plain_epilogue() {
     }();
     return v;
 }
+// plain C / R matrices AND an A map whose divisions have magic numbers (uniform clips of at least two rows, n-fastest tile walk):
+// what the PLAIN instantiations (small epilogue, lean set-up) require
 static bool p8_plain_cr(const GemmParams& p) {
     return p.cmap.clip_rows >= p.M && !p.cmap.pref && p.c_colblk == 0 && p.c_blk_step == 0 &&
-           (!p.R || (p.rmap.clip_rows >= p.M && !p.rmap.pref));
+           (!p.R || (p.rmap.clip_rows >= p.M && !p.rmap.pref)) &&
+           !p.amap.pref && p.group_m == 0 && (p.amap.clip_rows >= p.M || p.amap.clip_rows >= 2);
 }
 
 // three B buffers in the deep-pipelined bf16 kernel (B staged 1.75 K tiles ahead, 160 KB of LDS); NOMAD_BF16_B3=0: two (A/B runs)
