@@ -737,7 +737,11 @@ int pick_tile(int M, int N, int K) {
     if (quant && N % 128 == 0 && tiles256 >= 1024) {
         const long long per_cu_256 = (tiles256 + 255) / 256;
         const long long tiles128 = (long long)((M + 127) / 128) * (N / 128);
-        const double cost128 = (double)((tiles128 + 255) / 256) * 0.5 * 1.03;
+        static const double penalty = [] {   // what a flop costs more on 128 x 128 tiles (NOMAD_F32_QUANT_PENALTY, percent; A/B runs)
+            const char* e = getenv("NOMAD_F32_QUANT_PENALTY");
+            return 1.0 + (e ? atof(e) : 3.0) / 100.0;
+        }();
+        const double cost128 = (double)((tiles128 + 255) / 256) * 0.5 * penalty;
         return cost128 < (double)per_cu_256 ? 31 : 33;
     }
     if (N % 128 == 0 && tiles256 >= 1500) return 33;

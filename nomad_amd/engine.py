@@ -184,6 +184,8 @@ class Engine:
             # leave idle (every instantiation contracts k in the same order, so the parts' bits equal the whole batch's)
             cur = torch.cuda.current_stream(self.device)
             cuts = [B * i // ways for i in range(ways + 1)]
+            if ways == 2 and self.F32_SPLIT_FRAC != 0.5:   # (experiment: unequal halves, so that the two parts' launches do not end together)
+                cuts[1] = max(1, min(B - 1, int(round(B * self.F32_SPLIT_FRAC))))
             for k in range(1, ways):
                 st = self.side_stream(k)
                 st.wait_stream(cur)
@@ -202,6 +204,7 @@ class Engine:
     F32_SPLIT_ROWS = int(os.environ.get("NOMAD_F32_SPLIT_ROWS", 4000))
     F32_SPLIT_MAX_ROWS = int(os.environ.get("NOMAD_F32_SPLIT_MAX_ROWS", 1 << 30))
     F32_SPLIT_WAYS = int(os.environ.get("NOMAD_F32_SPLIT_WAYS", 2))
+    F32_SPLIT_FRAC = float(os.environ.get("NOMAD_F32_SPLIT_FRAC", 0.5))
 
     def fetch_async(self, dev: torch.Tensor) -> _AsyncFetch:
         """Start copying a result to the host; ``.result()`` (numpy) later waits for this copy alone."""
