@@ -745,46 +745,38 @@ __global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : (((
         const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(uniform_ptr(p.C + grp * p.c_goff + p.cmap.off + (long long)mw * p.cmap.ld + nw)), 0,
             clamp_bytes((long long)(p.M - mw) * p.cmap.ld * 4), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(uniform_ptr(p.R ? p.R + grp * p.r_goff + p.rmap.off + (long long)mw * p.rmap.ld + nw : p.C)), 0,
-            p.R ? clamp_bytes((long long)(p.M - mw) * p.rmap.ld * 4) : 0u, 0x00020000);
         const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(uniform_ptr(p.bias ? p.bias + grp * p.bias_goff + nw : p.C)), 0, p.bias ? (unsigned)(Cfg::WTN * 4) : 0u, 0x00020000);
-        const int c_voff = (mrow * p.cmap.ld + 4 * hh) * 4, r_voff = (mrow * p.rmap.ld + 4 * hh) * 4, b_voff = 16 * hh;
+        const int c_voff = (mrow * p.cmap.ld + 4 * hh) * 4, b_voff = 16 * hh;
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        // steps (j, i), the residual of step s + 1 loaded before step s is computed: 2 x 16 registers whatever TM is
-        f32x4 rres[2][4];
-        auto load_r = [&](int buf, int j, int i) {
+        // GEMMs WITHOUT a residual only (the caller checks; residual GEMMs keep the LDS epilogue).  All bias values of the wave tile are
+        // loaded BEFORE the first store: loads and stores share one in-order vmcnt, so a bias load issued behind a group of stores
+        // can only be waited for together with those stores' acknowledgements - the first version loaded the bias per 32-column
+        // block and paid two such round trips (timeline: 9 us from the end of the K loop to the last store issued for ~130 instructions).
+        f32x4 b4[TN][4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                rres[buf][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, r_voff + i * 32 * p.rmap.ld * 4 + (j * 32 + 8 * g) * 4, 0, 0));
-        };
-        if (p.R) load_r(0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            f32x4 b4[4];
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g)   // a zero-length descriptor (no bias) reads as 0.0f
-                b4[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, b_voff + (j * 32 + 8 * g) * 4, 0, 0));
+                b4[j][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, b_voff + (j * 32 + 8 * g) * 4, 0, 0));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const int st = j * TM + i;
-                if (p.R && st + 1 < TN * TM) load_r((st + 1) & 1, (st + 1) / TM, (st + 1) % TM);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 v;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + b4[g][e];
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + b4[j][g][e];
                     if (p.gelu) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
                     }
-                    if (p.R) v += rres[st & 1][g];
                     // The row-block offset goes into the VGPR offset, NOT the scalar offset: with an SGPR soffset the compiler's
                     // hazard recogniser (LLVM GCNHazardRecognizer, "VMEM store of more than 8 bytes followed by a VALU write of
                     // the data registers") emits no wait state, and on gfx950 the v_add of the next chunk, issued right behind
                     // buffer_store_dwordx4 ... s53 offen, then corrupted element 0 of lanes 12-15 / 28-31 / 44-47 / 60-63
-                    // (measured: tools/dbg_tr.py, gpurun_out/r4d/dbg_tr.txt)
+                    // (tools/micro/store_hazard.hip, profiles/r04_store_hazard_micro.txt)
                     if (!NOEPI || p.M < 0)   // (NOEPI, a timing probe: the never-true condition keeps the arithmetic alive)
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rc, c_voff + i * 32 * p.cmap.ld * 4 + (j * 32 + 8 * g) * 4, 0, 0);
                 }
@@ -824,6 +816,32 @@ __global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : (((
         const int n = n0 + wn * Cfg::WTN + j * 32 + (lane_e & 31);
         bv[j] = (biasg && n < p.n_valid) ? biasg[n] : 0.f;
     }
+    // OPT bit 32768 (round 4): residual AHEAD.  Loads and stores share one in-order vmcnt: a residual load issued behind a group of
+    // stores can only be waited for together with those stores' acknowledgements (1-3 us each under load) - the grouped prefetch
+    // below pays that four times per tile.  Here slab 0's residual is loaded at the very start, and chunk `it` of slab i + 1 is
+    // loaded into the register chunk `it` of slab i has just been consumed from, BEFORE that chunk's store: the only stores in
+    // front of a load a wave waits for were issued a whole slab earlier.  One slab of registers (NIT float4) next to the
+    // accumulators still to be parked, which fits the 128-register budget (two slabs ahead spilled 58 registers).
+    constexpr bool RA = (OPT & 32768) != 0 && PL && !(OPT & 32);
+    f32x4 rahead[RA ? NIT : 1];
+    // (through a buffer descriptor per slab: one VGPR offset per lane, rows >= M beyond num_records read as zero - eight 64-bit
+    // address pairs and their bounds masks would not fit the 128-register budget next to the accumulators)
+    auto slab_rsrc = [&](int i) {
+        const int mw = m0 + wm * Cfg::WTM + i * 32, nw = n0 + wn * Cfg::WTN;
+        long long nb = (long long)(p.M - mw) * p.rmap.ld * 4;
+        nb = nb < 0 ? 0 : (nb > (1ll << 30) ? (1ll << 30) : nb);
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(Rg + p.rmap.off + (long long)mw * p.rmap.ld + nw)), 0, (unsigned)nb, 0x00020000);
+    };
+    const int ra_v0 = RA ? ((lane_e / CG) * p.rmap.ld + (lane_e % CG) * 4) * 4 : 0;
+    // (slab 0: RA0 chunks before the accumulators are parked, the rest right after slab 0's - every accumulator is still live here)
+    constexpr int RA0 = NIT >= 8 ? NIT / 2 : NIT;
+    auto ahead0 = [&](int lo, int hi) {
+        const __amdgpu_buffer_rsrc_t rr = slab_rsrc(0);
+#pragma unroll
+        for (int it = lo; it < hi; ++it)
+            rahead[RA ? it : 0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, ra_v0 + it * (64 / CG) * p.rmap.ld * 4, 0, 0));
+    };
+    if (RA && Rg) ahead0(0, RA0);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         // the slab is private to the wave: after the first barrier (main loop done with the staging LDS) a wave-local
@@ -841,7 +859,7 @@ __global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : (((
                                                             : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         };
-        if (PL && Rg) prefetch(0);
+        if (PL && !RA && Rg) prefetch(0);
         if (!(OPT & 1) || i == 0) __syncthreads();
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -851,6 +869,7 @@ __global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : (((
                 slab[((r & 3) + 8 * (r >> 2) + 4 * (lane_e >> 5)) * ELD + j * 32 + (lane_e & 31)] = acc[i][j][r] + bv[j];
         if (!(OPT & 1)) __syncthreads();
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (RA && Rg && i == 0 && RA0 < NIT) ahead0(RA0, NIT);
         if (!NOEPI) {
 #pragma unroll
             for (int it = 0; it < 32 * CG / 64; ++it) {
@@ -858,12 +877,15 @@ __global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : (((
                 const int m = m0 + wm * Cfg::WTM + i * 32 + row;
                 const int n = n0 + wn * Cfg::WTN + cg * 4;
                 if (PL) {
-                    if (NH < NIT && it > 0 && it % NH == 0 && Rg) prefetch(it);   // next group: after the previous group's stores have been issued
+                    if (!RA && NH < NIT && it > 0 && it % NH == 0 && Rg) prefetch(it);   // next group: after the previous group's stores have been issued
+                    f32x4 ra = rahead[RA ? it : 0];
+                    if (RA && Rg && i + 1 < TM)
+                        rahead[RA ? it : 0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(slab_rsrc(i + 1), ra_v0 + it * (64 / CG) * p.rmap.ld * 4, 0, 0));
                     if (m < p.M && n < p.n_valid) {
                         f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * ELD + cg * 4);
                         const long long c_idx = p.cmap.off + (long long)m * p.cmap.ld + n;
                         if ((OPT & 32) && Ug) *reinterpret_cast<f32x4*>(Ug + c_idx) = v;   // OPT bit 32, training forward: the pre-activation copy
-                        if (p.gelu) {
+                        if (!RA && p.gelu) {   // (the residual-ahead instantiations are launched for GELU-free GEMMs only: erf's temporaries would not fit)
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
                         }
@@ -872,7 +894,7 @@ __global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : (((
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] *= dgelu_erf_(u[e]);
                         }
-                        if (Rg) v += rpre[it % NH];
+                        if (Rg) v += RA ? ra : rpre[it % NH];
                         *reinterpret_cast<f32x4*>(Cg + c_idx) = v;
                     }
                     // OPT bits 256 / 512 (experiment): pace the output stores (s_sleep 4 / 16 = 256 / 1024 cycles after each) so that the

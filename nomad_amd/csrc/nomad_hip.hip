@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -34,6 +35,9 @@
 #include "attention.hip.h"
 #include "attention_bf16_v2.hip.h"
 #include "attention_f32_v2.hip.h"
+#ifdef NOMAD_DIAG
+#include "attention_f32_v3.hip.h"
+#endif
 #include "attention_bwd.hip.h"
 #include "backward.hip.h"
 #include "frontend.hip.h"
@@ -318,6 +322,12 @@ struct nomad_ctx {
     // further blocks for the no-gradient branch(es) of Nomad.forward() (layer outputs wanted, nothing saved): they run concurrently
     // with the differentiated branch - and, under no_grad, with each other - on different streams, so each launch stream binds
     // its own block on first use (two exist; a third stream simply does not split).  splitk_cur: the block of the call being enqueued.
+#ifdef NOMAD_DIAG
+    // item-queue counters of the experimental persistent fp32 attention kernel (attention_f32_v3.hip.h): one 64-byte block per
+    // launch, handed out round-robin - 128 launches would have to be in flight at once for two of them to share one
+    int* attn_queue = nullptr;
+    std::atomic<unsigned> attn_queue_next{0};
+#endif
     float* splitk_extra[2] = {nullptr, nullptr};
     hipStream_t splitk_extra_stream[2] = {nullptr, nullptr};
     bool splitk_extra_bound[2] = {false, false};
@@ -566,14 +576,26 @@ int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, in
         // instantiations.  NOMAD_F32_LEAN=0 / NOMAD_F32_DIRECT_EPI=0 / NOMAD_F32_SKEW=0 switch them off (A/B runs).
         static const int variants = [] {
             auto on = [](const char* name) { const char* v = getenv(name); return !v || atoi(v) != 0; };
-            return (on("NOMAD_F32_LEAN") ? 1 : 0) | (on("NOMAD_F32_DIRECT_EPI") ? 2 : 0) | (on("NOMAD_F32_SKEW") ? 4 : 0);
+            return (on("NOMAD_F32_LEAN") ? 1 : 0) | (on("NOMAD_F32_DIRECT_EPI") ? 2 : 0) | (on("NOMAD_F32_SKEW") ? 4 : 0) | (on("NOMAD_F32_RES_AHEAD") ? 8 : 0);
         }();
         // (a divisor of 1 - clips of ONE row, the shortest legal input - has no 32-bit magic number: those stay on the general set-up)
         const bool lean = (variants & 1) && !tr && !p.amap.pref && p.group_m == 0 && p.kchunk >= p.K &&
                           (p.amap.clip_rows >= p.M || p.amap.clip_rows >= 2);
         const bool direct = lean && (variants & 2) && !p.R && p.n_valid == p.N;
         const bool skew = lean && (variants & 4);
-        constexpr int L = 16384, D = 1024, S = 64;
+        // residual GEMMs (out_proj, fc2; no GELU): the residual of the next slab loaded ahead of the current slab's stores (OPT bit 32768)
+        const bool ahead = lean && (variants & 8) && p.R && !p.gelu && p.n_valid == p.N && p.rmap.clip_rows >= p.M;
+        constexpr int L = 16384, D = 1024, S = 64, RA = 32768;
+        if (ahead && tile == 33 && skew) {
+            e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | P | L | S | RA>(p, groups, s);
+            if (e != hipSuccess) return fail(NOMAD_ERR_HIP, "gemm launch: %s", hipGetErrorString(e));
+            return 0;
+        }
+        if (ahead && tile == 31) {
+            e = launch_gemm_glds<128, 128, 32, 4, 2, 2, false, 12 | P | L | RA>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 4, 2>::LDS_BYTES));
+            if (e != hipSuccess) return fail(NOMAD_ERR_HIP, "gemm launch: %s", hipGetErrorString(e));
+            return 0;
+        }
         if (lean && tile == 33) {
             e = direct ? (skew ? launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | P | L | S | D>(p, groups, s) : launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | P | L | D>(p, groups, s))
                        : (skew ? launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | P | L | S>(p, groups, s) : launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | P | L>(p, groups, s));
@@ -795,6 +817,15 @@ DropCfg make_drop(const nomad_ctx* c, float p) {
     return d;
 }
 
+#ifdef NOMAD_DIAG
+constexpr unsigned kAttnQueueBlocks = 128;
+int* next_attn_queue(nomad_ctx* c) { return c->attn_queue + 16 * (c->attn_queue_next.fetch_add(1, std::memory_order_relaxed) % kAttnQueueBlocks); }
+bool attn_v3_on() {
+    static const bool on = [] { const char* v = getenv("NOMAD_ATTN_PIPE"); return v && atoi(v) != 0; }();
+    return on;
+}
+#endif
+
 int run_attention(nomad_ctx* c, const float* qkv, float* out, float* lse, int B, int T, hipStream_t s,
                   const DropCfg* dc = nullptr, uint32_t site = 0, int bh0 = 0) {
     const double flops = 4.0 * B * 12.0 * (double)T * T * 64;
@@ -803,7 +834,13 @@ int run_attention(nomad_ctx* c, const float* qkv, float* out, float* lse, int B,
     if (dc && dc->threshold)
         hipLaunchKernelGGL((attention_f32_kernel<float, true>), grid, dim3(256), 0, s, qkv, out, lse, T, kNoInts, *dc, site, bh0);
     else if (T >= kAttnV2MinT)  // by the clip's length only: the same clip takes the same kernel in every batch
+        {
+#ifdef NOMAD_DIAG
+        if (attn_v3_on()) HIP_TRY(launch_attention_f32_v3(qkv, out, lse, B, T, kNoInts, s, next_attn_queue(c)));
+        else
+#endif
         HIP_TRY(launch_attention_f32_v2(qkv, out, lse, B, T, kNoInts, s));
+    }
     else
         hipLaunchKernelGGL((attention_f32_kernel<float, false>), grid, dim3(256), 0, s, qkv, out, lse, T, kNoInts, DropCfg{}, 0u, 0);
     HIP_TRY(hipGetLastError());
@@ -988,6 +1025,17 @@ int nomad_create(nomad_ctx** out, int device, const nomad_weights* w) {
             c->allocs.push_back(d);
             c->pair_scratch.emplace_back(kNoStream, static_cast<double*>(d));
         }
+#ifdef NOMAD_DIAG
+        {
+            void* q = nullptr;
+            const hipError_t eq = hipMalloc(&q, kAttnQueueBlocks * 16 * sizeof(int));
+            if (eq != hipSuccess) rc = fail(NOMAD_ERR_HIP, "nomad_create: attention queues: %s", hipGetErrorString(eq));
+            else {
+                c->allocs.push_back(q);
+                c->attn_queue = static_cast<int*>(q);
+            }
+        }
+#endif
         // the split-K blocks of the layer-output forward (LossNetLayers) exist from the start: whether that forward splits must
         // not depend on whether a backward has been enabled meanwhile (its bits would change between two calls of a process)
         for (int i = 0; i < 2 && rc == 0; ++i) {
@@ -1469,7 +1517,13 @@ static int forward_ragged(nomad_ctx* c, const float* wav, int B, int stride, con
             // clips of kAttnV2MinT frames or more: the 32x32x2 kernel; shorter ones: the 16x16x4 kernel (each skips the
             // other's clips) - exactly the kernel the clip would get in a batch of its own
             if (rs.max_t >= kAttnV2MinT)
+                {
+#ifdef NOMAD_DIAG
+                if (attn_v3_on()) HIP_TRY(launch_attention_f32_v3(qkv, ctxb, nullptr, B, rs.max_t, tpref, s, next_attn_queue(c), kAttnV2MinT));
+                else
+#endif
                 HIP_TRY(launch_attention_f32_v2(qkv, ctxb, nullptr, B, rs.max_t, tpref, s, kAttnV2MinT));
+                }
             if (rs.min_t < kAttnV2MinT)
                 hipLaunchKernelGGL(attention_f32_kernel<float>, dim3((std::min(rs.max_t, kAttnV2MinT - 1) + 63) / 64, B * 12), dim3(256), 0,
                                    s, qkv, ctxb, static_cast<float*>(nullptr), 0, tpref, DropCfg{}, 0u, 0, 0LL, kAttnV2MinT);
@@ -3784,6 +3838,11 @@ int nomad_profile_read(nomad_ctx* c, double ms[NOMAD_K_COUNT], long long launche
 int nomad_diag_gemm(nomad_ctx* c, const float* A, const float* W, const float* bias, const float* R, float* C, int M,
                     int N, int K, int gelu, int tile, nomad_stream_t stream) {
     if (!c || !A || !W || !C || M <= 0) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: bad argument");
+    {   // the direct epilogue (gemm_f32.hip.h OPT bit 1024) serves GEMMs without a residual only
+        const int t = tile % 100;
+        const bool direct_tile = t == 72 || t == 74 || t == 75 || t == 77 || t == 79 || t == 80 || t == 84 || t == 85 || t == 89 || t == 90 || t == 93 || t == 94 || t == 95;
+        if (direct_tile && R) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile %d has the direct epilogue, which takes no residual", t);
+    }
     // diagnostics: tile id + 100 * group_m (grouped tile order) + 10000 * occ (workgroups per CU limit)
     const int occ = tile / 10000;
     const int group_m = (tile % 10000) / 100;
@@ -3805,6 +3864,15 @@ int nomad_diag_gemm(nomad_ctx* c, const float* A, const float* W, const float* b
         hipStream_t st = static_cast<hipStream_t>(stream);
         if (tile == 94) HIP_TRY((launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 64 | 1024 | 16384 | 128>(pp, 1, st)));
         else HIP_TRY((launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 64 | 1024 | 16384 | 128 | 8192>(pp, 1, st)));
+        return 0;
+    }
+    if (tile == 97 || tile == 98) {   // residual ahead (OPT bit 32768): 97 the 256 x 128 lean + skewed tile, 98 the 128 x 128 x 32 lean tile
+        if (N % 128 || K % 32 || gelu || !R) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile %d needs N %% 128 == 0, K %% 32 == 0, a residual and no GELU", tile);
+        GemmParams pp = dense(A, K, W, bias, R, C, M, N, K, gelu);
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        Scope sc(c, st, NOMAD_K_GEMM, 2.0 * M * (double)N * K, NOMAD_K_GEMM_BIG);
+        if (tile == 97) HIP_TRY((launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 64 | 16384 | 32768>(pp, 1, st)));
+        else HIP_TRY((launch_gemm_glds<128, 128, 32, 4, 2, 2, false, 12 | 16 | 16384 | 32768>(pp, 1, st, occ_pad(0, GldsCfg<128, 128, 32, 4, 2>::LDS_BYTES))));
         return 0;
     }
     if (tile >= 88 && tile <= 93) {   // lean set-up (OPT bit 16384) on: 88 production tile, 89 + direct epilogue, 90 + skewed + direct, 91 + skewed (LDS epilogue), 92 128x128x32 tile, 93 128x128x32 + direct

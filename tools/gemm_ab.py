@@ -57,9 +57,15 @@ def main():
 
         cand = [t for t in tiles if t < 0 or N % BNS.get(t % 100, 128) == 0]
         base, same, times = None, {}, {t: [] for t in cand}
-        for t in cand:  # warm-up + bit check
+        for t in list(cand):  # warm-up + bit check
             Co.zero_()
-            launch(t)
+            try:
+                launch(t)
+            except Exception as e:  # noqa: BLE001 - a tile that does not take this shape (e.g. the direct epilogue with a residual)
+                print(json.dumps({"shape": sname, "tile": t, "skipped": str(e)[-120:]}), flush=True)
+                cand.remove(t)
+                del times[t]
+                continue
             torch.cuda.synchronize()
             if t >= 0:
                 if base is None:
