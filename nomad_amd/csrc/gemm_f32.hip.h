@@ -96,6 +96,7 @@ struct GemmParams {
     // (fast_div_magic; magic 0 = quotient 0 / divisor 1)
     unsigned a_clip_magic, tn_magic;
     int a_clip_shift, tn_shift;
+    int tile_m_base;        // gemm_f32_mixed_kernel: the first row tile of this part of the problem (in units of its BM); 0 otherwise
 };
 
 // q = n / d for 0 <= n < 2^31 as (n * magic) >> (32 + shift): magic = ceil(2^(31 + l) / d), l = ceil(log2 d), shift = l - 1
@@ -423,8 +424,11 @@ __device__ __forceinline__ void split_frag8(const f32x4& a, const f32x4& b, cons
 //      accumulator costs 6 MFMAs of 32 cycles instead of 16 of 64: the K loop of the small-M problems (config C4:
 //      M = 1600 rows, one round of 64 x 64 tiles, where one wave's serial K loop IS the launch time) is ~5x shorter.
 //      Every X3 instantiation contracts k in the same order, so the tile choice changes no result bit, as in fp32.
+// (the kernel proper is gemm_f32_glds_kernel below; the body is a device function so that gemm_f32_mixed_kernel can run two tile
+// shapes in one launch.  blk_x / grid_x / grp: the workgroup's index among, and the number of, workgroups that walk THIS problem's
+// tiles, and the group index - the x block index, the x grid size and the y block index in the plain kernel.)
 template <int BM, int BN, int BK, int WM, int WN, int STAGES = 2, bool NOEPI = false, int OPT = 0, bool X3 = false>
-__global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : (((OPT & 16) && WM * WN == 4 && BM * BN == 256 * 128) ? (BK == 8 ? 3 : 2) : 1)) void gemm_f32_glds_kernel(const GemmParams p) {   // OPT bit 16: two 8-wave workgroups per CU = 128 VGPRs (8 values computed in the prologue for the epilogue are spilled over the K loop, none inside it)
+__device__ __forceinline__ void gemm_f32_glds_body(const GemmParams& p, const int blk_x, const int grid_x, const int grp) {
     using Cfg = GldsCfg<BM, BN, BK, WM, WN, STAGES>;
     constexpr int TM = Cfg::TM, TN = Cfg::TN, NT = Cfg::THREADS, KC = Cfg::KC, RB = Cfg::RB;
     // OPT bit 1024 (round 4): TRANSPOSED accumulators + direct epilogue.  The two operands of v_mfma_f32_32x32x2_f32 have the same
@@ -454,7 +458,7 @@ __global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : (((
 #endif
     // Persistent launch (gridDim.x < nwg): a workgroup walks tiles blockIdx.x, + gridDim.x, ...; its output stores
     // drain under the next tile's prologue instead of holding the wave slots until they are acknowledged.
-    for (int t_ = blockIdx.x; t_ < nwg; t_ += gridDim.x) {
+    for (int t_ = blk_x; t_ < nwg; t_ += grid_x) {
     // OPT bit 4096 (round 4): the address set-up and the epilogue run at raised wave priority.  The timeline probe shows the
     // set-up of a workgroup that starts next to a peer in its K loop taking 13 us instead of 2 (its scalar / vector instructions
     // queue behind the peer's MFMA stream), and the lone peer fills only ~3/4 of the matrix pipe meanwhile.
@@ -476,12 +480,12 @@ __global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : (((
     } else {
         tile_coords(wg, p.tiles_m, p.tiles_n, p.group_m, tile_m, tile_n);
     }
+    tile_m += p.tile_m_base;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     auto row_addr_lean = [&](int m) -> long long {
         const int c = p.a_clip_magic ? fast_div(m, p.a_clip_magic, p.a_clip_shift) : 0;
         return p.amap.off + (long long)c * p.amap.clip_stride + (long long)(m - c * p.amap.clip_rows) * p.amap.ld;
     };
-    const int grp = blockIdx.y;
     const float* Ag = p.A + grp * p.a_goff;
     const float* Wg = p.W + grp * p.w_goff;
 #ifdef NOMAD_DIAG
@@ -930,7 +934,7 @@ __global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : (((
         }
     }
     }   // !TR
-    if (t_ + (int)gridDim.x < nwg) __syncthreads();  // every wave has read its slab: the staging LDS may be refilled
+    if (t_ + grid_x < nwg) __syncthreads();  // every wave has read its slab: the staging LDS may be refilled
     }
 #ifdef NOMAD_DIAG
     if (OPT & 128) {
@@ -946,6 +950,24 @@ __global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : (((
         }
     }
 #endif
+}
+
+template <int BM, int BN, int BK, int WM, int WN, int STAGES = 2, bool NOEPI = false, int OPT = 0, bool X3 = false>
+__global__ __launch_bounds__(WM* WN * 64, ((OPT & 16) && WM * WN == 8) ? 4 : (((OPT & 16) && WM * WN == 4 && BM * BN == 256 * 128) ? (BK == 8 ? 3 : 2) : 1)) void gemm_f32_glds_kernel(const GemmParams p) {   // OPT bit 16: two 8-wave workgroups per CU = 128 VGPRs (8 values computed in the prologue for the epilogue are spilled over the K loop, none inside it)
+    gemm_f32_glds_body<BM, BN, BK, WM, WN, STAGES, NOEPI, OPT, X3>(p, blockIdx.x, gridDim.x, blockIdx.y);
+}
+
+// ---- Two tile shapes in one launch (round 4) ------------------------------------------------------------------------------------
+// N = 768 GEMMs of the bench batch are 2.33 rounds of 256 x 128 tiles on the 512 workgroup slots (fc1: 9.33): the last third of a
+// round runs one workgroup per CU on 170 CUs while 86 idle, and costs ~2/3 of a full round.  Workgroups are dispatched in index order:
+// here the first n_big workgroups take 256 x 128 tiles over the first rows (whole rounds' worth), the others 128 x 128 tiles (same 8
+// waves, same K depth and stages, wave tile 32 x 64) over the remaining rows - twice as many, half as long, spread over all CUs.
+// Every instantiation contracts k in the same order: which tile shape computes an element changes no bit of it.  pb / ps: the two
+// row ranges as separate problems (plain A / C / R matrices: the second's pointers start at its first row).
+template <int OPTB, int OPTS>
+__global__ __launch_bounds__(512, 4) void gemm_f32_mixed_kernel(const GemmParams pb, const GemmParams ps, const int n_big) {
+    if ((int)blockIdx.x < n_big) gemm_f32_glds_body<256, 128, 16, 4, 2, 3, false, OPTB, false>(pb, blockIdx.x, n_big, 0);
+    else gemm_f32_glds_body<128, 128, 16, 4, 2, 3, false, OPTS, false>(ps, (int)blockIdx.x - n_big, (int)gridDim.x - n_big, 0);
 }
 
 // persist_blocks > 0: launch at most that many workgroups, each walking several tiles (see the kernel)
@@ -972,6 +994,32 @@ inline hipError_t launch_gemm_glds(GemmParams p, int groups, hipStream_t s, int 
     dim3 grid(gx, groups);
     hipLaunchKernelGGL((gemm_f32_glds_kernel<BM, BN, BK, WM, WN, STAGES, NOEPI, OPT, X3>), grid, dim3(Cfg::THREADS),
                        Cfg::LDS_BYTES + extra_lds, s, p);
+    return hipGetLastError();
+}
+
+// M1: rows of the 256 x 128 part (a multiple of 256, 0 < M1 < p.M); the caller has checked what the lean set-up and the plain
+// epilogue need.  Both parts address the whole problem (row maps, bounds): the second only starts at row tile M1 / 128.
+template <int OPTB, int OPTS>
+inline hipError_t launch_gemm_mixed(GemmParams p, int M1, hipStream_t s) {
+    using CfgB = GldsCfg<256, 128, 16, 4, 2, 3>;
+    p.tiles_n = p.N / 128;
+    p.a_clip_magic = p.tn_magic = 0;
+    p.a_clip_shift = p.tn_shift = 0;
+    if (p.amap.clip_rows < p.M) fast_div_magic((unsigned)p.amap.clip_rows, &p.a_clip_magic, &p.a_clip_shift);
+    if (p.tiles_n > 1) fast_div_magic((unsigned)p.tiles_n, &p.tn_magic, &p.tn_shift);
+    GemmParams pb = p, ps = p;
+    pb.tiles_m = M1 / 256;
+    pb.tile_m_base = 0;
+    ps.tiles_m = (p.M - M1 + 127) / 128;
+    ps.tile_m_base = M1 / 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_mixed_kernel<OPTB, OPTS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int n_big = pb.tiles_m * pb.tiles_n, n_small = ps.tiles_m * ps.tiles_n;
+    hipLaunchKernelGGL((gemm_f32_mixed_kernel<OPTB, OPTS>), dim3(n_big + n_small), dim3(512), CfgB::LDS_BYTES, s, pb, ps, n_big);
     return hipGetLastError();
 }
 

@@ -468,6 +468,8 @@ int occ_pad(int occ, int lds) {
     return budget > lds ? budget - lds : 0;
 }
 
+int mixed_split_rows(int M, int N);   // (below, next to pick_tile)
+
 int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, int occ = 0);
 
 // Small-M dense GEMMs of the loss forward / backward (config C4: M = 1600): N = 768 is 300 tiles of 64 x 64 on 256 CUs,
@@ -586,6 +588,18 @@ int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, in
         // residual GEMMs (out_proj, fc2; no GELU): the residual of the next slab loaded ahead of the current slab's stores (OPT bit 32768)
         const bool ahead = lean && (variants & 8) && p.R && !p.gelu && p.n_valid == p.N && p.rmap.clip_rows >= p.M;
         constexpr int L = 16384, D = 1024, S = 64, RA = 32768;
+        // two tile shapes in one launch when the last round of 256 x 128 tiles would be sparsely filled
+        if (lean && skew && tile == 33 && groups == 1 && (p.R ? ahead : direct)) {
+            // (sending the launches that need no split through the same kernel as well - one instantiation less alternating between
+            // the launches of a transformer layer - changes nothing: 2405 vs 2408 clips/s)
+            const int m1 = mixed_split_rows(p.M, p.N);
+            if (m1 > 0) {
+                e = p.R ? launch_gemm_mixed<13 | P | L | S | RA, 13 | P | L | S | RA>(p, m1, s)
+                        : launch_gemm_mixed<13 | P | L | S | D, 13 | P | L | S | D>(p, m1, s);
+                if (e != hipSuccess) return fail(NOMAD_ERR_HIP, "gemm launch: %s", hipGetErrorString(e));
+                return 0;
+            }
+        }
         if (ahead && tile == 33 && skew) {
             e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | P | L | S | RA>(p, groups, s);
             if (e != hipSuccess) return fail(NOMAD_ERR_HIP, "gemm launch: %s", hipGetErrorString(e));
@@ -743,8 +757,33 @@ GemmParams dense(const float* A, int lda, const float* W, const float* bias, con
 //        256x128 tiles are too few); 34 = 128x64x32 for N not a multiple of 128
 //   37 = LDS-DMA 64x64x32, 4 waves, 3-stage: small problems
 // (all 32x32x2-MFMA instantiations contract k in the same order, so the choice never changes a result bit)
+// Rows of the 256 x 128 part of a two-shape launch (gemm_f32_mixed_kernel), or 0: whole rounds of the 2-per-CU workgroup slots go to
+// 256 x 128 tiles, the rows of the last, partial round to 128 x 128 tiles - when that round is between 5 % and 70 % full.
+// NOMAD_F32_MIXED=0 switches it off; NOMAD_F32_MIXED_M1=<rows> (diagnostics) forces a split.
+int g_mixed_cus = 256;   // multiProcessorCount of the device (nomad_create)
+int mixed_split_rows(int M, int N) {
+    static const int mode = [] { const char* e = getenv("NOMAD_F32_MIXED"); return e ? atoi(e) : 1; }();
+    static const int forced = [] { const char* e = getenv("NOMAD_F32_MIXED_M1"); return e ? atoi(e) : 0; }();
+    if (!mode || N % 128) return 0;
+    if (forced > 0) return forced < M && forced % 256 == 0 ? forced : 0;
+    static const int slots_env = [] { const char* e = getenv("NOMAD_F32_MIXED_SLOTS"); return e ? atoi(e) : 0; }();   // (A/B runs)
+    const int tn = N / 128, slots = slots_env > 0 ? slots_env : 2 * g_mixed_cus;
+    const long long tiles = (long long)((M + 255) / 256) * tn;
+    const long long rounds = tiles / slots;
+    const double frac = (double)(tiles - rounds * slots) / slots;
+    static const double fmin = [] { const char* e = getenv("NOMAD_F32_MIXED_MIN"); return e ? atof(e) : 0.05; }();   // (A/B runs)
+    static const double fmax = [] { const char* e = getenv("NOMAD_F32_MIXED_MAX"); return e ? atof(e) : 0.70; }();
+    if (rounds < 1 || frac < fmin || frac > fmax) return 0;
+    const long long m1 = rounds * slots / tn * 256;
+    return m1 > 0 && m1 < M ? (int)m1 : 0;
+}
+
 int pick_tile(int M, int N, int K) {
     const long long tiles256 = (long long)((M + 255) / 256) * (N / 128);
+    // where the two-shape launch applies (run_gemm turns tile 33 into it) it is taken over 128 x 128 tiles: +0.3 % of the bench step
+    // (NOMAD_F32_MIXED_PREFER=0: the 128 x 128 choice below first)
+    static const bool prefer_mixed = [] { const char* e = getenv("NOMAD_F32_MIXED_PREFER"); return !e || atoi(e) != 0; }();
+    if (prefer_mixed && N % 128 == 0 && mixed_split_rows(M, N) > 0) return 33;
     // 1500, not 2048: a half of the bench batch (Engine.embed runs the batch as two halves on two streams) has 1800 tiles in
     // QKV and 1600 in conv4 - the 256x128 kernel there is worth +0.5 % of the step (2230-2235 vs 2219-2222 clips/s, alternating)
     // 256 x 128 or 128 x 128 (round 4)?  Two workgroups share a CU and a lone one runs about twice as fast, so what a launch costs
@@ -948,6 +987,7 @@ int nomad_create(nomad_ctx** out, int device, const nomad_weights* w) {
     nomad_ctx* c = new nomad_ctx();
     c->device = device;
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    g_mixed_cus = c->num_cus;
     int rc = 0;
     auto up = [&](const float* h, size_t n, float** d) {
         if (rc == 0) rc = upload(c, h, n, d);
@@ -3840,7 +3880,7 @@ int nomad_diag_gemm(nomad_ctx* c, const float* A, const float* W, const float* b
     if (!c || !A || !W || !C || M <= 0) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: bad argument");
     {   // the direct epilogue (gemm_f32.hip.h OPT bit 1024) serves GEMMs without a residual only
         const int t = tile % 100;
-        const bool direct_tile = t == 72 || t == 74 || t == 75 || t == 77 || t == 79 || t == 80 || t == 84 || t == 85 || t == 89 || t == 90 || t == 93 || t == 94 || t == 95;
+        const bool direct_tile = (t == 99 && false) || t == 72 || t == 74 || t == 75 || t == 77 || t == 79 || t == 80 || t == 84 || t == 85 || t == 89 || t == 90 || t == 93 || t == 94 || t == 95;
         if (direct_tile && R) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile %d has the direct epilogue, which takes no residual", t);
     }
     // diagnostics: tile id + 100 * group_m (grouped tile order) + 10000 * occ (workgroups per CU limit)
@@ -3864,6 +3904,18 @@ int nomad_diag_gemm(nomad_ctx* c, const float* A, const float* W, const float* b
         hipStream_t st = static_cast<hipStream_t>(stream);
         if (tile == 94) HIP_TRY((launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 64 | 1024 | 16384 | 128>(pp, 1, st)));
         else HIP_TRY((launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 64 | 1024 | 16384 | 128 | 8192>(pp, 1, st)));
+        return 0;
+    }
+    if (tile == 99) {   // two tile shapes in one launch (gemm_f32_mixed_kernel): the split by mixed_split_rows (NOMAD_F32_MIXED_M1 forces one)
+        if (N % 128 || K % 32 || (R && gelu)) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile 99 needs N %% 128 == 0, K %% 32 == 0, no GELU with a residual");
+        GemmParams pp = dense(A, K, W, bias, R, C, M, N, K, gelu);
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        const int m1 = mixed_split_rows(M, N);
+        if (m1 <= 0) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile 99: no split for M = %d, N = %d", M, N);
+        Scope sc(c, st, NOMAD_K_GEMM, 2.0 * M * (double)N * K, NOMAD_K_GEMM_BIG);
+        constexpr int V = 13 | 16 | 64 | 16384;
+        if (R) HIP_TRY((launch_gemm_mixed<V | 32768, V | 32768>(pp, m1, st)));
+        else HIP_TRY((launch_gemm_mixed<V | 1024, V | 1024>(pp, m1, st)));
         return 0;
     }
     if (tile == 97 || tile == 98) {   // residual ahead (OPT bit 32768): 97 the 256 x 128 lean + skewed tile, 98 the 128 x 128 x 32 lean tile

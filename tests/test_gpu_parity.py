@@ -133,8 +133,11 @@ def test_full_c2_batch_properties(engine):
     torch.cuda.synchronize()
     assert torch.isfinite(emb).all()
     assert (emb.norm(dim=1) - 1).abs().max().item() < 1e-5
-    one = engine.embed(wav[200:201].contiguous())
-    assert torch.equal(one[0], emb[200])            # batch-invariant, bit-exact
+    # batch-invariant, bit-exact - also for the clips at the end of each half of the batch (Engine.embed runs it as two halves), whose
+    # rows the two-shape GEMM launches (gemm_f32_mixed_kernel) give to 128 x 128 tiles instead of 256 x 128 ones
+    for k in (200, 110, 127, 255):
+        one = engine.embed(wav[k:k + 1].contiguous())
+        assert torch.equal(one[0], emb[k]), k
     d, m = engine.pairwise(emb, emb)
     assert d.diagonal().abs().max().item() == 0.0   # d(a,a) = 0 exactly (difference form)
     assert (d - d.T).abs().max().item() == 0.0

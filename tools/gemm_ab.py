@@ -22,6 +22,10 @@ EXTRA = {  # quantisation probes for 256 x 128 tiles at 2 workgroups / CU (512 s
     "fc2_3r": (65280, 768, 3072, True, False, True),     # 255 x 6 = 1530 tiles: 2.99 rounds
     "qkv_7r": (50944, 2304, 768, True, False, False),    # 199 x 18 = 3582 tiles: 7.0 rounds (= qkv)
     "conv2": (818944, 512, 1536, False, True, False),
+    "fc2_h": (25472, 768, 3072, True, False, True),      # the bench batch as Engine.embed runs it: two halves on two streams
+    "out_h": (25472, 768, 768, True, False, True),
+    "fc1_h": (25472, 3072, 768, True, True, False),
+    "qkv_h": (25472, 2304, 768, True, False, False),
     "conv4": (204544, 512, 1536, False, True, False),
 }
 BNS = {67: 256}

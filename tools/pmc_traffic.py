@@ -16,18 +16,18 @@ L = [12799, 6399, 3199, 1599, 799, 399, 199]
 
 
 def algorithmic_by_kernel():
-    """Algorithmic bytes (A + W + C + residual) per launch, split by the instantiation pick_tile() selects at
-    B = 256 x 4 s: 256x128 = conv1-4, proj, qkv, fc1, fc2; 128x128 (key "gemm_128x64") = conv5, conv6, out_proj;
-    n48 = pos-conv."""
+    """Algorithmic bytes (A + W + C + residual) per launch, split by the instantiation the single-stream forward runs at
+    B = 256 x 4 s (round 4: every conv / proj / transformer GEMM takes 256x128 tiles, alone or in a two-shape launch with 128x128
+    tiles for the rows of the last round; key "gemm_128x64" = what is left on finer kernels: the pos-conv's N = 48 kernel)."""
     big, fine = [], []
     for i in range(1, 7):
         k = 3 if i < 5 else 2
-        b = B * L[i - 1] * 512 * 4 + 512 * 512 * k * 4 + B * L[i] * 512 * 4
-        (big if i <= 4 else fine).append(b)
+        big.append(B * L[i - 1] * 512 * 4 + 512 * 512 * k * 4 + B * L[i] * 512 * 4)
     big.append(M * 512 * 4 + 768 * 512 * 4 + M * 768 * 4)
+    fine.append(B * (T + 128) * 768 * 4 * 2 + 16 * 64 * 6144 * 4 + M * 768 * 4)
     for _ in range(12):
         big.append(M * 768 * 4 + 2304 * 768 * 4 + M * 2304 * 4)
-        fine.append(M * 768 * 4 + 768 * 768 * 4 + 2 * M * 768 * 4)
+        big.append(M * 768 * 4 + 768 * 768 * 4 + 2 * M * 768 * 4)
         big.append(M * 768 * 4 + 3072 * 768 * 4 + M * 3072 * 4)
         big.append(M * 3072 * 4 + 3072 * 768 * 4 + 2 * M * 768 * 4)
     return sum(big) / len(big), sum(fine) / len(fine)
@@ -91,7 +91,7 @@ def summarise(src, tag):
     out["gemm_all_launches"] = {"launches": gl, "hbm_bytes_per_launch": (gf + gw) / gl, "fetch": gf / gl, "write": gw / gl,
                                 "algorithmic_bytes_per_launch": alg, "ratio": (gf + gw) / gl / alg}
     # "gemm_128x64" keeps its name (bench.py's key) but now covers the finer instantiations: 128x128x32 and 128x64x32
-    for key, pats in (("gemm_256x128", ("<256, 128,",)), ("gemm_128x64", ("<128, 64,", "<128, 128,"))):
+    for key, pats in (("gemm_256x128", ("<256, 128,", "gemm_f32_mixed_kernel")), ("gemm_128x64", ("<128, 64,", "<128, 128,", "n48_kernel"))):
         sel = [v for k, v in out["kernels"].items() if "gemm" in k and any(p in k for p in pats)]
         n = sum(v["launches"] for v in sel)
         b = sum(v["launches"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) for v in sel)
