@@ -96,6 +96,7 @@ struct GemmParams {
     // (fast_div_magic; magic 0 = quotient 0 / divisor 1)
     unsigned a_clip_magic, tn_magic;
     int a_clip_shift, tn_shift;
+    long long a_soff, w_soff, c_soff;   // gemm_f32_n48_kernel, K split over blockIdx.z (loss path only): element offsets per slice of A, W and C
     int tile_m_base;        // gemm_f32_mixed_kernel: the first row tile of this part of the problem (in units of its BM); 0 otherwise
 };
 
@@ -1289,8 +1290,9 @@ __global__ __launch_bounds__(512) void gemm_f32_n48_kernel(const GemmParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m0 = xcd_remap(blockIdx.x, p.tiles_m) * BM;
     const int grp = blockIdx.y;
-    const float* Ag = p.A + grp * p.a_goff;
-    const float* Wg = p.W + grp * p.w_goff;
+    const int sl = blockIdx.z;   // K slice (launch_gemm_n48 slices > 1: the loss path's small-M problems; p.K is the slice's depth)
+    const float* Ag = p.A + grp * p.a_goff + sl * p.a_soff;
+    const float* Wg = p.W + grp * p.w_goff + sl * p.w_soff;
 
     // LDS-DMA through buffer descriptors (see dma16_buffer): base = this tile's first row, 32-bit lane offsets
     const long long tile_row0 = row_addr(p.amap, m0 < p.M ? m0 : p.M - 1);
@@ -1373,7 +1375,7 @@ __global__ __launch_bounds__(512) void gemm_f32_n48_kernel(const GemmParams p) {
     }
 #undef NOMAD_N48_TILE
 
-    float* Cg = p.C + grp * p.c_goff;
+    float* Cg = p.C + grp * p.c_goff + sl * p.c_soff;
     const float* Rg = p.R ? p.R + grp * p.r_goff : nullptr;
     const float* biasg = p.bias ? p.bias + grp * p.bias_goff : nullptr;
     const float* DGg = p.DG ? p.DG + grp * p.dg_goff : nullptr;
@@ -1416,7 +1418,7 @@ __global__ __launch_bounds__(512) void gemm_f32_n48_kernel(const GemmParams p) {
 }
 
 template <bool BUFLD = false>
-inline hipError_t launch_gemm_n48(GemmParams p, int groups, hipStream_t s) {
+inline hipError_t launch_gemm_n48(GemmParams p, int groups, hipStream_t s, int slices = 1) {
     p.tiles_m = (p.M + N48Cfg::BM - 1) / N48Cfg::BM;
     p.tiles_n = 1;
     static bool attr_set = false;
@@ -1426,7 +1428,7 @@ inline hipError_t launch_gemm_n48(GemmParams p, int groups, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_f32_n48_kernel<BUFLD>, dim3(p.tiles_m, groups), dim3(N48Cfg::THREADS), N48Cfg::LDS_BYTES, s, p);
+    hipLaunchKernelGGL(gemm_f32_n48_kernel<BUFLD>, dim3(p.tiles_m, groups, slices), dim3(N48Cfg::THREADS), N48Cfg::LDS_BYTES, s, p);
     return hipGetLastError();
 }
 

@@ -521,10 +521,48 @@ static int run_gemm_splitk(nomad_ctx* c, const GemmParams& p, int S, hipStream_t
     return 0;
 }
 
+// The grouped pos-conv (16 groups x [M x 48 x 6144]) at the loss path's M = 1600 is 7 row tiles x 16 groups = 112 workgroups with a
+// serial K loop of 384 tiles: 331 us per launch on fewer than half of the CUs (three launches per configs[3] step).  K in 4 fixed
+// slices over blockIdx.z (448 workgroups), partial products added in slice order by posconv_splitk_epilogue_kernel.  Where the
+// dense GEMMs of the same call split (splitk_applies): never on a scoring entry point.  NOMAD_SPLITK_POSCONV=0 switches it off.
+static bool posconv_splitk_applies(const nomad_ctx* c, const GemmParams& p, int groups, int tile) {
+    static const bool on = [] { const char* e = getenv("NOMAD_SPLITK_POSCONV"); return !e || atoi(e) != 0; }();
+    if (!on || !c->splitk_ok || !c->splitk_cur || groups != 16 || tile != 48) return false;
+    if (p.DG || p.K != 6144 || p.kchunk != p.K || p.n_valid != 48 || p.c_goff != 48) return false;
+    const bool c_plain = p.cmap.clip_rows >= p.M && p.cmap.off == 0 && p.cmap.ld == 768;
+    return c_plain && (long long)((p.M + 255) / 256) * 16 < 256 && (size_t)4 * p.M * 768 <= kSplitKPartFloats;
+}
+
+static int run_posconv_splitk(nomad_ctx* c, const GemmParams& p, hipStream_t s) {
+    constexpr int S = 4;
+    GemmParams q = p;
+    q.K = p.K / S;
+    q.kchunk = q.K;
+    q.a_soff = q.K;
+    q.w_soff = q.K;
+    q.C = c->splitk_cur;
+    q.cmap = plain_map(p.M, 768);
+    q.c_soff = (long long)p.M * 768;
+    q.bias = nullptr;
+    q.R = nullptr;
+    q.Upre = nullptr;
+    q.gelu = 0;
+    {
+        Scope sc(c, s, NOMAD_K_GEMM, 2.0 * p.M * 48.0 * p.K * 16, NOMAD_K_GEMM_FINE);
+        HIP_TRY(launch_gemm_n48<true>(q, 16, s, S));
+    }
+    Scope sc(c, s, NOMAD_K_ROW, 0.0);
+    hipLaunchKernelGGL(posconv_splitk_epilogue_kernel, dim3(p.M), dim3(192), 0, s, c->splitk_cur, S, p.M, p.bias, p.R, p.rmap, p.r_goff, p.Upre, p.C,
+                       p.gelu);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, int occ) {
     {
         int S = 0;
         if (splitk_applies(c, p, groups, tile, &S)) return run_gemm_splitk(c, p, S, s);
+        if (posconv_splitk_applies(c, p, groups, tile)) return run_posconv_splitk(c, p, s);
     }
     if (tile == 29 && occ == 0) occ = 4;  // measured: 4 workgroups/CU is the best residency for the 128x64x32 kernel
     const double flops = 2.0 * p.M * (double)p.n_valid * p.K * groups;

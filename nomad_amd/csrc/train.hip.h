@@ -90,6 +90,35 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float4* __re
     C[i] = a;
 }
 
+// Epilogue of the K-split grouped pos-conv GEMM (loss path, run_posconv_splitk): per row m and column c = 48 g + n
+//   v = sum_s partial[s][m][c] (+ bias[c]);  Upre[m][c] = v (training forward);  v = gelu(v) (forward);  C[m][c] = v + R(m, g, n)
+// R through its row map (the forward's residual is the padded per-group buffer: rmap + g * r_goff; the backward's a plain matrix).
+__global__ __launch_bounds__(192) void posconv_splitk_epilogue_kernel(const float* __restrict__ partial, int S, int M, const float* __restrict__ bias,
+                                                                      const float* __restrict__ R, RowMap rmap, long long r_goff,
+                                                                      float* __restrict__ Upre, float* __restrict__ C, int gelu) {
+    const int m = blockIdx.x, c4 = threadIdx.x;          // 192 float4 per row
+    const long long i = (long long)m * 768 + c4 * 4;
+    float4 a = *reinterpret_cast<const float4*>(partial + i);
+    for (int s = 1; s < S; ++s) {
+        const float4 b = *reinterpret_cast<const float4*>(partial + (long long)s * M * 768 + i);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    if (bias) {
+        const float4 b = *reinterpret_cast<const float4*>(bias + c4 * 4);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    if (Upre) *reinterpret_cast<float4*>(Upre + i) = a;
+    if (gelu) {
+        a.x = gelu_erf(a.x); a.y = gelu_erf(a.y); a.z = gelu_erf(a.z); a.w = gelu_erf(a.w);
+    }
+    if (R) {
+        const int g = c4 / 12, n = (c4 - g * 12) * 4;
+        const float4 r = *reinterpret_cast<const float4*>(R + g * r_goff + row_addr(rmap, m) + n);
+        a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
+    }
+    *reinterpret_cast<float4*>(C + i) = a;
+}
+
 // Bias gradient from the transposed dY: out[r] += scale * sum_m in[r][m].  One wave per row; ld % 4 == 0.
 __global__ __launch_bounds__(256) void rowsum_acc_kernel(const float* __restrict__ in, int ld, int rows,
                                                          float* __restrict__ out, float scale) {

@@ -26,6 +26,8 @@ EXTRA = {  # quantisation probes for 256 x 128 tiles at 2 workgroups / CU (512 s
     "out_h": (25472, 768, 768, True, False, True),
     "fc1_h": (25472, 3072, 768, True, True, False),
     "qkv_h": (25472, 2304, 768, True, False, False),
+    "conv6_h": (25472, 512, 1024, False, True, False),
+    "proj_h": (25472, 768, 512, True, False, False),
     "conv4": (204544, 512, 1536, False, True, False),
 }
 BNS = {67: 256}
