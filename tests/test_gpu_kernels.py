@@ -59,6 +59,37 @@ def test_gemm_epilogues(engine_for, tile, M, N, K, epi):
     assert err < 1e-5 * max(1.0, ref.abs().max().item()), err
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(25400, 768, 768, "bias_res"), (25472, 768, 3072, "bias_res"), (50900, 3072, 768, "bias_gelu"),
+                                       (25472, 2304, 768, "bias"), (51000, 768, 768, "none")])
+def test_gemm_two_tile_shapes_in_one_launch(engine, M, N, K, epi):
+    """gemm_f32_mixed_kernel (what the product dispatch makes of tile 33 when the last round of 256 x 128 tiles would be sparsely
+    filled: 256 x 128 tiles over the rows of the whole rounds, 128 x 128 tiles over the rest; M deliberately not always a multiple
+    of 128) must equal the single-shape 128 x 128 x 32 kernel (tile 31, never split) bit for bit - every instantiation contracts
+    k in the same order - and, on small integers, the exact product."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randint(-3, 4, (M, K), generator=g).float()
+    W = torch.randint(-2, 3, (N, K), generator=g).float() + (torch.arange(N)[:, None] % 3).float()
+    bias = torch.randint(-4, 5, (N,), generator=g).float() if "bias" in epi else None
+    R = torch.randint(-8, 9, (M, N), generator=g).float() if "res" in epi else None
+    args = (_dev(A), _dev(W), _dev(bias) if bias is not None else None, _dev(R) if R is not None else None)
+    mixed = engine.diag_gemm(*args, gelu="gelu" in epi, tile=33)
+    single = engine.diag_gemm(*args, gelu="gelu" in epi, tile=31)
+    assert torch.equal(mixed, single)
+    if "gelu" not in epi:   # |values| < 2^24: the fp32 result is the exact integer
+        rows = torch.cat([torch.arange(0, 300), torch.arange(M - 300, M)])   # both parts of the launch
+        ref = A[rows].double() @ W.double().T
+        if bias is not None:
+            ref = ref + bias.double()
+        if R is not None:
+            ref = ref + R[rows].double()
+        assert torch.equal(mixed[rows.cuda()].cpu().double(), ref)
+    # random data as well (rounding in every product)
+    A2 = torch.randn(M, K, generator=g)
+    W2 = torch.randn(N, K, generator=g) * K ** -0.5
+    a2 = (_dev(A2), _dev(W2), args[2], args[3])
+    assert torch.equal(engine.diag_gemm(*a2, gelu="gelu" in epi, tile=33), engine.diag_gemm(*a2, gelu="gelu" in epi, tile=31))
+
+
 @pytest.mark.parametrize("M", [1, 255, 256, 1000, 1500])
 @pytest.mark.parametrize("epi", ["exact", "bias_gelu_res"])
 def test_gemm_n48_kernel(engine, M, epi):

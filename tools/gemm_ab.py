@@ -27,6 +27,14 @@ EXTRA = {  # quantisation probes for 256 x 128 tiles at 2 workgroups / CU (512 s
     "fc1_h": (25472, 3072, 768, True, True, False),
     "qkv_h": (25472, 2304, 768, True, False, False),
     "conv6_h": (25472, 512, 1024, False, True, False),
+    "c4_qkv": (1600, 2304, 768, True, False, False),     # configs[3]: 32 clips x T = 50 per branch
+    "c4_out": (1600, 768, 768, True, False, True),
+    "c4_fc1": (1600, 3072, 768, True, True, False),
+    "c4_fc2": (1600, 768, 3072, True, False, True),
+    "c4_conv1": (52384, 512, 1536, False, True, False),
+    "c4_conv2": (26176, 512, 1536, False, True, False),
+    "c4_conv3": (13056, 512, 1536, False, True, False),
+    "c4_conv4": (6528, 512, 1536, False, True, False),
     "proj_h": (25472, 768, 512, True, False, False),
     "conv4": (204544, 512, 1536, False, True, False),
 }
