@@ -18,6 +18,12 @@ SHAPES = {  # name: (M, N, K, bias, gelu, residual)
     "fc1": (50944, 3072, 768, True, True, False),
     "fc2": (50944, 768, 3072, True, False, True),
     "conv3": (409344, 512, 1536, False, True, False),
+    # half of the bench batch: what Engine.embed launches (two halves on two streams)
+    "out_h": (25472, 768, 768, True, False, True),
+    "qkv_h": (25472, 2304, 768, True, False, False),
+    "fc1_h": (25472, 3072, 768, True, True, False),
+    "fc2_h": (25472, 768, 3072, True, False, True),
+    "conv3_h": (204672, 512, 1536, False, True, False),
     "conv1": (1638144, 512, 1536, False, True, False),   # dense stand-in for conv1's implicit GEMM (10 GB of split A)
     "conv5": (102144, 512, 1024, False, True, False),
     "conv6": (50944, 512, 1024, False, True, False),

@@ -1,0 +1,79 @@
+// Does the MFMA SHAPE change the clock the chip holds?  (round 4)
+// On some boxes the fp32 forward holds 2253 MHz and the 256x128 GEMM (v_mfma_f32_32x32x2_f32) runs 4-5 % below its rate on other
+// boxes, while hipBLASLt's kernel (MT128x128x64_MI16x16x1 = v_mfma_f32_16x16x4_f32) runs the same on both.  Per multiply-add the
+// 32x32x2 shape reads and writes TWICE the accumulator registers of 16x16x4 (16 + 16 registers per 2048 MACs against 4 + 4 per 1024).
+// This micro streams one shape at a time on every SIMD (2 waves per SIMD, independent accumulators, no memory traffic), for
+// ~3 ms each, and reports TFLOP/s and the shader clock held (clock64 against the 100 MHz wall clock), several rounds alternating.
+// Build+run: hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_shape_power tools/micro/mfma_shape_power.hip && /tmp/mfma_shape_power
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int SHAPE>
+__global__ __launch_bounds__(512) void k(unsigned long long* out, float* sink, int iters) {
+    const float a = (float)(threadIdx.x & 7) * 0.25f, b = 0.5f;
+    const unsigned long long w0 = wall_clock64(), c0 = clock64();
+    float s = 0.f;
+    if (SHAPE == 0) {   // 4 accumulators of 32x32: 64 registers, 4 MFMAs x 64 cycles per k-step of 2
+        f32x16 acc[4];
+        for (int i = 0; i < 4; ++i)
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+        }
+        for (int i = 0; i < 4; ++i)
+            for (int r = 0; r < 16; ++r) s += acc[i][r];
+    } else {            // 16 accumulators of 16x16: 64 registers, 16 MFMAs x 32 cycles per k-step of 4 (same flops per iteration)
+        f32x4 acc[16];
+        for (int i = 0; i < 16; ++i)
+            for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+        }
+        for (int i = 0; i < 16; ++i)
+            for (int r = 0; r < 4; ++r) s += acc[i][r];
+    }
+    const unsigned long long w1 = wall_clock64(), c1 = clock64();
+    if (threadIdx.x == 0) {
+        out[blockIdx.x * 2] = w1 - w0;
+        out[blockIdx.x * 2 + 1] = c1 - c0;
+    }
+    if (s == 12345.678f) sink[0] = s;
+}
+
+int main() {
+    unsigned long long* out;
+    float* sink;
+    hipMalloc(&out, 256 * 2 * 8);
+    hipMalloc(&sink, 4);
+    unsigned long long h[512];
+    const int iters = 6000;   // 16 x 32x32x2 (or 32 x 16x16x4) MFMAs per iteration and wave = 65536 flops x 64... per wave: 16 * 4096 flops
+    for (int round = 0; round < 4; ++round)
+        for (int shape = 0; shape < 2; ++shape) {
+            hipEvent_t e0, e1;
+            hipEventCreate(&e0);
+            hipEventCreate(&e1);
+            hipEventRecord(e0);
+            if (shape == 0) hipLaunchKernelGGL(k<0>, dim3(256), dim3(512), 0, 0, out, sink, iters);
+            else hipLaunchKernelGGL(k<1>, dim3(256), dim3(512), 0, 0, out, sink, iters);
+            hipEventRecord(e1);
+            hipDeviceSynchronize();
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost);
+            double mhz = 0;
+            for (int i = 0; i < 256; ++i) mhz += (double)h[2 * i + 1] / ((double)h[2 * i] / 100.0);
+            mhz /= 256;
+            const double flops = 256.0 * 8 * iters * 16 * 4096.0;
+            printf("round %d  %-24s %7.3f ms  %6.1f TFLOP/s  shader clock %6.0f MHz\n", round, shape == 0 ? "v_mfma_f32_32x32x2_f32" : "v_mfma_f32_16x16x4_f32", ms,
+                   flops / ms / 1e9, mhz);
+        }
+    return 0;
+}
