@@ -618,7 +618,7 @@ def main():
                          if dom is big else "gemm_bf16_glds_kernel 128x64 (v_mfma_f32_32x32x16_bf16)")
             else:
                 kname = ("gemm_f32_glds_kernel<256,128,16,4,2,3> + gemm_f32_mixed_kernel (256x128 tiles, 128x128 tiles for the rows of the last round)"
-                         if dom is big else "gemm_f32_glds_kernel<128,128,32,4,2 / n48>") + " (v_mfma_f32_32x32x2_f32)"
+                         if dom is big else "gemm_f32_glds_kernel<128,128,32,4,2 / n48>") + " (v_mfma_f32_16x16x4_f32)"
             ach = rate(dom)
             traffic = alg_bytes = None
             if traffic_tab:

@@ -174,7 +174,7 @@ int nomad_enable_backward(nomad_ctx* ctx);
 int nomad_set_feature_grad_mult(nomad_ctx* ctx, float mult);
 /*
  * Arithmetic of the fp32-layout GEMMs (nomad_embed, nomad_embed_ragged, nomad_embed_train, nomad_embed_backward,
- * nomad_train_backward): mode 0 (default) exact fp32 MFMA (v_mfma_f32_32x32x2_f32, the reference's arithmetic); mode 1
+ * nomad_train_backward): mode 0 (default) exact fp32 MFMA (v_mfma_f32_16x16x4_f32, the reference's arithmetic); mode 1
  * "bf16x3 products": every product a*w as a_hi*w_hi + a_hi*w_lo + a_lo*w_hi on the bf16 matrix cores, hi = bf16(x),
  * lo = bf16(x - hi) made in registers, fp32 accumulation - all buffers, epilogues and every other kernel unchanged.  A GEMM
  * is then within ~3e-5 (relative) of the fp32 one and its K loop ~5x shorter: for the small-M problems of Nomad.forward()

@@ -440,6 +440,16 @@ __device__ __forceinline__ void gemm_f32_glds_body(const GemmParams& p, const in
     // unchanged (a*w == w*a): bit-identical results.  Plain C / R matrices only (with bit 16).
     constexpr bool TR = (OPT & 1024) != 0;
     static_assert(!TR || ((OPT & 16) && !X3 && !(OPT & 32)), "transposed accumulators: plain scoring epilogue only");
+    // M16 (round 4, every fp32-product instantiation): the products on v_mfma_f32_16x16x4_f32 instead of v_mfma_f32_32x32x2_f32 - the
+    // same 64 FLOP / clk / SIMD with HALF the accumulator register traffic per multiply-add (4 + 4 registers per 1024 MACs against
+    // 16 + 16 per 2048).  Why: on some boxes the chip holds 2313 MHz under the 32x32x2 kernel and 2392 MHz under hipBLASLt's
+    // MI16x16x1 kernel (tools/clock_under_load.py), and tools/micro/mfma_shape_power.hip shows the 32x32x2 stream's clock sagging as
+    // LDS reads and LDS-DMA are added while the 16x16x4 stream's does not.  A 32 x 32 accumulator block is 2 x 2 sub-blocks q = 2 si + sj
+    // (registers 4q .. 4q+3); a lane (fi = lane & 15, g = lane >> 4) reads one ds_read_b128 per 16-row operand sub-tile and 16 k -
+    // logical chunk 4 kh + g - whose element c feeds MFMA c: k-step c contracts k = 16 kh + {c, 4 + c, 8 + c, 12 + c}.  Per output
+    // element the order is kt, kh, c ascending in every instantiation (BK = 16 or 32): the tile choice changes no bit, as before.
+    constexpr bool M16 = !X3;
+    static_assert(!M16 || BK % 16 == 0, "16x16x4 products: 16-deep k groups");
     static_assert(BK == 8 || BK == 16 || BK == 32, "swizzle is written for 32-, 64- and 128-B rows");
     static_assert(BM * KC % NT == 0 && BN * KC % NT == 0 && TM >= 1 && TN >= 1, "bad tile");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -586,17 +596,131 @@ __device__ __forceinline__ void gemm_f32_glds_body(const GemmParams& p, const in
     for (int kq = 0; kq < BK / 8; ++kq) koff[kq] = ((kq * 2 + h) ^ swz) * 4;
     const int a_row_off = (wm * Cfg::WTM + frag_row) * BK;
     const int b_row_off = (wn * Cfg::WTN + frag_row) * BK;
+    // M16: row fi of a 16-row sub-tile, logical chunk 4 kh + g (16 si rows further on: the same swizzle, 16 is a multiple of RB * KC)
+    const int fi16 = lane & 15, g16 = lane >> 4;
+    const int swz16 = (fi16 / RB) % KC;
+    int koff16[BK / 16 > 0 ? BK / 16 : 1];
+#pragma unroll
+    for (int kh = 0; kh < BK / 16; ++kh) koff16[kh] = ((kh * 4 + g16) ^ swz16) * 4;
+    const int a_row_off16 = (wm * Cfg::WTM + fi16) * BK;
+    const int b_row_off16 = (wn * Cfg::WTN + fi16) * BK;
+    // acc[i][j] sub-block q (registers 4q .. 4q+3) += x (A side) * y (W side) over 4 k; TR: W as the first operand
+    auto mfma16 = [&](f32x16& a, const int q, const float x, const float y) {
+        f32x4 t = {a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
+        t = TR ? __builtin_amdgcn_mfma_f32_16x16x4f32(y, x, t, 0, 0, 0) : __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, t, 0, 0, 0);
+        a[4 * q] = t[0];
+        a[4 * q + 1] = t[1];
+        a[4 * q + 2] = t[2];
+        a[4 * q + 3] = t[3];
+    };
 
     SplitConsts sk{};
     if (X3) sk = split_consts();
     int cur = 0;  // LDS buffer of tile kt
-    if constexpr ((OPT & 64) != 0) {
+    if constexpr ((OPT & 64) != 0 && M16) {
+        // OPT bit 64 with the 16x16x4 products: the skewed schedule in QUARTERS of a K tile.  The 2 TM x 2 TN operand sub-tiles of a tile are
+        // read as halves A0 / A1 (sub-tile rows si = 0 / 1 of every 32-row block) and B0 / B1 (sj = 0 / 1); quarter (Aa, Bb) is the
+        // TM x TN x 4 MFMAs of those sub-blocks, all four k-steps c.  Order (A0,B0) (A0,B1) | barrier | (A1,B1) (A1,B0): every quarter
+        // reads the half the NEXT quarter needs - B1, A1, then the next tile's A0 and B0 (into the registers of the half that has just
+        // died) - so 2 TM + 2 TN float4 are live, as in the 32x32x2 schedule; the per-tile vmcnt + barrier sits between the second and
+        // the third quarter, behind this wave's last read of the tile, and the DMA of tile kt + 3 follows the third quarter's first
+        // k-step.  The next tile's B0 lands in the registers of this tile's B1: tiles alternate the two B register sets (P).
+        // Per accumulator sub-block the four k-steps of a tile stay together and ascend: bit-identical to the straight schedule.
+        static_assert(STAGES == 3 && BK == 16, "skewed 16x16x4 schedule: 3 stages, one 16-deep k group per tile");
+        constexpr int D = Cfg::A_CHUNKS + Cfg::B_CHUNKS;
+#define NOMAD_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+        if (nk > 2) {
+            NOMAD_GLDS_TILE(2, 2)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * D) : "memory");
+        } else if (nk > 1) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        NOMAD_FENCE();
+#ifdef NOMAD_DIAG
+        if (OPT & 128) ts_[(OPT & 8192) ? 4 : (OPT & 2048) ? 3 : 1] = wall_clock64();
+#endif
+        f32x4 a0[TM], a1[TM], bq[2][TN];
+        auto rdA = [&](f32x4 (&dst)[TM], int st, int si) {
+            const float* as = As + st * BM * BK + a_row_off16 + 16 * si * BK + koff16[0];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) dst[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * BK);
+        };
+        auto rdB = [&](f32x4 (&dst)[TN], int st, int sj) {
+            const float* bs = Bs + st * BN * BK + b_row_off16 + 16 * sj * BK + koff16[0];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) dst[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * BK);
+        };
+        auto mmq = [&](const f32x4 (&a)[TM], const int si, const f32x4 (&b)[TN], const int sj, const int c0, const int c1) {
+#pragma unroll
+            for (int c = c0; c < c1; ++c)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) mfma16(acc[i][j], 2 * si + sj, a[i][c], b[j][c]);
+        };
+        // one full tile (not the last): B0 of this tile sits in bq[P]
+        auto tile_step = [&](auto par_c, const int kt) {
+            constexpr int P = decltype(par_c)::value;
+            rdB(bq[P ^ 1], cur, 1);
+            NOMAD_FENCE();
+            mmq(a0, 0, bq[P], 0, 0, 4);
+            NOMAD_FENCE();
+            rdA(a1, cur, 1);
+            NOMAD_FENCE();
+            mmq(a0, 0, bq[P ^ 1], 1, 0, 4);
+            NOMAD_FENCE();
+            const int nxt = cur + 1 == STAGES ? 0 : cur + 1;
+            // this wave has read all of tile kt, and its share of tile kt+1 has landed (tile kt+2 may still be in flight)
+            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(D) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            NOMAD_FENCE();
+            rdA(a0, nxt, 0);
+            NOMAD_FENCE();
+            mmq(a1, 1, bq[P ^ 1], 1, 0, 1);
+            NOMAD_FENCE();
+            if (kt + 3 < nk) NOMAD_GLDS_TILE(kt + 3, cur)
+            NOMAD_FENCE();
+            mmq(a1, 1, bq[P ^ 1], 1, 1, 4);
+            NOMAD_FENCE();
+            rdB(bq[P ^ 1], nxt, 0);
+            NOMAD_FENCE();
+            mmq(a1, 1, bq[P], 0, 0, 4);
+            NOMAD_FENCE();
+            cur = nxt;
+        };
+        auto last_tile = [&](auto par_c) {
+            constexpr int P = decltype(par_c)::value;
+            rdB(bq[P ^ 1], cur, 1);
+            NOMAD_FENCE();
+            mmq(a0, 0, bq[P], 0, 0, 4);
+            NOMAD_FENCE();
+            rdA(a1, cur, 1);
+            NOMAD_FENCE();
+            mmq(a0, 0, bq[P ^ 1], 1, 0, 4);
+            NOMAD_FENCE();
+            mmq(a1, 1, bq[P ^ 1], 1, 0, 4);
+            mmq(a1, 1, bq[P], 0, 0, 4);
+        };
+        rdA(a0, 0, 0);
+        rdB(bq[0], 0, 0);
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            tile_step(std::integral_constant<int, 0>{}, kt);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bq[0][j] = bq[1][j];
+        }
+        last_tile(std::integral_constant<int, 0>{});
+#undef NOMAD_FENCE
+    } else if constexpr ((OPT & 64) != 0 && !M16) {
         // OPT bit 64 (round 4): the skewed schedule.  All three stages are kept in flight; the fragments of k-step s+1 are read before
         // the MFMAs of step s, and the per-tile vmcnt + barrier sits in front of a tile's LAST step, so the first fragments of tile
         // kt+1 are read behind it under that step's MFMAs and the DMA of tile kt+3 refills the buffer the barrier has just released.
         // A wave waits for the barrier and for nothing else.  Same contraction order per accumulator (kq ascending, c ascending):
         // bit-identical to the straight schedule.
-        static_assert(STAGES == 3 && !X3 && (BK / 8) % 2 == 0, "skewed schedule: 3 stages, fp32 products, an even number of k-steps");
+        static_assert(STAGES == 3 && (BK / 8) % 2 == 0, "skewed schedule: 3 stages, fp32 products, an even number of k-steps");
         constexpr int NKQ = BK / 8, D = Cfg::A_CHUNKS + Cfg::B_CHUNKS;
 #define NOMAD_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
         if (nk > 2) {
@@ -711,6 +835,28 @@ __device__ __forceinline__ void gemm_f32_glds_body(const GemmParams& p, const in
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                     }
             }
+        } else if (M16) {
+            const float* as16 = As + cur * BM * BK + a_row_off16;
+            const float* bs16 = Bs + cur * BN * BK + b_row_off16;
+#pragma unroll
+            for (int kh = 0; kh < BK / 16; ++kh) {
+                f32x4 af[2 * TM], bf[2 * TN];
+#pragma unroll
+                for (int i = 0; i < 2 * TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(as16 + i * 16 * BK + koff16[kh]);
+#pragma unroll
+                for (int j = 0; j < 2 * TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(bs16 + j * 16 * BK + koff16[kh]);
+                if (OPT & 2) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    // the DMA of tile kt + STAGES - 1 behind the first quarter of the tile's MFMAs (OPT & 8), as in the 32x32x2 loop
+                    if ((OPT & 8) && kh == BK / 16 - 1 && c == 1 && nxt < nk) NOMAD_GLDS_TILE(nxt, nb)
+#pragma unroll
+                    for (int i = 0; i < 2 * TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2 * TN; ++j) mfma16(acc[i >> 1][j >> 1], 2 * (i & 1) + (j & 1), af[i][c], bf[j][c]);
+                }
+                if (OPT & 2) __builtin_amdgcn_s_setprio(0);
+            }
         } else
 #pragma unroll
         for (int kq = 0; kq < BK / 8; ++kq) {
@@ -758,6 +904,37 @@ __device__ __forceinline__ void gemm_f32_glds_body(const GemmParams& p, const in
         // loaded BEFORE the first store: loads and stores share one in-order vmcnt, so a bias load issued behind a group of stores
         // can only be waited for together with those stores' acknowledgements - the first version loaded the bias per 32-column
         // block and paid two such round trips (timeline: 9 us from the end of the K loop to the last store issued for ~130 instructions).
+        if constexpr (M16) {
+            // 16x16x4 accumulators, W as the first operand: sub-block q = 2 si + sj of acc[i][j] holds output row 32 i + 16 si + fi,
+            // columns 32 j + 16 sj + 4 g .. + 3 - one 16-byte store per sub-block, 64 contiguous bytes per row and instruction
+            const int fi = lane_e & 15, gg = lane_e >> 4;
+            const int c_voff16 = (fi * p.cmap.ld + 4 * gg) * 4;
+            f32x4 b16[TN][2];
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int sj = 0; sj < 2; ++sj)   // a zero-length descriptor (no bias) reads as 0.0f
+                    b16[j][sj] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, (j * 32 + sj * 16 + 4 * gg) * 4, 0, 0));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int si = 0; si < 2; ++si)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int sj = 0; sj < 2; ++sj) {
+                            f32x4 v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * (2 * si + sj) + e] + b16[j][sj][e];
+                            if (p.gelu) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                            }
+                            if (!NOEPI || p.M < 0)   // (row-block offset in the VGPR offset: see the store-data hazard note below)
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rc,
+                                                                       c_voff16 + (i * 32 + si * 16) * p.cmap.ld * 4 + (j * 32 + sj * 16) * 4, 0, 0);
+                        }
+        } else {
         f32x4 b4[TN][4];
 #pragma unroll
         for (int j = 0; j < TN; ++j)
@@ -787,6 +964,7 @@ __device__ __forceinline__ void gemm_f32_glds_body(const GemmParams& p, const in
                 }
             }
         }
+        }   // !M16
     } else {
     // Epilogue through LDS: an accumulator holds one output column per lane (4-byte stores, 64 per lane and
     // tile).  Each wave parks a 32-row slab (acc + bias) in LDS, then every lane owns 4 consecutive columns of
@@ -815,6 +993,14 @@ __device__ __forceinline__ void gemm_f32_glds_body(const GemmParams& p, const in
     asm volatile("" : "+v"(lane_e));
     constexpr int NIT = 32 * CG / 64;
     float* slab = smem + wave * (32 * ELD);
+    float bv16[TN][2];   // M16: the bias of this lane's column in each 16-column sub-block
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int sj = 0; sj < 2; ++sj) {
+            const int n = n0 + wn * Cfg::WTN + j * 32 + sj * 16 + (lane_e & 15);
+            bv16[j][sj] = (M16 && biasg && n < p.n_valid) ? biasg[n] : 0.f;
+        }
     float bv[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -867,6 +1053,15 @@ __device__ __forceinline__ void gemm_f32_glds_body(const GemmParams& p, const in
         if (PL && !RA && Rg) prefetch(0);
         if (!(OPT & 1) || i == 0) __syncthreads();
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (M16) {   // 16x16x4 accumulators: sub-block q = 2 si + sj, register r: row 16 si + 4 g + r, column 16 sj + fi
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        slab[(16 * (q >> 1) + 4 * (lane_e >> 4) + r) * ELD + j * 32 + 16 * (q & 1) + (lane_e & 15)] = acc[i][j][4 * q + r] + bv16[j][q & 1];
+        } else
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll

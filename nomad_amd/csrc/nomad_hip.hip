@@ -3985,8 +3985,8 @@ int nomad_diag_gemm(nomad_ctx* c, const float* A, const float* W, const float* b
         if (N % 128 || K % 16) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: N %% 128 or K %% 16 != 0");
         GemmParams pp = dense(A, K, W, bias, R, C, M, N, K, gelu);
         Scope sc(c, static_cast<hipStream_t>(stream), NOMAD_K_GEMM, 2.0 * M * (double)N * K, NOMAD_K_GEMM_BIG);
-        HIP_TRY(tile == 84 ? (launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 64 | 1024>(pp, 1, static_cast<hipStream_t>(stream)))
-                           : (launch_gemm_glds<256, 128, 8, 2, 2, 3, false, 1 | 4 | 16 | 1024>(pp, 1, static_cast<hipStream_t>(stream))));
+        if (tile == 85) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile 85 (BK = 8) went with the 16x16x4 products (16-deep k groups)");
+        HIP_TRY((launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 64 | 1024>(pp, 1, static_cast<hipStream_t>(stream))));
         return 0;
     }
     if (tile == 82 || tile == 83 || tile == 87 || tile == 96) {   // (96: persistent, second workgroup of a CU starts half a tile late)

@@ -10,6 +10,61 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// MODE 1 / 2: the same MFMA stream fed like the GEMM's K loop - per 16 MFMAs of 32x32x2 (32 of 16x16x4) eight ds_read_b128 whose
+// values ARE the operands (MODE >= 1) and three 16-byte-per-lane LDS-DMA loads from a 4 MB buffer (L2 hits; MODE 2), two 8-wave
+// workgroups per CU as in the GEMM.
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+template <int SHAPE, int MODE>
+__global__ __launch_bounds__(512, 4) void kfed(unsigned long long* out, float* sink, const float* src, int iters) {
+    __shared__ __attribute__((aligned(16))) float lds[16384];   // 64 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 16384; i += 512) lds[i] = (float)(i & 7) * 0.125f;
+    __syncthreads();
+    const unsigned long long w0 = wall_clock64(), c0 = clock64();
+    const float* rd = lds + wave * 1024 + lane * 4;     // 16 bytes per lane, consecutive: conflict-free ds_read_b128
+    const float* g = src + ((blockIdx.x * 512 + tid) & 0xFFFF) * 16;
+    float s = 0.f;
+    f32x16 acc32[4];
+    f32x4 acc16[16];
+    for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 16; ++r) acc32[i][r] = 0.f;
+    for (int i = 0; i < 16; ++i)
+        for (int r = 0; r < 4; ++r) acc16[i][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+        f32x4 f[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) f[q] = *reinterpret_cast<const f32x4*>(rd + ((q * 256 + it * 64) & 8191));
+        if (MODE == 2) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                __builtin_amdgcn_global_load_lds((gptr_t)(g + q * 4 + ((it & 63) << 14)), (lptr_t)(lds + 8192 + q * 2048 + wave * 256), 16, 0, 0);
+        }
+        if (SHAPE == 0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc32[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[i >> 1][u], f[4 + (i & 1) * 2][u], acc32[i], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc16[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[i >> 2][u], f[4 + (i & 3)][u], acc16[i], 0, 0, 0);
+        }
+        if (MODE == 2 && (it & 7) == 7) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 16; ++r) s += acc32[i][r];
+    for (int i = 0; i < 16; ++i)
+        for (int r = 0; r < 4; ++r) s += acc16[i][r];
+    const unsigned long long w1 = wall_clock64(), c1 = clock64();
+    if (threadIdx.x == 0) {
+        out[blockIdx.x * 2] = w1 - w0;
+        out[blockIdx.x * 2 + 1] = c1 - c0;
+    }
+    if (s == 12345.678f) sink[0] = s + lds[tid];
+}
+
 template <int SHAPE>
 __global__ __launch_bounds__(512) void k(unsigned long long* out, float* sink, int iters) {
     const float a = (float)(threadIdx.x & 7) * 0.25f, b = 0.5f;
@@ -51,9 +106,9 @@ __global__ __launch_bounds__(512) void k(unsigned long long* out, float* sink, i
 int main() {
     unsigned long long* out;
     float* sink;
-    hipMalloc(&out, 256 * 2 * 8);
+    hipMalloc(&out, 512 * 2 * 8);
     hipMalloc(&sink, 4);
-    unsigned long long h[512];
+    unsigned long long h[1024];
     const int iters = 6000;   // 16 x 32x32x2 (or 32 x 16x16x4) MFMAs per iteration and wave = 65536 flops x 64... per wave: 16 * 4096 flops
     for (int round = 0; round < 4; ++round)
         for (int shape = 0; shape < 2; ++shape) {
@@ -75,5 +130,32 @@ int main() {
             printf("round %d  %-24s %7.3f ms  %6.1f TFLOP/s  shader clock %6.0f MHz\n", round, shape == 0 ? "v_mfma_f32_32x32x2_f32" : "v_mfma_f32_16x16x4_f32", ms,
                    flops / ms / 1e9, mhz);
         }
+    float* src;
+    hipMalloc(&src, 64 << 20);
+    hipMemset(src, 0, 64 << 20);
+    for (int mode = 1; mode <= 2; ++mode)
+        for (int round = 0; round < 3; ++round)
+            for (int shape = 0; shape < 2; ++shape) {
+                hipEvent_t e0, e1;
+                hipEventCreate(&e0);
+                hipEventCreate(&e1);
+                hipEventRecord(e0);
+                const int it2 = 4000;
+                if (mode == 1 && shape == 0) hipLaunchKernelGGL((kfed<0, 1>), dim3(512), dim3(512), 0, 0, out, sink, src, it2);
+                if (mode == 1 && shape == 1) hipLaunchKernelGGL((kfed<1, 1>), dim3(512), dim3(512), 0, 0, out, sink, src, it2);
+                if (mode == 2 && shape == 0) hipLaunchKernelGGL((kfed<0, 2>), dim3(512), dim3(512), 0, 0, out, sink, src, it2);
+                if (mode == 2 && shape == 1) hipLaunchKernelGGL((kfed<1, 2>), dim3(512), dim3(512), 0, 0, out, sink, src, it2);
+                hipEventRecord(e1);
+                hipDeviceSynchronize();
+                float ms;
+                hipEventElapsedTime(&ms, e0, e1);
+                hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost);
+                double mhz = 0;
+                for (int i = 0; i < 256; ++i) mhz += (double)h[2 * i + 1] / ((double)h[2 * i] / 100.0);
+                mhz /= 256;
+                const double flops = 512.0 * 8 * it2 * 16 * 4096.0;
+                printf("%-34s round %d  %-24s %7.3f ms  %6.1f TFLOP/s  shader clock %6.0f MHz\n", mode == 1 ? "operands from ds_read_b128" : "... + LDS-DMA loads (L2 hits)", round,
+                       shape == 0 ? "v_mfma_f32_32x32x2_f32" : "v_mfma_f32_16x16x4_f32", ms, flops / ms / 1e9, mhz);
+            }
     return 0;
 }
