@@ -27,15 +27,42 @@ constexpr int kF2KT = 32;                         // keys per LDS tile
 constexpr int kF2Buf = kF2KT * 256 + 64 * 128;    // K [32][64 f32] + V^T [64][32 f32] = 16 KB
 constexpr int attn_f32_v2_lds() { return 2 * kF2Buf; }
 
+// Round 4 (end): the products moved from v_mfma_f32_32x32x2_f32 to v_mfma_f32_16x16x4_f32 - the same rate with half the accumulator
+// register traffic per multiply-add; under the 32x32x2 version the chip held 2.03-2.14 GHz (profiles/r04_attention_f32_timeline.txt),
+// and the fp32 GEMM gained 3 % of clock from the same change (gemm_f32.hip.h, M16).  The structure above carries over with
+// lane = (fi = lane & 15, g = lane >> 4): a 32-key x 32-query block is 2 x 2 sub-blocks s[sk][sq], register r of which is
+// S^T[key 16 sk + 4 g + r][query 16 sq + fi]: a lane owns TWO queries (sq = 0, 1) and 8 of a block's scores for each, the four lanes
+// fi + 16 g share a query (maximum / sum: register tree + v_permlane16_swap + v_permlane32_swap), and register r of s[sk][sq] IS the B
+// operand of P.V's k-step (sk, r), which contracts keys 16 sk + r + {0, 4, 8, 12}.  K and Q are read as float4 chunks d = 16 j + 4 g .. + 3
+// (k-step (j, e) contracts d = 16 j + e + {0, 4, 8, 12}), V^T as chunks of keys 16 sk + 4 g .. + 3: eight ds_read_b128 per operand and
+// 32-key tile as before, 64 + 4 + 64 MFMAs of half the length.  The clip's last, partial key tile skips its second 16-key half
+// entirely (scores and P.V) when it is empty.
 // lse (nullable): [B*12][T] natural-log log-sum-exp of every score row (the backward recomputes P from it).
 // grid: 1-D, ceil(T / 128) * B * 12 workgroups of 256 threads; dynamic LDS attn_f32_v2_lds().
 // tpref (nullable): ragged batches - clip b owns rows tpref[b] .. tpref[b+1]-1; T is then the longest clip's.
+__device__ __forceinline__ float f2_max4(float x) {   // maximum over the four lanes fi, fi + 16, fi + 32, fi + 48, in all of them
+    const unsigned u = __float_as_uint(x);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float y = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    float lo, hi;
+    a2_halves(y, lo, hi);
+    return fmaxf(lo, hi);
+}
+__device__ __forceinline__ float f2_sum4(float x) {   // sum over the same four lanes (fixed order: rows 0+1, 2+3, then the halves)
+    const unsigned u = __float_as_uint(x);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float y = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    float lo, hi;
+    a2_halves(y, lo, hi);
+    return lo + hi;
+}
+
 __global__ __launch_bounds__(256, 3) void attention_f32_v2_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                                   float* __restrict__ lse, int T, int nqblk,
                                                                   const int* __restrict__ tpref, int t_min) {
     extern __shared__ __attribute__((aligned(16))) char f2_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
+    const int fi = lane & 15, g = lane >> 4;
     const int nwg = gridDim.x, id = blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = id & 7;
     const int virt = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
@@ -49,33 +76,32 @@ __global__ __launch_bounds__(256, 3) void attention_f32_v2_kernel(const float* _
     if (qb * 128 >= T || T < t_min) return;  // whole workgroup, before any barrier (t_min: ragged batches leave short clips
                                              // to attention_f32_kernel)
     const float* __restrict__ src_bh = qkv + row0 * 2304 + hd * 64;
-    const int q_row = qb * 128 + wave * 32 + r;
-    float4 qf[8];  // Q[q][8j + 4h .. + 3] * log2(e)
-    {
-        const float* qp = src_bh + (long long)(q_row < T ? q_row : T - 1) * 2304 + 4 * h;
+    const int q_base = qb * 128 + wave * 32;
+    float4 qf[2][4];  // Q[query 16 sq + fi][16 j + 4 g .. + 3] * log2(e)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float4 v = *reinterpret_cast<const float4*>(qp + 8 * j);
-            qf[j] = make_float4(v.x * kLog2e, v.y * kLog2e, v.z * kLog2e, v.w * kLog2e);
+    for (int sq = 0; sq < 2; ++sq) {
+        const int q_row = q_base + 16 * sq + fi;
+        const float* qp = src_bh + (long long)(q_row < T ? q_row : T - 1) * 2304 + 4 * g;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(qp + 16 * j);
+            qf[sq][j] = make_float4(v.x * kLog2e, v.y * kLog2e, v.z * kLog2e, v.w * kLog2e);
         }
     }
-    f32x16 o0, o1;  // O^T: d = 32*dblk + (i&3) + 8(i>>2) + 4h, this lane's query
+    f32x4 o[4][2];  // O^T: d = 16 sd + 4 g + r, query 16 sq + fi
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        o0[i] = 0.f;
-        o1[i] = 0.f;
-    }
-    float m_ref = 0.f, l_run = 0.f;
-    const float ones_a = h == 0 ? 1.f : 0.f;  // A[key][k = h] of the extra k-step
-    float negm_b = 0.f;                        // B[k = h][query] = (h == 0) ? -m_ref : 0
-    const bool wave_active = qb * 128 + wave * 32 < T;
+    for (int sd = 0; sd < 4; ++sd)
+#pragma unroll
+        for (int sq = 0; sq < 2; ++sq) o[sd][sq] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_ref[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};
+    const float ones_a = g == 0 ? 1.f : 0.f;   // A[key][k = g] of the extra k-step
+    float negm_b[2] = {0.f, 0.f};              // B[k = g][query] = (g == 0) ? -m_ref : 0
+    const bool wave_active = q_base < T;
     const int ntiles = (T + kF2KT - 1) / kF2KT;
 
-    // ---- staging: thread -> (key row, float4 chunk) x 2 of the 32 x 64 tile, for K and for V ----
-    // Round 4: K goes global -> LDS by LDS-DMA (the instruction fills 1 KB per wave linearly, so the thread fetches the LOGICAL chunk
-    // that the XOR swizzle maps to its slot: chunk ^ (row & 15)); only V, which is stored transposed, still passes through registers.
-    // Before, the eight staging registers of K pushed the loop over its 168-register budget: the compiler spilled and reloaded 8
-    // registers through scratch in every key tile (llvm-objdump of the round-3 kernel: scratch_store / scratch_load_dwordx4 x 2).
+    // ---- staging: thread -> (key row, float4 chunk) x 2 of the 32 x 64 tile, for K and for V (unchanged) ----
+    // K goes global -> LDS by LDS-DMA (the instruction fills 1 KB per wave linearly, so the thread fetches the LOGICAL chunk that the XOR
+    // swizzle maps to its slot: chunk ^ (row & 15)); only V, which is stored transposed, passes through registers.
     float4 vreg[2];
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     auto fetch = [&](int kt) {
@@ -106,9 +132,9 @@ __global__ __launch_bounds__(256, 3) void attention_f32_v2_kernel(const float* _
         }
     };
     // ---- fragment addresses inside a buffer ----
-    const int k_base = r * 256 + 16 * (h ^ (r & 1)), k_x = (r >> 1) & 7;       // chunk 2j + h of row r at 32 * (j ^ k_x)
-    const int v_x = (r >> 1) & 7;                                               // V^T row d = r (+ 32): chunk 2m + h
-    const int v_base = kF2KT * 256 + r * 128 + 16 * (h ^ (v_x & 1)), v_xm = v_x >> 1;  // at 32 * (m ^ v_xm)
+    // K row (16 sk + fi): 256 B, logical chunk 4 j + g at physical chunk ^ fi; V^T row d = 16 sd + fi: 128 B, logical chunk 4 sk + g
+    // (keys 16 sk + 4 g .. + 3) at physical chunk ^ ((fi >> 1) & 7)
+    const int k_base = fi * 256, v_base = kF2KT * 256 + fi * 128, v_x = (fi >> 1) & 7;
 
     fetch(0);
     stage(0);
@@ -117,94 +143,110 @@ __global__ __launch_bounds__(256, 3) void attention_f32_v2_kernel(const float* _
         if (kt + 1 < ntiles) fetch(kt + 1);
         if (wave_active) {
             const char* B0 = f2_lds + (kt & 1) * kF2Buf;
-            // ---- S^T - m_ref (log2 units) for 32 keys x 32 queries ----
-            f32x16 s;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) s[i] = 0.f;
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(ones_a, negm_b, s, 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float4 kf = *reinterpret_cast<const float4*>(B0 + k_base + 32 * (j ^ k_x));
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[j].x, s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[j].y, s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[j].z, s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[j].w, s, 0, 0, 0);
-            }
             const int valid = T - kt * kF2KT;
-            if (valid < 32) {  // the clip's last, partial block
+            const int nsk = valid > 16 ? 2 : 1;   // the clip's last block may have an empty second half
+            // ---- S^T - m_ref (log2 units): 2 x 2 sub-blocks of 16 keys x 16 queries ----
+            f32x4 s[2][2];
 #pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    if ((i & 3) + 8 * (i >> 2) + 4 * h >= valid) s[i] = -1e30f;
+            for (int sk = 0; sk < 2; ++sk)
+#pragma unroll
+                for (int sq = 0; sq < 2; ++sq) s[sk][sq] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sk = 0; sk < 2; ++sk) {
+                if (sk < nsk) {
+#pragma unroll
+                    for (int sq = 0; sq < 2; ++sq) s[sk][sq] = __builtin_amdgcn_mfma_f32_16x16x4f32(ones_a, negm_b[sq], s[sk][sq], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float4 kf = *reinterpret_cast<const float4*>(B0 + k_base + sk * 4096 + 16 * ((4 * j + g) ^ fi));
+#pragma unroll
+                        for (int sq = 0; sq < 2; ++sq) {
+                            s[sk][sq] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[sq][j].x, s[sk][sq], 0, 0, 0);
+                            s[sk][sq] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[sq][j].y, s[sk][sq], 0, 0, 0);
+                            s[sk][sq] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[sq][j].z, s[sk][sq], 0, 0, 0);
+                            s[sk][sq] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[sq][j].w, s[sk][sq], 0, 0, 0);
+                        }
+                    }
+                }
             }
-            // ---- block maximum; first / last operations compiler-visible (MFMA -> VALU and VALU -> permlane wait states) ----
-            float pm = fmaxf(s[0], s[1]);
-            pm = a2_max3(pm, s[2], s[3]);
-            pm = a2_max3(pm, s[4], s[5]);
-            pm = a2_max3(pm, s[6], s[7]);
-            pm = a2_max3(pm, s[8], s[9]);
-            pm = a2_max3(pm, s[10], s[11]);
-            pm = a2_max3(pm, s[12], s[13]);
-            pm = fmaxf(pm, fmaxf(s[14], s[15]));
-            float plo, phi;
-            a2_halves(pm, plo, phi);
-            const float pmax = fmaxf(plo, phi);  // relative to m_ref
-            if (kt == 0 || __any(pmax > kA2Thr)) {  // rare after the first block: move the reference maximum
-                const float delta = kt == 0 ? pmax : fmaxf(pmax, 0.f);
-                const float alpha = __builtin_amdgcn_exp2f(-delta);
-                o0 *= alpha;
-                o1 *= alpha;
-                l_run *= alpha;
+            if (valid < 32) {  // the clip's last, partial block (an empty second half stays out of everything below through nsk)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) s[i] -= delta;
-                m_ref += delta;
-                negm_b = h == 0 ? -m_ref : 0.f;
+                for (int sk = 0; sk < 2; ++sk)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (16 * sk + 4 * g + r >= valid) {
+                            s[sk][0][r] = -1e30f;
+                            s[sk][1][r] = -1e30f;
+                        }
             }
-            // ---- p = 2^(s - m_ref), row sums; register i of s is k-step i of P.V ----
+            // ---- block maximum per query (8 scores in this lane, 4 lanes per query) ----
+            float pmax[2];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(s[i]);
-            float ls0 = 0.f, ls1 = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; i += 2) {
-                ls0 += s[i];
-                ls1 += s[i + 1];
+            for (int sq = 0; sq < 2; ++sq) {
+                float pm = fmaxf(s[0][sq][0], s[0][sq][1]);
+                pm = a2_max3(pm, s[0][sq][2], s[0][sq][3]);
+                pm = a2_max3(pm, s[1][sq][0], s[1][sq][1]);
+                pm = fmaxf(pm, fmaxf(s[1][sq][2], s[1][sq][3]));
+                pmax[sq] = f2_max4(pm);   // relative to m_ref
             }
-            l_run += ls0 + ls1;
-            // ---- O^T += V^T P^T: k-step i contracts keys (i&3) + 8(i>>2) (+4 in lanes 32-63); the groups of four k-steps
-            // (8 keys) past the clip's end in its last, partial block are skipped (their p are exact zeros) ----
-            const int ngrp = valid >= 32 ? 4 : (valid + 7) >> 3;
+            if (kt == 0 || __any(fmaxf(pmax[0], pmax[1]) > kA2Thr)) {  // rare after the first block: move the reference maxima
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                if (m < ngrp) {
-                    const float4 v0 = *reinterpret_cast<const float4*>(B0 + v_base + 32 * (m ^ v_xm));
-                    const float4 v1 = *reinterpret_cast<const float4*>(B0 + v_base + 4096 + 32 * (m ^ v_xm));
-                    o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0.x, s[4 * m], o0, 0, 0, 0);
-                    o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1.x, s[4 * m], o1, 0, 0, 0);
-                    o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0.y, s[4 * m + 1], o0, 0, 0, 0);
-                    o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1.y, s[4 * m + 1], o1, 0, 0, 0);
-                    o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0.z, s[4 * m + 2], o0, 0, 0, 0);
-                    o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1.z, s[4 * m + 2], o1, 0, 0, 0);
-                    o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0.w, s[4 * m + 3], o0, 0, 0, 0);
-                    o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1.w, s[4 * m + 3], o1, 0, 0, 0);
+                for (int sq = 0; sq < 2; ++sq) {
+                    const float delta = kt == 0 ? pmax[sq] : fmaxf(pmax[sq], 0.f);
+                    const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+                    for (int sd = 0; sd < 4; ++sd) o[sd][sq] *= alpha;
+                    l_run[sq] *= alpha;
+#pragma unroll
+                    for (int sk = 0; sk < 2; ++sk)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) s[sk][sq][r] -= delta;
+                    m_ref[sq] += delta;
+                    negm_b[sq] = g == 0 ? -m_ref[sq] : 0.f;
+                }
+            }
+            // ---- p = 2^(s - m_ref), row sums; register r of s[sk][sq] is k-step (sk, r) of P.V ----
+#pragma unroll
+            for (int sq = 0; sq < 2; ++sq) {
+#pragma unroll
+                for (int sk = 0; sk < 2; ++sk)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[sk][sq][r] = __builtin_amdgcn_exp2f(s[sk][sq][r]);
+                l_run[sq] += ((s[0][sq][0] + s[0][sq][1]) + (s[0][sq][2] + s[0][sq][3])) + ((s[1][sq][0] + s[1][sq][1]) + (s[1][sq][2] + s[1][sq][3]));
+            }
+            // ---- O^T += V^T P^T: k-step (sk, r) contracts keys 16 sk + r + {0, 4, 8, 12} ----
+#pragma unroll
+            for (int sk = 0; sk < 2; ++sk) {
+                if (sk < nsk) {
+#pragma unroll
+                    for (int sd = 0; sd < 4; ++sd) {
+                        const float4 vf = *reinterpret_cast<const float4*>(B0 + v_base + sd * 2048 + 16 * ((4 * sk + g) ^ v_x));
+#pragma unroll
+                        for (int sq = 0; sq < 2; ++sq) {
+                            o[sd][sq] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.x, s[sk][sq][0], o[sd][sq], 0, 0, 0);
+                            o[sd][sq] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.y, s[sk][sq][1], o[sd][sq], 0, 0, 0);
+                            o[sd][sq] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.z, s[sk][sq][2], o[sd][sq], 0, 0, 0);
+                            o[sd][sq] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.w, s[sk][sq][3], o[sd][sq], 0, 0, 0);
+                        }
+                    }
                 }
             }
         }
         if (kt + 1 < ntiles) stage((kt + 1) & 1);
         __syncthreads();
     }
-    float llo, lhi;
-    a2_halves(l_run, llo, lhi);
-    const float l_tot = llo + lhi;
-    const float inv = 1.0f / l_tot;
-    if (q_row < T) {
-        if (lse && h == 0)  // natural-log units; the two terms are large and nearly cancel in fp32: one float64 expression per query
-            lse[(long long)bh * T + q_row] = (float)(((double)m_ref + log2((double)l_tot)) * 0.69314718055994531);
-        float* dst = out + (row0 + q_row) * 768 + hd * 64 + 4 * h;
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            *reinterpret_cast<float4*>(dst + 8 * g4) =
-                make_float4(o0[4 * g4] * inv, o0[4 * g4 + 1] * inv, o0[4 * g4 + 2] * inv, o0[4 * g4 + 3] * inv);
-            *reinterpret_cast<float4*>(dst + 32 + 8 * g4) =
-                make_float4(o1[4 * g4] * inv, o1[4 * g4 + 1] * inv, o1[4 * g4 + 2] * inv, o1[4 * g4 + 3] * inv);
+    for (int sq = 0; sq < 2; ++sq) {
+        const float l_tot = f2_sum4(l_run[sq]);
+        const float inv = 1.0f / l_tot;
+        const int q_row = q_base + 16 * sq + fi;
+        if (q_row < T) {
+            if (lse && g == 0)  // natural-log units; the two terms are large and nearly cancel in fp32: one float64 expression per query
+                lse[(long long)bh * T + q_row] = (float)(((double)m_ref[sq] + log2((double)l_tot)) * 0.69314718055994531);
+            float* dst = out + (row0 + q_row) * 768 + hd * 64 + 4 * g;
+#pragma unroll
+            for (int sd = 0; sd < 4; ++sd)
+                *reinterpret_cast<float4*>(dst + 16 * sd) = make_float4(o[sd][sq][0] * inv, o[sd][sq][1] * inv, o[sd][sq][2] * inv, o[sd][sq][3] * inv);
         }
     }
 }
