@@ -432,12 +432,12 @@ template <int BM, int BN, int BK, int WM, int WN, int STAGES = 2, bool NOEPI = f
 __device__ __forceinline__ void gemm_f32_glds_body(const GemmParams& p, const int blk_x, const int grid_x, const int grp) {
     using Cfg = GldsCfg<BM, BN, BK, WM, WN, STAGES>;
     constexpr int TM = Cfg::TM, TN = Cfg::TN, NT = Cfg::THREADS, KC = Cfg::KC, RB = Cfg::RB;
-    // OPT bit 1024 (round 4): TRANSPOSED accumulators + direct epilogue.  The two operands of v_mfma_f32_32x32x2_f32 have the same
-    // lane layout, so passing W as the first and A as the second operand leaves D^T in the same registers: a lane then owns ONE
-    // output row (lane & 31) and, per accumulator, four runs of four CONSECUTIVE columns - 16-byte stores straight from the
-    // accumulators, no LDS slab, no barrier between the K loop and the stores, no per-store address arithmetic (buffer
-    // descriptors: per-lane offset + scalar row-block offset + immediate).  Products and their order per output element are
-    // unchanged (a*w == w*a): bit-identical results.  Plain C / R matrices only (with bit 16).
+    // OPT bit 1024 (round 4): TRANSPOSED accumulators + direct epilogue.  The two operands of the MFMA have the same lane layout, so
+    // passing W as the first and A as the second operand leaves D^T in the same registers: a lane then owns ONE output row per
+    // 16-row sub-block (lane & 15) and four CONSECUTIVE columns of it (4 (lane >> 4) .. + 3) - 16-byte stores straight from the
+    // accumulators, no LDS slab, no barrier between the K loop and the stores, no per-store address arithmetic (buffer descriptor:
+    // per-lane offset + immediate).  Products and their order per output element are unchanged (a*w == w*a): bit-identical
+    // results.  Plain C matrices only (with bit 16), no residual.
     constexpr bool TR = (OPT & 1024) != 0;
     static_assert(!TR || ((OPT & 16) && !X3 && !(OPT & 32)), "transposed accumulators: plain scoring epilogue only");
     // M16 (round 4, every fp32-product instantiation): the products on v_mfma_f32_16x16x4_f32 instead of v_mfma_f32_32x32x2_f32 - the
@@ -617,8 +617,10 @@ __device__ __forceinline__ void gemm_f32_glds_body(const GemmParams& p, const in
     SplitConsts sk{};
     if (X3) sk = split_consts();
     int cur = 0;  // LDS buffer of tile kt
-    if constexpr ((OPT & 64) != 0 && M16) {
-        // OPT bit 64 with the 16x16x4 products: the skewed schedule in QUARTERS of a K tile.  The 2 TM x 2 TN operand sub-tiles of a tile are
+    if constexpr ((OPT & 64) != 0) {
+        static_assert(M16, "skewed schedule: fp32 products only");
+        // OPT bit 64 (round 4): the skewed schedule, in QUARTERS of a K tile.  A wave waits for the barrier and for nothing else: all three
+        // stages stay in flight, the fragments a quarter needs are read under the previous quarter's MFMAs.  The 2 TM x 2 TN operand sub-tiles of a tile are
         // read as halves A0 / A1 (sub-tile rows si = 0 / 1 of every 32-row block) and B0 / B1 (sj = 0 / 1); quarter (Aa, Bb) is the
         // TM x TN x 4 MFMAs of those sub-blocks, all four k-steps c.  Order (A0,B0) (A0,B1) | barrier | (A1,B1) (A1,B0): every quarter
         // reads the half the NEXT quarter needs - B1, A1, then the next tile's A0 and B0 (into the registers of the half that has just
@@ -714,80 +716,6 @@ __device__ __forceinline__ void gemm_f32_glds_body(const GemmParams& p, const in
         }
         last_tile(std::integral_constant<int, 0>{});
 #undef NOMAD_FENCE
-    } else if constexpr ((OPT & 64) != 0 && !M16) {
-        // OPT bit 64 (round 4): the skewed schedule.  All three stages are kept in flight; the fragments of k-step s+1 are read before
-        // the MFMAs of step s, and the per-tile vmcnt + barrier sits in front of a tile's LAST step, so the first fragments of tile
-        // kt+1 are read behind it under that step's MFMAs and the DMA of tile kt+3 refills the buffer the barrier has just released.
-        // A wave waits for the barrier and for nothing else.  Same contraction order per accumulator (kq ascending, c ascending):
-        // bit-identical to the straight schedule.
-        static_assert(STAGES == 3 && (BK / 8) % 2 == 0, "skewed schedule: 3 stages, fp32 products, an even number of k-steps");
-        constexpr int NKQ = BK / 8, D = Cfg::A_CHUNKS + Cfg::B_CHUNKS;
-#define NOMAD_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-        if (nk > 2) {
-            NOMAD_GLDS_TILE(2, 2)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * D) : "memory");
-        } else if (nk > 1) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        NOMAD_FENCE();
-#ifdef NOMAD_DIAG
-        if (OPT & 128) ts_[(OPT & 8192) ? 4 : (OPT & 2048) ? 3 : 1] = wall_clock64();
-#endif
-        f32x4 af[2][TM], bf[2][TN];
-        auto rd = [&](int buf, int st, int kq) {
-            const float* as = As + st * BM * BK + a_row_off;
-            const float* bs = Bs + st * BN * BK + b_row_off;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[buf][i] = *reinterpret_cast<const f32x4*>(as + i * 32 * BK + koff[kq]);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[buf][j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * BK + koff[kq]);
-        };
-        auto mm = [&](int buf, int c0, int c1) {
-#pragma unroll
-            for (int c = c0; c < c1; ++c)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = TR ? __builtin_amdgcn_mfma_f32_32x32x2f32(bf[buf][j][c], af[buf][i][c], acc[i][j], 0, 0, 0)
-                                       : __builtin_amdgcn_mfma_f32_32x32x2f32(af[buf][i][c], bf[buf][j][c], acc[i][j], 0, 0, 0);
-        };
-        rd(0, 0, 0);
-        for (int kt = 0; kt + 1 < nk; ++kt) {
-#pragma unroll
-            for (int kq = 0; kq + 1 < NKQ; ++kq) {
-                rd((kq + 1) & 1, cur, kq + 1);
-                NOMAD_FENCE();
-                mm(kq & 1, 0, 4);
-                NOMAD_FENCE();
-            }
-            const int nxt = cur + 1 == STAGES ? 0 : cur + 1;
-            // this wave has read all of tile kt, and its share of tile kt+1 has landed (tile kt+2 may still be in flight)
-            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(D) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            NOMAD_FENCE();
-            rd(0, nxt, 0);
-            NOMAD_FENCE();
-            mm((NKQ - 1) & 1, 0, 1);
-            NOMAD_FENCE();
-            if (kt + 3 < nk) NOMAD_GLDS_TILE(kt + 3, cur)
-            NOMAD_FENCE();
-            mm((NKQ - 1) & 1, 1, 4);
-            NOMAD_FENCE();
-            cur = nxt;
-        }
-#pragma unroll
-        for (int kq = 0; kq < NKQ; ++kq) {   // the last tile
-            if (kq + 1 < NKQ) rd((kq + 1) & 1, cur, kq + 1);
-            NOMAD_FENCE();
-            mm(kq & 1, 0, 4);
-            NOMAD_FENCE();
-        }
-#undef NOMAD_FENCE
     } else
     for (int kt = 0; kt < nk; ++kt) {
         if (STAGES == 2) {
@@ -835,7 +763,7 @@ __device__ __forceinline__ void gemm_f32_glds_body(const GemmParams& p, const in
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                     }
             }
-        } else if (M16) {
+        } else {
             const float* as16 = As + cur * BM * BK + a_row_off16;
             const float* bs16 = Bs + cur * BN * BK + b_row_off16;
 #pragma unroll
@@ -857,25 +785,6 @@ __device__ __forceinline__ void gemm_f32_glds_body(const GemmParams& p, const in
                 }
                 if (OPT & 2) __builtin_amdgcn_s_setprio(0);
             }
-        } else
-#pragma unroll
-        for (int kq = 0; kq < BK / 8; ++kq) {
-            if ((OPT & 8) && kq == 1 && nxt < nk) NOMAD_GLDS_TILE(nxt, nb)
-            f32x4 af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * BK + koff[kq]);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * BK + koff[kq]);
-            if (OPT & 2) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = TR ? __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][c], af[i][c], acc[i][j], 0, 0, 0)
-                                       : __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][c], bf[j][c], acc[i][j], 0, 0, 0);
-            if (OPT & 2) __builtin_amdgcn_s_setprio(0);
         }
         cur = cur + 1 == STAGES ? 0 : cur + 1;
     }
@@ -890,7 +799,6 @@ __device__ __forceinline__ void gemm_f32_glds_body(const GemmParams& p, const in
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));   // keep the per-lane offsets below out of the K loop's live ranges
         const int mw = m0 + wm * Cfg::WTM, nw = n0 + wn * Cfg::WTN;   // this wave's first output row / column (uniform)
-        const int mrow = lane_e & 31, hh = lane_e >> 5;
         auto clamp_bytes = [](long long v) { return (unsigned)(v < 0 ? 0 : (v > (1ll << 30) ? (1ll << 30) : v)); };
         // rows >= M lie beyond num_records and are dropped (stores) / read as zero (loads) by the buffer addressing itself
         const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
@@ -898,13 +806,12 @@ __device__ __forceinline__ void gemm_f32_glds_body(const GemmParams& p, const in
             clamp_bytes((long long)(p.M - mw) * p.cmap.ld * 4), 0x00020000);
         const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(uniform_ptr(p.bias ? p.bias + grp * p.bias_goff + nw : p.C)), 0, p.bias ? (unsigned)(Cfg::WTN * 4) : 0u, 0x00020000);
-        const int c_voff = (mrow * p.cmap.ld + 4 * hh) * 4, b_voff = 16 * hh;
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         // GEMMs WITHOUT a residual only (the caller checks; residual GEMMs keep the LDS epilogue).  All bias values of the wave tile are
         // loaded BEFORE the first store: loads and stores share one in-order vmcnt, so a bias load issued behind a group of stores
         // can only be waited for together with those stores' acknowledgements - the first version loaded the bias per 32-column
         // block and paid two such round trips (timeline: 9 us from the end of the K loop to the last store issued for ~130 instructions).
-        if constexpr (M16) {
+        {
             // 16x16x4 accumulators, W as the first operand: sub-block q = 2 si + sj of acc[i][j] holds output row 32 i + 16 si + fi,
             // columns 32 j + 16 sj + 4 g .. + 3 - one 16-byte store per sub-block, 64 contiguous bytes per row and instruction
             const int fi = lane_e & 15, gg = lane_e >> 4;
@@ -930,41 +837,15 @@ __device__ __forceinline__ void gemm_f32_glds_body(const GemmParams& p, const in
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
                             }
-                            if (!NOEPI || p.M < 0)   // (row-block offset in the VGPR offset: see the store-data hazard note below)
+                            // The row-block offset goes into the VGPR offset, NOT the scalar offset: with an SGPR soffset the compiler's hazard
+                            // recogniser ("VMEM store of more than 8 bytes followed by a VALU write of the data registers") emits no wait state,
+                            // and on gfx950 the v_add of the next chunk, issued right behind buffer_store_dwordx4 ... sN offen, corrupted
+                            // element 0 of lanes 12-15 / 28-31 / 44-47 / 60-63 (tools/micro/store_hazard.hip, profiles/r04_store_hazard_micro.txt)
+                            if (!NOEPI || p.M < 0)   // (NOEPI, a timing probe: the never-true condition keeps the arithmetic alive)
                                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rc,
                                                                        c_voff16 + (i * 32 + si * 16) * p.cmap.ld * 4 + (j * 32 + sj * 16) * 4, 0, 0);
                         }
-        } else {
-        f32x4 b4[TN][4];
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)   // a zero-length descriptor (no bias) reads as 0.0f
-                b4[j][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, b_voff + (j * 32 + 8 * g) * 4, 0, 0));
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + b4[j][g][e];
-                    if (p.gelu) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-                    }
-                    // The row-block offset goes into the VGPR offset, NOT the scalar offset: with an SGPR soffset the compiler's
-                    // hazard recogniser (LLVM GCNHazardRecognizer, "VMEM store of more than 8 bytes followed by a VALU write of
-                    // the data registers") emits no wait state, and on gfx950 the v_add of the next chunk, issued right behind
-                    // buffer_store_dwordx4 ... s53 offen, then corrupted element 0 of lanes 12-15 / 28-31 / 44-47 / 60-63
-                    // (tools/micro/store_hazard.hip, profiles/r04_store_hazard_micro.txt)
-                    if (!NOEPI || p.M < 0)   // (NOEPI, a timing probe: the never-true condition keeps the arithmetic alive)
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rc, c_voff + i * 32 * p.cmap.ld * 4 + (j * 32 + 8 * g) * 4, 0, 0);
-                }
-            }
         }
-        }   // !M16
     } else {
     // Epilogue through LDS: an accumulator holds one output column per lane (4-byte stores, 64 per lane and
     // tile).  Each wave parks a 32-row slab (acc + bias) in LDS, then every lane owns 4 consecutive columns of

@@ -25,8 +25,14 @@ def load_vendor():
     for _ in range(40): torch.matmul(A, Wt, out=Co)
 def load_gemm_noepi():   # the shipped dispatch without bias / GELU (what the vendor line computes)
     for _ in range(40): eng.diag_gemm(A, W, None, None, gelu=False, tile=33)
+qkv32 = (torch.randn(256 * 199, 2304, generator=g) * 0.5).cuda()
+qkv16 = (torch.randn(32 * 1499, 2304, generator=g) * 0.5).cuda().bfloat16()
+def load_attn32():
+    for _ in range(60): eng.diag_attention(qkv32, 256, 199)
+def load_attn16():
+    for _ in range(100): eng.diag_attention_bf16(qkv16, 32, 1499, True)
 res = {}
-for name, fn, ms in (("idle", lambda: None, 20), ("fp32_gemm_256x128_fc1", load_gemm, 40), ("fp32_gemm_256x128_fc1_no_epilogue", load_gemm_noepi, 40),
+for name, fn, ms in (("fp32_attention_256x199", load_attn32, 20), ("bf16_attention_32x1499", load_attn16, 20), ("idle", lambda: None, 20), ("fp32_gemm_256x128_fc1", load_gemm, 40), ("fp32_gemm_256x128_fc1_no_epilogue", load_gemm_noepi, 40),
                      ("hipblaslt_fp32_fc1", load_vendor, 40), ("fp32_forward_256x4s", load_fwd, 200), ("bf16_gemm_8phase_fc1", load_bf16, 40)):
     fn(); torch.cuda.synchronize()          # warm
     fn()                                    # load in flight on the main stream
