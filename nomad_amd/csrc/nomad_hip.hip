@@ -818,9 +818,9 @@ int mixed_split_rows(int M, int N) {
 
 int pick_tile(int M, int N, int K) {
     const long long tiles256 = (long long)((M + 255) / 256) * (N / 128);
-    // where the two-shape launch applies (run_gemm turns tile 33 into it) it is taken over 128 x 128 tiles: +0.3 % of the bench step
-    // (NOMAD_F32_MIXED_PREFER=0: the 128 x 128 choice below first)
-    static const bool prefer_mixed = [] { const char* e = getenv("NOMAD_F32_MIXED_PREFER"); return !e || atoi(e) != 0; }();
+    // (NOMAD_F32_MIXED_PREFER=1, A/B: wherever the two-shape launch applies - run_gemm turns tile 33 into it - take it over the
+    // 128 x 128 choice below.  Was +0.3 % of the bench step with the 32x32x2 products, is -0.4 % with 16x16x4: off.)
+    static const bool prefer_mixed = [] { const char* e = getenv("NOMAD_F32_MIXED_PREFER"); return e && atoi(e) != 0; }();
     if (prefer_mixed && N % 128 == 0 && mixed_split_rows(M, N) > 0) return 33;
     // 1500, not 2048: a half of the bench batch (Engine.embed runs the batch as two halves on two streams) has 1800 tiles in
     // QKV and 1600 in conv4 - the 256x128 kernel there is worth +0.5 % of the step (2230-2235 vs 2219-2222 clips/s, alternating)
@@ -844,7 +844,11 @@ int pick_tile(int M, int N, int K) {
         return cost128 < (double)per_cu_256 ? 31 : 33;
     }
     if (N % 128 == 0 && tiles256 >= 1500) return 33;
-    if (N % 128 == 0 && tiles256 >= 512 && (K >= 2048 || K <= 512)) return 33;
+    // (NOMAD_F32_LONGK_33=1, A/B: one to two rounds of 256 x 128 tiles with a long or short K - fc2 / proj of HALF a bench batch - on
+    // the 256 x 128 kernel, as up to round 4; with the 16x16x4 products the 128 x 128 x 32 kernel is faster and steadier there:
+    // fc2 of half a batch 133.1 against 125 TFLOP/s median, out_proj 127 against 114)
+    static const bool longk33 = [] { const char* e = getenv("NOMAD_F32_LONGK_33"); return e && atoi(e) != 0; }();
+    if (longk33 && N % 128 == 0 && tiles256 >= 512 && (K >= 2048 || K <= 512)) return 33;
     // less than one round of 256x128 tiles (batch 1 .. a few dozen short clips, config C4): 64x64 tiles keep the
     // most CUs busy; one wave's K loop is the latency floor there (profiles/r01_gemm_sweep_small_m.json)
     if (tiles256 < 512) return 37;
