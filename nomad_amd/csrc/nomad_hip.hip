@@ -826,7 +826,7 @@ int pick_tile(int M, int N, int K) {
     // QKV and 1600 in conv4 - the 256x128 kernel there is worth +0.5 % of the step (2230-2235 vs 2219-2222 clips/s, alternating)
     // 256 x 128 or 128 x 128 (round 4)?  Two workgroups share a CU and a lone one runs about twice as fast, so what a launch costs
     // is the largest number of tiles any CU gets: ceil(tiles / CUs) big tiles against ceil(2 tiles / CUs) half-size ones, the latter
-    // ~3 % dearer per flop (more operand traffic per MFMA).  conv5 at the bench batch is 1596 big tiles = 6.2 per CU -> 7, or 3192
+    // ~8 % dearer per flop (more operand traffic per MFMA; 3 % before the 16x16x4 products).  conv5 at the bench batch is 1596 big tiles = 6.2 per CU -> 7, or 3192
     // small ones = 12.5 -> 13 halves = 6.5: 135 vs 127 TFLOP/s measured (profiles/r04_gemm_f32_variants.txt).  NOMAD_F32_QUANT_TILE=0:
     // the round-3 rule.
     static const bool quant = [] {
@@ -838,7 +838,7 @@ int pick_tile(int M, int N, int K) {
         const long long tiles128 = (long long)((M + 127) / 128) * (N / 128);
         static const double penalty = [] {   // what a flop costs more on 128 x 128 tiles (NOMAD_F32_QUANT_PENALTY, percent; A/B runs)
             const char* e = getenv("NOMAD_F32_QUANT_PENALTY");
-            return 1.0 + (e ? atof(e) : 3.0) / 100.0;
+            return 1.0 + (e ? atof(e) : 8.0) / 100.0;   // 3 % with the 32x32x2 products; re-swept with 16x16x4: 3 / 6 / 8 / 10 / 15 % -> 2411 / 2418 / 2419 / 2418 / 2415 clips/s
         }();
         const double cost128 = (double)((tiles128 + 255) / 256) * 0.5 * penalty;
         return cost128 < (double)per_cu_256 ? 31 : 33;
