@@ -86,6 +86,12 @@ const char* nomad_version(void);
 #define NOMAD_BUILD_PACKED_FP32 1
 #define NOMAD_BUILD_DIAG 2
 int nomad_build_flags(void);
+/* Scheduling hint: into how many parts, on as many streams, the host layer splits the batches it submits CONCURRENTLY (1 = one
+ * forward at a time, the default).  Results never depend on it - every fp32 GEMM instantiation contracts k in the same order -
+ * only the tile-shape choice does: next to another stream's kernels the 128 x 128 tiles' extra operand traffic costs more
+ * (measured: the 256 x 128 / 128 x 128 price ratio that minimises the bench step is 1.08 with two concurrent halves, 1.03 with
+ * one forward).  nomad_amd.Engine calls it with its split count.  Process-wide; returns 0, or NOMAD_ERR_INVALID for parts < 1. */
+int nomad_set_concurrent_parts(int parts);
 
 /* ---- shapes ------------------------------------------------------------------------------ */
 /* Encoder frames T for a clip of n_samples (conv stack (10,5),(3,2)x4,(2,2)x2); <=0 if too short. */

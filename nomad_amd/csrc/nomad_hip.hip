@@ -799,6 +799,7 @@ GemmParams dense(const float* A, int lda, const float* W, const float* bias, con
 // 256 x 128 tiles, the rows of the last, partial round to 128 x 128 tiles - when that round is between 5 % and 70 % full.
 // NOMAD_F32_MIXED=0 switches it off; NOMAD_F32_MIXED_M1=<rows> (diagnostics) forces a split.
 int g_mixed_cus = 256;   // multiProcessorCount of the device (nomad_create)
+int g_concurrent_parts = 1;   // nomad_set_concurrent_parts: batches the host layer runs concurrently on separate streams
 int mixed_split_rows(int M, int N) {
     static const int mode = [] { const char* e = getenv("NOMAD_F32_MIXED"); return e ? atoi(e) : 1; }();
     static const int forced = [] { const char* e = getenv("NOMAD_F32_MIXED_M1"); return e ? atoi(e) : 0; }();
@@ -836,10 +837,14 @@ int pick_tile(int M, int N, int K) {
     if (quant && N % 128 == 0 && tiles256 >= 1024) {
         const long long per_cu_256 = (tiles256 + 255) / 256;
         const long long tiles128 = (long long)((M + 127) / 128) * (N / 128);
-        static const double penalty = [] {   // what a flop costs more on 128 x 128 tiles (NOMAD_F32_QUANT_PENALTY, percent; A/B runs)
+        // what a flop costs more on 128 x 128 tiles: 8 % when the host layer runs two parts of a batch concurrently (swept with the
+        // 16x16x4 products: 3 / 6 / 8 / 10 / 15 % -> 2411 / 2418 / 2419 / 2418 / 2415 clips/s), 3 % for one forward at a time
+        // (NOMAD_F32_QUANT_PENALTY, percent: both, A/B runs)
+        static const double penalty_env = [] {
             const char* e = getenv("NOMAD_F32_QUANT_PENALTY");
-            return 1.0 + (e ? atof(e) : 8.0) / 100.0;   // 3 % with the 32x32x2 products; re-swept with 16x16x4: 3 / 6 / 8 / 10 / 15 % -> 2411 / 2418 / 2419 / 2418 / 2415 clips/s
+            return e ? 1.0 + atof(e) / 100.0 : 0.0;
         }();
+        const double penalty = penalty_env > 0.0 ? penalty_env : (g_concurrent_parts >= 2 ? 1.08 : 1.03);
         const double cost128 = (double)((tiles128 + 255) / 256) * 0.5 * penalty;
         return cost128 < (double)per_cu_256 ? 31 : 33;
     }
@@ -3775,6 +3780,12 @@ int nomad_train_set_convnet(nomad_ctx* c, int trainable) {
 int nomad_train_set_step(nomad_ctx* c, long long step) {
     if (!c || !c->train_ready || step < 0) return fail(NOMAD_ERR_INVALID, "nomad_train_set_step: bad argument");
     c->adam_t = step;
+    return 0;
+}
+
+int nomad_set_concurrent_parts(int parts) {
+    if (parts < 1) return fail(NOMAD_ERR_INVALID, "nomad_set_concurrent_parts: parts = %d", parts);
+    g_concurrent_parts = parts;
     return 0;
 }
 

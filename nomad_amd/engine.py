@@ -178,8 +178,11 @@ class Engine:
 
         ways = min(self.F32_SPLIT_WAYS, B)
         if side or want_layers or ways < 2 or not self.F32_SPLIT_ROWS or not (self.F32_SPLIT_ROWS <= B * T < self.F32_SPLIT_MAX_ROWS):
+            if not side:
+                self.lib.nomad_set_concurrent_parts(1)   # tile-shape hint only: results never depend on it (include/nomad_hip.h)
             run(wav, emb, side)
         else:
+            self.lib.nomad_set_concurrent_parts(ways)
             # parts of the batch on separate streams: each part's kernels fill the CUs the others' partial last rounds of tiles
             # leave idle (every instantiation contracts k in the same order, so the parts' bits equal the whole batch's)
             cur = torch.cuda.current_stream(self.device)
