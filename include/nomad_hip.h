@@ -90,8 +90,11 @@ int nomad_build_flags(void);
  * forward at a time, the default).  Results never depend on it - every fp32 GEMM instantiation contracts k in the same order -
  * only the tile-shape choice does: next to another stream's kernels the 128 x 128 tiles' extra operand traffic costs more
  * (measured: the 256 x 128 / 128 x 128 price ratio that minimises the bench step is 1.08 with two concurrent halves, 1.03 with
- * one forward).  nomad_amd.Engine calls it with its split count.  Process-wide; returns 0, or NOMAD_ERR_INVALID for parts < 1. */
-int nomad_set_concurrent_parts(int parts);
+ * one forward).  nomad_amd.Engine calls it with its split count.  Per context (round 5: it was process-wide state); like every
+ * other call on a context it must not race with another host thread's call on the SAME context.  The library keeps no mutable
+ * process-wide state and never reads the environment (tests/test_abi.py holds libnomad_hip.so to "imports no getenv").
+ * Returns 0, or NOMAD_ERR_INVALID for a null context or parts < 1. */
+int nomad_set_concurrent_parts(nomad_ctx* ctx, int parts);
 
 /* ---- shapes ------------------------------------------------------------------------------ */
 /* Encoder frames T for a clip of n_samples (conv stack (10,5),(3,2)x4,(2,2)x2); <=0 if too short. */

@@ -37,7 +37,7 @@ SIGNATURES = {
     "nomad_last_error": (C.c_char_p, []),
     "nomad_version": (C.c_char_p, []),
     "nomad_build_flags": (C.c_int, []),
-    "nomad_set_concurrent_parts": (C.c_int, [C.c_int]),
+    "nomad_set_concurrent_parts": (C.c_int, [C.c_void_p, C.c_int]),
     "nomad_num_frames": (C.c_int, [C.c_int]),
     "nomad_workspace_bytes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     "nomad_embed": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_size_t, _fp]),

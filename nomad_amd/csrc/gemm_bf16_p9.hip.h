@@ -1,0 +1,365 @@
+// bf16 GEMM, 256 x 256 tile, PERSISTENT form of the deep-pipelined "8-phase" schedule of gemm_bf16_8phase.hip.h (round 5,
+// config C5: every plain transformer / conv GEMM of the bf16 forward).
+//
+// Why: the per-workgroup timeline of the one-tile-per-workgroup kernel (profiles/r02_gemm_timeline.txt, re-measured in
+// profiles/r05_gemm_bf16_p9.txt) has a K = 768 tile spend 22.6 us in its K loop and ~9 us around it - 3 us from entry to the
+// first MFMA (address set-up, the first two K tiles' round trip to L2 / HBM), 6 us of epilogue (a workgroup barrier that also
+// waits for the bias / residual loads, fp32 slabs through LDS, store acknowledgements) - and with 128-160 KB of LDS per
+// workgroup nothing else is resident on the CU to fill those gaps.  Here ONE workgroup per CU stays resident and walks a
+// contiguous run of tiles of its XCD:
+//   * the LDS-DMA stream never drains: the load cursor runs two K tiles ahead of the multiply cursor and crosses into the
+//     next output tile first, so the next tile's K loop starts on operands that are already in LDS;
+//   * the epilogue is direct from TRANSPOSED accumulators (W fragment as the first MFMA operand): a lane owns one output row and,
+//     per pair of 16-column accumulator tiles, 8 consecutive columns - one 16-byte bf16 store, 64 contiguous bytes per row
+//     and instruction - no LDS (it cannot collide with the staged K tiles), no barrier;  the W rows of a wave's 64-column
+//     group are PERMUTED on their way into LDS (the per-lane DMA source address is free) so that the 8 values a lane holds for
+//     accumulator tiles 2 jh and 2 jh + 1 are those 8 consecutive columns;
+//   * bias and residual come through buffer descriptors whose size ends at row M: rows past the end load zero / store nothing.
+// Same MFMA (v_mfma_f32_16x16x32_bf16), same k order per output element, (acc + bias) -> GELU -> + residual in fp32 as every
+// other bf16 kernel: bit-identical to them (tests/test_gpu_bf16.py), so a clip's bits still do not depend on its batch.
+//
+// Requirements (the caller checks, p9_applies in nomad_hip.hip): C and R plain row-major matrices, one group, N % 256 == 0,
+// n_valid == N, K % 128 == 0, contiguous K (kchunk == K), A a plain matrix or uniform clips of >= 2 rows, no split planes.
+//
+// Synchronisation is the 8-phase template's (cdna_hip_programming.md 5, gemm_bf16_8phase.hip.h): raw s_barrier, lgkmcnt(0)
+// before each MFMA cluster, ONE counted vmcnt per K tile, the two wave rows one barrier apart.  vmcnt(8) in phase 4 means "all
+// but the 8 newest vector-memory operations of this wave are complete"; the 8 newest are always the DMA of K tile t + 2 (4 B + 4
+// A instructions), and loads complete in order, so A / B of tile t + 1 have landed whatever the epilogue's stores in between do.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "dtypes.hip.h"
+#include "gemm_bf16_8phase.hip.h"
+#include "gemm_f32.hip.h"
+
+namespace nomad {
+
+// LDS position p (0..63) of a wave's 64-column W group holds W row perm(p): accumulator tile j = p >> 4, operand row i16 = p & 15
+// (= 4 fq + r of the transposed result) -> column 32 (j >> 1) + 8 fq + 4 (j & 1) + r.
+__host__ __device__ constexpr int p9_wperm(int p) { return 32 * (p >> 5) + 8 * ((p >> 2) & 3) + 4 * ((p >> 4) & 1) + (p & 3); }
+
+// ABL: 0 = product; 7 = per-workgroup timeline probe (tools/gemm_timeline.py --p9); 1 = no output stores (timing probe)
+template <int ABL = 0>
+__global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
+    using Cfg = P8Cfg;
+    constexpr int A_BUF = 2 * Cfg::HALF_BYTES;   // A buffers at 0 / 32 KB, B buffers (three) from 64 KB on: 160 KB
+    extern __shared__ __attribute__((aligned(16))) char smem9[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int fr = lane & 15, fq = lane >> 4;
+    unsigned long long ts_[6] = {0, 0, 0, 0, 0, 0};
+    if (ABL == 7) ts_[0] = wall_clock64();
+
+    // this workgroup's run of tiles: XCD x (blocks b with b % 8 == x share an XCD) owns a contiguous range of the n-fastest
+    // tile walk, its workgroups take every wpx-th tile of it - tiles that are resident together share A row panels in L2
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int wpx = (int)gridDim.x >> 3, xcd = (int)blockIdx.x & 7, local = (int)blockIdx.x >> 3;
+    const int tq = ntiles >> 3, trem = ntiles & 7;
+    const int t_begin = xcd * tq + (xcd < trem ? xcd : trem) + local;
+    const int t_end = xcd * tq + (xcd < trem ? xcd : trem) + tq + (xcd < trem ? 1 : 0);
+    if (t_begin >= t_end) return;   // (uniform over the workgroup; before any barrier)
+
+    const bf16_t* Ag = reinterpret_cast<const bf16_t*>(p.A);
+    const bf16_t* Wg = reinterpret_cast<const bf16_t*>(p.W);
+    auto row_addr_a = [&](int m) -> long long {
+        const int c = p.a_clip_magic ? fast_div(m, p.a_clip_magic, p.a_clip_shift) : 0;
+        return p.amap.off + (long long)c * p.amap.clip_stride + (long long)(m - c * p.amap.clip_rows) * p.amap.ld;
+    };
+
+    // tile-independent per-lane DMA geometry.  Instruction i of a half-tile covers LDS rows (tid + 512 i) / 8, physical chunk
+    // (tid + 512 i) % 8; the source chunk is swizzled (gemm_bf16.hip.h).  B: LDS row R holds W row (R / 64) * 64 + perm(R % 64).
+    unsigned b_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int id = tid + i * 512, row = id >> 3, pc = id & 7;
+        const int sw = (pc ^ ((row >> 1) & 7)) * 8;
+        const int wrow = (row & ~63) + p9_wperm(row & 63);
+        b_off[i] = (unsigned)(((long long)wrow * p.ldw + sw) * 2);
+    }
+    // load cursor: the output tile whose K tiles are being staged, and the byte offset of the next K tile within its rows
+    int t_ld = t_begin, m0_ld, n0_ld;
+    unsigned a_off[2][2];
+    const char *a_base, *b_base0, *b_base1;
+    auto setup = [&](int t) {
+        const int tm = p.tn_magic ? fast_div(t, p.tn_magic, p.tn_shift) : t;
+        m0_ld = tm * Cfg::BM;
+        n0_ld = (t - tm * p.tiles_n) * Cfg::BN;
+        const long long row0 = row_addr_a(m0_ld < p.M ? m0_ld : p.M - 1);   // wave-uniform
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = tid + i * 512, row = id >> 3, pc = id & 7;
+            const int sw = (pc ^ ((row >> 1) & 7)) * 8;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                int m = m0_ld + h * 128 + row;
+                m = m < p.M ? m : p.M - 1;
+                a_off[h][i] = (unsigned)((row_addr_a(m) - row0 + sw) * 2);
+            }
+        }
+        a_base = reinterpret_cast<const char*>(uniform_ptr(reinterpret_cast<const float*>(Ag + row0)));
+        b_base0 = reinterpret_cast<const char*>(uniform_ptr(reinterpret_cast<const float*>(Wg + (long long)n0_ld * p.ldw)));
+        b_base1 = b_base0 + (long long)128 * p.ldw * 2;
+    };
+    unsigned ko = 0;                         // byte offset of the load cursor's K tile (contiguous K: 128 bytes per K tile)
+    const unsigned k_bytes = (unsigned)p.K * 2;
+    char* const dma_dst = smem9 + wave * 1024;  // + lane * 16 implicit (lane-linear LDS-DMA destination)
+    int b3_cur = 0;    // byte offset of the B buffer of the K tile being multiplied (rotates through three) ...
+    int b3_dst = 0;    // ... and of the buffer the load cursor fills
+
+#define NOMAD_P9_DMA_A(PAR, H)                                                                                            \
+    {                                                                                                                     \
+        char* d_ = dma_dst + (PAR)*A_BUF + (H)*Cfg::HALF_BYTES;                                                           \
+        __builtin_amdgcn_global_load_lds((gptr_t)(a_base + (a_off[H][0] + ko)), (lptr_t)(d_), 16, 0, 0);                  \
+        __builtin_amdgcn_global_load_lds((gptr_t)(a_base + (a_off[H][1] + ko)), (lptr_t)(d_ + 8192), 16, 0, 0);           \
+    }
+#define NOMAD_P9_DMA_B(H)                                                                                                 \
+    {                                                                                                                     \
+        char* d_ = dma_dst + 2 * A_BUF + b3_dst + (H)*Cfg::HALF_BYTES;                                                    \
+        const char* bb_ = (H) ? b_base1 : b_base0;                                                                        \
+        __builtin_amdgcn_global_load_lds((gptr_t)(bb_ + (b_off[0] + ko)), (lptr_t)(d_), 16, 0, 0);                        \
+        __builtin_amdgcn_global_load_lds((gptr_t)(bb_ + (b_off[1] + ko)), (lptr_t)(d_ + 8192), 16, 0, 0);                 \
+    }
+    // the load cursor moves on by one K tile; past the last K tile of its output tile it crosses into the workgroup's next
+    // output tile (the last one "crosses" into itself: two K tiles are staged that nobody reads - no has-next case in the loop)
+#define NOMAD_P9_ADVANCE()                                                                                                \
+    {                                                                                                                     \
+        ko += 128;                                                                                                        \
+        if (ko == k_bytes) {                                                                                              \
+            ko = 0;                                                                                                       \
+            if (t_ld + wpx < t_end) t_ld += wpx;                                                                          \
+            setup(t_ld);                                                                                                  \
+        }                                                                                                                 \
+    }
+
+    // prologue: K tiles 0 and 1 of the first output tile
+    setup(t_ld);
+    int m0 = m0_ld, n0 = n0_ld, t_cur = t_begin;
+    NOMAD_P9_DMA_A(0, 0)
+    NOMAD_P9_DMA_A(0, 1)
+    NOMAD_P9_DMA_B(0)
+    NOMAD_P9_DMA_B(1)
+    NOMAD_P9_ADVANCE()
+    b3_dst = A_BUF;
+    NOMAD_P9_DMA_A(1, 0)
+    NOMAD_P9_DMA_A(1, 1)
+    NOMAD_P9_DMA_B(0)
+    NOMAD_P9_DMA_B(1)
+    NOMAD_P9_ADVANCE()
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // K tile 0 has landed (this wave's share)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (ABL == 7) ts_[1] = wall_clock64();
+    if (wr == 1) __builtin_amdgcn_s_barrier();  // second wave row runs one barrier behind (ping-pong)
+
+    // fragment addresses: this lane's row fr of a 16-row tile, chunk (4 kh + fq) ^ swizzle
+    const int sw = (fr >> 1) & 7;
+    const int koff0 = ((0 + fq) ^ sw) * 16, koff1 = ((4 + fq) ^ sw) * 16;
+    const int a_frag = wr * Cfg::HALF_BYTES + fr * 128;                 // + i * 2048
+    const int b_frag = 2 * A_BUF + (wc * 64 + fr) * 128;                // + j * 2048
+
+    const int nk = p.K / 64;  // even
+    const bool has_r = p.R != nullptr, has_b = p.bias != nullptr;
+    int n_done = 0;
+
+    for (;;) {
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        bf16x8 af[8][2], bf[2][2];
+
+        // transposed product: W fragment first -> a lane holds row fr (of A tile i) x W rows 4 fq + r (of LDS tile j)
+#define NOMAD_P9_MMA(I0, J0)                                                                               \
+    _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                       \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                  \
+                acc[(I0) + i][(J0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][kh], af[(I0) + i][kh], acc[(I0) + i][(J0) + j], 0, 0, 0);
+#define NOMAD_P9_SYNC_COMPUTE(I0, J0)                   \
+    __builtin_amdgcn_s_barrier();                       \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
+    __builtin_amdgcn_s_setprio(1);                      \
+    NOMAD_P9_MMA(I0, J0)                                \
+    __builtin_amdgcn_s_setprio(0);                      \
+    __builtin_amdgcn_s_barrier();                       \
+    asm volatile("" ::: "memory");
+
+        // one K tile (A buffer PAR = parity of the K tile: a compile-time constant per call site, K tiles go in pairs)
+#define NOMAD_P9_KTILE(PAR)                                                                                \
+    {                                                                                                      \
+        const char* la_ = smem9 + (PAR)*A_BUF + a_frag;                                                    \
+        const char* lb_ = smem9 + b3_cur + b_frag;                                                         \
+        b3_dst = b3_cur >= A_BUF ? b3_cur - A_BUF : b3_cur + 2 * A_BUF; /* buffer of tile t+2 */           \
+        /* phase 1: B columns 0..31, A rows 0..63 */                                                       \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                    \
+            bf[j][0] = *reinterpret_cast<const bf16x8*>(lb_ + j * 2048 + koff0);                           \
+            bf[j][1] = *reinterpret_cast<const bf16x8*>(lb_ + j * 2048 + koff1);                           \
+        }                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                    \
+            af[i][0] = *reinterpret_cast<const bf16x8*>(la_ + i * 2048 + koff0);                           \
+            af[i][1] = *reinterpret_cast<const bf16x8*>(la_ + i * 2048 + koff1);                           \
+        }                                                                                                  \
+        NOMAD_P9_DMA_B(0)                                                                                  \
+        NOMAD_P9_SYNC_COMPUTE(0, 0)                                                                        \
+        /* phase 2: A rows 64..127 */                                                                      \
+        _Pragma("unroll") for (int i = 4; i < 8; ++i) {                                                    \
+            af[i][0] = *reinterpret_cast<const bf16x8*>(la_ + i * 2048 + koff0);                           \
+            af[i][1] = *reinterpret_cast<const bf16x8*>(la_ + i * 2048 + koff1);                           \
+        }                                                                                                  \
+        NOMAD_P9_DMA_B(1)                                                                                  \
+        NOMAD_P9_SYNC_COMPUTE(4, 0)                                                                        \
+        /* phase 3: B columns 32..63 */                                                                    \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                    \
+            bf[j][0] = *reinterpret_cast<const bf16x8*>(lb_ + (2 + j) * 2048 + koff0);                     \
+            bf[j][1] = *reinterpret_cast<const bf16x8*>(lb_ + (2 + j) * 2048 + koff1);                     \
+        }                                                                                                  \
+        NOMAD_P9_SYNC_COMPUTE(0, 2)                                                                        \
+        /* phase 4: both A halves of tile t+2 (their last read was phase 2), then "tile t+1 has landed" */ \
+        NOMAD_P9_DMA_A(PAR, 0)                                                                             \
+        NOMAD_P9_DMA_A(PAR, 1)                                                                             \
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                   \
+        NOMAD_P9_ADVANCE()                                                                                 \
+        NOMAD_P9_SYNC_COMPUTE(4, 2)                                                                        \
+        b3_cur = b3_cur >= 2 * A_BUF ? 0 : b3_cur + A_BUF;                                                 \
+    }
+
+        int kt = 0;
+        do {   // (nk >= 2: no zero-trip copy of the loop's live ranges)
+            NOMAD_P9_KTILE(0)
+            NOMAD_P9_KTILE(1)
+            kt += 2;
+        } while (kt < nk);
+        if (ABL == 7 && n_done < 2) ts_[2 + 2 * n_done] = wall_clock64();
+
+        // ---- direct epilogue: acc[i][j][r] = out[m0 + 128 wr + 16 i + fr][n0 + 64 wc + 32 (j >> 1) + 8 fq + 4 (j & 1) + r] ----
+        {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            // the per-lane offsets are recomputed per tile from a laundered lane id: hoisted out of the tile loop they would sit in
+            // 30-odd registers through the K loop, which has none to spare
+            int lane_e = lane;
+            asm volatile("" : "+v"(lane_e));
+            const int fr = lane_e & 15, fq = lane_e >> 4;
+            const int mw = m0 + wr * 128, nw = n0 + wc * 64;
+            auto clamp_bytes = [](long long v) { return (unsigned)(v < 0 ? 0 : (v > (1ll << 30) ? (1ll << 30) : v)); };
+            bf16_t* Cb = reinterpret_cast<bf16_t*>(p.C);
+            const bf16_t* Rb = reinterpret_cast<const bf16_t*>(p.R);
+            const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(uniform_ptr(reinterpret_cast<const float*>(Cb + p.cmap.off + (long long)mw * p.cmap.ld + nw))), 0,
+                clamp_bytes((long long)(p.M - mw) * p.cmap.ld * 2), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(uniform_ptr(reinterpret_cast<const float*>(has_r ? Rb + p.rmap.off + (long long)mw * p.rmap.ld + nw : Cb))), 0,
+                has_r ? clamp_bytes((long long)(p.M - mw) * p.rmap.ld * 2) : 0u, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(uniform_ptr(has_b ? p.bias + nw : p.C)), 0, has_b ? 64u * 4u : 0u, 0x00020000);
+            const int c_voff = (fr * p.cmap.ld + 8 * fq) * 2, r_voff = (fr * p.rmap.ld + 8 * fq) * 2;
+            // one straight-line copy per (GELU, residual) combination: decided once per tile, not once per chunk
+            auto epi = [&](auto gelu_c, auto res_c) {
+            constexpr bool GELU = decltype(gelu_c)::value, RES = decltype(res_c)::value;
+            // (the bias loads sit INSIDE each copy: issued in front of the four-way branch, the compiler's wait-count pass no longer
+            // knew them waited for at the K loop's header and put an s_waitcnt vmcnt(0) - a drained DMA queue - into every K tile pair)
+            // (an opaque zero as their scalar offset keeps the compiler from merging the four copies' loads back in front of the branch)
+            int zoff = 0;
+            asm volatile("" : "+s"(zoff));
+            f32x4 bv[2][2];
+#pragma unroll
+            for (int jh = 0; jh < 2; ++jh)
+#pragma unroll
+                for (int g = 0; g < 2; ++g)   // (no bias: a zero-sized descriptor reads zeros)
+                    bv[jh][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, (32 * jh + 8 * fq + 4 * g) * 4, zoff, 0));
+            // bias, then the whole residual (64 registers: the operand fragments are dead here) ahead of the first store: a load
+            // issued behind a store is waited for together with that store's acknowledgement (in-order vmcnt)
+            u32x4 rres[8][2];
+            if (RES) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int jh = 0; jh < 2; ++jh)
+                        rres[i][jh] = __builtin_amdgcn_raw_buffer_load_b128(rr, r_voff + i * 16 * p.rmap.ld * 2 + jh * 64, 0, 0);
+            }
+            {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int jh = 0; jh < 2; ++jh) {
+                    float v[8];
+#pragma unroll
+                    for (int g = 0; g < 2; ++g)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float x = acc[i][2 * jh + g][r] + bv[jh][g][r];
+                            if (GELU) x = gelu_erf(x);
+                            v[4 * g + r] = x;
+                        }
+                    if (RES) {
+                        const bf16x8 rv = __builtin_bit_cast(bf16x8, rres[i][jh]);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+                    }
+                    bf16x8 ov;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ov[e] = (bf16_t)v[e];
+                    // (row offset in the VGPR offset, never in the scalar offset: the store-data hazard of DESIGN.md 5)
+                    if (ABL != 1 || p.M < 0)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), rc, c_voff + i * 16 * p.cmap.ld * 2 + jh * 64, 0, 2);
+                }
+            }
+            };
+            if (p.gelu && has_r) epi(std::true_type{}, std::true_type{});
+            else if (p.gelu) epi(std::true_type{}, std::false_type{});
+            else if (has_r) epi(std::false_type{}, std::true_type{});
+            else epi(std::false_type{}, std::false_type{});
+        }
+        if (ABL == 7 && n_done < 2) ts_[3 + 2 * n_done] = wall_clock64();
+        ++n_done;
+        if (t_cur + wpx >= t_end) break;
+        t_cur += wpx;
+        {   // the next output tile's coordinates (the load cursor may already be one tile further on)
+            const int tm = p.tn_magic ? fast_div(t_cur, p.tn_magic, p.tn_shift) : t_cur;
+            m0 = tm * Cfg::BM;
+            n0 = (t_cur - tm * p.tiles_n) * Cfg::BN;
+        }
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();  // re-join the two wave rows
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two K tiles staged past the end: LDS must not be released under them
+#undef NOMAD_P9_KTILE
+#undef NOMAD_P9_SYNC_COMPUTE
+#undef NOMAD_P9_MMA
+#undef NOMAD_P9_DMA_A
+#undef NOMAD_P9_DMA_B
+#undef NOMAD_P9_ADVANCE
+    if (ABL == 7) {
+        if (tid == 0 && blockIdx.x < kTimelineSlots) {
+            unsigned hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            unsigned long long* o = g_timeline + (size_t)blockIdx.x * 6;
+            // entry, first K loop start, K loop end / epilogue end of the first tile, K loop end of the second, tiles done << 32 | HW_ID
+            o[0] = ts_[0]; o[1] = ts_[1]; o[2] = ts_[2]; o[3] = ts_[3]; o[4] = ts_[4]; o[5] = ((unsigned long long)n_done << 32) | hw;
+        }
+    }
+}
+
+// one workgroup per CU (160 KB of LDS), never more than there are tiles; the grid is a multiple of 8 (one share per XCD)
+template <int ABL = 0>
+inline hipError_t launch_gemm_bf16_p9(GemmParams p, hipStream_t s, int num_cus) {
+    p.tiles_m = (p.M + P8Cfg::BM - 1) / P8Cfg::BM;
+    p.tiles_n = p.N / 256;
+    p.a_clip_magic = p.tn_magic = 0;
+    p.a_clip_shift = p.tn_shift = 0;
+    if (p.amap.clip_rows < p.M) fast_div_magic((unsigned)p.amap.clip_rows, &p.a_clip_magic, &p.a_clip_shift);
+    if (p.tiles_n > 1) fast_div_magic((unsigned)p.tiles_n, &p.tn_magic, &p.tn_shift);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_p9_kernel<ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const long long ntiles = (long long)p.tiles_m * p.tiles_n;
+    long long per_xcd = (ntiles + 7) / 8;
+    const int cap = num_cus >= 8 ? num_cus / 8 : 1;
+    if (per_xcd > cap) per_xcd = cap;
+    hipLaunchKernelGGL((gemm_bf16_p9_kernel<ABL>), dim3((unsigned)(8 * per_xcd)), dim3(P8Cfg::THREADS), 160 * 1024, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace nomad

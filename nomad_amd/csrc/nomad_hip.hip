@@ -43,6 +43,7 @@
 #include "frontend.hip.h"
 #include "gemm_bf16.hip.h"
 #include "gemm_bf16_8phase.hip.h"
+#include "gemm_bf16_p9.hip.h"
 #include "gemm_bf16x3.hip.h"
 #include "gemm_f32.hip.h"
 #ifdef NOMAD_DIAG  // libnomad_diag.so only: experiments kept for A/B measurements (tools/, tests of the experimental tiles)
@@ -74,6 +75,7 @@ int fail(int code, const char* fmt, ...) {
 
 constexpr int kConvK[7] = {10, 3, 3, 3, 3, 2, 2};
 constexpr int kConvS[7] = {5, 2, 2, 2, 2, 2, 2};
+constexpr int kSplitKLayersMaxM = 4096;   // a forward that returns the layer outputs of fewer frames than this may split K (forward_impl)
 constexpr size_t kSplitKPartFloats = (size_t)4 * 512 * 64 * 64;  // 4 slices of the largest problem that is split (< 512 tiles of 64 x 64)
 constexpr long long kPairScratchDoubles = 1 << 21;  // 16 MB: e.g. 16 ref tiles x 131 072 deg rows per launch pair
 constexpr int kEventChunk = 8192;  // the profiling event pool grows by this many events whenever it runs out
@@ -118,7 +120,7 @@ void launch_wav_stats(const float* wav, int ld, int L0, int max_l0, int B, doubl
 }
 
 struct Layout {
-    size_t stats, scale, shift, conv[7], featln, xpad, x, x2, y, qkv, ctxb, h, total;
+    size_t stats, scale, shift, conv[7], featln, xpad, x, x2, y, qkv, ctxb, h, splitk, total;
 };
 
 Layout make_layout(const Shapes& s, bool keep) {
@@ -149,6 +151,9 @@ Layout make_layout(const Shapes& s, bool keep) {
     l.qkv = take(act * 3);
     l.ctxb = take(act);
     l.h = take(act * 4);
+    // partial products of the split-K GEMMs of a small layer-output forward (forward_impl): part of the CALL's workspace, so that
+    // whether such a forward splits depends on its shape alone - not on which streams other calls are running on
+    l.splitk = s.M < kSplitKLayersMaxM ? take(kSplitKPartFloats * sizeof(float)) : 0;
     l.total = off;
     return l;
 }
@@ -302,9 +307,73 @@ ParamOffsets make_param_offsets() {
 
 }  // namespace
 
+// Kernel-choice switches.  Every default below is the shipped configuration, and the product library (libnomad_hip.so) never
+// reads the environment: "nothing but the arguments" decides what a call does.  Only libnomad_diag.so (-DNOMAD_DIAG) fills a
+// context's copy from NOMAD_* environment variables, once, in nomad_create (tuning_from_env) - the A/B runs of tools/ and profiles/.
+struct Tuning {
+    bool splitk_posconv = true;    // NOMAD_SPLITK_POSCONV: the grouped pos-conv of the loss path splits K four ways
+    bool splitk_layers = true;     // NOMAD_SPLITK_LAYERS: so do the dense GEMMs of a small layer-output forward
+    bool f32_plain_epi = true;     // NOMAD_F32_PLAIN_EPI: small epilogue for plain C / R matrices
+    bool f32_lean = true, f32_direct_epi = true, f32_skew = true, f32_res_ahead = true;   // NOMAD_F32_LEAN / _DIRECT_EPI / _SKEW / _RES_AHEAD
+    int f32_mixed = 1;             // NOMAD_F32_MIXED: two tile shapes in one launch
+    int f32_mixed_m1 = 0;          // NOMAD_F32_MIXED_M1: forced row split (diagnostics)
+    int f32_mixed_slots = 0;       // NOMAD_F32_MIXED_SLOTS: 0 = two workgroup slots per CU
+    double f32_mixed_min = 0.05, f32_mixed_max = 0.70;   // NOMAD_F32_MIXED_MIN / _MAX: fill of the last round that takes the split
+    bool f32_mixed_prefer = false; // NOMAD_F32_MIXED_PREFER
+    bool f32_quant_tile = true;    // NOMAD_F32_QUANT_TILE: tile choice by the largest tile count any CU gets
+    double f32_quant_penalty = 0.0;  // NOMAD_F32_QUANT_PENALTY (percent): 0 = 8 % with two concurrent parts, 3 % alone
+    bool f32_longk_33 = false;     // NOMAD_F32_LONGK_33
+    int f32_mid_tile = 31;         // NOMAD_F32_MID_TILE
+    int bf16_attn_dma = 2;         // NOMAD_BF16_ATTN_DMA: K / V of the bf16 attention by LDS-DMA in 128-key tiles
+    bool bf16_conv0_mfma = true;   // NOMAD_BF16_CONV0_MFMA
+    int p8_min_tiles = 256;        // NOMAD_BF16_8PHASE_MIN_TILES: smallest grid (256 x 256 tiles) for the deep-pipelined bf16 kernels
+    bool p8_nt_stores = true;      // NOMAD_BF16_NT_STORES
+    int p8_rpre = 3;               // NOMAD_BF16_RPRE
+    bool x3_plain_epi = true;      // NOMAD_X3_PLAIN_EPI
+    bool p8_three_b = true;        // NOMAD_BF16_B3
+    int p8_n192 = 0;               // NOMAD_BF16_N192
+    bool p9 = true;                // NOMAD_BF16_P9: the persistent 256 x 256 bf16 kernel wherever it applies
+    int concurrent_parts = 1;      // nomad_set_concurrent_parts: batches the host layer runs concurrently on separate streams
+};
+
+#ifdef NOMAD_DIAG
+static void tuning_from_env(Tuning& t) {
+    auto geti = [](const char* n, int d) { const char* e = getenv(n); return e ? atoi(e) : d; };
+    auto getb = [](const char* n, bool d) { const char* e = getenv(n); return e ? atoi(e) != 0 : d; };
+    auto getd = [](const char* n, double d) { const char* e = getenv(n); return e ? atof(e) : d; };
+    t.splitk_posconv = getb("NOMAD_SPLITK_POSCONV", t.splitk_posconv);
+    t.splitk_layers = getb("NOMAD_SPLITK_LAYERS", t.splitk_layers);
+    t.f32_plain_epi = getb("NOMAD_F32_PLAIN_EPI", t.f32_plain_epi);
+    t.f32_lean = getb("NOMAD_F32_LEAN", t.f32_lean);
+    t.f32_direct_epi = getb("NOMAD_F32_DIRECT_EPI", t.f32_direct_epi);
+    t.f32_skew = getb("NOMAD_F32_SKEW", t.f32_skew);
+    t.f32_res_ahead = getb("NOMAD_F32_RES_AHEAD", t.f32_res_ahead);
+    t.f32_mixed = geti("NOMAD_F32_MIXED", t.f32_mixed);
+    t.f32_mixed_m1 = geti("NOMAD_F32_MIXED_M1", t.f32_mixed_m1);
+    t.f32_mixed_slots = geti("NOMAD_F32_MIXED_SLOTS", t.f32_mixed_slots);
+    t.f32_mixed_min = getd("NOMAD_F32_MIXED_MIN", t.f32_mixed_min);
+    t.f32_mixed_max = getd("NOMAD_F32_MIXED_MAX", t.f32_mixed_max);
+    t.f32_mixed_prefer = getb("NOMAD_F32_MIXED_PREFER", t.f32_mixed_prefer);
+    t.f32_quant_tile = getb("NOMAD_F32_QUANT_TILE", t.f32_quant_tile);
+    t.f32_quant_penalty = getd("NOMAD_F32_QUANT_PENALTY", t.f32_quant_penalty);
+    t.f32_longk_33 = getb("NOMAD_F32_LONGK_33", t.f32_longk_33);
+    t.f32_mid_tile = geti("NOMAD_F32_MID_TILE", t.f32_mid_tile);
+    t.bf16_attn_dma = geti("NOMAD_BF16_ATTN_DMA", t.bf16_attn_dma);
+    t.bf16_conv0_mfma = getb("NOMAD_BF16_CONV0_MFMA", t.bf16_conv0_mfma);
+    t.p8_min_tiles = geti("NOMAD_BF16_8PHASE_MIN_TILES", t.p8_min_tiles);
+    t.p8_nt_stores = getb("NOMAD_BF16_NT_STORES", t.p8_nt_stores);
+    t.p8_rpre = geti("NOMAD_BF16_RPRE", t.p8_rpre);
+    t.x3_plain_epi = getb("NOMAD_X3_PLAIN_EPI", t.x3_plain_epi);
+    t.p8_three_b = getb("NOMAD_BF16_B3", t.p8_three_b);
+    t.p8_n192 = geti("NOMAD_BF16_N192", t.p8_n192);
+    t.p9 = getb("NOMAD_BF16_P9", t.p9);
+}
+#endif
+
 struct nomad_ctx {
     int device = 0;
     int num_cus = 256;   // multiProcessorCount (the persistent GEMM launches two workgroups per CU)
+    Tuning tune;
     bool keep = false;
     // repacked weights (device)
     float* conv0_w = nullptr;            // [512][10]
@@ -319,20 +388,15 @@ struct nomad_ctx {
     // products of up to 4 K-slices, allocated by nomad_enable_backward; splitk_ok is raised for the duration of such a
     // call only (never for scoring forwards, whose bits must not depend on the batch; never in fine-tuning mode)
     float* splitk_part = nullptr;
-    // further blocks for the no-gradient branch(es) of Nomad.forward() (layer outputs wanted, nothing saved): they run concurrently
-    // with the differentiated branch - and, under no_grad, with each other - on different streams, so each launch stream binds
-    // its own block on first use (two exist; a third stream simply does not split).  splitk_cur: the block of the call being enqueued.
+    // (the no-gradient branches of Nomad.forward() - layer outputs wanted, nothing saved - take their partial-sum block from the
+    // call's own workspace: Layout::splitk)
+    float* splitk_cur = nullptr;                            // the block of the call being enqueued
 #ifdef NOMAD_DIAG
     // item-queue counters of the experimental persistent fp32 attention kernel (attention_f32_v3.hip.h): one 64-byte block per
     // launch, handed out round-robin - 128 launches would have to be in flight at once for two of them to share one
     int* attn_queue = nullptr;
     std::atomic<unsigned> attn_queue_next{0};
 #endif
-    float* splitk_extra[2] = {nullptr, nullptr};
-    hipStream_t splitk_extra_stream[2] = {nullptr, nullptr};
-    bool splitk_extra_bound[2] = {false, false};
-    hipEvent_t splitk_extra_done[2] = {nullptr, nullptr};   // recorded behind the last forward that used the block: a block whose event
-    float* splitk_cur = nullptr;                            // has completed may be re-bound to another stream
     bool splitk_ok = false;
     // nomad_pairwise: row sums per (64-ref tile, deg row), kPairScratchDoubles doubles PER LAUNCH STREAM - calls on
     // different streams of one context may be in flight together (Engine / ShardedScorer are driven from side streams), so
@@ -468,7 +532,7 @@ int occ_pad(int occ, int lds) {
     return budget > lds ? budget - lds : 0;
 }
 
-int mixed_split_rows(int M, int N);   // (below, next to pick_tile)
+int mixed_split_rows(const nomad_ctx* c, int M, int N);   // (below, next to pick_tile)
 
 int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, int occ = 0);
 
@@ -524,10 +588,9 @@ static int run_gemm_splitk(nomad_ctx* c, const GemmParams& p, int S, hipStream_t
 // The grouped pos-conv (16 groups x [M x 48 x 6144]) at the loss path's M = 1600 is 7 row tiles x 16 groups = 112 workgroups with a
 // serial K loop of 384 tiles: 331 us per launch on fewer than half of the CUs (three launches per configs[3] step).  K in 4 fixed
 // slices over blockIdx.z (448 workgroups), partial products added in slice order by posconv_splitk_epilogue_kernel.  Where the
-// dense GEMMs of the same call split (splitk_applies): never on a scoring entry point.  NOMAD_SPLITK_POSCONV=0 switches it off.
+// dense GEMMs of the same call split (splitk_applies): never on a scoring entry point.  Tuning::splitk_posconv = 0 switches it off.
 static bool posconv_splitk_applies(const nomad_ctx* c, const GemmParams& p, int groups, int tile) {
-    static const bool on = [] { const char* e = getenv("NOMAD_SPLITK_POSCONV"); return !e || atoi(e) != 0; }();
-    if (!on || !c->splitk_ok || !c->splitk_cur || groups != 16 || tile != 48) return false;
+    if (!c->tune.splitk_posconv || !c->splitk_ok || !c->splitk_cur || groups != 16 || tile != 48) return false;
     if (p.DG || p.K != 6144 || p.kchunk != p.K || p.n_valid != 48 || p.c_goff != 48) return false;
     const bool c_plain = p.cmap.clip_rows >= p.M && p.cmap.off == 0 && p.cmap.ld == 768;
     return c_plain && (long long)((p.M + 255) / 256) * 16 < 256 && (size_t)4 * p.M * 768 <= kSplitKPartFloats;
@@ -578,11 +641,7 @@ int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, in
     // plain C / R (/ Upre / DG) matrices: the instantiations with the small, residual-prefetching epilogue (gemm_f32.hip.h, OPT bits
     // 16 / 32) - every GEMM of the uniform scoring forward but the pos-conv's neighbours.  NOMAD_F32_PLAIN_EPI=0: the general
     // epilogue (A/B runs)
-    static const bool plain_epi = [] {
-        const char* e = getenv("NOMAD_F32_PLAIN_EPI");
-        return e ? atoi(e) != 0 : true;
-    }();
-    const bool plain_cr = plain_epi && p.c_colblk == 0 && p.cmap.clip_rows >= p.M && !p.cmap.pref &&
+    const bool plain_cr = c->tune.f32_plain_epi && p.c_colblk == 0 && p.cmap.clip_rows >= p.M && !p.cmap.pref &&
                           (!p.R || (p.rmap.clip_rows >= p.M && !p.rmap.pref)) && (!p.DG || (p.dgmap.clip_rows >= p.M && !p.dgmap.pref));
     if (c->gemm_x3 && plain_cr && (tile == 20 || tile == 31 || tile == 34 || tile == 37)) {   // (not 33: its X3 form needs 146 VGPRs)
         constexpr int T = 16 | 32;   // one plain instantiation per tile for scoring and training alike (this mode is the small-batch / training one)
@@ -614,10 +673,7 @@ int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, in
         // clip maps take the lean set-up (magic-number divisions on the scalar unit), the 256 x 128 tile also the skewed K
         // loop, and GEMMs without a residual the direct epilogue from transposed accumulators.  All bit-identical to the plain
         // instantiations.  NOMAD_F32_LEAN=0 / NOMAD_F32_DIRECT_EPI=0 / NOMAD_F32_SKEW=0 switch them off (A/B runs).
-        static const int variants = [] {
-            auto on = [](const char* name) { const char* v = getenv(name); return !v || atoi(v) != 0; };
-            return (on("NOMAD_F32_LEAN") ? 1 : 0) | (on("NOMAD_F32_DIRECT_EPI") ? 2 : 0) | (on("NOMAD_F32_SKEW") ? 4 : 0) | (on("NOMAD_F32_RES_AHEAD") ? 8 : 0);
-        }();
+        const int variants = (c->tune.f32_lean ? 1 : 0) | (c->tune.f32_direct_epi ? 2 : 0) | (c->tune.f32_skew ? 4 : 0) | (c->tune.f32_res_ahead ? 8 : 0);
         // (a divisor of 1 - clips of ONE row, the shortest legal input - has no 32-bit magic number: those stay on the general set-up)
         const bool lean = (variants & 1) && !tr && !p.amap.pref && p.group_m == 0 && p.kchunk >= p.K &&
                           (p.amap.clip_rows >= p.M || p.amap.clip_rows >= 2);
@@ -630,7 +686,7 @@ int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, in
         if (lean && skew && tile == 33 && groups == 1 && (p.R ? ahead : direct)) {
             // (sending the launches that need no split through the same kernel as well - one instantiation less alternating between
             // the launches of a transformer layer - changes nothing: 2405 vs 2408 clips/s)
-            const int m1 = mixed_split_rows(p.M, p.N);
+            const int m1 = mixed_split_rows(c, p.M, p.N);
             if (m1 > 0) {
                 e = p.R ? launch_gemm_mixed<13 | P | L | S | RA, 13 | P | L | S | RA>(p, m1, s)
                         : launch_gemm_mixed<13 | P | L | S | D, 13 | P | L | S | D>(p, m1, s);
@@ -797,32 +853,27 @@ GemmParams dense(const float* A, int lda, const float* W, const float* bias, con
 // (all 32x32x2-MFMA instantiations contract k in the same order, so the choice never changes a result bit)
 // Rows of the 256 x 128 part of a two-shape launch (gemm_f32_mixed_kernel), or 0: whole rounds of the 2-per-CU workgroup slots go to
 // 256 x 128 tiles, the rows of the last, partial round to 128 x 128 tiles - when that round is between 5 % and 70 % full.
-// NOMAD_F32_MIXED=0 switches it off; NOMAD_F32_MIXED_M1=<rows> (diagnostics) forces a split.
-int g_mixed_cus = 256;   // multiProcessorCount of the device (nomad_create)
-int g_concurrent_parts = 1;   // nomad_set_concurrent_parts: batches the host layer runs concurrently on separate streams
-int mixed_split_rows(int M, int N) {
-    static const int mode = [] { const char* e = getenv("NOMAD_F32_MIXED"); return e ? atoi(e) : 1; }();
-    static const int forced = [] { const char* e = getenv("NOMAD_F32_MIXED_M1"); return e ? atoi(e) : 0; }();
-    if (!mode || N % 128) return 0;
-    if (forced > 0) return forced < M && forced % 256 == 0 ? forced : 0;
-    static const int slots_env = [] { const char* e = getenv("NOMAD_F32_MIXED_SLOTS"); return e ? atoi(e) : 0; }();   // (A/B runs)
-    const int tn = N / 128, slots = slots_env > 0 ? slots_env : 2 * g_mixed_cus;
+// Tuning::f32_mixed = 0 switches it off; f32_mixed_m1 = <rows> (diagnostics) forces a split.
+int mixed_split_rows(const nomad_ctx* c, int M, int N) {
+    const Tuning& t = c->tune;
+    if (!t.f32_mixed || N % 128) return 0;
+    if (t.f32_mixed_m1 > 0) return t.f32_mixed_m1 < M && t.f32_mixed_m1 % 256 == 0 ? t.f32_mixed_m1 : 0;
+    const int tn = N / 128, slots = t.f32_mixed_slots > 0 ? t.f32_mixed_slots : 2 * c->num_cus;
     const long long tiles = (long long)((M + 255) / 256) * tn;
     const long long rounds = tiles / slots;
     const double frac = (double)(tiles - rounds * slots) / slots;
-    static const double fmin = [] { const char* e = getenv("NOMAD_F32_MIXED_MIN"); return e ? atof(e) : 0.05; }();   // (A/B runs)
-    static const double fmax = [] { const char* e = getenv("NOMAD_F32_MIXED_MAX"); return e ? atof(e) : 0.70; }();
-    if (rounds < 1 || frac < fmin || frac > fmax) return 0;
+    if (rounds < 1 || frac < t.f32_mixed_min || frac > t.f32_mixed_max) return 0;
     const long long m1 = rounds * slots / tn * 256;
     return m1 > 0 && m1 < M ? (int)m1 : 0;
 }
 
-int pick_tile(int M, int N, int K) {
+int pick_tile(const nomad_ctx* c, int M, int N, int K) {
+    const Tuning& tu = c->tune;
+    const int cus = c->num_cus;
     const long long tiles256 = (long long)((M + 255) / 256) * (N / 128);
     // (NOMAD_F32_MIXED_PREFER=1, A/B: wherever the two-shape launch applies - run_gemm turns tile 33 into it - take it over the
     // 128 x 128 choice below.  Was +0.3 % of the bench step with the 32x32x2 products, is -0.4 % with 16x16x4: off.)
-    static const bool prefer_mixed = [] { const char* e = getenv("NOMAD_F32_MIXED_PREFER"); return e && atoi(e) != 0; }();
-    if (prefer_mixed && N % 128 == 0 && mixed_split_rows(M, N) > 0) return 33;
+    if (tu.f32_mixed_prefer && N % 128 == 0 && mixed_split_rows(c, M, N) > 0) return 33;
     // 1500, not 2048: a half of the bench batch (Engine.embed runs the batch as two halves on two streams) has 1800 tiles in
     // QKV and 1600 in conv4 - the 256x128 kernel there is worth +0.5 % of the step (2230-2235 vs 2219-2222 clips/s, alternating)
     // 256 x 128 or 128 x 128 (round 4)?  Two workgroups share a CU and a lone one runs about twice as fast, so what a launch costs
@@ -830,30 +881,21 @@ int pick_tile(int M, int N, int K) {
     // ~8 % dearer per flop (more operand traffic per MFMA; 3 % before the 16x16x4 products).  conv5 at the bench batch is 1596 big tiles = 6.2 per CU -> 7, or 3192
     // small ones = 12.5 -> 13 halves = 6.5: 135 vs 127 TFLOP/s measured (profiles/r04_gemm_f32_variants.txt).  NOMAD_F32_QUANT_TILE=0:
     // the round-3 rule.
-    static const bool quant = [] {
-        const char* e = getenv("NOMAD_F32_QUANT_TILE");
-        return !e || atoi(e) != 0;
-    }();
-    if (quant && N % 128 == 0 && tiles256 >= 1024) {
-        const long long per_cu_256 = (tiles256 + 255) / 256;
+    if (tu.f32_quant_tile && N % 128 == 0 && tiles256 >= 4LL * cus) {
+        const long long per_cu_256 = (tiles256 + cus - 1) / cus;
         const long long tiles128 = (long long)((M + 127) / 128) * (N / 128);
         // what a flop costs more on 128 x 128 tiles: 8 % when the host layer runs two parts of a batch concurrently (swept with the
         // 16x16x4 products: 3 / 6 / 8 / 10 / 15 % -> 2411 / 2418 / 2419 / 2418 / 2415 clips/s), 3 % for one forward at a time
         // (NOMAD_F32_QUANT_PENALTY, percent: both, A/B runs)
-        static const double penalty_env = [] {
-            const char* e = getenv("NOMAD_F32_QUANT_PENALTY");
-            return e ? 1.0 + atof(e) / 100.0 : 0.0;
-        }();
-        const double penalty = penalty_env > 0.0 ? penalty_env : (g_concurrent_parts >= 2 ? 1.08 : 1.03);
-        const double cost128 = (double)((tiles128 + 255) / 256) * 0.5 * penalty;
+        const double penalty = tu.f32_quant_penalty != 0.0 ? 1.0 + tu.f32_quant_penalty / 100.0 : (tu.concurrent_parts >= 2 ? 1.08 : 1.03);
+        const double cost128 = (double)((tiles128 + cus - 1) / cus) * 0.5 * penalty;
         return cost128 < (double)per_cu_256 ? 31 : 33;
     }
     if (N % 128 == 0 && tiles256 >= 1500) return 33;
     // (NOMAD_F32_LONGK_33=1, A/B: one to two rounds of 256 x 128 tiles with a long or short K - fc2 / proj of HALF a bench batch - on
     // the 256 x 128 kernel, as up to round 4; with the 16x16x4 products the 128 x 128 x 32 kernel is faster and steadier there:
     // fc2 of half a batch 133.1 against 125 TFLOP/s median, out_proj 127 against 114)
-    static const bool longk33 = [] { const char* e = getenv("NOMAD_F32_LONGK_33"); return e && atoi(e) != 0; }();
-    if (longk33 && N % 128 == 0 && tiles256 >= 512 && (K >= 2048 || K <= 512)) return 33;
+    if (tu.f32_longk_33 && N % 128 == 0 && tiles256 >= 512 && (K >= 2048 || K <= 512)) return 33;
     // less than one round of 256x128 tiles (batch 1 .. a few dozen short clips, config C4): 64x64 tiles keep the
     // most CUs busy; one wave's K loop is the latency floor there (profiles/r01_gemm_sweep_small_m.json)
     if (tiles256 < 512) return 37;
@@ -863,11 +905,7 @@ int pick_tile(int M, int N, int K) {
     // out_proj, conv5/6 at full batch (K = 768 / 1024, N = 768 / 512): 128x128x32 tiles, 8 waves, 2 stages: +2..5 % over
     // 128x64 (profiles/r01_gemm_sweep_n768_128x128.json).  NOMAD_F32_MID_TILE=33 (A/B): the 256x128 kernel there too, so that the
     // transformer layers run ONE GEMM instantiation (no alternation)
-    static const int mid = [] {
-        const char* e = getenv("NOMAD_F32_MID_TILE");
-        return e ? atoi(e) : 31;
-    }();
-    return N % 128 == 0 ? mid : 34;
+    return N % 128 == 0 ? tu.f32_mid_tile : 34;
 }
 
 int run_layernorm(nomad_ctx* c, const float* in, const float* g, const float* b, float* out, float* out2, int M, int N,
@@ -1034,7 +1072,9 @@ int nomad_create(nomad_ctx** out, int device, const nomad_weights* w) {
     nomad_ctx* c = new nomad_ctx();
     c->device = device;
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    g_mixed_cus = c->num_cus;
+#ifdef NOMAD_DIAG
+    tuning_from_env(c->tune);
+#endif
     int rc = 0;
     auto up = [&](const float* h, size_t n, float** d) {
         if (rc == 0) rc = upload(c, h, n, d);
@@ -1123,17 +1163,6 @@ int nomad_create(nomad_ctx** out, int device, const nomad_weights* w) {
             }
         }
 #endif
-        // the split-K blocks of the layer-output forward (LossNetLayers) exist from the start: whether that forward splits must
-        // not depend on whether a backward has been enabled meanwhile (its bits would change between two calls of a process)
-        for (int i = 0; i < 2 && rc == 0; ++i) {
-            void* b = nullptr;
-            const hipError_t e2 = hipMalloc(&b, kSplitKPartFloats * sizeof(float));
-            if (e2 != hipSuccess) rc = fail(NOMAD_ERR_HIP, "nomad_create: split-K block: %s", hipGetErrorString(e2));
-            else {
-                c->allocs.push_back(b);
-                c->splitk_extra[i] = static_cast<float*>(b);
-            }
-        }
     }
     if (rc != 0) {
         nomad_destroy(c);
@@ -1148,8 +1177,6 @@ void nomad_destroy(nomad_ctx* c) {
     (void)hipSetDevice(c->device);
     for (void* p : c->allocs) (void)hipFree(p);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
-    for (hipEvent_t e : c->splitk_extra_done)
-        if (e) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -1213,34 +1240,10 @@ static int forward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, co
     // other branch of that loss - a forward that returns the 12 layer outputs (LossNetLayers: `clean`, or `estimate` under
     // no_grad) on fewer than 4096 frames.  The split is a function of the GEMM shape only (fixed slices, ordered fold): the
     // results are deterministic, but they are the loss path's bits, not the scoring path's - nomad_embed WITHOUT layer outputs
-    // (TripletModel / predict) never splits, whatever the batch.  NOMAD_SPLITK_LAYERS=0 switches the new case off (A/B).
-    static const bool splitk_layers = [] {
-        const char* e = getenv("NOMAD_SPLITK_LAYERS");
-        return !e || atoi(e) != 0;
-    }();
-    float* loss_block = nullptr;
-    if (sv == nullptr && layers_out != nullptr && M < 4096 && splitk_layers && c->splitk_extra[0]) {
-        for (int i = 0; i < 2 && !loss_block; ++i)
-            if (c->splitk_extra_bound[i] && c->splitk_extra_stream[i] == s) loss_block = c->splitk_extra[i];
-        for (int i = 0; i < 2 && !loss_block; ++i)   // an unbound block, or one whose last user has finished (a third stream takes it over)
-            if (!c->splitk_extra_bound[i] || (c->splitk_extra_done[i] && hipEventQuery(c->splitk_extra_done[i]) == hipSuccess)) {
-                c->splitk_extra_bound[i] = true;
-                c->splitk_extra_stream[i] = s;
-                loss_block = c->splitk_extra[i];
-            }
-        (void)hipGetLastError();   // (hipEventQuery's hipErrorNotReady is not an error of this call)
-    }
-    struct BlockDone {   // behind everything this forward enqueues: the block's "last user finished" event
-        nomad_ctx* c; float* blk; hipStream_t st;
-        ~BlockDone() {
-            if (!blk) return;
-            for (int i = 0; i < 2; ++i)
-                if (c->splitk_extra[i] == blk) {
-                    if (!c->splitk_extra_done[i] && hipEventCreateWithFlags(&c->splitk_extra_done[i], hipEventDisableTiming) != hipSuccess) c->splitk_extra_done[i] = nullptr;
-                    if (c->splitk_extra_done[i]) (void)hipEventRecord(c->splitk_extra_done[i], st);
-                }
-        }
-    } block_done{c, loss_block, s};
+    // (TripletModel / predict) never splits, whatever the batch.  The partial sums live in the call's own workspace (round 5; they
+    // were two context-wide blocks handed to launch streams by hipEventQuery: whether a third stream's forward split depended on
+    // timing).  Tuning::splitk_layers = 0 switches the case off (A/B, diag library).
+    float* const loss_block = (sv == nullptr && layers_out != nullptr && lay.splitk != 0 && c->tune.splitk_layers) ? F(lay.splitk) : nullptr;
     const SplitKScope splitk(c, (sv != nullptr || loss_block != nullptr) && !c->train_ready);
     float* const prev_cur = c->splitk_cur;
     c->splitk_cur = sv != nullptr ? c->splitk_part : loss_block;
@@ -1295,7 +1298,7 @@ static int forward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, co
         p.cmap = plain_map(p.M, 512);
         p.rmap = p.cmap;
         p.gelu = 1;
-        if ((rc = run_gemm(c, p, 1, pick_tile(p.M, 512, p.K), s))) return rc;
+        if ((rc = run_gemm(c, p, 1, pick_tile(c, p.M, 512, p.K), s))) return rc;
     }
 
     // ---- LayerNorm(512) + post_extract_proj into the padded pos-conv buffer ------------------
@@ -1314,7 +1317,7 @@ static int forward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, co
         p.cmap = pad_map;
         p.c_colblk = 48;
         p.c_colblk_stride = grp_stride;
-        if ((rc = run_gemm(c, p, 1, pick_tile(M, 768, 512), s))) return rc;
+        if ((rc = run_gemm(c, p, 1, pick_tile(c, M, 768, 512), s))) return rc;
     }
     if (d_in.threshold) {  // dropout_input: on the features that feed both the pos-conv and its residual
         Scope sc(c, s, NOMAD_K_ROW, 0.0);
@@ -1371,23 +1374,23 @@ static int forward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, co
         float* lo = layers_out ? layers_out + (size_t)l * M * 768 + r0 * 768 : nullptr;
         const unsigned long long idx0 = (unsigned long long)r0 * 768;
         int rc;
-        if ((rc = run_gemm(c, dense(xs, 768, d.qkv_w, d.qkv_b, nullptr, qkv, Ms, 2304, 768, 0), 1, pick_tile(Ms, 2304, 768), s)))
+        if ((rc = run_gemm(c, dense(xs, 768, d.qkv_w, d.qkv_b, nullptr, qkv, Ms, 2304, 768, 0), 1, pick_tile(c, Ms, 2304, 768), s)))
             return rc;
         if ((rc = run_attention(c, qkv, ctxb, lse, nc, T, s, &d_att, site_attn(l), c0 * 12))) return rc;
         // residual dropout: y = x + dropout(W a + b) needs the branch on its own, so the residual add moves out
         // of the GEMM epilogue into the dropout kernel
         if ((rc = run_gemm(c, dense(ctxb, 768, d.o_w, d.o_b, d_res.threshold ? nullptr : xs, y1, Ms, 768, 768, 0), 1,
-                           pick_tile(Ms, 768, 768), s)))
+                           pick_tile(c, Ms, 768, 768), s)))
             return rc;
         if (d_res.threshold && (rc = run_dropout(c, y1, xs, y1, acts, d_res, site_proj(l), s, idx0))) return rc;
         if ((rc = run_layernorm(c, y1, d.ln1_w, d.ln1_b, x2s, nullptr, Ms, 768, s))) return rc;
         {
             GemmParams p = dense(x2s, 768, d.fc1_w, d.fc1_b, nullptr, hs, Ms, 3072, 768, 1);
             p.Upre = sv ? sv->L[l].u + r0 * 3072 : nullptr;
-            if ((rc = run_gemm(c, p, 1, pick_tile(Ms, 3072, 768), s))) return rc;
+            if ((rc = run_gemm(c, p, 1, pick_tile(c, Ms, 3072, 768), s))) return rc;
         }
         if ((rc = run_gemm(c, dense(hs, 3072, d.fc2_w, d.fc2_b, d_res.threshold ? nullptr : x2s, y2, Ms, 768, 3072, 0), 1,
-                           pick_tile(Ms, 768, 3072), s)))
+                           pick_tile(c, Ms, 768, 3072), s)))
             return rc;
         if (d_res.threshold && (rc = run_dropout(c, y2, x2s, y2, acts, d_res, site_ffn(l), s, idx0))) return rc;
         return run_layernorm(c, y2, d.ln2_w, d.ln2_b, xs, lo, Ms, 768, s);
@@ -1546,7 +1549,7 @@ static int forward_ragged(nomad_ctx* c, const float* wav, int B, int stride, con
         p.cmap = plain_map(p.M, 512);
         p.rmap = p.cmap;
         p.gelu = 1;
-        if ((rc = run_gemm(c, p, 1, pick_tile(p.M, 512, p.K), s))) return rc;
+        if ((rc = run_gemm(c, p, 1, pick_tile(c, p.M, 512, p.K), s))) return rc;
     }
     float* featln = cb[1];
     if ((rc = run_layernorm(c, cb[0], c->fln_w, c->fln_b, featln, nullptr, M, 512, s))) return rc;
@@ -1562,7 +1565,7 @@ static int forward_ragged(nomad_ctx* c, const float* wav, int B, int stride, con
         p.cmap = pad_map;
         p.c_colblk = 48;
         p.c_colblk_stride = grp_stride;
-        if ((rc = run_gemm(c, p, 1, pick_tile(M, 768, 512), s))) return rc;
+        if ((rc = run_gemm(c, p, 1, pick_tile(c, M, 768, 512), s))) return rc;
     }
     float *x = F(lay.x), *x2 = F(lay.x2), *y = F(lay.y), *qkv = F(lay.qkv), *ctxb = F(lay.ctxb), *hbuf = F(lay.h);
     {
@@ -1597,7 +1600,7 @@ static int forward_ragged(nomad_ctx* c, const float* wav, int B, int stride, con
     }
     for (int l = 0; l < NOMAD_NUM_LAYERS; ++l) {
         const LayerDev& d = c->layers[l];
-        if ((rc = run_gemm(c, dense(x, 768, d.qkv_w, d.qkv_b, nullptr, qkv, M, 2304, 768, 0), 1, pick_tile(M, 2304, 768), s)))
+        if ((rc = run_gemm(c, dense(x, 768, d.qkv_w, d.qkv_b, nullptr, qkv, M, 2304, 768, 0), 1, pick_tile(c, M, 2304, 768), s)))
             return rc;
         {
             Scope sc(c, s, NOMAD_K_ATTN, attn_flops);
@@ -1615,11 +1618,11 @@ static int forward_ragged(nomad_ctx* c, const float* wav, int B, int stride, con
                 hipLaunchKernelGGL(attention_f32_kernel<float>, dim3((std::min(rs.max_t, kAttnV2MinT - 1) + 63) / 64, B * 12), dim3(256), 0,
                                    s, qkv, ctxb, static_cast<float*>(nullptr), 0, tpref, DropCfg{}, 0u, 0, 0LL, kAttnV2MinT);
         }
-        if ((rc = run_gemm(c, dense(ctxb, 768, d.o_w, d.o_b, x, y, M, 768, 768, 0), 1, pick_tile(M, 768, 768), s))) return rc;
+        if ((rc = run_gemm(c, dense(ctxb, 768, d.o_w, d.o_b, x, y, M, 768, 768, 0), 1, pick_tile(c, M, 768, 768), s))) return rc;
         if ((rc = run_layernorm(c, y, d.ln1_w, d.ln1_b, x2, nullptr, M, 768, s))) return rc;
-        if ((rc = run_gemm(c, dense(x2, 768, d.fc1_w, d.fc1_b, nullptr, hbuf, M, 3072, 768, 1), 1, pick_tile(M, 3072, 768), s)))
+        if ((rc = run_gemm(c, dense(x2, 768, d.fc1_w, d.fc1_b, nullptr, hbuf, M, 3072, 768, 1), 1, pick_tile(c, M, 3072, 768), s)))
             return rc;
-        if ((rc = run_gemm(c, dense(hbuf, 3072, d.fc2_w, d.fc2_b, x2, y, M, 768, 3072, 0), 1, pick_tile(M, 768, 3072), s)))
+        if ((rc = run_gemm(c, dense(hbuf, 3072, d.fc2_w, d.fc2_b, x2, y, M, 768, 3072, 0), 1, pick_tile(c, M, 768, 3072), s)))
             return rc;
         if ((rc = run_layernorm(c, y, d.ln2_w, d.ln2_b, x, nullptr, M, 768, s))) return rc;
     }
@@ -1632,7 +1635,7 @@ static int bwd_gemm(nomad_ctx* c, const float* A, const float* Wt, float* C, int
     GemmParams p = dense(A, K, Wt, nullptr, R, C, M, N, K, 0);
     p.DG = DG;
     p.dgmap = plain_map(M, N);
-    return run_gemm(c, p, 1, pick_tile(M, N, K), s);
+    return run_gemm(c, p, 1, pick_tile(c, M, N, K), s);
 }
 
 static int run_ln_bwd(nomad_ctx* c, const float* x, const float* g, const float* g2, const float* gamma, float* dx, int M,
@@ -1651,19 +1654,13 @@ static int run_ln_bwd(nomad_ctx* c, const float* x, const float* g, const float*
 // The forward's (log2e) kernels stage K / V by LDS-DMA, 128-key tiles for the 256-query workgroups: attention 3.33 -> 3.05 ms per
 // C5 step, 1637-1646 -> 1676-1679 clips/s, bit-identical (gpurun_out/attndma).  NOMAD_BF16_ATTN_DMA = 0: staging through registers,
 // 1: LDS-DMA with 64-key tiles (A/B runs).
-static int bf16_attn_dma() {
-    static const int v = [] {
-        const char* e = getenv("NOMAD_BF16_ATTN_DMA");
-        return e ? atoi(e) : 2;
-    }();
-    return v;
-}
-static hipError_t run_attention_bf16(const bf16_t* qkv, bf16_t* out, int B, int T, const int* tpref, bool log2e, hipStream_t s) {
+static hipError_t run_attention_bf16(const nomad_ctx* c, const bf16_t* qkv, bf16_t* out, int B, int T, const int* tpref, bool log2e, hipStream_t s) {
+    const int dma = c->tune.bf16_attn_dma;
     const bool big = (long long)((T + 255) / 256) * B * 12 >= 1024;
-    if (log2e && bf16_attn_dma() == 1)
+    if (log2e && dma == 1)
         return big ? launch_attention_bf16_v2<8, 64, 4, true, true>(qkv, out, B, T, tpref, s)
                    : launch_attention_bf16_v2<4, 64, 4, true, true>(qkv, out, B, T, tpref, s);
-    if (log2e && bf16_attn_dma() == 2)
+    if (log2e && dma == 2)
         return big ? launch_attention_bf16_v2<8, 128, 4, true, true>(qkv, out, B, T, tpref, s)
                    : launch_attention_bf16_v2<4, 64, 4, true, true>(qkv, out, B, T, tpref, s);
     if (log2e) return big ? launch_attention_bf16_v2<8, 64, 4, true>(qkv, out, B, T, tpref, s)
@@ -1672,18 +1669,10 @@ static hipError_t run_attention_bf16(const bf16_t* qkv, bf16_t* out, int B, int 
                : launch_attention_bf16_v2<4, 64, 4, false>(qkv, out, B, T, tpref, s);
 }
 
-// conv0 of the bf16 path on the matrix cores (conv0_mfma_gn_gelu_kernel); NOMAD_BF16_CONV0_MFMA=0: the VALU kernel (A/B runs)
-static bool bf16_conv0_mfma() {
-    static const bool v = [] {
-        const char* e = getenv("NOMAD_BF16_CONV0_MFMA");
-        return e ? atoi(e) != 0 : true;
-    }();
-    return v;
-}
 // wav rows `stride` apart; lens == nullptr: every clip has l0 frames, else ragged (max_l0 = the longest clip's, pref0 = packed rows)
 static void launch_conv0_bf16(nomad_ctx* c, const float* wav, int stride, int l0, int max_l0, int B, const float* scale,
                               const float* shift, bf16_t* out, const int* lens, const int* pref0, hipStream_t s) {
-    if (bf16_conv0_mfma() && c->conv0_wfrag)
+    if (c->tune.bf16_conv0_mfma && c->conv0_wfrag)   // (Tuning::bf16_conv0_mfma = 0: the VALU kernel, A/B runs)
         hipLaunchKernelGGL((conv0_mfma_gn_gelu_kernel<kConv0MfmaOcc, kConv0MfmaUf>), dim3((max_l0 + kConv0MfmaFrames - 1) / kConv0MfmaFrames, B), dim3(256), 0, s, wav,
                            stride, l0, c->conv0_wfrag, scale, shift, out, lens, pref0);
     else
@@ -1691,43 +1680,6 @@ static void launch_conv0_bf16(nomad_ctx* c, const float* wav, int stride, int l0
                            stride, l0, c->conv0_w, scale, shift, out, lens, pref0, 0LL);
 }
 
-// smallest grid (in 256 x 256 tiles) that takes the deep-pipelined bf16 kernel; NOMAD_BF16_8PHASE_MIN_TILES overrides (A/B runs)
-static int p8_min_tiles() {
-    static const int v = [] {
-        const char* e = getenv("NOMAD_BF16_8PHASE_MIN_TILES");
-        return e ? atoi(e) : 256;
-    }();
-    return v;
-}
-
-// output stores of the deep-pipelined bf16 kernel carry the non-temporal hint; NOMAD_BF16_NT_STORES=0 switches it off (A/B runs)
-static bool p8_nt_stores() {
-    static const bool v = [] {
-        const char* e = getenv("NOMAD_BF16_NT_STORES");
-        return e ? atoi(e) != 0 : true;
-    }();
-    return v;
-}
-
-// residual prefetch in the epilogue of the deep-pipelined bf16 kernel (p8_epilogue, RPRE); NOMAD_BF16_RPRE=0 / 1 (A/B runs)
-// 0 = off, 1 = the RPRE instantiation for GEMMs with a residual only (alternates with the plain one: slower, kept for A/B),
-// 2 = for every GEMM (one code object), 3 (default) = 2 + the small epilogue for plain C / R matrices
-static int p8_residual_prefetch() {
-    static const int v = [] {
-        const char* e = getenv("NOMAD_BF16_RPRE");
-        return e ? atoi(e) : 3;
-    }();
-    return v;
-}
-// bf16x3 GEMMs on plain C / R matrices: one instantiation with a run-time output format and the small epilogue
-// (gemm_bf16x3.hip.h); NOMAD_X3_PLAIN_EPI=0: the two templated ones (A/B runs)
-static bool x3_plain_epilogue() {
-    static const bool v = [] {
-        const char* e = getenv("NOMAD_X3_PLAIN_EPI");
-        return e ? atoi(e) != 0 : true;
-    }();
-    return v;
-}
 // plain C / R matrices AND an A map whose divisions have magic numbers (uniform clips of at least two rows, n-fastest tile walk):
 // what the PLAIN instantiations (small epilogue, lean set-up) require
 static bool p8_plain_cr(const GemmParams& p) {
@@ -1736,13 +1688,11 @@ static bool p8_plain_cr(const GemmParams& p) {
            !p.amap.pref && p.group_m == 0 && (p.amap.clip_rows >= p.M || p.amap.clip_rows >= 2);
 }
 
-// three B buffers in the deep-pipelined bf16 kernel (B staged 1.75 K tiles ahead, 160 KB of LDS); NOMAD_BF16_B3=0: two (A/B runs)
-static bool p8_three_b() {
-    static const bool v = [] {
-        const char* e = getenv("NOMAD_BF16_B3");
-        return e ? atoi(e) != 0 : true;
-    }();
-    return v;
+// what the persistent 256 x 256 kernel (gemm_bf16_p9.hip.h) requires on top of p8_plain_cr: one group, contiguous K, every column
+// stored, no split planes
+static bool p9_applies(const GemmParams& p, int groups) {
+    return groups == 1 && p8_plain_cr(p) && p.N % 256 == 0 && p.n_valid == p.N && p.K % 128 == 0 && p.kchunk == p.K &&
+           p.a_plane == 0 && p.c_plane == 0 && !p.Upre && !p.DG;
 }
 
 // 256 x 192 instead of 256 x 256 tiles in the deep-pipelined bf16 kernel (gemm_bf16_8phase.hip.h, NJ = 3) for the N = 768 GEMMs
@@ -1751,11 +1701,8 @@ static bool p8_three_b() {
 // the C5 forward the other GEMMs slow down by more than that - the chip holds 2130 instead of 2157 MHz (2400 nominal) with
 // them, 19.25 vs 18.98 ms per forward (profiles/r03_n192_null.txt).  NOMAD_BF16_N192=1 takes them wherever they save a round
 // (a 192-column tile costs ~0.78 of a 256-column one), =2 wherever N % 192 == 0.
-static bool p8_use_n192(int M, int N, int K) {
-    static const int mode = [] {
-        const char* e = getenv("NOMAD_BF16_N192");
-        return e ? atoi(e) : 0;
-    }();
+static bool p8_use_n192(const nomad_ctx* c, int M, int N, int K) {
+    const int mode = c->tune.p8_n192;
     if (N % 192 != 0 || mode <= 0) return false;
     if (mode == 2) return true;
     if (mode == 3 && K < 2048) return false;   // A/B: the long-K problems only (fc2)
@@ -1766,6 +1713,17 @@ static bool p8_use_n192(int M, int N, int K) {
 }
 
 static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, int tile = -1) {
+    // Tuning (A/B switches of the diag library; defaults = shipped): p8_min_tiles - smallest grid in 256 x 256 tiles that takes the
+    // deep-pipelined kernels; p8_nt_stores - their output stores carry the non-temporal hint; p8_rpre - residual prefetch in p8_epilogue
+    // (0 off, 1 residual GEMMs only, 2 every GEMM, 3 = 2 + the small epilogue for plain C / R); x3_plain_epi - one bf16x3 instantiation
+    // with a run-time output format; p8_three_b - three B buffers (160 KB of LDS); p9 - the persistent kernel wherever it applies
+    const Tuning& tu = c->tune;
+    auto p8_min_tiles = [&] { return tu.p8_min_tiles; };
+    auto p8_nt_stores = [&] { return tu.p8_nt_stores; };
+    auto p8_residual_prefetch = [&] { return tu.p8_rpre; };
+    auto x3_plain_epilogue = [&] { return tu.x3_plain_epi; };
+    auto p8_three_b = [&] { return tu.p8_three_b; };
+    auto p9_on = [&] { return tu.p9; };
     const double flops = 2.0 * p.M * (double)p.n_valid * p.K * groups;  // bf16x3: the fp32-equivalent count, not 3x
     if (tile < 0) {
         // measured (profiles/r01_gemm_sweep_bf16.json): 256x256 tiles (wave tile 64x128) win on wide (N >= 1024)
@@ -1773,10 +1731,10 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
         if (p.N % 128 != 0) tile = p.M < 512 ? 4 : 2;
         else if (p.M < 512) tile = 4;
         else if (p.N % 256 == 0 && p.K % 128 == 0 && groups == 1 && (long long)((p.M + 255) / 256) * (p.N / 256) >= p8_min_tiles())
-            tile = (p8_three_b() && p8_nt_stores() && p8_use_n192(p.M, p.N, p.K)) ? 55 : 16;  // deep-pipelined 256x256 / 256x192 kernel once there are >= 2 rounds of tiles (profiles/r01_gemm_sweep_bf16_8phase.json)
+            tile = (p9_on() && p9_applies(p, groups)) ? 60 : (p8_three_b() && p8_nt_stores() && p8_use_n192(c, p.M, p.N, p.K)) ? 55 : 16;  // deep-pipelined 256x256 / 256x192 kernel once there are >= 2 rounds of tiles (profiles/r01_gemm_sweep_bf16_8phase.json)
         else tile = (p.N % 256 == 0 && (p.N >= 1024 || p.M >= 100000)) ? 3 : 1;
     }
-    Scope sc(c, s, NOMAD_K_GEMM, flops, (tile == 1 || tile == 3 || tile == 16 || tile == 55 || tile == 56 || tile == 57 || tile == 58 || tile == 42 || tile == 43 || tile == 44 || tile == 45 || tile == 46 || tile == 47 || tile == 48 || tile == 49 || tile == 50 || tile == 51 || tile == 52 || tile == 53 || tile == 54 || tile == 20 || tile == 21 || tile == 27 || tile == 28 || tile == 32 || tile == 33) ? NOMAD_K_GEMM_BIG : (tile == 2 ? NOMAD_K_GEMM_FINE : -1));
+    Scope sc(c, s, NOMAD_K_GEMM, flops, (tile == 1 || tile == 3 || tile == 16 || tile == 60 || tile == 61 || tile == 62 || tile == 55 || tile == 56 || tile == 57 || tile == 58 || tile == 42 || tile == 43 || tile == 44 || tile == 45 || tile == 46 || tile == 47 || tile == 48 || tile == 49 || tile == 50 || tile == 51 || tile == 52 || tile == 53 || tile == 54 || tile == 20 || tile == 21 || tile == 27 || tile == 28 || tile == 32 || tile == 33) ? NOMAD_K_GEMM_BIG : (tile == 2 ? NOMAD_K_GEMM_FINE : -1));
     hipError_t e;
     switch (tile) {
         // the instantiations the bf16 / bf16x3 forwards select
@@ -1791,6 +1749,10 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
                 : (p8_residual_prefetch() == 3 && p8_plain_cr(p)) ? launch_gemm_bf16_8phase<8, false, 0, 3, 4, true, true>(p, groups, s)
                 : ((p.R && p8_residual_prefetch() == 1) || p8_residual_prefetch() >= 2) ? launch_gemm_bf16_8phase<8, false, 0, 3, 4, true>(p, groups, s)
                                                   : launch_gemm_bf16_8phase<8, false, 0, 3>(p, groups, s);
+            break;
+        case 60:  // persistent form of the deep-pipelined kernel: one workgroup per CU walks tiles, direct epilogue (gemm_bf16_p9.hip.h)
+            if (!p9_applies(p, groups)) return fail(NOMAD_ERR_INVALID, "bf16 persistent gemm: plain C / R, one group, N %% 256, K %% 128, contiguous K");
+            e = launch_gemm_bf16_p9<0>(p, s, c->num_cus);
             break;
         case 57:  // the deep-pipelined kernel with the residual prefetch in the epilogue, general C / R addressing
         case 58:  // ... with the small epilogue for plain C / R matrices (what tile 16 resolves to for them)
@@ -1880,6 +1842,11 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
         case 36:  // timing probe: per-workgroup timeline (nomad_diag_timeline, tools/gemm_timeline.py)
             if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
             e = launch_gemm_bf16_8phase<7>(p, groups, s);
+            break;
+        case 61:  // persistent kernel: per-workgroup timeline probe / no output stores (timing)
+        case 62:
+            if (!p9_applies(p, groups)) return fail(NOMAD_ERR_INVALID, "bf16 persistent gemm: plain C / R, one group, N %% 256, K %% 128, contiguous K");
+            e = tile == 61 ? launch_gemm_bf16_p9<7>(p, s, c->num_cus) : launch_gemm_bf16_p9<1>(p, s, c->num_cus);
             break;
         case 22: e = launch_gemm_bf16_8phase<3, false, 2>(p, groups, s); break;  // bf16x3 timing probes, fp32 output
         case 23: e = launch_gemm_bf16_8phase<4, false, 2>(p, groups, s); break;
@@ -2109,7 +2076,7 @@ static int forward_bf16(nomad_ctx* c, const float* wav, int B, int n_samples, fl
         CK(qkv, B, clip768 * 3);
         {
             Scope sc(c, s, NOMAD_K_ATTN, 4.0 * B * 12.0 * (double)T * T * 64);
-            HIP_TRY(run_attention_bf16(qkv, ctxb, B, T, nullptr, true, s));
+            HIP_TRY(run_attention_bf16(c, qkv, ctxb, B, T, nullptr, true, s));
         }
         CK(ctxb, B, clip768);
         if ((rc = run_gemm_bf16(c, dense(asf(ctxb), 768, asf(c->o_w16[l]), d.o_b, asf(x), asfm(y), M, 768, 768, 0), 1, s)))
@@ -2605,7 +2572,7 @@ static int forward_ragged_bf16(nomad_ctx* c, const float* wav, int B, int stride
             return rc;
         {
             Scope sc(c, s, NOMAD_K_ATTN, attn_flops);
-            HIP_TRY(run_attention_bf16(qkv, ctxb, B, rs.max_t, tpref, true, s));
+            HIP_TRY(run_attention_bf16(c, qkv, ctxb, B, rs.max_t, tpref, true, s));
         }
         if ((rc = run_gemm_bf16(c, dense(asf(ctxb), 768, asf(c->o_w16[l]), d.o_b, asf(x), asfm(y), M, 768, 768, 0), 1, s)))
             return rc;
@@ -2889,7 +2856,7 @@ int nomad_diag_timeline(unsigned long long* out_host, int n) {
 int nomad_diag_gemm_bf16(nomad_ctx* c, const void* A, const void* W, const float* bias, const void* R, void* C, int M,
                          int N, int K, int gelu, int tile, nomad_stream_t stream) {
     static const int kBN[] = {128, 128, 64, 256, 64, 128, 128, 128, 128, 256, 256, 128, 128, 128, 128, 256, 256, 256, 256, 256};
-    const bool big256 = tile == 36 || (tile >= 42 && tile <= 54) || tile == 57 || tile == 58;
+    const bool big256 = tile == 36 || (tile >= 42 && tile <= 54) || tile == 57 || tile == 58 || (tile >= 60 && tile <= 62);
     if (tile == 55 || tile == 56) {  // 256 x 192 tiles of the deep-pipelined kernel
         if (!c || !A || !W || !C || M <= 0) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: bad argument");
         if (N % 192 || K % 128) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: N %% 192 or K %% 128 != 0");
@@ -3277,7 +3244,7 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
             p.cmap = RowMap{64LL * 48, (long long)(T + 128) * 48, T, 48};
             p.c_colblk = 48;
             p.c_colblk_stride = grp_stride;
-            if ((rc = run_gemm(c, p, 1, pick_tile(M, 768, 512), s))) return rc;
+            if ((rc = run_gemm(c, p, 1, pick_tile(c, M, 768, 512), s))) return rc;
         }
         if (d_in.threshold) {
             Scope sc(c, s, NOMAD_K_ROW, 0.0);
@@ -3378,7 +3345,7 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
             p.cmap = RowMap{out_off, out_clip, Lout, 1024};
             p.dgmap = RowMap{0, (long long)Lin * 512, Lout, 1024};
             p.kchunk = p.K; p.ldw = p.K; p.n_valid = p.N;
-            if ((rc = run_gemm(c, p, 1, pick_tile(p.M, p.N, p.K), s))) return rc;
+            if ((rc = run_gemm(c, p, 1, pick_tile(c, p.M, p.N, p.K), s))) return rc;
         } else {
             const int E = (Lin + 1) / 2, O = Lin / 2;
             // even input frames 2t': dU[t'-1] W_tap2 + dU[t'] W_tap0
@@ -3390,7 +3357,7 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
             p.cmap = RowMap{out_off, out_clip, E, 1024};
             p.dgmap = RowMap{0, (long long)Lin * 512, E, 1024};
             p.kchunk = p.K; p.ldw = p.K; p.n_valid = p.N;
-            if ((rc = run_gemm(c, p, 1, pick_tile(p.M, p.N, p.K), s))) return rc;
+            if ((rc = run_gemm(c, p, 1, pick_tile(c, p.M, p.N, p.K), s))) return rc;
             // odd input frames 2t'+1: dU[t'] W_tap1
             p.amap = RowMap{512, (long long)(Lout + 2) * 512, O, 512};
             p.K = 512;
@@ -3399,7 +3366,7 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
             p.cmap = RowMap{out_off + 512, out_clip, O, 1024};
             p.dgmap = RowMap{512, (long long)Lin * 512, O, 1024};
             p.kchunk = p.K; p.ldw = p.K;
-            if (O > 0 && (rc = run_gemm(c, p, 1, pick_tile(p.M, p.N, p.K), s))) return rc;
+            if (O > 0 && (rc = run_gemm(c, p, 1, pick_tile(c, p.M, p.N, p.K), s))) return rc;
         }
     }
     // ---- conv0 + GroupNorm -> d loss / d waveform -------------------------------------------------------
@@ -3783,9 +3750,9 @@ int nomad_train_set_step(nomad_ctx* c, long long step) {
     return 0;
 }
 
-int nomad_set_concurrent_parts(int parts) {
-    if (parts < 1) return fail(NOMAD_ERR_INVALID, "nomad_set_concurrent_parts: parts = %d", parts);
-    g_concurrent_parts = parts;
+int nomad_set_concurrent_parts(nomad_ctx* c, int parts) {
+    if (!c || parts < 1) return fail(NOMAD_ERR_INVALID, "nomad_set_concurrent_parts: ctx %p, parts = %d", (void*)c, parts);
+    c->tune.concurrent_parts = parts;
     return 0;
 }
 
@@ -3963,7 +3930,7 @@ int nomad_diag_gemm(nomad_ctx* c, const float* A, const float* W, const float* b
         if (N % 128 || K % 32 || (R && gelu)) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile 99 needs N %% 128 == 0, K %% 32 == 0, no GELU with a residual");
         GemmParams pp = dense(A, K, W, bias, R, C, M, N, K, gelu);
         hipStream_t st = static_cast<hipStream_t>(stream);
-        const int m1 = mixed_split_rows(M, N);
+        const int m1 = mixed_split_rows(c, M, N);
         if (m1 <= 0) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile 99: no split for M = %d, N = %d", M, N);
         Scope sc(c, st, NOMAD_K_GEMM, 2.0 * M * (double)N * K, NOMAD_K_GEMM_BIG);
         constexpr int V = 13 | 16 | 64 | 16384;
@@ -4073,7 +4040,7 @@ int nomad_diag_attention_bf16(nomad_ctx* c, const void* qkv, void* out, int B, i
     if (!c || !qkv || !out || B <= 0 || T <= 0) return fail(NOMAD_ERR_INVALID, "nomad_diag_attention_bf16: bad argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     Scope sc(c, s, NOMAD_K_ATTN, 4.0 * B * 12.0 * (double)T * T * 64);
-    HIP_TRY(run_attention_bf16(static_cast<const bf16_t*>(qkv), static_cast<bf16_t*>(out), B, T, nullptr, q_has_log2e != 0, s));
+    HIP_TRY(run_attention_bf16(c, static_cast<const bf16_t*>(qkv), static_cast<bf16_t*>(out), B, T, nullptr, q_has_log2e != 0, s));
     return 0;
 }
 

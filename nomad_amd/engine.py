@@ -179,10 +179,10 @@ class Engine:
         ways = min(self.F32_SPLIT_WAYS, B)
         if side or want_layers or ways < 2 or not self.F32_SPLIT_ROWS or not (self.F32_SPLIT_ROWS <= B * T < self.F32_SPLIT_MAX_ROWS):
             if not side:
-                self.lib.nomad_set_concurrent_parts(1)   # tile-shape hint only: results never depend on it (include/nomad_hip.h)
+                self.lib.nomad_set_concurrent_parts(self.ctx, 1)   # tile-shape hint only: results never depend on it (include/nomad_hip.h)
             run(wav, emb, side)
         else:
-            self.lib.nomad_set_concurrent_parts(ways)
+            self.lib.nomad_set_concurrent_parts(self.ctx, ways)
             # parts of the batch on separate streams: each part's kernels fill the CUs the others' partial last rounds of tiles
             # leave idle (every instantiation contracts k in the same order, so the parts' bits equal the whole batch's)
             cur = torch.cuda.current_stream(self.device)
@@ -488,10 +488,11 @@ class Engine:
                    "nomad_diag_attention_bf16")
         return out
 
-    def diag_gemm_bf16(self, A, W, bias=None, R=None, gelu=False, tile=0):
+    def diag_gemm_bf16(self, A, W, bias=None, R=None, gelu=False, tile=0, out=None):
         M, K = A.shape
         N = W.shape[0]
-        out = torch.zeros(M, N, dtype=torch.bfloat16, device=self.device)  # zeros: a kernel that writes nothing shows
+        if out is None:
+            out = torch.zeros(M, N, dtype=torch.bfloat16, device=self.device)  # zeros: a kernel that writes nothing shows
         _lib.check(self.lib.nomad_diag_gemm_bf16(self.ctx, A.data_ptr(), W.data_ptr(),
                                                  bias.data_ptr() if bias is not None else None,
                                                  R.data_ptr() if R is not None else None, out.data_ptr(),

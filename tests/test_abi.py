@@ -39,6 +39,23 @@ def test_shape_helpers(built_lib):
     assert _lib.load(diag=True).nomad_build_flags() == 2
 
 
+def test_product_library_reads_no_environment(built_lib):
+    """include/nomad_hip.h: "nothing but the arguments" decides what a call does.  The kernel-choice switches of the A/B runs
+    (NOMAD_F32_*, NOMAD_BF16_*, NOMAD_SPLITK_*) live in a per-context struct whose defaults are the shipped configuration; only
+    libnomad_diag.so fills it from the environment.  Hold the product to that: it does not even import getenv."""
+    import shutil
+    import subprocess
+    from nomad_amd import build
+    nm = shutil.which("nm") or shutil.which("llvm-nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    if not os.path.exists(nm):
+        pytest.skip("nm not available")
+    syms = subprocess.run([nm, "-D", "--undefined-only", build.LIB], capture_output=True, text=True, check=True).stdout
+    assert "hipLaunchKernel" in syms or "hipModuleLaunchKernel" in syms or "__hipPushCallConfiguration" in syms, "nm output looks empty"
+    assert not re.search(r"\b(secure_)?getenv\b", syms), "libnomad_hip.so imports getenv"
+    diag = subprocess.run([nm, "-D", "--undefined-only", build.DIAG_LIB], capture_output=True, text=True, check=True).stdout
+    assert re.search(r"\bgetenv\b", diag), "libnomad_diag.so is expected to read its A/B switches from the environment"
+
+
 def test_create_fails_loudly_without_gpu(built_lib, sd0):
     import torch
     if torch.cuda.is_available():
