@@ -162,6 +162,20 @@ def c3_sharded_scores(embed_fn, pairwise_fn, wav, n_deg_local, batch, use_pg, st
     return scores, ref_all, d
 
 
+def agree_or_raise(err, use_pg, what):
+    """All ranks learn whether ANY rank failed a local set-up step, before the leg's first collective: a rank that failed alone
+    must not leave the others waiting inside an all-gather.  Raises on every rank if one did."""
+    if use_pg:
+        import torch
+        import torch.distributed as dist
+        bad = torch.tensor([0 if err is None else 1], dtype=torch.int32, device="cuda")
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if int(bad.item()) and err is None:
+            err = RuntimeError(f"{what}: another rank could not set the leg up")
+    if err is not None:
+        raise err
+
+
 def time_c3(eng, world, rank, use_pg, fence, n_deg=10000, n_ref=1000, batch=256):
     """BASELINE.json configs[2]: 10 000 degraded x 1 000 non-matching references (16 kHz x 4 s, fp32), clips sharded over the
     ranks, ONE all-gather of the reference embeddings, each rank's distance slab + row means, one gather of the scores.
@@ -435,6 +449,17 @@ def main():
             # what long-form scores within the north star's 1e-4 cost next to the bf16 figure
             c5_x3 = None
             try:
+                # what can fail on ONE rank only (the workspaces of the extra bf16x3 / fp32 passes over 32 x 480 000 samples) happens
+                # locally, without a collective, and the ranks agree before the sharded scoring below (ShardedScorer.score all-gathers)
+                err5 = None
+                try:
+                    eng.embed_bf16x3(wav5)
+                    eng.embed(wav5)
+                    fence_local = torch.cuda.synchronize
+                    fence_local()
+                except Exception as e:  # noqa: BLE001
+                    err5 = e
+                agree_or_raise(err5, use_pg, "configs[4] fp32-class leg")
                 sc5x = ShardedScorer(eng.embed_bf16x3, eng.pairwise, equal_shards=True, force_collective=use_pg)
                 for _ in range(2):
                     m5x, _, _ = sc5x.score(wav5[:28], wav5[28:], want_matrix=True)

@@ -1,0 +1,241 @@
+// bf16 self-attention for long clips on the 16-wide matrix shape (round 5; BASELINE config C5: 30 s, T = 1499).
+//
+// attention_bf16_v2.hip.h computes both products with v_mfma_f32_32x32x16_bf16; the chip holds 1994 MHz of its 2400 under that
+// kernel (profiles/NOTEBOOK.md, "Open at the end of round 4") - the 32-wide shape moves twice the accumulator registers per
+// multiply-add, the same effect that cost the fp32 GEMM and the fp32 attention 3-4 % of clock until they moved to 16x16x4.
+// Same algorithm here on v_mfma_f32_16x16x32_bf16, with lane = (fr = lane & 15, fq = lane >> 4):
+//   * a wave owns 32 queries as two 16-query sub-blocks qs; a 32-key block is two 16-key sub-blocks kb.  Both products are
+//     TRANSPOSED: S^T[kb][qs] = K[kb] Q[qs]^T leaves lane (fr, fq) the scores of query fr for keys 4 fq + r, and those four registers of
+//     kb = 0 and kb = 1, converted to bf16 in place, ARE the B operand of O^T[db][qs] += V^T[db] P^T[qs] once the contraction slot
+//     (fq, j) of that product is DEFINED as key 16 (j >> 2) + 4 fq + (j & 3): no lane exchange, no LDS round trip;
+//   * the matching A operand V^T (rows d = 16 db + fr, slots (fq, j)) is two ds_read_b64_tr_b16 per db: lane group fq gathers
+//     4 key rows x 16 d columns, which is exactly keys 4 fq .. 4 fq + 3 (j < 4) and 16 + 4 fq .. (j >= 4) of the row-major V tile;
+//   * the reference maximum m_ref enters as the C operand of the first score MFMA (a register quad holding -m_ref): the
+//     accumulator comes out as s - m_ref at no cost - the 32-wide kernel spent a fifth k-step (ones x (-m_ref)) on that, 11 % of
+//     its matrix time;
+//   * the deferred rescale is decided on the lanes' OWN maxima (any lane above the threshold <=> some query's maximum above it), so
+//     the common block has no cross-lane operation at all; only a rescale reduces over the four lanes of a query
+//     (v_permlane16_swap + v_permlane32_swap);
+//   * K rows keep the GEMM's chunk swizzle ((row >> 1) & 7); V rows are swizzled in 32-byte pairs by (row >> 1) & 3, which spreads
+//     the 8 rows x 32 bytes a 32-lane half gathers per transposing read over all 64 banks once.
+// Scores in log2 units (q carries log2 e), p = 2^(s - m_ref) <= 2^kA2Thr between rescales, fp32 row sums and accumulation, K / V
+// tiles of KT keys double-buffered by LDS-DMA with one barrier per tile: as attention_bf16_v2.hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "attention_bf16_v2.hip.h"
+#include "attention_f32_v2.hip.h"
+
+namespace nomad {
+
+// grid: 1-D, nqblk * B * 12 workgroups of 64 * NW threads (nqblk = ceil(T / (32 NW))); dynamic LDS attn_bf16_v2_lds(KT).
+// tpref (nullable): ragged batches - clip b owns rows tpref[b] .. tpref[b+1]-1 of qkv / out; T is then the longest clip's.
+// q must carry the factor log2(e) (nomad_enable_bf16 folds it into the q rows of the QKV weight).
+template <int NW, int KT, int OCC>
+__global__ __launch_bounds__(64 * NW, OCC) void attention_bf16_v3_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                                         int T, int nqblk, const int* __restrict__ tpref) {
+    extern __shared__ __attribute__((aligned(16))) char a3_lds[];
+    constexpr int NT = 64 * NW;       // threads
+    constexpr int QB = 32 * NW;       // queries per workgroup
+    constexpr int NB = KT / 32;       // 32-key blocks per tile
+    constexpr int NCH = KT * 8 / NT;  // 16-byte chunks of K (and of V) each thread stages per tile
+    static_assert(NCH >= 1 && NCH * NT == KT * 8, "tile rows must divide over the threads");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    // XCD-aware placement: the query blocks of one head run on one XCD (their K / V re-reads are L2 hits)
+    const int nwg = gridDim.x, id = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = id & 7;
+    const int virt = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
+    const int bh = virt / nqblk, qb = virt - bh * nqblk;
+    const int b = bh / 12, hd = bh - b * 12;
+    long long row0 = (long long)b * T;
+    if (tpref) {
+        row0 = tpref[b];
+        T = tpref[b + 1] - tpref[b];
+    }
+    if (qb * QB >= T) return;  // whole workgroup, before any barrier
+    const bf16_t* __restrict__ src_bh = qkv + row0 * 2304 + hd * 64;
+    const int q_row0 = qb * QB + wave * 32 + fr;   // + 16 qs
+    bf16x8 qf[2][2];   // B operand of S^T: query fr of sub-block qs, d = 32 ks + 8 fq .. + 7
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+        const int qr = q_row0 + 16 * qs;
+        const bf16_t* qp = src_bh + (long long)(qr < T ? qr : T - 1) * 2304 + 8 * fq;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) qf[qs][ks] = *reinterpret_cast<const bf16x8*>(qp + 32 * ks);
+    }
+    f32x4 o[4][2];   // O^T[db][qs]: d = 16 db + 4 fq + r, query fr of sub-block qs
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) o[db][qs] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_ref[2] = {0.f, 0.f};   // reference maximum of this lane's two queries (log2 units), the same in the four lanes of a query
+    f32x4 negm[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};   // -m_ref: the C operand of the first score MFMA
+    float l_run[2] = {0.f, 0.f};   // sum of p over THIS lane's keys (reduced over the query's four lanes at the end)
+    const bool wave_active = qb * QB + wave * 32 < T;  // wave-uniform: the transposing reads need a full EXEC mask
+    const int ntiles = (T + KT - 1) / KT;
+
+    // ---- staging by LDS-DMA: a wave's instruction fills 1 KB = 8 rows linearly; lane (row l >> 3, physical chunk l & 7) fetches the
+    // LOGICAL chunk the swizzle maps there (K: chunk ^ ((row >> 1) & 7); V: chunk ^ 2 ((row >> 1) & 3)) ----
+    auto fetch = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int cid = tid + i * NT, row = cid >> 3, ch = cid & 7;
+            int key = kt * KT + row;
+            key = key < T ? key : T - 1;
+            const bf16_t* src = src_bh + (long long)key * 2304;
+            char* dk = a3_lds + ((kt & 1) * (KT * 256)) + (i * NT + wave * 64) * 16;
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + 768 + 8 * (ch ^ ((row >> 1) & 7))), (lptr_t)dk, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + 1536 + 8 * (ch ^ (2 * ((row >> 1) & 3)))), (lptr_t)(dk + KT * 128), 16, 0, 0);
+        }
+    };
+    // ---- fragment read addresses (bytes inside a buffer, 32-key block 0) ----
+    // K (A operand of S^T): lane (key row 16 kb + fr, chunk 4 ks + fq) -> physical chunk (4 ks + fq) ^ ((fr >> 1) & 7)
+    const int kswz = (fr >> 1) & 7;
+    const int k_off0 = fr * 128 + 16 * ((0 + fq) ^ kswz), k_off1 = fr * 128 + 16 * ((4 + fq) ^ kswz);   // ks = 0 / 1; + 2048 kb
+    // V (A operand of O^T): within the 16-lane group fq, lane 4 q4 + p4 addresses key row 16 half + 4 fq + q4, d columns 16 db + 4 p4 ..:
+    // byte 32 (db ^ x) + 8 p4 of the row, x = (2 (fq & 1) + (q4 >> 1)) & 3 the row's pair swizzle
+    const int q4 = fr >> 2, p4 = fr & 3;
+    const int vx = (2 * (fq & 1) + (q4 >> 1)) & 3;
+    const int v_row = KT * 128 + (4 * fq + q4) * 128 + 8 * p4;   // + 2048 half + 4096 blk
+    int v_db[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) v_db[db] = v_row + 32 * (db ^ vx);
+
+    fetch(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < ntiles; ++kt) {
+        if (kt + 1 < ntiles) fetch(kt + 1);  // in flight during the whole compute phase, into the buffer the last barrier released
+        if (wave_active) {
+            const char* B0 = a3_lds + (kt & 1) * (KT * 256);
+            const int left = T - kt * KT;  // valid keys from this tile on
+            const int nb = left >= KT ? NB : (left + 31) >> 5;
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) {
+                if (blk < nb) {
+                    // ---- scores: S^T[kb][qs] - m_ref = K[kb] Q[qs]^T + (-m_ref) ----
+                    f32x4 s[2][2];
+                    {
+                        const char* kp = B0 + blk * 4096;
+                        bf16x8 kf[2][2];
+#pragma unroll
+                        for (int kb = 0; kb < 2; ++kb) {
+                            kf[kb][0] = *reinterpret_cast<const bf16x8*>(kp + kb * 2048 + k_off0);
+                            kf[kb][1] = *reinterpret_cast<const bf16x8*>(kp + kb * 2048 + k_off1);
+                        }
+#pragma unroll
+                        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                            for (int qs = 0; qs < 2; ++qs) {
+                                s[kb][qs] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kb][0], qf[qs][0], negm[qs], 0, 0, 0);
+                                s[kb][qs] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kb][1], qf[qs][1], s[kb][qs], 0, 0, 0);
+                            }
+                    }
+                    const int valid = left - blk * 32;
+                    if (valid < 32) {  // the clip's last, partial block: keys past its end drop out of the softmax
+#pragma unroll
+                        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (16 * kb + 4 * fq + r >= valid) {
+                                    s[kb][0][r] = -1e30f;
+                                    s[kb][1][r] = -1e30f;
+                                }
+                    }
+                    // ---- this lane's maxima (relative to m_ref); a rescale only when some lane is above the threshold ----
+                    float pm[2];
+#pragma unroll
+                    for (int qs = 0; qs < 2; ++qs) {
+                        float m = fmaxf(s[0][qs][0], s[0][qs][1]);
+                        m = a2_max3(m, s[0][qs][2], s[0][qs][3]);
+                        m = a2_max3(m, s[1][qs][0], s[1][qs][1]);
+                        pm[qs] = a2_max3(m, s[1][qs][2], s[1][qs][3]);
+                    }
+                    const bool first = (kt == 0 && blk == 0);
+                    if (first || __any(fmaxf(pm[0], pm[1]) > kA2Thr)) {  // rare after the first block: move the reference maxima
+#pragma unroll
+                        for (int qs = 0; qs < 2; ++qs) {
+                            const float pmax = f2_max4(pm[qs]);   // over the four lanes of the query: the same value in all of them
+                            const float delta = first ? pmax : fmaxf(pmax, 0.f);
+                            const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+                            for (int db = 0; db < 4; ++db) o[db][qs] *= alpha;
+                            l_run[qs] *= alpha;
+#pragma unroll
+                            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) s[kb][qs][r] -= delta;
+                            m_ref[qs] += delta;
+                            negm[qs] = (f32x4){-m_ref[qs], -m_ref[qs], -m_ref[qs], -m_ref[qs]};
+                        }
+                    }
+                    // ---- p = 2^(s - m_ref), row sums, P^T[qs] as the B operand (slot (fq, j) = key 16 (j >> 2) + 4 fq + (j & 3)) ----
+                    bf16x8 pf[2];
+#pragma unroll
+                    for (int qs = 0; qs < 2; ++qs) {
+                        float ls0 = 0.f, ls1 = 0.f;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            s[0][qs][r] = __builtin_amdgcn_exp2f(s[0][qs][r]);
+                            s[1][qs][r] = __builtin_amdgcn_exp2f(s[1][qs][r]);
+                            ls0 += s[0][qs][r];
+                            ls1 += s[1][qs][r];
+                        }
+                        l_run[qs] += ls0 + ls1;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            pf[qs][r] = (bf16_t)s[0][qs][r];
+                            pf[qs][4 + r] = (bf16_t)s[1][qs][r];
+                        }
+                    }
+                    // ---- O^T[db][qs] += V^T[db] P^T[qs] ----
+                    const char* vp = B0 + blk * 4096;
+#pragma unroll
+                    for (int db = 0; db < 4; ++db) {
+                        const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(vp + v_db[db]));
+                        const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(vp + 2048 + v_db[db]));
+                        bf16x8 vf;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            vf[j] = v0[j];
+                            vf[4 + j] = v1[j];
+                        }
+                        o[db][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[0], o[db][0], 0, 0, 0);
+                        o[db][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[1], o[db][1], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (kt + 1 < ntiles) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the next tile has landed
+        __syncthreads();
+    }
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+        const float inv = 1.0f / f2_sum4(l_run[qs]);
+        const int qr = q_row0 + 16 * qs;
+        if (qr < T) {
+            bf16_t* dst = out + (row0 + qr) * 768 + hd * 64 + 4 * fq;
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+                store4<bf16_t>(dst + 16 * db, make_float4(o[db][qs][0] * inv, o[db][qs][1] * inv, o[db][qs][2] * inv, o[db][qs][3] * inv));
+        }
+    }
+}
+
+template <int NW, int KT, int OCC>
+inline hipError_t launch_attention_bf16_v3(const bf16_t* qkv, bf16_t* out, int B, int T, const int* tpref, hipStream_t s) {
+    static bool configured = false;
+    auto kern = attention_bf16_v3_kernel<NW, KT, OCC>;
+    constexpr int lds = attn_bf16_v2_lds(KT);
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    const int nqblk = (T + 32 * NW - 1) / (32 * NW);
+    hipLaunchKernelGGL(kern, dim3(nqblk * B * 12), dim3(64 * NW), lds, s, qkv, out, T, nqblk, tpref);
+    return hipGetLastError();
+}
+
+}  // namespace nomad

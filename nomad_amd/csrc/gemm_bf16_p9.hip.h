@@ -34,14 +34,41 @@
 
 namespace nomad {
 
+// s_waitcnt vmcnt(N) as the real instruction (__builtin_amdgcn_s_waitcnt), not as inline asm: the compiler's wait-count pass
+// understands it - it knows every vector-memory operation older than the N newest complete behind it, so it adds no wait of its own
+// (which would be vmcnt(0): a drained LDS-DMA queue) for an ordinary load that one of these counted waits already covers.
+// gfx9 encoding of the immediate: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14 (other counters left at "do not wait").
+__device__ __forceinline__ constexpr int p9_vmcnt(int n) { return (n & 15) | (7 << 4) | (15 << 8) | ((n >> 4) << 14); }
+#define NOMAD_P9_WAIT_VM(N)                              \
+    {                                                    \
+        __builtin_amdgcn_s_waitcnt(p9_vmcnt(N));         \
+        asm volatile("" ::: "memory");                   \
+    }
+
 // LDS position p (0..63) of a wave's 64-column W group holds W row perm(p): accumulator tile j = p >> 4, operand row i16 = p & 15
 // (= 4 fq + r of the transposed result) -> column 32 (j >> 1) + 8 fq + 4 (j & 1) + r.
 __host__ __device__ constexpr int p9_wperm(int p) { return 32 * (p >> 5) + 8 * ((p >> 2) & 3) + 4 * ((p >> 4) & 1) + (p & 3); }
 
-// ABL: 0 = product; 7 = per-workgroup timeline probe (tools/gemm_timeline.py --p9); 1 = no output stores (timing probe)
-template <int ABL = 0>
+// ABL: 0 = product; 7 = per-workgroup timeline probe (tools/p9_timeline.py); 1 = no output stores (timing probe)
+// INTER (round 5, second step): the epilogue of a tile WITHOUT a residual is interleaved into the first K tile of the workgroup's NEXT
+//   tile.  The accumulators of the finished tile stay where they are; in phase q of the next tile's K tile 0 - between that phase's LDS
+//   reads / DMA issue and its barrier, i.e. while the OTHER wave row's MFMA cluster occupies the matrix cores - a wave adds the bias,
+//   applies GELU, converts and stores the 64 x 32 quadrant that phase's MFMAs are about to overwrite, then zeroes it.  Both wave rows
+//   do that one barrier apart, so VALU / store work of one row always sits next to matrix work of the other (MI355X_MICROARCH.md
+//   "Two waves per SIMD", item 9: the measured form of this overlap).  The last tile of a workgroup is flushed by ONE more K tile 0
+//   (same code; its matrix work lands in zeroed accumulators that nobody stores).  Tiles WITH a residual keep the epilogue between
+//   tiles (their 16 residual loads per lane need 64 registers, which only exist there).
+//   The bias reaches the epilogue without a wait of its own: lane l of a wave holds bias[n0 + 64 wc + l] in ONE register, loaded in K
+//   tile 1 of the tile - the counted vmcnt of that K tile's phase 4 covers it (it is older than the 8 newest operations), and because
+//   that wait is a real s_waitcnt instruction (NOMAD_P9_WAIT_VM) the compiler knows so and never drains the LDS-DMA queue for it
+//   (cdna_hip_programming.md 5, "mixing load kinds") - and distributed with ds_bpermute_b32.  (A first version loaded it by inline asm
+//   and tied the register to an asm wait: the compiler copied the register BEFORE the wait - stale bias in some runs.)
+//   vmcnt in the interleaved K tile: its phase 4 must see K tile 1 landed, whose DMA was issued before 12 + 4 + 4 = 20 newer
+//   operations (2 + 2 B DMA, 3 x 4 quadrant stores, 4 A DMA): vmcnt(20); everywhere else vmcnt(8) as before.
+template <int ABL = 0, bool INTER = true>
 __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
     using Cfg = P8Cfg;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     constexpr int A_BUF = 2 * Cfg::HALF_BYTES;   // A buffers at 0 / 32 KB, B buffers (three) from 64 KB on: 160 KB
     extern __shared__ __attribute__((aligned(16))) char smem9[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -146,7 +173,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
     NOMAD_P9_DMA_B(0)
     NOMAD_P9_DMA_B(1)
     NOMAD_P9_ADVANCE()
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // K tile 0 has landed (this wave's share)
+    NOMAD_P9_WAIT_VM(8)   // K tile 0 has landed (this wave's share)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (ABL == 7) ts_[1] = wall_clock64();
@@ -160,17 +187,63 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
 
     const int nk = p.K / 64;  // even
     const bool has_r = p.R != nullptr, has_b = p.bias != nullptr;
+    const bool inter = INTER && !has_r && ABL != 1;   // this problem's epilogues are interleaved into the next tile's first K tile
     int n_done = 0;
 
-    for (;;) {
-        f32x4 acc[8][4];
+    f32x4 acc[8][4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        bf16x8 af[8][2], bf[2][2];
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 af[8][2], bf[2][2];
+    float bias_lane = 0.f;   // bias[n0 + 64 wc + lane] of the tile being multiplied (of the finished tile during its interleaved epilogue)
+    bool pend = false;       // a finished tile's accumulators are waiting for their (interleaved) epilogue ...
+    bool flush = false;      // the pass after the last tile: one more K tile 0 (on the operands staged past the end) for its hooks
+    // ... whose output descriptor (base = first row of this wave's 128 x 64 part, size = up to row M) is:
+    __amdgpu_buffer_rsrc_t rc_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(p.C)), 0, 0, 0x00020000);
+    auto clamp_bytes = [](long long v) { return (unsigned)(v < 0 ? 0 : (v > (1ll << 30) ? (1ll << 30) : v)); };
+    auto out_rsrc = [&](int m0_, int n0_) {
+        const int mw = m0_ + wr * 128, nw = n0_ + wc * 64;
+        return __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(uniform_ptr(reinterpret_cast<const float*>(reinterpret_cast<bf16_t*>(p.C) + p.cmap.off + (long long)mw * p.cmap.ld + nw))), 0,
+            clamp_bytes((long long)(p.M - mw) * p.cmap.ld * 2), 0x00020000);
+    };
 
-        // transposed product: W fragment first -> a lane holds row fr (of A tile i) x W rows 4 fq + r (of LDS tile j)
+    // epilogue of accumulator row tiles I0 .. I0 + 3 x column half JH (a 64 x 32 quadrant of the wave tile) straight from the
+    // registers: acc[i][j][r] = out[m0 + 128 wr + 16 i + fr][n0 + 64 wc + 32 (j >> 1) + 8 fq + 4 (j & 1) + r]; leaves them zero
+#define NOMAD_P9_EPI_QUAD(I0, JH, GELU_)                                                                                  \
+    {                                                                                                                     \
+        int lane_e = lane;                                                                                                \
+        asm volatile("" : "+v"(lane_e));  /* offsets recomputed here: hoisted, they would sit in registers through the K loop */ \
+        const int fq_e = lane_e >> 4;                                                                                     \
+        const int c_voff = ((lane_e & 15) * p.cmap.ld + 8 * fq_e) * 2 + (JH)*64;                                          \
+        const int bsel = (32 * (JH) + 8 * fq_e) * 4;                                                                      \
+        float bq[8];                                                                                                      \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                                     \
+            bq[e] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bsel + 4 * e, __builtin_bit_cast(int, bias_lane))); \
+        _Pragma("unroll") for (int i = (I0); i < (I0) + 4; ++i) {                                                         \
+            bf16x8 ov;                                                                                                    \
+            _Pragma("unroll") for (int g = 0; g < 2; ++g)                                                                 \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                           \
+                    float x = acc[i][2 * (JH) + g][r] + bq[4 * g + r];                                                    \
+                    if (GELU_) x = gelu_erf(x);                                                                           \
+                    ov[4 * g + r] = (bf16_t)x;                                                                            \
+                }                                                                                                         \
+            /* (row offset in the VGPR offset, never in the scalar offset: the store-data hazard of DESIGN.md 5) */       \
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), rc_p, c_voff + i * 16 * p.cmap.ld * 2, 0, 2); \
+            acc[i][2 * (JH)] = (f32x4){0.f, 0.f, 0.f, 0.f};                                                               \
+            acc[i][2 * (JH) + 1] = (f32x4){0.f, 0.f, 0.f, 0.f};                                                           \
+        }                                                                                                                 \
+    }
+#define NOMAD_P9_EPI_HOOK(I0, JH)                                        \
+    if (epi_now) {                                                       \
+        __builtin_amdgcn_sched_barrier(0);                               \
+        if (p.gelu) NOMAD_P9_EPI_QUAD(I0, JH, true)                      \
+        else NOMAD_P9_EPI_QUAD(I0, JH, false)                            \
+        __builtin_amdgcn_sched_barrier(0);                               \
+    }
+
+    // transposed product: W fragment first -> a lane holds row fr (of A tile i) x W rows 4 fq + r (of LDS tile j)
 #define NOMAD_P9_MMA(I0, J0)                                                                               \
     _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                       \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
@@ -185,12 +258,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
     __builtin_amdgcn_s_barrier();                       \
     asm volatile("" ::: "memory");
 
-        // one K tile (A buffer PAR = parity of the K tile: a compile-time constant per call site, K tiles go in pairs)
-#define NOMAD_P9_KTILE(PAR)                                                                                \
+    // one K tile (A buffer PAR = parity of the K tile: a compile-time constant per call site, K tiles go in pairs).
+    // HOOKS: the K tile 0 call site - epilogue hooks of the pending tile (epi_now).
+    // BIAS: the K tile 1 call site - the tile's bias register is loaded in the first pair (kt == 0).
+#define NOMAD_P9_KTILE(PAR, HOOKS, BIAS)                                                                   \
     {                                                                                                      \
         const char* la_ = smem9 + (PAR)*A_BUF + a_frag;                                                    \
         const char* lb_ = smem9 + b3_cur + b_frag;                                                         \
         b3_dst = b3_cur >= A_BUF ? b3_cur - A_BUF : b3_cur + 2 * A_BUF; /* buffer of tile t+2 */           \
+        if ((BIAS) && kt == 0 && has_b) bias_lane = p.bias[n0 + wc * 64 + lane];                           \
         /* phase 1: B columns 0..31, A rows 0..63 */                                                       \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                    \
             bf[j][0] = *reinterpret_cast<const bf16x8*>(lb_ + j * 2048 + koff0);                           \
@@ -201,6 +277,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
             af[i][1] = *reinterpret_cast<const bf16x8*>(la_ + i * 2048 + koff1);                           \
         }                                                                                                  \
         NOMAD_P9_DMA_B(0)                                                                                  \
+        if (HOOKS) NOMAD_P9_EPI_HOOK(0, 0)                                                                 \
         NOMAD_P9_SYNC_COMPUTE(0, 0)                                                                        \
         /* phase 2: A rows 64..127 */                                                                      \
         _Pragma("unroll") for (int i = 4; i < 8; ++i) {                                                    \
@@ -208,111 +285,119 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
             af[i][1] = *reinterpret_cast<const bf16x8*>(la_ + i * 2048 + koff1);                           \
         }                                                                                                  \
         NOMAD_P9_DMA_B(1)                                                                                  \
+        if (HOOKS) NOMAD_P9_EPI_HOOK(4, 0)                                                                 \
         NOMAD_P9_SYNC_COMPUTE(4, 0)                                                                        \
         /* phase 3: B columns 32..63 */                                                                    \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                    \
             bf[j][0] = *reinterpret_cast<const bf16x8*>(lb_ + (2 + j) * 2048 + koff0);                     \
             bf[j][1] = *reinterpret_cast<const bf16x8*>(lb_ + (2 + j) * 2048 + koff1);                     \
         }                                                                                                  \
+        if (HOOKS) NOMAD_P9_EPI_HOOK(0, 1)                                                                 \
         NOMAD_P9_SYNC_COMPUTE(0, 2)                                                                        \
         /* phase 4: both A halves of tile t+2 (their last read was phase 2), then "tile t+1 has landed" */ \
         NOMAD_P9_DMA_A(PAR, 0)                                                                             \
         NOMAD_P9_DMA_A(PAR, 1)                                                                             \
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                   \
+        if ((HOOKS) && epi_now) NOMAD_P9_WAIT_VM(20)                                                       \
+        else NOMAD_P9_WAIT_VM(8)                                                                           \
         NOMAD_P9_ADVANCE()                                                                                 \
+        if (HOOKS) NOMAD_P9_EPI_HOOK(4, 1)                                                                 \
         NOMAD_P9_SYNC_COMPUTE(4, 2)                                                                        \
         b3_cur = b3_cur >= 2 * A_BUF ? 0 : b3_cur + A_BUF;                                                 \
     }
 
+    for (;;) {
         int kt = 0;
         do {   // (nk >= 2: no zero-trip copy of the loop's live ranges)
-            NOMAD_P9_KTILE(0)
-            NOMAD_P9_KTILE(1)
+            const bool epi_now = pend && kt == 0;
+            NOMAD_P9_KTILE(0, true, false)
+            if (epi_now) pend = false;
+            if (flush) break;
+            NOMAD_P9_KTILE(1, false, true)
             kt += 2;
         } while (kt < nk);
+        if (flush) break;
         if (ABL == 7 && n_done < 2) ts_[2 + 2 * n_done] = wall_clock64();
 
-        // ---- direct epilogue: acc[i][j][r] = out[m0 + 128 wr + 16 i + fr][n0 + 64 wc + 32 (j >> 1) + 8 fq + 4 (j & 1) + r] ----
-        {
-            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            // the per-lane offsets are recomputed per tile from a laundered lane id: hoisted out of the tile loop they would sit in
-            // 30-odd registers through the K loop, which has none to spare
+        if (inter) {   // the accumulators stay; the next tile's first K tile (or the flush pass) stores them
+            pend = true;
+            rc_p = out_rsrc(m0, n0);
+        } else {
+            // ---- epilogue between tiles (residual GEMMs; every GEMM of the INTER = false instantiation) ----
             int lane_e = lane;
             asm volatile("" : "+v"(lane_e));
-            const int fr = lane_e & 15, fq = lane_e >> 4;
+            const int fr_e = lane_e & 15, fq_e = lane_e >> 4;
             const int mw = m0 + wr * 128, nw = n0 + wc * 64;
-            auto clamp_bytes = [](long long v) { return (unsigned)(v < 0 ? 0 : (v > (1ll << 30) ? (1ll << 30) : v)); };
-            bf16_t* Cb = reinterpret_cast<bf16_t*>(p.C);
             const bf16_t* Rb = reinterpret_cast<const bf16_t*>(p.R);
-            const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<float*>(uniform_ptr(reinterpret_cast<const float*>(Cb + p.cmap.off + (long long)mw * p.cmap.ld + nw))), 0,
-                clamp_bytes((long long)(p.M - mw) * p.cmap.ld * 2), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rc = out_rsrc(m0, n0);
             const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<float*>(uniform_ptr(reinterpret_cast<const float*>(has_r ? Rb + p.rmap.off + (long long)mw * p.rmap.ld + nw : Cb))), 0,
+                const_cast<float*>(uniform_ptr(reinterpret_cast<const float*>(has_r ? Rb + p.rmap.off + (long long)mw * p.rmap.ld + nw : reinterpret_cast<const bf16_t*>(p.C)))), 0,
                 has_r ? clamp_bytes((long long)(p.M - mw) * p.rmap.ld * 2) : 0u, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<float*>(uniform_ptr(has_b ? p.bias + nw : p.C)), 0, has_b ? 64u * 4u : 0u, 0x00020000);
-            const int c_voff = (fr * p.cmap.ld + 8 * fq) * 2, r_voff = (fr * p.rmap.ld + 8 * fq) * 2;
+            const int c_voff = (fr_e * p.cmap.ld + 8 * fq_e) * 2, r_voff = (fr_e * p.rmap.ld + 8 * fq_e) * 2;
             // one straight-line copy per (GELU, residual) combination: decided once per tile, not once per chunk
             auto epi = [&](auto gelu_c, auto res_c) {
-            constexpr bool GELU = decltype(gelu_c)::value, RES = decltype(res_c)::value;
-            // (the bias loads sit INSIDE each copy: issued in front of the four-way branch, the compiler's wait-count pass no longer
-            // knew them waited for at the K loop's header and put an s_waitcnt vmcnt(0) - a drained DMA queue - into every K tile pair)
-            // (an opaque zero as their scalar offset keeps the compiler from merging the four copies' loads back in front of the branch)
-            int zoff = 0;
-            asm volatile("" : "+s"(zoff));
-            f32x4 bv[2][2];
+                constexpr bool GELU = decltype(gelu_c)::value, RES = decltype(res_c)::value;
+                // the whole residual (64 registers: the operand fragments are dead here) ahead of the first store: a load issued
+                // behind a store is waited for together with that store's acknowledgement (in-order vmcnt)
+                u32x4 rres[8][2];
+                if (RES) {
 #pragma unroll
-            for (int jh = 0; jh < 2; ++jh)
+                    for (int i = 0; i < 8; ++i)
 #pragma unroll
-                for (int g = 0; g < 2; ++g)   // (no bias: a zero-sized descriptor reads zeros)
-                    bv[jh][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, (32 * jh + 8 * fq + 4 * g) * 4, zoff, 0));
-            // bias, then the whole residual (64 registers: the operand fragments are dead here) ahead of the first store: a load
-            // issued behind a store is waited for together with that store's acknowledgement (in-order vmcnt)
-            u32x4 rres[8][2];
-            if (RES) {
+                        for (int jh = 0; jh < 2; ++jh)
+                            rres[i][jh] = __builtin_amdgcn_raw_buffer_load_b128(rr, r_voff + i * 16 * p.rmap.ld * 2 + jh * 64, 0, 0);
+                    NOMAD_P9_WAIT_VM(0)   // (explicit: nothing is left pending for the compiler's pass to wait for at the K loop's header)
+                }
+                float bq[2][8];
+#pragma unroll
+                for (int jh = 0; jh < 2; ++jh)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        bq[jh][e] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((32 * jh + 8 * fq_e + e) * 4, __builtin_bit_cast(int, bias_lane)));
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
 #pragma unroll
-                    for (int jh = 0; jh < 2; ++jh)
-                        rres[i][jh] = __builtin_amdgcn_raw_buffer_load_b128(rr, r_voff + i * 16 * p.rmap.ld * 2 + jh * 64, 0, 0);
-            }
-            {
+                    for (int jh = 0; jh < 2; ++jh) {
+                        float v[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+                        for (int g = 0; g < 2; ++g)
 #pragma unroll
-                for (int jh = 0; jh < 2; ++jh) {
-                    float v[8];
+                            for (int r = 0; r < 4; ++r) {
+                                float x = acc[i][2 * jh + g][r] + bq[jh][4 * g + r];
+                                if (GELU) x = gelu_erf(x);
+                                v[4 * g + r] = x;
+                            }
+                        if (RES) {
+                            const bf16x8 rv = __builtin_bit_cast(bf16x8, rres[i][jh]);
 #pragma unroll
-                    for (int g = 0; g < 2; ++g)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float x = acc[i][2 * jh + g][r] + bv[jh][g][r];
-                            if (GELU) x = gelu_erf(x);
-                            v[4 * g + r] = x;
+                            for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
                         }
-                    if (RES) {
-                        const bf16x8 rv = __builtin_bit_cast(bf16x8, rres[i][jh]);
+                        bf16x8 ov;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+                        for (int e = 0; e < 8; ++e) ov[e] = (bf16_t)v[e];
+                        // (row offset in the VGPR offset, never in the scalar offset: the store-data hazard of DESIGN.md 5)
+                        if (ABL != 1 || p.M < 0)
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), rc, c_voff + i * 16 * p.cmap.ld * 2 + jh * 64, 0, 2);
+                        acc[i][2 * jh] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        acc[i][2 * jh + 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
                     }
-                    bf16x8 ov;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) ov[e] = (bf16_t)v[e];
-                    // (row offset in the VGPR offset, never in the scalar offset: the store-data hazard of DESIGN.md 5)
-                    if (ABL != 1 || p.M < 0)
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), rc, c_voff + i * 16 * p.cmap.ld * 2 + jh * 64, 0, 2);
-                }
-            }
             };
-            if (p.gelu && has_r) epi(std::true_type{}, std::true_type{});
-            else if (p.gelu) epi(std::true_type{}, std::false_type{});
-            else if (has_r) epi(std::false_type{}, std::true_type{});
-            else epi(std::false_type{}, std::false_type{});
+            if (INTER) {   // (only residual GEMMs - and the no-store probe - come here: one copy)
+                if (has_r) epi(std::false_type{}, std::true_type{});
+                else epi(std::false_type{}, std::false_type{});
+            } else {
+                if (p.gelu && has_r) epi(std::true_type{}, std::true_type{});
+                else if (p.gelu) epi(std::true_type{}, std::false_type{});
+                else if (has_r) epi(std::false_type{}, std::true_type{});
+                else epi(std::false_type{}, std::false_type{});
+            }
         }
         if (ABL == 7 && n_done < 2) ts_[3 + 2 * n_done] = wall_clock64();
         ++n_done;
-        if (t_cur + wpx >= t_end) break;
+        if (t_cur + wpx >= t_end) {
+            if (!pend) break;
+            flush = true;   // one more K tile 0 for its epilogue hooks: its matrix work runs on the K tiles the load cursor staged past
+            continue;       // the end (the last tile's own, again) into the zeroed accumulators and is never stored - 1 K tile per launch
+        }
         t_cur += wpx;
         {   // the next output tile's coordinates (the load cursor may already be one tile further on)
             const int tm = p.tn_magic ? fast_div(t_cur, p.tn_magic, p.tn_shift) : t_cur;
@@ -321,10 +406,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
         }
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();  // re-join the two wave rows
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two K tiles staged past the end: LDS must not be released under them
+    NOMAD_P9_WAIT_VM(0)   // the two K tiles staged past the end: LDS must not be released under them
 #undef NOMAD_P9_KTILE
 #undef NOMAD_P9_SYNC_COMPUTE
 #undef NOMAD_P9_MMA
+#undef NOMAD_P9_EPI_HOOK
+#undef NOMAD_P9_EPI_QUAD
 #undef NOMAD_P9_DMA_A
 #undef NOMAD_P9_DMA_B
 #undef NOMAD_P9_ADVANCE
@@ -340,7 +427,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
 }
 
 // one workgroup per CU (160 KB of LDS), never more than there are tiles; the grid is a multiple of 8 (one share per XCD)
-template <int ABL = 0>
+template <int ABL = 0, bool INTER = true>
 inline hipError_t launch_gemm_bf16_p9(GemmParams p, hipStream_t s, int num_cus) {
     p.tiles_m = (p.M + P8Cfg::BM - 1) / P8Cfg::BM;
     p.tiles_n = p.N / 256;
@@ -350,7 +437,7 @@ inline hipError_t launch_gemm_bf16_p9(GemmParams p, hipStream_t s, int num_cus) 
     if (p.tiles_n > 1) fast_div_magic((unsigned)p.tiles_n, &p.tn_magic, &p.tn_shift);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_p9_kernel<ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_p9_kernel<ABL, INTER>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -358,7 +445,7 @@ inline hipError_t launch_gemm_bf16_p9(GemmParams p, hipStream_t s, int num_cus) 
     long long per_xcd = (ntiles + 7) / 8;
     const int cap = num_cus >= 8 ? num_cus / 8 : 1;
     if (per_xcd > cap) per_xcd = cap;
-    hipLaunchKernelGGL((gemm_bf16_p9_kernel<ABL>), dim3((unsigned)(8 * per_xcd)), dim3(P8Cfg::THREADS), 160 * 1024, s, p);
+    hipLaunchKernelGGL((gemm_bf16_p9_kernel<ABL, INTER>), dim3((unsigned)(8 * per_xcd)), dim3(P8Cfg::THREADS), 160 * 1024, s, p);
     return hipGetLastError();
 }
 

@@ -34,6 +34,7 @@
 // target feature is off for every kernel rather than relying on kernels never being co-scheduled.
 #include "attention.hip.h"
 #include "attention_bf16_v2.hip.h"
+#include "attention_bf16_v3.hip.h"
 #include "attention_f32_v2.hip.h"
 #ifdef NOMAD_DIAG
 #include "attention_f32_v3.hip.h"
@@ -325,6 +326,7 @@ struct Tuning {
     bool f32_longk_33 = false;     // NOMAD_F32_LONGK_33
     int f32_mid_tile = 31;         // NOMAD_F32_MID_TILE
     int bf16_attn_dma = 2;         // NOMAD_BF16_ATTN_DMA: K / V of the bf16 attention by LDS-DMA in 128-key tiles
+    bool bf16_attn_v3 = true;      // NOMAD_BF16_ATTN_V3: the bf16 attention on v_mfma_f32_16x16x32_bf16 (0: the 32x32x16 kernel)
     bool bf16_conv0_mfma = true;   // NOMAD_BF16_CONV0_MFMA
     int p8_min_tiles = 256;        // NOMAD_BF16_8PHASE_MIN_TILES: smallest grid (256 x 256 tiles) for the deep-pipelined bf16 kernels
     bool p8_nt_stores = true;      // NOMAD_BF16_NT_STORES
@@ -333,6 +335,7 @@ struct Tuning {
     bool p8_three_b = true;        // NOMAD_BF16_B3
     int p8_n192 = 0;               // NOMAD_BF16_N192
     bool p9 = true;                // NOMAD_BF16_P9: the persistent 256 x 256 bf16 kernel wherever it applies
+    bool p9_tail_split = true;     // NOMAD_BF16_P9_TAIL: rows of a sparse last round of its tiles go to the 128 x 128 kernel
     int concurrent_parts = 1;      // nomad_set_concurrent_parts: batches the host layer runs concurrently on separate streams
 };
 
@@ -359,6 +362,7 @@ static void tuning_from_env(Tuning& t) {
     t.f32_longk_33 = getb("NOMAD_F32_LONGK_33", t.f32_longk_33);
     t.f32_mid_tile = geti("NOMAD_F32_MID_TILE", t.f32_mid_tile);
     t.bf16_attn_dma = geti("NOMAD_BF16_ATTN_DMA", t.bf16_attn_dma);
+    t.bf16_attn_v3 = getb("NOMAD_BF16_ATTN_V3", t.bf16_attn_v3);
     t.bf16_conv0_mfma = getb("NOMAD_BF16_CONV0_MFMA", t.bf16_conv0_mfma);
     t.p8_min_tiles = geti("NOMAD_BF16_8PHASE_MIN_TILES", t.p8_min_tiles);
     t.p8_nt_stores = getb("NOMAD_BF16_NT_STORES", t.p8_nt_stores);
@@ -367,6 +371,7 @@ static void tuning_from_env(Tuning& t) {
     t.p8_three_b = getb("NOMAD_BF16_B3", t.p8_three_b);
     t.p8_n192 = geti("NOMAD_BF16_N192", t.p8_n192);
     t.p9 = getb("NOMAD_BF16_P9", t.p9);
+    t.p9_tail_split = getb("NOMAD_BF16_P9_TAIL", t.p9_tail_split);
 }
 #endif
 
@@ -1657,6 +1662,9 @@ static int run_ln_bwd(nomad_ctx* c, const float* x, const float* g, const float*
 static hipError_t run_attention_bf16(const nomad_ctx* c, const bf16_t* qkv, bf16_t* out, int B, int T, const int* tpref, bool log2e, hipStream_t s) {
     const int dma = c->tune.bf16_attn_dma;
     const bool big = (long long)((T + 255) / 256) * B * 12 >= 1024;
+    // round 5: the 16-wide matrix shape (attention_bf16_v3.hip.h) for every batch size - a clip's bits do not depend on its batch
+    if (log2e && c->tune.bf16_attn_v3)
+        return big ? launch_attention_bf16_v3<8, 128, 4>(qkv, out, B, T, tpref, s) : launch_attention_bf16_v3<4, 64, 4>(qkv, out, B, T, tpref, s);
     if (log2e && dma == 1)
         return big ? launch_attention_bf16_v2<8, 64, 4, true, true>(qkv, out, B, T, tpref, s)
                    : launch_attention_bf16_v2<4, 64, 4, true, true>(qkv, out, B, T, tpref, s);
@@ -1734,7 +1742,7 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
             tile = (p9_on() && p9_applies(p, groups)) ? 60 : (p8_three_b() && p8_nt_stores() && p8_use_n192(c, p.M, p.N, p.K)) ? 55 : 16;  // deep-pipelined 256x256 / 256x192 kernel once there are >= 2 rounds of tiles (profiles/r01_gemm_sweep_bf16_8phase.json)
         else tile = (p.N % 256 == 0 && (p.N >= 1024 || p.M >= 100000)) ? 3 : 1;
     }
-    Scope sc(c, s, NOMAD_K_GEMM, flops, (tile == 1 || tile == 3 || tile == 16 || tile == 60 || tile == 61 || tile == 62 || tile == 55 || tile == 56 || tile == 57 || tile == 58 || tile == 42 || tile == 43 || tile == 44 || tile == 45 || tile == 46 || tile == 47 || tile == 48 || tile == 49 || tile == 50 || tile == 51 || tile == 52 || tile == 53 || tile == 54 || tile == 20 || tile == 21 || tile == 27 || tile == 28 || tile == 32 || tile == 33) ? NOMAD_K_GEMM_BIG : (tile == 2 ? NOMAD_K_GEMM_FINE : -1));
+    Scope sc(c, s, NOMAD_K_GEMM, flops, (tile == 1 || tile == 3 || tile == 16 || tile == 60 || tile == 61 || tile == 62 || tile == 63 || tile == 64 || tile == 55 || tile == 56 || tile == 57 || tile == 58 || tile == 42 || tile == 43 || tile == 44 || tile == 45 || tile == 46 || tile == 47 || tile == 48 || tile == 49 || tile == 50 || tile == 51 || tile == 52 || tile == 53 || tile == 54 || tile == 20 || tile == 21 || tile == 27 || tile == 28 || tile == 32 || tile == 33) ? NOMAD_K_GEMM_BIG : (tile == 2 ? NOMAD_K_GEMM_FINE : -1));
     hipError_t e;
     switch (tile) {
         // the instantiations the bf16 / bf16x3 forwards select
@@ -1751,9 +1759,38 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
                                                   : launch_gemm_bf16_8phase<8, false, 0, 3>(p, groups, s);
             break;
         case 60:  // persistent form of the deep-pipelined kernel: one workgroup per CU walks tiles, direct epilogue (gemm_bf16_p9.hip.h)
+        case 64: {  // ... (64: never split by rows - A/B)
             if (!p9_applies(p, groups)) return fail(NOMAD_ERR_INVALID, "bf16 persistent gemm: plain C / R, one group, N %% 256, K %% 128, contiguous K");
-            e = launch_gemm_bf16_p9<0>(p, s, c->num_cus);
+            // Tile quantisation (round 5).  One workgroup per CU and tiles of 256 x 256: the N = 768 GEMMs of config C5 (out_proj, fc2) are
+            // 564 tiles = 2.2 rounds of the 256 CUs, i.e. three rounds' time.  The one-tile-per-workgroup kernel hid that behind the
+            // OTHER half of the batch on a second stream; persistent workgroups of two launches cannot share CUs.  Instead the rows of
+            // the whole rounds go to the persistent kernel and the rows of the sparse last round to the 128 x 128 kernel (tile 1,
+            // two workgroups per CU) right behind it on the same stream: every bf16 kernel contracts k in the same order, so which
+            // kernel computes a row changes no bit (tests/test_gpu_bf16.py).  Plain A matrices only (the conv stack's per-clip maps
+            // have thousands of tiles); Tuning::p9_tail_split = 0 switches it off.
+            const int grid = 8 * std::max(1, c->num_cus / 8);
+            const long long tn = p.N / 256, tm = (p.M + 255) / 256, tiles = tm * tn;
+            const long long rounds = tiles / grid, rem = tiles - rounds * grid;
+            if (tile == 60 && tu.p9_tail_split && rounds >= 1 && rounds <= 4 && rem > 0 && rem * 10 < grid * 6 && p.amap.clip_rows >= p.M && p.N % 128 == 0) {
+                const int m_main = (int)(rounds * grid / tn) * 256;
+                if (m_main > 0 && m_main < p.M) {
+                    GemmParams a = p, b = p;
+                    a.M = m_main;
+                    a.amap = plain_map(a.M, p.amap.ld); a.amap.off = p.amap.off;
+                    a.cmap = plain_map(a.M, p.cmap.ld); a.cmap.off = p.cmap.off;
+                    a.rmap = plain_map(a.M, p.rmap.ld); a.rmap.off = p.rmap.off;
+                    b.M = p.M - m_main;
+                    b.amap = plain_map(b.M, p.amap.ld); b.amap.off = p.amap.off + (long long)m_main * p.amap.ld;
+                    b.cmap = plain_map(b.M, p.cmap.ld); b.cmap.off = p.cmap.off + (long long)m_main * p.cmap.ld;
+                    b.rmap = plain_map(b.M, p.rmap.ld); b.rmap.off = p.rmap.off + (long long)m_main * p.rmap.ld;
+                    e = launch_gemm_bf16_p9<0, true>(a, s, c->num_cus);
+                    if (e == hipSuccess) e = launch_gemm_bf16<128, 128, 4, 2>(b, groups, s);
+                    break;
+                }
+            }
+            e = launch_gemm_bf16_p9<0, true>(p, s, c->num_cus);
             break;
+        }
         case 57:  // the deep-pipelined kernel with the residual prefetch in the epilogue, general C / R addressing
         case 58:  // ... with the small epilogue for plain C / R matrices (what tile 16 resolves to for them)
             if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
@@ -1843,10 +1880,12 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
             if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
             e = launch_gemm_bf16_8phase<7>(p, groups, s);
             break;
-        case 61:  // persistent kernel: per-workgroup timeline probe / no output stores (timing)
+        case 61:  // persistent kernel: per-workgroup timeline probe / no output stores (timing) / every epilogue between tiles (A/B)
         case 62:
+        case 63:
             if (!p9_applies(p, groups)) return fail(NOMAD_ERR_INVALID, "bf16 persistent gemm: plain C / R, one group, N %% 256, K %% 128, contiguous K");
-            e = tile == 61 ? launch_gemm_bf16_p9<7>(p, s, c->num_cus) : launch_gemm_bf16_p9<1>(p, s, c->num_cus);
+            e = tile == 61 ? launch_gemm_bf16_p9<7, true>(p, s, c->num_cus) : tile == 62 ? launch_gemm_bf16_p9<1, true>(p, s, c->num_cus)
+                                                                                      : launch_gemm_bf16_p9<0, false>(p, s, c->num_cus);
             break;
         case 22: e = launch_gemm_bf16_8phase<3, false, 2>(p, groups, s); break;  // bf16x3 timing probes, fp32 output
         case 23: e = launch_gemm_bf16_8phase<4, false, 2>(p, groups, s); break;
@@ -2856,7 +2895,7 @@ int nomad_diag_timeline(unsigned long long* out_host, int n) {
 int nomad_diag_gemm_bf16(nomad_ctx* c, const void* A, const void* W, const float* bias, const void* R, void* C, int M,
                          int N, int K, int gelu, int tile, nomad_stream_t stream) {
     static const int kBN[] = {128, 128, 64, 256, 64, 128, 128, 128, 128, 256, 256, 128, 128, 128, 128, 256, 256, 256, 256, 256};
-    const bool big256 = tile == 36 || (tile >= 42 && tile <= 54) || tile == 57 || tile == 58 || (tile >= 60 && tile <= 62);
+    const bool big256 = tile == 36 || (tile >= 42 && tile <= 54) || tile == 57 || tile == 58 || (tile >= 60 && tile <= 64);
     if (tile == 55 || tile == 56) {  // 256 x 192 tiles of the deep-pipelined kernel
         if (!c || !A || !W || !C || M <= 0) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: bad argument");
         if (N % 192 || K % 128) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: N %% 192 or K %% 128 != 0");

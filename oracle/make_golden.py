@@ -323,6 +323,9 @@ class _FairseqFullAdapter(torch.nn.Module):
         return {"x": o.last_hidden_state, "layer_results": [(h.transpose(0, 1), None) for h in o.hidden_states[1:]]}
 
 
+REF_NOMAD_PY_SHA256 = "484dfd800773a987b7979bef205b11a612f65d98c264a6b42406a46f9d2839bd"   # /root/reference/src/nomad_audio/nomad.py as reviewed
+
+
 def reference_nomad_namespace(fixed_now=None):
     """The reference's OWN classes ``Nomad``, ``TripletModel``, ``LossNetLayers``, ``NomadLoss`` (nomad.py:35-282), compiled from
     the ClassDef nodes of /root/reference/src/nomad_audio/nomad.py WITHOUT importing the module - so none of its import-time
@@ -348,8 +351,16 @@ def reference_nomad_namespace(fixed_now=None):
         def now():
             return fixed_now or _dt.datetime(2024, 1, 2, 3, 4, 5)
 
-    with open(os.path.join(REF, "src", "nomad_audio", "nomad.py")) as f:
-        tree = ast.parse(f.read())
+    # The class bodies below are EXECUTED (with a real os: predict() writes CSVs and changes directory).  Only the file that was read
+    # and reviewed when this script was written may run: anything else - an edited or replaced reference tree - is refused.
+    # Regenerate fixtures in a throwaway container without credentials or network only.
+    import hashlib
+    with open(os.path.join(REF, "src", "nomad_audio", "nomad.py"), "rb") as f:
+        raw = f.read()
+    digest = hashlib.sha256(raw).hexdigest()
+    if digest != REF_NOMAD_PY_SHA256:
+        raise RuntimeError(f"{REF}/src/nomad_audio/nomad.py has sha256 {digest}, not the reviewed {REF_NOMAD_PY_SHA256}: refusing to execute it")
+    tree = ast.parse(raw.decode())
     wanted = ("Nomad", "TripletModel", "LossNetLayers", "NomadLoss")
     body = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name in wanted]
     assert sorted(n.name for n in body) == sorted(wanted)

@@ -59,7 +59,7 @@ def engine_peaky(built_lib, sd_peaky):
 
 # Kernel instantiations that exist in the PRODUCT library (what the scoring / training paths can select); every other
 # nomad_diag_gemm* tile id is an experiment that lives in libnomad_diag.so only (nomad_amd/build.py).
-PRODUCT_TILES = {"f32": {20, 31, 33, 34, 37, 48}, "bf16": {1, 2, 3, 4, 16, 55, 57, 58}, "bf16x3": {7, 8}}
+PRODUCT_TILES = {"f32": {20, 31, 33, 34, 37, 48}, "bf16": {1, 2, 3, 4, 16, 55, 57, 58, 60}, "bf16x3": {7, 8}}
 
 
 @pytest.fixture(scope="session")

@@ -65,6 +65,31 @@ def test_gemm_bf16_192_column_tiles_are_bit_identical(engine_for, M, N, K, epi):
         assert torch.equal(o, outs[0])
 
 
+@pytest.mark.parametrize("M,N,K", [(70000, 768, 3072), (70000, 768, 768), (47968, 2304, 768), (40000, 512, 1536), (2999, 768, 768),
+                                    (513, 2304, 768), (255, 768, 128), (256 * 300 + 17, 256, 256), (100000, 256, 128)])
+@pytest.mark.parametrize("epi", ["none", "bias", "bias_gelu", "bias_res"])
+def test_gemm_bf16_persistent_kernel_is_bit_identical(engine_for, M, N, K, epi):
+    """Round 5: the persistent 256 x 256 kernel (gemm_bf16_p9.hip.h; tile 60 = epilogue interleaved into the next tile's first K tile,
+    63 = every epilogue between tiles) against the one-tile-per-workgroup kernel 58 and the 128 x 128 kernel 1: same k order per
+    element, same epilogue arithmetic - the same bits.  Shapes from less than one tile per workgroup to 9 tiles per workgroup, a ragged
+    last row tile, K of 2 to 48 K tiles; repeated, because what this guards against (a staged K tile read early, a stale bias
+    register) shows up in some runs only."""
+    g = torch.Generator().manual_seed(M + K)
+    A = torch.randn(M, K, generator=g).bfloat16().cuda()
+    W = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16().cuda()
+    bias = torch.randn(N, generator=g).cuda() if "bias" in epi else None
+    R = torch.randn(M, N, generator=g).bfloat16().cuda() if "res" in epi else None
+    eng = engine_for("bf16", 63)   # (the diag library: it has every instantiation)
+    ref = eng.diag_gemm_bf16(A, W, bias, R, gelu="gelu" in epi, tile=58)
+    assert torch.equal(eng.diag_gemm_bf16(A, W, bias, R, gelu="gelu" in epi, tile=1), ref)
+    out = torch.empty_like(ref)
+    for t in (60, 63):
+        for rep in range(6):
+            out.fill_(float("nan"))
+            eng.diag_gemm_bf16(A, W, bias, R, gelu="gelu" in epi, tile=t, out=out)
+            assert torch.equal(out, ref), (t, rep)
+
+
 LOG2E = 1.4426950408889634
 
 

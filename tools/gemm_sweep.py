@@ -117,9 +117,9 @@ def main():
                  15: "bf16 256x256 w2x4 bk64 2st", 16: "bf16 256x256 8-phase", 17: "bf16 256x256 8-phase ABL no-epilogue", 18: "bf16 256x256 8-phase buffer_load..lds", 19: "bf16 256x256 8-phase no setprio", 36: "bf16 256x256 8-phase, timeline probe build",
                  42: "bf16 256x256 8-phase, non-temporal C stores", 43: "bf16 256x256 8-phase, non-temporal C stores + R loads", 44: "bf16 256x256 8-phase, non-temporal R loads", 45: "bf16 256x256 8-phase, probe: A tile 0 for every workgroup", 46: "bf16 256x256 8-phase, 3 B buffers", 47: "bf16 8-phase probe: no LDS-DMA", 48: "bf16 8-phase probe: no DMA, no LDS reads", 49: "bf16 8-phase probe: no LDS reads", 50: "bf16 8-phase probe: no loads, no barriers", 51: "bf16 8-phase, LDS-DMA nt on A", 52: "bf16 8-phase, LDS-DMA nt on B", 53: "bf16 8-phase, LDS-DMA nt on A and B", 54: "bf16 8-phase, LDS-DMA sc1 on A and B",
                  58: "bf16 256x256 8-phase, 3 B buffers, nt stores, residual prefetch, plain epilogue (shipped until round 5)",
-                 60: "bf16 256x256 8-phase PERSISTENT, direct epilogue (round 5)", 62: "bf16 persistent, probe: no output stores"}
+                 60: "bf16 256x256 8-phase PERSISTENT, direct epilogue (round 5)", 62: "bf16 persistent, probe: no output stores", 63: "bf16 persistent, every epilogue between tiles (round 5, first step)"}
         bn = {0: 128, 1: 128, 2: 64, 3: 256, 4: 64, 5: 128, 6: 128, 7: 128, 8: 128, 9: 256, 10: 256, 11: 128, 12: 128,
-              13: 128, 14: 128, 15: 256, 16: 256, 17: 256, 18: 256, 19: 256, 36: 256, 42: 256, 43: 256, 44: 256, 45: 256, 46: 256, 47: 256, 48: 256, 49: 256, 50: 256, 51: 256, 52: 256, 53: 256, 54: 256, 58: 256, 60: 256, 62: 256}
+              13: 128, 14: 128, 15: 256, 16: 256, 17: 256, 18: 256, 19: 256, 36: 256, 42: 256, 43: 256, 44: 256, 45: 256, 46: 256, 47: 256, 48: 256, 49: 256, 50: 256, 51: 256, 52: 256, 53: 256, 54: 256, 58: 256, 60: 256, 62: 256, 63: 256}
         for sname in a.shapes.split(","):
             M, N, K, has_b, gelu, has_r = SHAPES[sname]
             A = torch.randn(M, K, generator=g).bfloat16().cuda()
@@ -128,7 +128,7 @@ def main():
             R = torch.randn(M, N, generator=g).bfloat16().cuda() if has_r else None
             first = None
             for t in (int(x) for x in a.tiles.split(",")):
-                if N % bn[t] or (t in (16, 17, 18, 19, 36, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 54, 58, 60, 62) and K % 128):
+                if N % bn[t] or (t in (16, 17, 18, 19, 36, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 54, 58, 60, 62, 63) and K % 128):
                     continue
                 out = eng.diag_gemm_bf16(A, W, b, R, gelu=gelu, tile=t).float()
                 if first is None:
