@@ -51,6 +51,21 @@ def cpu_baseline(sd, n_samples, budget_s=20.0, max_clips=256):
     ncpu = os.cpu_count() or 1
     g = torch.Generator().manual_seed(0)
     wav = (0.1 * torch.randn(max_clips, n_samples, generator=g)).clamp(-1, 1)
+    # what the reference itself would do: torch's DEFAULT thread count (it never calls set_num_threads), a few clips - reported next
+    # to the calibrated figure so that a reader can tell "the reference's CPU path as shipped" from "the same path, threads tuned"
+    default_threads = torch.get_num_threads()
+    default_leg = None
+    try:
+        with torch.no_grad():
+            O.triplet_forward(sd, wav[:1])
+            t0, nd = time.perf_counter(), 0
+            while nd < 8 and (nd < 2 or time.perf_counter() - t0 < budget_s / 5):
+                O.triplet_forward(sd, wav[nd:nd + 1])
+                nd += 1
+            default_leg = {"value": round(nd / (time.perf_counter() - t0), 3), "unit": "clips/s", "cores": default_threads, "clips": nd,
+                           "note": "torch's default thread count, as the reference would run"}
+    except Exception as ex:  # noqa: BLE001
+        default_leg = {"error": str(ex)[:120]}
     t_start = time.perf_counter()
     best_threads, best_dt = None, None
     with torch.no_grad():
@@ -106,7 +121,7 @@ def cpu_baseline(sd, n_samples, budget_s=20.0, max_clips=256):
     except OSError:
         pass
     return {"value": round(n / dt, 3), "unit": "clips/s", "cores": best_threads, "kind": "port", "cpu_model": cpu_model,
-            "batched_b8": batched,
+            "batched_b8": batched, "torch_default_threads": default_leg,
             "sample": f"{n} clips of {n_samples} samples, batch-1 loop (as nomad.py:171-183) + float64 cdist "
                       f"{n - half}x{half}, {dt:.1f} s wall; host has {ncpu} logical CPUs, thread count calibrated "
                       f"over 8/16/32/64"}
@@ -266,6 +281,25 @@ def time_c4(sd, device, steps=10, warmup=3, batch=32, samples=16384):
             res[name] = round(1e3 * (time.perf_counter() - t0) / steps, 3)
             out["finite"] = bool(torch.isfinite(r).all().item()) and out["finite"]
         losses[prec] = float(fwd())
+        if prec == "fp32":
+            # the same step replayed from ONE captured HIP graph (Nomad.graphed_loss: for training loops with a fixed batch shape):
+            # same kernels, same order, same bits - only the ~440 launches' host time and the gaps between dependent kernels go
+            try:
+                eager_grad = fwd_bwd().clone()
+                graphed = nmd.graphed_loss(est0, clean)
+                for _ in range(warmup):
+                    graphed.step(est0, clean)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    gl, gg = graphed.step(est0, clean)
+                torch.cuda.synchronize()
+                res["forward_backward_graph_replay_ms"] = round(1e3 * (time.perf_counter() - t0) / steps, 3)
+                res["graph_replay_bit_identical_to_eager"] = bool(torch.equal(gg, eager_grad))
+                del graphed
+            except Exception as e:  # noqa: BLE001
+                res["forward_backward_graph_replay_ms"] = None
+                res["graph_replay_error"] = str(e)[:200]
         nmd.engine.close()
         if prec == "fp32":
             out.update(res)

@@ -18,7 +18,7 @@
 //     (v_permlane16_swap + v_permlane32_swap);
 //   * K rows keep the GEMM's chunk swizzle ((row >> 1) & 7); V rows are swizzled in 32-byte pairs by (row >> 1) & 3, which spreads
 //     the 8 rows x 32 bytes a 32-lane half gathers per transposing read over all 64 banks once.
-// Scores in log2 units (q carries log2 e), p = 2^(s - m_ref) <= 2^kA2Thr between rescales, fp32 row sums and accumulation, K / V
+// Scores in log2 units (q carries log2 e), p = 2^(s - m_ref) <= 2^kA2Thr between rescales, fp32 accumulation of O and of the row sums, K / V
 // tiles of KT keys double-buffered by LDS-DMA with one barrier per tile: as attention_bf16_v2.hip.h.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -28,15 +28,22 @@
 
 namespace nomad {
 
-// grid: 1-D, nqblk * B * 12 workgroups of 64 * NW threads (nqblk = ceil(T / (32 NW))); dynamic LDS attn_bf16_v2_lds(KT).
+// grid: 1-D, nqblk * B * 12 workgroups of 64 * NW threads (nqblk = ceil(T / (16 QS NW))); dynamic LDS attn_bf16_v2_lds(KT).
 // tpref (nullable): ragged batches - clip b owns rows tpref[b] .. tpref[b+1]-1 of qkv / out; T is then the longest clip's.
 // q must carry the factor log2(e) (nomad_enable_bf16 folds it into the q rows of the QKV weight).
-template <int NW, int KT, int OCC>
+// QS: 16-query sub-blocks per wave (2 or 4).  Round 5, second step: with 32 queries per wave the kernel is co-limited by LDS bandwidth - a
+// 32-key block costs a wave 8 KB of fragment reads (4 ds_read_b128 of K, 8 transposing reads of V) for 16 MFMAs, and sixteen such waves
+// per CU read 128 KB per block step = 1024 cycles at 128 bytes per clock, exactly the 4 x 256 cycles the four waves of a SIMD spend in
+// MFMAs - which is why the 16-wide shape alone (QS = 2: 11 % fewer matrix cycles, no per-block lane exchange) changed nothing in the
+// forward (profiles/r05_c5_layer_table.txt).  QS = 4 reuses every K / V fragment for twice the queries: half the LDS bytes per MFMA, at
+// 2 waves per SIMD instead of 4 (about 190 registers).
+template <int NW, int KT, int OCC, int QS = 2>
 __global__ __launch_bounds__(64 * NW, OCC) void attention_bf16_v3_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                                          int T, int nqblk, const int* __restrict__ tpref) {
     extern __shared__ __attribute__((aligned(16))) char a3_lds[];
     constexpr int NT = 64 * NW;       // threads
-    constexpr int QB = 32 * NW;       // queries per workgroup
+    constexpr int QW = 16 * QS;       // queries per wave
+    constexpr int QB = QW * NW;       // queries per workgroup
     constexpr int NB = KT / 32;       // 32-key blocks per tile
     constexpr int NCH = KT * 8 / NT;  // 16-byte chunks of K (and of V) each thread stages per tile
     static_assert(NCH >= 1 && NCH * NT == KT * 8, "tile rows must divide over the threads");
@@ -55,24 +62,35 @@ __global__ __launch_bounds__(64 * NW, OCC) void attention_bf16_v3_kernel(const b
     }
     if (qb * QB >= T) return;  // whole workgroup, before any barrier
     const bf16_t* __restrict__ src_bh = qkv + row0 * 2304 + hd * 64;
-    const int q_row0 = qb * QB + wave * 32 + fr;   // + 16 qs
-    bf16x8 qf[2][2];   // B operand of S^T: query fr of sub-block qs, d = 32 ks + 8 fq .. + 7
+    const int q_row0 = qb * QB + wave * QW + fr;   // + 16 qs
+    bf16x8 qf[QS][2];   // B operand of S^T: query fr of sub-block qs, d = 32 ks + 8 fq .. + 7
 #pragma unroll
-    for (int qs = 0; qs < 2; ++qs) {
+    for (int qs = 0; qs < QS; ++qs) {
         const int qr = q_row0 + 16 * qs;
         const bf16_t* qp = src_bh + (long long)(qr < T ? qr : T - 1) * 2304 + 8 * fq;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) qf[qs][ks] = *reinterpret_cast<const bf16x8*>(qp + 32 * ks);
     }
-    f32x4 o[4][2];   // O^T[db][qs]: d = 16 db + 4 fq + r, query fr of sub-block qs
+    f32x4 o[4][QS];   // O^T[db][qs]: d = 16 db + 4 fq + r, query fr of sub-block qs
+    float m_ref[QS];    // reference maximum of this lane's queries (log2 units), the same in the four lanes of a query
+    f32x4 negm[QS];     // -m_ref: the C operand of the first score MFMA
+    // Row sums on the matrix core (round 5): lsum[qs] += ones[16 x 32] P^T[qs] - every row of the result is the sum of the block's 32
+    // values of p for query fr, over ALL four lanes' contraction slots.  Two MFMAs per block instead of 16 v_add_f32 + a final lane
+    // reduction: the kernel is bound by vector-instruction ISSUE (an MFMA holds the SIMD's issue for 8 cycles, a v_add for 4; see the
+    // NOTEBOOK), so this is 48 issue cycles less per block and wave.  The sum is over the bf16-rounded p the numerator uses as well.
+    f32x4 lsum[QS];
+    bf16x8 ones_f;
 #pragma unroll
-    for (int db = 0; db < 4; ++db)
+    for (int j = 0; j < 8; ++j) ones_f[j] = (bf16_t)1.0f;
 #pragma unroll
-        for (int qs = 0; qs < 2; ++qs) o[db][qs] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m_ref[2] = {0.f, 0.f};   // reference maximum of this lane's two queries (log2 units), the same in the four lanes of a query
-    f32x4 negm[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};   // -m_ref: the C operand of the first score MFMA
-    float l_run[2] = {0.f, 0.f};   // sum of p over THIS lane's keys (reduced over the query's four lanes at the end)
-    const bool wave_active = qb * QB + wave * 32 < T;  // wave-uniform: the transposing reads need a full EXEC mask
+    for (int qs = 0; qs < QS; ++qs) {
+#pragma unroll
+        for (int db = 0; db < 4; ++db) o[db][qs] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        m_ref[qs] = 0.f;
+        negm[qs] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        lsum[qs] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const bool wave_active = qb * QB + wave * QW < T;  // wave-uniform: the transposing reads need a full EXEC mask
     const int ntiles = (T + KT - 1) / KT;
 
     // ---- staging by LDS-DMA: a wave's instruction fills 1 KB = 8 rows linearly; lane (row l >> 3, physical chunk l & 7) fetches the
@@ -115,7 +133,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void attention_bf16_v3_kernel(const b
             for (int blk = 0; blk < NB; ++blk) {
                 if (blk < nb) {
                     // ---- scores: S^T[kb][qs] - m_ref = K[kb] Q[qs]^T + (-m_ref) ----
-                    f32x4 s[2][2];
+                    f32x4 s[2][QS];
                     {
                         const char* kp = B0 + blk * 4096;
                         bf16x8 kf[2][2];
@@ -127,7 +145,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void attention_bf16_v3_kernel(const b
 #pragma unroll
                         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                            for (int qs = 0; qs < 2; ++qs) {
+                            for (int qs = 0; qs < QS; ++qs) {
                                 s[kb][qs] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kb][0], qf[qs][0], negm[qs], 0, 0, 0);
                                 s[kb][qs] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kb][1], qf[qs][1], s[kb][qs], 0, 0, 0);
                             }
@@ -139,29 +157,30 @@ __global__ __launch_bounds__(64 * NW, OCC) void attention_bf16_v3_kernel(const b
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
                                 if (16 * kb + 4 * fq + r >= valid) {
-                                    s[kb][0][r] = -1e30f;
-                                    s[kb][1][r] = -1e30f;
+#pragma unroll
+                                    for (int qs = 0; qs < QS; ++qs) s[kb][qs][r] = -1e30f;
                                 }
                     }
                     // ---- this lane's maxima (relative to m_ref); a rescale only when some lane is above the threshold ----
-                    float pm[2];
+                    float pm[QS], pall = -1e30f;
 #pragma unroll
-                    for (int qs = 0; qs < 2; ++qs) {
+                    for (int qs = 0; qs < QS; ++qs) {
                         float m = fmaxf(s[0][qs][0], s[0][qs][1]);
                         m = a2_max3(m, s[0][qs][2], s[0][qs][3]);
                         m = a2_max3(m, s[1][qs][0], s[1][qs][1]);
                         pm[qs] = a2_max3(m, s[1][qs][2], s[1][qs][3]);
+                        pall = fmaxf(pall, pm[qs]);
                     }
                     const bool first = (kt == 0 && blk == 0);
-                    if (first || __any(fmaxf(pm[0], pm[1]) > kA2Thr)) {  // rare after the first block: move the reference maxima
+                    if (first || __any(pall > kA2Thr)) {  // rare after the first block: move the reference maxima
 #pragma unroll
-                        for (int qs = 0; qs < 2; ++qs) {
+                        for (int qs = 0; qs < QS; ++qs) {
                             const float pmax = f2_max4(pm[qs]);   // over the four lanes of the query: the same value in all of them
                             const float delta = first ? pmax : fmaxf(pmax, 0.f);
                             const float alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
                             for (int db = 0; db < 4; ++db) o[db][qs] *= alpha;
-                            l_run[qs] *= alpha;
+                            lsum[qs] *= alpha;
 #pragma unroll
                             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -171,23 +190,15 @@ __global__ __launch_bounds__(64 * NW, OCC) void attention_bf16_v3_kernel(const b
                         }
                     }
                     // ---- p = 2^(s - m_ref), row sums, P^T[qs] as the B operand (slot (fq, j) = key 16 (j >> 2) + 4 fq + (j & 3)) ----
-                    bf16x8 pf[2];
+                    bf16x8 pf[QS];
 #pragma unroll
-                    for (int qs = 0; qs < 2; ++qs) {
-                        float ls0 = 0.f, ls1 = 0.f;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            s[0][qs][r] = __builtin_amdgcn_exp2f(s[0][qs][r]);
-                            s[1][qs][r] = __builtin_amdgcn_exp2f(s[1][qs][r]);
-                            ls0 += s[0][qs][r];
-                            ls1 += s[1][qs][r];
-                        }
-                        l_run[qs] += ls0 + ls1;
+                    for (int qs = 0; qs < QS; ++qs) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            pf[qs][r] = (bf16_t)s[0][qs][r];
-                            pf[qs][4 + r] = (bf16_t)s[1][qs][r];
+                            pf[qs][r] = (bf16_t)__builtin_amdgcn_exp2f(s[0][qs][r]);
+                            pf[qs][4 + r] = (bf16_t)__builtin_amdgcn_exp2f(s[1][qs][r]);
                         }
+                        lsum[qs] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_f, pf[qs], lsum[qs], 0, 0, 0);
                     }
                     // ---- O^T[db][qs] += V^T[db] P^T[qs] ----
                     const char* vp = B0 + blk * 4096;
@@ -201,8 +212,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void attention_bf16_v3_kernel(const b
                             vf[j] = v0[j];
                             vf[4 + j] = v1[j];
                         }
-                        o[db][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[0], o[db][0], 0, 0, 0);
-                        o[db][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[1], o[db][1], 0, 0, 0);
+#pragma unroll
+                        for (int qs = 0; qs < QS; ++qs) o[db][qs] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qs], o[db][qs], 0, 0, 0);
                     }
                 }
             }
@@ -211,8 +222,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void attention_bf16_v3_kernel(const b
         __syncthreads();
     }
 #pragma unroll
-    for (int qs = 0; qs < 2; ++qs) {
-        const float inv = 1.0f / f2_sum4(l_run[qs]);
+    for (int qs = 0; qs < QS; ++qs) {
+        const float inv = 1.0f / lsum[qs][0];
         const int qr = q_row0 + 16 * qs;
         if (qr < T) {
             bf16_t* dst = out + (row0 + qr) * 768 + hd * 64 + 4 * fq;
@@ -223,17 +234,17 @@ __global__ __launch_bounds__(64 * NW, OCC) void attention_bf16_v3_kernel(const b
     }
 }
 
-template <int NW, int KT, int OCC>
+template <int NW, int KT, int OCC, int QS = 2>
 inline hipError_t launch_attention_bf16_v3(const bf16_t* qkv, bf16_t* out, int B, int T, const int* tpref, hipStream_t s) {
     static bool configured = false;
-    auto kern = attention_bf16_v3_kernel<NW, KT, OCC>;
+    auto kern = attention_bf16_v3_kernel<NW, KT, OCC, QS>;
     constexpr int lds = attn_bf16_v2_lds(KT);
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
         configured = true;
     }
-    const int nqblk = (T + 32 * NW - 1) / (32 * NW);
+    const int nqblk = (T + 16 * QS * NW - 1) / (16 * QS * NW);
     hipLaunchKernelGGL(kern, dim3(nqblk * B * 12), dim3(64 * NW), lds, s, qkv, out, T, nqblk, tpref);
     return hipGetLastError();
 }

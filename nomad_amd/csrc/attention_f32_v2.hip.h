@@ -1,15 +1,16 @@
 // fp32 self-attention, second generation (the reference's arithmetic: exact fp32 products, fp32 softmax):
 //   ctx[b,t,h*64:(h+1)*64] = softmax_j(q[b,t,h] . k[b,j,h]) v[b,j,h]        (fairseq MultiheadAttention)
-// on qkv[B*T][2304] = [q*64^-0.5 | k | v] fp32.  Same structure as attention_bf16_v2.hip.h, on v_mfma_f32_32x32x2_f32:
-//   * 128 queries per workgroup, 32 per wave; both products TRANSPOSED (S^T = K Q^T, O^T += V^T P^T), so a lane owns
-//     ONE query (column lane & 31) and 16 of a 32-key block's scores (rows (i&3) + 8(i>>2) + 4(lane>>5)): maximum and
-//     sum are register trees + one v_permlane32_swap, and the score accumulator's register i IS the B operand of
-//     P.V's k-step i (keys (i&3) + 8(i>>2) of lanes 0-31 with keys +4 of lanes 32-63) - no conversion, no LDS trip;
-//   * the contraction order of S^T is free as well: a lane reads K and Q as float4 chunks d = 8j + 4h .. + 3 and
-//     k-step (j, r) contracts d = 8j + r with 8j + 4 + r; V is staged TRANSPOSED ([d][key]) so that one float4 holds a
-//     lane's A operands of four k-steps.  Eight ds_read_b128 per operand and 32-key block, 65 MFMAs;
-//   * scores in log2 units (q * log2 e at load), reference maximum subtracted by the matrix core (one extra k-step
-//     ones x (-m_ref)), moved only when a block exceeds it by 2^kA2Thr: per score one v_exp and one v_add remain;
+// on qkv[B*T][2304] = [q*64^-0.5 | k | v] fp32.  Same structure as attention_bf16_v2.hip.h.  Matrix shape: v_mfma_f32_16x16x4_f32
+// since the end of round 4 (the operand maps of THAT shape are in the second comment block below; this first block describes the
+// structure, which the shape change kept):
+//   * 128 queries per workgroup, 32 per wave; both products TRANSPOSED (S^T = K Q^T, O^T += V^T P^T), so a lane owns its
+//     queries' scores in registers: maximum and sum are register trees + lane swaps, and the score accumulator's registers ARE the
+//     B operand of P.V - no conversion, no LDS trip;
+//   * the contraction order of S^T is free as well: a lane reads K and Q as float4 chunks and one float4 feeds four k-steps;
+//     V is staged TRANSPOSED ([d][key]) so that one float4 holds a lane's A operands of four k-steps.  Eight ds_read_b128 per
+//     operand and 32-key block, 128 MFMAs;
+//   * scores in log2 units (q * log2 e at load), reference maximum subtracted by the matrix core (the C operand of a block's first
+//     MFMA is -m_ref), moved only when a block exceeds it by 2^kA2Thr: per score one v_exp and one v_add remain;
 //   * K / V^T tiles of 32 keys double-buffered in LDS (32 KB per workgroup), ONE barrier per tile, rows XOR-swizzled
 //     by 16-byte chunk (conflict-free ds_read_b128 lane groups); the workgroups of a head share an XCD.
 // Round 1's kernel (attention_f32_kernel, attention.hip.h: 16x16x4 tiles, two barriers per 64 keys) measured 80 TFLOP/s,
@@ -35,7 +36,7 @@ constexpr int attn_f32_v2_lds() { return 2 * kF2Buf; }
 // fi + 16 g share a query (maximum / sum: register tree + v_permlane16_swap + v_permlane32_swap), and register r of s[sk][sq] IS the B
 // operand of P.V's k-step (sk, r), which contracts keys 16 sk + r + {0, 4, 8, 12}.  K and Q are read as float4 chunks d = 16 j + 4 g .. + 3
 // (k-step (j, e) contracts d = 16 j + e + {0, 4, 8, 12}), V^T as chunks of keys 16 sk + 4 g .. + 3: eight ds_read_b128 per operand and
-// 32-key tile as before, 64 + 4 + 64 MFMAs of half the length.  The clip's last, partial key tile skips its second 16-key half
+// 32-key tile as before, 64 + 64 MFMAs of half the length (+ 4 for the reference maximum until round 5).  The clip's last, partial key tile skips its second 16-key half
 // entirely (scores and P.V) when it is empty.
 // lse (nullable): [B*12][T] natural-log log-sum-exp of every score row (the backward recomputes P from it).
 // grid: 1-D, ceil(T / 128) * B * 12 workgroups of 256 threads; dynamic LDS attn_f32_v2_lds().
@@ -94,8 +95,10 @@ __global__ __launch_bounds__(256, 3) void attention_f32_v2_kernel(const float* _
 #pragma unroll
         for (int sq = 0; sq < 2; ++sq) o[sd][sq] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float m_ref[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};
-    const float ones_a = g == 0 ? 1.f : 0.f;   // A[key][k = g] of the extra k-step
-    float negm_b[2] = {0.f, 0.f};              // B[k = g][query] = (g == 0) ? -m_ref : 0
+    // -m_ref enters the score chain as the C operand of its first MFMA (round 5; a lane's four accumulator registers of a sub-block
+    // belong to ONE query): the accumulator comes out as s - m_ref exactly as with the extra k-step ones x (-m_ref) this replaced
+    // (0 + 1 x (-m_ref) is exact), at four MFMAs less per 32-key block
+    f32x4 negm[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     const bool wave_active = q_base < T;
     const int ntiles = (T + kF2KT - 1) / kF2KT;
 
@@ -150,12 +153,10 @@ __global__ __launch_bounds__(256, 3) void attention_f32_v2_kernel(const float* _
 #pragma unroll
             for (int sk = 0; sk < 2; ++sk)
 #pragma unroll
-                for (int sq = 0; sq < 2; ++sq) s[sk][sq] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int sq = 0; sq < 2; ++sq) s[sk][sq] = negm[sq];
 #pragma unroll
             for (int sk = 0; sk < 2; ++sk) {
                 if (sk < nsk) {
-#pragma unroll
-                    for (int sq = 0; sq < 2; ++sq) s[sk][sq] = __builtin_amdgcn_mfma_f32_16x16x4f32(ones_a, negm_b[sq], s[sk][sq], 0, 0, 0);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float4 kf = *reinterpret_cast<const float4*>(B0 + k_base + sk * 4096 + 16 * ((4 * j + g) ^ fi));
@@ -179,20 +180,21 @@ __global__ __launch_bounds__(256, 3) void attention_f32_v2_kernel(const float* _
                             s[sk][1][r] = -1e30f;
                         }
             }
-            // ---- block maximum per query (8 scores in this lane, 4 lanes per query) ----
-            float pmax[2];
+            // ---- block maximum per query (8 scores in this lane, 4 lanes per query).  Whether ANY query's maximum is above the threshold is
+            // decided on the lanes' own maxima (round 5: no lane exchange in the common block); a rescale reduces over the query's lanes ----
+            float pm_l[2];
 #pragma unroll
             for (int sq = 0; sq < 2; ++sq) {
                 float pm = fmaxf(s[0][sq][0], s[0][sq][1]);
                 pm = a2_max3(pm, s[0][sq][2], s[0][sq][3]);
                 pm = a2_max3(pm, s[1][sq][0], s[1][sq][1]);
-                pm = fmaxf(pm, fmaxf(s[1][sq][2], s[1][sq][3]));
-                pmax[sq] = f2_max4(pm);   // relative to m_ref
+                pm_l[sq] = fmaxf(pm, fmaxf(s[1][sq][2], s[1][sq][3]));
             }
-            if (kt == 0 || __any(fmaxf(pmax[0], pmax[1]) > kA2Thr)) {  // rare after the first block: move the reference maxima
+            if (kt == 0 || __any(fmaxf(pm_l[0], pm_l[1]) > kA2Thr)) {  // rare after the first block: move the reference maxima
 #pragma unroll
                 for (int sq = 0; sq < 2; ++sq) {
-                    const float delta = kt == 0 ? pmax[sq] : fmaxf(pmax[sq], 0.f);
+                    const float pmax_q = f2_max4(pm_l[sq]);   // relative to m_ref, the same in the query's four lanes
+                    const float delta = kt == 0 ? pmax_q : fmaxf(pmax_q, 0.f);
                     const float alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
                     for (int sd = 0; sd < 4; ++sd) o[sd][sq] *= alpha;
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(256, 3) void attention_f32_v2_kernel(const float* _
 #pragma unroll
                         for (int r = 0; r < 4; ++r) s[sk][sq][r] -= delta;
                     m_ref[sq] += delta;
-                    negm_b[sq] = g == 0 ? -m_ref[sq] : 0.f;
+                    negm[sq] = (f32x4){-m_ref[sq], -m_ref[sq], -m_ref[sq], -m_ref[sq]};
                 }
             }
             // ---- p = 2^(s - m_ref), row sums; register r of s[sk][sq] is k-step (sk, r) of P.V ----

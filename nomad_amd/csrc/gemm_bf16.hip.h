@@ -165,7 +165,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_glds_kernel(const GemmP
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = acc[i][j][r] + bv[j];
-                if (p.gelu) v = gelu_erf(v);
+                if (p.gelu) v = gelu_bf16out(v);
                 slab[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * ELD + j * 32 + (lane & 31)] = v;
             }
         __syncthreads();

@@ -105,7 +105,7 @@ __device__ __forceinline__ void p8_epilogue(const GemmParams& p, const f32x4 (&a
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float v = acc[2 * s4 + ii][j][r] + bv[j];
-                    if (p.gelu) v = gelu_erf(v);
+                    if (p.gelu) v = X3 ? gelu_erf(v) : gelu_bf16out(v);   // (X3: fp32-class results, exact GELU)
                     slab[(ii * 16 + 4 * fq + r) * ELD + j * 16 + fr] = v;
                 }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
             _Pragma("unroll") for (int g = 0; g < 2; ++g)                                                                 \
                 _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                           \
                     float x = acc[i][2 * (JH) + g][r] + bq[4 * g + r];                                                    \
-                    if (GELU_) x = gelu_erf(x);                                                                           \
+                    if (GELU_) x = gelu_bf16out(x);                                                                       \
                     ov[4 * g + r] = (bf16_t)x;                                                                            \
                 }                                                                                                         \
             /* (row offset in the VGPR offset, never in the scalar offset: the store-data hazard of DESIGN.md 5) */       \
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 float x = acc[i][2 * jh + g][r] + bq[jh][4 * g + r];
-                                if (GELU) x = gelu_erf(x);
+                                if (GELU) x = gelu_bf16out(x);
                                 v[4 * g + r] = x;
                             }
                         if (RES) {

@@ -8,11 +8,14 @@
 // (1536).  The only extra machinery is the RowMap (rows restart per clip) and a chunked K map
 // (pos-conv: 128 taps x 48 channels, taps 768 floats apart).
 //
-// Matrix core: v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD = the fp32 peak).
-// Operand maps (cdna_hip_programming.md section 3): lane l supplies A[i=l&31][k=l>>5] and
-// B[k=l>>5][j=l&31]; D[i][j] lands at col j = lane&31, row i = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-// The contraction index may be visited in any order, so one ds_read_b128 per lane feeds four
-// consecutive MFMAs: lane half h reads k = 8q+4h .. 8q+4h+3 and MFMA j contracts {8q+j, 8q+4+j}.
+// Matrix core: v_mfma_f32_16x16x4_f32 in every production instantiation since the end of round 4 (exact fp32, 64 FLOP/clk/SIMD = the
+// fp32 peak; half the accumulator-register traffic per multiply-add of v_mfma_f32_32x32x2_f32, under which the chip held a lower
+// clock - DESIGN.md 4a "MFMA shape and the clock").  Operand maps of that shape (cdna_hip_programming.md section 3): lane l supplies
+// A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; D[i][j] lands at column j = l & 15, rows i = 4 (l >> 4) + reg.  A 32 x 32
+// accumulator block is 2 x 2 such sub-blocks.  The contraction index may be visited in any order, so one ds_read_b128 per lane feeds
+// four consecutive k-steps: lane (fi, g) reads logical chunk 4 kh + g of its row and element c of it feeds k-step c, which contracts
+// k = 16 kh + c + {0, 4, 8, 12} (gemm_f32_glds_body, M16).  The legacy register-staged kernel gemm_f32_kernel (diag tiles 0-19) and the
+// persistent experiment gemm_f32_pers_kernel are still on 32x32x2: they are NOT bit-identical to the production tiles any more.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -152,6 +155,21 @@ __device__ __forceinline__ float gelu_erf(float x) {
     poly *= t;
     const float e = __builtin_amdgcn_exp2f(-0.72134752044f * x * x);  // exp(-x^2/2) = 2^(-x^2 log2(e) / 2)
     return fmaf(-ax, poly * e, fmaxf(x, 0.0f));
+}
+
+// GELU for epilogues whose OUTPUT is bf16 (the bf16 path's GEMMs, config C5; never the fp32 or bf16x3 paths): x * sigmoid(g(x)) with
+// g(x) = x (c0 + c1 x^2 + c2 x^4) fitted to logit(Phi(x)) (minimax on [-9, 9] in float64: c = 1.59501055, 7.40160400e-2, -7.03804789e-4),
+// x^2 clamped at 50 so that g stays monotone.  Maximum absolute error against the exact erf GELU 2.55e-5 over [-30, 30] (evaluated in
+// fp32) - a 150th of the bf16 rounding step of an activation of size 1, and below it for every |gelu(x)| > 0.007 - at 9 instructions
+// (2 transcendental) instead of 13: the epilogues are bound by vector-instruction issue (4 cycles per instruction, 8 per
+// transcendental), so this is 44 instead of 60 issue cycles per activation.  Every bf16 GEMM kernel uses THIS function (their results
+// stay bit-identical to each other); conv0 and every fp32 / bf16x3 epilogue keep gelu_erf.
+__device__ __forceinline__ float gelu_bf16out(float x) {
+    const float x2 = fminf(x * x, 50.0f);
+    float p = fmaf(x2, 1.0153758e-3f, -1.0678258e-1f);     // -log2(e) * (c2 x^2 + c1)
+    p = fmaf(p, x2, -2.3011138f);                            // -log2(e) * c0
+    const float e = __builtin_amdgcn_exp2f(p * x);           // 2^(-g(x) log2 e) = exp(-g(x))
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
 // XCD-aware bijective remap of a 1-D grid: blocks b and b+8 share an XCD (round-robin dispatch),

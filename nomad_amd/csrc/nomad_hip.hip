@@ -36,9 +36,6 @@
 #include "attention_bf16_v2.hip.h"
 #include "attention_bf16_v3.hip.h"
 #include "attention_f32_v2.hip.h"
-#ifdef NOMAD_DIAG
-#include "attention_f32_v3.hip.h"
-#endif
 #include "attention_bwd.hip.h"
 #include "backward.hip.h"
 #include "frontend.hip.h"
@@ -326,7 +323,8 @@ struct Tuning {
     bool f32_longk_33 = false;     // NOMAD_F32_LONGK_33
     int f32_mid_tile = 31;         // NOMAD_F32_MID_TILE
     int bf16_attn_dma = 2;         // NOMAD_BF16_ATTN_DMA: K / V of the bf16 attention by LDS-DMA in 128-key tiles
-    bool bf16_attn_v3 = true;      // NOMAD_BF16_ATTN_V3: the bf16 attention on v_mfma_f32_16x16x32_bf16 (0: the 32x32x16 kernel)
+    int bf16_attn_v3 = 2;          // NOMAD_BF16_ATTN_V3: the bf16 attention on v_mfma_f32_16x16x32_bf16 with 32 queries per wave (2, shipped);
+                                   // 4 / 8: 64 queries per wave, 4 / 8 waves per workgroup (A/B: no faster); 0: the 32x32x16 kernel
     bool bf16_conv0_mfma = true;   // NOMAD_BF16_CONV0_MFMA
     int p8_min_tiles = 256;        // NOMAD_BF16_8PHASE_MIN_TILES: smallest grid (256 x 256 tiles) for the deep-pipelined bf16 kernels
     bool p8_nt_stores = true;      // NOMAD_BF16_NT_STORES
@@ -335,7 +333,8 @@ struct Tuning {
     bool p8_three_b = true;        // NOMAD_BF16_B3
     int p8_n192 = 0;               // NOMAD_BF16_N192
     bool p9 = true;                // NOMAD_BF16_P9: the persistent 256 x 256 bf16 kernel wherever it applies
-    bool p9_tail_split = true;     // NOMAD_BF16_P9_TAIL: rows of a sparse last round of its tiles go to the 128 x 128 kernel
+    bool p9_tail_split = false;    // NOMAD_BF16_P9_TAIL: rows of a sparse last round of its tiles go to the 128 x 128 kernel (+4-17 % on the
+                                   // N = 768 GEMMs alone, -3 % in the two-stream forward, where the other half's kernels fill that round)
     int concurrent_parts = 1;      // nomad_set_concurrent_parts: batches the host layer runs concurrently on separate streams
 };
 
@@ -362,7 +361,7 @@ static void tuning_from_env(Tuning& t) {
     t.f32_longk_33 = getb("NOMAD_F32_LONGK_33", t.f32_longk_33);
     t.f32_mid_tile = geti("NOMAD_F32_MID_TILE", t.f32_mid_tile);
     t.bf16_attn_dma = geti("NOMAD_BF16_ATTN_DMA", t.bf16_attn_dma);
-    t.bf16_attn_v3 = getb("NOMAD_BF16_ATTN_V3", t.bf16_attn_v3);
+    t.bf16_attn_v3 = geti("NOMAD_BF16_ATTN_V3", t.bf16_attn_v3);
     t.bf16_conv0_mfma = getb("NOMAD_BF16_CONV0_MFMA", t.bf16_conv0_mfma);
     t.p8_min_tiles = geti("NOMAD_BF16_8PHASE_MIN_TILES", t.p8_min_tiles);
     t.p8_nt_stores = getb("NOMAD_BF16_NT_STORES", t.p8_nt_stores);
@@ -396,12 +395,6 @@ struct nomad_ctx {
     // (the no-gradient branches of Nomad.forward() - layer outputs wanted, nothing saved - take their partial-sum block from the
     // call's own workspace: Layout::splitk)
     float* splitk_cur = nullptr;                            // the block of the call being enqueued
-#ifdef NOMAD_DIAG
-    // item-queue counters of the experimental persistent fp32 attention kernel (attention_f32_v3.hip.h): one 64-byte block per
-    // launch, handed out round-robin - 128 launches would have to be in flight at once for two of them to share one
-    int* attn_queue = nullptr;
-    std::atomic<unsigned> attn_queue_next{0};
-#endif
     bool splitk_ok = false;
     // nomad_pairwise: row sums per (64-ref tile, deg row), kPairScratchDoubles doubles PER LAUNCH STREAM - calls on
     // different streams of one context may be in flight together (Engine / ShardedScorer are driven from side streams), so
@@ -855,7 +848,7 @@ GemmParams dense(const float* A, int lda, const float* W, const float* bias, con
 //   31 = LDS-DMA 128x128x32, 8 waves, 2-stage: out_proj, conv5/6 (N = 768 / 512 with K around 1000: 2.3 rounds of
 //        256x128 tiles are too few); 34 = 128x64x32 for N not a multiple of 128
 //   37 = LDS-DMA 64x64x32, 4 waves, 3-stage: small problems
-// (all 32x32x2-MFMA instantiations contract k in the same order, so the choice never changes a result bit)
+// (all production instantiations (v_mfma_f32_16x16x4_f32, gemm_f32_glds_body) contract k in the same order, so the choice never changes a result bit)
 // Rows of the 256 x 128 part of a two-shape launch (gemm_f32_mixed_kernel), or 0: whole rounds of the 2-per-CU workgroup slots go to
 // 256 x 128 tiles, the rows of the last, partial round to 128 x 128 tiles - when that round is between 5 % and 70 % full.
 // Tuning::f32_mixed = 0 switches it off; f32_mixed_m1 = <rows> (diagnostics) forces a split.
@@ -946,14 +939,6 @@ DropCfg make_drop(const nomad_ctx* c, float p) {
     return d;
 }
 
-#ifdef NOMAD_DIAG
-constexpr unsigned kAttnQueueBlocks = 128;
-int* next_attn_queue(nomad_ctx* c) { return c->attn_queue + 16 * (c->attn_queue_next.fetch_add(1, std::memory_order_relaxed) % kAttnQueueBlocks); }
-bool attn_v3_on() {
-    static const bool on = [] { const char* v = getenv("NOMAD_ATTN_PIPE"); return v && atoi(v) != 0; }();
-    return on;
-}
-#endif
 
 int run_attention(nomad_ctx* c, const float* qkv, float* out, float* lse, int B, int T, hipStream_t s,
                   const DropCfg* dc = nullptr, uint32_t site = 0, int bh0 = 0) {
@@ -964,10 +949,6 @@ int run_attention(nomad_ctx* c, const float* qkv, float* out, float* lse, int B,
         hipLaunchKernelGGL((attention_f32_kernel<float, true>), grid, dim3(256), 0, s, qkv, out, lse, T, kNoInts, *dc, site, bh0);
     else if (T >= kAttnV2MinT)  // by the clip's length only: the same clip takes the same kernel in every batch
         {
-#ifdef NOMAD_DIAG
-        if (attn_v3_on()) HIP_TRY(launch_attention_f32_v3(qkv, out, lse, B, T, kNoInts, s, next_attn_queue(c)));
-        else
-#endif
         HIP_TRY(launch_attention_f32_v2(qkv, out, lse, B, T, kNoInts, s));
     }
     else
@@ -1157,17 +1138,6 @@ int nomad_create(nomad_ctx** out, int device, const nomad_weights* w) {
             c->allocs.push_back(d);
             c->pair_scratch.emplace_back(kNoStream, static_cast<double*>(d));
         }
-#ifdef NOMAD_DIAG
-        {
-            void* q = nullptr;
-            const hipError_t eq = hipMalloc(&q, kAttnQueueBlocks * 16 * sizeof(int));
-            if (eq != hipSuccess) rc = fail(NOMAD_ERR_HIP, "nomad_create: attention queues: %s", hipGetErrorString(eq));
-            else {
-                c->allocs.push_back(q);
-                c->attn_queue = static_cast<int*>(q);
-            }
-        }
-#endif
     }
     if (rc != 0) {
         nomad_destroy(c);
@@ -1609,16 +1579,9 @@ static int forward_ragged(nomad_ctx* c, const float* wav, int B, int stride, con
             return rc;
         {
             Scope sc(c, s, NOMAD_K_ATTN, attn_flops);
-            // clips of kAttnV2MinT frames or more: the 32x32x2 kernel; shorter ones: the 16x16x4 kernel (each skips the
+            // clips of kAttnV2MinT frames or more: attention_f32_v2_kernel; shorter ones: attention_f32_kernel (each skips the
             // other's clips) - exactly the kernel the clip would get in a batch of its own
-            if (rs.max_t >= kAttnV2MinT)
-                {
-#ifdef NOMAD_DIAG
-                if (attn_v3_on()) HIP_TRY(launch_attention_f32_v3(qkv, ctxb, nullptr, B, rs.max_t, tpref, s, next_attn_queue(c), kAttnV2MinT));
-                else
-#endif
-                HIP_TRY(launch_attention_f32_v2(qkv, ctxb, nullptr, B, rs.max_t, tpref, s, kAttnV2MinT));
-                }
+            if (rs.max_t >= kAttnV2MinT) HIP_TRY(launch_attention_f32_v2(qkv, ctxb, nullptr, B, rs.max_t, tpref, s, kAttnV2MinT));
             if (rs.min_t < kAttnV2MinT)
                 hipLaunchKernelGGL(attention_f32_kernel<float>, dim3((std::min(rs.max_t, kAttnV2MinT - 1) + 63) / 64, B * 12), dim3(256), 0,
                                    s, qkv, ctxb, static_cast<float*>(nullptr), 0, tpref, DropCfg{}, 0u, 0, 0LL, kAttnV2MinT);
@@ -1663,8 +1626,18 @@ static hipError_t run_attention_bf16(const nomad_ctx* c, const bf16_t* qkv, bf16
     const int dma = c->tune.bf16_attn_dma;
     const bool big = (long long)((T + 255) / 256) * B * 12 >= 1024;
     // round 5: the 16-wide matrix shape (attention_bf16_v3.hip.h) for every batch size - a clip's bits do not depend on its batch
-    if (log2e && c->tune.bf16_attn_v3)
+    // (the wave composition - 32 consecutive queries - is the same in both workgroup shapes, so the deferred-rescale decisions and
+    // every bit are too)
+    if (log2e && c->tune.bf16_attn_v3 == 2)
         return big ? launch_attention_bf16_v3<8, 128, 4>(qkv, out, B, T, tpref, s) : launch_attention_bf16_v3<4, 64, 4>(qkv, out, B, T, tpref, s);
+#ifdef NOMAD_DIAG
+    // 64 queries per wave (half the LDS bytes per MFMA, 2 waves per SIMD): measured no faster - 262 / 271 / 310 us best launch at C5's
+    // shape for 32 queries, 64 queries x 4 waves, 64 queries x 8 waves (profiles/r05_attention_bf16_variants.txt)
+    if (log2e && c->tune.bf16_attn_v3 == 8)
+        return big ? launch_attention_bf16_v3<8, 128, 2, 4>(qkv, out, B, T, tpref, s) : launch_attention_bf16_v3<4, 64, 2, 4>(qkv, out, B, T, tpref, s);
+    if (log2e && c->tune.bf16_attn_v3 == 4)
+        return big ? launch_attention_bf16_v3<4, 128, 2, 4>(qkv, out, B, T, tpref, s) : launch_attention_bf16_v3<4, 64, 2, 4>(qkv, out, B, T, tpref, s);
+#endif
     if (log2e && dma == 1)
         return big ? launch_attention_bf16_v2<8, 64, 4, true, true>(qkv, out, B, T, tpref, s)
                    : launch_attention_bf16_v2<4, 64, 4, true, true>(qkv, out, B, T, tpref, s);
@@ -3939,7 +3912,7 @@ int nomad_diag_gemm(nomad_ctx* c, const float* A, const float* W, const float* b
     if (!c || !A || !W || !C || M <= 0) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: bad argument");
     {   // the direct epilogue (gemm_f32.hip.h OPT bit 1024) serves GEMMs without a residual only
         const int t = tile % 100;
-        const bool direct_tile = (t == 99 && false) || t == 72 || t == 74 || t == 75 || t == 77 || t == 79 || t == 80 || t == 84 || t == 85 || t == 89 || t == 90 || t == 93 || t == 94 || t == 95;
+        const bool direct_tile = t == 72 || t == 74 || t == 75 || t == 77 || t == 79 || t == 80 || t == 84 || t == 85 || t == 89 || t == 90 || t == 93 || t == 94 || t == 95;
         if (direct_tile && R) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile %d has the direct epilogue, which takes no residual", t);
     }
     // diagnostics: tile id + 100 * group_m (grouped tile order) + 10000 * occ (workgroups per CU limit)

@@ -177,6 +177,66 @@ class _NomadLossFn(torch.autograd.Function):
         return dwav.reshape(ctx.shape), None, None
 
 
+class GraphedLoss:
+    """``nomad.forward`` + its backward to ``estimate`` for ONE input shape, captured once as a HIP graph and replayed per step.
+
+    A configs[3] training step (2 x (32,1,16384)) is ~440 kernel launches of 5-90 us: issued one by one, the host is still launching
+    when the first two thirds of the step's GPU work are done (profiles/r04_c4_posconv_splitk_ab.txt).  A training loop with a fixed
+    batch shape can capture the launch sequence once (``torch.cuda.graph``; every entry point on the path is capture-safe: the
+    library allocates nothing and queries no event after the first call of a shape) and replay it - same kernels, same order,
+    same bits (``tests/test_gpu_backward.py::test_graphed_loss_replays_bit_identically``).
+
+    ``loss = graphed(estimate, clean)`` is differentiable with respect to ``estimate`` like ``nomad.forward``: the replay computes the
+    loss AND d loss / d estimate; the autograd node hands the stored gradient (times the incoming one) on."""
+
+    def __init__(self, nomad: "Nomad", estimate: torch.Tensor, clean: torch.Tensor, warmup: int = 3):
+        self.nomad = nomad
+        dev = nomad.engine.device
+        self._est = estimate.detach().to(dev, torch.float32).clone().requires_grad_(True)
+        self._cln = clean.detach().to(dev, torch.float32).clone()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):           # warm-up off the capture: workspaces, kernel attributes, autograd buffers
+            for _ in range(max(1, warmup)):
+                self._est.grad = None
+                nomad.forward(self._est, self._cln).backward()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self._graph = torch.cuda.CUDAGraph()
+        self._est.grad = None
+        with torch.cuda.graph(self._graph):
+            self._loss = nomad.forward(self._est, self._cln)
+            self._loss.backward()
+        self._grad = self._est.grad
+
+    def step(self, estimate: torch.Tensor, clean: torch.Tensor):
+        """-> (loss, d loss / d estimate): views of the graph's static outputs, valid until the next step."""
+        if estimate.shape != self._est.shape or clean.shape != self._cln.shape:
+            raise ValueError(f"GraphedLoss was captured for {tuple(self._est.shape)} / {tuple(self._cln.shape)}")
+        with torch.no_grad():
+            self._est.copy_(estimate)
+            self._cln.copy_(clean)
+        self._graph.replay()
+        return self._loss, self._grad
+
+    def __call__(self, estimate: torch.Tensor, clean: torch.Tensor) -> torch.Tensor:
+        return _GraphedLossFn.apply(estimate, clean, self)
+
+
+class _GraphedLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, estimate, clean, graphed):
+        loss, grad = graphed.step(estimate.detach(), clean.detach())
+        ctx.save_for_backward(grad.clone())
+        ctx.shape = estimate.shape
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (g,) = ctx.saved_tensors
+        return (g * grad_out).reshape(ctx.shape), None, None
+
+
 # precision="bf16x3": from about 2 500 frames per batch (12 clips of 4 s, 50 of 1 s) the split-storage forward (256 x 256 tiles,
 # embed_bf16x3) is the fastest; below that the batch stays on fp32 buffers with the same three-product arithmetic in its
 # small-tile GEMMs (Engine.gemm_precision = "bf16x3").  Measured on MI355X (tools/bench_small_batch.py,
@@ -504,6 +564,11 @@ class Nomad:
         BASE; ``Nomad(feature_grad_mult=...)`` / ``self.engine.feature_grad_mult``).  The backbone is frozen: the reference would also accumulate parameter gradients nobody reads
         (the freeze is commented out at nomad.py:74-76); ``clean`` receives no gradient."""
         return _NomadLossFn.apply(estimate, clean, self)
+
+    def graphed_loss(self, estimate: torch.Tensor, clean: torch.Tensor) -> "GraphedLoss":
+        """``forward`` + backward for inputs of this shape, captured as one HIP graph (see ``GraphedLoss``): for training loops with
+        a fixed batch shape - the per-step launch overhead of ~440 small kernels disappears, the bits do not change."""
+        return GraphedLoss(self, estimate, clean)
 
     def _all_gather_rows(self, x: torch.Tensor) -> torch.Tensor:
         """Rows of every rank, in rank order, on every rank (nccl = RCCL needs device tensors, gloo takes host ones)."""

@@ -180,3 +180,33 @@ def test_forward_is_differentiable_like_the_reference(built_lib, sd0):
     assert F.cosine_similarity(grad_nomad.flatten(), ref.flatten(), dim=0).item() > 0.9999
     # without requires_grad the same call still returns the loss value
     assert abs(nmd.forward(est.detach(), clean).item() - float(g["loss"])) < 1e-4
+
+
+def test_graphed_loss_replays_bit_identically(built_lib, sd0):
+    """Round 5 (config C4): nomad.forward + backward captured once as a HIP graph (Nomad.graphed_loss) and replayed on new inputs
+    gives the bits of the eager call - same kernels in the same order; every entry point on the path is capture-safe (the split-K
+    block of the layer forward used to be bound to a stream by hipEventQuery, which a capture cannot contain)."""
+    import torch
+    from nomad_amd.nomad import Nomad
+    nmd = Nomad(weights=sd0)
+    gen = torch.Generator().manual_seed(31)
+    shape = (8, 1, 16384)
+    clean = [(0.1 * torch.randn(*shape, generator=gen)).clamp(-1, 1).cuda() for _ in range(3)]
+    est = [(c + 0.02 * torch.randn(*shape, generator=gen).cuda()).clamp(-1, 1) for c in clean]
+    eager = []
+    for e0, c in zip(est, clean):
+        e = e0.clone().requires_grad_(True)
+        loss = nmd.forward(e, c)
+        loss.backward()
+        eager.append((loss.detach().clone(), e.grad.clone()))
+    graphed = nmd.graphed_loss(est[0], clean[0])
+    for rep in range(2):
+        for k in (2, 0, 1):
+            loss, grad = graphed.step(est[k], clean[k])
+            torch.cuda.synchronize()
+            assert torch.equal(loss, eager[k][0]) and torch.equal(grad, eager[k][1]), (rep, k)
+    # ... and as an autograd node inside a larger graph: d (2 loss) / d estimate = 2 * grad
+    e = est[1].clone().requires_grad_(True)
+    (2.0 * graphed(e, clean[1])).backward()
+    assert torch.equal(e.grad, 2.0 * eager[1][1])
+    nmd.engine.close()
