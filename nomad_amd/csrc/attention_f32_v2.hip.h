@@ -100,6 +100,9 @@ __global__ __launch_bounds__(256, 3) void attention_f32_v2_kernel(const float* _
     // (0 + 1 x (-m_ref) is exact), at four MFMAs less per 32-key block
     f32x4 negm[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     const bool wave_active = q_base < T;
+    // a clip's last query wave may own fewer than 17 queries (T = 199: queries 192 .. 198): its second sub-block then has no query at
+    // all and is left out of both products (round 5; wave-uniform, and the other sub-block's arithmetic is untouched: bit-identical)
+    const int nsq = q_base + 16 < T ? 2 : 1;
     const int ntiles = (T + kF2KT - 1) / kF2KT;
 
     // ---- staging: thread -> (key row, float4 chunk) x 2 of the 32 x 64 tile, for K and for V (unchanged) ----
@@ -162,10 +165,12 @@ __global__ __launch_bounds__(256, 3) void attention_f32_v2_kernel(const float* _
                         const float4 kf = *reinterpret_cast<const float4*>(B0 + k_base + sk * 4096 + 16 * ((4 * j + g) ^ fi));
 #pragma unroll
                         for (int sq = 0; sq < 2; ++sq) {
-                            s[sk][sq] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[sq][j].x, s[sk][sq], 0, 0, 0);
-                            s[sk][sq] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[sq][j].y, s[sk][sq], 0, 0, 0);
-                            s[sk][sq] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[sq][j].z, s[sk][sq], 0, 0, 0);
-                            s[sk][sq] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[sq][j].w, s[sk][sq], 0, 0, 0);
+                            if (sq < nsq) {
+                                s[sk][sq] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[sq][j].x, s[sk][sq], 0, 0, 0);
+                                s[sk][sq] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[sq][j].y, s[sk][sq], 0, 0, 0);
+                                s[sk][sq] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[sq][j].z, s[sk][sq], 0, 0, 0);
+                                s[sk][sq] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[sq][j].w, s[sk][sq], 0, 0, 0);
+                            }
                         }
                     }
                 }
@@ -225,10 +230,12 @@ __global__ __launch_bounds__(256, 3) void attention_f32_v2_kernel(const float* _
                         const float4 vf = *reinterpret_cast<const float4*>(B0 + v_base + sd * 2048 + 16 * ((4 * sk + g) ^ v_x));
 #pragma unroll
                         for (int sq = 0; sq < 2; ++sq) {
-                            o[sd][sq] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.x, s[sk][sq][0], o[sd][sq], 0, 0, 0);
-                            o[sd][sq] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.y, s[sk][sq][1], o[sd][sq], 0, 0, 0);
-                            o[sd][sq] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.z, s[sk][sq][2], o[sd][sq], 0, 0, 0);
-                            o[sd][sq] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.w, s[sk][sq][3], o[sd][sq], 0, 0, 0);
+                            if (sq < nsq) {
+                                o[sd][sq] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.x, s[sk][sq][0], o[sd][sq], 0, 0, 0);
+                                o[sd][sq] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.y, s[sk][sq][1], o[sd][sq], 0, 0, 0);
+                                o[sd][sq] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.z, s[sk][sq][2], o[sd][sq], 0, 0, 0);
+                                o[sd][sq] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.w, s[sk][sq][3], o[sd][sq], 0, 0, 0);
+                            }
                         }
                     }
                 }

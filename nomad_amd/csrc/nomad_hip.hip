@@ -333,6 +333,7 @@ struct Tuning {
     bool p8_three_b = true;        // NOMAD_BF16_B3
     int p8_n192 = 0;               // NOMAD_BF16_N192
     bool p9 = true;                // NOMAD_BF16_P9: the persistent 256 x 256 bf16 kernel wherever it applies
+    bool p9_share = false;         // NOMAD_BF16_P9_SHARE: persistent launches of concurrent batch parts share the CUs (1 / parts each)
     bool p9_tail_split = false;    // NOMAD_BF16_P9_TAIL: rows of a sparse last round of its tiles go to the 128 x 128 kernel (+4-17 % on the
                                    // N = 768 GEMMs alone, -3 % in the two-stream forward, where the other half's kernels fill that round)
     int concurrent_parts = 1;      // nomad_set_concurrent_parts: batches the host layer runs concurrently on separate streams
@@ -371,6 +372,7 @@ static void tuning_from_env(Tuning& t) {
     t.p8_n192 = geti("NOMAD_BF16_N192", t.p8_n192);
     t.p9 = getb("NOMAD_BF16_P9", t.p9);
     t.p9_tail_split = getb("NOMAD_BF16_P9_TAIL", t.p9_tail_split);
+    t.p9_share = getb("NOMAD_BF16_P9_SHARE", t.p9_share);
 }
 #endif
 
@@ -1741,7 +1743,10 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
             // two workgroups per CU) right behind it on the same stream: every bf16 kernel contracts k in the same order, so which
             // kernel computes a row changes no bit (tests/test_gpu_bf16.py).  Plain A matrices only (the conv stack's per-clip maps
             // have thousands of tiles); Tuning::p9_tail_split = 0 switches it off.
-            const int grid = 8 * std::max(1, c->num_cus / 8);
+            // (Tuning::p9_share, A/B: with n concurrent parts of a batch on n streams each launch takes 1 / n of the CUs, so that the parts'
+            // persistent launches run side by side instead of queueing for each other's LDS)
+            const int cus = (tu.p9_share && tu.concurrent_parts > 1) ? std::max(8, c->num_cus / tu.concurrent_parts) : c->num_cus;
+            const int grid = 8 * std::max(1, cus / 8);
             const long long tn = p.N / 256, tm = (p.M + 255) / 256, tiles = tm * tn;
             const long long rounds = tiles / grid, rem = tiles - rounds * grid;
             if (tile == 60 && tu.p9_tail_split && rounds >= 1 && rounds <= 4 && rem > 0 && rem * 10 < grid * 6 && p.amap.clip_rows >= p.M && p.N % 128 == 0) {
@@ -1756,12 +1761,12 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
                     b.amap = plain_map(b.M, p.amap.ld); b.amap.off = p.amap.off + (long long)m_main * p.amap.ld;
                     b.cmap = plain_map(b.M, p.cmap.ld); b.cmap.off = p.cmap.off + (long long)m_main * p.cmap.ld;
                     b.rmap = plain_map(b.M, p.rmap.ld); b.rmap.off = p.rmap.off + (long long)m_main * p.rmap.ld;
-                    e = launch_gemm_bf16_p9<0, true>(a, s, c->num_cus);
+                    e = launch_gemm_bf16_p9<0, true>(a, s, cus);
                     if (e == hipSuccess) e = launch_gemm_bf16<128, 128, 4, 2>(b, groups, s);
                     break;
                 }
             }
-            e = launch_gemm_bf16_p9<0, true>(p, s, c->num_cus);
+            e = launch_gemm_bf16_p9<0, true>(p, s, cus);
             break;
         }
         case 57:  // the deep-pipelined kernel with the residual prefetch in the epilogue, general C / R addressing

@@ -364,8 +364,10 @@ class Engine:
         rows = B * int(self.lib.nomad_num_frames(N))
         ways = min(self.BF16_SPLIT_WAYS, B)
         if ways < 2 or not self.BF16_SPLIT_ROWS or rows < self.BF16_SPLIT_ROWS:
+            self.lib.nomad_set_concurrent_parts(self.ctx, 1)   # scheduling hint only: results never depend on it (include/nomad_hip.h)
             self._embed_bf16_into(wav, emb, side=False)
             return emb
+        self.lib.nomad_set_concurrent_parts(self.ctx, ways)
         cur = torch.cuda.current_stream(self.device)
         cuts = [B * i // ways for i in range(ways + 1)]
         for k in range(1, ways):
