@@ -333,6 +333,7 @@ struct Tuning {
     bool p8_three_b = true;        // NOMAD_BF16_B3
     int p8_n192 = 0;               // NOMAD_BF16_N192
     bool p9 = true;                // NOMAD_BF16_P9: the persistent 256 x 256 bf16 kernel wherever it applies
+    bool p9_res = true;            // NOMAD_BF16_P9_RES: residual GEMMs on the persistent kernel too (0: the one-tile-per-workgroup kernel, A/B)
     bool p9_share = false;         // NOMAD_BF16_P9_SHARE: persistent launches of concurrent batch parts share the CUs (1 / parts each)
     bool p9_tail_split = false;    // NOMAD_BF16_P9_TAIL: rows of a sparse last round of its tiles go to the 128 x 128 kernel (+4-17 % on the
                                    // N = 768 GEMMs alone, -3 % in the two-stream forward, where the other half's kernels fill that round)
@@ -373,6 +374,7 @@ static void tuning_from_env(Tuning& t) {
     t.p9 = getb("NOMAD_BF16_P9", t.p9);
     t.p9_tail_split = getb("NOMAD_BF16_P9_TAIL", t.p9_tail_split);
     t.p9_share = getb("NOMAD_BF16_P9_SHARE", t.p9_share);
+    t.p9_res = getb("NOMAD_BF16_P9_RES", t.p9_res);
 }
 #endif
 
@@ -1672,10 +1674,11 @@ static bool p8_plain_cr(const GemmParams& p) {
 }
 
 // what the persistent 256 x 256 kernel (gemm_bf16_p9.hip.h) requires on top of p8_plain_cr: one group, contiguous K, every column
-// stored, no split planes
+// stored, no split planes, not GELU and residual together
 static bool p9_applies(const GemmParams& p, int groups) {
     return groups == 1 && p8_plain_cr(p) && p.N % 256 == 0 && p.n_valid == p.N && p.K % 128 == 0 && p.kchunk == p.K &&
-           p.a_plane == 0 && p.c_plane == 0 && !p.Upre && !p.DG;
+           p.a_plane == 0 && p.c_plane == 0 && !p.Upre && !p.DG &&
+           !(p.gelu && p.R);   // (GELU and a residual in one epilogue: no GEMM of the model has both, and the shipped instantiation has no copy for it)
 }
 
 // 256 x 192 instead of 256 x 256 tiles in the deep-pipelined bf16 kernel (gemm_bf16_8phase.hip.h, NJ = 3) for the N = 768 GEMMs
@@ -1714,7 +1717,7 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
         if (p.N % 128 != 0) tile = p.M < 512 ? 4 : 2;
         else if (p.M < 512) tile = 4;
         else if (p.N % 256 == 0 && p.K % 128 == 0 && groups == 1 && (long long)((p.M + 255) / 256) * (p.N / 256) >= p8_min_tiles())
-            tile = (p9_on() && p9_applies(p, groups)) ? 60 : (p8_three_b() && p8_nt_stores() && p8_use_n192(c, p.M, p.N, p.K)) ? 55 : 16;  // deep-pipelined 256x256 / 256x192 kernel once there are >= 2 rounds of tiles (profiles/r01_gemm_sweep_bf16_8phase.json)
+            tile = (p9_on() && p9_applies(p, groups) && (tu.p9_res || !p.R)) ? 60 : (p8_three_b() && p8_nt_stores() && p8_use_n192(c, p.M, p.N, p.K)) ? 55 : 16;  // deep-pipelined 256x256 / 256x192 kernel once there are >= 2 rounds of tiles (profiles/r01_gemm_sweep_bf16_8phase.json)
         else tile = (p.N % 256 == 0 && (p.N >= 1024 || p.M >= 100000)) ? 3 : 1;
     }
     Scope sc(c, s, NOMAD_K_GEMM, flops, (tile == 1 || tile == 3 || tile == 16 || tile == 60 || tile == 61 || tile == 62 || tile == 63 || tile == 64 || tile == 55 || tile == 56 || tile == 57 || tile == 58 || tile == 42 || tile == 43 || tile == 44 || tile == 45 || tile == 46 || tile == 47 || tile == 48 || tile == 49 || tile == 50 || tile == 51 || tile == 52 || tile == 53 || tile == 54 || tile == 20 || tile == 21 || tile == 27 || tile == 28 || tile == 32 || tile == 33) ? NOMAD_K_GEMM_BIG : (tile == 2 ? NOMAD_K_GEMM_FINE : -1));

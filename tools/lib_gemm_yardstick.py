@@ -45,7 +45,7 @@ for dtype, names in (("bf16", args.bf16), ("f32", args.f32)):
         if dtype == "bf16":
             A, W = A.bfloat16(), W.bfloat16()
             R = R.bfloat16() if R is not None else None
-            fn, tile = eng.lib.nomad_diag_gemm_bf16, 16   # the shipped 256x256 8-phase kernel
+            fn, tile = eng.lib.nomad_diag_gemm_bf16, 60   # the shipped persistent 256x256 kernel (round 5; 16 / 58 = the one-tile-per-workgroup kernel before it)
         else:
             fn, tile = eng.lib.nomad_diag_gemm, 33         # the shipped 256x128x16 3-stage kernel
         Co = torch.empty(M, N, device="cuda", dtype=A.dtype)  # preallocated: no memset inside the timed region

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Round 5 race screen for the persistent bf16 GEMM (gemm_bf16_p9.hip.h, tile 60: interleaved epilogue, counted vmcnt with the
+epilogue's stores in between, bias register, flush pass): (1) the whole bf16 forward on 4 s and 30 s batches, repeated - every run
+bit-identical; (2) tile 60 on the model's shapes with each epilogue kind, against the one-tile-per-workgroup kernel's bits (tile 58),
+while a second stream hammers HBM and a third runs another persistent GEMM (changes DMA arrival order and which CUs are free).
+Usage: python tools/soak_p9.py [repeats]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from nomad_amd.engine import Engine
+from nomad_amd.weights import seeded_state_dict
+eng = Engine(seeded_state_dict(0), 0, diag=True)
+g = torch.Generator().manual_seed(0)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+bad = 0
+for B, ns in ((256, 64000), (32, 480000), (5, 200000)):
+    wav = (0.1 * torch.randn(B, ns, generator=g)).clamp(-1, 1).cuda()
+    ref = eng.embed_bf16(wav).clone()
+    miss = sum(int(not torch.equal(eng.embed_bf16(wav), ref)) for _ in range(n // 2))
+    print(f"forward {B} x {ns}: repeat mismatches {miss}/{n // 2}", flush=True)
+    bad += miss
+    del wav
+side, side2 = torch.cuda.Stream(), torch.cuda.Stream()
+junk = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+A2 = torch.randn(30000, 768, generator=g).bfloat16().cuda()
+W2 = (torch.randn(2304, 768, generator=g) * 768 ** -0.5).bfloat16().cuda()
+out2 = torch.empty(30000, 2304, dtype=torch.bfloat16, device="cuda")
+shapes = [(47968, 2304, 768), (47968, 768, 3072), (47968, 768, 768), (47968, 3072, 768), (383968, 512, 1536), (12000, 3072, 768), (4096 + 17, 768, 512), (70001, 256, 256)]
+for M, N, K in shapes:
+    A = torch.randn(M, K, generator=g).bfloat16().cuda()
+    W = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16().cuda()
+    b = torch.randn(N, generator=g).cuda()
+    R = torch.randn(M, N, generator=g).bfloat16().cuda()
+    out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    for kind, (bb, rr, ge) in {"bias": (b, None, False), "bias+gelu": (b, None, True), "bias+residual": (b, R, False), "none": (None, None, False)}.items():
+        ref = eng.diag_gemm_bf16(A, W, bb, rr, gelu=ge, tile=58).clone()
+        miss = 0
+        for i in range(n):
+            if i % 2:
+                with torch.cuda.stream(side):
+                    junk.add_(1)  # background HBM traffic
+            if i % 3 == 0:
+                with torch.cuda.stream(side2):
+                    eng.diag_gemm_bf16(A2, W2, None, None, gelu=False, tile=60, out=out2)   # a second persistent launch competing for the CUs
+            out.fill_(float("nan"))
+            eng.diag_gemm_bf16(A, W, bb, rr, gelu=ge, tile=60, out=out)
+            miss += int(not torch.equal(out, ref))
+        torch.cuda.synchronize()
+        print(f"shape {M}x{N}x{K} [{kind}]: mismatches vs tile 58 {miss}/{n}", flush=True)
+        bad += miss
+    del A, W, R, out
+print(f"soak_p9: mismatches = {bad}")
+sys.exit(1 if bad else 0)
