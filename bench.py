@@ -529,10 +529,11 @@ def main():
                        "model_frac_of_mfma_peak": round(v5 * 500.044e9 / world / 2.5e15, 4),
                        "finite": bool(torch.isfinite(m5).all().item()),
                        "fp32_class_scores_same_batch": c5_x3,
-                       "context": "STATIC notes, not measured in this run: this forward holds a shader clock of 2015-2160 MHz of the "
-                                  "2400 nominal (profiles/r03_n192_null.txt, r03_clock_c5.jsonl); sustained on its GEMM shapes hipBLASLt "
-                                  "reaches 725-1205 TFLOP/s, the shipped kernels 715-1086 (profiles/r03_vendor_yardstick.txt; out_proj / fc2 with the "
-                                  "prefetching epilogue: profiles/NOTEBOOK.md, last section)"}
+                       "context": "STATIC notes, not measured in this run: this forward holds a shader clock of 1997-2090 MHz of the 2400 nominal "
+                                  "(profiles/r05_clock_c5.jsonl); alone on the GPU the shipped persistent bf16 GEMM does 1016-1131 TFLOP/s on QKV, "
+                                  "903-1018 on fc1 + GELU, 866-1045 on fc2, hipBLASLt (no epilogue) 933-967 / 949-1041 / 1115-1180 "
+                                  "(profiles/r05_vendor_yardstick_bf16.jsonl, r05_gemm_bf16_p9_ab.jsonl); per-shape times inside the forward: "
+                                  "profiles/r05_c5_layer_table_*.json"}
             del wav5
         except Exception as e:
             also_c5 = {"workload": "configs[4]", "error": str(e)[:200]}
