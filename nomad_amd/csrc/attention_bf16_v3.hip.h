@@ -25,6 +25,7 @@
 
 #include "attention_bf16_v2.hip.h"
 #include "attention_f32_v2.hip.h"
+#include "gemm_f32.hip.h"
 
 namespace nomad {
 
@@ -48,6 +49,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void attention_bf16_v3_kernel(const b
     constexpr int NCH = KT * 8 / NT;  // 16-byte chunks of K (and of V) each thread stages per tile
     static_assert(NCH >= 1 && NCH * NT == KT * 8, "tile rows must divide over the threads");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // (the LDS-DMA destination goes through M0: a scalar)
     const int fr = lane & 15, fq = lane >> 4;
     // XCD-aware placement: the query blocks of one head run on one XCD (their K / V re-reads are L2 hits)
     const int nwg = gridDim.x, id = blockIdx.x;
@@ -90,12 +92,37 @@ __global__ __launch_bounds__(64 * NW, OCC) void attention_bf16_v3_kernel(const b
         negm[qs] = (f32x4){0.f, 0.f, 0.f, 0.f};
         lsum[qs] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    float inf_v;   // +inf, opaque to the compiler (see the block maxima below)
+    asm volatile("v_mov_b32 %0, 0x7f800000" : "=v"(inf_v));
     const bool wave_active = qb * QB + wave * QW < T;  // wave-uniform: the transposing reads need a full EXEC mask
     const int ntiles = (T + KT - 1) / KT;
 
     // ---- staging by LDS-DMA: a wave's instruction fills 1 KB = 8 rows linearly; lane (row l >> 3, physical chunk l & 7) fetches the
     // LOGICAL chunk the swizzle maps there (K: chunk ^ ((row >> 1) & 7); V: chunk ^ 2 ((row >> 1) & 3)) ----
+    // (tiles that lie wholly inside the clip - all but the last - take a wave-uniform tile base + per-thread 32-bit offsets computed once:
+    // the per-tile 64-bit address arithmetic of the general form is vector-instruction issue the kernel is short of)
+    unsigned k_voff[NCH], v_voff[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int cid = tid + i * NT, row = cid >> 3, ch = cid & 7;
+        k_voff[i] = (unsigned)((row * 2304 + 768 + 8 * (ch ^ ((row >> 1) & 7))) * 2);
+        v_voff[i] = (unsigned)((row * 2304 + 1536 + 8 * (ch ^ (2 * ((row >> 1) & 3)))) * 2);
+    }
     auto fetch = [&](int kt) {
+        if (kt * KT + KT <= T) {
+            const char* tile = reinterpret_cast<const char*>(uniform_ptr(reinterpret_cast<const float*>(src_bh + (long long)kt * KT * 2304)));
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                char* dk = a3_lds + ((kt & 1) * (KT * 256)) + (i * NT + wave_u * 64) * 16;
+                // (laundered: hoisted out of the loop as 64-bit values the offsets no longer match the scalar-base + 32-bit-offset form of
+                // the instruction, and every DMA costs a 64-bit vector add)
+                unsigned ko = k_voff[i], vo = v_voff[i];
+                asm volatile("" : "+v"(ko), "+v"(vo));
+                __builtin_amdgcn_global_load_lds((gptr_t)(tile + ko), (lptr_t)dk, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(tile + vo), (lptr_t)(dk + KT * 128), 16, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int cid = tid + i * NT, row = cid >> 3, ch = cid & 7;
@@ -162,14 +189,19 @@ __global__ __launch_bounds__(64 * NW, OCC) void attention_bf16_v3_kernel(const b
                                 }
                     }
                     // ---- this lane's maxima (relative to m_ref); a rescale only when some lane is above the threshold ----
-                    float pm[QS], pall = -1e30f;
+                    float pm[QS], pall = 0.f;
 #pragma unroll
                     for (int qs = 0; qs < QS; ++qs) {
-                        float m = fmaxf(s[0][qs][0], s[0][qs][1]);
-                        m = a2_max3(m, s[0][qs][2], s[0][qs][3]);
-                        m = a2_max3(m, s[1][qs][0], s[1][qs][1]);
-                        pm[qs] = a2_max3(m, s[1][qs][2], s[1][qs][3]);
-                        pall = fmaxf(pall, pm[qs]);
+                        // The FIRST read of each accumulator quad is a compiler-visible instruction (v_med3_f32 with +inf = the maximum of
+                        // two; the +inf sits in a register the compiler cannot see through, or it folds the median back into a maxnum): hipcc places the MFMA -> VALU wait states for it and pads nothing around inline asm; the rest are v_max3
+                        // through asm.  (fmaxf() there would cost two more instructions per quad: the compiler canonicalises each input of
+                        // a maxnum on fresh MFMA results with v_max_f32 x, x - in a loop bound by vector-instruction issue.)
+                        const float t0 = __builtin_amdgcn_fmed3f(s[0][qs][0], s[0][qs][1], inf_v);
+                        const float t1 = __builtin_amdgcn_fmed3f(s[1][qs][0], s[1][qs][1], inf_v);
+                        float m = a2_max3(t0, s[0][qs][2], s[0][qs][3]);
+                        m = a2_max3(m, t1, s[1][qs][2]);
+                        pm[qs] = a2_max3(m, s[1][qs][3], s[1][qs][3]);
+                        pall = qs == 0 ? pm[0] : a2_max3(pall, pm[qs], pm[qs]);
                     }
                     const bool first = (kt == 0 && blk == 0);
                     if (first || __any(pall > kA2Thr)) {  // rare after the first block: move the reference maxima
