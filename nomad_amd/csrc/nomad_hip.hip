@@ -1635,6 +1635,9 @@ static hipError_t run_attention_bf16(const nomad_ctx* c, const bf16_t* qkv, bf16
     if (log2e && c->tune.bf16_attn_v3 == 2)
         return big ? launch_attention_bf16_v3<8, 128, 4>(qkv, out, B, T, tpref, s) : launch_attention_bf16_v3<4, 64, 4>(qkv, out, B, T, tpref, s);
 #ifdef NOMAD_DIAG
+    // 16 waves per workgroup (512 queries share a staged K / V tile: half the LDS-DMA pieces per wave): A/B
+    if (log2e && c->tune.bf16_attn_v3 == 16)
+        return big ? launch_attention_bf16_v3<16, 128, 4, 2>(qkv, out, B, T, tpref, s) : launch_attention_bf16_v3<4, 64, 4>(qkv, out, B, T, tpref, s);
     // 64 queries per wave (half the LDS bytes per MFMA, 2 waves per SIMD): measured no faster - 262 / 271 / 310 us best launch at C5's
     // shape for 32 queries, 64 queries x 4 waves, 64 queries x 8 waves (profiles/r05_attention_bf16_variants.txt)
     if (log2e && c->tune.bf16_attn_v3 == 8)
