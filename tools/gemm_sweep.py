@@ -119,7 +119,7 @@ def main():
                  58: "bf16 256x256 8-phase, 3 B buffers, nt stores, residual prefetch, plain epilogue (shipped until round 5)",
                  60: "bf16 256x256 8-phase PERSISTENT, direct epilogue (round 5)", 62: "bf16 persistent, probe: no output stores", 63: "bf16 persistent, every epilogue between tiles (round 5, first step)"}
         bn = {0: 128, 1: 128, 2: 64, 3: 256, 4: 64, 5: 128, 6: 128, 7: 128, 8: 128, 9: 256, 10: 256, 11: 128, 12: 128,
-              13: 128, 14: 128, 15: 256, 16: 256, 17: 256, 18: 256, 19: 256, 36: 256, 42: 256, 43: 256, 44: 256, 45: 256, 46: 256, 47: 256, 48: 256, 49: 256, 50: 256, 51: 256, 52: 256, 53: 256, 54: 256, 58: 256, 60: 256, 62: 256, 63: 256}
+              13: 128, 14: 128, 15: 256, 16: 256, 17: 256, 18: 256, 19: 256, 36: 256, 42: 256, 43: 256, 44: 256, 45: 256, 46: 256, 47: 256, 48: 256, 49: 256, 50: 256, 51: 256, 52: 256, 53: 256, 54: 256, 58: 256, 60: 256, 62: 256, 63: 256, 64: 256, 65: 256, 66: 256, 67: 256}
         for sname in a.shapes.split(","):
             M, N, K, has_b, gelu, has_r = SHAPES[sname]
             A = torch.randn(M, K, generator=g).bfloat16().cuda()
