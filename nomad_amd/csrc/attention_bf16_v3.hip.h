@@ -23,11 +23,45 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "attention_bf16_v2.hip.h"
 #include "attention_f32_v2.hip.h"
 #include "gemm_f32.hip.h"
 
 namespace nomad {
+
+// Compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{}) (the transposing reads below take
+// their LDS offset as an instruction immediate, so the block index has to be a constant expression).
+template <class F, int... I>
+__device__ __forceinline__ void a3_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void a3_static_for(F&& f) {
+    a3_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// Two transposing reads (keys 4 fq .. and 16 + 4 fq .. of one d block) through inline asm, and the wait that goes with them.
+// WHY asm (round 5, last finding): __builtin_amdgcn_ds_read_tr16_b64 carries no alias information, so hipcc orders it against every
+// LDS-DMA in flight - "the DMA issued at the top of the tile may write what this reads" - with s_waitcnt vmcnt(0) in front of the first
+// V read of the tile: the NEXT tile's fetch, issued to overlap this tile's products, was waited for before this tile's first P.V (the
+// double buffer makes the wait unnecessary; the K reads, plain ext-vector loads with alias information, never got it).  The compiler
+// does not see an asm's LDS traffic: the waits are explicit - LDS operations return in order, so "all but the N newest" covers every
+// older read whatever else the scheduler has put in between; the compiler's own lgkmcnt values for its own reads can only over-wait.
+template <int OFF>
+__device__ __forceinline__ void a3_tr_pair(bf16x4& lo, bf16x4& hi, unsigned addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+                 : "=&v"(lo), "=&v"(hi)
+                 : "v"(addr), "n"(OFF), "n"(OFF + 2048));
+}
+template <int N>
+__device__ __forceinline__ void a3_lds_wait(bf16x4& lo, bf16x4& hi) {   // (the operands tie the MFMAs that use them behind the wait)
+    static_assert(N == 0 || N == 2, "lgkmcnt");
+    if (N == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo), "+v"(hi));
+    else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(lo), "+v"(hi));
+}
 
 // grid: 1-D, nqblk * B * 12 workgroups of 64 * NW threads (nqblk = ceil(T / (16 QS NW))); dynamic LDS attn_bf16_v2_lds(KT).
 // tpref (nullable): ragged batches - clip b owns rows tpref[b] .. tpref[b+1]-1 of qkv / out; T is then the longest clip's.
@@ -38,7 +72,8 @@ namespace nomad {
 // MFMAs - which is why the 16-wide shape alone (QS = 2: 11 % fewer matrix cycles, no per-block lane exchange) changed nothing in the
 // forward (profiles/r05_c5_layer_table.txt).  QS = 4 reuses every K / V fragment for twice the queries: half the LDS bytes per MFMA, at
 // 2 waves per SIMD instead of 4 (about 190 registers).
-template <int NW, int KT, int OCC, int QS = 2>
+// ASMV: the V reads through a3_tr_pair (false: the builtin, A/B runs of libnomad_diag.so).
+template <int NW, int KT, int OCC, int QS = 2, bool ASMV = true>
 __global__ __launch_bounds__(64 * NW, OCC) void attention_bf16_v3_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                                          int T, int nqblk, const int* __restrict__ tpref) {
     extern __shared__ __attribute__((aligned(16))) char a3_lds[];
@@ -156,8 +191,11 @@ __global__ __launch_bounds__(64 * NW, OCC) void attention_bf16_v3_kernel(const b
             const char* B0 = a3_lds + (kt & 1) * (KT * 256);
             const int left = T - kt * KT;  // valid keys from this tile on
             const int nb = left >= KT ? NB : (left + 31) >> 5;
+            unsigned va[4];   // LDS byte addresses of this lane's V rows in the tile (+ 4096 blk + 2048 half as instruction offsets)
 #pragma unroll
-            for (int blk = 0; blk < NB; ++blk) {
+            for (int db = 0; db < 4; ++db) va[db] = (unsigned)(size_t)(lptr_t)(a3_lds) + (unsigned)((kt & 1) * (KT * 256) + v_db[db]);
+            a3_static_for<NB>([&](auto blk_c) {
+                constexpr int blk = decltype(blk_c)::value;
                 if (blk < nb) {
                     // ---- scores: S^T[kb][qs] - m_ref = K[kb] Q[qs]^T + (-m_ref) ----
                     f32x4 s[2][QS];
@@ -233,22 +271,38 @@ __global__ __launch_bounds__(64 * NW, OCC) void attention_bf16_v3_kernel(const b
                         lsum[qs] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_f, pf[qs], lsum[qs], 0, 0, 0);
                     }
                     // ---- O^T[db][qs] += V^T[db] P^T[qs] ----
-                    const char* vp = B0 + blk * 4096;
+                    if (ASMV) {   // two d blocks' reads in flight ahead of the MFMAs that consume them
+                        bf16x4 vlo[4], vhi[4];
+                        a3_tr_pair<blk * 4096>(vlo[0], vhi[0], va[0]);
+                        a3_tr_pair<blk * 4096>(vlo[1], vhi[1], va[1]);
 #pragma unroll
-                    for (int db = 0; db < 4; ++db) {
-                        const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(vp + v_db[db]));
-                        const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(vp + 2048 + v_db[db]));
-                        bf16x8 vf;
+                        for (int db = 0; db < 4; ++db) {
+                            if (db < 3) a3_lds_wait<2>(vlo[db], vhi[db]);   // the pair issued after this one may still be in flight
+                            else a3_lds_wait<0>(vlo[db], vhi[db]);
+                            const bf16x8 vf = __builtin_shufflevector(vlo[db], vhi[db], 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            vf[j] = v0[j];
-                            vf[4 + j] = v1[j];
+                            for (int qs = 0; qs < QS; ++qs) o[db][qs] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qs], o[db][qs], 0, 0, 0);
+                            if (db == 0) a3_tr_pair<blk * 4096>(vlo[2], vhi[2], va[2]);
+                            if (db == 1) a3_tr_pair<blk * 4096>(vlo[3], vhi[3], va[3]);
                         }
+                    } else {
+                        const char* vp = B0 + blk * 4096;
 #pragma unroll
-                        for (int qs = 0; qs < QS; ++qs) o[db][qs] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qs], o[db][qs], 0, 0, 0);
+                        for (int db = 0; db < 4; ++db) {
+                            const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(vp + v_db[db]));
+                            const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(vp + 2048 + v_db[db]));
+                            bf16x8 vf;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                vf[j] = v0[j];
+                                vf[4 + j] = v1[j];
+                            }
+#pragma unroll
+                            for (int qs = 0; qs < QS; ++qs) o[db][qs] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qs], o[db][qs], 0, 0, 0);
+                        }
                     }
                 }
-            }
+            });
         }
         if (kt + 1 < ntiles) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the next tile has landed
         __syncthreads();
@@ -266,10 +320,10 @@ __global__ __launch_bounds__(64 * NW, OCC) void attention_bf16_v3_kernel(const b
     }
 }
 
-template <int NW, int KT, int OCC, int QS = 2>
+template <int NW, int KT, int OCC, int QS = 2, bool ASMV = true>
 inline hipError_t launch_attention_bf16_v3(const bf16_t* qkv, bf16_t* out, int B, int T, const int* tpref, hipStream_t s) {
     static bool configured = false;
-    auto kern = attention_bf16_v3_kernel<NW, KT, OCC, QS>;
+    auto kern = attention_bf16_v3_kernel<NW, KT, OCC, QS, ASMV>;
     constexpr int lds = attn_bf16_v2_lds(KT);
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -58,6 +58,9 @@ __device__ __forceinline__ float f2_sum4(float x) {   // sum over the same four 
     return lo + hi;
 }
 
+// EXTV (true in every product launch): the K / V fragments as ext-vector loads; false = float4 struct copies, in front of which hipcc
+// waits for the next tile's LDS-DMA (A/B runs of libnomad_diag.so, NOMAD_F32_ATTN_STRUCT_LOADS=1).
+template <bool EXTV = true>
 __global__ __launch_bounds__(256, 3) void attention_f32_v2_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                                   float* __restrict__ lse, int T, int nqblk,
                                                                   const int* __restrict__ tpref, int t_min) {
@@ -162,7 +165,16 @@ __global__ __launch_bounds__(256, 3) void attention_f32_v2_kernel(const float* _
                 if (sk < nsk) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float4 kf = *reinterpret_cast<const float4*>(B0 + k_base + sk * 4096 + 16 * ((4 * j + g) ^ fi));
+                        // (an ext-vector load, not a float4 struct copy: the struct's load carries no alias information and hipcc then
+                        // puts s_waitcnt vmcnt(0) in front of it - "the LDS-DMA issued above may alias" - which serialises the next
+                        // tile's fetch with this tile's products; profiles/NOTEBOOK.md, round 5)
+                        float4 kf;
+                        if (EXTV) {
+                            const f32x4 kv = *reinterpret_cast<const f32x4*>(B0 + k_base + sk * 4096 + 16 * ((4 * j + g) ^ fi));
+                            kf = make_float4(kv[0], kv[1], kv[2], kv[3]);
+                        } else {
+                            kf = *reinterpret_cast<const float4*>(B0 + k_base + sk * 4096 + 16 * ((4 * j + g) ^ fi));
+                        }
 #pragma unroll
                         for (int sq = 0; sq < 2; ++sq) {
                             if (sq < nsq) {
@@ -227,7 +239,13 @@ __global__ __launch_bounds__(256, 3) void attention_f32_v2_kernel(const float* _
                 if (sk < nsk) {
 #pragma unroll
                     for (int sd = 0; sd < 4; ++sd) {
-                        const float4 vf = *reinterpret_cast<const float4*>(B0 + v_base + sd * 2048 + 16 * ((4 * sk + g) ^ v_x));
+                        float4 vf;
+                        if (EXTV) {
+                            const f32x4 vv = *reinterpret_cast<const f32x4*>(B0 + v_base + sd * 2048 + 16 * ((4 * sk + g) ^ v_x));
+                            vf = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                        } else {
+                            vf = *reinterpret_cast<const float4*>(B0 + v_base + sd * 2048 + 16 * ((4 * sk + g) ^ v_x));
+                        }
 #pragma unroll
                         for (int sq = 0; sq < 2; ++sq) {
                             if (sq < nsq) {
@@ -260,10 +278,11 @@ __global__ __launch_bounds__(256, 3) void attention_f32_v2_kernel(const float* _
     }
 }
 
+template <bool EXTV = true>
 inline hipError_t launch_attention_f32_v2(const float* qkv, float* out, float* lse, int B, int T, const int* tpref, hipStream_t s,
                                           int t_min = 0) {
     const int nqblk = (T + 127) / 128;
-    hipLaunchKernelGGL(attention_f32_v2_kernel, dim3(nqblk * B * 12), dim3(256), attn_f32_v2_lds(), s, qkv, out, lse, T, nqblk, tpref, t_min);
+    hipLaunchKernelGGL(attention_f32_v2_kernel<EXTV>, dim3(nqblk * B * 12), dim3(256), attn_f32_v2_lds(), s, qkv, out, lse, T, nqblk, tpref, t_min);
     return hipGetLastError();
 }
 

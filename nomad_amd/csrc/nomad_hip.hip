@@ -322,9 +322,10 @@ struct Tuning {
     double f32_quant_penalty = 0.0;  // NOMAD_F32_QUANT_PENALTY (percent): 0 = 8 % with two concurrent parts, 3 % alone
     bool f32_longk_33 = false;     // NOMAD_F32_LONGK_33
     int f32_mid_tile = 31;         // NOMAD_F32_MID_TILE
+    bool f32_attn_struct_loads = false;  // NOMAD_F32_ATTN_STRUCT_LOADS (diag): the fp32 attention's LDS fragments as float4 struct copies (A/B)
     int bf16_attn_dma = 2;         // NOMAD_BF16_ATTN_DMA: K / V of the bf16 attention by LDS-DMA in 128-key tiles
     int bf16_attn_v3 = 2;          // NOMAD_BF16_ATTN_V3: the bf16 attention on v_mfma_f32_16x16x32_bf16 with 32 queries per wave (2, shipped);
-                                   // 4 / 8: 64 queries per wave, 4 / 8 waves per workgroup (A/B: no faster); 0: the 32x32x16 kernel
+                                   // 3: its V reads through the builtin; 4 / 8: 64 queries per wave, 4 / 8 waves per workgroup (A/B: no faster); 0: the 32x32x16 kernel
     bool bf16_conv0_mfma = true;   // NOMAD_BF16_CONV0_MFMA
     int p8_min_tiles = 256;        // NOMAD_BF16_8PHASE_MIN_TILES: smallest grid (256 x 256 tiles) for the deep-pipelined bf16 kernels
     bool p8_nt_stores = true;      // NOMAD_BF16_NT_STORES
@@ -363,6 +364,7 @@ static void tuning_from_env(Tuning& t) {
     t.f32_longk_33 = getb("NOMAD_F32_LONGK_33", t.f32_longk_33);
     t.f32_mid_tile = geti("NOMAD_F32_MID_TILE", t.f32_mid_tile);
     t.bf16_attn_dma = geti("NOMAD_BF16_ATTN_DMA", t.bf16_attn_dma);
+    t.f32_attn_struct_loads = geti("NOMAD_F32_ATTN_STRUCT_LOADS", t.f32_attn_struct_loads) != 0;
     t.bf16_attn_v3 = geti("NOMAD_BF16_ATTN_V3", t.bf16_attn_v3);
     t.bf16_conv0_mfma = getb("NOMAD_BF16_CONV0_MFMA", t.bf16_conv0_mfma);
     t.p8_min_tiles = geti("NOMAD_BF16_8PHASE_MIN_TILES", t.p8_min_tiles);
@@ -952,8 +954,12 @@ int run_attention(nomad_ctx* c, const float* qkv, float* out, float* lse, int B,
     if (dc && dc->threshold)
         hipLaunchKernelGGL((attention_f32_kernel<float, true>), grid, dim3(256), 0, s, qkv, out, lse, T, kNoInts, *dc, site, bh0);
     else if (T >= kAttnV2MinT)  // by the clip's length only: the same clip takes the same kernel in every batch
-        {
-        HIP_TRY(launch_attention_f32_v2(qkv, out, lse, B, T, kNoInts, s));
+    {
+#ifdef NOMAD_DIAG
+        if (c->tune.f32_attn_struct_loads) HIP_TRY(launch_attention_f32_v2<false>(qkv, out, lse, B, T, kNoInts, s));
+        else
+#endif
+            HIP_TRY(launch_attention_f32_v2(qkv, out, lse, B, T, kNoInts, s));
     }
     else
         hipLaunchKernelGGL((attention_f32_kernel<float, false>), grid, dim3(256), 0, s, qkv, out, lse, T, kNoInts, DropCfg{}, 0u, 0);
@@ -1635,6 +1641,9 @@ static hipError_t run_attention_bf16(const nomad_ctx* c, const bf16_t* qkv, bf16
     if (log2e && c->tune.bf16_attn_v3 == 2)
         return big ? launch_attention_bf16_v3<8, 128, 4>(qkv, out, B, T, tpref, s) : launch_attention_bf16_v3<4, 64, 4>(qkv, out, B, T, tpref, s);
 #ifdef NOMAD_DIAG
+    // the V reads through the compiler's builtin (it waits for the next tile's LDS-DMA in front of them: attention_bf16_v3.hip.h): A/B
+    if (log2e && c->tune.bf16_attn_v3 == 3)
+        return big ? launch_attention_bf16_v3<8, 128, 4, 2, false>(qkv, out, B, T, tpref, s) : launch_attention_bf16_v3<4, 64, 4, 2, false>(qkv, out, B, T, tpref, s);
     // 16 waves per workgroup (512 queries share a staged K / V tile: half the LDS-DMA pieces per wave): A/B
     if (log2e && c->tune.bf16_attn_v3 == 16)
         return big ? launch_attention_bf16_v3<16, 128, 4, 2>(qkv, out, B, T, tpref, s) : launch_attention_bf16_v3<4, 64, 4>(qkv, out, B, T, tpref, s);
