@@ -35,6 +35,7 @@
 #include "attention.hip.h"
 #include "attention_bf16_v2.hip.h"
 #include "attention_bf16_v3.hip.h"
+#include "posconv_bf16_slab.hip.h"
 #include "attention_f32_v2.hip.h"
 #include "attention_bwd.hip.h"
 #include "backward.hip.h"
@@ -323,6 +324,8 @@ struct Tuning {
     bool f32_longk_33 = false;     // NOMAD_F32_LONGK_33
     int f32_mid_tile = 31;         // NOMAD_F32_MID_TILE
     bool f32_attn_struct_loads = false;  // NOMAD_F32_ATTN_STRUCT_LOADS (diag): the fp32 attention's LDS fragments as float4 struct copies (A/B)
+    bool bf16_posconv_slab = true;  // NOMAD_BF16_POSCONV_SLAB: the bf16 pos-conv with its input slab resident in LDS (posconv_bf16_slab.hip.h);
+                                    // false: the grouped GEMM on 128 x 64 tiles it replaces (A/B)
     int bf16_attn_dma = 2;         // NOMAD_BF16_ATTN_DMA: K / V of the bf16 attention by LDS-DMA in 128-key tiles
     int bf16_attn_v3 = 2;          // NOMAD_BF16_ATTN_V3: the bf16 attention on v_mfma_f32_16x16x32_bf16 with 32 queries per wave (2, shipped);
                                    // 3: its V reads through the builtin; 4 / 8: 64 queries per wave, 4 / 8 waves per workgroup (A/B: no faster); 0: the 32x32x16 kernel
@@ -365,6 +368,7 @@ static void tuning_from_env(Tuning& t) {
     t.f32_mid_tile = geti("NOMAD_F32_MID_TILE", t.f32_mid_tile);
     t.bf16_attn_dma = geti("NOMAD_BF16_ATTN_DMA", t.bf16_attn_dma);
     t.f32_attn_struct_loads = geti("NOMAD_F32_ATTN_STRUCT_LOADS", t.f32_attn_struct_loads) != 0;
+    t.bf16_posconv_slab = geti("NOMAD_BF16_POSCONV_SLAB", t.bf16_posconv_slab) != 0;
     t.bf16_attn_v3 = geti("NOMAD_BF16_ATTN_V3", t.bf16_attn_v3);
     t.bf16_conv0_mfma = getb("NOMAD_BF16_CONV0_MFMA", t.bf16_conv0_mfma);
     t.p8_min_tiles = geti("NOMAD_BF16_8PHASE_MIN_TILES", t.p8_min_tiles);
@@ -1666,6 +1670,20 @@ static hipError_t run_attention_bf16(const nomad_ctx* c, const bf16_t* qkv, bf16
                : launch_attention_bf16_v2<4, 64, 4, false>(qkv, out, B, T, tpref, s);
 }
 
+// x + gelu(pos_conv(x) + bias) of the bf16 forward from the padded group-major buffer: y[M][768] (posconv_bf16_slab.hip.h).  max_t: the
+// (longest) clip's frames; tpref / ppref: nullptr for a uniform batch.  The frames per workgroup follow the clip length only to keep
+// short clips from idling waves and from streaming the weights for a few rows - an output's bits do not depend on it.
+static int run_posconv_bf16_slab(nomad_ctx* c, const bf16_t* xpad, bf16_t* y, int max_t, int B, long long M, const int* tpref,
+                                 const int* ppref, hipStream_t s) {
+    Scope sc(c, s, NOMAD_K_GEMM, 2.0 * (double)M * 768.0 * 6144.0);
+    hipError_t e;
+    if (max_t > 256) e = launch_posconv_bf16_slab<8, 1>(xpad, c->pos_w16, c->pos_b, y, max_t, B, tpref, ppref, s);        // 512 frames of one clip
+    else if (max_t > 128) e = launch_posconv_bf16_slab<8, 2>(xpad, c->pos_w16, c->pos_b, y, max_t, B, tpref, ppref, s);   // 256 frames of two clips
+    else e = launch_posconv_bf16_slab<4, 2>(xpad, c->pos_w16, c->pos_b, y, max_t, B, tpref, ppref, s);                    // 128 frames of two clips
+    HIP_TRY(e);
+    return 0;
+}
+
 // wav rows `stride` apart; lens == nullptr: every clip has l0 frames, else ragged (max_l0 = the longest clip's, pref0 = packed rows)
 static void launch_conv0_bf16(nomad_ctx* c, const float* wav, int stride, int l0, int max_l0, int B, const float* scale,
                               const float* shift, bf16_t* out, const int* lens, const int* pref0, hipStream_t s) {
@@ -2077,7 +2095,9 @@ static int forward_bf16(nomad_ctx* c, const float* wav, int B, int n_samples, fl
     }
     CK(xpad, 16 * B, sizeof(bf16_t) * 48 * (size_t)(T + 128));
     bf16_t *x = H(lay.x), *x2 = H(lay.x2), *y = H(lay.y), *qkv = H(lay.qkv), *ctxb = H(lay.ctxb), *hb = H(lay.h);
-    {
+    if (c->tune.bf16_posconv_slab) {
+        if ((rc = run_posconv_bf16_slab(c, xpad, y, T, B, M, nullptr, nullptr, s))) return rc;
+    } else {
         GemmParams p{};
         p.A = asf(xpad);
         p.amap = RowMap{0, (long long)(T + 128) * 48, T, 48};
@@ -2572,7 +2592,9 @@ static int forward_ragged_bf16(nomad_ctx* c, const float* wav, int B, int stride
         if ((rc = run_gemm_bf16(c, p, 1, s))) return rc;
     }
     bf16_t *x = H(lay.x), *x2 = H(lay.x2), *y = H(lay.y), *qkv = H(lay.qkv), *ctxb = H(lay.ctxb), *hb = H(lay.h);
-    {
+    if (c->tune.bf16_posconv_slab) {
+        if ((rc = run_posconv_bf16_slab(c, xpad, y, rs.max_t, B, M, tpref, ppref, s))) return rc;
+    } else {
         GemmParams p{};
         p.A = asf(xpad);
         p.amap = RowMap{0, 0, 0, 48, tpref, ppref, B, 48};
@@ -2883,6 +2905,44 @@ int nomad_diag_conv0_bf16(nomad_ctx* c, const float* wav, int B, int n_samples, 
 #endif
 
 #ifdef NOMAD_DIAG
+/* The bf16 forward's positional convolution alone: y_dev [B*T][768] bf16 = x + gelu(pos_conv(x) + bias) from xpad_dev, the padded
+ * group-major input [16][B][T + 128][48] bf16 (zero frames 0..63 and T+64.. of every clip).  variant 1: posconv_bf16_slab.hip.h (what
+ * the forward launches); 0: the grouped GEMM on 128 x 64 tiles it replaced.  Needs nomad_enable_bf16. */
+int nomad_diag_posconv_bf16(nomad_ctx* c, const void* xpad_dev, void* y_dev, int B, int T, nomad_stream_t stream, int variant) {
+    if (!c || !xpad_dev || !y_dev || B <= 0 || T <= 0 || !c->pos_w16) return fail(NOMAD_ERR_INVALID, "nomad_diag_posconv_bf16: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bf16_t* xpad = static_cast<const bf16_t*>(xpad_dev);
+    bf16_t* y = static_cast<bf16_t*>(y_dev);
+    const long long M = (long long)B * T;
+    if (variant == 1) return run_posconv_bf16_slab(c, xpad, y, T, B, M, nullptr, nullptr, s);
+    if (variant != 0) return fail(NOMAD_ERR_INVALID, "nomad_diag_posconv_bf16: variant %d", variant);
+    const long long grp_stride = (long long)B * (T + 128) * 48;
+    auto asf = [](const bf16_t* p_) { return reinterpret_cast<const float*>(p_); };  // GemmParams carries typeless pointers
+    auto asfm = [](bf16_t* p_) { return reinterpret_cast<float*>(p_); };
+    GemmParams p{};
+    p.A = asf(xpad);
+    p.amap = RowMap{0, (long long)(T + 128) * 48, T, 48};
+    p.a_goff = grp_stride;
+    p.K = 6144;
+    p.kchunk = 6144;
+    p.W = asf(c->pos_w16);
+    p.ldw = 6144;
+    p.w_goff = 64LL * 6144;
+    p.bias = c->pos_b;
+    p.bias_goff = 48;
+    p.C = asfm(y);
+    p.cmap = plain_map(M, 768);
+    p.c_goff = 48;
+    p.R = asf(xpad);
+    p.rmap = RowMap{64LL * 48, (long long)(T + 128) * 48, T, 48};
+    p.r_goff = grp_stride;
+    p.M = (int)M;
+    p.N = 64;
+    p.n_valid = 48;
+    p.gelu = 1;
+    return run_gemm_bf16(c, p, 16, s);
+}
+
 // timeline of the last tile-36 GEMM: out_host[6 * n] = per workgroup {entry, loop start, loop end, stores done, HW_ID, XCC_ID}
 int nomad_diag_timeline(unsigned long long* out_host, int n) {
     if (!out_host || n <= 0 || n > kTimelineSlots) return fail(NOMAD_ERR_INVALID, "nomad_diag_timeline: bad argument");

@@ -251,3 +251,39 @@ def test_conv0_on_the_matrix_cores(built_lib, sd0, B, N):
     assert (diff <= 2 ** -7 * outs[0].abs() + 8e-5).all(), diff.max().item()      # never more than one bf16 ulp apart (outputs near zero: the absolute 2^-16 floor)
     frac = (diff > 0).float().mean().item()
     assert frac < 0.05, frac                                                        # and different in a few per cent of the elements only
+
+
+@pytest.mark.parametrize("B,T", [(2, 1499), (3, 199), (2, 50), (1, 1), (1, 130), (2, 513), (1, 257), (5, 199), (3, 100), (7, 128), (4, 256)])
+def test_posconv_with_the_input_slab_in_lds(built_lib, sd0, B, T):
+    """posconv_bf16_slab_kernel (the bf16 forward's positional convolution: a workgroup keeps the (frames + 128) x 48 input slab of one
+    clip and group in LDS and streams the weights through registers) against the grouped GEMM it replaced, on the same bf16 input and
+    weights: the two differ in fp32 summation order only, i.e. by at most one rounding of the bf16 output.  T covers one / several /
+    partial workgroup tiles (512, 256 and 128 frames per workgroup), a single frame, and waves without any valid row."""
+    import ctypes as C
+    from nomad_amd import _lib
+    from nomad_amd.engine import Engine
+    eng = Engine(sd0, 0, diag=True)
+    lib = eng.lib
+    _lib.check(lib.nomad_enable_bf16(eng.ctx), "nomad_enable_bf16")
+    lib.nomad_diag_posconv_bf16.restype = C.c_int
+    lib.nomad_diag_posconv_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    gen = torch.Generator().manual_seed(100 * B + T)
+    xpad = torch.zeros(16, B, T + 128, 48)
+    xpad[:, :, 64:64 + T] = torch.randn(16, B, T, 48, generator=gen)
+    xdev = xpad.bfloat16().cuda()
+    outs = []
+    for variant in (0, 1):
+        y = torch.full((B * T, 768), float("nan"), dtype=torch.bfloat16, device="cuda")
+        assert lib.nomad_diag_posconv_bf16(eng.ctx, xdev.data_ptr(), y.data_ptr(), B, T, torch.cuda.current_stream().cuda_stream, variant) == 0
+        torch.cuda.synchronize()
+        assert torch.isfinite(y.float()).all()
+        outs.append(y.float().cpu())
+    diff = (outs[1] - outs[0]).abs()
+    tol = 2.0 ** -7 * outs[0].abs().clamp_min(0.25)      # one bf16 ulp of the larger of |y| and 0.25
+    assert (diff <= tol).all(), (diff.max().item(), (diff > tol).sum().item())
+    assert (diff > 0).float().mean().item() < 0.2        # (most outputs round to the same bf16 value)
+    again = torch.empty_like(y)
+    assert lib.nomad_diag_posconv_bf16(eng.ctx, xdev.data_ptr(), again.data_ptr(), B, T, torch.cuda.current_stream().cuda_stream, 1) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(again, y)
+    eng.close()
