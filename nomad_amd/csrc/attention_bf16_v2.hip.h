@@ -311,14 +311,10 @@ __global__ __launch_bounds__(64 * NW, OCC) void attention_bf16_v2_kernel(const b
 // host-side launcher of one instantiation.  Returns the hipError of the launch.
 template <int NW, int KT, int OCC, bool LOG2E, bool DMA = false>
 inline hipError_t launch_attention_bf16_v2(const bf16_t* qkv, bf16_t* out, int B, int T, const int* tpref, hipStream_t s) {
-    static bool configured = false;
+    static LdsAttrOnce configured;
     auto kern = attention_bf16_v2_kernel<NW, KT, OCC, LOG2E, DMA>;
     constexpr int lds = attn_bf16_v2_lds(KT);
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
+    if (hipError_t e = configured.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
     const int nqblk = (T + 32 * NW - 1) / (32 * NW);
     hipLaunchKernelGGL(kern, dim3(nqblk * B * 12), dim3(64 * NW), lds, s, qkv, out, T, nqblk, tpref);
     return hipGetLastError();

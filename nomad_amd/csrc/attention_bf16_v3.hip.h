@@ -322,14 +322,10 @@ __global__ __launch_bounds__(64 * NW, OCC) void attention_bf16_v3_kernel(const b
 
 template <int NW, int KT, int OCC, int QS = 2, bool ASMV = true>
 inline hipError_t launch_attention_bf16_v3(const bf16_t* qkv, bf16_t* out, int B, int T, const int* tpref, hipStream_t s) {
-    static bool configured = false;
+    static LdsAttrOnce configured;
     auto kern = attention_bf16_v3_kernel<NW, KT, OCC, QS, ASMV>;
     constexpr int lds = attn_bf16_v2_lds(KT);
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
+    if (hipError_t e = configured.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
     const int nqblk = (T + 16 * QS * NW - 1) / (16 * QS * NW);
     hipLaunchKernelGGL(kern, dim3(nqblk * B * 12), dim3(64 * NW), lds, s, qkv, out, T, nqblk, tpref);
     return hipGetLastError();

@@ -111,4 +111,20 @@ __global__ __launch_bounds__(256) void scale_head_kernel(const float* __restrict
     if (i < n) out[i] = in[i] * (i < n_scaled ? scale : 1.0f);
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to ONE device: a flag per (kernel instantiation, device), so that a process
+// that drives several GPUs (one engine each) configures every kernel on each of them.  (Racing host threads at worst set it twice.)
+struct LdsAttrOnce {
+    static constexpr int kMaxDev = 64;
+    bool done[kMaxDev] = {};
+    hipError_t ensure(const void* kern, int bytes) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < kMaxDev && done[dev]) return hipSuccess;
+        e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e == hipSuccess && dev >= 0 && dev < kMaxDev) done[dev] = true;
+        return e;
+    }
+};
+
 }  // namespace nomad

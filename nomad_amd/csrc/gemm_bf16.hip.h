@@ -206,13 +206,8 @@ inline hipError_t launch_gemm_bf16(GemmParams p, int groups, hipStream_t s, int 
     using Cfg = Bf16Cfg<BM, BN, WM, WN, BK, STAGES>;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = p.N / BN;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_glds_kernel<BM, BN, WM, WN, ABL, BK, STAGES>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static LdsAttrOnce attr_set;
+    if (hipError_t e = attr_set.ensure(reinterpret_cast<const void*>(gemm_bf16_glds_kernel<BM, BN, WM, WN, ABL, BK, STAGES>), 160 * 1024); e != hipSuccess) return e;
     dim3 grid(p.tiles_m * p.tiles_n, groups);
     hipLaunchKernelGGL((gemm_bf16_glds_kernel<BM, BN, WM, WN, ABL, BK, STAGES>), grid, dim3(Cfg::THREADS), Cfg::LDS_BYTES + extra_lds, s,
                        p);

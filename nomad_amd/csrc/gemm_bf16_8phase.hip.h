@@ -462,13 +462,8 @@ inline hipError_t launch_gemm_bf16_8phase(GemmParams p, int groups, hipStream_t 
         if (p.amap.clip_rows < p.M) fast_div_magic((unsigned)p.amap.clip_rows, &p.a_clip_magic, &p.a_clip_shift);
         if (p.tiles_n > 1) fast_div_magic((unsigned)p.tiles_n, &p.tn_magic, &p.tn_shift);
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_8phase_kernel<ABL, BUFLD, X3, NB, NJ, RPRE, PLAIN>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static LdsAttrOnce attr_set;
+    if (hipError_t e = attr_set.ensure(reinterpret_cast<const void*>(gemm_bf16_8phase_kernel<ABL, BUFLD, X3, NB, NJ, RPRE, PLAIN>), 160 * 1024); e != hipSuccess) return e;
     hipLaunchKernelGGL((gemm_bf16_8phase_kernel<ABL, BUFLD, X3, NB, NJ, RPRE, PLAIN>), dim3(p.tiles_m * p.tiles_n, groups), dim3(P8Cfg::THREADS),
                        NB == 3 ? 160 * 1024 : P8Cfg::LDS_BYTES, s, p);
     return hipGetLastError();

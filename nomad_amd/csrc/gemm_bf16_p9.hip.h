@@ -462,12 +462,8 @@ inline hipError_t launch_gemm_bf16_p9(GemmParams p, hipStream_t s, int num_cus) 
     p.a_clip_shift = p.tn_shift = 0;
     if (p.amap.clip_rows < p.M) fast_div_magic((unsigned)p.amap.clip_rows, &p.a_clip_magic, &p.a_clip_shift);
     if (p.tiles_n > 1) fast_div_magic((unsigned)p.tiles_n, &p.tn_magic, &p.tn_shift);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_p9_kernel<ABL, INTER, DMAP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static LdsAttrOnce attr_set;
+    if (hipError_t e = attr_set.ensure(reinterpret_cast<const void*>(gemm_bf16_p9_kernel<ABL, INTER, DMAP>), 160 * 1024); e != hipSuccess) return e;
     const long long ntiles = (long long)p.tiles_m * p.tiles_n;
     long long per_xcd = (ntiles + 7) / 8;
     const int cap = num_cus >= 8 ? num_cus / 8 : 1;

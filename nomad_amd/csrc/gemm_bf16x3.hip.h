@@ -241,13 +241,8 @@ template <int ABL, int X3, int NA = 2, bool PLAIN = false>
 inline hipError_t launch_gemm_bf16x3(GemmParams p, int groups, hipStream_t s) {
     p.tiles_m = (p.M + X3Cfg::BM - 1) / X3Cfg::BM;
     p.tiles_n = p.N / X3Cfg::BN;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel<ABL, X3, NA, PLAIN>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static LdsAttrOnce attr_set;
+    if (hipError_t e = attr_set.ensure(reinterpret_cast<const void*>(gemm_bf16x3_kernel<ABL, X3, NA, PLAIN>), 160 * 1024); e != hipSuccess) return e;
     hipLaunchKernelGGL((gemm_bf16x3_kernel<ABL, X3, NA, PLAIN>), dim3(p.tiles_m * p.tiles_n, groups), dim3(X3Cfg::THREADS), (NA + 2) * X3Cfg::PAIR_BYTES, s, p);
     return hipGetLastError();
 }

@@ -1077,13 +1077,8 @@ inline hipError_t launch_gemm_glds(GemmParams p, int groups, hipStream_t s, int 
         if (p.amap.clip_rows < p.M) fast_div_magic((unsigned)p.amap.clip_rows, &p.a_clip_magic, &p.a_clip_shift);
         if (p.tiles_n > 1) fast_div_magic((unsigned)p.tiles_n, &p.tn_magic, &p.tn_shift);
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_glds_kernel<BM, BN, BK, WM, WN, STAGES, NOEPI, OPT, X3>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static LdsAttrOnce attr_set;
+    if (hipError_t e = attr_set.ensure(reinterpret_cast<const void*>(gemm_f32_glds_kernel<BM, BN, BK, WM, WN, STAGES, NOEPI, OPT, X3>), 160 * 1024); e != hipSuccess) return e;
     int gx = p.tiles_m * p.tiles_n;
     if (persist_blocks > 0 && gx > persist_blocks) gx = persist_blocks;
     dim3 grid(gx, groups);
@@ -1107,12 +1102,8 @@ inline hipError_t launch_gemm_mixed(GemmParams p, int M1, hipStream_t s) {
     pb.tile_m_base = 0;
     ps.tiles_m = (p.M - M1 + 127) / 128;
     ps.tile_m_base = M1 / 128;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_mixed_kernel<OPTB, OPTS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static LdsAttrOnce attr_set;
+    if (hipError_t e = attr_set.ensure(reinterpret_cast<const void*>(gemm_f32_mixed_kernel<OPTB, OPTS>), 160 * 1024); e != hipSuccess) return e;
     const int n_big = pb.tiles_m * pb.tiles_n, n_small = ps.tiles_m * ps.tiles_n;
     hipLaunchKernelGGL((gemm_f32_mixed_kernel<OPTB, OPTS>), dim3(n_big + n_small), dim3(512), CfgB::LDS_BYTES, s, pb, ps, n_big);
     return hipGetLastError();
@@ -1333,24 +1324,17 @@ inline hipError_t launch_gemm_pers(GemmParams p, hipStream_t s, int num_cus, boo
     p.a_clip_shift = p.tn_shift = 0;
     if (p.amap.clip_rows < p.M) fast_div_magic((unsigned)p.amap.clip_rows, &p.a_clip_magic, &p.a_clip_shift);
     if (p.tiles_n > 1) fast_div_magic((unsigned)p.tiles_n, &p.tn_magic, &p.tn_shift);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_pers_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_pers_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static LdsAttrOnce attr_set;
+    if (hipError_t e = attr_set.ensure(reinterpret_cast<const void*>(gemm_f32_pers_kernel<false>), 160 * 1024); e != hipSuccess) return e;
+    static LdsAttrOnce attr_set_2;
+    if (hipError_t e = attr_set_2.ensure(reinterpret_cast<const void*>(gemm_f32_pers_kernel<true>), 160 * 1024); e != hipSuccess) return e;
     const long long nwg = (long long)p.tiles_m * p.tiles_n;
     // one_tile_each: the same kernel launched with one workgroup per tile - no tile loop, only its lean set-up and direct epilogue
     const int grid = (int)((one_tile_each || nwg < 2ll * num_cus) ? nwg : 2ll * num_cus);
     constexpr int lds = 3 * (256 + 128) * 16 * 4;
     if (stagger) {
-        static bool attr2 = false;
-        if (!attr2) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_pers_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-            attr2 = true;
-        }
+        static LdsAttrOnce attr2;
+        if (hipError_t e = attr2.ensure(reinterpret_cast<const void*>(gemm_f32_pers_kernel<false, 1>), 160 * 1024); e != hipSuccess) return e;
         hipLaunchKernelGGL((gemm_f32_pers_kernel<false, 1>), dim3(grid), dim3(512), lds, s, p);
     } else if (noepi) hipLaunchKernelGGL(gemm_f32_pers_kernel<true>, dim3(grid), dim3(512), lds, s, p);
     else hipLaunchKernelGGL(gemm_f32_pers_kernel<false>, dim3(grid), dim3(512), lds, s, p);
@@ -1515,13 +1499,8 @@ template <bool BUFLD = false>
 inline hipError_t launch_gemm_n48(GemmParams p, int groups, hipStream_t s, int slices = 1) {
     p.tiles_m = (p.M + N48Cfg::BM - 1) / N48Cfg::BM;
     p.tiles_n = 1;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_n48_kernel<BUFLD>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static LdsAttrOnce attr_set;
+    if (hipError_t e = attr_set.ensure(reinterpret_cast<const void*>(gemm_f32_n48_kernel<BUFLD>), 160 * 1024); e != hipSuccess) return e;
     hipLaunchKernelGGL(gemm_f32_n48_kernel<BUFLD>, dim3(p.tiles_m, groups, slices), dim3(N48Cfg::THREADS), N48Cfg::LDS_BYTES, s, p);
     return hipGetLastError();
 }
@@ -1531,13 +1510,8 @@ inline hipError_t launch_gemm(GemmParams p, int groups, hipStream_t s, int extra
     using Cfg = GemmCfg<BM, BN, BK, WM, WN>;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = p.N / BN;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<BM, BN, BK, WM, WN, ABL>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static LdsAttrOnce attr_set;
+    if (hipError_t e = attr_set.ensure(reinterpret_cast<const void*>(gemm_f32_kernel<BM, BN, BK, WM, WN, ABL>), 160 * 1024); e != hipSuccess) return e;
     dim3 grid(p.tiles_m * p.tiles_n, groups);
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, WM, WN, ABL>), grid, dim3(Cfg::THREADS), Cfg::LDS_BYTES + extra_lds, s,
                        p);

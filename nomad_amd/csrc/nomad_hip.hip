@@ -2181,12 +2181,8 @@ static int run_attention_x3(nomad_ctx* c, const bf16s_t* qkv, long long in_plane
     if (waves < 0) waves = max_t <= kAttnResidentMaxT ? kAttnResidentWaves : 0;
     if (waves > 0) {
         if (max_t > kAttnResidentMaxT) return fail(NOMAD_ERR_INVALID, "bf16x3 resident attention: T = %d > %d", max_t, kAttnResidentMaxT);
-        static bool attr_set = false;
-        if (!attr_set) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_x3_resident_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
-        }
+        static LdsAttrOnce attr_set;
+        HIP_TRY(attr_set.ensure(reinterpret_cast<const void*>(attention_x3_resident_kernel), 160 * 1024));
         hipLaunchKernelGGL(attention_x3_resident_kernel, dim3(B * 12), dim3(waves * 64), attn_x3_resident_lds(max_t), s, qkv,
                            in_plane, out, out_plane, T, attn_x3_resident_rows(max_t), tpref);
     } else {

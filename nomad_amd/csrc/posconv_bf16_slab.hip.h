@@ -180,15 +180,11 @@ __global__ __launch_bounds__(256, 2) void posconv_bf16_slab_kernel(const bf16_t*
 template <int RT, int CPW>
 inline hipError_t launch_posconv_bf16_slab(const bf16_t* xpad, const bf16_t* W, const float* bias, bf16_t* y, int max_t, int B,
                                            const int* tpref, const int* ppref, hipStream_t s) {
-    static bool configured = false;
+    static LdsAttrOnce configured;
     auto kern = posconv_bf16_slab_kernel<RT, CPW>;
     constexpr int lds = posconv_slab_lds(RT, CPW);
     constexpr int frc = posconv_slab_frames(RT, CPW);
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
+    if (hipError_t e = configured.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((max_t + frc - 1) / frc, (B + CPW - 1) / CPW, 16), dim3(256), lds, s, xpad, W, bias, y, max_t, B, tpref, ppref);
     return hipGetLastError();
 }
