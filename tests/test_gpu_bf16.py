@@ -190,6 +190,18 @@ def test_ragged_bf16_bit_identical_to_single_clips(engine):
         engine.embed_ragged(waves, head=(torch.zeros(256, 768).cuda(), torch.zeros(256).cuda()), bf16=True)
 
 
+def test_ragged_bf16_with_a_long_clip_in_the_batch(engine):
+    """A 30 s clip (T = 1499) next to short ones: the batch's longest clip picks the pos-conv's frames per workgroup (512 here, 256 / 128 in
+    the single-clip calls of the short files) - every clip still bit-equal to its own nomad_embed_bf16 call."""
+    g = torch.Generator().manual_seed(22)
+    lens = [480000, 400, 64000, 5000, 90000]
+    waves = [(0.1 * torch.randn(n, generator=g)).clamp(-1, 1) for n in lens]
+    rag = engine.embed_ragged(waves, bf16=True)
+    for i, w in enumerate(waves):
+        single = engine.embed_bf16(w[None, :].cuda())
+        assert torch.equal(rag[i], single[0]), (i, lens[i])
+
+
 def test_predict_in_bf16_precision(built_lib):
     """Nomad(precision='bf16').predict on the reference's example files: same files, same layout, scores within 1e-3 of
     the fp32 run."""
