@@ -425,6 +425,7 @@ struct nomad_ctx {
     bf16_t* conv_w16[7] = {};
     bf16_t* conv0_wfrag = nullptr;       // conv0's MFMA A operands [8][4][64][8] (conv0_wfrag_kernel): bf16 path
     bf16_t *proj_w16 = nullptr, *pos_w16 = nullptr;
+    bf16_t* pos_wfrag16 = nullptr;        // the pos-conv weights in MFMA fragment order (posconv_wfrag_kernel): bf16 path
     bf16_t *qkv_w16[NOMAD_NUM_LAYERS] = {}, *o_w16[NOMAD_NUM_LAYERS] = {}, *fc1_w16[NOMAD_NUM_LAYERS] = {},
            *fc2_w16[NOMAD_NUM_LAYERS] = {};
     // the bf16 path's q rows of the fused QKV weight and bias also carry log2(e): its attention kernel works in log2
@@ -1677,9 +1678,9 @@ static int run_posconv_bf16_slab(nomad_ctx* c, const bf16_t* xpad, bf16_t* y, in
                                  const int* ppref, hipStream_t s) {
     Scope sc(c, s, NOMAD_K_GEMM, 2.0 * (double)M * 768.0 * 6144.0);
     hipError_t e;
-    if (max_t > 256) e = launch_posconv_bf16_slab<8, 1>(xpad, c->pos_w16, c->pos_b, y, max_t, B, tpref, ppref, s);        // 512 frames of one clip
-    else if (max_t > 128) e = launch_posconv_bf16_slab<8, 2>(xpad, c->pos_w16, c->pos_b, y, max_t, B, tpref, ppref, s);   // 256 frames of two clips
-    else e = launch_posconv_bf16_slab<4, 2>(xpad, c->pos_w16, c->pos_b, y, max_t, B, tpref, ppref, s);                    // 128 frames of two clips
+    if (max_t > 256) e = launch_posconv_bf16_slab<8, 1>(xpad, c->pos_wfrag16, c->pos_b, y, max_t, B, tpref, ppref, s);        // 512 frames of one clip
+    else if (max_t > 128) e = launch_posconv_bf16_slab<8, 2>(xpad, c->pos_wfrag16, c->pos_b, y, max_t, B, tpref, ppref, s);   // 256 frames of two clips
+    else e = launch_posconv_bf16_slab<4, 2>(xpad, c->pos_wfrag16, c->pos_b, y, max_t, B, tpref, ppref, s);                    // 128 frames of two clips
     HIP_TRY(e);
     return 0;
 }
@@ -2680,6 +2681,13 @@ int nomad_enable_bf16(nomad_ctx* c) {
         if ((rc = conv(c->conv_w[i], (size_t)512 * kConvK[i] * 512, &c->conv_w16[i]))) return rc;
     if ((rc = conv(c->proj_w, (size_t)768 * 512, &c->proj_w16))) return rc;
     if ((rc = conv(c->pos_w, (size_t)16 * 64 * 6144, &c->pos_w16))) return rc;
+    if (!c->pos_wfrag16) {
+        void* d = nullptr;
+        HIP_TRY(hipMalloc(&d, posconv_wfrag_elems() * sizeof(bf16_t)));
+        c->allocs.push_back(d);
+        c->pos_wfrag16 = static_cast<bf16_t*>(d);
+    }
+    hipLaunchKernelGGL(posconv_wfrag_kernel, dim3(16 * 192), dim3(192), 0, 0, c->pos_w, c->pos_wfrag16);
     for (int l = 0; l < NOMAD_NUM_LAYERS; ++l) {
         const LayerDev& d = c->layers[l];
         if ((rc = conv(d.qkv_w, (size_t)2304 * 768, &c->qkv_w16[l]))) return rc;

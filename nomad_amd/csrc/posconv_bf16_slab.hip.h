@@ -11,9 +11,9 @@
 //   * row m's K vector is then the 12 KB starting at LDS byte 96 m, so the fragment of row m for k-step ks (32 values) is the 16 bytes
 //     at 96 m + 64 ks + 16 fq: one address per lane for the whole K loop, the k-step in the instruction's offset field.  The 96-byte row
 //     stride is bank-conflict-free for 8 consecutive rows (24 banks apart, 4 banks each);
-//   * the weights (48 x 6144 per group, the same for every workgroup of the group) never pass through LDS: each lane loads the 16 bytes
-//     of its (W row, k chunk) straight into the MFMA operand registers, two k-steps ahead; a workgroup's four waves read the same lines
-//     (L1 hits).  No barrier inside the K loop;
+//   * the weights (48 x 6144 per group, the same for every workgroup of the group) never pass through LDS: each lane loads its 16 bytes
+//     of a k-step straight into the MFMA operand registers, two k-steps ahead, from a copy of the panel in FRAGMENT order (a wave's
+//     load is 1 KB of consecutive bytes); a workgroup's four waves read the same lines (L1 hits).  No barrier inside the K loop;
 //   * v_mfma_f32_16x16x32_bf16, transposed product (W rows x frames): N = 48 is three 16-row tiles exactly - no padded columns - and a
 //     lane ends up with 4 consecutive output channels of one frame: 8-byte stores, the residual (the input itself, frame 64 + t of the
 //     slab) read back from LDS.
@@ -27,6 +27,21 @@
 
 namespace nomad {
 
+// The weights in FRAGMENT ORDER: wfrag[g][ks][j][lane][8] = W[g][16 j + (lane & 15)][32 ks + 8 (lane >> 4) ..] - what lane `lane` feeds
+// v_mfma_f32_16x16x32_bf16 for k-step ks and W row tile j, so that a wave's load instruction reads 1 KB of CONSECUTIVE bytes.  Loaded from
+// the row-major panel the same instruction touched 16 cache lines (64 bytes of each) and the texture-address units were 93 % busy with
+// the kernel at 45 % of its matrix time (profiles/r05_pmc_posconv_bf16_slab.txt).  grid: 16 * 192 blocks of 192 threads.
+__global__ __launch_bounds__(192) void posconv_wfrag_kernel(const float* __restrict__ w /* [16][64][6144] */, bf16_t* __restrict__ wfrag) {
+    const int g = blockIdx.x / 192, ks = blockIdx.x - g * 192;
+    const int j = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float* src = w + ((long long)g * 64 + 16 * j + (lane & 15)) * 6144 + 32 * ks + 8 * (lane >> 4);
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (bf16_t)src[e];
+    *reinterpret_cast<bf16x8*>(wfrag + (((long long)g * 192 + ks) * 3 + j) * 512 + lane * 8) = v;
+}
+constexpr size_t posconv_wfrag_elems() { return (size_t)16 * 192 * 3 * 512; }
+
 constexpr int posconv_slab_frames(int rt, int cpw) { return (4 / cpw) * 16 * rt; }                  // frames of one clip per workgroup
 constexpr int posconv_slab_lds(int rt, int cpw) { return cpw * (posconv_slab_frames(rt, cpw) + 128) * 96; }
 
@@ -36,7 +51,7 @@ constexpr int posconv_slab_lds(int rt, int cpw) { return cpw * (posconv_slab_fra
 // than the GEMM it replaces.  An output's contraction order does not depend on any of this.
 // grid: (ceil(max T / FRC), ceil(B / CPW), 16 groups), 256 threads, dynamic LDS posconv_slab_lds(RT, CPW).
 // xpad: [16][frames of all clips + 128 each][48] bf16 (uniform: clip b at frame b (T + 128); ragged: at ppref[b], ppref[B] per group);
-// W: [16][64][6144] bf16 (rows 48 .. 63 unused); bias: [768] fp32; y: [M][768] bf16, rows row0(b) + t, columns 48 g ..
+// W: posconv_wfrag_kernel's fragment-ordered weights; bias: [768] fp32; y: [M][768] bf16, rows row0(b) + t, columns 48 g ..
 template <int RT, int CPW>
 __global__ __launch_bounds__(256, 2) void posconv_bf16_slab_kernel(const bf16_t* __restrict__ xpad, const bf16_t* __restrict__ W,
                                                                    const float* __restrict__ bias, bf16_t* __restrict__ y, int T_uniform, int B,
@@ -81,17 +96,14 @@ __global__ __launch_bounds__(256, 2) void posconv_bf16_slab_kernel(const bf16_t*
         }
     }
     if (!any) return;  // whole workgroup (every condition above is uniform over it), before any barrier
-    // ---- this lane's weight rows: W[g][16 j + fr][32 ks + 8 fq ..], two k-steps in flight ----
-    // (a wave-uniform group base + 32-bit per-lane byte offsets: the scalar-base form of the load, no 64-bit vector arithmetic in the loop)
-    const char* wg = reinterpret_cast<const char*>(W + (long long)g * 64 * 6144);   // (blockIdx.z: already scalar)
-    unsigned woff[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) woff[j] = (unsigned)(((16 * j + fr) * 6144 + 8 * fq) * 2);
+    // ---- this lane's weight fragments: wfrag[g][ks][j][lane], two k-steps in flight (a wave-uniform base + one 32-bit lane offset) ----
+    const char* wg = reinterpret_cast<const char*>(W + (long long)g * 192 * 3 * 512);   // (blockIdx.z: already scalar)
+    const unsigned wlane = (unsigned)lane * 16u;
     bf16x8 w0[3], w1[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        w0[j] = *reinterpret_cast<const bf16x8*>(wg + woff[j]);
-        w1[j] = *reinterpret_cast<const bf16x8*>(wg + (woff[j] + 64u));
+        w0[j] = *reinterpret_cast<const bf16x8*>(wg + (wlane + (unsigned)j * 1024u));
+        w1[j] = *reinterpret_cast<const bf16x8*>(wg + (wlane + 3072u + (unsigned)j * 1024u));
     }
     f32x4 acc[RT][3];
 #pragma unroll
@@ -117,8 +129,8 @@ __global__ __launch_bounds__(256, 2) void posconv_bf16_slab_kernel(const bf16_t*
         const int kn = ks + 2 < 192 ? ks + 2 : 190;   // (the last call re-reads the panel's end: in bounds, unused)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            wn0[j] = *reinterpret_cast<const bf16x8*>(wg + (woff[j] + (unsigned)kn * 64u));
-            wn1[j] = *reinterpret_cast<const bf16x8*>(wg + (woff[j] + (unsigned)kn * 64u + 64u));
+            wn0[j] = *reinterpret_cast<const bf16x8*>(wg + (wlane + (unsigned)kn * 3072u + (unsigned)j * 1024u));
+            wn1[j] = *reinterpret_cast<const bf16x8*>(wg + (wlane + (unsigned)kn * 3072u + 3072u + (unsigned)j * 1024u));
         }
 #pragma unroll
         for (int i = 0; i < RT; ++i) a1[i] = *reinterpret_cast<const bf16x8*>(ap + i * 1536 + (ks + 1) * 64);
