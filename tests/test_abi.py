@@ -120,4 +120,16 @@ def test_shipped_libraries_have_no_packed_fp32_instructions(built_lib):
             # offset instead; hold the libraries to "no wide buffer store with a register soffset".
             bad = re.findall(r"buffer_store_dwordx[34] v\[\d+:\d+\], v\d+, s\[\d+:\d+\], s\d+ offen", asm)
             assert not bad, f"{os.path.basename(lib)}: wide buffer stores with an SGPR soffset: {bad[:3]}"
+            # Round 5 ("LDS reads hipcc does not order behind the next tile's LDS-DMA"): an LDS read without alias
+            # information - a float4 STRUCT copy, the ds_read_tr builtin - gets s_waitcnt vmcnt(0) in front of it while an LDS-DMA is in
+            # flight, which serialises a double-buffered kernel's prefetch with its products.  The attention kernels the forwards
+            # launch read LDS through ext-vector loads / inline asm instead: hold them to "no vmcnt wait directly in front of a ds_read".
+            if lib == build.LIB:
+                for name in ("attention_f32_v2_kernel", "attention_bf16_v3_kernel"):
+                    bodies = re.findall(r"<_ZN5nomad\d+%s\w*>:\n(.*?)s_endpgm" % name, asm, re.S)
+                    assert bodies, name
+                    for body in bodies:
+                        assert "global_load_lds" in body, name
+                        hits = re.findall(r"s_waitcnt vmcnt\(\d+\)[^\n]*\n\s*ds_read", body)
+                        assert not hits, f"{name}: {len(hits)} vmcnt waits directly in front of LDS reads"
         assert found == 1, (lib, found)
