@@ -310,6 +310,7 @@ ParamOffsets make_param_offsets() {
 // reads the environment: "nothing but the arguments" decides what a call does.  Only libnomad_diag.so (-DNOMAD_DIAG) fills a
 // context's copy from NOMAD_* environment variables, once, in nomad_create (tuning_from_env) - the A/B runs of tools/ and profiles/.
 struct Tuning {
+    bool splitk_ln_fuse = true;    // NOMAD_SPLITK_LN: a split-K out_proj / fc2 normalises its rows in its own epilogue (splitk_epilogue_ln_kernel)
     bool splitk_posconv = true;    // NOMAD_SPLITK_POSCONV: the grouped pos-conv of the loss path splits K four ways
     bool splitk_layers = true;     // NOMAD_SPLITK_LAYERS: so do the dense GEMMs of a small layer-output forward
     bool f32_plain_epi = true;     // NOMAD_F32_PLAIN_EPI: small epilogue for plain C / R matrices
@@ -349,6 +350,7 @@ static void tuning_from_env(Tuning& t) {
     auto geti = [](const char* n, int d) { const char* e = getenv(n); return e ? atoi(e) : d; };
     auto getb = [](const char* n, bool d) { const char* e = getenv(n); return e ? atoi(e) != 0 : d; };
     auto getd = [](const char* n, double d) { const char* e = getenv(n); return e ? atof(e) : d; };
+    t.splitk_ln_fuse = getb("NOMAD_SPLITK_LN", t.splitk_ln_fuse);
     t.splitk_posconv = getb("NOMAD_SPLITK_POSCONV", t.splitk_posconv);
     t.splitk_layers = getb("NOMAD_SPLITK_LAYERS", t.splitk_layers);
     t.f32_plain_epi = getb("NOMAD_F32_PLAIN_EPI", t.f32_plain_epi);
@@ -406,6 +408,16 @@ struct nomad_ctx {
     // call's own workspace: Layout::splitk)
     float* splitk_cur = nullptr;                            // the block of the call being enqueued
     bool splitk_ok = false;
+    // A LayerNorm(768) the caller will apply to the output of the NEXT dense GEMM (run_layer: out_proj -> LN, fc2 -> LN): when that GEMM
+    // splits K, its epilogue normalises the rows itself (splitk_epilogue_ln_kernel) and sets `done`; otherwise the caller launches the
+    // stand-alone LayerNorm.  Per context, set and consumed inside one forward call.
+    struct PendingLn {
+        const float* gamma = nullptr;
+        const float* beta = nullptr;
+        float* out = nullptr;
+        float* out2 = nullptr;
+        bool armed = false, done = false;
+    } pending_ln;
     // nomad_pairwise: row sums per (64-ref tile, deg row), kPairScratchDoubles doubles PER LAUNCH STREAM - calls on
     // different streams of one context may be in flight together (Engine / ShardedScorer are driven from side streams), so
     // each stream gets its own block: the first at nomad_create, further ones on a stream's first call
@@ -586,6 +598,13 @@ static int run_gemm_splitk(nomad_ctx* c, const GemmParams& p, int S, hipStream_t
     c->splitk_ok = keep;
     if (rc) return rc;
     Scope sc(c, s, NOMAD_K_ROW, 0.0);
+    if (c->pending_ln.armed && !c->pending_ln.done && p.N == 768 && !p.gelu) {
+        hipLaunchKernelGGL(splitk_epilogue_ln_kernel, dim3((unsigned)((p.M + 3) / 4)), dim3(256), 0, s, c->splitk_cur, S, p.M, p.bias, p.R, p.C,
+                           c->pending_ln.gamma, c->pending_ln.beta, c->pending_ln.out, c->pending_ln.out2);
+        HIP_TRY(hipGetLastError());
+        c->pending_ln.done = true;
+        return 0;
+    }
     const long long count4 = (long long)p.M * p.N / 4;
     hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((count4 + 255) / 256)), dim3(256), 0, s,
                        reinterpret_cast<const float4*>(c->splitk_cur), S, count4, p.N / 4, reinterpret_cast<const float4*>(p.bias),
@@ -1369,21 +1388,42 @@ static int forward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, co
         if ((rc = run_attention(c, qkv, ctxb, lse, nc, T, s, &d_att, site_attn(l), c0 * 12))) return rc;
         // residual dropout: y = x + dropout(W a + b) needs the branch on its own, so the residual add moves out
         // of the GEMM epilogue into the dropout kernel
+        // (the LayerNorm behind a residual GEMM: inside the GEMM's split-K epilogue where it has one - configs[3] - else on its own)
+        auto arm_ln = [&](const float* g_, const float* b_, float* out_, float* out2_) {
+            c->pending_ln = {};
+            if (!c->tune.splitk_ln_fuse || d_res.threshold) return;   // (residual dropout moves the residual add out of the GEMM)
+            c->pending_ln.gamma = g_;
+            c->pending_ln.beta = b_;
+            c->pending_ln.out = out_;
+            c->pending_ln.out2 = out2_;
+            c->pending_ln.armed = true;
+        };
+        auto ln_after = [&](const float* in_, const float* g_, const float* b_, float* out_, float* out2_) -> int {
+            const bool done = c->pending_ln.armed && c->pending_ln.done;
+            c->pending_ln = {};
+            return done ? 0 : run_layernorm(c, in_, g_, b_, out_, out2_, Ms, 768, s);
+        };
+        arm_ln(d.ln1_w, d.ln1_b, x2s, nullptr);
         if ((rc = run_gemm(c, dense(ctxb, 768, d.o_w, d.o_b, d_res.threshold ? nullptr : xs, y1, Ms, 768, 768, 0), 1,
-                           pick_tile(c, Ms, 768, 768), s)))
+                           pick_tile(c, Ms, 768, 768), s))) {
+            c->pending_ln = {};
             return rc;
+        }
         if (d_res.threshold && (rc = run_dropout(c, y1, xs, y1, acts, d_res, site_proj(l), s, idx0))) return rc;
-        if ((rc = run_layernorm(c, y1, d.ln1_w, d.ln1_b, x2s, nullptr, Ms, 768, s))) return rc;
+        if ((rc = ln_after(y1, d.ln1_w, d.ln1_b, x2s, nullptr))) return rc;
         {
             GemmParams p = dense(x2s, 768, d.fc1_w, d.fc1_b, nullptr, hs, Ms, 3072, 768, 1);
             p.Upre = sv ? sv->L[l].u + r0 * 3072 : nullptr;
             if ((rc = run_gemm(c, p, 1, pick_tile(c, Ms, 3072, 768), s))) return rc;
         }
+        arm_ln(d.ln2_w, d.ln2_b, xs, lo);
         if ((rc = run_gemm(c, dense(hs, 3072, d.fc2_w, d.fc2_b, d_res.threshold ? nullptr : x2s, y2, Ms, 768, 3072, 0), 1,
-                           pick_tile(c, Ms, 768, 3072), s)))
+                           pick_tile(c, Ms, 768, 3072), s))) {
+            c->pending_ln = {};
             return rc;
+        }
         if (d_res.threshold && (rc = run_dropout(c, y2, x2s, y2, acts, d_res, site_ffn(l), s, idx0))) return rc;
-        return run_layernorm(c, y2, d.ln2_w, d.ln2_b, xs, lo, Ms, 768, s);
+        return ln_after(y2, d.ln2_w, d.ln2_b, xs, lo);
     };
     for (int l = 0; l < NOMAD_NUM_LAYERS; ++l) {
         unsigned all = 1u, any = 0u;

@@ -20,6 +20,36 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// One row of LayerNorm by one wave: lane l holds elements 4 (l + 64 i) .. + 3 of the row, i < VPT (N = 256 VPT).  layernorm_kernel below
+// and the split-K epilogue that normalises its own rows (splitk_epilogue_ln_kernel, train.hip.h) run exactly this code - one summation
+// order, so a row's result does not depend on which kernel normalised it.
+template <int VPT, typename TOut>
+__device__ __forceinline__ void ln_row_finish(const float4 (&v)[VPT], const float4 (&g)[VPT], const float4 (&bb)[VPT], TOut* __restrict__ o,
+                                              long long out_plane, float4* __restrict__ o2, int lane) {
+    constexpr int N = 256 * VPT;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    const float mean = wave_sum(s) * (1.0f / N);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+        q += (a * a + b * b) + (c * c + d * d);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / N) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        float4 r;
+        r.x = (v[i].x - mean) * rstd * g[i].x + bb[i].x;
+        r.y = (v[i].y - mean) * rstd * g[i].y + bb[i].y;
+        r.z = (v[i].z - mean) * rstd * g[i].z + bb[i].z;
+        r.w = (v[i].w - mean) * rstd * g[i].w + bb[i].w;
+        store4p<TOut>(o + 4 * (lane + 64 * i), out_plane, r);
+        if (o2) o2[lane + 64 * i] = r;
+    }
+}
+
 // out[m][:] = (in[m][:] - mean) * rstd * gamma + beta; optional second copy out2 (layer_results).
 // VPT float4 per lane: N = 256 * VPT (512 -> 2, 768 -> 3).  grid: ceil(M/4) blocks of 256 threads.
 template <int VPT, typename TIn = float, typename TOut = float>
@@ -32,36 +62,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TIn* __restrict__ 
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
     const TIn* row = in + (long long)m * N;
-    float4 v[VPT];
-    float s = 0.f;
+    float4 v[VPT], g[VPT], bb[VPT];
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
         v[i] = load4p<TIn>(row + 4 * (lane + 64 * i), in_plane);
-        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        g[i] = reinterpret_cast<const float4*>(gamma)[lane + 64 * i];
+        bb[i] = reinterpret_cast<const float4*>(beta)[lane + 64 * i];
     }
-    const float mean = wave_sum(s) * (1.0f / N);
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < VPT; ++i) {
-        const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
-        q += (a * a + b * b) + (c * c + d * d);
-    }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / N) + 1e-5f);
-    const float4* g4 = reinterpret_cast<const float4*>(gamma);
-    const float4* b4 = reinterpret_cast<const float4*>(beta);
-    TOut* o = out + (long long)m * N;
-    float4* o2 = out2 ? reinterpret_cast<float4*>(out2 + (long long)m * N) : nullptr;
-#pragma unroll
-    for (int i = 0; i < VPT; ++i) {
-        const float4 g = g4[lane + 64 * i], bb = b4[lane + 64 * i];
-        float4 r;
-        r.x = (v[i].x - mean) * rstd * g.x + bb.x;
-        r.y = (v[i].y - mean) * rstd * g.y + bb.y;
-        r.z = (v[i].z - mean) * rstd * g.z + bb.z;
-        r.w = (v[i].w - mean) * rstd * g.w + bb.w;
-        store4p<TOut>(o + 4 * (lane + 64 * i), out_plane, r);
-        if (o2) o2[lane + 64 * i] = r;
-    }
+    ln_row_finish<VPT, TOut>(v, g, bb, out + (long long)m * N, out_plane, out2 ? reinterpret_cast<float4*>(out2 + (long long)m * N) : nullptr, lane);
 }
 
 // ---- head: mean over time -> ReLU -> Linear(768, 256) -> L2 normalise (nomad.py:228-230) ---------------------------

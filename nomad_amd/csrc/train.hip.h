@@ -90,6 +90,44 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float4* __re
     C[i] = a;
 }
 
+// The same epilogue for the N = 768 residual GEMMs of a transformer layer (out_proj, fc2) TOGETHER with the LayerNorm that follows
+// them: y[m][:] = sum_s partial[s][m][:] + bias + R[m][:] (stored: the backward needs it), x[m][:] = LayerNorm(y[m][:]) (+ the copy x2
+// for layer_results).  One wave per row; every element's sum is the stand-alone epilogue's (slice order, then bias, then residual) and
+// the row code is the stand-alone LayerNorm's (ln_row_finish): the same bits as splitk_epilogue_kernel + layernorm_kernel<3>, one
+// launch and one pass over y less.  configs[3] runs 48 such pairs per step.  grid: ceil(M / 4) blocks of 256 threads.
+__global__ __launch_bounds__(256) void splitk_epilogue_ln_kernel(const float* __restrict__ partial, int S, int M, const float* __restrict__ bias,
+                                                                 const float* __restrict__ R, float* __restrict__ y,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 float* __restrict__ x, float* __restrict__ x2) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const long long row = (long long)m * 768, plane = (long long)M * 768;
+    float4 v[3], g[3], bb[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = 4 * (lane + 64 * i);
+        float4 a = *reinterpret_cast<const float4*>(partial + row + c);
+        for (int s = 1; s < S; ++s) {
+            const float4 b = *reinterpret_cast<const float4*>(partial + (long long)s * plane + row + c);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        if (bias) {
+            const float4 b = *reinterpret_cast<const float4*>(bias + c);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        if (R) {
+            const float4 r = *reinterpret_cast<const float4*>(R + row + c);
+            a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
+        }
+        *reinterpret_cast<float4*>(y + row + c) = a;
+        v[i] = a;
+        g[i] = reinterpret_cast<const float4*>(gamma)[lane + 64 * i];
+        bb[i] = reinterpret_cast<const float4*>(beta)[lane + 64 * i];
+    }
+    ln_row_finish<3, float>(v, g, bb, x + row, 0, x2 ? reinterpret_cast<float4*>(x2 + row) : nullptr, lane);
+}
+
 // Epilogue of the K-split grouped pos-conv GEMM (loss path, run_posconv_splitk): per row m and column c = 48 g + n
 //   v = sum_s partial[s][m][c] (+ bias[c]);  Upre[m][c] = v (training forward);  v = gelu(v) (forward);  C[m][c] = v + R(m, g, n)
 // R through its row map (the forward's residual is the padded per-group buffer: rmap + g * r_goff; the backward's a plain matrix).

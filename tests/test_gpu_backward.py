@@ -210,3 +210,26 @@ def test_graphed_loss_replays_bit_identically(built_lib, sd0):
     (2.0 * graphed(e, clean[1])).backward()
     assert torch.equal(e.grad, 2.0 * eager[1][1])
     nmd.engine.close()
+
+
+def test_splitk_epilogue_with_its_layernorm_is_bit_identical(built_lib, sd0, monkeypatch):
+    """configs[3]'s small-M residual GEMMs split K; their epilogue (slices + bias + residual) now also normalises the row
+    (splitk_epilogue_ln_kernel: the stand-alone epilogue's sums, the stand-alone LayerNorm's row code).  Against the two-launch form
+    (NOMAD_SPLITK_LN=0 on the diag library): the 12 layer outputs, the embedding and d loss / d waveform bit for bit."""
+    from nomad_amd.engine import Engine
+    gen = torch.Generator().manual_seed(5)
+    wav = (0.1 * torch.randn(8, 16384, generator=gen)).clamp(-1, 1).cuda()
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("NOMAD_SPLITK_LN", flag)
+        eng = Engine(sd0, 0, diag=True)
+        emb, layers, saved = eng.embed_train(wav)
+        dl = torch.ones_like(layers) / layers.numel()
+        de = torch.ones_like(emb) / emb.numel()
+        dwav = eng.embed_backward(wav, layers, saved, dl, de)
+        torch.cuda.synchronize()
+        outs.append((emb.clone(), layers.clone(), dwav.clone()))
+        eng.close()
+    assert torch.isfinite(outs[0][1]).all()
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
