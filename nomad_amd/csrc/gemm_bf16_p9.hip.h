@@ -83,8 +83,30 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int fr = lane & 15, fq = lane >> 4;
+    // SHORT tiles (round 6): p.p9_short = 1 makes the workgroup tile 192 x 256 - each wave row owns 96 rows (row tiles 0 .. 5 of its
+    // eight), the LDS image keeps its 128-row halves with the last 32 rows of each unused.  A RUN-TIME mode of the one instantiation,
+    // not a second kernel (two large kernels alternating between launches cost the launch after each switch 12-17 us of instruction
+    // cache, which is what ate the 256 x 192 tiles' gain in round 3): the phases keep their shape, phases 2 and 4 multiply two row
+    // tiles instead of four behind scalar branches.  Every wave still issues 8 LDS-DMA instructions per K tile and every hooked K tile
+    // 12 stores: the compiler's wait-count pass is not path-sensitive, and with the instruction count (or the counted wait) behind a
+    // branch it no longer sees that the K tile's counted vmcnt covers the bias load and drains the LDS-DMA queue (vmcnt(0)) in front
+    // of every bias use.  So the surplus is made harmless by DATA instead: the second instruction of an A half in waves 4 .. 7 (rows
+    // 96 .. 127 of the half, which nobody reads) fetches one 16-byte chunk for all lanes (one cache line instead of sixteen), the
+    // stores of row tiles 6, 7 go past the end of the output descriptor.
+    // For the N = 768 GEMMs of config C5 (out_proj, fc2): 188 x 3 = 564 tiles are 2.2 rounds of the 256 CUs, 250 x 3 = 750 are 2.93.
+    const bool sh = p.p9_short != 0;
+    const int bm_rows = sh ? 192 : 256, half_rows = sh ? 96 : 128;
+    const bool a_skip = sh && wave >= 4;
     unsigned long long ts_[6] = {0, 0, 0, 0, 0, 0};
-    if (ABL == 7) ts_[0] = wall_clock64();
+    if (ABL == 7) {
+        // probe (round 6): are the epilogue's memory bursts expensive because every CU issues them at the same time?  Start the four groups
+        // of workgroups p9_skew x 10 ns apart and compare the stamps of tile 1 (tools/p9_timeline.py --skew)
+        if (p.p9_skew > 0) {
+            const unsigned long long until = wall_clock64() + (unsigned long long)p.p9_skew * (((unsigned)blockIdx.x >> 3) & 3u);
+            while (wall_clock64() < until) __builtin_amdgcn_s_sleep(32);
+        }
+        ts_[0] = wall_clock64();
+    }
 
     // this workgroup's run of tiles: XCD x (blocks b with b % 8 == x share an XCD) owns a contiguous range of the n-fastest
     // tile walk, its workgroups take every wpx-th tile of it - tiles that are resident together share A row panels in L2
@@ -118,7 +140,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
     const char *a_base, *b_base0, *b_base1;
     auto setup = [&](int t) {
         const int tm = p.tn_magic ? fast_div(t, p.tn_magic, p.tn_shift) : t;
-        m0_ld = tm * Cfg::BM;
+        m0_ld = tm * bm_rows;
         n0_ld = (t - tm * p.tiles_n) * Cfg::BN;
         const long long row0 = row_addr_a(m0_ld < p.M ? m0_ld : p.M - 1);   // wave-uniform
 #pragma unroll
@@ -127,9 +149,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
             const int sw = (pc ^ ((row >> 1) & 7)) * 8;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                int m = m0_ld + h * 128 + row;
+                int m = m0_ld + h * half_rows + row;
                 m = m < p.M ? m : p.M - 1;
-                a_off[h][i] = (unsigned)((row_addr_a(m) - row0 + sw) * 2);
+                a_off[h][i] = (a_skip && i == 1) ? 0u : (unsigned)((row_addr_a(m) - row0 + sw) * 2);
             }
         }
         a_base = reinterpret_cast<const char*>(uniform_ptr(reinterpret_cast<const float*>(Ag + row0)));
@@ -211,7 +233,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
     __amdgpu_buffer_rsrc_t rc_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(p.C)), 0, 0, 0x00020000);
     auto clamp_bytes = [](long long v) { return (unsigned)(v < 0 ? 0 : (v > (1ll << 30) ? (1ll << 30) : v)); };
     auto out_rsrc = [&](int m0_, int n0_) {
-        const int mw = m0_ + wr * 128, nw = n0_ + wc * 64;
+        const int mw = m0_ + wr * half_rows, nw = n0_ + wc * 64;
         return __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(uniform_ptr(reinterpret_cast<const float*>(reinterpret_cast<bf16_t*>(p.C) + p.cmap.off + (long long)mw * p.cmap.ld + nw))), 0,
             clamp_bytes((long long)(p.M - mw) * p.cmap.ld * 2), 0x00020000);
@@ -238,7 +260,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
                     ov[4 * g + r] = (bf16_t)x;                                                                            \
                 }                                                                                                         \
             /* (row offset in the VGPR offset, never in the scalar offset: the store-data hazard of DESIGN.md 5) */       \
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), rc_p, c_voff + i * 16 * p.cmap.ld * 2, 0, 2); \
+            /* (short tiles: row tiles 6, 7 of a wave do not exist - their stores fall past the end of the descriptor) */ \
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), rc_p, c_voff + i * 16 * p.cmap.ld * 2 + ((i >= 6 && sh) ? 0x40000000 : 0), 0, 2); \
             acc[i][2 * (JH)] = (f32x4){0.f, 0.f, 0.f, 0.f};                                                               \
             acc[i][2 * (JH) + 1] = (f32x4){0.f, 0.f, 0.f, 0.f};                                                           \
         }                                                                                                                 \
@@ -252,10 +275,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
     }
 
     // transposed product: W fragment first -> a lane holds row fr (of A tile i) x W rows 4 fq + r (of LDS tile j)
-#define NOMAD_P9_MMA_KH(I0, J0, KH)                                                                        \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
+#define NOMAD_P9_MMA_ROWS(I0, J0, KH, IB, IE)                                                              \
+        _Pragma("unroll") for (int i = (IB); i < (IE); ++i)                                                \
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                  \
                 acc[(I0) + i][(J0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][KH], af[(I0) + i][KH], acc[(I0) + i][(J0) + j], 0, 0, 0);
+    // (short tiles: the second half of a wave's rows is two row tiles, not four - a scalar branch around the other two's MFMAs)
+#define NOMAD_P9_MMA_KH(I0, J0, KH)                                                                        \
+        NOMAD_P9_MMA_ROWS(I0, J0, KH, 0, 2)                                                                \
+        if ((I0) == 0 || !sh) NOMAD_P9_MMA_ROWS(I0, J0, KH, 2, 4)
     // MID (DMAP == 3 only): a half-tile of LDS-DMA issued between the cluster's two k-halves, in the shadow of its MFMAs
     // (1 / 2 = B half 0 / 1, 3 / 4 = A half 0 / 1 of K tile t + 2; PAR = the A buffer's parity)
 #define NOMAD_P9_SYNC_COMPUTE(I0, J0, MID, PAR)         \
@@ -298,9 +325,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
         if (HOOKS) NOMAD_P9_EPI_HOOK(0, 0)                                                                 \
         NOMAD_P9_SYNC_COMPUTE(0, 0, 1, PAR)                                                                     \
         /* phase 2: A rows 64..127 */                                                                      \
-        _Pragma("unroll") for (int i = 4; i < 8; ++i) {                                                    \
+        _Pragma("unroll") for (int i = 4; i < 6; ++i) {                                                    \
             af[i][0] = *reinterpret_cast<const bf16x8*>(la_ + i * 2048 + koff0);                           \
             af[i][1] = *reinterpret_cast<const bf16x8*>(la_ + i * 2048 + koff1);                           \
+        }                                                                                                  \
+        if (!sh) {                                                                                         \
+            _Pragma("unroll") for (int i = 6; i < 8; ++i) {                                                \
+                af[i][0] = *reinterpret_cast<const bf16x8*>(la_ + i * 2048 + koff0);                       \
+                af[i][1] = *reinterpret_cast<const bf16x8*>(la_ + i * 2048 + koff1);                       \
+            }                                                                                              \
         }                                                                                                  \
         if (DMAP == 0) NOMAD_P9_DMA_B(1)                                                                   \
         if (DMAP == 2) NOMAD_P9_DMA_B(0)                                                                   \
@@ -353,7 +386,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
             int lane_e = lane;
             asm volatile("" : "+v"(lane_e));
             const int fr_e = lane_e & 15, fq_e = lane_e >> 4;
-            const int mw = m0 + wr * 128, nw = n0 + wc * 64;
+            const int mw = m0 + wr * half_rows, nw = n0 + wc * 64;
             const bf16_t* Rb = reinterpret_cast<const bf16_t*>(p.R);
             const __amdgpu_buffer_rsrc_t rc = out_rsrc(m0, n0);
             const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
@@ -368,10 +401,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
                 u32x4 rres[8][2];
                 if (RES) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i)
+                    for (int i = 0; i < 8; ++i) {
+                        if (i >= 6 && sh) continue;   // short tiles: 6 row tiles per wave
 #pragma unroll
                         for (int jh = 0; jh < 2; ++jh)
                             rres[i][jh] = __builtin_amdgcn_raw_buffer_load_b128(rr, r_voff + i * 16 * p.rmap.ld * 2 + jh * 64, 0, 0);
+                    }
                     NOMAD_P9_WAIT_VM(0)   // (explicit: nothing is left pending for the compiler's pass to wait for at the K loop's header)
                 }
                 float bq[2][8];
@@ -381,7 +416,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
                     for (int e = 0; e < 8; ++e)
                         bq[jh][e] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((32 * jh + 8 * fq_e + e) * 4, __builtin_bit_cast(int, bias_lane)));
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
+                for (int i = 0; i < 8; ++i) {
+                    if (i >= 6 && sh) continue;
 #pragma unroll
                     for (int jh = 0; jh < 2; ++jh) {
                         float v[8];
@@ -407,6 +443,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
                         acc[i][2 * jh] = (f32x4){0.f, 0.f, 0.f, 0.f};
                         acc[i][2 * jh + 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
                     }
+                }
             };
             if (INTER) {   // (only residual GEMMs - and the no-store probe - come here: one copy)
                 if (has_r) epi(std::false_type{}, std::true_type{});
@@ -428,7 +465,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
         t_cur += wpx;
         {   // the next output tile's coordinates (the load cursor may already be one tile further on)
             const int tm = p.tn_magic ? fast_div(t_cur, p.tn_magic, p.tn_shift) : t_cur;
-            m0 = tm * Cfg::BM;
+            m0 = tm * bm_rows;
             n0 = (t_cur - tm * p.tiles_n) * Cfg::BN;
         }
     }
@@ -437,6 +474,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
 #undef NOMAD_P9_KTILE
 #undef NOMAD_P9_SYNC_COMPUTE
 #undef NOMAD_P9_MMA_KH
+#undef NOMAD_P9_MMA_ROWS
 #undef NOMAD_P9_EPI_HOOK
 #undef NOMAD_P9_EPI_QUAD
 #undef NOMAD_P9_DMA_A
@@ -456,7 +494,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
 // one workgroup per CU (160 KB of LDS), never more than there are tiles; the grid is a multiple of 8 (one share per XCD)
 template <int ABL = 0, bool INTER = true, int DMAP = 0>
 inline hipError_t launch_gemm_bf16_p9(GemmParams p, hipStream_t s, int num_cus) {
-    p.tiles_m = (p.M + P8Cfg::BM - 1) / P8Cfg::BM;
+    const int bm = p.p9_short ? 192 : P8Cfg::BM;   // (short tiles: DMAP == 0 instantiations only)
+    p.tiles_m = (p.M + bm - 1) / bm;
     p.tiles_n = p.N / 256;
     p.a_clip_magic = p.tn_magic = 0;
     p.a_clip_shift = p.tn_shift = 0;

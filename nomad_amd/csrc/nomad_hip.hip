@@ -342,6 +342,10 @@ struct Tuning {
     bool p9_share = false;         // NOMAD_BF16_P9_SHARE: persistent launches of concurrent batch parts share the CUs (1 / parts each)
     bool p9_tail_split = false;    // NOMAD_BF16_P9_TAIL: rows of a sparse last round of its tiles go to the 128 x 128 kernel (+4-17 % on the
                                    // N = 768 GEMMs alone, -3 % in the two-stream forward, where the other half's kernels fill that round)
+    int p9_short = 1;              // NOMAD_BF16_P9_SHORT: 192-row tiles of the persistent kernel (a run-time mode of the same instantiation) where they
+                                   // save more than they cost: 1 = by the round count, batches that run alone only (the N = 768 GEMMs of config C5 on one
+                                   // stream), 2 = every problem, 0 = never
+    int p9_skew = 0;               // NOMAD_BF16_P9_SKEW (diag, timeline probe tile 61 only): start skew between workgroup groups, units of 10 ns
     int concurrent_parts = 1;      // nomad_set_concurrent_parts: batches the host layer runs concurrently on separate streams
 };
 
@@ -383,6 +387,8 @@ static void tuning_from_env(Tuning& t) {
     t.p9_tail_split = getb("NOMAD_BF16_P9_TAIL", t.p9_tail_split);
     t.p9_share = getb("NOMAD_BF16_P9_SHARE", t.p9_share);
     t.p9_res = getb("NOMAD_BF16_P9_RES", t.p9_res);
+    t.p9_short = geti("NOMAD_BF16_P9_SHORT", t.p9_short);
+    t.p9_skew = geti("NOMAD_BF16_P9_SKEW", t.p9_skew);
 }
 #endif
 
@@ -1791,7 +1797,7 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
             tile = (p9_on() && p9_applies(p, groups) && (tu.p9_res || !p.R)) ? 60 : (p8_three_b() && p8_nt_stores() && p8_use_n192(c, p.M, p.N, p.K)) ? 55 : 16;  // deep-pipelined 256x256 / 256x192 kernel once there are >= 2 rounds of tiles (profiles/r01_gemm_sweep_bf16_8phase.json)
         else tile = (p.N % 256 == 0 && (p.N >= 1024 || p.M >= 100000)) ? 3 : 1;
     }
-    Scope sc(c, s, NOMAD_K_GEMM, flops, (tile == 1 || tile == 3 || tile == 16 || tile == 60 || tile == 61 || tile == 62 || tile == 63 || tile == 64 || tile == 65 || tile == 66 || tile == 67 || tile == 55 || tile == 56 || tile == 57 || tile == 58 || tile == 42 || tile == 43 || tile == 44 || tile == 45 || tile == 46 || tile == 47 || tile == 48 || tile == 49 || tile == 50 || tile == 51 || tile == 52 || tile == 53 || tile == 54 || tile == 20 || tile == 21 || tile == 27 || tile == 28 || tile == 32 || tile == 33) ? NOMAD_K_GEMM_BIG : (tile == 2 ? NOMAD_K_GEMM_FINE : -1));
+    Scope sc(c, s, NOMAD_K_GEMM, flops, (tile == 1 || tile == 3 || tile == 16 || tile == 60 || tile == 61 || tile == 62 || tile == 63 || tile == 64 || tile == 68 || tile == 65 || tile == 66 || tile == 67 || tile == 55 || tile == 56 || tile == 57 || tile == 58 || tile == 42 || tile == 43 || tile == 44 || tile == 45 || tile == 46 || tile == 47 || tile == 48 || tile == 49 || tile == 50 || tile == 51 || tile == 52 || tile == 53 || tile == 54 || tile == 20 || tile == 21 || tile == 27 || tile == 28 || tile == 32 || tile == 33) ? NOMAD_K_GEMM_BIG : (tile == 2 ? NOMAD_K_GEMM_FINE : -1));
     hipError_t e;
     switch (tile) {
         // the instantiations the bf16 / bf16x3 forwards select
@@ -1839,6 +1845,16 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
                     if (e == hipSuccess) e = launch_gemm_bf16<128, 128, 4, 2>(b, groups, s);
                     break;
                 }
+            }
+            // Short (192-row) tiles, round 6: a run-time mode of the same instantiation.  A 192 x 256 tile costs ~0.80 of a 256 x 256 one (three
+            // quarters of the MFMAs, 7 / 8 of the LDS-DMA bytes); it is taken where the largest tile count any CU gets, priced so, is smaller.
+            // Only for a batch that runs ALONE (concurrent_parts == 1): next to the other half of a two-stream batch the CUs never idle - the
+            // other half's workgroups take a CU the moment a workgroup leaves it - so what counts there is the total work, which short tiles
+            // raise (measured, gpurun_out/r6a: two streams 1888 -> 1877 clips/s with short tiles, one stream 1828-1845 -> 1876-1878).
+            if (tile == 60 && (tu.p9_short == 2 || (tu.p9_short == 1 && tu.concurrent_parts <= 1))) {
+                const long long tm_s = (p.M + 191) / 192;
+                const long long r_full = (tiles + grid - 1) / grid, r_short = (tm_s * tn + grid - 1) / grid;
+                p.p9_short = (tu.p9_short == 2 || 0.80 * (double)r_short < 0.95 * (double)r_full) ? 1 : 0;
             }
             e = launch_gemm_bf16_p9<0, true>(p, s, cus);
             break;
@@ -1939,10 +1955,16 @@ static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, 
             e = tile == 65 ? launch_gemm_bf16_p9<0, true, 1>(p, s, c->num_cus) : tile == 66 ? launch_gemm_bf16_p9<0, true, 2>(p, s, c->num_cus)
                                                                                       : launch_gemm_bf16_p9<0, true, 3>(p, s, c->num_cus);
             break;
+        case 68:  // persistent kernel, 192-row tiles forced (A/B against 64 = never short; 60 = the shipped choice)
+            if (!p9_applies(p, groups)) return fail(NOMAD_ERR_INVALID, "bf16 persistent gemm: plain C / R, one group, N %% 256, K %% 128, contiguous K");
+            p.p9_short = 1;
+            e = launch_gemm_bf16_p9<0, true>(p, s, c->num_cus);
+            break;
         case 61:  // persistent kernel: per-workgroup timeline probe / no output stores (timing) / every epilogue between tiles (A/B)
         case 62:
         case 63:
             if (!p9_applies(p, groups)) return fail(NOMAD_ERR_INVALID, "bf16 persistent gemm: plain C / R, one group, N %% 256, K %% 128, contiguous K");
+            if (tile == 61) p.p9_skew = tu.p9_skew;
             e = tile == 61 ? launch_gemm_bf16_p9<7, true>(p, s, c->num_cus) : tile == 62 ? launch_gemm_bf16_p9<1, true>(p, s, c->num_cus)
                                                                                       : launch_gemm_bf16_p9<0, false>(p, s, c->num_cus);
             break;
@@ -2999,7 +3021,7 @@ int nomad_diag_timeline(unsigned long long* out_host, int n) {
 int nomad_diag_gemm_bf16(nomad_ctx* c, const void* A, const void* W, const float* bias, const void* R, void* C, int M,
                          int N, int K, int gelu, int tile, nomad_stream_t stream) {
     static const int kBN[] = {128, 128, 64, 256, 64, 128, 128, 128, 128, 256, 256, 128, 128, 128, 128, 256, 256, 256, 256, 256};
-    const bool big256 = tile == 36 || (tile >= 42 && tile <= 54) || tile == 57 || tile == 58 || (tile >= 60 && tile <= 67);
+    const bool big256 = tile == 36 || (tile >= 42 && tile <= 54) || tile == 57 || tile == 58 || (tile >= 60 && tile <= 68);
     if (tile == 55 || tile == 56) {  // 256 x 192 tiles of the deep-pipelined kernel
         if (!c || !A || !W || !C || M <= 0) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: bad argument");
         if (N % 192 || K % 128) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm_bf16: N %% 192 or K %% 128 != 0");

@@ -43,6 +43,11 @@ EMB_DIM = 256
 
 def _resolve_device(device) -> int:
     if device is None:
+        # the reference falls back to the CPU here (nomad.py:40-43); this build has no CPU path, so a host without a GPU gets the
+        # same clear message an explicit device='cpu' gets, not a failure somewhere inside nomad_create
+        if not torch.cuda.is_available():
+            raise RuntimeError("NOMAD (MI355X build) runs on a HIP GPU only and no GPU is visible to PyTorch "
+                               "(device=None resolves to 'cuda'; there is no CPU path)")
         device = "cuda"
     dev = torch.device(device)
     if dev.type != "cuda":
@@ -131,7 +136,8 @@ def _stack_layers(layers) -> torch.Tensor:
 
 
 class _NomadLossFn(torch.autograd.Function):
-    """loss = NomadLoss(LossNetLayers(clean), LossNetLayers(estimate)); backward = d loss / d estimate."""
+    """loss = NomadLoss(LossNetLayers(clean), LossNetLayers(estimate)); backward = d loss / d estimate and, when ``clean`` requires a
+    gradient too, d loss / d clean - the reference's ``forward`` (nomad.py:142-146) is differentiable in both arguments."""
 
     @staticmethod
     def forward(ctx, estimate, clean, nomad):
@@ -140,41 +146,55 @@ class _NomadLossFn(torch.autograd.Function):
         est = estimate.detach().to(eng.device, torch.float32).contiguous()
         cln = clean.detach().to(eng.device, torch.float32).contiguous()
         need_grad = estimate.requires_grad
+        need_clean_grad = clean.requires_grad
         # the two forwards are independent: at training batch sizes (32 x 1 s) one of them fills less than half
         # of the chip, so the clean branch runs concurrently on a side stream with its own workspace
         cur = torch.cuda.current_stream(eng.device)
-        side = eng.side_stream()
-        side.wait_stream(cur)
         # precision="bf16x3": the branches that carry no gradient (always `clean`; `estimate` too under no_grad) run
         # the split-bf16 forward (layer outputs within ~1e-5 of fp32); the branch that is differentiated stays on fp32 BUFFERS
         # (embed_train), its GEMM products in whatever Engine.gemm_precision says - "bf16x3" when the Nomad was made with
         # precision="bf16x3", exact fp32 otherwise
         fwd = eng.embed_bf16x3 if _takes_bf16x3(nomad.precision, cln) else eng.embed
-        with torch.cuda.stream(side):
-            c_emb, c_layers = fwd(cln, head=head, want_layers=True, side=True)
+        saved_c = None
+        if need_clean_grad:
+            # the uncommon case (the speech-enhancement example differentiates `estimate` only, nomad_loss_test.py:69): the clean branch
+            # keeps its activations too, on the caller's stream - the training-mode forward has one workspace per context
+            c_emb, c_layers, saved_c = eng.embed_train(cln, head)
+        else:
+            side = eng.side_stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                c_emb, c_layers = fwd(cln, head=head, want_layers=True, side=True)
         if need_grad:
             e_emb, e_layers, saved = eng.embed_train(est, head)
         else:
             e_emb, e_layers = fwd(est, head=head, want_layers=True)
             saved = None
-        cur.wait_stream(side)
-        for t in (c_emb, c_layers, cln):
-            t.record_stream(cur)
+        if not need_clean_grad:
+            cur.wait_stream(side)
+            for t in (c_emb, c_layers, cln):
+                t.record_stream(cur)
         loss = eng.l1_loss(e_layers, c_layers, e_emb, c_emb)
-        if need_grad:
+        if need_grad or need_clean_grad:
             ctx.nomad = nomad
-            ctx.shape = estimate.shape
-            ctx.save_for_backward(est, e_layers, e_emb, c_layers, c_emb, saved)
+            ctx.shapes = (estimate.shape, clean.shape)
+            ctx.save_for_backward(est, e_layers, e_emb, cln, c_layers, c_emb, saved, saved_c)
         return loss
 
     @staticmethod
     def backward(ctx, grad_out):
-        est, e_layers, e_emb, c_layers, c_emb, saved = ctx.saved_tensors
+        est, e_layers, e_emb, cln, c_layers, c_emb, saved, saved_c = ctx.saved_tensors
         eng = ctx.nomad.engine
         head = (ctx.nomad.lossnet_layers.embedding_weight, ctx.nomad.lossnet_layers.embedding_bias)
-        dl, de = eng.l1_loss_backward(e_layers, c_layers, e_emb, c_emb, grad_out)
-        dwav = eng.embed_backward(est, e_layers, saved, dl, de, head)
-        return dwav.reshape(ctx.shape), None, None
+        dwav = dcln = None
+        if saved is not None and ctx.needs_input_grad[0]:
+            dl, de = eng.l1_loss_backward(e_layers, c_layers, e_emb, c_emb, grad_out)
+            dwav = eng.embed_backward(est, e_layers, saved, dl, de, head).reshape(ctx.shapes[0])
+        if saved_c is not None and ctx.needs_input_grad[1]:
+            # |e - c| is symmetric: the gradient with respect to the clean side is the same kernel with the arguments swapped
+            dl, de = eng.l1_loss_backward(c_layers, e_layers, c_emb, e_emb, grad_out)
+            dcln = eng.embed_backward(cln, c_layers, saved_c, dl, de, head).reshape(ctx.shapes[1])
+        return dwav, dcln, None
 
 
 class GraphedLoss:

@@ -72,6 +72,16 @@ def test_cpu_device_is_rejected():
         Nomad(device="cpu", weights="seeded")
 
 
+def test_default_device_without_a_gpu_is_rejected_like_cpu():
+    """Nomad(device=None): the reference falls back to the CPU (nomad.py:40-43); this build says there is no CPU path, at construction."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from nomad_amd.nomad import Nomad
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        Nomad(weights="seeded")
+
+
 def test_no_oracle_import_in_product():
     """The product must not route through the oracle."""
     for dirpath, _, files in os.walk(os.path.join(ROOT, "nomad_amd")):

@@ -182,6 +182,36 @@ def test_forward_is_differentiable_like_the_reference(built_lib, sd0):
     assert abs(nmd.forward(est.detach(), clean).item() - float(g["loss"])) < 1e-4
 
 
+def test_forward_gradient_with_respect_to_clean(built_lib, sd0):
+    """The reference's forward (nomad.py:142-146) is differentiable in BOTH arguments.  |e - c| is symmetric, so d forward(e, c) / d c must equal
+    d forward(c, e) / d (first argument) - the path the HF goldens above pin; with both inputs requiring a gradient, both come back."""
+    from nomad_amd.nomad import Nomad
+    g = np.load(os.path.join(GOLD, "hf_loss.npz"))
+    nmd = Nomad(weights=sd0)
+    nmd.lossnet_layers.embedding_weight = torch.from_numpy(g["emb_w"]).cuda()
+    nmd.lossnet_layers.embedding_bias = torch.from_numpy(g["emb_b"]).cuda()
+    est0, cln0 = torch.from_numpy(g["estimate"]).cuda(), torch.from_numpy(g["clean"]).cuda()
+    # reference: the clean waveform in the differentiated (first) slot
+    a = cln0.clone().requires_grad_(True)
+    nmd.forward(a, est0).backward()
+    ref_c = a.grad.clone()
+    e = est0.clone().requires_grad_(True)
+    nmd.forward(e, cln0).backward()
+    ref_e = e.grad.clone()
+    # clean only
+    c = cln0.clone().requires_grad_(True)
+    loss = nmd.forward(est0, c)
+    assert abs(loss.item() - float(g["loss"])) < 1e-4
+    loss.backward()
+    assert c.grad is not None and c.grad.shape == cln0.shape
+    assert _rel(c.grad, ref_c) < 3e-3, _rel(c.grad, ref_c)
+    assert F.cosine_similarity(c.grad.flatten(), ref_c.flatten(), dim=0).item() > 0.9999
+    # both
+    e2, c2 = est0.clone().requires_grad_(True), cln0.clone().requires_grad_(True)
+    nmd.forward(e2, c2).backward()
+    assert _rel(e2.grad, ref_e) < 3e-3 and _rel(c2.grad, ref_c) < 3e-3, (_rel(e2.grad, ref_e), _rel(c2.grad, ref_c))
+
+
 def test_graphed_loss_replays_bit_identically(built_lib, sd0):
     """Round 5 (config C4): nomad.forward + backward captured once as a HIP graph (Nomad.graphed_loss) and replayed on new inputs
     gives the bits of the eager call - same kernels in the same order; every entry point on the path is capture-safe (the split-K

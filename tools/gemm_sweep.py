@@ -56,6 +56,8 @@ SHAPES = {  # name: (M, N, K, bias, gelu, residual)
     "dw_out": (768, 768, 512, False, False, False),
     # config C5 (32 clips x 30 s, T = 1499): the encoder GEMMs and two conv layers
     "c5_out": (47968, 768, 768, True, False, True),
+    "c5_out_nores": (47968, 768, 768, True, False, False),            # what the residual epilogue (between tiles) costs against the interleaved one
+    "c5_fc2_nores": (47968, 768, 3072, True, False, False),
     "c5_qkv": (47968, 2304, 768, True, False, False),
     "c5_fc1": (47968, 3072, 768, True, True, False),
     "c5_fc2": (47968, 768, 3072, True, False, True),

@@ -42,6 +42,10 @@ def main():
                "epilogue_tile0_us": round(float((us[:, 3] - us[:, 2]).mean()), 2),
                "k_loop_tile1_us": round(float((us[two, 4] - us[two, 3]).mean()), 2) if two.any() else None,
                "per_k_tile_us_tile1": round(float((us[two, 4] - us[two, 3]).mean()) / (K // 64), 3) if two.any() else None,
+               "epilogue_tile0_us_median": round(float(np.median(us[:, 3] - us[:, 2])), 2),
+               "k_loop_tile1_us_median": round(float(np.median(us[two, 4] - us[two, 3])), 2) if two.any() else None,
+               "start_spread_us": round(float(us[:, 0].max()), 2),
+               "skew_x10ns": int(os.environ.get("NOMAD_BF16_P9_SKEW", "0")),
                "tiles_done_max": int(done.max())}
         print(json.dumps(res), flush=True)
 
