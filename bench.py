@@ -238,6 +238,42 @@ def time_c3(eng, world, rank, use_pg, fence, n_deg=10000, n_ref=1000, batch=256)
             "scaling": "strong", "finite": ok}
 
 
+def rank_census(world, rank, local_rank, use_pg, my_elapsed, steps, ref_rows_seen, ref_rows_local):
+    """What proves, from the ONE line rank 0 prints, that the collective really spanned `world` ranks on `world` different GPUs
+    (VERDICT r5 item 5): an all-reduce of ones, every rank's device (name, PCI bus, uuid where the runtime has one) and hostname,
+    the min / max over ranks of the timed loop, and the row count of the all-gathered reference embeddings against what the ranks
+    put in.  Runs after the timed region; gloo / CPU tensors work too (tests/test_dist_cpu.py calls it at world size 8)."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    cuda = torch.cuda.is_available() and (not use_pg or dist.get_backend() == "nccl")
+    dev = torch.device("cuda", local_rank) if cuda else torch.device("cpu")
+    me = {"rank": rank, "local_rank": local_rank, "host": socket.gethostname(), "pid": os.getpid()}
+    if cuda:
+        pr = torch.cuda.get_device_properties(local_rank)
+        me.update(device=pr.name, pci_bus_id=getattr(pr, "pci_bus_id", None), uuid=str(getattr(pr, "uuid", "")) or None,
+                  hbm_gb=round(pr.total_memory / 2 ** 30, 1))
+    ones = torch.ones(1, dtype=torch.float64, device=dev)
+    tmin = torch.tensor([my_elapsed], dtype=torch.float64, device=dev)
+    tmax = tmin.clone()
+    rows = torch.tensor([float(ref_rows_local)], dtype=torch.float64, device=dev)
+    everyone = [me]
+    if use_pg:
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rows, op=dist.ReduceOp.SUM)
+        everyone = [None] * world
+        dist.all_gather_object(everyone, me)
+    gpus = {(m["host"], m.get("pci_bus_id"), m.get("uuid"), m["local_rank"]) for m in everyone}
+    return {"ranks_seen": int(round(float(ones.item()))), "world_size": world,
+            "distinct_devices": len(gpus), "ranks": everyone,
+            "rank_ms_per_step": {"min": round(1e3 * float(tmin.item()) / steps, 3), "max": round(1e3 * float(tmax.item()) / steps, 3)},
+            "ref_rows_all_gathered": int(ref_rows_seen), "ref_rows_contributed_sum": int(round(float(rows.item()))),
+            "consistent": bool(int(round(float(ones.item()))) == world and len(gpus) == world
+                               and int(ref_rows_seen) == int(round(float(rows.item()))))}
+
+
 def time_c4(sd, device, steps=10, warmup=3, batch=32, samples=16384):
     """BASELINE.json configs[3]: nomad.forward() as an auxiliary loss (nomad_loss_test.py:60-79 shapes: 2 x (32,1,16384),
     T = 50) - per-step latency of the loss forward and of forward + backward to `estimate`, one GPU.  fp32 (the reference's
@@ -413,9 +449,10 @@ def main():
         eng.profile_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        mean, d, _ = step()
+        mean, d, ref_all_seen = step()
     fence()
     elapsed = time.perf_counter() - t0
+    my_elapsed = elapsed
     prof = eng.profile_read() if profile and not split_prof else None
     if profile and not split_prof:
         eng.profile_enable(False)
@@ -437,6 +474,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     assert torch.isfinite(mean).all()
+    census = rank_census(world, rank, local_rank, use_pg, my_elapsed, args.steps, ref_all_seen.shape[0], n_ref)
 
     # After the headline measurement (never part of `value`): the same workload through the bf16x3 precision mode,
     # timed the same way, and how far its scores are from the fp32 ones just computed.
@@ -633,6 +671,8 @@ def main():
                                       f"version {'.'.join(map(str, torch.cuda.nccl.version()))})" if use_pg
                                       else "none (single process, no process group)")},
         }
+        out["ranks_seen"] = census["ranks_seen"]
+        out["rank_census"] = census
         if flop_clip:
             out["model_tflops_per_gpu"] = round(value * flop_clip / world / 1e12, 2)
             out["model_frac_of_mfma_peak"] = round(value * flop_clip / world / peak, 4)

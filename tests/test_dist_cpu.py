@@ -106,6 +106,55 @@ def test_bench_c3_leg_sharded_over_four_ranks_equals_unsharded(tmp_path):
     assert out["scores"].shape == (n_deg,) and np.abs(out["scores"] - m.numpy()).max() < 1e-12
 
 
+def _c3_census_worker(rank, world, port, n_deg, n_ref, out_dir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(7)
+    deg = torch.randn(n_deg, 64, generator=g)
+    ref = torch.randn(n_ref, 64, generator=g)
+    (ds, de), (rs, re_) = partition(n_deg, world, rank), partition(n_ref, world, rank)
+    wav = torch.cat([deg[ds:de], ref[rs:re_]])
+    emb = lambda w: torch.nn.functional.normalize(torch.cat([w.double(), w.double() ** 2], 1)[:, :128].repeat(1, 2), dim=1).float()   # noqa: E731
+    pw = lambda a, b, m: _fake_pairwise(a, b, m)                                                                                       # noqa: E731
+    scores, ref_all, slab = bench.c3_sharded_scores(emb, pw, wav, de - ds, 256, True)
+    census = bench.rank_census(world, rank, rank, True, 0.001 * (rank + 1), 1, ref_all.shape[0], re_ - rs)
+    assert slab.shape == (de - ds, n_ref)
+    if rank == 0:
+        import json
+        np.savez(os.path.join(out_dir, "c3w8.npz"), scores=scores.numpy(), ref=ref_all.numpy())
+        json.dump(census, open(os.path.join(out_dir, "census.json"), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_c3_leg_world_8_uneven_shards_and_rank_census(tmp_path):
+    """configs[2]'s sharded leg at the world size the driver's 8-GPU run uses, with shards that do not divide
+    (10 001 x 1 003: 1251 / 1250 degraded, 126 / 125 references per rank), and the census bench.py prints so that its line is
+    self-verifying: ranks_seen from an all-reduce, the all-gathered reference rows against the sum of what the ranks put in,
+    min / max of the per-rank timed loops."""
+    n_deg, n_ref, world = 10001, 1003, 8
+    mp.spawn(_c3_census_worker, args=(world, _free_port(), n_deg, n_ref, str(tmp_path)), nprocs=world, join=True)
+    out = np.load(os.path.join(tmp_path, "c3w8.npz"))
+    import json
+    census = json.load(open(os.path.join(tmp_path, "census.json")))
+    g = torch.Generator().manual_seed(7)
+    deg = torch.randn(n_deg, 64, generator=g)
+    ref = torch.randn(n_ref, 64, generator=g)
+    emb = lambda w: torch.nn.functional.normalize(torch.cat([w.double(), w.double() ** 2], 1)[:, :128].repeat(1, 2), dim=1).float()   # noqa: E731
+    _, m = _fake_pairwise(emb(deg), emb(ref), True)
+    assert np.array_equal(out["ref"], emb(ref).numpy())
+    assert out["scores"].shape == (n_deg,) and np.abs(out["scores"] - m.numpy()).max() < 1e-12
+    assert census["ranks_seen"] == 8 and census["world_size"] == 8 and len(census["ranks"]) == 8
+    assert sorted(r["rank"] for r in census["ranks"]) == list(range(8))
+    assert census["ref_rows_all_gathered"] == n_ref == census["ref_rows_contributed_sum"]
+    assert census["rank_ms_per_step"] == {"min": 1.0, "max": 8.0}
+    assert census["distinct_devices"] == 8 and census["consistent"]
+
+
 # ---- data-parallel fine-tuning: gradient averaging across ranks (gloo, world_size 2) ------------------------------
 def _ddp_worker(rank, world, port, out):
     import os

@@ -48,6 +48,11 @@ def test_bench_under_the_distributed_launcher():
     assert out["n_gpus"] == 1 and out["steps"] == 1 and "also_measured" not in out
     # under the launcher the RCCL process group exists at world size 1 too and the all-gather is really issued
     assert out["config"]["collective"].startswith("RCCL all_gather_into_tensor executed")
+    # the line verifies itself: ranks counted by an all-reduce, one distinct device per rank, the all-gathered reference rows
+    c = out["rank_census"]
+    assert out["ranks_seen"] == 1 == c["ranks_seen"] == c["distinct_devices"] and c["consistent"]
+    assert c["ref_rows_all_gathered"] == 2 == c["ref_rows_contributed_sum"] and c["ranks"][0]["device"]
+    assert c["rank_ms_per_step"]["min"] <= c["rank_ms_per_step"]["max"]
 
 
 def test_bench_spawns_its_own_ranks():
@@ -55,6 +60,7 @@ def test_bench_spawns_its_own_ranks():
     and relays rank 0's line - exercised here with one rank (--spawn), and N = 2 on this one-GPU box must fail cleanly."""
     out = _run(["--gpus", "1", "--spawn", "--steps", "1", "--warmup", "1", "--batch", "8", "--refs", "2", "--no-cpu-baseline", "--no-also"])
     assert out["n_gpus"] == 1 and out["config"]["collective"].startswith("RCCL all_gather_into_tensor executed")
+    assert out["ranks_seen"] == 1 and out["rank_census"]["consistent"]
     import torch
     if torch.cuda.device_count() < 2:
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
