@@ -36,6 +36,7 @@ SIGNATURES = {
     "nomad_destroy": (None, [C.c_void_p]),
     "nomad_last_error": (C.c_char_p, []),
     "nomad_version": (C.c_char_p, []),
+    "nomad_abi_version": (C.c_int, []),
     "nomad_build_flags": (C.c_int, []),
     "nomad_set_concurrent_parts": (C.c_int, [C.c_void_p, C.c_int]),
     "nomad_num_frames": (C.c_int, [C.c_int]),
@@ -114,6 +115,9 @@ DIAG_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libnom
 _libs = {}
 
 
+ABI_VERSION = 3   # == NOMAD_ABI_VERSION in include/nomad_hip.h (tests/test_abi.py compares the two)
+
+
 def load(diag=None):
     """Load an in-tree shared library; raises if it has not been built (no fallback exists).
 
@@ -136,6 +140,11 @@ def load(diag=None):
         fn = getattr(lib, name)  # AttributeError if the export is missing
         fn.restype = res
         fn.argtypes = args
+    # the binding above was written against ONE layout of the entry points (include/nomad_hip.h: NOMAD_ABI_VERSION): refuse a
+    # library built from another one before any call that takes arguments
+    if lib.nomad_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{path} reports ABI {lib.nomad_abi_version()}, this binding is written against {ABI_VERSION}: rebuild it "
+                           "(`python -m nomad_amd.build`)")
     _libs[diag] = lib
     return lib
 

@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 namespace nomad {
 
 // per-workgroup timeline of the GEMM timing probes (gemm_bf16_8phase.hip.h ABL 7, gemm_f32.hip.h OPT bit 128; nomad_diag_timeline)
@@ -112,17 +114,20 @@ __global__ __launch_bounds__(256) void scale_head_kernel(const float* __restrict
 }
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to ONE device: a flag per (kernel instantiation, device), so that a process
-// that drives several GPUs (one engine each) configures every kernel on each of them.  (Racing host threads at worst set it twice.)
+// that drives several GPUs (one engine each) configures every kernel on each of them.  Racing host threads at worst set the attribute
+// twice (the same value); the flags are relaxed atomics so that this is not a data race in the language's sense either.  These
+// flags, the last-error text and the diagnostic library's timeline buffer are the only process-wide state; none affects a result.
+// (hipGetDevice is a thread-local read of the runtime, ~20 ns per launch.)
 struct LdsAttrOnce {
     static constexpr int kMaxDev = 64;
-    bool done[kMaxDev] = {};
+    std::atomic<bool> done[kMaxDev] = {};
     hipError_t ensure(const void* kern, int bytes) {
         int dev = 0;
         hipError_t e = hipGetDevice(&dev);
         if (e != hipSuccess) return e;
-        if (dev >= 0 && dev < kMaxDev && done[dev]) return hipSuccess;
+        if (dev >= 0 && dev < kMaxDev && done[dev].load(std::memory_order_relaxed)) return hipSuccess;
         e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        if (e == hipSuccess && dev >= 0 && dev < kMaxDev) done[dev] = true;
+        if (e == hipSuccess && dev >= 0 && dev < kMaxDev) done[dev].store(true, std::memory_order_relaxed);
         return e;
     }
 };

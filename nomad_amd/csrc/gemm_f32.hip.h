@@ -166,12 +166,18 @@ __device__ __forceinline__ float gelu_erf(float x) {
 // (2 transcendental) instead of 13: the epilogues are bound by vector-instruction issue (4 cycles per instruction, 8 per
 // transcendental), so this is 44 instead of 60 issue cycles per activation.  Every bf16 GEMM kernel uses THIS function (their results
 // stay bit-identical to each other); conv0 and every fp32 / bf16x3 epilogue keep gelu_erf.
+extern "C" __device__ float nomad_fmul_legacy(float, float) __asm("llvm.amdgcn.fmul.legacy");   // this clang has no __builtin_amdgcn_fmul_legacy
 __device__ __forceinline__ float gelu_bf16out(float x) {
     const float x2 = fminf(x * x, 50.0f);
     float p = fmaf(x2, 1.0153758e-3f, -1.0678258e-1f);     // -log2(e) * (c2 x^2 + c1)
     p = fmaf(p, x2, -2.3011138f);                            // -log2(e) * c0
     const float e = __builtin_amdgcn_exp2f(p * x);           // 2^(-g(x) log2 e) = exp(-g(x))
-    return x * __builtin_amdgcn_rcpf(1.0f + e);
+    // v_mul_legacy_f32 (0 x anything = 0): the same product as v_mul_f32 for every finite x; for x = -inf (an overflowed activation)
+    // the sigmoid is exactly 0 and the IEEE product -inf x 0 would be NaN where the erf form gives -0.  Same instruction count.
+    // (through the LLVM intrinsic, not inline asm: gfx950 needs a wait state between a transcendental instruction and the first read of
+    // its result - the compiler places it, or schedules another element's work there, for instructions it knows; an asm v_mul_legacy_f32
+    // straight behind v_rcp_f32 read the register one cycle early: 0.24 of error in tests/test_gpu_abi_errors.py, round 6)
+    return nomad_fmul_legacy(x, __builtin_amdgcn_rcpf(1.0f + e));
 }
 
 // XCD-aware bijective remap of a 1-D grid: blocks b and b+8 share an XCD (round-robin dispatch),

@@ -152,7 +152,9 @@ Layout make_layout(const Shapes& s, bool keep) {
     l.h = take(act * 4);
     // partial products of the split-K GEMMs of a small layer-output forward (forward_impl): part of the CALL's workspace, so that
     // whether such a forward splits depends on its shape alone - not on which streams other calls are running on
-    l.splitk = s.M < kSplitKLayersMaxM ? take(kSplitKPartFloats * sizeof(float)) : 0;
+    // Sized from the shape: S x M x N floats for the largest problem splitk_applies / posconv_splitk_applies let through at this M
+    // (S x N <= 6144: fc1 2 x 3072, qkv 2 x 2304, fc2 / pos-conv 4 x 768), never more than the fixed cap those checks use.
+    l.splitk = s.M < kSplitKLayersMaxM ? take(std::min(kSplitKPartFloats, (size_t)6144 * (size_t)s.M) * sizeof(float)) : 0;
     l.total = off;
     return l;
 }
@@ -583,7 +585,7 @@ static bool splitk_applies(const nomad_ctx* c, const GemmParams& p, int groups, 
     const long long tiles = (long long)((p.M + 63) / 64) * (p.N / 64);
     if (tiles >= 512 || p.K < 768) return false;
     *S = p.K >= 2304 ? 4 : 2;
-    return p.K % (*S * 32) == 0 && (size_t)*S * p.M * p.N <= kSplitKPartFloats;
+    return p.K % (*S * 32) == 0 && (size_t)*S * p.N <= 6144 && (size_t)*S * p.M * p.N <= kSplitKPartFloats;   // (make_layout sizes the block by these two)
 }
 
 static int run_gemm_splitk(nomad_ctx* c, const GemmParams& p, int S, hipStream_t s) {
@@ -1015,11 +1017,12 @@ extern "C" {
 const char* nomad_last_error(void) { return g_err; }
 const char* nomad_version(void) {
 #ifdef NOMAD_DIAG
-    return "nomad_hip 0.2 (gfx950) + experimental kernel instantiations (libnomad_diag.so)";
+    return "nomad_hip 0.3 (gfx950) + experimental kernel instantiations (libnomad_diag.so)";
 #else
-    return "nomad_hip 0.2 (gfx950)";
+    return "nomad_hip 0.3 (gfx950)";
 #endif
 }
+int nomad_abi_version(void) { return NOMAD_ABI_VERSION; }
 
 int nomad_wav_probe(const char* const* paths, int n, nomad_wav_info* info, int* status, int threads) {
     if (n < 0 || (n > 0 && (!paths || !info || !status))) return fail(NOMAD_ERR_INVALID, "nomad_wav_probe: null argument");

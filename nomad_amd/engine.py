@@ -92,6 +92,7 @@ class Engine:
         # forwards concurrently: v_pk_fma_f32 can lose a product next to the other forward's bf16 128 x 128 GEMM (DESIGN.md
         # "The packed-FP32 hazard").  The shipped build reports 0 here; with the bit set every two-stream batch split is off.
         self.build_flags = int(self.lib.nomad_build_flags())
+        self.stochastic = self.stochastic_branches = False   # train_set_stochastic / train_set_branches: dropout or LayerDrop is on
         if self.build_flags & 1:
             import warnings
             warnings.warn("nomad_amd: this library was built with packed-FP32 instructions; the two-stream batch splits are switched "
@@ -667,10 +668,13 @@ class Engine:
         _lib.check(self.lib.nomad_train_set_stochastic(self.ctx, float(dropout), float(attention_dropout),
                                                        float(dropout_input), int(seed) & (2 ** 64 - 1),
                                                        int(layer_mask) & 0xFFF), "nomad_train_set_stochastic")
+        # (what GraphedLoss asks: a captured graph freezes the dropout masks and the step counter of its capture)
+        self.stochastic = bool(dropout > 0 or attention_dropout > 0 or dropout_input > 0 or (int(layer_mask) & 0xFFF) != 0xFFF)
 
     def train_set_branches(self, layer_masks=None):
         """The following training batches are len(layer_masks) equal groups of clips, each with its own LayerDrop
         mask (None: back to one group using train_set_stochastic's layer_mask)."""
+        self.stochastic_branches = bool(layer_masks) and any((int(m) & 0xFFF) != 0xFFF for m in layer_masks)
         if not layer_masks:
             _lib.check(self.lib.nomad_train_set_branches(self.ctx, 1, None), "nomad_train_set_branches")
             return

@@ -207,10 +207,30 @@ class GraphedLoss:
     same bits (``tests/test_gpu_backward.py::test_graphed_loss_replays_bit_identically``).
 
     ``loss = graphed(estimate, clean)`` is differentiable with respect to ``estimate`` like ``nomad.forward``: the replay computes the
-    loss AND d loss / d estimate; the autograd node hands the stored gradient (times the incoming one) on."""
+    loss AND d loss / d estimate; the autograd node hands the stored gradient (times the incoming one) on.
+
+    Restrictions (checked): a captured graph holds its kernel arguments BY VALUE - the dropout / LayerDrop masks, the step counter and
+    the addresses of ``lossnet_layers.embedding_weight`` / ``embedding_bias`` of the moment of capture.  So capture is refused while the
+    engine has dropout or LayerDrop switched on (``Engine.train_set_stochastic`` / ``train_set_branches``: every replay would reuse one
+    set of masks), and ``step`` raises when the head tensors have been replaced since (the graph would read freed memory) or
+    stochastic mode has been switched on; "same bits as eager" is a statement about the frozen, eval-mode loss path only."""
+
+    def _state(self):
+        ll = self.nomad.lossnet_layers
+        return (ll.embedding_weight.data_ptr(), ll.embedding_bias.data_ptr())
+
+    def _check_not_stochastic(self, what: str):
+        eng = self.nomad.engine
+        if getattr(eng, "stochastic", False) or getattr(eng, "stochastic_branches", False):
+            raise RuntimeError(f"GraphedLoss: {what} while the engine has dropout / LayerDrop switched on - a HIP graph replays the masks "
+                               "and the step counter of its capture; use nomad.forward() for stochastic passes")
 
     def __init__(self, nomad: "Nomad", estimate: torch.Tensor, clean: torch.Tensor, warmup: int = 3):
         self.nomad = nomad
+        self._check_not_stochastic("capture")
+        # the graph reads the head through these addresses: keep the tensors alive and notice a replacement
+        self._head = (nomad.lossnet_layers.embedding_weight, nomad.lossnet_layers.embedding_bias)
+        self._head_ptrs = self._state()
         dev = nomad.engine.device
         self._est = estimate.detach().to(dev, torch.float32).clone().requires_grad_(True)
         self._cln = clean.detach().to(dev, torch.float32).clone()
@@ -233,6 +253,10 @@ class GraphedLoss:
         """-> (loss, d loss / d estimate): views of the graph's static outputs, valid until the next step."""
         if estimate.shape != self._est.shape or clean.shape != self._cln.shape:
             raise ValueError(f"GraphedLoss was captured for {tuple(self._est.shape)} / {tuple(self._cln.shape)}")
+        self._check_not_stochastic("replay")
+        if self._state() != self._head_ptrs:
+            raise RuntimeError("GraphedLoss: lossnet_layers.embedding_weight / embedding_bias were replaced after capture (the graph holds "
+                               "their old addresses); update them in place (copy_) or capture a new graph with nomad.graphed_loss()")
         with torch.no_grad():
             self._est.copy_(estimate)
             self._cln.copy_(clean)

@@ -29,7 +29,10 @@ def test_shape_helpers(built_lib):
     from nomad_amd import _lib
     from nomad_amd.weights import num_frames
     lib = _lib.load()
-    assert lib.nomad_version().startswith(b"nomad_hip")
+    assert lib.nomad_version().startswith(b"nomad_hip 0.3")
+    # binding, header and library agree on the binary-interface number (bumped when nomad_set_concurrent_parts gained its context argument)
+    hdr = open(os.path.join(ROOT, "include", "nomad_hip.h")).read()
+    assert int(re.search(r"#define NOMAD_ABI_VERSION (\d+)", hdr).group(1)) == _lib.ABI_VERSION == lib.nomad_abi_version() == 3
     for n in (9, 400, 16384, 27225, 64000, 223840, 480000):
         assert lib.nomad_num_frames(n) == max(num_frames(n), 0)
     assert lib.nomad_l1_scratch_bytes() > 0

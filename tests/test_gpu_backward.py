@@ -239,6 +239,24 @@ def test_graphed_loss_replays_bit_identically(built_lib, sd0):
     e = est[1].clone().requires_grad_(True)
     (2.0 * graphed(e, clean[1])).backward()
     assert torch.equal(e.grad, 2.0 * eager[1][1])
+    # the restrictions of a captured graph are checked, not just documented: a replaced head tensor (the graph holds the
+    # old address) and dropout / LayerDrop (the graph would replay one set of masks) are refused
+    keep = nmd.lossnet_layers.embedding_weight
+    nmd.lossnet_layers.embedding_weight = keep.clone()
+    with pytest.raises(RuntimeError, match="replaced after capture"):
+        graphed.step(est[0], clean[0])
+    nmd.lossnet_layers.embedding_weight = keep
+    graphed.step(est[0], clean[0])
+    nmd.engine.enable_backward()
+    nmd.engine.train_set_stochastic(dropout=0.1, seed=3)
+    with pytest.raises(RuntimeError, match="dropout / LayerDrop"):
+        graphed.step(est[0], clean[0])
+    with pytest.raises(RuntimeError, match="dropout / LayerDrop"):
+        nmd.graphed_loss(est[0], clean[0])
+    nmd.engine.train_set_stochastic()
+    loss, grad = graphed.step(est[0], clean[0])
+    torch.cuda.synchronize()
+    assert torch.equal(loss, eager[0][0]) and torch.equal(grad, eager[0][1])
     nmd.engine.close()
 
 

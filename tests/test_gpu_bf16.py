@@ -92,6 +92,26 @@ def test_gemm_bf16_persistent_kernel_is_bit_identical(engine_for, M, N, K, epi):
             assert torch.equal(out, ref), (t, rep)
 
 
+def test_bf16_gelu_of_an_overflowed_activation_is_zero_not_nan(engine_for):
+    """x * sigmoid(g(x)) evaluated the IEEE way is -inf * 0 = NaN at x = -inf, where the erf GELU gives -0; the bf16
+    epilogues' GELU multiplies with v_mul_legacy_f32 (0 * anything = 0).  +inf stays +inf, NaN stays NaN, finite values unchanged."""
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 512, 256, 128
+    A = torch.randn(M, K, generator=g).bfloat16().cuda()
+    W = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16().cuda()
+    bias = torch.randn(N, generator=g)
+    bias[3], bias[77], bias[130] = float("-inf"), float("inf"), float("nan")
+    bias = bias.cuda()
+    eng = engine_for("bf16", 63)
+    ref = torch.nn.functional.gelu(A.float() @ W.float().t() + bias)
+    for t in (1, 60):
+        out = eng.diag_gemm_bf16(A, W, bias, None, gelu=True, tile=t).float()
+        assert (out[:, 3] == 0).all() and torch.isinf(out[:, 77]).all() and (out[:, 77] > 0).all() and torch.isnan(out[:, 130]).all()
+        ok = torch.ones(N, dtype=torch.bool)
+        ok[[3, 77, 130]] = False
+        assert (out[:, ok.cuda()] - ref[:, ok.cuda()]).abs().max() < 0.02
+
+
 LOG2E = 1.4426950408889634
 
 
