@@ -20,6 +20,7 @@
 
 #include "attention.hip.h"
 #include "dropout.hip.h"
+#include "dtypes.hip.h"
 
 namespace nomad {
 
@@ -260,12 +261,184 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
     }
 }
 
+// ---- T <= 64: the three kernels above as ONE launch (round 6) --------------------------------------------------------------------
+// configs[3] (nomad.forward() on 1 s clips, T = 50) ran rowdot + dkv + dq as 36 launches of 5-15 us per step, each a single workgroup
+// per (clip, head) that re-reads the same four 64 x 64 tiles.  Here one workgroup per (clip, head) stages Q, K, V, dO once, takes
+// D = rowdot(dO, O) into LDS, then runs the dkv body (wave = 16 keys) and the dq body (wave = 16 queries) on the staged tiles.  Every
+// product, sum and exponential is the one the three-kernel path computes, in the same order: bit-identical results
+// (tests/test_gpu_backward.py::test_attention_backward); the choice depends on T alone, so a clip's bits do not depend on its batch.
+// No attention dropout here (the fine-tuning path with dropout keeps the three kernels).  D is still written: the caller's scratch.
+constexpr int kAttnBwdSmallLds = (4 * 64 * kAttnLD + 128) * 4;
+__global__ __launch_bounds__(256) void attn_bwd_small_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
+                                                             const float* __restrict__ dO, const float* __restrict__ lse,
+                                                             float* __restrict__ D, float* __restrict__ dqkv, int T) {
+    extern __shared__ __attribute__((aligned(16))) float abw_smem[];   // kAttnBwdSmallLds bytes (four 64 x 68 tiles: over the 64 KB static limit)
+    float* const Qs = abw_smem;
+    float* const Gs = Qs + 64 * kAttnLD;  // dO
+    float* const Ks = Gs + 64 * kAttnLD;
+    float* const Vs = Ks + 64 * kAttnLD;
+    float* const lse_s = Vs + 64 * kAttnLD;
+    float* const D_s = lse_s + 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fi = lane & 15, g = lane >> 4;
+    const int bh = blockIdx.x, b = bh / 12, h = bh - b * 12;
+    const float* qb = qkv + (long long)b * T * 2304 + h * 64;
+    const float* gb = dO + (long long)b * T * 768 + h * 64;
+    const float* ob = o + (long long)b * T * 768 + h * 64;
+    {
+        f32x4 r0[4], r1[4], r2[4], r3[4];
+        abw_fetch(r0, qb, 2304, 0, T, tid);
+        abw_fetch(r1, gb, 768, 0, T, tid);
+        abw_fetch(r2, qb + 768, 2304, 0, T, tid);
+        abw_fetch(r3, qb + 1536, 2304, 0, T, tid);
+        // D[q] = sum_d dO[q][d] O[q][d]: 16 lanes per row, lane j holds d = 4 j .. 4 j + 3, then the xor tree - attn_bwd_rowdot_kernel's order
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int q = pass * 16 + (tid >> 4), j = tid & 15;
+            const int qr = q < T ? q : T - 1;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(ob + (long long)qr * 768 + 4 * j);
+            const f32x4 gg = *reinterpret_cast<const f32x4*>(gb + (long long)qr * 768 + 4 * j);
+            float sdot = (a[0] * gg[0] + a[1] * gg[1]) + (a[2] * gg[2] + a[3] * gg[3]);
+            sdot += __shfl_xor(sdot, 1);
+            sdot += __shfl_xor(sdot, 2);
+            sdot += __shfl_xor(sdot, 4);
+            sdot += __shfl_xor(sdot, 8);
+            if (j == 0) {
+                D_s[q] = q < T ? sdot : 0.f;
+                if (q < T) D[(long long)bh * T + q] = sdot;
+            }
+        }
+        if (tid < 64) lse_s[tid] = tid < T ? lse[(long long)bh * T + tid] : 0.f;
+        abw_store(Qs, r0, tid);
+        abw_store(Gs, r1, tid);
+        abw_store(Ks, r2, tid);
+        abw_store(Vs, r3, tid);
+    }
+    __syncthreads();
+    if (wave * 16 >= T) return;   // (wave-uniform; no barrier below)
+    const int nsub = min(4, (T + 15) / 16);
+    // ---- dK, dV: this wave's 16 keys -------------------------------------------------------------------------------------------
+    {
+        const int key = wave * 16 + fi;
+        const int key_ld = key < T ? key : T - 1;
+        f32x4 kf[4], vf[4];
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) {
+            kf[dd] = *reinterpret_cast<const f32x4*>(Ks + key_ld * kAttnLD + dd * 16 + g * 4);
+            vf[dd] = *reinterpret_cast<const f32x4*>(Vs + key_ld * kAttnLD + dd * 16 + g * 4);
+        }
+        f32x4 dk[4], dv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dk[i] = dv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int sub = 0; sub < nsub; ++sub) {
+            f32x4 sacc = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) {
+                const f32x4 qa = *reinterpret_cast<const f32x4*>(Qs + (sub * 16 + fi) * kAttnLD + dd * 16 + g * 4);
+                const f32x4 ga = *reinterpret_cast<const f32x4*>(Gs + (sub * 16 + fi) * kAttnLD + dd * 16 + g * 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[c], kf[dd][c], sacc, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[c], vf[dd][c], dp, 0, 0, 0);
+                }
+            }
+            const f32x4 lv = *reinterpret_cast<const f32x4*>(lse_s + sub * 16 + g * 4);
+            const f32x4 Dv = *reinterpret_cast<const f32x4*>(D_s + sub * 16 + g * 4);
+            f32x4 pm, ds;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = sub * 16 + g * 4 + r;
+                const bool ok = q < T && key < T;
+                const float pr = ok ? fast_exp(sacc[r] - lv[r]) : 0.f;
+                pm[r] = pr * 1.0f;
+                ds[r] = pr * (dp[r] * 1.0f - Dv[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float* grow = Gs + (sub * 16 + g * 4 + r) * kAttnLD + fi;
+                const float* qrow = Qs + (sub * 16 + g * 4 + r) * kAttnLD + fi;
+#pragma unroll
+                for (int di = 0; di < 4; ++di) {
+                    dv[di] = __builtin_amdgcn_mfma_f32_16x16x4f32(pm[r], grow[di * 16], dv[di], 0, 0, 0);
+                    dk[di] = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[r], qrow[di * 16], dk[di], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int kk = wave * 16 + g * 4 + r;
+            if (kk < T) {
+                float* dst = dqkv + ((long long)b * T + kk) * 2304 + h * 64 + fi;
+#pragma unroll
+                for (int di = 0; di < 4; ++di) {
+                    dst[768 + di * 16] = dk[di][r];
+                    dst[1536 + di * 16] = dv[di][r];
+                }
+            }
+        }
+    }
+    // ---- dQ: this wave's 16 queries --------------------------------------------------------------------------------------------
+    {
+        const int q = wave * 16 + fi;
+        const int q_ld = q < T ? q : T - 1;
+        f32x4 qf[4], gf[4];
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) {
+            qf[dd] = *reinterpret_cast<const f32x4*>(Qs + q_ld * kAttnLD + dd * 16 + g * 4);
+            gf[dd] = *reinterpret_cast<const f32x4*>(Gs + q_ld * kAttnLD + dd * 16 + g * 4);
+        }
+        const float lse_q = lse_s[q_ld], D_q = D_s[q_ld];
+        f32x4 dq[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int sub = 0; sub < nsub; ++sub) {
+            f32x4 sacc = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) {
+                const f32x4 ka = *reinterpret_cast<const f32x4*>(Ks + (sub * 16 + fi) * kAttnLD + dd * 16 + g * 4);
+                const f32x4 va = *reinterpret_cast<const f32x4*>(Vs + (sub * 16 + fi) * kAttnLD + dd * 16 + g * 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[c], qf[dd][c], sacc, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x4f32(va[c], gf[dd][c], dp, 0, 0, 0);
+                }
+            }
+            f32x4 ds;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = sub * 16 + g * 4 + r;
+                const bool ok = q < T && key < T;
+                const float pr = ok ? fast_exp(sacc[r] - lse_q) : 0.f;
+                ds[r] = pr * (dp[r] * 1.0f - D_q);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float* krow = Ks + (sub * 16 + g * 4 + r) * kAttnLD + fi;
+#pragma unroll
+                for (int di = 0; di < 4; ++di)
+                    dq[di] = __builtin_amdgcn_mfma_f32_16x16x4f32(krow[di * 16], ds[r], dq[di], 0, 0, 0);
+            }
+        }
+        if (q < T) {
+            float* dst = dqkv + ((long long)b * T + q) * 2304 + h * 64 + g * 4;
+#pragma unroll
+            for (int di = 0; di < 4; ++di) *reinterpret_cast<f32x4*>(dst + di * 16) = dq[di];
+        }
+    }
+}
+
 // D scratch: [B*12][T] floats.
 // bh0: (clip, head) index of the first clip within the whole batch (dropout mask indexing of a per-branch call)
 inline hipError_t launch_attention_bwd(const float* qkv, const float* o, const float* dO, const float* lse, float* D,
                                        float* dqkv, int B, int T, const DropCfg& dc, uint32_t site, hipStream_t s,
-                                       int bh0 = 0) {
+                                       int bh0 = 0, bool force_three = false) {
     const int M = B * T;
+    if (T <= 64 && !dc.threshold && !force_three) {   // by the clip's length only: one fused launch (bit-identical to the three below)
+        static LdsAttrOnce attr_set;
+        if (hipError_t e = attr_set.ensure(reinterpret_cast<const void*>(attn_bwd_small_kernel), kAttnBwdSmallLds); e != hipSuccess) return e;
+        hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(B * 12), dim3(256), kAttnBwdSmallLds, s, qkv, o, dO, lse, D, dqkv, T);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(attn_bwd_rowdot_kernel, dim3((M + 3) / 4), dim3(256), 0, s, o, dO, D, M, T);
     const dim3 grid((T + 63) / 64, B * 12);
     if (dc.threshold) {

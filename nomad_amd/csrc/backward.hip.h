@@ -126,6 +126,16 @@ __global__ __launch_bounds__(128) void dgelu_rows512_kernel(const float* __restr
     reinterpret_cast<float4*>(out + row_addr(omap, m))[threadIdx.x] = r;
 }
 
+// Rows [a0, a1) and [b0, b1) of every clip's [rows][512] block set to zero: the pad rows (and the frames no output frame reaches) of a
+// padded dU buffer of the conv stack's backward - the GEMMs write every other row, so the buffer as a whole needs no memset (round 6:
+// the full memsets were 8 launches / 89 us of a configs[3] step, 215 MB for conv0's output gradient alone).  grid: B blocks of 256.
+__global__ __launch_bounds__(256) void zero_rows512_kernel(float* __restrict__ base, long long clip_stride, int a0, int a1, int b0, int b1) {
+    float* p = base + (long long)blockIdx.x * clip_stride;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = threadIdx.x; i < (a1 - a0) * 128; i += 256) reinterpret_cast<float4*>(p + (long long)a0 * 512)[i] = z;
+    for (int i = threadIdx.x; i < (b1 - b0) * 128; i += 256) reinterpret_cast<float4*>(p + (long long)b0 * 512)[i] = z;
+}
+
 // Pos-conv: dug[grp][clip][64 + t][48] = dy0[m][grp*48 + c] * gelu'(upc[m][grp*48 + c])   (group-major, padded)
 // grid: M blocks of 192 threads (one float4 each).
 __global__ __launch_bounds__(192) void dgelu_to_groups_kernel(const float* __restrict__ g, const float* __restrict__ u,
@@ -142,16 +152,19 @@ __global__ __launch_bounds__(192) void dgelu_to_groups_kernel(const float* __res
 
 // ---- head backward ----------------------------------------------------------------------------------
 // e = normalize(W relu(mean_t x) + b).  Given de -> gx[b][t][:] = relu'(mean) * (W^T dz) / T for every t.
-// grid: B blocks of 256 threads.
-__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ x, int T, const float* __restrict__ w,
-                                                       const float* __restrict__ bias, const float* __restrict__ de,
-                                                       float* __restrict__ gx, float* __restrict__ pooled_out = nullptr,
-                                                       float* __restrict__ dz_out = nullptr) {
+// grid: B blocks of 1024 threads (round 6: 16 waves - with 4 the kernel took 55 us for the 32 clips of configs[3], all of it the latency
+// of streaming W twice through 128 waves).  The time sum keeps the forward's order (waves 0 .. 3 take frames w, w + 4, ..: for T <= 64 the
+// same bits as head_pool_kernel, so the ReLU mask is the forward's); z = W pooled + b as in head_kernel (a row's dot product is one
+// wave's, same order); W^T dz in four fixed slices of 64 rows, folded in slice order.
+__global__ __launch_bounds__(1024) void head_bwd_kernel(const float* __restrict__ x, int T, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, const float* __restrict__ de,
+                                                        float* __restrict__ gx, float* __restrict__ pooled_out = nullptr,
+                                                        float* __restrict__ dz_out = nullptr) {
     __shared__ float pooled[768], mask[768], z[256], dz[256], red[4], red2[4];
     __shared__ __attribute__((aligned(16))) float psum[4][768];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* xb = x + (long long)b * T * 768;
-    {   // time sum: wave w takes frames w, w+4, ... (16-byte loads), the four partial sums are combined in fixed order
+    if (wave < 4) {   // time sum: wave w takes frames w, w+4, ... (16-byte loads), the four partial sums are combined in fixed order
         float4 acc[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -167,59 +180,86 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
         for (int i = 0; i < 3; ++i) reinterpret_cast<float4*>(psum[wave])[lane + 64 * i] = acc[i];
     }
     __syncthreads();
-    const float s0 = (psum[0][tid] + psum[1][tid]) + (psum[2][tid] + psum[3][tid]);
-    const float s1 = (psum[0][tid + 256] + psum[1][tid + 256]) + (psum[2][tid + 256] + psum[3][tid + 256]);
-    const float s2 = (psum[0][tid + 512] + psum[1][tid + 512]) + (psum[2][tid + 512] + psum[3][tid + 512]);
-    const float inv = 1.0f / (float)T;
-    const float m0 = s0 * inv, m1 = s1 * inv, m2 = s2 * inv;
-    pooled[tid] = fmaxf(m0, 0.f); pooled[tid + 256] = fmaxf(m1, 0.f); pooled[tid + 512] = fmaxf(m2, 0.f);
-    mask[tid] = m0 > 0.f ? inv : 0.f; mask[tid + 256] = m1 > 0.f ? inv : 0.f; mask[tid + 512] = m2 > 0.f ? inv : 0.f;
+    if (tid < 256) {
+        const float s0 = (psum[0][tid] + psum[1][tid]) + (psum[2][tid] + psum[3][tid]);
+        const float s1 = (psum[0][tid + 256] + psum[1][tid + 256]) + (psum[2][tid + 256] + psum[3][tid + 256]);
+        const float s2 = (psum[0][tid + 512] + psum[1][tid + 512]) + (psum[2][tid + 512] + psum[3][tid + 512]);
+        const float inv = 1.0f / (float)T;
+        const float m0 = s0 * inv, m1 = s1 * inv, m2 = s2 * inv;
+        pooled[tid] = fmaxf(m0, 0.f); pooled[tid + 256] = fmaxf(m1, 0.f); pooled[tid + 512] = fmaxf(m2, 0.f);
+        mask[tid] = m0 > 0.f ? inv : 0.f; mask[tid + 256] = m1 > 0.f ? inv : 0.f; mask[tid + 512] = m2 > 0.f ? inv : 0.f;
+    }
     __syncthreads();
     float p[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) p[i] = pooled[lane + 64 * i];
-    for (int o = wave * 64; o < wave * 64 + 64; ++o) {
-        const float* wr = w + (long long)o * 768;
-        float d = 0.f;
+#pragma unroll 1
+    for (int o0 = wave * 16; o0 < wave * 16 + 16; o0 += 4) {
+        float wv[4][12];
 #pragma unroll
-        for (int i = 0; i < 12; ++i) d = fmaf(wr[lane + 64 * i], p[i], d);
-        d = wave_sum(d);
-        if (lane == 0) z[o] = d + bias[o];
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < 12; ++i) wv[u][i] = w[(long long)(o0 + u) * 768 + lane + 64 * i];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float d = 0.f;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) d = fmaf(wv[u][i], p[i], d);
+            d = wave_sum(d);
+            if (lane == 0) z[o0 + u] = d + bias[o0 + u];
+        }
     }
     __syncthreads();
-    const float zv = z[tid], dev = de[(long long)b * 256 + tid];
-    const float ss = wave_sum(zv * zv);
-    if (lane == 0) red[wave] = ss;
+    float zv = 0.f, dev = 0.f;
+    if (tid < 256) {
+        zv = z[tid];
+        dev = de[(long long)b * 256 + tid];
+        const float ss = wave_sum(zv * zv);
+        if (lane == 0) red[wave] = ss;
+    }
     __syncthreads();
     const float nrm = fmaxf(sqrtf((red[0] + red[1]) + (red[2] + red[3])), 1e-12f);
     const float ev = zv / nrm;
-    const float dot = wave_sum(ev * dev);
-    if (lane == 0) red2[wave] = dot;
-    __syncthreads();
-    const float edot = (red2[0] + red2[1]) + (red2[2] + red2[3]);
-    dz[tid] = (dev - ev * edot) / nrm;
-    if (dz_out) {  // what the head's own parameter gradients need (train.hip.h: head_param_grad_kernel)
-        dz_out[(long long)b * 256 + tid] = dz[tid];
-        pooled_out[(long long)b * 768 + tid] = pooled[tid];
-        pooled_out[(long long)b * 768 + tid + 256] = pooled[tid + 256];
-        pooled_out[(long long)b * 768 + tid + 512] = pooled[tid + 512];
+    if (tid < 256) {
+        const float dot = wave_sum(ev * dev);
+        if (lane == 0) red2[wave] = dot;
     }
     __syncthreads();
-    // dp[c] = sum_o W[o][c] dz[o]; thread handles c = tid, tid+256, tid+512 (coalesced over c)
-    float d0 = 0.f, d1 = 0.f, d2 = 0.f;
-    for (int o = 0; o < 256; ++o) {
-        const float* wr = w + (long long)o * 768;
-        const float dzo = dz[o];
-        d0 = fmaf(wr[tid], dzo, d0); d1 = fmaf(wr[tid + 256], dzo, d1); d2 = fmaf(wr[tid + 512], dzo, d2);
+    if (tid < 256) {
+        const float edot = (red2[0] + red2[1]) + (red2[2] + red2[3]);
+        dz[tid] = (dev - ev * edot) / nrm;
+        if (dz_out) {  // what the head's own parameter gradients need (train.hip.h: head_param_grad_kernel)
+            dz_out[(long long)b * 256 + tid] = dz[tid];
+            pooled_out[(long long)b * 768 + tid] = pooled[tid];
+            pooled_out[(long long)b * 768 + tid + 256] = pooled[tid + 256];
+            pooled_out[(long long)b * 768 + tid + 512] = pooled[tid + 512];
+        }
     }
-    __syncthreads();  // psum is free again: row 0 carries the per-column gradient to the broadcast below
-    psum[0][tid] = d0 * mask[tid]; psum[0][tid + 256] = d1 * mask[tid + 256]; psum[0][tid + 512] = d2 * mask[tid + 512];
+    __syncthreads();
+    // dp[c] = sum_o W[o][c] dz[o]: slice q = tid / 256 takes o = 64 q .. 64 q + 63 for the columns c = tid % 256 + 256 j (coalesced over c);
+    // psum is free again and carries the four slices' sums
+    {
+        const int q = tid >> 8, c0 = tid & 255;
+        float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+#pragma unroll 8
+        for (int o = 64 * q; o < 64 * q + 64; ++o) {
+            const float* wr = w + (long long)o * 768;
+            const float dzo = dz[o];
+            d0 = fmaf(wr[c0], dzo, d0); d1 = fmaf(wr[c0 + 256], dzo, d1); d2 = fmaf(wr[c0 + 512], dzo, d2);
+        }
+        psum[q][c0] = d0; psum[q][c0 + 256] = d1; psum[q][c0 + 512] = d2;
+    }
+    __syncthreads();
+    if (tid < 768) {
+        const float d = (psum[0][tid] + psum[1][tid]) + (psum[2][tid] + psum[3][tid]);
+        pooled[tid] = d * mask[tid];     // (pooled is dead: it carries the per-column gradient to the broadcast below)
+    }
     __syncthreads();
     float4 gv[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) gv[i] = reinterpret_cast<const float4*>(psum[0])[lane + 64 * i];
+    for (int i = 0; i < 3; ++i) gv[i] = reinterpret_cast<const float4*>(pooled)[lane + 64 * i];
     float* gb = gx + (long long)b * T * 768;
-    for (int t = wave; t < T; t += 4) {
+    for (int t = wave; t < T; t += 16) {
         float4* r = reinterpret_cast<float4*>(gb + (long long)t * 768);
 #pragma unroll
         for (int i = 0; i < 3; ++i) r[lane + 64 * i] = gv[i];

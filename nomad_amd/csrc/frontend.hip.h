@@ -26,7 +26,10 @@ constexpr int kStatsPerClip = 65;  // 10 sums + 55 upper-triangular products
 // grid: (ceil(max L0 / kStatsChunk), B) blocks of 256 threads.  part[(b * gridDim.x + j)][0..9] = S, [10..64] = R
 // (j<=k, row-major) over frames [j * kStatsChunk, ...).  Ragged batches: lens != nullptr gives each clip's sample
 // count, clips are `n_samples` (the row stride) apart.
-constexpr int kStatsChunk = 8192;
+// 1024 (round 6; 8192 before): a 1 s clip (3 276 frames, configs[3]) was ONE workgroup per clip - 32 workgroups, 13 dependent load rounds
+// each, 49 us per launch for 2 MB of waveform; four chunks per such clip fill 128 workgroups.  The statistics stay a function of the
+// clip's length only.
+constexpr int kStatsChunk = 1024;
 __global__ __launch_bounds__(256) void wav_stats_kernel(const float* __restrict__ wav, int n_samples, int L0,
                                                         double* __restrict__ part, const int* __restrict__ lens) {
     const int b = blockIdx.y, j = blockIdx.x;

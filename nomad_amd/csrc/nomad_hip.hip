@@ -347,6 +347,7 @@ struct Tuning {
     int p9_short = 1;              // NOMAD_BF16_P9_SHORT: 192-row tiles of the persistent kernel (a run-time mode of the same instantiation) where they
                                    // save more than they cost: 1 = by the round count, batches that run alone only (the N = 768 GEMMs of config C5 on one
                                    // stream), 2 = every problem, 0 = never
+    bool attn_bwd_small = true;    // NOMAD_ATTN_BWD_SMALL: clips of at most 64 frames take the fused attention backward (one launch; 0: rowdot + dkv + dq)
     int p9_skew = 0;               // NOMAD_BF16_P9_SKEW (diag, timeline probe tile 61 only): start skew between workgroup groups, units of 10 ns
     int concurrent_parts = 1;      // nomad_set_concurrent_parts: batches the host layer runs concurrently on separate streams
 };
@@ -391,6 +392,7 @@ static void tuning_from_env(Tuning& t) {
     t.p9_res = getb("NOMAD_BF16_P9_RES", t.p9_res);
     t.p9_short = geti("NOMAD_BF16_P9_SHORT", t.p9_short);
     t.p9_skew = geti("NOMAD_BF16_P9_SKEW", t.p9_skew);
+    t.attn_bwd_small = getb("NOMAD_ATTN_BWD_SMALL", t.attn_bwd_small);
 }
 #endif
 
@@ -962,7 +964,7 @@ int run_head(nomad_ctx* c, const TIn* x, int B, int T, const float* w, const flo
              float* pool, hipStream_t s) {
     Scope sc(c, s, NOMAD_K_ROW, 2.0 * B * 768 * 256);
     hipLaunchKernelGGL(head_pool_kernel<TIn>, dim3((T + kHeadChunk - 1) / kHeadChunk, B), dim3(256), 0, s, x, tpref ? 0 : T, pool, tpref);
-    hipLaunchKernelGGL(head_kernel, dim3(B), dim3(256), 0, s, pool, tpref ? 0 : T, w, b, emb, tpref);
+    hipLaunchKernelGGL(head_kernel, dim3(B), dim3(1024), 0, s, pool, tpref ? 0 : T, w, b, emb, tpref);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -3265,7 +3267,7 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
     // ---- head -> d loss / d x_12 -------------------------------------------------------------------
     {
         Scope sc(c, s, NOMAD_K_ROW, 0.0);
-        hipLaunchKernelGGL(head_bwd_kernel, dim3(B), dim3(256), 0, s, layers_out + (size_t)11 * M * 768, T,
+        hipLaunchKernelGGL(head_bwd_kernel, dim3(B), dim3(1024), 0, s, layers_out + (size_t)11 * M * 768, T,
                            head_w ? head_w : c->emb_w, head_b ? head_b : c->emb_b, demb, gx,
                            train ? F(lay.headp) : nullptr, train ? F(lay.headdz) : nullptr);
         if (train)
@@ -3328,7 +3330,7 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
         if ((rc = bwd_gemm(c, dy1b, c->o_wT[l], dybs, Ms, 768, 768, nullptr, nullptr, s))) return rc;  // dctx
         {
             Scope sc(c, s, NOMAD_K_ATTN, 14.0 * nc * 12.0 * (double)T * T * 64);  // 7 T x T x 64 products (S, dP twice)
-            HIP_TRY(launch_attention_bwd(qkv, ctx, dybs, lse, F(lay.attnd), dqkvs, nc, T, d_att, site_attn(l), s, c0 * 12));
+            HIP_TRY(launch_attention_bwd(qkv, ctx, dybs, lse, F(lay.attnd), dqkvs, nc, T, d_att, site_attn(l), s, c0 * 12, !c->tune.attn_bwd_small));
         }
         if (pg) {
             // the forward's fused weight holds q scaled by head_dim^-0.5: d q_proj = 0.125 * d fused rows 0..767
@@ -3489,7 +3491,16 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
         const bool to_g0 = (i == 1);          // conv0's output gradient is compact and gets no GELU' here
         const long long out_clip = to_g0 ? (long long)Lin * 512 : (long long)(Lin + 2) * 512;
         const long long out_off = to_g0 ? 0 : 512;
-        HIP_TRY(hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * out_clip, s));
+        // the two GEMMs below write frames 0 .. covered - 1 of every clip (k = 3: every input frame; k = 2: 2 L_out of them); what they
+        // do not write is zeroed here: the two pad rows of a padded buffer and the frames behind the last window (a full memset of
+        // the buffer cost 20-40 us per layer at configs[3]'s size)
+        if (!to_g0) {
+            const int covered = kConvK[i] == 2 ? 2 * Lout : Lin;
+            Scope sc(c, s, NOMAD_K_ROW, 0.0);
+            hipLaunchKernelGGL(zero_rows512_kernel, dim3(B), dim3(256), 0, s, out, out_clip, 0, 1, covered + 1, Lin + 2);
+        } else if (kConvK[i] == 2) {
+            HIP_TRY(hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * out_clip, s));   // (not reached: conv1 has k = 3 and writes every frame of G0)
+        }
         if (conv_pg) {  // input of layer i: gelu(u_{i-1}) recomputed in the transpose; for i = 1 conv0's output, recomputed whole
             if (i == 1) {
                 Scope sc(c, s, NOMAD_K_FRONT, 0.0);
@@ -4197,7 +4208,7 @@ int nomad_diag_attention_bwd(nomad_ctx* c, const float* qkv, const float* dctx, 
     if (rc) return rc;
     float* D = nullptr;  // diagnostics only: the product path carves this from the caller's workspace
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&D), sizeof(float) * 12 * (size_t)B * T));
-    const hipError_t e = launch_attention_bwd(qkv, ctx_out, dctx, lse, D, dqkv, B, T, DropCfg{}, 0, s);
+    const hipError_t e = launch_attention_bwd(qkv, ctx_out, dctx, lse, D, dqkv, B, T, DropCfg{}, 0, s, 0, !c->tune.attn_bwd_small);
     (void)hipStreamSynchronize(s);
     (void)hipFree(D);
     if (e != hipSuccess) return fail(NOMAD_ERR_HIP, "attention backward: %s", hipGetErrorString(e));

@@ -122,10 +122,14 @@ __global__ __launch_bounds__(256) void head_pool_kernel(const TIn* __restrict__ 
     }
 }
 
-// Stage 2.  grid: B blocks of 256 threads.  pool (stage 1) -> emb [B][256].
-__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ pool, int T, const float* __restrict__ w,
-                                                   const float* __restrict__ bias, float* __restrict__ emb,
-                                                   const int* __restrict__ tpref = nullptr) {
+// Stage 2.  grid: B blocks of 1024 threads.  pool (stage 1) -> emb [B][256].
+// Round 6: 16 waves instead of 4 - with one 4-wave workgroup per clip a batch of 32 clips (configs[3]) kept 128 waves busy streaming the
+// 786 KB of W each: 66 us per launch, all of it load latency.  Wave w now takes output rows 16 w .. 16 w + 15, four rows (48 loads) in
+// flight per trip.  A row's dot product is still one wave's: lane l multiplies elements l + 64 i in the order i = 0 .. 11, then the
+// wave sum - the same bits as before; the squared norm is summed by waves 0 .. 3 over e[64 w ..] and folded as before.
+__global__ __launch_bounds__(1024) void head_kernel(const float* __restrict__ pool, int T, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, float* __restrict__ emb,
+                                                    const int* __restrict__ tpref = nullptr) {
     __shared__ float pooled[768];
     __shared__ float e[256];
     __shared__ float wsum[4];
@@ -135,35 +139,35 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ poo
         row0 = tpref[b];
         T = tpref[b + 1] - tpref[b];
     }
-    const float* pb = pool + (row0 / kHeadChunk + b) * 768;
-    const int nchunk = (T + kHeadChunk - 1) / kHeadChunk;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    for (int j = 0; j < nchunk; ++j) {  // chunks in order
-        const float* r = pb + (long long)j * 768;
-        s0 += r[tid];
-        s1 += r[tid + 256];
-        s2 += r[tid + 512];
+    if (tid < 256) {
+        const float* pb = pool + (row0 / kHeadChunk + b) * 768;
+        const int nchunk = (T + kHeadChunk - 1) / kHeadChunk;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        for (int j = 0; j < nchunk; ++j) {  // chunks in order
+            const float* r = pb + (long long)j * 768;
+            s0 += r[tid];
+            s1 += r[tid + 256];
+            s2 += r[tid + 512];
+        }
+        const float inv = 1.0f / (float)T;
+        pooled[tid] = fmaxf(s0 * inv, 0.f);
+        pooled[tid + 256] = fmaxf(s1 * inv, 0.f);
+        pooled[tid + 512] = fmaxf(s2 * inv, 0.f);
     }
-    const float inv = 1.0f / (float)T;
-    pooled[tid] = fmaxf(s0 * inv, 0.f);
-    pooled[tid + 256] = fmaxf(s1 * inv, 0.f);
-    pooled[tid + 512] = fmaxf(s2 * inv, 0.f);
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6;
     float p[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) p[i] = pooled[lane + 64 * i];
-    // 8 output rows per trip: their 96 loads are in flight together (one row at a time, each trip waited ~0.7 us for its own
-    // 12 loads: 76 us for the 64 rows of a wave); every row's own sum keeps its order
 #pragma unroll 1
-    for (int o0 = wave * 64; o0 < wave * 64 + 64; o0 += 8) {
-        float wv[8][12];
+    for (int o0 = wave * 16; o0 < wave * 16 + 16; o0 += 4) {
+        float wv[4][12];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int i = 0; i < 12; ++i) wv[u][i] = w[(long long)(o0 + u) * 768 + lane + 64 * i];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 4; ++u) {
             float d = 0.f;
 #pragma unroll
             for (int i = 0; i < 12; ++i) d = fmaf(wv[u][i], p[i], d);
@@ -172,12 +176,16 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ poo
         }
     }
     __syncthreads();
-    const float v = e[tid];
-    const float ss = wave_sum(v * v);
-    if (lane == 0) wsum[wave] = ss;
+    if (tid < 256) {
+        const float v = e[tid];
+        const float ss = wave_sum(v * v);
+        if (lane == 0) wsum[wave] = ss;
+    }
     __syncthreads();
-    const float nrm = sqrtf((wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
-    emb[(long long)b * 256 + tid] = v / fmaxf(nrm, 1e-12f);  // F.normalize eps
+    if (tid < 256) {
+        const float nrm = sqrtf((wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
+        emb[(long long)b * 256 + tid] = e[tid] / fmaxf(nrm, 1e-12f);  // F.normalize eps
+    }
 }
 
 // NomadLoss.  Stage 1: per-block fp64 partial sums of |a-b| over the 12 layer tensors (n_layer

@@ -44,6 +44,27 @@ def test_attention_backward(engine, B, T):
     assert _rel(dqkv.cpu().double(), ref) < 5e-5
 
 
+@pytest.mark.parametrize("B,T", [(3, 50), (1, 64), (2, 1), (1, 17), (2, 33)])
+def test_fused_attention_backward_of_short_clips_is_bit_identical(built_lib, sd0, monkeypatch, B, T):
+    """Round 6: clips of at most 64 frames take ONE fused launch (attn_bwd_small_kernel) instead of rowdot + dkv + dq; every product and
+    sum is the three-kernel path's, in its order - the same bits (NOMAD_ATTN_BWD_SMALL=0 on the diag library = the three kernels)."""
+    from nomad_amd.engine import Engine
+    g = torch.Generator().manual_seed(100 + T)
+    qkv = (torch.randn(B * T, 2304, generator=g) * 0.5).cuda()
+    dctx = torch.randn(B * T, 768, generator=g).cuda()
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("NOMAD_ATTN_BWD_SMALL", flag)
+        eng = Engine(sd0, 0, diag=True)
+        out, lse, dqkv = eng.diag_attention_bwd(qkv, dctx, B, T)
+        torch.cuda.synchronize()
+        outs.append((out.clone(), lse.clone(), dqkv.clone()))
+        eng.close()
+    assert torch.isfinite(outs[1][2]).all()
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+
+
 def _oracle_grad(sd, wav, head_w, head_b, G_layers, G_emb, mult=1.0):
     w = wav.clone().requires_grad_(True)
     outs = O.lossnet_forward(sd, w, head_w, head_b, feature_grad_mult=mult, required_seq_len_multiple=2)
