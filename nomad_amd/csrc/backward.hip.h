@@ -291,7 +291,12 @@ __global__ __launch_bounds__(256) void l1_bwd_kernel(const float4* __restrict__ 
 //   dy = gamma * rstd * (dz - s1/L0 - yhat * s2/L0);  dx[5t+j] += sum_c dy[t,c] w[c,j]
 // Pass 1 (gn_bwd_stats_kernel): per-(clip, frame chunk) partial s1, s2 -> fixed-order fold in pass 2's prologue.
 // Pass 2 (conv0_bwd_kernel): dy, then the 512-channel contraction per frame (tiled through LDS, registers per frame).
-constexpr int kGnChunk = 256;  // frames per block in both passes
+constexpr int kGnChunk = 256;  // frames per block of the parameter-gradient pass (train.hip.h)
+// Round 6: the statistics pass takes 64 frames per block (256 before: 13 x 32 = 416 workgroups for configs[3], 1.6 per CU, each a serial
+// loop of 256 frames x ~100 vector instructions - 156 us for a pass whose 215 MB take 45 us to read); its per-chunk sums are folded ONCE per
+// clip by gn_bwd_fold_kernel (every block of pass 2 used to fold all of them itself), which also lays out the 16 per-channel constants of
+// pass 2 as one float4-loadable table.
+constexpr int kGnStatsChunk = 64;
 
 __device__ __forceinline__ void conv0_frame(const float* xs, int t, const float (&w)[2][10], const float (&sc)[2],
                                             const float (&sh)[2], const float (&mean)[2], const float (&rstd)[2],
@@ -312,8 +317,8 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restri
                                                            const float* __restrict__ shift, const float* __restrict__ gmean,
                                                            const float* __restrict__ grstd, const float* __restrict__ G,
                                                            float* __restrict__ partial) {
-    __shared__ float xs[kGnChunk * 5 + 8];
-    const int b = blockIdx.y, t0 = blockIdx.x * kGnChunk, nfr = min(kGnChunk, L0 - t0), tid = threadIdx.x;
+    __shared__ float xs[kGnStatsChunk * 5 + 8];
+    const int b = blockIdx.y, t0 = blockIdx.x * kGnStatsChunk, nfr = min(kGnStatsChunk, L0 - t0), tid = threadIdx.x;
     const float* x = wav + (long long)b * n_samples + 5 * t0;
     for (int i = tid; i < 5 * nfr + 5; i += 256) xs[i] = x[i];
     float w[2][10], sc[2], sh[2], mean[2], rstd[2];
@@ -328,14 +333,23 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restri
     __syncthreads();
     float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
     const float* g = G + ((long long)b * L0 + t0) * 512;
-    for (int t = 0; t < nfr; ++t) {
-        float z[2], yh[2];
-        conv0_frame(xs, t, w, sc, sh, mean, rstd, z, yh);
+    for (int tb = 0; tb < nfr; tb += 4) {   // four frames' loads in flight; the sums keep the frame order
+        float gv[4][2];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const float dz = g[(long long)t * 512 + tid + 256 * q] * dgelu_erf(z[q]);
-            s1[q] += dz;
-            s2[q] = fmaf(dz, yh[q], s2[q]);
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) gv[u][q] = tb + u < nfr ? g[(long long)(tb + u) * 512 + tid + 256 * q] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (tb + u >= nfr) break;
+            float z[2], yh[2];
+            conv0_frame(xs, tb + u, w, sc, sh, mean, rstd, z, yh);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float dz = gv[u][q] * dgelu_erf(z[q]);
+                s1[q] += dz;
+                s2[q] = fmaf(dz, yh[q], s2[q]);
+            }
         }
     }
     float* p = partial + ((long long)b * gridDim.x + blockIdx.x) * 1024;
@@ -346,6 +360,31 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restri
     }
 }
 
+// Fold.  grid: B blocks of 512 threads (one per channel): the chunk sums of pass 1 in chunk order -> fold[b][0..511] = s1, [512..1023] = s2
+// (raw sums: the parameter-gradient kernels of train.hip.h read them too), and the table pass 2 stages with one float4 per thread:
+// cwtab[b][c][0..9] = w0[c][:], [10] = scale, [11] = shift, [12] = mean, [13] = rstd, [14] = s1 / L0, [15] = s2 / L0.
+__global__ __launch_bounds__(512) void gn_bwd_fold_kernel(const float* __restrict__ partial, int nchunks, int L0,
+                                                          const float* __restrict__ w0, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, const float* __restrict__ gmean,
+                                                          const float* __restrict__ grstd, float* __restrict__ fold,
+                                                          float* __restrict__ cwtab) {
+    const int b = blockIdx.x, c = threadIdx.x;
+    float a1 = 0.f, a2 = 0.f;
+    for (int k = 0; k < nchunks; ++k) {
+        const float* p = partial + ((long long)b * nchunks + k) * 1024;
+        a1 += p[c];
+        a2 += p[512 + c];
+    }
+    fold[(long long)b * 1024 + c] = a1;
+    fold[(long long)b * 1024 + 512 + c] = a2;
+    float4* t = reinterpret_cast<float4*>(cwtab + ((long long)b * 512 + c) * 16);
+    const float* w = w0 + c * 10;
+    t[0] = make_float4(w[0], w[1], w[2], w[3]);
+    t[1] = make_float4(w[4], w[5], w[6], w[7]);
+    t[2] = make_float4(w[8], w[9], scale[b * 512 + c], shift[b * 512 + c]);
+    t[3] = make_float4(gmean[b * 512 + c], grstd[b * 512 + c], a1 / (float)L0, a2 / (float)L0);
+}
+
 // Pass 2.  grid: (ceil(L0 / 64), B), 256 threads = 64 frames x 4 channel groups; a block walks the 512 channels in chunks of 64:
 // the chunk's slice of G goes through LDS (coalesced 256-byte rows in, conflict-free column reads out), its per-channel
 // constants sit in LDS as broadcasts, and thread (frame f, group g) accumulates its 10 tap contributions over channels
@@ -353,32 +392,33 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restri
 // LDS; only that sum goes to memory.  dwav must be zero-initialised: a sample on a block boundary receives one more
 // contribution from the neighbouring block, and two float atomics commute.  (The version this replaces made 10 wave
 // reductions, two barriers and an atomic per FRAME: 687 us for config C4's 32 x 16384 samples; this one ~10 x less.)
+// Round 6: the next chunk's G slice and constants (one float4 of cwtab per thread) are in flight while the current chunk is
+// multiplied - before, every chunk began with 16 dependent scalar loads per thread and a branchy gather of the constants.
 constexpr int kC0Frames = 64;
 __global__ __launch_bounds__(256) void conv0_bwd_kernel(const float* __restrict__ wav, int n_samples, int L0,
-                                                        const float* __restrict__ w0, const float* __restrict__ scale,
-                                                        const float* __restrict__ shift, const float* __restrict__ gmean,
-                                                        const float* __restrict__ grstd, const float* __restrict__ G,
-                                                        const float* __restrict__ partial, int nchunks,
+                                                        const float* __restrict__ cwtab, const float* __restrict__ G,
                                                         float* __restrict__ dwav) {
     __shared__ float xs[kC0Frames * 5 + 8];
     __shared__ float gt[kC0Frames][65];        // G chunk: [frame][channel of the chunk]
-    __shared__ float cw[64][16];               // per channel of the chunk: w[0..9], sc, sh, mean, rstd, m1, m2
-    __shared__ float m12[2][512];              // s1 / L0, s2 / L0 per channel (chunk partials folded in order)
+    __shared__ __attribute__((aligned(16))) float cw[64][16];   // per channel of the chunk: w[0..9], sc, sh, mean, rstd, m1, m2
     __shared__ float red[4][kC0Frames][10];
     const int b = blockIdx.y, t0 = blockIdx.x * kC0Frames, nfr = min(kC0Frames, L0 - t0), tid = threadIdx.x;
     const int f = tid & 63, g = tid >> 6;
     const float* x = wav + (long long)b * n_samples + 5 * t0;
     for (int i = tid; i < 5 * nfr + 5; i += 256) xs[i] = x[i];
-    for (int c = tid; c < 512; c += 256) {
-        float a1 = 0.f, a2 = 0.f;
-        for (int k = 0; k < nchunks; ++k) {
-            const float* p = partial + ((long long)b * nchunks + k) * 1024;
-            a1 += p[c];
-            a2 += p[512 + c];
+    const float* gbase = G + ((long long)b * L0 + t0) * 512;
+    const float4* ctab = reinterpret_cast<const float4*>(cwtab + (long long)b * 512 * 16);
+    // staging map: G slice as float4 - thread -> (frame tid / 16 + 16 i, channels 4 (tid % 16) .. + 3); constants: float4 tid of the chunk
+    float4 greg[4], creg;
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int fr = (tid >> 4) + 16 * i;
+            greg[i] = fr < nfr ? *reinterpret_cast<const float4*>(gbase + (long long)fr * 512 + c0 + 4 * (tid & 15)) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        m12[0][c] = a1 / (float)L0;
-        m12[1][c] = a2 / (float)L0;
-    }
+        creg = ctab[c0 * 4 + tid];
+    };
+    fetch(0);
     __syncthreads();
     float xr[10], contrib[10];
 #pragma unroll
@@ -386,26 +426,15 @@ __global__ __launch_bounds__(256) void conv0_bwd_kernel(const float* __restrict_
         xr[j] = f < nfr ? xs[5 * f + j] : 0.f;
         contrib[j] = 0.f;
     }
-    const float* gbase = G + ((long long)b * L0 + t0) * 512;
     for (int c0 = 0; c0 < 512; c0 += 64) {
-        // stage: 64 frames x 64 channels of G (thread: frame tid / 4 + 16 i... rows of 64 floats), channel constants
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int id = tid + 256 * i, fr = id >> 6, cc = id & 63;
-            gt[fr][cc] = fr < nfr ? gbase[(long long)fr * 512 + c0 + cc] : 0.f;
+        for (int i = 0; i < 4; ++i) {
+            const int fr = (tid >> 4) + 16 * i, cc = 4 * (tid & 15);
+            gt[fr][cc] = greg[i].x; gt[fr][cc + 1] = greg[i].y; gt[fr][cc + 2] = greg[i].z; gt[fr][cc + 3] = greg[i].w;
         }
-        for (int id = tid; id < 64 * 16; id += 256) {
-            const int cc = id >> 4, k = id & 15, c = c0 + cc;
-            float v;
-            if (k < 10) v = w0[c * 10 + k];
-            else if (k == 10) v = scale[b * 512 + c];
-            else if (k == 11) v = shift[b * 512 + c];
-            else if (k == 12) v = gmean[b * 512 + c];
-            else if (k == 13) v = grstd[b * 512 + c];
-            else v = m12[k - 14][c];
-            cw[cc][k] = v;
-        }
+        reinterpret_cast<float4*>(&cw[0][0])[tid] = creg;
         __syncthreads();
+        if (c0 + 64 < 512) fetch(c0 + 64);
         if (f < nfr) {
             for (int cc = g; cc < 64; cc += 4) {
                 const float* q = cw[cc];

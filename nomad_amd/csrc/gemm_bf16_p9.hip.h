@@ -101,8 +101,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
     if (ABL == 7) {
         // probe (round 6): are the epilogue's memory bursts expensive because every CU issues them at the same time?  Start the four groups
         // of workgroups p9_skew x 10 ns apart and compare the stamps of tile 1 (tools/p9_timeline.py --skew)
-        if (p.p9_skew > 0) {
-            const unsigned long long until = wall_clock64() + (unsigned long long)p.p9_skew * (((unsigned)blockIdx.x >> 3) & 3u);
+        if (p.p9_skew != 0) {   // (> 0: four groups; < 0: sixteen groups of 16 CUs, |p9_skew| x 10 ns apart)
+            const unsigned long long until = wall_clock64() + (unsigned long long)(p.p9_skew < 0 ? -p.p9_skew : p.p9_skew) * (((unsigned)blockIdx.x >> 3) & (p.p9_skew < 0 ? 15u : 3u));
             while (wall_clock64() < until) __builtin_amdgcn_s_sleep(32);
         }
         ts_[0] = wall_clock64();

@@ -205,8 +205,8 @@ Saved make_saved(const Shapes& s, void* base) {
 // Scratch of nomad_embed_backward.  train = true adds what the parameter gradients need (nomad_train_backward):
 // two transposed operand buffers [3072][Mp], split-K partial products, the recomputed pos-conv input.
 struct BwdLayout {
-    size_t gx, dya, dyb, dh, dqkv, dug, f1, f2, bufa, bufb, partial, attnd, total;
-    int nchunks;
+    size_t gx, dya, dyb, dh, dqkv, dug, f1, f2, bufa, bufb, partial, gnfold, cwtab, attnd, total;
+    int nchunks, nstat;   // frame chunks of the conv0 parameter-gradient pass / of the GroupNorm-backward statistics pass
     size_t ta, tb, kpart, xg, dwe, lnpart, headp, headdz, dmask;
     int Mp, pos_split, ln_blocks;
     size_t h0, convtmp, c0part;  // trainable conv feature extractor: recomputed conv0 output, one layer's dW, conv0 partials
@@ -237,7 +237,10 @@ BwdLayout make_bwd_layout(const Shapes& s, bool train = false, bool train_conv =
     l.bufa = take(512 * (size_t)s.B * (s.L[0] + 2));
     l.bufb = take(512 * (size_t)s.B * (s.L[1] + 2));
     l.nchunks = (s.L[0] + kGnChunk - 1) / kGnChunk;
-    l.partial = take(1024 * (size_t)s.B * l.nchunks);
+    l.nstat = (s.L[0] + kGnStatsChunk - 1) / kGnStatsChunk;
+    l.partial = take(1024 * (size_t)s.B * l.nstat);
+    l.gnfold = take(1024 * (size_t)s.B);
+    l.cwtab = take((size_t)512 * 16 * s.B);
     l.attnd = take(12 * M);
     if (train) {
         l.Mp = (s.M + 511) / 512 * 512;  // contraction length of the dW GEMMs: any split S | 16 keeps K % 32 == 0
@@ -3555,15 +3558,18 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
         if (dwav) HIP_TRY(hipMemsetAsync(dwav, 0, sizeof(float) * (size_t)B * n_samples, s));
         Scope sc(c, s, NOMAD_K_FRONT, 0.0);
         const dim3 grid(lay.nchunks, B);
-        hipLaunchKernelGGL(gn_bwd_stats_kernel, grid, dim3(256), 0, s, wav, n_samples, sh.L[0], c->conv0_w, sv.gn_scale,
+        float* fold = F(lay.gnfold);
+        hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(lay.nstat, B), dim3(256), 0, s, wav, n_samples, sh.L[0], c->conv0_w, sv.gn_scale,
                            sv.gn_shift, sv.gn_mean, sv.gn_rstd, G0, partial);
+        hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3(B), dim3(512), 0, s, partial, lay.nstat, sh.L[0], c->conv0_w, sv.gn_scale, sv.gn_shift,
+                           sv.gn_mean, sv.gn_rstd, fold, F(lay.cwtab));
         if (dwav)
             hipLaunchKernelGGL(conv0_bwd_kernel, dim3((sh.L[0] + kC0Frames - 1) / kC0Frames, B), dim3(256), 0, s, wav, n_samples, sh.L[0],
-                               c->conv0_w, sv.gn_scale, sv.gn_shift, sv.gn_mean, sv.gn_rstd, G0, partial, lay.nchunks, dwav);
+                               F(lay.cwtab), G0, dwav);
         if (conv_pg) {  // conv0 weight, GroupNorm gamma / beta
             hipLaunchKernelGGL(conv0_param_partial_kernel, grid, dim3(256), 0, s, wav, n_samples, sh.L[0], c->conv0_w, sv.gn_scale,
-                               sv.gn_shift, sv.gn_mean, sv.gn_rstd, G0, partial, lay.nchunks, F(lay.c0part));
-            hipLaunchKernelGGL(conv0_param_final_kernel, dim3(24), dim3(256), 0, s, F(lay.c0part), partial, B, lay.nchunks,
+                               sv.gn_shift, sv.gn_mean, sv.gn_rstd, G0, fold, lay.nchunks, F(lay.c0part));
+            hipLaunchKernelGGL(conv0_param_final_kernel, dim3(24), dim3(256), 0, s, F(lay.c0part), fold, B, lay.nchunks,
                                G(po.conv0_w), G(po.gn_w), G(po.gn_b));
         }
     }

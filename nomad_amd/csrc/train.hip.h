@@ -615,8 +615,8 @@ __global__ __launch_bounds__(256) void conv0_param_partial_kernel(const float* _
                                                                   const float* __restrict__ w0, const float* __restrict__ scale,
                                                                   const float* __restrict__ shift, const float* __restrict__ gmean,
                                                                   const float* __restrict__ grstd, const float* __restrict__ G,
-                                                                  const float* __restrict__ partial, int nchunks,
-                                                                  float* __restrict__ cpart) {
+                                                                  const float* __restrict__ fold, int nchunks,
+                                                                  float* __restrict__ cpart) {   // fold: gn_bwd_fold_kernel's [B][2][512] raw sums
     __shared__ float xs[kGnChunk * 5 + 8];
     const int b = blockIdx.y, t0 = blockIdx.x * kGnChunk, nfr = min(kGnChunk, L0 - t0), tid = threadIdx.x;
     const float* x = wav + (long long)b * n_samples + 5 * t0;
@@ -629,14 +629,8 @@ __global__ __launch_bounds__(256) void conv0_param_partial_kernel(const float* _
         mean[q] = gmean[b * 512 + c]; rstd[q] = grstd[b * 512 + c];
 #pragma unroll
         for (int j = 0; j < 10; ++j) { w[q][j] = w0[c * 10 + j]; dw[q][j] = 0.f; }
-        float a1 = 0.f, a2 = 0.f;
-        for (int k = 0; k < nchunks; ++k) {
-            const float* p = partial + ((long long)b * nchunks + k) * 1024;
-            a1 += p[c];
-            a2 += p[512 + c];
-        }
-        m1[q] = a1 / (float)L0;
-        m2[q] = a2 / (float)L0;
+        m1[q] = fold[(long long)b * 1024 + c] / (float)L0;
+        m2[q] = fold[(long long)b * 1024 + 512 + c] / (float)L0;
     }
     __syncthreads();
     const float* g = G + ((long long)b * L0 + t0) * 512;
@@ -660,7 +654,7 @@ __global__ __launch_bounds__(256) void conv0_param_partial_kernel(const float* _
 
 // grid: 22 blocks of 256: elements 0..5119 = d w0, 5120..5631 = d gamma, 5632..6143 = d beta (accumulated into the
 // gradient vector; (b, chunk) folded in fixed order).
-__global__ __launch_bounds__(256) void conv0_param_final_kernel(const float* __restrict__ cpart, const float* __restrict__ partial,
+__global__ __launch_bounds__(256) void conv0_param_final_kernel(const float* __restrict__ cpart, const float* __restrict__ fold,
                                                                 int B, int nchunks, float* __restrict__ dw0,
                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -671,7 +665,7 @@ __global__ __launch_bounds__(256) void conv0_param_final_kernel(const float* __r
     } else if (i < 6144) {
         const int c = (i - 5120) & 511, which = (i - 5120) >> 9;  // 0: gamma <- s2, 1: beta <- s1
         float a = 0.f;
-        for (int k = 0; k < B * nchunks; ++k) a += partial[(long long)k * 1024 + (which == 0 ? 512 : 0) + c];
+        for (int k = 0; k < B; ++k) a += fold[(long long)k * 1024 + (which == 0 ? 512 : 0) + c];   // per-clip sums (gn_bwd_fold_kernel), clip order
         (which == 0 ? dgamma : dbeta)[c] += a;
     }
 }
