@@ -16,8 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnomad_hip.so")
 DIAG_LIB = os.path.join(HERE, "libnomad_diag.so")
-SOURCES = ["nomad_hip.hip"]
-# every header the one translation unit includes: *.hip.h kernels AND plain *.h host code (wav_reader.h)
+SOURCES = ["nomad_hip.hip", "nomad_gemm_f32.hip", "nomad_gemm_bf16.hip"]   # three translation units, compiled side by side (csrc/nomad_ctx.hip.h)
+# every header the translation units include: *.hip.h kernels AND plain *.h host code (wav_reader.h)
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "nomad_hip.h")]
 
 
@@ -48,28 +48,52 @@ def pk_path(lib: str) -> str:
     return lib[:-3] + "_pk.so"
 
 
-def _command(lib: str, diag: bool, verbose: bool):
-    tmp = lib + f".tmp{os.getpid()}"
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Wall", "-Wno-unused-function", "-pthread", "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+def _flags(lib: str, diag: bool, verbose: bool):
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-pthread"]
     if os.environ.get("NOMAD_PACKED_FP32", "0") != "1" and not lib.endswith("_pk.so"):
-        cmd[2:2] = NO_PACKED_FP32
+        flags = NO_PACKED_FP32 + flags
     else:
-        cmd.insert(1, "-DNOMAD_PACKED_FP32_BUILD=1")   # nomad_build_flags() reports it; Engine then keeps its two-stream split off
+        flags.insert(0, "-DNOMAD_PACKED_FP32_BUILD=1")   # nomad_build_flags() reports it; Engine then keeps its two-stream split off
     if diag:
-        cmd.insert(1, "-DNOMAD_DIAG")
+        flags.insert(0, "-DNOMAD_DIAG")
     if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    return cmd, tmp
+        flags.insert(0, "-Rpass-analysis=kernel-resource-usage")
+    return flags
 
 
-def _finish(proc, tmp: str, lib: str) -> None:
-    out, err = proc.communicate()
-    if proc.returncode != 0:
-        if os.path.exists(tmp):
-            os.remove(tmp)
-        raise RuntimeError("hipcc failed:\n" + out + err)
-    os.replace(tmp, lib)  # atomic: a concurrent dlopen never sees a half-written library
+class _Job:
+    """One library: its translation units are compiled to objects in parallel, then linked."""
+
+    def __init__(self, lib: str, diag: bool, verbose: bool = False):
+        self.lib, self.t0 = lib, time.perf_counter()
+        self.tmp = lib + f".tmp{os.getpid()}"
+        self.flags = _flags(lib, diag, verbose)
+        self.objs = [f"{lib}.{os.path.splitext(s)[0]}.{os.getpid()}.o" for s in SOURCES]
+        self.procs = [subprocess.Popen([hipcc_path(), *self.flags, "-c", os.path.join(CSRC, s), "-o", o],
+                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for s, o in zip(SOURCES, self.objs)]
+
+    def _cleanup(self):
+        for f in self.objs + [self.tmp]:
+            if os.path.exists(f):
+                os.remove(f)
+
+    def finish(self) -> float:
+        errs = []
+        for p in self.procs:
+            out, err = p.communicate()
+            if p.returncode != 0:
+                errs.append(out + err)
+        if errs:
+            self._cleanup()
+            raise RuntimeError("hipcc failed:\n" + "\n".join(errs))
+        link = subprocess.run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", self.tmp, *self.objs],
+                              capture_output=True, text=True)
+        if link.returncode != 0:
+            self._cleanup()
+            raise RuntimeError("hipcc (link) failed:\n" + link.stdout + link.stderr)
+        os.replace(self.tmp, self.lib)  # atomic: a concurrent dlopen never sees a half-written library
+        self._cleanup()
+        return round(time.perf_counter() - self.t0, 1)
 
 
 def build_library(force: bool = False, verbose: bool = False, diag: bool = False) -> str:
@@ -77,37 +101,20 @@ def build_library(force: bool = False, verbose: bool = False, diag: bool = False
     lib = DIAG_LIB if diag else LIB
     if not force and not needs_build(lib):
         return lib
-    cmd, tmp = _command(lib, diag, verbose)
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-    _finish(proc, tmp, lib)
+    _Job(lib, diag, verbose).finish()
     return lib
 
 
 def build_all(force: bool = False) -> dict:
-    """Both libraries, the two hipcc runs side by side; -> {name: seconds} of what was rebuilt."""
-    jobs = []
-    for lib, diag in ((LIB, False), (DIAG_LIB, True)):
-        if force or needs_build(lib):
-            cmd, tmp = _command(lib, diag, False)
-            jobs.append((lib, tmp, time.perf_counter(), subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
-    took = {}
-    for lib, tmp, t0, proc in jobs:
-        _finish(proc, tmp, lib)
-        took[os.path.basename(lib)] = round(time.perf_counter() - t0, 1)
-    return took
+    """Both libraries, all six hipcc compilations side by side; -> {name: seconds} of what was rebuilt."""
+    jobs = [_Job(lib, diag) for lib, diag in ((LIB, False), (DIAG_LIB, True)) if force or needs_build(lib)]
+    return {os.path.basename(j.lib): j.finish() for j in jobs}
 
 
 def build_pk_variants() -> dict:
     """libnomad_hip_pk.so / libnomad_diag_pk.so: the same libraries WITH the packed-FP32 instructions, for A/B runs."""
-    jobs = []
-    for lib, diag in ((pk_path(LIB), False), (pk_path(DIAG_LIB), True)):
-        cmd, tmp = _command(lib, diag, False)
-        jobs.append((lib, tmp, time.perf_counter(), subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
-    took = {}
-    for lib, tmp, t0, proc in jobs:
-        _finish(proc, tmp, lib)
-        took[os.path.basename(lib)] = round(time.perf_counter() - t0, 1)
-    return took
+    jobs = [_Job(lib, diag) for lib, diag in ((pk_path(LIB), False), (pk_path(DIAG_LIB), True))]
+    return {os.path.basename(j.lib): j.finish() for j in jobs}
 
 
 if __name__ == "__main__":

@@ -9,7 +9,8 @@ namespace nomad {
 
 // per-workgroup timeline of the GEMM timing probes (gemm_bf16_8phase.hip.h ABL 7, gemm_f32.hip.h OPT bit 128; nomad_diag_timeline)
 constexpr int kTimelineSlots = 4096;
-__device__ unsigned long long g_timeline[kTimelineSlots * 6];
+// (static: this header is part of three translation units; each GEMM unit's probes write, and its reader reads, its own copy)
+static __device__ unsigned long long g_timeline[kTimelineSlots * 6];
 
 
 typedef __bf16 bf16_t;
@@ -79,26 +80,26 @@ __device__ __forceinline__ void store4p<bf16s_t>(bf16s_t* p, long long plane, fl
 }
 
 // fp32 -> split planes (weights at nomad_enable_bf16x3, test inputs).  out[0..n) = hi, out[plane..plane+n) = lo.
-__global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ in, bf16s_t* __restrict__ out,
+static __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ in, bf16s_t* __restrict__ out,
                                                          long long plane, long long n4) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256)
         store4p<bf16s_t>(out + 4 * i, plane, *reinterpret_cast<const float4*>(in + 4 * i));
 }
 // split planes -> fp32 (tests)
-__global__ __launch_bounds__(256) void unsplit_bf16_kernel(const bf16s_t* __restrict__ in, long long plane,
+static __global__ __launch_bounds__(256) void unsplit_bf16_kernel(const bf16s_t* __restrict__ in, long long plane,
                                                            float* __restrict__ out, long long n4) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256)
         *reinterpret_cast<float4*>(out + 4 * i) = load4p<bf16s_t>(in + 4 * i, plane);
 }
 
 // fp32 -> bf16 copy (weights at nomad_enable_bf16).  n % 4 == 0.
-__global__ __launch_bounds__(256) void to_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long long n4) {
+static __global__ __launch_bounds__(256) void to_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long long n4) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256)
         store4<bf16_t>(out + 4 * i, *reinterpret_cast<const float4*>(in + 4 * i));
 }
 
 // the same with the first `n4_scaled` float4 groups multiplied by `scale` (q rows of the fused QKV weight: log2 e)
-__global__ __launch_bounds__(256) void to_bf16_scaled_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long long n4,
+static __global__ __launch_bounds__(256) void to_bf16_scaled_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long long n4,
                                                              long long n4_scaled, float scale) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
         float4 v = *reinterpret_cast<const float4*>(in + 4 * i);
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void to_bf16_scaled_kernel(const float* __rest
     }
 }
 // out[i] = in[i] * (i < n_scaled ? scale : 1)   (fp32 bias of the fused QKV projection, q part)
-__global__ __launch_bounds__(256) void scale_head_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int n_scaled,
+static __global__ __launch_bounds__(256) void scale_head_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int n_scaled,
                                                          float scale) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = in[i] * (i < n_scaled ? scale : 1.0f);

@@ -11,20 +11,7 @@
 //   12 x { QKV GEMM -> attention -> out_proj GEMM (+bias,+x) -> LN -> fc1 GEMM (+bias,GELU)
 //          -> fc2 GEMM (+bias,+x) -> LN }
 //   head (mean_t, ReLU, Linear 768->256, L2 normalise)
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <atomic>
-#include <mutex>
-#include <string>
-#include <vector>
-
-#include "../../include/nomad_hip.h"
+#include "nomad_ctx.hip.h"
 
 // The device pass of this file is compiled WITHOUT the packed-FP32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 /
 // v_pk_add_f32 / v_pk_mov_b32: nomad_amd/build.py passes -target-feature -packed-fp32-ops).  DESIGN.md, "The packed-FP32
@@ -52,38 +39,7 @@
 #include "train.hip.h"
 #include "wav_reader.h"
 
-using namespace nomad;
-
 namespace {
-
-thread_local char g_err[512] = "";
-
-int fail(int code, const char* fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
-    va_end(ap);
-    return code;
-}
-
-#define HIP_TRY(expr)                                                                        \
-    do {                                                                                     \
-        hipError_t _e = (expr);                                                              \
-        if (_e != hipSuccess) return fail(NOMAD_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
-    } while (0)
-
-constexpr int kConvK[7] = {10, 3, 3, 3, 3, 2, 2};
-constexpr int kConvS[7] = {5, 2, 2, 2, 2, 2, 2};
-constexpr int kSplitKLayersMaxM = 4096;   // a forward that returns the layer outputs of fewer frames than this may split K (forward_impl)
-constexpr size_t kSplitKPartFloats = (size_t)4 * 512 * 64 * 64;  // 4 slices of the largest problem that is split (< 512 tiles of 64 x 64)
-constexpr long long kPairScratchDoubles = 1 << 21;  // 16 MB: e.g. 16 ref tiles x 131 072 deg rows per launch pair
-constexpr int kEventChunk = 8192;  // the profiling event pool grows by this many events whenever it runs out
-const int* const kNoInts = nullptr;  // "uniform batch" for the kernels' optional ragged-metadata pointers
-const hipStream_t kNoStream = reinterpret_cast<hipStream_t>(~uintptr_t(0));  // nomad_pairwise: a scratch block bound to no stream
-
-struct LayerDev {
-    float *qkv_w, *qkv_b, *o_w, *o_b, *ln1_w, *ln1_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b, *ln2_w, *ln2_b;
-};
 
 struct Shapes {
     int B, N, L[7], T, M;
@@ -311,204 +267,6 @@ ParamOffsets make_param_offsets() {
 
 }  // namespace
 
-// Kernel-choice switches.  Every default below is the shipped configuration, and the product library (libnomad_hip.so) never
-// reads the environment: "nothing but the arguments" decides what a call does.  Only libnomad_diag.so (-DNOMAD_DIAG) fills a
-// context's copy from NOMAD_* environment variables, once, in nomad_create (tuning_from_env) - the A/B runs of tools/ and profiles/.
-struct Tuning {
-    bool splitk_ln_fuse = true;    // NOMAD_SPLITK_LN: a split-K out_proj / fc2 normalises its rows in its own epilogue (splitk_epilogue_ln_kernel)
-    bool splitk_posconv = true;    // NOMAD_SPLITK_POSCONV: the grouped pos-conv of the loss path splits K four ways
-    bool splitk_layers = true;     // NOMAD_SPLITK_LAYERS: so do the dense GEMMs of a small layer-output forward
-    bool f32_plain_epi = true;     // NOMAD_F32_PLAIN_EPI: small epilogue for plain C / R matrices
-    bool f32_lean = true, f32_direct_epi = true, f32_skew = true, f32_res_ahead = true;   // NOMAD_F32_LEAN / _DIRECT_EPI / _SKEW / _RES_AHEAD
-    int f32_mixed = 1;             // NOMAD_F32_MIXED: two tile shapes in one launch
-    int f32_mixed_m1 = 0;          // NOMAD_F32_MIXED_M1: forced row split (diagnostics)
-    int f32_mixed_slots = 0;       // NOMAD_F32_MIXED_SLOTS: 0 = two workgroup slots per CU
-    double f32_mixed_min = 0.05, f32_mixed_max = 0.70;   // NOMAD_F32_MIXED_MIN / _MAX: fill of the last round that takes the split
-    bool f32_mixed_prefer = false; // NOMAD_F32_MIXED_PREFER
-    bool f32_quant_tile = true;    // NOMAD_F32_QUANT_TILE: tile choice by the largest tile count any CU gets
-    double f32_quant_penalty = 0.0;  // NOMAD_F32_QUANT_PENALTY (percent): 0 = 8 % with two concurrent parts, 3 % alone
-    bool f32_longk_33 = false;     // NOMAD_F32_LONGK_33
-    int f32_mid_tile = 31;         // NOMAD_F32_MID_TILE
-    bool f32_attn_struct_loads = false;  // NOMAD_F32_ATTN_STRUCT_LOADS (diag): the fp32 attention's LDS fragments as float4 struct copies (A/B)
-    bool bf16_posconv_slab = true;  // NOMAD_BF16_POSCONV_SLAB: the bf16 pos-conv with its input slab resident in LDS (posconv_bf16_slab.hip.h);
-                                    // false: the grouped GEMM on 128 x 64 tiles it replaces (A/B)
-    int bf16_attn_dma = 2;         // NOMAD_BF16_ATTN_DMA: K / V of the bf16 attention by LDS-DMA in 128-key tiles
-    int bf16_attn_v3 = 2;          // NOMAD_BF16_ATTN_V3: the bf16 attention on v_mfma_f32_16x16x32_bf16 with 32 queries per wave (2, shipped);
-                                   // 3: its V reads through the builtin; 4 / 8: 64 queries per wave, 4 / 8 waves per workgroup (A/B: no faster); 0: the 32x32x16 kernel
-    bool bf16_conv0_mfma = true;   // NOMAD_BF16_CONV0_MFMA
-    int p8_min_tiles = 256;        // NOMAD_BF16_8PHASE_MIN_TILES: smallest grid (256 x 256 tiles) for the deep-pipelined bf16 kernels
-    bool p8_nt_stores = true;      // NOMAD_BF16_NT_STORES
-    int p8_rpre = 3;               // NOMAD_BF16_RPRE
-    bool x3_plain_epi = true;      // NOMAD_X3_PLAIN_EPI
-    bool p8_three_b = true;        // NOMAD_BF16_B3
-    int p8_n192 = 0;               // NOMAD_BF16_N192
-    bool p9 = true;                // NOMAD_BF16_P9: the persistent 256 x 256 bf16 kernel wherever it applies
-    bool p9_res = true;            // NOMAD_BF16_P9_RES: residual GEMMs on the persistent kernel too (0: the one-tile-per-workgroup kernel, A/B)
-    bool p9_share = false;         // NOMAD_BF16_P9_SHARE: persistent launches of concurrent batch parts share the CUs (1 / parts each)
-    bool p9_tail_split = false;    // NOMAD_BF16_P9_TAIL: rows of a sparse last round of its tiles go to the 128 x 128 kernel (+4-17 % on the
-                                   // N = 768 GEMMs alone, -3 % in the two-stream forward, where the other half's kernels fill that round)
-    int p9_short = 1;              // NOMAD_BF16_P9_SHORT: 192-row tiles of the persistent kernel (a run-time mode of the same instantiation) where they
-                                   // save more than they cost: 1 = by the round count, batches that run alone only (the N = 768 GEMMs of config C5 on one
-                                   // stream), 2 = every problem, 0 = never
-    bool attn_bwd_small = true;    // NOMAD_ATTN_BWD_SMALL: clips of at most 64 frames take the fused attention backward (one launch; 0: rowdot + dkv + dq)
-    int p9_skew = 0;               // NOMAD_BF16_P9_SKEW (diag, timeline probe tile 61 only): start skew between workgroup groups, units of 10 ns
-    int concurrent_parts = 1;      // nomad_set_concurrent_parts: batches the host layer runs concurrently on separate streams
-};
-
-#ifdef NOMAD_DIAG
-static void tuning_from_env(Tuning& t) {
-    auto geti = [](const char* n, int d) { const char* e = getenv(n); return e ? atoi(e) : d; };
-    auto getb = [](const char* n, bool d) { const char* e = getenv(n); return e ? atoi(e) != 0 : d; };
-    auto getd = [](const char* n, double d) { const char* e = getenv(n); return e ? atof(e) : d; };
-    t.splitk_ln_fuse = getb("NOMAD_SPLITK_LN", t.splitk_ln_fuse);
-    t.splitk_posconv = getb("NOMAD_SPLITK_POSCONV", t.splitk_posconv);
-    t.splitk_layers = getb("NOMAD_SPLITK_LAYERS", t.splitk_layers);
-    t.f32_plain_epi = getb("NOMAD_F32_PLAIN_EPI", t.f32_plain_epi);
-    t.f32_lean = getb("NOMAD_F32_LEAN", t.f32_lean);
-    t.f32_direct_epi = getb("NOMAD_F32_DIRECT_EPI", t.f32_direct_epi);
-    t.f32_skew = getb("NOMAD_F32_SKEW", t.f32_skew);
-    t.f32_res_ahead = getb("NOMAD_F32_RES_AHEAD", t.f32_res_ahead);
-    t.f32_mixed = geti("NOMAD_F32_MIXED", t.f32_mixed);
-    t.f32_mixed_m1 = geti("NOMAD_F32_MIXED_M1", t.f32_mixed_m1);
-    t.f32_mixed_slots = geti("NOMAD_F32_MIXED_SLOTS", t.f32_mixed_slots);
-    t.f32_mixed_min = getd("NOMAD_F32_MIXED_MIN", t.f32_mixed_min);
-    t.f32_mixed_max = getd("NOMAD_F32_MIXED_MAX", t.f32_mixed_max);
-    t.f32_mixed_prefer = getb("NOMAD_F32_MIXED_PREFER", t.f32_mixed_prefer);
-    t.f32_quant_tile = getb("NOMAD_F32_QUANT_TILE", t.f32_quant_tile);
-    t.f32_quant_penalty = getd("NOMAD_F32_QUANT_PENALTY", t.f32_quant_penalty);
-    t.f32_longk_33 = getb("NOMAD_F32_LONGK_33", t.f32_longk_33);
-    t.f32_mid_tile = geti("NOMAD_F32_MID_TILE", t.f32_mid_tile);
-    t.bf16_attn_dma = geti("NOMAD_BF16_ATTN_DMA", t.bf16_attn_dma);
-    t.f32_attn_struct_loads = geti("NOMAD_F32_ATTN_STRUCT_LOADS", t.f32_attn_struct_loads) != 0;
-    t.bf16_posconv_slab = geti("NOMAD_BF16_POSCONV_SLAB", t.bf16_posconv_slab) != 0;
-    t.bf16_attn_v3 = geti("NOMAD_BF16_ATTN_V3", t.bf16_attn_v3);
-    t.bf16_conv0_mfma = getb("NOMAD_BF16_CONV0_MFMA", t.bf16_conv0_mfma);
-    t.p8_min_tiles = geti("NOMAD_BF16_8PHASE_MIN_TILES", t.p8_min_tiles);
-    t.p8_nt_stores = getb("NOMAD_BF16_NT_STORES", t.p8_nt_stores);
-    t.p8_rpre = geti("NOMAD_BF16_RPRE", t.p8_rpre);
-    t.x3_plain_epi = getb("NOMAD_X3_PLAIN_EPI", t.x3_plain_epi);
-    t.p8_three_b = getb("NOMAD_BF16_B3", t.p8_three_b);
-    t.p8_n192 = geti("NOMAD_BF16_N192", t.p8_n192);
-    t.p9 = getb("NOMAD_BF16_P9", t.p9);
-    t.p9_tail_split = getb("NOMAD_BF16_P9_TAIL", t.p9_tail_split);
-    t.p9_share = getb("NOMAD_BF16_P9_SHARE", t.p9_share);
-    t.p9_res = getb("NOMAD_BF16_P9_RES", t.p9_res);
-    t.p9_short = geti("NOMAD_BF16_P9_SHORT", t.p9_short);
-    t.p9_skew = geti("NOMAD_BF16_P9_SKEW", t.p9_skew);
-    t.attn_bwd_small = getb("NOMAD_ATTN_BWD_SMALL", t.attn_bwd_small);
-}
-#endif
-
-struct nomad_ctx {
-    int device = 0;
-    int num_cus = 256;   // multiProcessorCount (the persistent GEMM launches two workgroups per CU)
-    Tuning tune;
-    bool keep = false;
-    // repacked weights (device)
-    float* conv0_w = nullptr;            // [512][10]
-    float* conv_w[7] = {};               // i>=1: [512][k*512] with k index = tap*512 + cin
-    float *gn_w = nullptr, *gn_b = nullptr, *fln_w = nullptr, *fln_b = nullptr;
-    float *proj_w = nullptr, *proj_b = nullptr;
-    float *pos_w = nullptr, *pos_b = nullptr;  // [16][64][6144] (rows 48..63 zero), k = tap*48 + cin
-    float *eln_w = nullptr, *eln_b = nullptr;
-    LayerDev layers[NOMAD_NUM_LAYERS] = {};
-    float *emb_w = nullptr, *emb_b = nullptr;
-    // Split-K for the small-M GEMMs of Nomad.forward()'s loss forward / backward (config C4: M = 1600 rows): partial
-    // products of up to 4 K-slices, allocated by nomad_enable_backward; splitk_ok is raised for the duration of such a
-    // call only (never for scoring forwards, whose bits must not depend on the batch; never in fine-tuning mode)
-    float* splitk_part = nullptr;
-    // (the no-gradient branches of Nomad.forward() - layer outputs wanted, nothing saved - take their partial-sum block from the
-    // call's own workspace: Layout::splitk)
-    float* splitk_cur = nullptr;                            // the block of the call being enqueued
-    bool splitk_ok = false;
-    // A LayerNorm(768) the caller will apply to the output of the NEXT dense GEMM (run_layer: out_proj -> LN, fc2 -> LN): when that GEMM
-    // splits K, its epilogue normalises the rows itself (splitk_epilogue_ln_kernel) and sets `done`; otherwise the caller launches the
-    // stand-alone LayerNorm.  Per context, set and consumed inside one forward call.
-    struct PendingLn {
-        const float* gamma = nullptr;
-        const float* beta = nullptr;
-        float* out = nullptr;
-        float* out2 = nullptr;
-        bool armed = false, done = false;
-    } pending_ln;
-    // nomad_pairwise: row sums per (64-ref tile, deg row), kPairScratchDoubles doubles PER LAUNCH STREAM - calls on
-    // different streams of one context may be in flight together (Engine / ShardedScorer are driven from side streams), so
-    // each stream gets its own block: the first at nomad_create, further ones on a stream's first call
-    std::vector<std::pair<hipStream_t, double*>> pair_scratch;   // (kNoStream: block not bound to a stream)
-    std::mutex pair_mu;   // guards pair_scratch: nomad_pairwise may be called from several host threads (one stream each)
-    // transposed copies for the dX-only backward (built by nomad_enable_backward)
-    bool bwd_ready = false;
-    float* conv_bw_even[7] = {};  // k=3 layers 1..4: [512][1024] = [W_tap2^T | W_tap0^T]
-    float* conv_bw_odd[7] = {};   // k=3 layers 1..4: [512][512]  = W_tap1^T
-    float* conv_bw2[7] = {};      // k=2 layers 5,6: [1024][512]
-    float* proj_wT = nullptr;     // [512][768]
-    float* pos_wb = nullptr;      // [16][64][6144], taps flipped
-    float *qkv_wT[NOMAD_NUM_LAYERS] = {}, *o_wT[NOMAD_NUM_LAYERS] = {}, *fc1_wT[NOMAD_NUM_LAYERS] = {},
-          *fc2_wT[NOMAD_NUM_LAYERS] = {};
-    // bf16 weight copies for the bf16 path (built by nomad_enable_bf16); biases and norm parameters stay fp32
-    bool bf16_ready = false;
-    bf16_t* conv_w16[7] = {};
-    bf16_t* conv0_wfrag = nullptr;       // conv0's MFMA A operands [8][4][64][8] (conv0_wfrag_kernel): bf16 path
-    bf16_t *proj_w16 = nullptr, *pos_w16 = nullptr;
-    bf16_t* pos_wfrag16 = nullptr;        // the pos-conv weights in MFMA fragment order (posconv_wfrag_kernel): bf16 path
-    bf16_t *qkv_w16[NOMAD_NUM_LAYERS] = {}, *o_w16[NOMAD_NUM_LAYERS] = {}, *fc1_w16[NOMAD_NUM_LAYERS] = {},
-           *fc2_w16[NOMAD_NUM_LAYERS] = {};
-    // the bf16 path's q rows of the fused QKV weight and bias also carry log2(e): its attention kernel works in log2
-    // units (p = 2^(s - m), attention_bf16_v2.hip.h); qkv_b16 is the matching fp32 bias
-    float* qkv_b16[NOMAD_NUM_LAYERS] = {};
-    // split (hi | lo bf16 planes) weight copies for the bf16x3 path (built by nomad_enable_bf16x3)
-    bool x3_ready = false;
-    bf16s_t* conv_wx[7] = {};
-    bf16s_t* proj_wx = nullptr;
-    bf16s_t* pos_wx = nullptr;   // Toeplitz form [16][256][kPosKt] (posconv_toeplitz_kernel)
-    float* pos_bx = nullptr;     // [16][256]
-    bf16s_t *qkv_wx[NOMAD_NUM_LAYERS] = {}, *o_wx[NOMAD_NUM_LAYERS] = {}, *fc1_wx[NOMAD_NUM_LAYERS] = {},
-            *fc2_wx[NOMAD_NUM_LAYERS] = {};
-    // fine-tuning state (nomad_train_enable): master parameters, gradients, Adam moments; see ParamOffsets
-    bool train_ready = false;
-    float *theta = nullptr, *grad = nullptr, *adam_m = nullptr, *adam_v = nullptr;
-    double *pos_nrm2 = nullptr, *tap_partial = nullptr, *tap_dot = nullptr;
-    long long adam_t = 0;
-    // model.train() regularisation applied by nomad_embed_train / nomad_train_backward (nomad_train_set_stochastic)
-    float p_drop = 0.f, p_attn = 0.f, p_input = 0.f;
-    // fairseq Wav2Vec2Model.feature_grad_mult: the gradient entering the conv feature extractor is scaled by this
-    // (GradMultiply on the extractor's output); 0.1 in the wav2vec 2.0 BASE config that wav2vec_small.pt carries
-    float feature_grad_mult = 0.1f;
-    // nomad_set_gemm_precision: 1 = the fp32-layout GEMMs (forward, nomad_embed_train, backward, dW) form their products as
-    // three bf16 MFMA products over hi / lo halves split in registers (gemm_f32_glds_kernel<..., X3>); buffers stay fp32
-    int gemm_x3 = 0;
-    unsigned long long drop_seed = 0;
-    unsigned layer_mask = 0xFFFu;  // bit l set: encoder layer l runs (LayerDrop clears bits)
-    // A training batch may be several equal groups of clips ("branches": anchor | positive | negative), each with
-    // its own LayerDrop mask, as if each had been its own forward call (nomad_train_set_branches)
-    bool train_convnet = false;    // config freeze_convnet: False - the conv feature extractor's parameters get gradients (nomad_train_set_convnet)
-    bool freeze_encoder = false;   // config freeze_all: the encoder's parameters get no gradient (nomad_train_set_frozen)
-    int branches = 1;
-    unsigned branch_mask[4] = {0xFFFu, 0xFFFu, 0xFFFu, 0xFFFu};
-    std::vector<void*> allocs;
-    // host copies of the last ragged batches' metadata (sources of asynchronous H2D copies); a ring, so that two
-    // forwards enqueued back to back on different streams do not share a staging vector
-    std::vector<int> ragged_meta_ring[4];
-    unsigned ragged_seq = 0;
-    // profiling
-    bool prof = false;
-    std::vector<hipEvent_t> ev;   // grows on demand (Scope): a long timed region is never silently truncated
-    std::vector<int> ev_class;
-    int ev_used = 0;
-    double p_ms[NOMAD_K_COUNT] = {};
-    long long p_n[NOMAD_K_COUNT] = {};
-    double p_fl[NOMAD_K_COUNT] = {};
-    bool ev_ready = false;
-    bool prof_overflow = false;   // an event could not be created: the counters are incomplete and profile_read says so
-    // libnomad_diag.so only (nomad_diag_set_cksum): per-stage, per-clip checksums of the NEXT bf16 forward's intermediates
-    unsigned long long* cksum = nullptr;
-    int cksum_stages = 0, cksum_segs = 0;
-    // ... and device-to-device copies of up to 4 of those stages' buffers (nomad_diag_set_snapshot)
-    int snap_stage[4] = {-1, -1, -1, -1};
-    void* snap_dst[4] = {};
-    size_t snap_cap[4] = {};
-};
-
 namespace {
 
 int upload(nomad_ctx* c, const float* host, size_t n, float** out) {
@@ -520,55 +278,6 @@ int upload(nomad_ctx* c, const float* host, size_t n, float** out) {
     return 0;
 }
 
-// Brackets one launch with events when profiling is on.
-struct Scope {
-    nomad_ctx* c;
-    hipStream_t s;
-    int slot = -1;
-    // cls2 (optional): a sub-class that receives the same time / launch / FLOP counts
-    Scope(nomad_ctx* c_, hipStream_t s_, int cls, double flops, int cls2 = -1) : c(c_), s(s_) {
-        if (!c->prof) return;
-        if (c->ev_used + 2 > (int)c->ev.size()) {  // pool used up: grow it (event creation is host-only work)
-            const size_t old = c->ev.size();
-            c->ev.resize(old + kEventChunk);
-            c->ev_class.resize((old + kEventChunk) / 2);
-            for (size_t i = old; i < c->ev.size(); ++i)
-                if (hipEventCreate(&c->ev[i]) != hipSuccess) {  // out of events: stop profiling LOUDLY (profile_read fails)
-                    for (size_t j = old; j < i; ++j) (void)hipEventDestroy(c->ev[j]);
-                    c->ev.resize(old);
-                    c->ev_class.resize(old / 2);
-                    c->prof_overflow = true;
-                    return;
-                }
-        }
-        c->p_fl[cls] += flops;
-        c->p_n[cls] += 1;
-        if (cls2 >= 0) {
-            c->p_fl[cls2] += flops;
-            c->p_n[cls2] += 1;
-        }
-        slot = c->ev_used;
-        c->ev_class[slot / 2] = cls | ((cls2 + 1) << 8);
-        c->ev_used += 2;
-        (void)hipEventRecord(c->ev[slot], s);
-    }
-    ~Scope() {
-        if (slot >= 0) (void)hipEventRecord(c->ev[slot + 1], s);
-    }
-};
-
-RowMap plain_map(int M, int ld) { return RowMap{0, 0, M > 0 ? M : 1, ld}; }
-
-// LDS padding that limits residency to `occ` workgroups per CU (0 = no limit) for a kernel using `lds` bytes.
-int occ_pad(int occ, int lds) {
-    if (occ <= 0) return 0;
-    const int budget = (160 * 1024 / occ) & ~255;
-    return budget > lds ? budget - lds : 0;
-}
-
-int mixed_split_rows(const nomad_ctx* c, int M, int N);   // (below, next to pick_tile)
-
-int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, int occ = 0);
 
 // Small-M dense GEMMs of the loss forward / backward (config C4: M = 1600): N = 768 is 300 tiles of 64 x 64 on 256 CUs,
 // 44 CUs get two tiles and the launch takes two tiles' time (fc2: 82 us where a balanced split would take 48).  The
@@ -653,7 +362,7 @@ static int run_posconv_splitk(nomad_ctx* c, const GemmParams& p, hipStream_t s) 
     q.gelu = 0;
     {
         Scope sc(c, s, NOMAD_K_GEMM, 2.0 * p.M * 48.0 * p.K * 16, NOMAD_K_GEMM_FINE);
-        HIP_TRY(launch_gemm_n48<true>(q, 16, s, S));
+        HIP_TRY(gemm_f32_n48_split(q, 16, s, S));
     }
     Scope sc(c, s, NOMAD_K_ROW, 0.0);
     hipLaunchKernelGGL(posconv_splitk_epilogue_kernel, dim3(p.M), dim3(192), 0, s, c->splitk_cur, S, p.M, p.bias, p.R, p.rmap, p.r_goff, p.Upre, p.C,
@@ -662,292 +371,20 @@ static int run_posconv_splitk(nomad_ctx* c, const GemmParams& p, hipStream_t s) 
     return 0;
 }
 
+}  // namespace
+
+// split-K wrappers in front of the fp32 GEMM dispatch (nomad_gemm_f32.hip)
 int run_gemm(nomad_ctx* c, GemmParams p, int groups, int tile, hipStream_t s, int occ) {
     {
         int S = 0;
         if (splitk_applies(c, p, groups, tile, &S)) return run_gemm_splitk(c, p, S, s);
         if (posconv_splitk_applies(c, p, groups, tile)) return run_posconv_splitk(c, p, s);
     }
-    if (tile == 29 && occ == 0) occ = 4;  // measured: 4 workgroups/CU is the best residency for the 128x64x32 kernel
-    const double flops = 2.0 * p.M * (double)p.n_valid * p.K * groups;
-    Scope sc(c, s, NOMAD_K_GEMM, flops, tile == 33 ? NOMAD_K_GEMM_BIG : ((tile == 34 || tile == 31 || tile == 48) ? NOMAD_K_GEMM_FINE : -1));
-    hipError_t e;
-    if (c->gemm_x3 && tile == 48 && p.N == 64)
-        tile = 37;  // bf16x3 products: the grouped pos-conv on the generic 64 x 64 tile (N padded 48 -> 64: a quarter of the MFMAs
-                    // wasted, but 6 bf16 MFMAs of 32 cycles per 32-deep k range instead of 48 fp32 ones of 32 in the N = 48 kernel)
-    if (c->gemm_x3 && (tile == 31 || tile == 34 || tile == 37) && p.N % 128 == 0 &&
-        (long long)((p.M + 127) / 128) * (p.N / 128) >= 512)
-        tile = 20;  // bf16x3 products: a 64 x 64 wave tile (128 x 128, 4 waves) does 12 MFMAs per 4 fragment splits where the
-                    // 32 x 32 one does 3 per 2 - the split is VALU work - so it is taken as soon as it fills two rounds of CUs
-    // plain C / R (/ Upre / DG) matrices: the instantiations with the small, residual-prefetching epilogue (gemm_f32.hip.h, OPT bits
-    // 16 / 32) - every GEMM of the uniform scoring forward but the pos-conv's neighbours.  NOMAD_F32_PLAIN_EPI=0: the general
-    // epilogue (A/B runs)
-    const bool plain_cr = c->tune.f32_plain_epi && p.c_colblk == 0 && p.cmap.clip_rows >= p.M && !p.cmap.pref &&
-                          (!p.R || (p.rmap.clip_rows >= p.M && !p.rmap.pref)) && (!p.DG || (p.dgmap.clip_rows >= p.M && !p.dgmap.pref));
-    if (c->gemm_x3 && plain_cr && (tile == 20 || tile == 31 || tile == 34 || tile == 37)) {   // (not 33: its X3 form needs 146 VGPRs)
-        constexpr int T = 16 | 32;   // one plain instantiation per tile for scoring and training alike (this mode is the small-batch / training one)
-        switch (tile) {
-            case 20: e = launch_gemm_glds<128, 128, 32, 2, 2, 2, false, 12 | T, true>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 2, 2>::LDS_BYTES)); break;
-            case 31: e = launch_gemm_glds<128, 128, 32, 4, 2, 2, false, 12 | T, true>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 4, 2>::LDS_BYTES)); break;
-            case 34: e = launch_gemm_glds<128, 64, 32, 4, 2, 3, false, 12 | T, true>(p, groups, s); break;
-            default: e = launch_gemm_glds<64, 64, 32, 2, 2, 3, false, 12 | T, true>(p, groups, s); break;
-        }
-        if (e != hipSuccess) return fail(NOMAD_ERR_HIP, "gemm (bf16x3 products) launch: %s", hipGetErrorString(e));
-        return 0;
-    }
-    if (c->gemm_x3 && (tile == 20 || tile == 31 || tile == 33 || tile == 34 || tile == 37)) {
-        // bf16x3 products on the same fp32 operands (nomad_set_gemm_precision): same tiles, staging and epilogues
-        switch (tile) {
-            case 20: e = launch_gemm_glds<128, 128, 32, 2, 2, 2, false, 12, true>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 2, 2>::LDS_BYTES)); break;
-            case 31: e = launch_gemm_glds<128, 128, 32, 4, 2, 2, false, 12, true>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 4, 2>::LDS_BYTES)); break;
-            case 33: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13, true>(p, groups, s); break;
-            case 34: e = launch_gemm_glds<128, 64, 32, 4, 2, 3, false, 12, true>(p, groups, s); break;
-            default: e = launch_gemm_glds<64, 64, 32, 2, 2, 3, false, 12, true>(p, groups, s); break;
-        }
-        if (e != hipSuccess) return fail(NOMAD_ERR_HIP, "gemm (bf16x3 products) launch: %s", hipGetErrorString(e));
-        return 0;
-    }
-    if (plain_cr && (tile == 33 || tile == 31 || tile == 37 || tile == 34 || tile == 20)) {
-        constexpr int P = 16, T = 16 | 32;   // plain epilogue; + the training side operands (Upre / DG)
-        const bool tr = p.Upre || p.DG;
-        // Round 4 (gemm_f32.hip.h OPT bits 16384 / 64 / 1024; profiles/r04_gemm_f32_variants.txt): the scoring GEMMs on uniform
-        // clip maps take the lean set-up (magic-number divisions on the scalar unit), the 256 x 128 tile also the skewed K
-        // loop, and GEMMs without a residual the direct epilogue from transposed accumulators.  All bit-identical to the plain
-        // instantiations.  NOMAD_F32_LEAN=0 / NOMAD_F32_DIRECT_EPI=0 / NOMAD_F32_SKEW=0 switch them off (A/B runs).
-        const int variants = (c->tune.f32_lean ? 1 : 0) | (c->tune.f32_direct_epi ? 2 : 0) | (c->tune.f32_skew ? 4 : 0) | (c->tune.f32_res_ahead ? 8 : 0);
-        // (a divisor of 1 - clips of ONE row, the shortest legal input - has no 32-bit magic number: those stay on the general set-up)
-        const bool lean = (variants & 1) && !tr && !p.amap.pref && p.group_m == 0 && p.kchunk >= p.K &&
-                          (p.amap.clip_rows >= p.M || p.amap.clip_rows >= 2);
-        const bool direct = lean && (variants & 2) && !p.R && p.n_valid == p.N;
-        const bool skew = lean && (variants & 4);
-        // residual GEMMs (out_proj, fc2; no GELU): the residual of the next slab loaded ahead of the current slab's stores (OPT bit 32768)
-        const bool ahead = lean && (variants & 8) && p.R && !p.gelu && p.n_valid == p.N && p.rmap.clip_rows >= p.M;
-        constexpr int L = 16384, D = 1024, S = 64, RA = 32768;
-        // two tile shapes in one launch when the last round of 256 x 128 tiles would be sparsely filled
-        if (lean && skew && tile == 33 && groups == 1 && (p.R ? ahead : direct)) {
-            // (sending the launches that need no split through the same kernel as well - one instantiation less alternating between
-            // the launches of a transformer layer - changes nothing: 2405 vs 2408 clips/s)
-            const int m1 = mixed_split_rows(c, p.M, p.N);
-            if (m1 > 0) {
-                e = p.R ? launch_gemm_mixed<13 | P | L | S | RA, 13 | P | L | S | RA>(p, m1, s)
-                        : launch_gemm_mixed<13 | P | L | S | D, 13 | P | L | S | D>(p, m1, s);
-                if (e != hipSuccess) return fail(NOMAD_ERR_HIP, "gemm launch: %s", hipGetErrorString(e));
-                return 0;
-            }
-        }
-        if (ahead && tile == 33 && skew) {
-            e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | P | L | S | RA>(p, groups, s);
-            if (e != hipSuccess) return fail(NOMAD_ERR_HIP, "gemm launch: %s", hipGetErrorString(e));
-            return 0;
-        }
-        if (ahead && tile == 31) {
-            e = launch_gemm_glds<128, 128, 32, 4, 2, 2, false, 12 | P | L | RA>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 4, 2>::LDS_BYTES));
-            if (e != hipSuccess) return fail(NOMAD_ERR_HIP, "gemm launch: %s", hipGetErrorString(e));
-            return 0;
-        }
-        if (lean && tile == 33) {
-            e = direct ? (skew ? launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | P | L | S | D>(p, groups, s) : launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | P | L | D>(p, groups, s))
-                       : (skew ? launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | P | L | S>(p, groups, s) : launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | P | L>(p, groups, s));
-            if (e != hipSuccess) return fail(NOMAD_ERR_HIP, "gemm launch: %s", hipGetErrorString(e));
-            return 0;
-        }
-        if (lean && tile == 31) {
-            e = direct ? launch_gemm_glds<128, 128, 32, 4, 2, 2, false, 12 | P | L | D>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 4, 2>::LDS_BYTES))
-                       : launch_gemm_glds<128, 128, 32, 4, 2, 2, false, 12 | P | L>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 4, 2>::LDS_BYTES));
-            if (e != hipSuccess) return fail(NOMAD_ERR_HIP, "gemm launch: %s", hipGetErrorString(e));
-            return 0;
-        }
-        if (lean && (tile == 37 || tile == 34 || tile == 20)) {   // the small-problem tiles (batch 1 .. config C4): one round of workgroups, the set-up is a visible part of each
-            switch (tile) {
-                case 37: e = direct ? launch_gemm_glds<64, 64, 32, 2, 2, 3, false, 12 | P | L | D>(p, groups, s) : launch_gemm_glds<64, 64, 32, 2, 2, 3, false, 12 | P | L>(p, groups, s); break;
-                case 34: e = direct ? launch_gemm_glds<128, 64, 32, 4, 2, 3, false, 12 | P | L | D>(p, groups, s) : launch_gemm_glds<128, 64, 32, 4, 2, 3, false, 12 | P | L>(p, groups, s); break;
-                default: e = direct ? launch_gemm_glds<128, 128, 32, 2, 2, 2, false, 12 | P | L | D>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 2, 2>::LDS_BYTES))
-                                    : launch_gemm_glds<128, 128, 32, 2, 2, 2, false, 12 | P | L>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 2, 2>::LDS_BYTES)); break;
-            }
-            if (e != hipSuccess) return fail(NOMAD_ERR_HIP, "gemm launch: %s", hipGetErrorString(e));
-            return 0;
-        }
-        switch (tile) {
-            case 33: e = tr ? launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | T>(p, groups, s) : launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | P>(p, groups, s); break;
-            case 31: e = tr ? launch_gemm_glds<128, 128, 32, 4, 2, 2, false, 12 | T>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 4, 2>::LDS_BYTES))
-                            : launch_gemm_glds<128, 128, 32, 4, 2, 2, false, 12 | P>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 4, 2>::LDS_BYTES)); break;
-            case 20: e = tr ? launch_gemm_glds<128, 128, 32, 2, 2, 2, false, 12 | T>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 2, 2>::LDS_BYTES))
-                            : launch_gemm_glds<128, 128, 32, 2, 2, 2, false, 12 | P>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 2, 2>::LDS_BYTES)); break;
-            case 34: e = tr ? launch_gemm_glds<128, 64, 32, 4, 2, 3, false, 12 | T>(p, groups, s) : launch_gemm_glds<128, 64, 32, 4, 2, 3, false, 12 | P>(p, groups, s); break;
-            default: e = tr ? launch_gemm_glds<64, 64, 32, 2, 2, 3, false, 12 | T>(p, groups, s) : launch_gemm_glds<64, 64, 32, 2, 2, 3, false, 12 | P>(p, groups, s); break;
-        }
-        if (e != hipSuccess) return fail(NOMAD_ERR_HIP, "gemm launch: %s", hipGetErrorString(e));
-        return 0;
-    }
-    switch (tile) {
-        // the instantiations pick_tile() / the pos-conv can select
-        case 20: e = launch_gemm_glds<128, 128, 32, 2, 2, 2, false, 12>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 2, 2>::LDS_BYTES)); break;
-        case 31: e = launch_gemm_glds<128, 128, 32, 4, 2, 2, false, 12>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 4, 2>::LDS_BYTES)); break;
-        case 33: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13>(p, groups, s); break;   // 3-stage LDS-DMA pipeline (buffer_load..lds, issued mid-cluster), counted vmcnt
-        case 34: e = launch_gemm_glds<128, 64, 32, 4, 2, 3, false, 12>(p, groups, s); break;
-        case 37: e = launch_gemm_glds<64, 64, 32, 2, 2, 3, false, 12>(p, groups, s); break;
-        case 48: e = launch_gemm_n48<true>(p, groups, s); break;    // N = 48 exactly (16x16x4 MFMA): the grouped pos-conv
-#ifdef NOMAD_DIAG
-        // experimental instantiations and ablations (libnomad_diag.so; tools/gemm_sweep.py, tests of the experimental tiles)
-        case 0: e = launch_gemm<128, 128, 32, 2, 2>(p, groups, s); break;
-        case 1: e = launch_gemm<128, 64, 16, 2, 2>(p, groups, s); break;
-        case 2: e = launch_gemm<64, 64, 32, 2, 2>(p, groups, s); break;
-        // experimental instantiations (tools/gemm_sweep.py)
-        case 3: e = launch_gemm<128, 128, 16, 2, 2>(p, groups, s); break;
-        case 4: e = launch_gemm<256, 128, 32, 4, 2>(p, groups, s); break;
-        case 5: e = launch_gemm<256, 256, 32, 4, 2>(p, groups, s); break;
-        case 6: e = launch_gemm<256, 128, 16, 4, 2>(p, groups, s); break;
-        case 7: e = launch_gemm<128, 256, 32, 2, 2>(p, groups, s); break;
-        case 8: e = launch_gemm<256, 256, 16, 4, 2>(p, groups, s); break;
-        case 9: e = launch_gemm<128, 128, 16, 4, 2>(p, groups, s, 16 * 1024); break;   // 8 waves, forced 2 WG/CU
-        case 10: e = launch_gemm<128, 128, 16, 2, 4>(p, groups, s, 16 * 1024); break;
-        case 11: e = launch_gemm<128, 128, 32, 4, 2>(p, groups, s); break;
-        case 12: e = launch_gemm<128, 128, 32, 2, 4>(p, groups, s); break;
-        case 13: e = launch_gemm<128, 128, 16, 4, 2>(p, groups, s); break;               // 3 WG/CU if registers allow
-        case 21: e = launch_gemm_glds<256, 128, 16, 4, 2>(p, groups, s, occ_pad(occ, GldsCfg<256, 128, 16, 4, 2>::LDS_BYTES)); break;
-        case 22: e = launch_gemm_glds<128, 128, 16, 4, 2>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 16, 4, 2>::LDS_BYTES)); break;
-        case 23: e = launch_gemm_glds<256, 128, 32, 4, 2>(p, groups, s, occ_pad(occ, GldsCfg<256, 128, 32, 4, 2>::LDS_BYTES)); break;
-        case 24: e = launch_gemm_glds<256, 256, 16, 4, 2>(p, groups, s, occ_pad(occ, GldsCfg<256, 256, 16, 4, 2>::LDS_BYTES)); break;
-        case 25: e = launch_gemm_glds<256, 256, 32, 4, 2>(p, groups, s, occ_pad(occ, GldsCfg<256, 256, 32, 4, 2>::LDS_BYTES)); break;
-        case 26: e = launch_gemm_glds<128, 128, 16, 2, 2>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 16, 2, 2>::LDS_BYTES)); break;
-        case 27: e = launch_gemm_glds<256, 256, 16, 4, 4>(p, groups, s, occ_pad(occ, GldsCfg<256, 256, 16, 4, 4>::LDS_BYTES)); break;
-        case 28: e = launch_gemm_glds<128, 64, 16, 2, 2>(p, groups, s, occ_pad(occ, GldsCfg<128, 64, 16, 2, 2>::LDS_BYTES)); break;
-        case 29: e = launch_gemm_glds<128, 64, 32, 4, 2>(p, groups, s, occ_pad(occ, GldsCfg<128, 64, 32, 4, 2>::LDS_BYTES)); break;
-        case 30: e = launch_gemm_glds<128, 64, 32, 2, 2>(p, groups, s, occ_pad(occ, GldsCfg<128, 64, 32, 2, 2>::LDS_BYTES)); break;
-        case 32: e = launch_gemm_glds<256, 128, 16, 4, 2, 2, true>(p, groups, s); break;  // ablation: no epilogue stores
-        case 35: e = launch_gemm_glds<256, 128, 32, 4, 2, 3>(p, groups, s); break;
-        case 36: e = launch_gemm_glds<64, 32, 32, 2, 1, 3>(p, groups, s); break;    // small problems: many small workgroups
-        case 38: e = launch_gemm_glds<128, 32, 32, 4, 1, 3>(p, groups, s); break;
-        case 39: e = launch_gemm_glds<32, 32, 32, 1, 1, 3>(p, groups, s); break;
-        case 40: e = launch_gemm_glds<256, 256, 16, 4, 4, 3>(p, groups, s); break;   // one 16-wave workgroup per CU
-        case 41: e = launch_gemm_glds<256, 256, 16, 4, 4, 2>(p, groups, s); break;
-        case 42: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 0>(p, groups, s); break;   // t33 with workgroup barriers between epilogue slabs
-        case 43: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 3>(p, groups, s); break;   // t33 + s_setprio around the MFMAs (-4 %)
-        case 44: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 1>(p, groups, s); break;            // t33 with global_load_lds (64-bit per-lane pointers)
-        case 45: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 5>(p, groups, s); break;            // t33 with the DMA issued right behind the barrier
-        case 49: e = launch_gemm_n48<false>(p, groups, s); break;   // A/B: global_load_lds instead of buffer_load..lds   // N = 48 exactly (16x16x4 MFMA): the grouped pos-conv
-        // round 4: fewer, fatter waves and the skewed schedule (OPT bit 64); plain C / R operands only (nomad_diag_gemm's are)
-        case 60: e = launch_gemm_glds<256, 128, 16, 2, 2, 3, false, 13 | 16>(p, groups, s); break;        // 4 waves of 128 x 64, straight schedule
-        case 61: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, true, 13 | 16>(p, groups, s); break;         // production tile 33 without its epilogue stores
-        case 62: e = launch_gemm_glds<128, 128, 16, 2, 2, 3, false, 13 | 16>(p, groups, s); break;        // 4 waves of 64 x 64, 48 KB: 3 workgroups / CU
-        case 63: e = launch_gemm_glds<256, 128, 16, 2, 2, 3, true, 13 | 16 | 64>(p, groups, s); break;    // tile 65 without its epilogue stores
-        case 64: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 64>(p, groups, s); break;   // production tile, skewed schedule
-        case 65: e = launch_gemm_glds<256, 128, 16, 2, 2, 3, false, 13 | 16 | 64>(p, groups, s); break;   // 4 waves of 128 x 64, skewed schedule
-        case 66: e = launch_gemm_glds<128, 128, 16, 2, 2, 3, false, 13 | 16 | 64>(p, groups, s); break;   // 4 waves of 64 x 64, skewed, 3 workgroups / CU
-        case 67: e = launch_gemm_glds<128, 256, 16, 2, 2, 3, false, 13 | 16 | 64>(p, groups, s); break;   // 4 waves of 64 x 128, skewed
-        case 68: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 128>(p, groups, s); break;  // production tile + per-workgroup timeline stamps (nomad_diag_timeline)
-        case 69: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, true, 13 | 16 | 128>(p, groups, s); break;   // ... without the epilogue stores
-        case 70: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 256>(p, groups, s); break;  // production tile, output stores paced (s_sleep 4)
-        case 71: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 512>(p, groups, s); break;  // ... s_sleep 16
-        case 72: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 1024>(p, groups, s); break;        // transposed accumulators + direct epilogue
-        case 73: e = launch_gemm_glds<128, 128, 32, 4, 2, 2, false, 12 | 16 | 1024>(p, groups, s, occ_pad(occ, GldsCfg<128, 128, 32, 4, 2>::LDS_BYTES)); break;
-        case 74: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, true, 13 | 16 | 1024>(p, groups, s); break;         // ... without its stores
-        case 75: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 1024 | 128>(p, groups, s); break;  // ... with timeline stamps
-        case 76: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 128 | 2048>(p, groups, s); break;  // production tile, prologue-detail stamps
-        case 77: e = launch_gemm_glds<256, 128, 16, 2, 2, 3, false, 13 | 16 | 64 | 1024>(p, groups, s); break;   // 4 waves of 128 x 64, skewed, direct epilogue
-        case 78: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 4096>(p, groups, s); break;          // production tile, set-up and epilogue at raised priority
-        case 79: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 1024 | 4096>(p, groups, s); break;   // direct epilogue + raised priority
-        case 80: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 1024 | 4096 | 128>(p, groups, s); break;   // ... with timeline stamps
-        case 81: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 4096 | 128 | 2048>(p, groups, s); break;   // production + raised priority, prologue detail
-        case 86: e = launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 128 | 8192>(p, groups, s); break;   // production, set-up detail stamps
-        case 14: e = launch_gemm<128, 128, 32, 2, 2, 1>(p, groups, s); break;            // ablations of tile 0
-        case 15: e = launch_gemm<128, 128, 32, 2, 2, 2>(p, groups, s); break;
-        case 16: e = launch_gemm<128, 128, 32, 2, 2, 3>(p, groups, s); break;
-        case 17: e = launch_gemm<256, 128, 16, 4, 2, 1>(p, groups, s); break;            // ablations of tile 6
-        case 18: e = launch_gemm<256, 128, 16, 4, 2, 2>(p, groups, s); break;
-        case 19: e = launch_gemm<256, 128, 16, 4, 2, 3>(p, groups, s); break;
-#endif
-        default: return fail(NOMAD_ERR_INVALID, "gemm tile id %d is not in this library (experimental instantiations live in libnomad_diag.so)", tile);
-    }
-    if (e != hipSuccess) return fail(NOMAD_ERR_HIP, "gemm launch: %s", hipGetErrorString(e));
-    return 0;
+    return gemm_f32_dispatch(c, p, groups, tile, s, occ);
 }
 
-GemmParams dense(const float* A, int lda, const float* W, const float* bias, const float* R, float* C, int M, int N,
-                 int K, int gelu) {
-    GemmParams p{};
-    p.A = A;
-    p.amap = plain_map(M, lda);
-    p.kchunk = K;
-    p.kstride = 0;
-    p.W = W;
-    p.ldw = K;
-    p.C = C;
-    p.cmap = plain_map(M, N);
-    p.bias = bias;
-    p.R = R;
-    p.rmap = plain_map(M, N);
-    p.M = M;
-    p.N = N;
-    p.K = K;
-    p.n_valid = N;
-    p.gelu = gelu;
-    return p;
-}
+namespace {
 
-// Kernel instantiation for a dense problem (measured on MI355X, tools/gemm_sweep.py, profiles/r01_gemm_sweep_*.json):
-//   33 = LDS-DMA 256x128x16, 8 waves, 3-stage pipeline: best when the grid is many tiles deep (QKV, fc1, conv1-4)
-//        and for the long-K / short-K N = 768 problems of the full batch (fc2, proj)
-//   31 = LDS-DMA 128x128x32, 8 waves, 2-stage: out_proj, conv5/6 (N = 768 / 512 with K around 1000: 2.3 rounds of
-//        256x128 tiles are too few); 34 = 128x64x32 for N not a multiple of 128
-//   37 = LDS-DMA 64x64x32, 4 waves, 3-stage: small problems
-// (all production instantiations (v_mfma_f32_16x16x4_f32, gemm_f32_glds_body) contract k in the same order, so the choice never changes a result bit)
-// Rows of the 256 x 128 part of a two-shape launch (gemm_f32_mixed_kernel), or 0: whole rounds of the 2-per-CU workgroup slots go to
-// 256 x 128 tiles, the rows of the last, partial round to 128 x 128 tiles - when that round is between 5 % and 70 % full.
-// Tuning::f32_mixed = 0 switches it off; f32_mixed_m1 = <rows> (diagnostics) forces a split.
-int mixed_split_rows(const nomad_ctx* c, int M, int N) {
-    const Tuning& t = c->tune;
-    if (!t.f32_mixed || N % 128) return 0;
-    if (t.f32_mixed_m1 > 0) return t.f32_mixed_m1 < M && t.f32_mixed_m1 % 256 == 0 ? t.f32_mixed_m1 : 0;
-    const int tn = N / 128, slots = t.f32_mixed_slots > 0 ? t.f32_mixed_slots : 2 * c->num_cus;
-    const long long tiles = (long long)((M + 255) / 256) * tn;
-    const long long rounds = tiles / slots;
-    const double frac = (double)(tiles - rounds * slots) / slots;
-    if (rounds < 1 || frac < t.f32_mixed_min || frac > t.f32_mixed_max) return 0;
-    const long long m1 = rounds * slots / tn * 256;
-    return m1 > 0 && m1 < M ? (int)m1 : 0;
-}
-
-int pick_tile(const nomad_ctx* c, int M, int N, int K) {
-    const Tuning& tu = c->tune;
-    const int cus = c->num_cus;
-    const long long tiles256 = (long long)((M + 255) / 256) * (N / 128);
-    // (NOMAD_F32_MIXED_PREFER=1, A/B: wherever the two-shape launch applies - run_gemm turns tile 33 into it - take it over the
-    // 128 x 128 choice below.  Was +0.3 % of the bench step with the 32x32x2 products, is -0.4 % with 16x16x4: off.)
-    if (tu.f32_mixed_prefer && N % 128 == 0 && mixed_split_rows(c, M, N) > 0) return 33;
-    // 1500, not 2048: a half of the bench batch (Engine.embed runs the batch as two halves on two streams) has 1800 tiles in
-    // QKV and 1600 in conv4 - the 256x128 kernel there is worth +0.5 % of the step (2230-2235 vs 2219-2222 clips/s, alternating)
-    // 256 x 128 or 128 x 128 (round 4)?  Two workgroups share a CU and a lone one runs about twice as fast, so what a launch costs
-    // is the largest number of tiles any CU gets: ceil(tiles / CUs) big tiles against ceil(2 tiles / CUs) half-size ones, the latter
-    // ~8 % dearer per flop (more operand traffic per MFMA; 3 % before the 16x16x4 products).  conv5 at the bench batch is 1596 big tiles = 6.2 per CU -> 7, or 3192
-    // small ones = 12.5 -> 13 halves = 6.5: 135 vs 127 TFLOP/s measured (profiles/r04_gemm_f32_variants.txt).  NOMAD_F32_QUANT_TILE=0:
-    // the round-3 rule.
-    if (tu.f32_quant_tile && N % 128 == 0 && tiles256 >= 4LL * cus) {
-        const long long per_cu_256 = (tiles256 + cus - 1) / cus;
-        const long long tiles128 = (long long)((M + 127) / 128) * (N / 128);
-        // what a flop costs more on 128 x 128 tiles: 8 % when the host layer runs two parts of a batch concurrently (swept with the
-        // 16x16x4 products: 3 / 6 / 8 / 10 / 15 % -> 2411 / 2418 / 2419 / 2418 / 2415 clips/s), 3 % for one forward at a time
-        // (NOMAD_F32_QUANT_PENALTY, percent: both, A/B runs)
-        const double penalty = tu.f32_quant_penalty != 0.0 ? 1.0 + tu.f32_quant_penalty / 100.0 : (tu.concurrent_parts >= 2 ? 1.08 : 1.03);
-        const double cost128 = (double)((tiles128 + cus - 1) / cus) * 0.5 * penalty;
-        return cost128 < (double)per_cu_256 ? 31 : 33;
-    }
-    if (N % 128 == 0 && tiles256 >= 1500) return 33;
-    // (NOMAD_F32_LONGK_33=1, A/B: one to two rounds of 256 x 128 tiles with a long or short K - fc2 / proj of HALF a bench batch - on
-    // the 256 x 128 kernel, as up to round 4; with the 16x16x4 products the 128 x 128 x 32 kernel is faster and steadier there:
-    // fc2 of half a batch 133.1 against 125 TFLOP/s median, out_proj 127 against 114)
-    if (tu.f32_longk_33 && N % 128 == 0 && tiles256 >= 512 && (K >= 2048 || K <= 512)) return 33;
-    // less than one round of 256x128 tiles (batch 1 .. a few dozen short clips, config C4): 64x64 tiles keep the
-    // most CUs busy; one wave's K loop is the latency floor there (profiles/r01_gemm_sweep_small_m.json)
-    if (tiles256 < 512) return 37;
-    // a few rounds of tiles with wide N (the merged training batch, M ~ 12k): 128x128 tiles, 4 waves
-    // (profiles/r01_gemm_sweep_train_m.json)
-    if (N >= 2048 && N % 128 == 0 && tiles256 < 2048) return 20;
-    // out_proj, conv5/6 at full batch (K = 768 / 1024, N = 768 / 512): 128x128x32 tiles, 8 waves, 2 stages: +2..5 % over
-    // 128x64 (profiles/r01_gemm_sweep_n768_128x128.json).  NOMAD_F32_MID_TILE=33 (A/B): the 256x128 kernel there too, so that the
-    // transformer layers run ONE GEMM instantiation (no alternation)
-    return N % 128 == 0 ? tu.f32_mid_tile : 34;
-}
 
 int run_layernorm(nomad_ctx* c, const float* in, const float* g, const float* b, float* out, float* out2, int M, int N,
                   hipStream_t s) {
@@ -1751,254 +1188,6 @@ static void launch_conv0_bf16(nomad_ctx* c, const float* wav, int stride, int l0
 }
 
 // plain C / R matrices AND an A map whose divisions have magic numbers (uniform clips of at least two rows, n-fastest tile walk):
-// what the PLAIN instantiations (small epilogue, lean set-up) require
-static bool p8_plain_cr(const GemmParams& p) {
-    return p.cmap.clip_rows >= p.M && !p.cmap.pref && p.c_colblk == 0 && p.c_blk_step == 0 &&
-           (!p.R || (p.rmap.clip_rows >= p.M && !p.rmap.pref)) &&
-           !p.amap.pref && p.group_m == 0 && (p.amap.clip_rows >= p.M || p.amap.clip_rows >= 2);
-}
-
-// what the persistent 256 x 256 kernel (gemm_bf16_p9.hip.h) requires on top of p8_plain_cr: one group, contiguous K, every column
-// stored, no split planes, not GELU and residual together
-static bool p9_applies(const GemmParams& p, int groups) {
-    return groups == 1 && p8_plain_cr(p) && p.N % 256 == 0 && p.n_valid == p.N && p.K % 128 == 0 && p.kchunk == p.K &&
-           p.a_plane == 0 && p.c_plane == 0 && !p.Upre && !p.DG &&
-           !(p.gelu && p.R);   // (GELU and a residual in one epilogue: no GEMM of the model has both, and the shipped instantiation has no copy for it)
-}
-
-// 256 x 192 instead of 256 x 256 tiles in the deep-pipelined bf16 kernel (gemm_bf16_8phase.hip.h, NJ = 3) for the N = 768 GEMMs
-// of config C5 (out_proj, fc2: 188 row tiles x 3 = 2.2 rounds of the 256 CUs, 2.94 with 192-column tiles).  Bit-identical
-// results.  OFF by default: in isolation fc2 runs 19 % and out_proj 12 % faster (hipBLASLt picks MT256x192 there too), but inside
-// the C5 forward the other GEMMs slow down by more than that - the chip holds 2130 instead of 2157 MHz (2400 nominal) with
-// them, 19.25 vs 18.98 ms per forward (profiles/r03_n192_null.txt).  NOMAD_BF16_N192=1 takes them wherever they save a round
-// (a 192-column tile costs ~0.78 of a 256-column one), =2 wherever N % 192 == 0.
-static bool p8_use_n192(const nomad_ctx* c, int M, int N, int K) {
-    const int mode = c->tune.p8_n192;
-    if (N % 192 != 0 || mode <= 0) return false;
-    if (mode == 2) return true;
-    if (mode == 3 && K < 2048) return false;   // A/B: the long-K problems only (fc2)
-    if (mode == 4 && K >= 2048) return false;  // A/B: the short-K problems only (out_proj, proj)
-    const long long tm = (M + 255) / 256;
-    const long long r256 = (tm * (N / 256) + 255) / 256, r192 = (tm * (N / 192) + 255) / 256;
-    return 0.80 * (double)r192 < 0.95 * (double)r256;
-}
-
-static int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, int tile = -1) {
-    // Tuning (A/B switches of the diag library; defaults = shipped): p8_min_tiles - smallest grid in 256 x 256 tiles that takes the
-    // deep-pipelined kernels; p8_nt_stores - their output stores carry the non-temporal hint; p8_rpre - residual prefetch in p8_epilogue
-    // (0 off, 1 residual GEMMs only, 2 every GEMM, 3 = 2 + the small epilogue for plain C / R); x3_plain_epi - one bf16x3 instantiation
-    // with a run-time output format; p8_three_b - three B buffers (160 KB of LDS); p9 - the persistent kernel wherever it applies
-    const Tuning& tu = c->tune;
-    auto p8_min_tiles = [&] { return tu.p8_min_tiles; };
-    auto p8_nt_stores = [&] { return tu.p8_nt_stores; };
-    auto p8_residual_prefetch = [&] { return tu.p8_rpre; };
-    auto x3_plain_epilogue = [&] { return tu.x3_plain_epi; };
-    auto p8_three_b = [&] { return tu.p8_three_b; };
-    auto p9_on = [&] { return tu.p9; };
-    const double flops = 2.0 * p.M * (double)p.n_valid * p.K * groups;  // bf16x3: the fp32-equivalent count, not 3x
-    if (tile < 0) {
-        // measured (profiles/r01_gemm_sweep_bf16.json): 256x256 tiles (wave tile 64x128) win on wide (N >= 1024)
-        // and very tall problems, 128x128 (8 waves) on the N = 768 / 512 transformer shapes
-        if (p.N % 128 != 0) tile = p.M < 512 ? 4 : 2;
-        else if (p.M < 512) tile = 4;
-        else if (p.N % 256 == 0 && p.K % 128 == 0 && groups == 1 && (long long)((p.M + 255) / 256) * (p.N / 256) >= p8_min_tiles())
-            tile = (p9_on() && p9_applies(p, groups) && (tu.p9_res || !p.R)) ? 60 : (p8_three_b() && p8_nt_stores() && p8_use_n192(c, p.M, p.N, p.K)) ? 55 : 16;  // deep-pipelined 256x256 / 256x192 kernel once there are >= 2 rounds of tiles (profiles/r01_gemm_sweep_bf16_8phase.json)
-        else tile = (p.N % 256 == 0 && (p.N >= 1024 || p.M >= 100000)) ? 3 : 1;
-    }
-    Scope sc(c, s, NOMAD_K_GEMM, flops, (tile == 1 || tile == 3 || tile == 16 || tile == 60 || tile == 61 || tile == 62 || tile == 63 || tile == 64 || tile == 68 || tile == 65 || tile == 66 || tile == 67 || tile == 55 || tile == 56 || tile == 57 || tile == 58 || tile == 42 || tile == 43 || tile == 44 || tile == 45 || tile == 46 || tile == 47 || tile == 48 || tile == 49 || tile == 50 || tile == 51 || tile == 52 || tile == 53 || tile == 54 || tile == 20 || tile == 21 || tile == 27 || tile == 28 || tile == 32 || tile == 33) ? NOMAD_K_GEMM_BIG : (tile == 2 ? NOMAD_K_GEMM_FINE : -1));
-    hipError_t e;
-    switch (tile) {
-        // the instantiations the bf16 / bf16x3 forwards select
-        case 1: e = launch_gemm_bf16<128, 128, 4, 2>(p, groups, s); break;
-        case 2: e = launch_gemm_bf16<128, 64, 4, 2>(p, groups, s); break;
-        case 3: e = launch_gemm_bf16<256, 256, 4, 2>(p, groups, s); break;
-        case 4: e = launch_gemm_bf16<64, 64, 2, 2>(p, groups, s); break;
-        case 16:  // 256x256 deep-pipelined schedule (gemm_bf16_8phase.hip.h)
-            if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
-            e = !p8_nt_stores() ? launch_gemm_bf16_8phase<0>(p, groups, s)
-                : !p8_three_b() ? launch_gemm_bf16_8phase<8>(p, groups, s)
-                : (p8_residual_prefetch() == 3 && p8_plain_cr(p)) ? launch_gemm_bf16_8phase<8, false, 0, 3, 4, true, true>(p, groups, s)
-                : ((p.R && p8_residual_prefetch() == 1) || p8_residual_prefetch() >= 2) ? launch_gemm_bf16_8phase<8, false, 0, 3, 4, true>(p, groups, s)
-                                                  : launch_gemm_bf16_8phase<8, false, 0, 3>(p, groups, s);
-            break;
-        case 60:  // persistent form of the deep-pipelined kernel: one workgroup per CU walks tiles, direct epilogue (gemm_bf16_p9.hip.h)
-        case 64: {  // ... (64: never split by rows - A/B)
-            if (!p9_applies(p, groups)) return fail(NOMAD_ERR_INVALID, "bf16 persistent gemm: plain C / R, one group, N %% 256, K %% 128, contiguous K");
-            // Tile quantisation (round 5).  One workgroup per CU and tiles of 256 x 256: the N = 768 GEMMs of config C5 (out_proj, fc2) are
-            // 564 tiles = 2.2 rounds of the 256 CUs, i.e. three rounds' time.  The one-tile-per-workgroup kernel hid that behind the
-            // OTHER half of the batch on a second stream; persistent workgroups of two launches cannot share CUs.  Instead the rows of
-            // the whole rounds go to the persistent kernel and the rows of the sparse last round to the 128 x 128 kernel (tile 1,
-            // two workgroups per CU) right behind it on the same stream: every bf16 kernel contracts k in the same order, so which
-            // kernel computes a row changes no bit (tests/test_gpu_bf16.py).  Plain A matrices only (the conv stack's per-clip maps
-            // have thousands of tiles); Tuning::p9_tail_split = 0 switches it off.
-            // (Tuning::p9_share, A/B: with n concurrent parts of a batch on n streams each launch takes 1 / n of the CUs, so that the parts'
-            // persistent launches run side by side instead of queueing for each other's LDS)
-            const int cus = (tu.p9_share && tu.concurrent_parts > 1) ? std::max(8, c->num_cus / tu.concurrent_parts) : c->num_cus;
-            const int grid = 8 * std::max(1, cus / 8);
-            const long long tn = p.N / 256, tm = (p.M + 255) / 256, tiles = tm * tn;
-            const long long rounds = tiles / grid, rem = tiles - rounds * grid;
-            if (tile == 60 && tu.p9_tail_split && rounds >= 1 && rounds <= 4 && rem > 0 && rem * 10 < grid * 6 && p.amap.clip_rows >= p.M && p.N % 128 == 0) {
-                const int m_main = (int)(rounds * grid / tn) * 256;
-                if (m_main > 0 && m_main < p.M) {
-                    GemmParams a = p, b = p;
-                    a.M = m_main;
-                    a.amap = plain_map(a.M, p.amap.ld); a.amap.off = p.amap.off;
-                    a.cmap = plain_map(a.M, p.cmap.ld); a.cmap.off = p.cmap.off;
-                    a.rmap = plain_map(a.M, p.rmap.ld); a.rmap.off = p.rmap.off;
-                    b.M = p.M - m_main;
-                    b.amap = plain_map(b.M, p.amap.ld); b.amap.off = p.amap.off + (long long)m_main * p.amap.ld;
-                    b.cmap = plain_map(b.M, p.cmap.ld); b.cmap.off = p.cmap.off + (long long)m_main * p.cmap.ld;
-                    b.rmap = plain_map(b.M, p.rmap.ld); b.rmap.off = p.rmap.off + (long long)m_main * p.rmap.ld;
-                    e = launch_gemm_bf16_p9<0, true>(a, s, cus);
-                    if (e == hipSuccess) e = launch_gemm_bf16<128, 128, 4, 2>(b, groups, s);
-                    break;
-                }
-            }
-            // Short (192-row) tiles, round 6: a run-time mode of the same instantiation.  A 192 x 256 tile costs ~0.80 of a 256 x 256 one (three
-            // quarters of the MFMAs, 7 / 8 of the LDS-DMA bytes); it is taken where the largest tile count any CU gets, priced so, is smaller.
-            // Only for a batch that runs ALONE (concurrent_parts == 1): next to the other half of a two-stream batch the CUs never idle - the
-            // other half's workgroups take a CU the moment a workgroup leaves it - so what counts there is the total work, which short tiles
-            // raise (measured, gpurun_out/r6a: two streams 1888 -> 1877 clips/s with short tiles, one stream 1828-1845 -> 1876-1878).
-            if (tile == 60 && (tu.p9_short == 2 || (tu.p9_short == 1 && tu.concurrent_parts <= 1))) {
-                const long long tm_s = (p.M + 191) / 192;
-                const long long r_full = (tiles + grid - 1) / grid, r_short = (tm_s * tn + grid - 1) / grid;
-                p.p9_short = (tu.p9_short == 2 || 0.80 * (double)r_short < 0.95 * (double)r_full) ? 1 : 0;
-            }
-            e = launch_gemm_bf16_p9<0, true>(p, s, cus);
-            break;
-        }
-        case 57:  // the deep-pipelined kernel with the residual prefetch in the epilogue, general C / R addressing
-        case 58:  // ... with the small epilogue for plain C / R matrices (what tile 16 resolves to for them)
-            if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
-            if (tile == 58 && !p8_plain_cr(p)) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm, plain epilogue: C / R are not plain matrices");
-            e = tile == 57 ? launch_gemm_bf16_8phase<8, false, 0, 3, 4, true>(p, groups, s) : launch_gemm_bf16_8phase<8, false, 0, 3, 4, true, true>(p, groups, s);
-            break;
-        case 55:  // 256x192 tiles of the same schedule (three B buffers, nt stores)
-            if (p.N % 192 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm, 192-column tiles: N %% 192, K %% 128");
-            e = (p8_residual_prefetch() == 3 && p8_plain_cr(p)) ? launch_gemm_bf16_8phase<8, false, 0, 3, 3, true, true>(p, groups, s)
-                                                                : launch_gemm_bf16_8phase<8, false, 0, 3, 3>(p, groups, s);
-            break;
-        case 27:  // bf16x3, every plane staged once (gemm_bf16x3.hip.h): split output
-        case 28:  // ... fp32 output
-            if (p.N % 256 != 0 || p.K % 64 != 0) return fail(NOMAD_ERR_INVALID, "bf16x3 gemm: N %% 256, K %% 64");
-            if (p8_nt_stores() && x3_plain_epilogue() && p8_plain_cr(p) && (tile == 27) == (p.c_plane != 0))
-                e = launch_gemm_bf16x3<8, 3, 2, true>(p, groups, s);   // one instantiation for both output formats, small epilogue
-            else if (p8_nt_stores()) e = tile == 27 ? launch_gemm_bf16x3<8, 1>(p, groups, s) : launch_gemm_bf16x3<8, 2>(p, groups, s);
-            else e = tile == 27 ? launch_gemm_bf16x3<0, 1>(p, groups, s) : launch_gemm_bf16x3<0, 2>(p, groups, s);
-            break;
-#ifdef NOMAD_DIAG
-        // experimental instantiations, cross-check kernels and timing probes (libnomad_diag.so)
-        case 0: e = launch_gemm_bf16<256, 128, 4, 2>(p, groups, s); break;
-        case 5: e = launch_gemm_bf16<128, 128, 2, 2>(p, groups, s); break;
-        case 6: e = launch_gemm_bf16<256, 128, 2, 2>(p, groups, s); break;
-        case 7: e = launch_gemm_bf16<128, 128, 4, 2, 1>(p, groups, s); break;   // ablation: no epilogue stores
-        case 8: e = launch_gemm_bf16<128, 128, 4, 2, 2>(p, groups, s); break;   // ablation: one K tile only
-        case 9: e = launch_gemm_bf16<256, 256, 2, 4, 0, 32, 4>(p, groups, s); break;   // wave 128x64, BK 32, 4-stage
-        case 10: e = launch_gemm_bf16<256, 256, 4, 2, 0, 32, 4>(p, groups, s); break;  // wave 64x128
-        case 11: e = launch_gemm_bf16<128, 128, 4, 2, 0, 32, 4>(p, groups, s); break;
-        case 12: e = launch_gemm_bf16<128, 128, 4, 2, 0, 64, 3>(p, groups, s); break;
-        case 13: e = launch_gemm_bf16<256, 128, 4, 2, 0, 64, 3>(p, groups, s); break;
-        case 14: e = launch_gemm_bf16<256, 128, 4, 2, 0, 32, 4>(p, groups, s); break;
-        case 15: e = launch_gemm_bf16<256, 256, 2, 4, 0, 64, 2>(p, groups, s); break;
-        case 17:  // 8-phase ablation: no epilogue stores
-            if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
-            e = launch_gemm_bf16_8phase<1>(p, groups, s);
-            break;
-        case 18:  // A/B: 8-phase kernel with buffer_load..lds
-            if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
-            e = launch_gemm_bf16_8phase<0, true>(p, groups, s);
-            break;
-        case 19:  // A/B: 8-phase kernel without s_setprio
-            if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
-            e = launch_gemm_bf16_8phase<2>(p, groups, s);
-            break;
-        case 20:  // bf16x3 cross-check (K-concatenated operands in the 8-phase kernel): split output
-        case 21:  // ... fp32 output
-            if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16x3 gemm: N %% 256, K %% 128");
-            e = tile == 20 ? launch_gemm_bf16_8phase<0, false, 1>(p, groups, s) : launch_gemm_bf16_8phase<0, false, 2>(p, groups, s);
-            break;
-        case 42:  // A/B: 8-phase kernel with non-temporal output stores / + residual loads / residual loads only
-        case 43:
-        case 44:
-            if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
-            e = tile == 42 ? launch_gemm_bf16_8phase<8>(p, groups, s) : tile == 43 ? launch_gemm_bf16_8phase<9>(p, groups, s) : launch_gemm_bf16_8phase<10>(p, groups, s);
-            break;
-        case 56:  // 256x192 tiles with two B buffers (A/B against 55)
-            if (p.N % 192 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm, 192-column tiles: N %% 192, K %% 128");
-            e = launch_gemm_bf16_8phase<8, false, 0, 2, 3>(p, groups, s);
-            break;
-        case 46:  // three B buffers: B staged 1.75 K tiles ahead (non-temporal stores as tile 16 ships them)
-            if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
-            e = launch_gemm_bf16_8phase<8, false, 0, 3>(p, groups, s);
-            break;
-        case 47:  // timing probes on the plain bf16 kernel (wrong results): no LDS-DMA / neither DMA nor LDS reads / no LDS reads
-        case 48:
-        case 49:
-            if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
-            e = tile == 47 ? launch_gemm_bf16_8phase<4>(p, groups, s) : tile == 48 ? launch_gemm_bf16_8phase<5>(p, groups, s) : launch_gemm_bf16_8phase<6>(p, groups, s);
-            break;
-        case 51:  // cache-policy probes of the LDS-DMA on the shipped kernel (three B buffers, nt stores): nt on A / B / both, sc1 on both
-        case 52:
-        case 53:
-        case 54:
-            if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
-            e = tile == 51 ? launch_gemm_bf16_8phase<13, false, 0, 3>(p, groups, s) : tile == 52 ? launch_gemm_bf16_8phase<14, false, 0, 3>(p, groups, s)
-              : tile == 53 ? launch_gemm_bf16_8phase<15, false, 0, 3>(p, groups, s) : launch_gemm_bf16_8phase<16, false, 0, 3>(p, groups, s);
-            break;
-        case 50:  // timing probe: no loads and no barriers in the loop (both wave rows issue MFMAs at once)
-            e = launch_gemm_bf16_8phase<12>(p, groups, s);
-            break;
-        case 45:  // timing probe: every workgroup stages A tile 0 (wrong results)
-            if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
-            e = launch_gemm_bf16_8phase<11>(p, groups, s);
-            break;
-        case 36:  // timing probe: per-workgroup timeline (nomad_diag_timeline, tools/gemm_timeline.py)
-            if (p.N % 256 != 0 || p.K % 128 != 0) return fail(NOMAD_ERR_INVALID, "bf16 8-phase gemm: N %% 256, K %% 128");
-            e = launch_gemm_bf16_8phase<7>(p, groups, s);
-            break;
-        case 65:  // persistent kernel, B DMA of a K tile issued in phase 3 / in phases 2 and 3 / every DMA inside an MFMA cluster (A/B against 60)
-        case 66:
-        case 67:
-            if (!p9_applies(p, groups)) return fail(NOMAD_ERR_INVALID, "bf16 persistent gemm: plain C / R, one group, N %% 256, K %% 128, contiguous K");
-            e = tile == 65 ? launch_gemm_bf16_p9<0, true, 1>(p, s, c->num_cus) : tile == 66 ? launch_gemm_bf16_p9<0, true, 2>(p, s, c->num_cus)
-                                                                                      : launch_gemm_bf16_p9<0, true, 3>(p, s, c->num_cus);
-            break;
-        case 68:  // persistent kernel, 192-row tiles forced (A/B against 64 = never short; 60 = the shipped choice)
-            if (!p9_applies(p, groups)) return fail(NOMAD_ERR_INVALID, "bf16 persistent gemm: plain C / R, one group, N %% 256, K %% 128, contiguous K");
-            p.p9_short = 1;
-            e = launch_gemm_bf16_p9<0, true>(p, s, c->num_cus);
-            break;
-        case 61:  // persistent kernel: per-workgroup timeline probe / no output stores (timing) / every epilogue between tiles (A/B)
-        case 62:
-        case 63:
-            if (!p9_applies(p, groups)) return fail(NOMAD_ERR_INVALID, "bf16 persistent gemm: plain C / R, one group, N %% 256, K %% 128, contiguous K");
-            if (tile == 61) p.p9_skew = tu.p9_skew;
-            e = tile == 61 ? launch_gemm_bf16_p9<7, true>(p, s, c->num_cus) : tile == 62 ? launch_gemm_bf16_p9<1, true>(p, s, c->num_cus)
-                                                                                      : launch_gemm_bf16_p9<0, false>(p, s, c->num_cus);
-            break;
-        case 22: e = launch_gemm_bf16_8phase<3, false, 2>(p, groups, s); break;  // bf16x3 timing probes, fp32 output
-        case 23: e = launch_gemm_bf16_8phase<4, false, 2>(p, groups, s); break;
-        case 24: e = launch_gemm_bf16_8phase<5, false, 2>(p, groups, s); break;
-        case 25: e = launch_gemm_bf16_8phase<6, false, 2>(p, groups, s); break;
-        case 26: e = launch_gemm_bf16_8phase<1, false, 2>(p, groups, s); break;
-        case 29:  // timing probe: no epilogue stores
-        case 30:  // timing probe: no LDS-DMA
-        case 31:  // timing probe: every workgroup stages A tile 0 (A always hits in L2)
-            if (p.N % 256 != 0 || p.K % 64 != 0) return fail(NOMAD_ERR_INVALID, "bf16x3 gemm: N %% 256, K %% 64");
-            e = tile == 29 ? launch_gemm_bf16x3<1, 2>(p, groups, s) : tile == 30 ? launch_gemm_bf16x3<4, 2>(p, groups, s)
-                                                                                  : launch_gemm_bf16x3<7, 2>(p, groups, s);
-            break;
-        case 32:  // three A buffers (K % 192 == 0): split output
-        case 33:  // ... fp32 output
-            if (p.N % 256 != 0 || p.K % 192 != 0) return fail(NOMAD_ERR_INVALID, "bf16x3 gemm (3 A buffers): N %% 256, K %% 192");
-            e = tile == 32 ? launch_gemm_bf16x3<0, 1, 3>(p, groups, s) : launch_gemm_bf16x3<0, 2, 3>(p, groups, s);
-            break;
-#endif
-        default: return fail(NOMAD_ERR_INVALID, "bf16 gemm tile id %d is not in this library (experimental instantiations live in libnomad_diag.so)", tile);
-    }
-    if (e != hipSuccess) return fail(NOMAD_ERR_HIP, "bf16 gemm launch: %s", hipGetErrorString(e));
-    return 0;
-}
 
 #ifdef NOMAD_DIAG
 // Race hunting (tools/race_hunt_bf16.py): order-independent checksum of `nseg` equal byte segments of a buffer -
@@ -3017,11 +2206,17 @@ int nomad_diag_posconv_bf16(nomad_ctx* c, const void* xpad_dev, void* y_dev, int
     return run_gemm_bf16(c, p, 16, s);
 }
 
-// timeline of the last tile-36 GEMM: out_host[6 * n] = per workgroup {entry, loop start, loop end, stores done, HW_ID, XCC_ID}
+// timeline of the last probe GEMM: out_host[6 * n] = per workgroup {entry, loop start, loop end, stores done, HW_ID, XCC_ID}.  The probe kernels
+// live in two translation units, each with its own copy of the device buffer: the copy with the newer stamps is the last probe's.
 int nomad_diag_timeline(unsigned long long* out_host, int n) {
     if (!out_host || n <= 0 || n > kTimelineSlots) return fail(NOMAD_ERR_INVALID, "nomad_diag_timeline: bad argument");
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_timeline), sizeof(unsigned long long) * 6 * (size_t)n));
+    std::vector<unsigned long long> a(6 * (size_t)n), b(6 * (size_t)n);
+    if (int rc = gemm_f32_timeline_read(a.data(), n)) return rc;
+    if (int rc = gemm_bf16_timeline_read(b.data(), n)) return rc;
+    unsigned long long ma = 0, mb = 0;
+    for (int i = 0; i < n; ++i) { ma = std::max(ma, a[6 * (size_t)i]); mb = std::max(mb, b[6 * (size_t)i]); }
+    std::memcpy(out_host, (ma >= mb ? a : b).data(), sizeof(unsigned long long) * 6 * (size_t)n);
     return 0;
 }
 #endif
@@ -4079,98 +3274,6 @@ int nomad_profile_read(nomad_ctx* c, double ms[NOMAD_K_COUNT], long long launche
     return 0;
 }
 
-// ---- diagnostics -------------------------------------------------------------------------------
-int nomad_diag_gemm(nomad_ctx* c, const float* A, const float* W, const float* bias, const float* R, float* C, int M,
-                    int N, int K, int gelu, int tile, nomad_stream_t stream) {
-    if (!c || !A || !W || !C || M <= 0) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: bad argument");
-    {   // the direct epilogue (gemm_f32.hip.h OPT bit 1024) serves GEMMs without a residual only
-        const int t = tile % 100;
-        const bool direct_tile = t == 72 || t == 74 || t == 75 || t == 77 || t == 79 || t == 80 || t == 84 || t == 85 || t == 89 || t == 90 || t == 93 || t == 94 || t == 95;
-        if (direct_tile && R) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile %d has the direct epilogue, which takes no residual", t);
-    }
-    // diagnostics: tile id + 100 * group_m (grouped tile order) + 10000 * occ (workgroups per CU limit)
-    const int occ = tile / 10000;
-    const int group_m = (tile % 10000) / 100;
-    tile %= 100;
-    static const int kBN[] = {128, 64, 64, 128, 128, 256, 128, 256, 256, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128,
-                              128, 128, 128, 128, 256, 256, 128, 256, 64, 64, 64, 128, 128, 128, 64, 128, 32, 64, 32, 32, 256, 256,
-                              128, 128, 128, 128, 256, 256};
-    static const int kBK[] = {32, 16, 32, 16, 32, 32, 16, 32, 16, 16, 16, 32, 32, 16, 32, 32, 32, 16, 16, 16,
-                              32, 16, 16, 32, 16, 32, 16, 16, 16, 32, 32, 32, 16, 16, 32, 32, 32, 32, 32, 32, 16, 16,
-                              16, 16, 16, 16, 64, 64};
-    if (tile == 48 || tile == 49) {
-        if (N != 48 || K % 16) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile 48 needs N == 48 and K %% 16 == 0");
-        GemmParams p48 = dense(A, K, W, bias, R, C, M, N, K, gelu);
-        return run_gemm(c, p48, 1, tile, static_cast<hipStream_t>(stream));
-    }
-    if (tile == 94 || tile == 95) {   // the shipped lean + skewed + direct-epilogue instantiation with timeline stamps (94) / set-up detail stamps (95)
-        if (N % 128 || K % 32) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: N %% 128 or K %% 32 != 0");
-        GemmParams pp = dense(A, K, W, bias, R, C, M, N, K, gelu);
-        hipStream_t st = static_cast<hipStream_t>(stream);
-        if (tile == 94) HIP_TRY((launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 64 | 1024 | 16384 | 128>(pp, 1, st)));
-        else HIP_TRY((launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 64 | 1024 | 16384 | 128 | 8192>(pp, 1, st)));
-        return 0;
-    }
-    if (tile == 99) {   // two tile shapes in one launch (gemm_f32_mixed_kernel): the split by mixed_split_rows (NOMAD_F32_MIXED_M1 forces one)
-        if (N % 128 || K % 32 || (R && gelu)) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile 99 needs N %% 128 == 0, K %% 32 == 0, no GELU with a residual");
-        GemmParams pp = dense(A, K, W, bias, R, C, M, N, K, gelu);
-        hipStream_t st = static_cast<hipStream_t>(stream);
-        const int m1 = mixed_split_rows(c, M, N);
-        if (m1 <= 0) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile 99: no split for M = %d, N = %d", M, N);
-        Scope sc(c, st, NOMAD_K_GEMM, 2.0 * M * (double)N * K, NOMAD_K_GEMM_BIG);
-        constexpr int V = 13 | 16 | 64 | 16384;
-        if (R) HIP_TRY((launch_gemm_mixed<V | 32768, V | 32768>(pp, m1, st)));
-        else HIP_TRY((launch_gemm_mixed<V | 1024, V | 1024>(pp, m1, st)));
-        return 0;
-    }
-    if (tile == 97 || tile == 98) {   // residual ahead (OPT bit 32768): 97 the 256 x 128 lean + skewed tile, 98 the 128 x 128 x 32 lean tile
-        if (N % 128 || K % 32 || gelu || !R) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile %d needs N %% 128 == 0, K %% 32 == 0, a residual and no GELU", tile);
-        GemmParams pp = dense(A, K, W, bias, R, C, M, N, K, gelu);
-        hipStream_t st = static_cast<hipStream_t>(stream);
-        Scope sc(c, st, NOMAD_K_GEMM, 2.0 * M * (double)N * K, NOMAD_K_GEMM_BIG);
-        if (tile == 97) HIP_TRY((launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 64 | 16384 | 32768>(pp, 1, st)));
-        else HIP_TRY((launch_gemm_glds<128, 128, 32, 4, 2, 2, false, 12 | 16 | 16384 | 32768>(pp, 1, st, occ_pad(0, GldsCfg<128, 128, 32, 4, 2>::LDS_BYTES))));
-        return 0;
-    }
-    if (tile >= 88 && tile <= 93) {   // lean set-up (OPT bit 16384) on: 88 production tile, 89 + direct epilogue, 90 + skewed + direct, 91 + skewed (LDS epilogue), 92 128x128x32 tile, 93 128x128x32 + direct
-        if (N % 128 || K % 32) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: N %% 128 or K %% 32 != 0");
-        GemmParams pp = dense(A, K, W, bias, R, C, M, N, K, gelu);
-        hipStream_t st = static_cast<hipStream_t>(stream);
-        Scope sc(c, st, NOMAD_K_GEMM, 2.0 * M * (double)N * K, NOMAD_K_GEMM_BIG);
-        constexpr int L = 16384;
-        switch (tile) {
-            case 88: HIP_TRY((launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | L>(pp, 1, st))); break;
-            case 89: HIP_TRY((launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 1024 | L>(pp, 1, st))); break;
-            case 90: HIP_TRY((launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 64 | 1024 | L>(pp, 1, st))); break;
-            case 91: HIP_TRY((launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 64 | L>(pp, 1, st))); break;
-            case 92: HIP_TRY((launch_gemm_glds<128, 128, 32, 4, 2, 2, false, 12 | 16 | L>(pp, 1, st, occ_pad(0, GldsCfg<128, 128, 32, 4, 2>::LDS_BYTES)))); break;
-            default: HIP_TRY((launch_gemm_glds<128, 128, 32, 4, 2, 2, false, 12 | 16 | 1024 | L>(pp, 1, st, occ_pad(0, GldsCfg<128, 128, 32, 4, 2>::LDS_BYTES)))); break;
-        }
-        return 0;
-    }
-    if (tile == 84 || tile == 85) {   // 84: production tile, skewed schedule + direct epilogue; 85: 4 waves of 128 x 64, BK = 8 (36 KB: three workgroups / CU)
-        if (N % 128 || K % 16) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: N %% 128 or K %% 16 != 0");
-        GemmParams pp = dense(A, K, W, bias, R, C, M, N, K, gelu);
-        Scope sc(c, static_cast<hipStream_t>(stream), NOMAD_K_GEMM, 2.0 * M * (double)N * K, NOMAD_K_GEMM_BIG);
-        if (tile == 85) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile 85 (BK = 8) went with the 16x16x4 products (16-deep k groups)");
-        HIP_TRY((launch_gemm_glds<256, 128, 16, 4, 2, 3, false, 13 | 16 | 64 | 1024>(pp, 1, static_cast<hipStream_t>(stream))));
-        return 0;
-    }
-    if (tile == 82 || tile == 83 || tile == 87 || tile == 96) {   // (96: persistent, second workgroup of a CU starts half a tile late)
-   // the persistent 256 x 128 kernel (83: without its output stores; 87: one workgroup per tile)
-        if (N % 128 || K % 16 || K < 64) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: persistent kernel needs N %% 128 == 0, K %% 16 == 0, K >= 64");
-        GemmParams pp = dense(A, K, W, bias, R, C, M, N, K, gelu);
-        Scope sc(c, static_cast<hipStream_t>(stream), NOMAD_K_GEMM, 2.0 * M * (double)N * K, NOMAD_K_GEMM_BIG);
-        HIP_TRY(launch_gemm_pers(pp, static_cast<hipStream_t>(stream), c->num_cus, tile == 83, tile == 87, tile == 96));
-        return 0;
-    }
-    if (tile < 0 || (tile > 47 && (tile < 60 || tile > 81) && tile != 86)) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile id %d", tile);
-    const int bn = tile >= 60 ? (tile == 67 ? 256 : 128) : kBN[tile], bk = tile >= 60 ? (tile == 73 ? 32 : 16) : kBK[tile];
-    if (N % bn || K % bk) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: N %% %d or K %% %d != 0", bn, bk);
-    GemmParams p = dense(A, K, W, bias, R, C, M, N, K, gelu);
-    p.group_m = group_m;
-    return run_gemm(c, p, 1, tile, static_cast<hipStream_t>(stream), occ);
-}
 
 // One wave spins for `spin_ticks` ticks of the 100 MHz wall counter and reports the shader-clock cycles that passed:
 // launched on a second stream while a kernel under test runs, it reads the clock that kernel actually gets.
