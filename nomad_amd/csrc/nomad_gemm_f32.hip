@@ -152,6 +152,10 @@ int gemm_f32_dispatch(nomad_ctx* c, GemmParams p, int groups, int tile, hipStrea
         case 32: e = launch_gemm_glds<256, 128, 16, 4, 2, 2, true>(p, groups, s); break;  // ablation: no epilogue stores
         case 35: e = launch_gemm_glds<256, 128, 32, 4, 2, 3>(p, groups, s); break;
         case 36: e = launch_gemm_glds<64, 32, 32, 2, 1, 3>(p, groups, s); break;    // small problems: many small workgroups
+        // round 6, small-M probes (configs[3]: 900 QKV tiles of 64 x 64 are 1.17 rounds of the 768 slots three 48 KB workgroups per CU give):
+        // the same tile with 2 stages (32 KB: 5 per CU), with 16-deep K tiles (24 KB: 6 per CU), and both with the lean set-up + direct epilogue
+        case 46: e = launch_gemm_glds<64, 64, 32, 2, 2, 2, false, 12 | 16>(p, groups, s); break;
+        case 47: e = launch_gemm_glds<64, 64, 16, 2, 2, 3, false, 12 | 16>(p, groups, s); break;
         case 38: e = launch_gemm_glds<128, 32, 32, 4, 1, 3>(p, groups, s); break;
         case 39: e = launch_gemm_glds<32, 32, 32, 1, 1, 3>(p, groups, s); break;
         case 40: e = launch_gemm_glds<256, 256, 16, 4, 4, 3>(p, groups, s); break;   // one 16-wave workgroup per CU
@@ -359,7 +363,7 @@ int nomad_diag_gemm(nomad_ctx* c, const float* A, const float* W, const float* b
         return 0;
     }
     if (tile < 0 || (tile > 47 && (tile < 60 || tile > 81) && tile != 86)) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: tile id %d", tile);
-    const int bn = tile >= 60 ? (tile == 67 ? 256 : 128) : kBN[tile], bk = tile >= 60 ? (tile == 73 ? 32 : 16) : kBK[tile];
+    const int bn = (tile == 46 || tile == 47) ? 64 : tile >= 60 ? (tile == 67 ? 256 : 128) : kBN[tile], bk = tile == 46 ? 32 : tile == 47 ? 16 : tile >= 60 ? (tile == 73 ? 32 : 16) : kBK[tile];
     if (N % bn || K % bk) return fail(NOMAD_ERR_INVALID, "nomad_diag_gemm: N %% %d or K %% %d != 0", bn, bk);
     GemmParams p = dense(A, K, W, bias, R, C, M, N, K, gelu);
     p.group_m = group_m;

@@ -68,3 +68,24 @@ def test_c5_full_batch_properties(engine, precision):
     # distinct random clips are far from identical
     off = d + torch.eye(32, device=d.device, dtype=d.dtype) * 10
     assert off.min().item() > 1e-4
+
+
+def test_c5_one_stream_equals_two_streams_bit_for_bit(engine):
+    """Round 6: a batch that runs ALONE (Engine.BF16_SPLIT_ROWS = 0: one stream) takes the persistent GEMM's 192-row tile mode for its
+    N = 768 GEMMs (out_proj, fc2: 2.93 instead of 2.2 rounds of tiles), the two-stream default keeps 256-row tiles - the same instantiation,
+    the same k order per element: every embedding bit-equal, at configs[4]'s full size."""
+    gen = torch.Generator().manual_seed(11)
+    wav = (0.1 * torch.randn(32, 480000, generator=gen)).clamp(-1, 1).cuda()
+    assert engine.BF16_SPLIT_ROWS
+    two = engine.embed_bf16(wav)
+    keep = engine.BF16_SPLIT_ROWS
+    engine.BF16_SPLIT_ROWS = 0
+    try:
+        one = engine.embed_bf16(wav)
+        one_again = engine.embed_bf16(wav)
+    finally:
+        engine.BF16_SPLIT_ROWS = keep
+    torch.cuda.synchronize()
+    assert torch.isfinite(one).all()
+    assert torch.equal(one, two) and torch.equal(one, one_again)
+

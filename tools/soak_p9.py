@@ -19,6 +19,12 @@ for B, ns in ((256, 64000), (32, 480000), (5, 200000)):
     miss = sum(int(not torch.equal(eng.embed_bf16(wav), ref)) for _ in range(n // 2))
     print(f"forward {B} x {ns}: repeat mismatches {miss}/{n // 2}", flush=True)
     bad += miss
+    # round 6: the same batch on ONE stream - its N = 768 GEMMs then run the 192-row tile mode - against the two-stream bits
+    keep, eng.BF16_SPLIT_ROWS = eng.BF16_SPLIT_ROWS, 0
+    miss = sum(int(not torch.equal(eng.embed_bf16(wav), ref)) for _ in range(n // 2))
+    eng.BF16_SPLIT_ROWS = keep
+    print(f"forward {B} x {ns}, one stream (short tiles): mismatches vs two streams {miss}/{n // 2}", flush=True)
+    bad += miss
     del wav
 side, side2 = torch.cuda.Stream(), torch.cuda.Stream()
 junk = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
@@ -43,7 +49,7 @@ for M, N, K in shapes:
                 with torch.cuda.stream(side2):
                     eng.diag_gemm_bf16(A2, W2, None, None, gelu=False, tile=60, out=out2)   # a second persistent launch competing for the CUs
             out.fill_(float("nan"))
-            eng.diag_gemm_bf16(A, W, bb, rr, gelu=ge, tile=60, out=out)
+            eng.diag_gemm_bf16(A, W, bb, rr, gelu=ge, tile=68 if i % 4 == 3 else 60, out=out)   # (68: the 192-row tile mode forced, round 6)
             miss += int(not torch.equal(out, ref))
         torch.cuda.synchronize()
         print(f"shape {M}x{N}x{K} [{kind}]: mismatches vs tile 58 {miss}/{n}", flush=True)
