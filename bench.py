@@ -517,6 +517,26 @@ def main():
             if use_pg:
                 dist.all_reduce(t5, op=dist.ReduceOp.MAX)
             v5 = world * 32 * 5 / float(t5.item())
+            # the same loop with the batch on ONE stream (Engine.BF16_SPLIT_ROWS = 0): what a caller who submits one forward at a time
+            # gets; since round 6 the N = 768 GEMMs of such a forward run the persistent kernel's 192-row tile mode
+            keep5 = eng.BF16_SPLIT_ROWS
+            eng.BF16_SPLIT_ROWS = 0
+            try:
+                for _ in range(2):
+                    m5s, _, _ = sc5.score(wav5[:28], wav5[28:], want_matrix=True)
+                fence()
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    m5s, _, _ = sc5.score(wav5[:28], wav5[28:], want_matrix=True)
+                fence()
+                t5s = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
+                if use_pg:
+                    dist.all_reduce(t5s, op=dist.ReduceOp.MAX)
+                c5_one = {"value": round(world * 32 * 5 / float(t5s.item()), 2), "unit": "clips/s", "steps": 5,
+                          "ms_per_step": round(1e3 * float(t5s.item()) / 5, 3),
+                          "scores_bit_equal_to_two_streams": bool(torch.equal(m5s, m5))}
+            finally:
+                eng.BF16_SPLIT_ROWS = keep5
             # the same 32 x 480 000 batch through bf16x3 (fp32-class scores from the bf16 matrix cores) and, once, through fp32:
             # what long-form scores within the north star's 1e-4 cost next to the bf16 figure
             c5_x3 = None
@@ -566,12 +586,13 @@ def main():
                        "ms_per_step": round(1e3 * float(t5.item()) / 5, 3),
                        "model_frac_of_mfma_peak": round(v5 * 500.044e9 / world / 2.5e15, 4),
                        "finite": bool(torch.isfinite(m5).all().item()),
+                       "one_stream": c5_one,
                        "fp32_class_scores_same_batch": c5_x3,
                        "context": "STATIC notes, not measured in this run: this forward holds a shader clock of 1997-2090 MHz of the 2400 nominal "
-                                  "(profiles/r05_clock_c5.jsonl); alone on the GPU the shipped persistent bf16 GEMM does 1016-1131 TFLOP/s on QKV, "
-                                  "903-1018 on fc1 + GELU, 866-1045 on fc2, hipBLASLt (no epilogue) 933-967 / 949-1041 / 1115-1180 "
-                                  "(profiles/r05_vendor_yardstick_bf16.jsonl, r05_gemm_bf16_p9_ab.jsonl); per-shape times inside the forward: "
-                                  "profiles/r05_c5_layer_table_*.json"}
+                                  "(profiles/r05_clock_c5.jsonl); alone on the GPU the shipped persistent bf16 GEMM does 1016-1146 TFLOP/s on QKV, "
+                                  "903-1018 on fc1 + GELU, 985-1108 on fc2 (192-row tiles), hipBLASLt (no epilogue) 933-967 / 949-1041 / 1115-1180 "
+                                  "(profiles/r05_vendor_yardstick_bf16.jsonl, r06_gemm_bf16_p9_short_ab.jsonl); per-shape times inside the forward: "
+                                  "profiles/r06_c5_layer_table_*.json; what the GEMM's epilogues cost per tile: profiles/r06_gemm_bf16_p9_epilogue_cost.txt"}
             del wav5
         except Exception as e:
             also_c5 = {"workload": "configs[4]", "error": str(e)[:200]}

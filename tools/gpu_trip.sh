@@ -14,6 +14,7 @@
 #   c2stats:<name>           rocprofv3 --kernel-trace --stats of bench.py --single-stream -> kernel_stats_<name>.csv
 #   c4table:<name>[:VAR=val,..]   kernel trace of configs[3] -> c4_trace_table_<name>.txt
 #   pmc:<shape>:<tile>:<name>     PMC passes (matrix pipe, TA, waits) of one bf16 GEMM shape
+#   pmcpy:<script>:<kernel substr>:<name>   the same PMC passes (+ SALU / waves / LDS conflicts) over any tools/ script
 #   attnab:<VAR>:<v1,v2,..>  tools/attn_bf16_ab.py per value
 #   attnf32:<VAR>:<v1,v2,..> tools/attn_f32_time.py per value
 #   py:<script>[:args]       python3 tools/<script> args  (stdout -> <script>.log)
@@ -76,6 +77,15 @@ for step in "$@"; do
         (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/pmc_${NAME}_p$i -o p -- python3 $ROOTDIR/tools/gemm_bf16_one.py $SHAPE $TILE > $OUT/pmc_${NAME}_p$i.log 2>&1)
       done
       python3 tools/pmc_summary.py $OUT "pmc_${NAME}_p" gemm_bf16 > $OUT/pmc_$NAME.txt; cat $OUT/pmc_$NAME.txt | tee -a $SUM
+      find $OUT -name "*.csv" -path "*pmc_${NAME}_p*" -delete ;;
+    pmcpy)   # pmcpy:<tools script>:<kernel name substring>:<name>[:script args] - the same PMC passes over any tools/ script
+      SCRIPT=${S[1]}; SUB=${S[2]}; NAME=${S[3]:-$SCRIPT}
+      i=0
+      for grp in "TA_BUSY_avr TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INST_CYCLES_VMEM" "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_INSTS_SALU SQ_WAVES SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS"; do
+        i=$((i+1))
+        (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/pmc_${NAME}_p$i -o p -- python3 $ROOTDIR/tools/$SCRIPT ${S[@]:4} > $OUT/pmc_${NAME}_p$i.log 2>&1)
+      done
+      python3 tools/pmc_summary.py $OUT "pmc_${NAME}_p" "$SUB" > $OUT/pmc_$NAME.txt; cat $OUT/pmc_$NAME.txt | tee -a $SUM
       find $OUT -name "*.csv" -path "*pmc_${NAME}_p*" -delete ;;
     attnab)
       VAR=${S[1]}; IFS=',' read -r -a VALS <<< "${S[2]}"
