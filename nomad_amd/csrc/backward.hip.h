@@ -53,17 +53,22 @@ __global__ void posconv_bwd_weight_kernel(const float* __restrict__ w, float* __
 // ---- LayerNorm backward -----------------------------------------------------------------------------
 // x = LN input, g (+ g2) = d loss / d LN output; dx = rstd * (gg - mean(gg) - xhat * mean(gg * xhat)),
 // gg = (g + g2) * gamma.  One wave per row; N = 256 * VPT.
-template <int VPT>
+// SPLITK (round 6): g is not read but formed here as the epilogue of a split-K GEMM - g[m][:] = sum_s partial[s][m][:] + R[m][:], slices in
+// order, then the residual: splitk_epilogue_kernel's arithmetic, element for element - so that the dX GEMM in front of a LayerNorm
+// backward (fc1^T before LN1, qkv^T before the previous layer's LN2 / the encoder LN) needs no epilogue launch of its own and g never
+// goes to memory.  The same bits as the two launches (tests/test_gpu_backward.py); dx may alias R (a wave reads its whole row first).
+template <int VPT, bool SPLITK = false>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                             const float* __restrict__ g2,
                                                             const float* __restrict__ gamma, float* __restrict__ dx,
-                                                            int M) {
+                                                            int M, int S = 0, const float* __restrict__ R = nullptr) {
     constexpr int N = 256 * VPT;
     const int lane = threadIdx.x & 63;
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
     const float4* xr = reinterpret_cast<const float4*>(x + (long long)m * N);
-    const float4* gr = reinterpret_cast<const float4*>(g + (long long)m * N);
+    const float4* gr = reinterpret_cast<const float4*>(g + (long long)m * N);   // (SPLITK: slice 0 of the partial products)
+    const float4* rr = (SPLITK && R) ? reinterpret_cast<const float4*>(R + (long long)m * N) : nullptr;
     const float4* g2r = g2 ? reinterpret_cast<const float4*>(g2 + (long long)m * N) : nullptr;
     const float4* gm4 = reinterpret_cast<const float4*>(gamma);
     float xv[VPT][4], gv[VPT][4];
@@ -72,6 +77,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     for (int i = 0; i < VPT; ++i) {
         const float4 a = xr[lane + 64 * i];
         float4 b = gr[lane + 64 * i];
+        if (SPLITK) {
+            for (int sl = 1; sl < S; ++sl) {
+                const float4 c = reinterpret_cast<const float4*>(g + ((long long)sl * M + m) * N)[lane + 64 * i];
+                b.x += c.x; b.y += c.y; b.z += c.z; b.w += c.w;
+            }
+            if (rr) {
+                const float4 c = rr[lane + 64 * i];
+                b.x += c.x; b.y += c.y; b.z += c.z; b.w += c.w;
+            }
+        }
         if (g2r) {
             const float4 c = g2r[lane + 64 * i];
             b.x += c.x; b.y += c.y; b.z += c.z; b.w += c.w;

@@ -64,6 +64,7 @@ struct LayerDev {
 // reads the environment: "nothing but the arguments" decides what a call does.  Only libnomad_diag.so (-DNOMAD_DIAG) fills a
 // context's copy from NOMAD_* environment variables, once, in nomad_create (tuning_from_env) - the A/B runs of tools/ and profiles/.
 struct Tuning {
+    bool splitk_lnb_fuse = true;   // NOMAD_SPLITK_LNB: a split-K dX GEMM in front of a LayerNorm backward has that kernel form its output (no epilogue launch)
     bool splitk_ln_fuse = true;    // NOMAD_SPLITK_LN: a split-K out_proj / fc2 normalises its rows in its own epilogue (splitk_epilogue_ln_kernel)
     bool splitk_posconv = true;    // NOMAD_SPLITK_POSCONV: the grouped pos-conv of the loss path splits K four ways
     bool splitk_layers = true;     // NOMAD_SPLITK_LAYERS: so do the dense GEMMs of a small layer-output forward
@@ -144,6 +145,7 @@ static void tuning_from_env(Tuning& t) {
     t.p9_res = getb("NOMAD_BF16_P9_RES", t.p9_res);
     t.p9_short = geti("NOMAD_BF16_P9_SHORT", t.p9_short);
     t.p9_skew = geti("NOMAD_BF16_P9_SKEW", t.p9_skew);
+    t.splitk_lnb_fuse = getb("NOMAD_SPLITK_LNB", t.splitk_lnb_fuse);
     t.attn_bwd_small = getb("NOMAD_ATTN_BWD_SMALL", t.attn_bwd_small);
 }
 #endif
@@ -180,6 +182,16 @@ struct nomad_ctx {
         float* out2 = nullptr;
         bool armed = false, done = false;
     } pending_ln;
+    // The backward's mirror (round 6): the LayerNorm BACKWARD the caller will apply to the output of the next dX GEMM (+ g2, the layer-output
+    // gradient).  When that GEMM splits K, the LayerNorm-backward kernel forms the GEMM's output row itself from the partial products
+    // (layernorm_bwd_kernel<3, true>) and sets `done`: no epilogue launch, the GEMM's output never goes to memory.  dX-only backward.
+    struct PendingLnBwd {
+        const float* x = nullptr;      // the LayerNorm's input (saved by the forward)
+        const float* g2 = nullptr;
+        const float* gamma = nullptr;
+        float* out = nullptr;
+        bool armed = false, done = false;
+    } pending_lnb;
     // nomad_pairwise: row sums per (64-ref tile, deg row), kPairScratchDoubles doubles PER LAUNCH STREAM - calls on
     // different streams of one context may be in flight together (Engine / ShardedScorer are driven from side streams), so
     // each stream gets its own block: the first at nomad_create, further ones on a stream's first call

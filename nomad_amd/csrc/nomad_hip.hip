@@ -320,6 +320,13 @@ static int run_gemm_splitk(nomad_ctx* c, const GemmParams& p, int S, hipStream_t
     c->splitk_ok = keep;
     if (rc) return rc;
     Scope sc(c, s, NOMAD_K_ROW, 0.0);
+    if (c->pending_lnb.armed && !c->pending_lnb.done && p.N == 768 && !p.gelu && !p.bias && c->tune.splitk_lnb_fuse) {
+        hipLaunchKernelGGL((layernorm_bwd_kernel<3, true>), dim3((unsigned)((p.M + 3) / 4)), dim3(256), 0, s, c->pending_lnb.x, c->splitk_cur,
+                           c->pending_lnb.g2, c->pending_lnb.gamma, c->pending_lnb.out, p.M, S, p.R);
+        HIP_TRY(hipGetLastError());
+        c->pending_lnb.done = true;
+        return 0;
+    }
     if (c->pending_ln.armed && !c->pending_ln.done && p.N == 768 && !p.gelu) {
         hipLaunchKernelGGL(splitk_epilogue_ln_kernel, dim3((unsigned)((p.M + 3) / 4)), dim3(256), 0, s, c->splitk_cur, S, p.M, p.bias, p.R, p.C,
                            c->pending_ln.gamma, c->pending_ln.beta, c->pending_ln.out, c->pending_ln.out2);
@@ -2474,6 +2481,10 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
     }
     // ---- 12 transformer layers, last to first ---------------------------------------------------------
     // One layer over clips [c0, c0 + nc): the whole batch, or one branch when LayerDrop split the branches.
+    bool lnb_prefused = false;   // the LayerNorm backward at the head of the next bwd_layer call (or the encoder's) ran inside the last GEMM's epilogue
+    bool whole_batch = true;     // every layer runs for every clip (no LayerDrop branch skips one)
+    for (int l = 0; l < NOMAD_NUM_LAYERS; ++l)
+        for (int br = 0; br < nbr; ++br) whole_batch = whole_batch && ((bmask[br] >> l) & 1u);
     auto bwd_layer = [&](int l, int c0, int nc) -> int {
         const LayerDev& d = c->layers[l];
         const LayerOffsets& lo = po.L[l];
@@ -2488,7 +2499,8 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
               *dqkvs = dqkv + r0 * 2304, *dmasks = dmask ? dmask + r0 * 768 : nullptr;
         const float* dl = dlayers ? dlayers + (size_t)l * M * 768 + r0 * 768 : nullptr;
         int rc;
-        if ((rc = run_ln_bwd(c, y2, gxs, dl, d.ln2_w, dyas, Ms, 768, s))) return rc;                    // dy2
+        if (!lnb_prefused && (rc = run_ln_bwd(c, y2, gxs, dl, d.ln2_w, dyas, Ms, 768, s))) return rc;   // dy2 (prefused: by the layer above's last GEMM)
+        lnb_prefused = false;
         // dy2 feeds the residual as is and the fc2 branch through its dropout mask
         const float* dy2b = dyas;
         if (d_res.threshold) {
@@ -2511,8 +2523,16 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
             tpose(gxs, 768, TB, false, Ms, Mps);
             if ((rc = dw_gemm(c, TA, TB, 3072, 768, Mps, part, G(lo.fc1_w), 0, 1.0f, s))) return rc;
         }
-        if ((rc = bwd_gemm(c, dhs, c->fc1_wT[l], dybs, Ms, 768, 3072, nullptr, dyas, s))) return rc;   // dx1 = du W1 + dy2
-        if ((rc = run_ln_bwd(c, y1, dybs, nullptr, d.ln1_w, dyas, Ms, 768, s))) return rc;             // dy1
+        // (dX-only backward: when the GEMM splits K, the LayerNorm backward forms dx1 from the partial products itself - pending_lnb)
+        c->pending_lnb = {};
+        if (!train) {
+            c->pending_lnb.x = y1; c->pending_lnb.gamma = d.ln1_w; c->pending_lnb.out = dyas; c->pending_lnb.armed = true;
+        }
+        rc = bwd_gemm(c, dhs, c->fc1_wT[l], dybs, Ms, 768, 3072, nullptr, dyas, s);                    // dx1 = du W1 + dy2
+        const bool ln1_done = c->pending_lnb.armed && c->pending_lnb.done;
+        c->pending_lnb = {};
+        if (rc) return rc;
+        if (!ln1_done && (rc = run_ln_bwd(c, y1, dybs, nullptr, d.ln1_w, dyas, Ms, 768, s))) return rc;   // dy1
         if (pg) ln_params(y1, dybs, nullptr, 768, G(lo.ln1_w), G(lo.ln1_b), Ms);
         const float* dy1b = dyas;  // dy1 through out_proj's dropout mask
         if (d_res.threshold) {
@@ -2544,7 +2564,22 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
             tpose(xin, 768, TB, false, Ms, Mps);
             if ((rc = dw_gemm(c, TA, TB, 2304, 768, Mps, part, G(lo.qkv_w), 768, 0.125f, s))) return rc;
         }
-        return bwd_gemm(c, dqkvs, c->qkv_wT[l], gxs, Ms, 768, 2304, nullptr, dyas, s);                 // dx_in = dqkv Wqkv + dy1
+        // dx_in = dqkv Wqkv + dy1; what follows it is the LayerNorm backward of the layer below (its LN2, with that layer's output gradient) or
+        // of the encoder's LayerNorm: fused into the split-K epilogue where the whole batch walks the layers together (no LayerDrop)
+        c->pending_lnb = {};
+        if (!train && whole_batch && !d_res.threshold) {
+            if (l > 0) {
+                c->pending_lnb.x = sv.L[l - 1].y2; c->pending_lnb.gamma = c->layers[l - 1].ln2_w;
+                c->pending_lnb.g2 = dlayers ? dlayers + (size_t)(l - 1) * M * 768 : nullptr;
+            } else {
+                c->pending_lnb.x = sv.y0; c->pending_lnb.gamma = c->eln_w;
+            }
+            c->pending_lnb.out = dya; c->pending_lnb.armed = true;
+        }
+        rc = bwd_gemm(c, dqkvs, c->qkv_wT[l], gxs, Ms, 768, 2304, nullptr, dyas, s);
+        lnb_prefused = c->pending_lnb.armed && c->pending_lnb.done;
+        c->pending_lnb = {};
+        return rc;
     };
     for (int l = NOMAD_NUM_LAYERS - 1; l >= 0; --l) {
         unsigned all = 1u;
@@ -2560,7 +2595,7 @@ static int backward_impl(nomad_ctx* c, const float* wav, int B, int n_samples, c
     const int Mp = lay.Mp;
     // ---- encoder input: LayerNorm, x + gelu(pos_conv(x)) --------------------------------------------
     if (d_res.threshold && (rc = run_dropout(c, gx, nullptr, gx, act, d_res, kSiteEncoder, s))) return rc;
-    if ((rc = run_ln_bwd(c, sv.y0, gx, nullptr, c->eln_w, dya, M, 768, s))) return rc;                   // dy0
+    if (!lnb_prefused && (rc = run_ln_bwd(c, sv.y0, gx, nullptr, c->eln_w, dya, M, 768, s))) return rc;   // dy0
     if (pg) ln_params(sv.y0, gx, nullptr, 768, G(po.eln_w), G(po.eln_b), M);
     const long long grp_stride = (long long)B * (T + 128) * 48;
     {

@@ -302,3 +302,29 @@ def test_splitk_epilogue_with_its_layernorm_is_bit_identical(built_lib, sd0, mon
     assert torch.isfinite(outs[0][1]).all()
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
+
+
+def test_layernorm_backward_inside_the_split_k_epilogue_is_bit_identical(built_lib, sd0, monkeypatch):
+    """Round 6: in the dX-only backward of a small batch the GEMMs in front of a LayerNorm backward (fc1^T, and qkv^T in front of the layer
+    below's LN2 / the encoder LN) split K; the LayerNorm-backward kernel then forms their output row from the partial products itself
+    (layernorm_bwd_kernel<3, true>) - 25 epilogue launches fewer per configs[3] step.  Against NOMAD_SPLITK_LNB=0 (epilogue + stand-alone
+    kernel): d loss / d waveform bit for bit, with and without layer-output gradients, and for a batch too large to split (unchanged path)."""
+    from nomad_amd.engine import Engine
+    gen = torch.Generator().manual_seed(6)
+    for B, n, with_layers in ((8, 16384, True), (3, 9000, False), (40, 64000, True)):
+        wav = (0.1 * torch.randn(B, n, generator=gen)).clamp(-1, 1).cuda()
+        outs = []
+        for flag in ("0", "1"):
+            monkeypatch.setenv("NOMAD_SPLITK_LNB", flag)
+            eng = Engine(sd0, 0, diag=True)
+            emb, layers, saved = eng.embed_train(wav)
+            g2 = torch.Generator().manual_seed(7)
+            dl = (torch.randn(layers.shape, generator=g2) / layers.numel()).cuda() if with_layers else None
+            de = (torch.randn(emb.shape, generator=g2) / emb.numel()).cuda()
+            dwav = eng.embed_backward(wav, layers, saved, dl, de)
+            torch.cuda.synchronize()
+            outs.append(dwav.clone())
+            eng.close()
+        assert torch.isfinite(outs[0]).all() and outs[0].abs().max() > 0
+        assert torch.equal(outs[0], outs[1]), (B, n)
+
