@@ -60,7 +60,7 @@ __device__ __forceinline__ float f2_sum4(float x) {   // sum over the same four 
 
 // EXTV (true in every product launch): the K / V fragments as ext-vector loads; false = float4 struct copies, in front of which hipcc
 // waits for the next tile's LDS-DMA (A/B runs of libnomad_diag.so, NOMAD_F32_ATTN_STRUCT_LOADS=1).
-template <bool EXTV = true>
+template <bool EXTV = true, bool VT4 = true>
 __global__ __launch_bounds__(256, 3) void attention_f32_v2_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                                   float* __restrict__ lse, int T, int nqblk,
                                                                   const int* __restrict__ tpref, int t_min) {
@@ -131,6 +131,20 @@ __global__ __launch_bounds__(256, 3) void attention_f32_v2_kernel(const float* _
         for (int i = 0; i < 2; ++i) {
             // V[key = row][d = 4*c16 + c] -> V^T[d][key]: row d is 128 B, chunk (key >> 2) ^ ((d >> 1) & 7), element key & 3
             const int cid = tid + i * 256, row = cid >> 4, c16 = cid & 15;
+            if (VT4) {
+                // Round 6: lanes l, l + 16, l + 32, l + 48 of a wave hold keys 4 kq .. 4 kq + 3 of the same four d: a 4 x 4 transpose across
+                // them (two v_permlane16_swap, two v_permlane32_swap) leaves lane group k with the four KEYS of d = 4 c16 + k - one chunk
+                // of V^T, one ds_write_b128 instead of four ds_write_b32 whose 16 lanes of a key hit 4 banks (PMC: 3.9 % of the kernel's
+                // cycles were LDS bank conflicts, all from these stores).  Data movement only: the same bytes land in the same places.
+                const auto ab = __builtin_amdgcn_permlane16_swap(__float_as_uint(vreg[i].x), __float_as_uint(vreg[i].y), false, false);
+                const auto cd = __builtin_amdgcn_permlane16_swap(__float_as_uint(vreg[i].z), __float_as_uint(vreg[i].w), false, false);
+                const auto ac = __builtin_amdgcn_permlane32_swap(ab[0], cd[0], false, false);
+                const auto bd = __builtin_amdgcn_permlane32_swap(ab[1], cd[1], false, false);
+                const int kq = row >> 2, k = row & 3, d = 4 * c16 + k;
+                f32x4 v4 = {__uint_as_float(ac[0]), __uint_as_float(bd[0]), __uint_as_float(ac[1]), __uint_as_float(bd[1])};
+                *reinterpret_cast<f32x4*>(B0 + kF2KT * 256 + d * 128 + 16 * (kq ^ ((d >> 1) & 7))) = v4;
+                continue;
+            }
             const int kq = row >> 2, ke = row & 3;
             char* vt = B0 + kF2KT * 256 + 4 * ke;
             const int d0 = 4 * c16, x0 = (d0 >> 1) & 7, x1 = x0 + 1;  // d0, d0+1 share x0; d0+2, d0+3 share x0 + 1 (d0 % 4 == 0)
@@ -278,11 +292,11 @@ __global__ __launch_bounds__(256, 3) void attention_f32_v2_kernel(const float* _
     }
 }
 
-template <bool EXTV = true>
+template <bool EXTV = true, bool VT4 = true>
 inline hipError_t launch_attention_f32_v2(const float* qkv, float* out, float* lse, int B, int T, const int* tpref, hipStream_t s,
                                           int t_min = 0) {
     const int nqblk = (T + 127) / 128;
-    hipLaunchKernelGGL(attention_f32_v2_kernel<EXTV>, dim3(nqblk * B * 12), dim3(256), attn_f32_v2_lds(), s, qkv, out, lse, T, nqblk, tpref, t_min);
+    hipLaunchKernelGGL((attention_f32_v2_kernel<EXTV, VT4>), dim3(nqblk * B * 12), dim3(256), attn_f32_v2_lds(), s, qkv, out, lse, T, nqblk, tpref, t_min);
     return hipGetLastError();
 }
 

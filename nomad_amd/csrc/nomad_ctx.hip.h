@@ -79,6 +79,7 @@ struct Tuning {
     double f32_quant_penalty = 0.0;  // NOMAD_F32_QUANT_PENALTY (percent): 0 = 8 % with two concurrent parts, 3 % alone
     bool f32_longk_33 = false;     // NOMAD_F32_LONGK_33
     int f32_mid_tile = 31;         // NOMAD_F32_MID_TILE
+    bool f32_attn_vt4 = true;      // NOMAD_F32_ATTN_VT4 (diag): the fp32 attention transposes V across lanes and stores 16-byte chunks (0: four ds_write_b32, A/B)
     bool f32_attn_struct_loads = false;  // NOMAD_F32_ATTN_STRUCT_LOADS (diag): the fp32 attention's LDS fragments as float4 struct copies (A/B)
     bool bf16_posconv_slab = true;  // NOMAD_BF16_POSCONV_SLAB: the bf16 pos-conv with its input slab resident in LDS (posconv_bf16_slab.hip.h);
                                     // false: the grouped GEMM on 128 x 64 tiles it replaces (A/B)
@@ -146,6 +147,7 @@ static void tuning_from_env(Tuning& t) {
     t.p9_short = geti("NOMAD_BF16_P9_SHORT", t.p9_short);
     t.p9_skew = geti("NOMAD_BF16_P9_SKEW", t.p9_skew);
     t.splitk_lnb_fuse = getb("NOMAD_SPLITK_LNB", t.splitk_lnb_fuse);
+    t.f32_attn_vt4 = getb("NOMAD_F32_ATTN_VT4", t.f32_attn_vt4);
     t.attn_bwd_small = getb("NOMAD_ATTN_BWD_SMALL", t.attn_bwd_small);
 }
 #endif

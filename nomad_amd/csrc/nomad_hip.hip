@@ -438,6 +438,7 @@ int run_attention(nomad_ctx* c, const float* qkv, float* out, float* lse, int B,
     {
 #ifdef NOMAD_DIAG
         if (c->tune.f32_attn_struct_loads) HIP_TRY(launch_attention_f32_v2<false>(qkv, out, lse, B, T, kNoInts, s));
+        else if (!c->tune.f32_attn_vt4) HIP_TRY((launch_attention_f32_v2<true, false>(qkv, out, lse, B, T, kNoInts, s)));
         else
 #endif
             HIP_TRY(launch_attention_f32_v2(qkv, out, lse, B, T, kNoInts, s));
