@@ -87,6 +87,7 @@ struct Tuning {
     int bf16_attn_v3 = 2;          // NOMAD_BF16_ATTN_V3: the bf16 attention on v_mfma_f32_16x16x32_bf16 with 32 queries per wave (2, shipped);
                                    // 3: its V reads through the builtin; 4 / 8: 64 queries per wave, 4 / 8 waves per workgroup (A/B: no faster); 0: the 32x32x16 kernel
     bool bf16_conv0_mfma = true;   // NOMAD_BF16_CONV0_MFMA
+    bool bf16_conv0_gelu_erf = false;   // NOMAD_BF16_CONV0_GELU_ERF (diag): the matrix-core conv0 with the erf GELU instead of the bf16-output one (A/B)
     int p8_min_tiles = 256;        // NOMAD_BF16_8PHASE_MIN_TILES: smallest grid (256 x 256 tiles) for the deep-pipelined bf16 kernels
     bool p8_nt_stores = true;      // NOMAD_BF16_NT_STORES
     int p8_rpre = 3;               // NOMAD_BF16_RPRE
@@ -148,6 +149,7 @@ static void tuning_from_env(Tuning& t) {
     t.p9_skew = geti("NOMAD_BF16_P9_SKEW", t.p9_skew);
     t.splitk_lnb_fuse = getb("NOMAD_SPLITK_LNB", t.splitk_lnb_fuse);
     t.f32_attn_vt4 = getb("NOMAD_F32_ATTN_VT4", t.f32_attn_vt4);
+    t.bf16_conv0_gelu_erf = getb("NOMAD_BF16_CONV0_GELU_ERF", t.bf16_conv0_gelu_erf);
     t.attn_bwd_small = getb("NOMAD_ATTN_BWD_SMALL", t.attn_bwd_small);
 }
 #endif

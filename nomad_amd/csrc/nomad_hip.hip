@@ -1187,6 +1187,13 @@ static int run_posconv_bf16_slab(nomad_ctx* c, const bf16_t* xpad, bf16_t* y, in
 // wav rows `stride` apart; lens == nullptr: every clip has l0 frames, else ragged (max_l0 = the longest clip's, pref0 = packed rows)
 static void launch_conv0_bf16(nomad_ctx* c, const float* wav, int stride, int l0, int max_l0, int B, const float* scale,
                               const float* shift, bf16_t* out, const int* lens, const int* pref0, hipStream_t s) {
+#ifdef NOMAD_DIAG
+    if (c->tune.bf16_conv0_mfma && c->conv0_wfrag && c->tune.bf16_conv0_gelu_erf) {   // A/B: the erf GELU (what shipped up to round 5)
+        hipLaunchKernelGGL((conv0_mfma_gn_gelu_kernel<kConv0MfmaOcc, kConv0MfmaUf, 3>), dim3((max_l0 + kConv0MfmaFrames - 1) / kConv0MfmaFrames, B), dim3(256), 0, s, wav,
+                           stride, l0, c->conv0_wfrag, scale, shift, out, lens, pref0);
+        return;
+    }
+#endif
     if (c->tune.bf16_conv0_mfma && c->conv0_wfrag)   // (Tuning::bf16_conv0_mfma = 0: the VALU kernel, A/B runs)
         hipLaunchKernelGGL((conv0_mfma_gn_gelu_kernel<kConv0MfmaOcc, kConv0MfmaUf>), dim3((max_l0 + kConv0MfmaFrames - 1) / kConv0MfmaFrames, B), dim3(256), 0, s, wav,
                            stride, l0, c->conv0_wfrag, scale, shift, out, lens, pref0);
