@@ -26,21 +26,30 @@ constexpr int kStatsPerClip = 65;  // 10 sums + 55 upper-triangular products
 // grid: (ceil(max L0 / kStatsChunk), B) blocks of 256 threads.  part[(b * gridDim.x + j)][0..9] = S, [10..64] = R
 // (j<=k, row-major) over frames [j * kStatsChunk, ...).  Ragged batches: lens != nullptr gives each clip's sample
 // count, clips are `n_samples` (the row stride) apart.
-// 1024 (round 6; 8192 before): a 1 s clip (3 276 frames, configs[3]) was ONE workgroup per clip - 32 workgroups, 13 dependent load rounds
-// each, 49 us per launch for 2 MB of waveform; four chunks per such clip fill 128 workgroups.  The statistics stay a function of the
-// clip's length only.
-constexpr int kStatsChunk = 1024;
+// Round 6: clips of at most 8192 frames (2.6 s) are summed in chunks of 1024 frames - a 1 s clip (3 276 frames, configs[3]) was ONE
+// workgroup per clip: 32 workgroups, 13 dependent load rounds each, 49 us per launch for 2 MB of waveform; four chunks per such clip fill
+// 128 workgroups.  Longer clips keep 8192 (with 1024 the 65 wave reductions per chunk tripled the kernel's time on 30 s clips: 38 -> 118 us
+// per configs[4] pass).  The chunk size, hence the summation order, is a function of the CLIP's length only.
+constexpr int kStatsChunk = 8192, kStatsChunkShort = 1024;
+__host__ __device__ constexpr int stats_chunk(int L0) { return L0 <= kStatsChunk ? kStatsChunkShort : kStatsChunk; }
+// chunk slots a batch needs per clip when its longest clip has max_l0 frames (a short clip beside a long one may need 8 of its own)
+__host__ __device__ constexpr int stats_chunk_slots(int max_l0) {
+    return max_l0 <= kStatsChunk ? (max_l0 + kStatsChunkShort - 1) / kStatsChunkShort
+                                 : ((max_l0 + kStatsChunk - 1) / kStatsChunk > kStatsChunk / kStatsChunkShort ? (max_l0 + kStatsChunk - 1) / kStatsChunk
+                                                                                                            : kStatsChunk / kStatsChunkShort);
+}
 __global__ __launch_bounds__(256) void wav_stats_kernel(const float* __restrict__ wav, int n_samples, int L0,
                                                         double* __restrict__ part, const int* __restrict__ lens) {
     const int b = blockIdx.y, j = blockIdx.x;
     const float* x = wav + (long long)b * n_samples;
     if (lens) L0 = (lens[b] - 10) / 5 + 1;
-    if (j * kStatsChunk >= L0) return;
-    const int t_end = min(L0, (j + 1) * kStatsChunk);
+    const int chunk = stats_chunk(L0);
+    if (j * chunk >= L0) return;
+    const int t_end = min(L0, (j + 1) * chunk);
     double acc[kStatsPerClip];
 #pragma unroll
     for (int i = 0; i < kStatsPerClip; ++i) acc[i] = 0.0;
-    for (int t = j * kStatsChunk + threadIdx.x; t < t_end; t += 256) {
+    for (int t = j * chunk + threadIdx.x; t < t_end; t += 256) {
         double v[10];
 #pragma unroll
         for (int q = 0; q < 10; ++q) v[q] = (double)x[5 * t + q];
@@ -73,7 +82,7 @@ __global__ __launch_bounds__(128) void wav_stats_fold_kernel(const double* __res
     const int b = blockIdx.x, i = threadIdx.x;
     if (i >= kStatsPerClip) return;
     if (lens) L0 = (lens[b] - 10) / 5 + 1;
-    const int nchunk = (L0 + kStatsChunk - 1) / kStatsChunk;
+    const int chunk = stats_chunk(L0), nchunk = (L0 + chunk - 1) / chunk;
     double s = 0.0;
     for (int j = 0; j < nchunk; ++j) s += part[((long long)b * nchunk_max + j) * kStatsPerClip + i];
     stats[(long long)b * kStatsPerClip + i] = s;

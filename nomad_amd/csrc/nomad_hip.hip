@@ -64,11 +64,11 @@ size_t align_up(size_t v) { return (v + 255) & ~size_t(255); }
 // Workspace carve.  With keep=false the conv stack ping-pongs between two buffers.
 // doubles in a forward's GroupNorm-statistics region: [B][65] final sums + [B][chunks][65] per-chunk partial sums
 size_t stats_doubles(int B, int max_l0) {
-    return (size_t)kStatsPerClip * B * (1 + (max_l0 + kStatsChunk - 1) / kStatsChunk);
+    return (size_t)kStatsPerClip * B * (1 + stats_chunk_slots(max_l0));
 }
 // the two launches that fill it (frontend.hip.h); L0: conv-0 frames per clip (0 with lens), max_l0: the longest clip's
 void launch_wav_stats(const float* wav, int ld, int L0, int max_l0, int B, double* stats, const int* lens, hipStream_t s) {
-    const int nchunk = (max_l0 + kStatsChunk - 1) / kStatsChunk;
+    const int nchunk = stats_chunk_slots(max_l0);
     double* part = stats + (size_t)kStatsPerClip * B;
     hipLaunchKernelGGL(wav_stats_kernel, dim3(nchunk, B), dim3(256), 0, s, wav, ld, L0, part, lens);
     hipLaunchKernelGGL(wav_stats_fold_kernel, dim3(B), dim3(128), 0, s, part, nchunk, L0, stats, lens);
