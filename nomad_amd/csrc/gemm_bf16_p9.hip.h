@@ -218,6 +218,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
     const int nk = p.K / 64;  // even
     const bool has_r = p.R != nullptr, has_b = p.bias != nullptr;
     const bool inter = INTER && !has_r && ABL != 1;   // this problem's epilogues are interleaved into the next tile's first K tile
+    const bool late_hook = p.gelu && wr == 0 && p.p9_late != 0;   // (see NOMAD_P9_EPI_HOOK_LATE)
     int n_done = 0;
 
     f32x4 acc[8][4];
@@ -266,11 +267,25 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
             acc[i][2 * (JH) + 1] = (f32x4){0.f, 0.f, 0.f, 0.f};                                                           \
         }                                                                                                                 \
     }
+    // Round 6, LATE hooks of the first wave row in GELU problems.  A hook with GELU is ~340 vector instructions (1 360 issue cycles for one
+    // wave) against the 256 cycles of the partner wave's MFMA cluster beside it: hooked phases are vector-issue time, and with the two rows'
+    // hooks in ALTERNATE slots (each next to the other row's matrix work) a SIMD issues them one wave at a time - 4 cycles per instruction.
+    // Two waves issuing vector instructions together get 2 cycles per instruction.  So wave row 0 runs its hook of phase q not in its load
+    // slot but right behind the barrier, in front of its own MFMAs of that phase - the slot in which wave row 1 (one barrier behind) runs
+    // ITS hook of phase q: both hooks at once, then row 0's cluster.  Per hooked phase 1 360 + 256 + 256 instead of 2 x 1 360 cycles.
+    // The count and order of a wave's vector-memory operations in front of the phase-4 wait do not change.  Without GELU a hook is shorter
+    // than a cluster and the alternate placement stays.
 #define NOMAD_P9_EPI_HOOK(I0, JH)                                        \
-    if (epi_now) {                                                       \
+    if (epi_now && !late_hook) {                                         \
         __builtin_amdgcn_sched_barrier(0);                               \
         if (p.gelu) NOMAD_P9_EPI_QUAD(I0, JH, true)                      \
         else NOMAD_P9_EPI_QUAD(I0, JH, false)                            \
+        __builtin_amdgcn_sched_barrier(0);                               \
+    }
+#define NOMAD_P9_EPI_HOOK_LATE(I0, JH)                                   \
+    if (epi_now && late_hook) {                                          \
+        __builtin_amdgcn_sched_barrier(0);                               \
+        NOMAD_P9_EPI_QUAD(I0, JH, true)                                  \
         __builtin_amdgcn_sched_barrier(0);                               \
     }
 
@@ -285,9 +300,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
         if ((I0) == 0 || !sh) NOMAD_P9_MMA_ROWS(I0, J0, KH, 2, 4)
     // MID (DMAP == 3 only): a half-tile of LDS-DMA issued between the cluster's two k-halves, in the shadow of its MFMAs
     // (1 / 2 = B half 0 / 1, 3 / 4 = A half 0 / 1 of K tile t + 2; PAR = the A buffer's parity)
-#define NOMAD_P9_SYNC_COMPUTE(I0, J0, MID, PAR)         \
+#define NOMAD_P9_SYNC_COMPUTE(I0, J0, MID, PAR, HOOKS, HI0, HJH) \
     __builtin_amdgcn_s_barrier();                       \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
+    if (HOOKS) NOMAD_P9_EPI_HOOK_LATE(HI0, HJH)         \
     __builtin_amdgcn_s_setprio(1);                      \
     NOMAD_P9_MMA_KH(I0, J0, 0)                          \
     if (DMAP == 3) {                                    \
@@ -323,7 +339,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
         }                                                                                                  \
         if (DMAP == 0) NOMAD_P9_DMA_B(0)                                                                   \
         if (HOOKS) NOMAD_P9_EPI_HOOK(0, 0)                                                                 \
-        NOMAD_P9_SYNC_COMPUTE(0, 0, 1, PAR)                                                                     \
+        NOMAD_P9_SYNC_COMPUTE(0, 0, 1, PAR, HOOKS, 0, 0)                                                   \
         /* phase 2: A rows 64..127 */                                                                      \
         _Pragma("unroll") for (int i = 4; i < 6; ++i) {                                                    \
             af[i][0] = *reinterpret_cast<const bf16x8*>(la_ + i * 2048 + koff0);                           \
@@ -338,7 +354,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
         if (DMAP == 0) NOMAD_P9_DMA_B(1)                                                                   \
         if (DMAP == 2) NOMAD_P9_DMA_B(0)                                                                   \
         if (HOOKS) NOMAD_P9_EPI_HOOK(4, 0)                                                                 \
-        NOMAD_P9_SYNC_COMPUTE(4, 0, 2, PAR)                                                                     \
+        NOMAD_P9_SYNC_COMPUTE(4, 0, 2, PAR, HOOKS, 4, 0)                                                   \
         /* phase 3: B columns 32..63 */                                                                    \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                    \
             bf[j][0] = *reinterpret_cast<const bf16x8*>(lb_ + (2 + j) * 2048 + koff0);                     \
@@ -347,7 +363,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
         if (DMAP == 1) NOMAD_P9_DMA_B(0)                                                                   \
         if (DMAP == 1 || DMAP == 2) NOMAD_P9_DMA_B(1)                                                      \
         if (HOOKS) NOMAD_P9_EPI_HOOK(0, 1)                                                                 \
-        NOMAD_P9_SYNC_COMPUTE(0, 2, 3, PAR)                                                                     \
+        NOMAD_P9_SYNC_COMPUTE(0, 2, 3, PAR, HOOKS, 0, 1)                                                   \
         /* phase 4: both A halves of tile t+2 (their last read was phase 2), then "tile t+1 has landed" */ \
         if (DMAP != 3) {                                                                                   \
             NOMAD_P9_DMA_A(PAR, 0)                                                                         \
@@ -360,7 +376,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
             else NOMAD_P9_WAIT_VM(6)                                                                       \
         }                                                                                                  \
         if (HOOKS) NOMAD_P9_EPI_HOOK(4, 1)                                                                 \
-        NOMAD_P9_SYNC_COMPUTE(4, 2, 4, PAR)                                                                \
+        NOMAD_P9_SYNC_COMPUTE(4, 2, 4, PAR, HOOKS, 4, 1)                                                   \
         if (DMAP == 3) NOMAD_P9_ADVANCE()                                                                  \
         b3_cur = b3_cur >= 2 * A_BUF ? 0 : b3_cur + A_BUF;                                                 \
     }
@@ -476,6 +492,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
 #undef NOMAD_P9_MMA_KH
 #undef NOMAD_P9_MMA_ROWS
 #undef NOMAD_P9_EPI_HOOK
+#undef NOMAD_P9_EPI_HOOK_LATE
 #undef NOMAD_P9_EPI_QUAD
 #undef NOMAD_P9_DMA_A
 #undef NOMAD_P9_DMA_B

@@ -120,6 +120,7 @@ int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, int til
                 const long long r_full = (tiles + grid - 1) / grid, r_short = (tm_s * tn + grid - 1) / grid;
                 p.p9_short = (tu.p9_short == 2 || 0.80 * (double)r_short < 0.95 * (double)r_full) ? 1 : 0;
             }
+            p.p9_late = tu.p9_late ? 1 : 0;
             e = launch_gemm_bf16_p9<0, true>(p, s, cus);
             break;
         }
@@ -222,6 +223,7 @@ int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, int til
         case 68:  // persistent kernel, 192-row tiles forced (A/B against 64 = never short; 60 = the shipped choice)
             if (!p9_applies(p, groups)) return fail(NOMAD_ERR_INVALID, "bf16 persistent gemm: plain C / R, one group, N %% 256, K %% 128, contiguous K");
             p.p9_short = 1;
+            p.p9_late = tu.p9_late ? 1 : 0;
             e = launch_gemm_bf16_p9<0, true>(p, s, c->num_cus);
             break;
         case 61:  // persistent kernel: per-workgroup timeline probe / no output stores (timing) / every epilogue between tiles (A/B)
