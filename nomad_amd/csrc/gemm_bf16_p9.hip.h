@@ -63,8 +63,9 @@ __host__ __device__ constexpr int p9_wperm(int p) { return 32 * (p >> 5) + 8 * (
 //   that wait is a real s_waitcnt instruction (NOMAD_P9_WAIT_VM) the compiler knows so and never drains the LDS-DMA queue for it
 //   (cdna_hip_programming.md 5, "mixing load kinds") - and distributed with ds_bpermute_b32.  (A first version loaded it by inline asm
 //   and tied the register to an asm wait: the compiler copied the register BEFORE the wait - stale bias in some runs.)
-//   vmcnt in the interleaved K tile: its phase 4 must see K tile 1 landed, whose DMA was issued before 12 + 4 + 4 = 20 newer
-//   operations (2 + 2 B DMA, 3 x 4 quadrant stores, 4 A DMA): vmcnt(20); everywhere else vmcnt(8) as before.
+//   vmcnt in the interleaved K tile: its phase 4 must see K tile 1 landed, whose DMA was issued before 4 + 16 + 4 = 24 newer
+//   operations (2 + 2 B DMA, the two hooks' 2 x 8 stores, 4 A DMA): vmcnt(24); everywhere else vmcnt(8) as before.  (Round 5: four hooks of one
+//   64 x 32 quadrant each, 12 stores before the wait: vmcnt(20); round 6's whole-line stores pair the column halves of a row.)
 // DMAP: in which phase slots the B tile of K tile t + 2 is issued: 0 = phases 1 / 2 (next to the 12 / 8 fragment reads of those slots, as
 //   the one-tile-per-workgroup kernel does), 1 = both halves in phase 3 (4 fragment reads), 2 = phases 2 / 3.  The microarchitecture guide
 //   prices an LDS-DMA instruction at 100-185 issue cycles inside a slot that already carries many LDS reads and at 25-60 in a quiet one;
@@ -218,7 +219,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
     const int nk = p.K / 64;  // even
     const bool has_r = p.R != nullptr, has_b = p.bias != nullptr;
     const bool inter = INTER && !has_r && ABL != 1;   // this problem's epilogues are interleaved into the next tile's first K tile
-    const bool late_hook = p.gelu && wr == 0 && p.p9_late != 0;   // (see NOMAD_P9_EPI_HOOK_LATE)
+    const bool late_hook = wr == 0 && p.p9_late != 0;   // (see NOMAD_P9_EPI_HOOK_LATE)
+    const bool wl = p.p9_wl != 0;                        // whole-line output stores (NOMAD_P9_LINE_SWAP)
     int n_done = 0;
 
     f32x4 acc[8][4];
@@ -240,31 +242,52 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
             clamp_bytes((long long)(p.M - mw) * p.cmap.ld * 2), 0x00020000);
     };
 
-    // epilogue of accumulator row tiles I0 .. I0 + 3 x column half JH (a 64 x 32 quadrant of the wave tile) straight from the
-    // registers: acc[i][j][r] = out[m0 + 128 wr + 16 i + fr][n0 + 64 wc + 32 (j >> 1) + 8 fq + 4 (j & 1) + r]; leaves them zero
-#define NOMAD_P9_EPI_QUAD(I0, JH, GELU_)                                                                                  \
+    // epilogue of accumulator row tiles I0 .. I0 + 3 (64 rows x the wave's 64 columns) straight from the registers:
+    // acc[i][j][r] = out[m0 + 128 wr + 16 i + fr][n0 + 64 wc + 32 (j >> 1) + 8 fq + 4 (j & 1) + r]; leaves them zero.
+    // WHOLE-LINE stores (round 6, tools/micro/store_pattern.hip): as it stands an accumulator gives a store instruction of 16 rows x 64 bytes
+    // - sixteen half cache lines, the other halves in a second instruction - and 256 CUs storing their tiles that way reach 4.2 TB/s
+    // (8.0 us per 128 KB tile) where 8 rows x 128 bytes per instruction reach 5.6-5.9 (6.0 us).  A lane holds chunk fq of BOTH 64-byte
+    // halves of its row fr; lanes fr and fr + 8 of a 16-lane row swap one chunk each (DPP row_ror:8 under a bank mask: two instructions and a
+    // copy per register) so that instruction X carries rows 0 .. 7 of the row tile whole (lanes fr < 8: half 0, lanes fr >= 8: half 1 of row
+    // fr - 8) and instruction Y rows 8 .. 15.  Same bytes, same places.
+#define NOMAD_P9_LINE_SWAP(P0, P1)                                                                                        \
+    _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                                                    \
+        const int t_ = (int)(P1)[r_];                                                                                     \
+        (P1)[r_] = (unsigned)__builtin_amdgcn_update_dpp((int)(P1)[r_], (int)(P0)[r_], 0x128, 0xF, 0x3, false);  /* Y: lanes 0-7 <- half 0 of rows 8-15 */ \
+        (P0)[r_] = (unsigned)__builtin_amdgcn_update_dpp((int)(P0)[r_], t_, 0x128, 0xF, 0xC, false);              /* X: lanes 8-15 <- half 1 of rows 0-7 */ \
+    }
+#define NOMAD_P9_EPI_ROWS(I0, NI, GELU_)                                                                                   \
     {                                                                                                                     \
         int lane_e = lane;                                                                                                \
         asm volatile("" : "+v"(lane_e));  /* offsets recomputed here: hoisted, they would sit in registers through the K loop */ \
-        const int fq_e = lane_e >> 4;                                                                                     \
-        const int c_voff = ((lane_e & 15) * p.cmap.ld + 8 * fq_e) * 2 + (JH)*64;                                          \
-        const int bsel = (32 * (JH) + 8 * fq_e) * 4;                                                                      \
-        float bq[8];                                                                                                      \
-        _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                                     \
-            bq[e] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bsel + 4 * e, __builtin_bit_cast(int, bias_lane))); \
-        _Pragma("unroll") for (int i = (I0); i < (I0) + 4; ++i) {                                                         \
-            bf16x8 ov;                                                                                                    \
+        const int fr_e = lane_e & 15, fq_e = lane_e >> 4;                                                                 \
+        /* (wl = false, A/B: the accumulator's own shape - instruction X = the row's first 64 bytes, Y = its second) */   \
+        const int c_voff = wl ? ((fr_e & 7) * p.cmap.ld) * 2 + 16 * (4 * (fr_e >> 3) + fq_e) : (fr_e * p.cmap.ld + 8 * fq_e) * 2; \
+        const int y_step = wl ? 8 * p.cmap.ld * 2 : 64;                                                                   \
+        float bq[2][8];                                                                                                   \
+        _Pragma("unroll") for (int jh = 0; jh < 2; ++jh)                                                                  \
+            _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                                 \
+                bq[jh][e] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((32 * jh + 8 * fq_e + e) * 4, __builtin_bit_cast(int, bias_lane))); \
+        _Pragma("unroll") for (int i = (I0); i < (I0) + (NI); ++i) {                                                      \
+            bf16x8 o0, o1;                                                                                                \
             _Pragma("unroll") for (int g = 0; g < 2; ++g)                                                                 \
                 _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                           \
-                    float x = acc[i][2 * (JH) + g][r] + bq[4 * g + r];                                                    \
-                    if (GELU_) x = gelu_bf16out(x);                                                                       \
-                    ov[4 * g + r] = (bf16_t)x;                                                                            \
+                    float x0 = acc[i][g][r] + bq[0][4 * g + r], x1 = acc[i][2 + g][r] + bq[1][4 * g + r];                 \
+                    if (GELU_) {                                                                                          \
+                        x0 = gelu_bf16out(x0);                                                                            \
+                        x1 = gelu_bf16out(x1);                                                                            \
+                    }                                                                                                     \
+                    o0[4 * g + r] = (bf16_t)x0;                                                                           \
+                    o1[4 * g + r] = (bf16_t)x1;                                                                           \
                 }                                                                                                         \
+            u32x4 px = __builtin_bit_cast(u32x4, o0), py = __builtin_bit_cast(u32x4, o1);                                 \
+            if (wl) NOMAD_P9_LINE_SWAP(px, py)                                                                            \
             /* (row offset in the VGPR offset, never in the scalar offset: the store-data hazard of DESIGN.md 5) */       \
             /* (short tiles: row tiles 6, 7 of a wave do not exist - their stores fall past the end of the descriptor) */ \
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), rc_p, c_voff + i * 16 * p.cmap.ld * 2 + ((i >= 6 && sh) ? 0x40000000 : 0), 0, 2); \
-            acc[i][2 * (JH)] = (f32x4){0.f, 0.f, 0.f, 0.f};                                                               \
-            acc[i][2 * (JH) + 1] = (f32x4){0.f, 0.f, 0.f, 0.f};                                                           \
+            const int o_ = c_voff + i * 16 * p.cmap.ld * 2 + ((i >= 6 && sh) ? 0x40000000 : 0);                           \
+            __builtin_amdgcn_raw_buffer_store_b128(px, rc_p, o_, 0, 2);                                                   \
+            __builtin_amdgcn_raw_buffer_store_b128(py, rc_p, o_ + y_step, 0, 2);                                          \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};                        \
         }                                                                                                                 \
     }
     // Round 6, LATE hooks of the first wave row in GELU problems.  A hook with GELU is ~340 vector instructions (1 360 issue cycles for one
@@ -275,17 +298,21 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
     // ITS hook of phase q: both hooks at once, then row 0's cluster.  Per hooked phase 1 360 + 256 + 256 instead of 2 x 1 360 cycles.
     // The count and order of a wave's vector-memory operations in front of the phase-4 wait do not change.  Without GELU a hook is shorter
     // than a cluster and the alternate placement stays.
+    // (with whole-line stores a hook needs both column halves of a row at once, and 16 bias values instead of 8: the ONE hook of a K tile 0
+    // sits in phase 1 and takes the whole 128 x 64 wave tile - there the A fragments of rows 64 .. 127, loaded in phase 2, are dead and
+    // their 32 registers carry it; two hooks in phases 1 and 2 spilled.  JH != 0 / I0 != 0 mark the call sites without a hook.)
 #define NOMAD_P9_EPI_HOOK(I0, JH)                                        \
-    if (epi_now && !late_hook) {                                         \
+    if ((I0) == 0 && (JH) == 0 && epi_now && !late_hook) {               \
         __builtin_amdgcn_sched_barrier(0);                               \
-        if (p.gelu) NOMAD_P9_EPI_QUAD(I0, JH, true)                      \
-        else NOMAD_P9_EPI_QUAD(I0, JH, false)                            \
+        if (p.gelu) NOMAD_P9_EPI_ROWS(0, 8, true)                        \
+        else NOMAD_P9_EPI_ROWS(0, 8, false)                              \
         __builtin_amdgcn_sched_barrier(0);                               \
     }
 #define NOMAD_P9_EPI_HOOK_LATE(I0, JH)                                   \
-    if (epi_now && late_hook) {                                          \
+    if ((I0) == 0 && (JH) == 0 && epi_now && late_hook) {                \
         __builtin_amdgcn_sched_barrier(0);                               \
-        NOMAD_P9_EPI_QUAD(I0, JH, true)                                  \
+        if (p.gelu) NOMAD_P9_EPI_ROWS(0, 8, true)                        \
+        else NOMAD_P9_EPI_ROWS(0, 8, false)                              \
         __builtin_amdgcn_sched_barrier(0);                               \
     }
 
@@ -368,11 +395,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
         if (DMAP != 3) {                                                                                   \
             NOMAD_P9_DMA_A(PAR, 0)                                                                         \
             NOMAD_P9_DMA_A(PAR, 1)                                                                         \
-            if ((HOOKS) && epi_now) NOMAD_P9_WAIT_VM(20)                                                   \
+            if ((HOOKS) && epi_now) NOMAD_P9_WAIT_VM(24)   /* 2 + 2 B DMA, 2 x 8 hook stores, 4 A DMA */            \
             else NOMAD_P9_WAIT_VM(8)                                                                       \
             NOMAD_P9_ADVANCE()                                                                             \
         } else {  /* B and A half 0 of tile t+2 were issued in clusters 1-3: 6 newer operations (+ 12 stores of the hooks) */ \
-            if ((HOOKS) && epi_now) NOMAD_P9_WAIT_VM(18)                                                   \
+            if ((HOOKS) && epi_now) NOMAD_P9_WAIT_VM(22)                                                   \
             else NOMAD_P9_WAIT_VM(6)                                                                       \
         }                                                                                                  \
         if (HOOKS) NOMAD_P9_EPI_HOOK(4, 1)                                                                 \
@@ -408,7 +435,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
             const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(uniform_ptr(reinterpret_cast<const float*>(has_r ? Rb + p.rmap.off + (long long)mw * p.rmap.ld + nw : reinterpret_cast<const bf16_t*>(p.C)))), 0,
                 has_r ? clamp_bytes((long long)(p.M - mw) * p.rmap.ld * 2) : 0u, 0x00020000);
-            const int c_voff = (fr_e * p.cmap.ld + 8 * fq_e) * 2, r_voff = (fr_e * p.rmap.ld + 8 * fq_e) * 2;
+            const int cl_voff = wl ? ((fr_e & 7) * p.cmap.ld) * 2 + 16 * (4 * (fr_e >> 3) + fq_e) : (fr_e * p.cmap.ld + 8 * fq_e) * 2;
+            const int cl_ystep = wl ? 8 * p.cmap.ld * 2 : 64, r_voff = (fr_e * p.rmap.ld + 8 * fq_e) * 2;
             // one straight-line copy per (GELU, residual) combination: decided once per tile, not once per chunk
             auto epi = [&](auto gelu_c, auto res_c) {
                 constexpr bool GELU = decltype(gelu_c)::value, RES = decltype(res_c)::value;
@@ -434,6 +462,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     if (i >= 6 && sh) continue;
+                    u32x4 pxy[2];
 #pragma unroll
                     for (int jh = 0; jh < 2; ++jh) {
                         float v[8];
@@ -453,11 +482,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
                         bf16x8 ov;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) ov[e] = (bf16_t)v[e];
-                        // (row offset in the VGPR offset, never in the scalar offset: the store-data hazard of DESIGN.md 5)
-                        if (ABL != 1 || p.M < 0)
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), rc, c_voff + i * 16 * p.cmap.ld * 2 + jh * 64, 0, 2);
+                        pxy[jh] = __builtin_bit_cast(u32x4, ov);
                         acc[i][2 * jh] = (f32x4){0.f, 0.f, 0.f, 0.f};
                         acc[i][2 * jh + 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
+                    // whole-line stores (NOMAD_P9_EPI_ROWS): rows 0 .. 7 of the row tile in one instruction, rows 8 .. 15 in the other
+                    if (wl) NOMAD_P9_LINE_SWAP(pxy[0], pxy[1])
+                    // (row offset in the VGPR offset, never in the scalar offset: the store-data hazard of DESIGN.md 5)
+                    if (ABL != 1 || p.M < 0) {
+                        __builtin_amdgcn_raw_buffer_store_b128(pxy[0], rc, cl_voff + i * 16 * p.cmap.ld * 2, 0, 2);
+                        __builtin_amdgcn_raw_buffer_store_b128(pxy[1], rc, cl_voff + i * 16 * p.cmap.ld * 2 + cl_ystep, 0, 2);
                     }
                 }
             };
@@ -493,7 +527,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
 #undef NOMAD_P9_MMA_ROWS
 #undef NOMAD_P9_EPI_HOOK
 #undef NOMAD_P9_EPI_HOOK_LATE
-#undef NOMAD_P9_EPI_QUAD
+#undef NOMAD_P9_EPI_ROWS
+#undef NOMAD_P9_LINE_SWAP
 #undef NOMAD_P9_DMA_A
 #undef NOMAD_P9_DMA_B
 #undef NOMAD_P9_ADVANCE

@@ -102,6 +102,7 @@ struct GemmParams {
     long long a_soff, w_soff, c_soff;   // gemm_f32_n48_kernel, K split over blockIdx.z (loss path only): element offsets per slice of A, W and C
     int tile_m_base;        // gemm_f32_mixed_kernel: the first row tile of this part of the problem (in units of its BM); 0 otherwise
     int p9_skew;            // gemm_bf16_p9_kernel, timeline probe only (ABL = 7): workgroup group (blockIdx.x >> 3) & 3 starts p9_skew x 10 ns x group late
+    int p9_wl;              // gemm_bf16_p9_kernel: 1 = output stores of 8 rows x 128 bytes per instruction (lanes fr / fr + 8 swap a chunk), 0 = 16 rows x 64 bytes
     int p9_late;            // gemm_bf16_p9_kernel: 1 = wave row 0 runs its GELU epilogue hooks behind the phase's barrier, beside wave row 1's (round 6)
     int p9_short;           // gemm_bf16_p9_kernel: 1 = 192-row tiles (96 rows per wave row) instead of 256-row ones, same instantiation (run-time)
 };

@@ -103,6 +103,8 @@ struct Tuning {
                                    // save more than they cost: 1 = by the round count, batches that run alone only (the N = 768 GEMMs of config C5 on one
                                    // stream), 2 = every problem, 0 = never
     bool attn_bwd_small = true;    // NOMAD_ATTN_BWD_SMALL: clips of at most 64 frames take the fused attention backward (one launch; 0: rowdot + dkv + dq)
+    bool p9_wl = false;            // NOMAD_BF16_P9_WL: whole-line output stores of the persistent kernel (8 rows x 128 bytes per instruction instead of the
+                                   // accumulator's 16 x 64: 5.6 against 4.2 TB/s in tools/micro/store_pattern.hip, QKV -3.5 % alone, configs[4] -0.8 %: off)
     bool p9_late = true;           // NOMAD_BF16_P9_LATE: GELU epilogue hooks of wave row 0 behind the phase barrier, concurrent with wave row 1's
     int p9_skew = 0;               // NOMAD_BF16_P9_SKEW (diag, timeline probe tile 61 only): start skew between workgroup groups, units of 10 ns
     int concurrent_parts = 1;      // nomad_set_concurrent_parts: batches the host layer runs concurrently on separate streams
@@ -149,6 +151,7 @@ static void tuning_from_env(Tuning& t) {
     t.p9_short = geti("NOMAD_BF16_P9_SHORT", t.p9_short);
     t.p9_skew = geti("NOMAD_BF16_P9_SKEW", t.p9_skew);
     t.p9_late = getb("NOMAD_BF16_P9_LATE", t.p9_late);
+    t.p9_wl = getb("NOMAD_BF16_P9_WL", t.p9_wl);
     t.splitk_lnb_fuse = getb("NOMAD_SPLITK_LNB", t.splitk_lnb_fuse);
     t.f32_attn_vt4 = getb("NOMAD_F32_ATTN_VT4", t.f32_attn_vt4);
     t.bf16_conv0_gelu_erf = getb("NOMAD_BF16_CONV0_GELU_ERF", t.bf16_conv0_gelu_erf);

@@ -121,6 +121,7 @@ int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, int til
                 p.p9_short = (tu.p9_short == 2 || 0.80 * (double)r_short < 0.95 * (double)r_full) ? 1 : 0;
             }
             p.p9_late = tu.p9_late ? 1 : 0;
+            p.p9_wl = tu.p9_wl ? 1 : 0;
             e = launch_gemm_bf16_p9<0, true>(p, s, cus);
             break;
         }
@@ -224,6 +225,7 @@ int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, int til
             if (!p9_applies(p, groups)) return fail(NOMAD_ERR_INVALID, "bf16 persistent gemm: plain C / R, one group, N %% 256, K %% 128, contiguous K");
             p.p9_short = 1;
             p.p9_late = tu.p9_late ? 1 : 0;
+            p.p9_wl = tu.p9_wl ? 1 : 0;
             e = launch_gemm_bf16_p9<0, true>(p, s, c->num_cus);
             break;
         case 61:  // persistent kernel: per-workgroup timeline probe / no output stores (timing) / every epilogue between tiles (A/B)
@@ -231,6 +233,7 @@ int run_gemm_bf16(nomad_ctx* c, GemmParams p, int groups, hipStream_t s, int til
         case 63:
             if (!p9_applies(p, groups)) return fail(NOMAD_ERR_INVALID, "bf16 persistent gemm: plain C / R, one group, N %% 256, K %% 128, contiguous K");
             if (tile == 61) p.p9_skew = tu.p9_skew;
+            if (tile != 63) { p.p9_late = tu.p9_late ? 1 : 0; p.p9_wl = tu.p9_wl ? 1 : 0; }   // (63 keeps the accumulator-shaped stores: the bit-identity tests cover both)
             e = tile == 61 ? launch_gemm_bf16_p9<7, true>(p, s, c->num_cus) : tile == 62 ? launch_gemm_bf16_p9<1, true>(p, s, c->num_cus)
                                                                                       : launch_gemm_bf16_p9<0, false>(p, s, c->num_cus);
             break;

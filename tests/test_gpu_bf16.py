@@ -112,6 +112,34 @@ def test_bf16_gelu_of_an_overflowed_activation_is_zero_not_nan(engine_for):
         assert (out[:, ok.cuda()] - ref[:, ok.cuda()]).abs().max() < 0.02
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(47968, 768, 768, "bias_res"), (2999, 2304, 768, "bias"), (40000, 512, 1536, "bias_gelu"), (192 * 7 + 5, 768, 3072, "bias_res")])
+def test_gemm_bf16_persistent_kernel_whole_line_stores_are_bit_identical(built_lib, sd0, monkeypatch, M, N, K, epi):
+    """Round 6: the persistent kernel can store 8 rows x 128 bytes per instruction (lanes fr / fr + 8 of a 16-lane row swap a 16-byte chunk by
+    DPP) instead of the accumulator's 16 rows x 64 bytes.  Measured and left OFF (NOMAD_BF16_P9_WL, diag library), but the path stays in the kernel:
+    the same bytes in the same places, 256- and 192-row tiles, interleaved and between-tile epilogues."""
+    from nomad_amd.engine import Engine
+    g = torch.Generator().manual_seed(M + K)
+    A = torch.randn(M, K, generator=g).bfloat16().cuda()
+    W = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16().cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    R = torch.randn(M, N, generator=g).bfloat16().cuda() if "res" in epi else None
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("NOMAD_BF16_P9_WL", flag)
+        eng = Engine(sd0, 0, diag=True)
+        res = []
+        for t in (60, 68):
+            out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+            eng.diag_gemm_bf16(A, W, bias, R, gelu="gelu" in epi, tile=t, out=out)
+            res.append(out)
+        torch.cuda.synchronize()
+        outs.append(res)
+        eng.close()
+    assert torch.isfinite(outs[0][0].float()).all()
+    for t in range(2):
+        assert torch.equal(outs[0][t], outs[1][t]) and torch.equal(outs[0][0], outs[1][t])
+
+
 LOG2E = 1.4426950408889634
 
 
