@@ -50,22 +50,23 @@ __device__ __forceinline__ constexpr int p9_vmcnt(int n) { return (n & 15) | (7 
 __host__ __device__ constexpr int p9_wperm(int p) { return 32 * (p >> 5) + 8 * ((p >> 2) & 3) + 4 * ((p >> 4) & 1) + (p & 3); }
 
 // ABL: 0 = product; 7 = per-workgroup timeline probe (tools/p9_timeline.py); 1 = no output stores (timing probe)
-// INTER (round 5, second step): the epilogue of a tile WITHOUT a residual is interleaved into the first K tile of the workgroup's NEXT
-//   tile.  The accumulators of the finished tile stay where they are; in phase q of the next tile's K tile 0 - between that phase's LDS
-//   reads / DMA issue and its barrier, i.e. while the OTHER wave row's MFMA cluster occupies the matrix cores - a wave adds the bias,
-//   applies GELU, converts and stores the 64 x 32 quadrant that phase's MFMAs are about to overwrite, then zeroes it.  Both wave rows
-//   do that one barrier apart, so VALU / store work of one row always sits next to matrix work of the other (MI355X_MICROARCH.md
-//   "Two waves per SIMD", item 9: the measured form of this overlap).  The last tile of a workgroup is flushed by ONE more K tile 0
-//   (same code; its matrix work lands in zeroed accumulators that nobody stores).  Tiles WITH a residual keep the epilogue between
-//   tiles (their 16 residual loads per lane need 64 registers, which only exist there).
+// INTER (round 5, second step; reshaped in round 6): the epilogue of a tile WITHOUT a residual is interleaved into the first K tile of the
+//   workgroup's NEXT tile.  The accumulators of the finished tile stay where they are; in PHASE 1 of the next tile's K tile 0 a wave adds the
+//   bias, applies GELU, converts and stores its whole 128 x 64 wave tile and zeroes it - ONE hook (round 5 had four, one 64 x 32 quadrant per
+//   phase, each beside the other wave row's MFMA cluster; round 6 measured a hook at 1 360 vector-issue cycles with GELU against the cluster's
+//   256, and two waves of a SIMD in vector code issue at twice one wave's rate): wave row 1 runs its hook in its phase-1 load slot, wave row 0
+//   - one barrier ahead - behind the phase's barrier, in front of its own MFMAs, i.e. in the SAME time slot.  In phase 1 the A fragments of rows
+//   64 .. 127 (loaded in phase 2) are dead; their registers carry the hook's 16 bias values and temporaries.  The last tile of a workgroup is
+//   flushed by ONE more K tile 0 (same code; its matrix work lands in zeroed accumulators that nobody stores).  Tiles WITH a residual keep the
+//   epilogue between tiles (their 16 residual loads per lane need 64 registers, which only exist there).
 //   The bias reaches the epilogue without a wait of its own: lane l of a wave holds bias[n0 + 64 wc + l] in ONE register, loaded in K
 //   tile 1 of the tile - the counted vmcnt of that K tile's phase 4 covers it (it is older than the 8 newest operations), and because
 //   that wait is a real s_waitcnt instruction (NOMAD_P9_WAIT_VM) the compiler knows so and never drains the LDS-DMA queue for it
 //   (cdna_hip_programming.md 5, "mixing load kinds") - and distributed with ds_bpermute_b32.  (A first version loaded it by inline asm
 //   and tied the register to an asm wait: the compiler copied the register BEFORE the wait - stale bias in some runs.)
 //   vmcnt in the interleaved K tile: its phase 4 must see K tile 1 landed, whose DMA was issued before 4 + 16 + 4 = 24 newer
-//   operations (2 + 2 B DMA, the two hooks' 2 x 8 stores, 4 A DMA): vmcnt(24); everywhere else vmcnt(8) as before.  (Round 5: four hooks of one
-//   64 x 32 quadrant each, 12 stores before the wait: vmcnt(20); round 6's whole-line stores pair the column halves of a row.)
+//   operations (2 + 2 B DMA, the hook's 16 stores, 4 A DMA): vmcnt(24); everywhere else vmcnt(8) as before.  (Round 5's four hooks had 12
+//   stores in front of the wait: vmcnt(20).)
 // DMAP: in which phase slots the B tile of K tile t + 2 is issued: 0 = phases 1 / 2 (next to the 12 / 8 fragment reads of those slots, as
 //   the one-tile-per-workgroup kernel does), 1 = both halves in phase 3 (4 fragment reads), 2 = phases 2 / 3.  The microarchitecture guide
 //   prices an LDS-DMA instruction at 100-185 issue cycles inside a slot that already carries many LDS reads and at 25-60 in a quiet one;
