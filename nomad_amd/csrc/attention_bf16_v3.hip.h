@@ -73,7 +73,8 @@ __device__ __forceinline__ void a3_lds_wait(bf16x4& lo, bf16x4& hi) {   // (the 
 // forward (profiles/r05_c5_layer_table.txt).  QS = 4 reuses every K / V fragment for twice the queries: half the LDS bytes per MFMA, at
 // 2 waves per SIMD instead of 4 (about 190 registers).
 // ASMV: the V reads through a3_tr_pair (false: the builtin, A/B runs of libnomad_diag.so).
-template <int NW, int KT, int OCC, int QS = 2, bool ASMV = true>
+// HOLD (round 6): -m_ref moved in place and the ones operand / V addresses held in registers (false: round 5's form, A/B runs).
+template <int NW, int KT, int OCC, int QS = 2, bool ASMV = true, bool HOLD = true>
 __global__ __launch_bounds__(64 * NW, OCC) void attention_bf16_v3_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                                          int T, int nqblk, const int* __restrict__ tpref) {
     extern __shared__ __attribute__((aligned(16))) char a3_lds[];
@@ -109,8 +110,13 @@ __global__ __launch_bounds__(64 * NW, OCC) void attention_bf16_v3_kernel(const b
         for (int ks = 0; ks < 2; ++ks) qf[qs][ks] = *reinterpret_cast<const bf16x8*>(qp + 32 * ks);
     }
     f32x4 o[4][QS];   // O^T[db][qs]: d = 16 db + 4 fq + r, query fr of sub-block qs
-    float m_ref[QS];    // reference maximum of this lane's queries (log2 units), the same in the four lanes of a query
-    f32x4 negm[QS];     // -m_ref: the C operand of the first score MFMA
+    // -m_ref (m_ref: reference maximum of this lane's queries in log2 units, the same in the four lanes of a query): the C operand of the
+    // first score MFMA.  Moved IN PLACE by a rescale (negm -= delta, which is -(m_ref + delta) bit for bit): round 6 - rebuilt from a scalar
+    // m_ref the quad was a fresh value on the rare path, and hipcc kept a second copy of both quads for the blocks behind the branch,
+    // refreshed by four v_mov_b64 in EVERY block, and for want of those 8 registers re-made the ones operand and the four V addresses per
+    // block as well (10 of the 48 vector instructions of a block, in a loop bound by vector-instruction issue).
+    f32x4 negm[QS];
+    float m_ref[QS];    // (HOLD = false only)
     // Row sums on the matrix core (round 5): lsum[qs] += ones[16 x 32] P^T[qs] - every row of the result is the sum of the block's 32
     // values of p for query fr, over ALL four lanes' contraction slots.  Two MFMAs per block instead of 16 v_add_f32 + a final lane
     // reduction: the kernel is bound by vector-instruction ISSUE (an MFMA holds the SIMD's issue for 8 cycles, a v_add for 4; see the
@@ -119,12 +125,15 @@ __global__ __launch_bounds__(64 * NW, OCC) void attention_bf16_v3_kernel(const b
     bf16x8 ones_f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones_f[j] = (bf16_t)1.0f;
+    // (laundered, like va[] below: hipcc re-makes a constant operand and an address sum in every block rather than hold them - 2 v_mov_b64 and
+    // 4 v_add_u32 per block, in a loop bound by vector-instruction issue, with registers to spare since the -m_ref quads are moved in place)
+    if (HOLD) asm volatile("" : "+v"(ones_f));
 #pragma unroll
     for (int qs = 0; qs < QS; ++qs) {
 #pragma unroll
         for (int db = 0; db < 4; ++db) o[db][qs] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        m_ref[qs] = 0.f;
         negm[qs] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        m_ref[qs] = 0.f;
         lsum[qs] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     float inf_v;   // +inf, opaque to the compiler (see the block maxima below)
@@ -193,7 +202,10 @@ __global__ __launch_bounds__(64 * NW, OCC) void attention_bf16_v3_kernel(const b
             const int nb = left >= KT ? NB : (left + 31) >> 5;
             unsigned va[4];   // LDS byte addresses of this lane's V rows in the tile (+ 4096 blk + 2048 half as instruction offsets)
 #pragma unroll
-            for (int db = 0; db < 4; ++db) va[db] = (unsigned)(size_t)(lptr_t)(a3_lds) + (unsigned)((kt & 1) * (KT * 256) + v_db[db]);
+            for (int db = 0; db < 4; ++db) {
+                va[db] = (unsigned)(size_t)(lptr_t)(a3_lds) + (unsigned)((kt & 1) * (KT * 256) + v_db[db]);
+                if (HOLD) asm volatile("" : "+v"(va[db]));
+            }
             a3_static_for<NB>([&](auto blk_c) {
                 constexpr int blk = decltype(blk_c)::value;
                 if (blk < nb) {
@@ -255,8 +267,13 @@ __global__ __launch_bounds__(64 * NW, OCC) void attention_bf16_v3_kernel(const b
                             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) s[kb][qs][r] -= delta;
-                            m_ref[qs] += delta;
-                            negm[qs] = (f32x4){-m_ref[qs], -m_ref[qs], -m_ref[qs], -m_ref[qs]};
+                            if (HOLD) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) negm[qs][r] -= delta;
+                            } else {
+                                m_ref[qs] += delta;
+                                negm[qs] = (f32x4){-m_ref[qs], -m_ref[qs], -m_ref[qs], -m_ref[qs]};
+                            }
                         }
                     }
                     // ---- p = 2^(s - m_ref), row sums, P^T[qs] as the B operand (slot (fq, j) = key 16 (j >> 2) + 4 fq + (j & 3)) ----
@@ -320,10 +337,10 @@ __global__ __launch_bounds__(64 * NW, OCC) void attention_bf16_v3_kernel(const b
     }
 }
 
-template <int NW, int KT, int OCC, int QS = 2, bool ASMV = true>
+template <int NW, int KT, int OCC, int QS = 2, bool ASMV = true, bool HOLD = true>
 inline hipError_t launch_attention_bf16_v3(const bf16_t* qkv, bf16_t* out, int B, int T, const int* tpref, hipStream_t s) {
     static LdsAttrOnce configured;
-    auto kern = attention_bf16_v3_kernel<NW, KT, OCC, QS, ASMV>;
+    auto kern = attention_bf16_v3_kernel<NW, KT, OCC, QS, ASMV, HOLD>;
     constexpr int lds = attn_bf16_v2_lds(KT);
     if (hipError_t e = configured.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
     const int nqblk = (T + 16 * QS * NW - 1) / (16 * QS * NW);

@@ -85,7 +85,7 @@ struct Tuning {
                                     // false: the grouped GEMM on 128 x 64 tiles it replaces (A/B)
     int bf16_attn_dma = 2;         // NOMAD_BF16_ATTN_DMA: K / V of the bf16 attention by LDS-DMA in 128-key tiles
     int bf16_attn_v3 = 2;          // NOMAD_BF16_ATTN_V3: the bf16 attention on v_mfma_f32_16x16x32_bf16 with 32 queries per wave (2, shipped);
-                                   // 3: its V reads through the builtin; 4 / 8: 64 queries per wave, 4 / 8 waves per workgroup (A/B: no faster); 0: the 32x32x16 kernel
+                                   // 3: its V reads through the builtin; 5: round 5's register use; 4 / 8: 64 queries per wave, 4 / 8 waves per workgroup (A/B: no faster); 0: the 32x32x16 kernel
     bool bf16_conv0_mfma = true;   // NOMAD_BF16_CONV0_MFMA
     bool bf16_conv0_gelu_erf = false;   // NOMAD_BF16_CONV0_GELU_ERF (diag): the matrix-core conv0 with the erf GELU instead of the bf16-output one (A/B)
     int p8_min_tiles = 256;        // NOMAD_BF16_8PHASE_MIN_TILES: smallest grid (256 x 256 tiles) for the deep-pipelined bf16 kernels

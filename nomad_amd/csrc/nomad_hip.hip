@@ -1148,6 +1148,9 @@ static hipError_t run_attention_bf16(const nomad_ctx* c, const bf16_t* qkv, bf16
     // the V reads through the compiler's builtin (it waits for the next tile's LDS-DMA in front of them: attention_bf16_v3.hip.h): A/B
     if (log2e && c->tune.bf16_attn_v3 == 3)
         return big ? launch_attention_bf16_v3<8, 128, 4, 2, false>(qkv, out, B, T, tpref, s) : launch_attention_bf16_v3<4, 64, 4, 2, false>(qkv, out, B, T, tpref, s);
+    // round 5's register use (a second copy of the -m_ref quads, the ones operand and the V addresses re-made per block): A/B
+    if (log2e && c->tune.bf16_attn_v3 == 5)
+        return big ? launch_attention_bf16_v3<8, 128, 4, 2, true, false>(qkv, out, B, T, tpref, s) : launch_attention_bf16_v3<4, 64, 4, 2, true, false>(qkv, out, B, T, tpref, s);
     // 16 waves per workgroup (512 queries share a staged K / V tile: half the LDS-DMA pieces per wave): A/B
     if (log2e && c->tune.bf16_attn_v3 == 16)
         return big ? launch_attention_bf16_v3<16, 128, 4, 2>(qkv, out, B, T, tpref, s) : launch_attention_bf16_v3<4, 64, 4>(qkv, out, B, T, tpref, s);
