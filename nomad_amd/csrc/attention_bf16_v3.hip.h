@@ -63,7 +63,10 @@ __device__ __forceinline__ void a3_lds_wait(bf16x4& lo, bf16x4& hi) {   // (the 
     else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(lo), "+v"(hi));
 }
 
-// grid: 1-D, nqblk * B * 12 workgroups of 64 * NW threads (nqblk = ceil(T / (16 QS NW))); dynamic LDS attn_bf16_v2_lds(KT).
+// grid: 1-D, workgroups of 64 * NW threads, one per work item; dynamic LDS attn_bf16_v2_lds(KT).  The work items of a batch are the
+// nqblk * B * 12 pairs (clip-head bh, query block qb), item = bh * nqblk + qb, nqblk = ceil(T / (16 QS NW)); a launch covers items
+// virt0 .. virt0 + gridDim.x - 1 (round 6: the items of a sparsely filled last round go to a second launch with half-size workgroups,
+// nomad_hip.hip run_attention_bf16).
 // tpref (nullable): ragged batches - clip b owns rows tpref[b] .. tpref[b+1]-1 of qkv / out; T is then the longest clip's.
 // q must carry the factor log2(e) (nomad_enable_bf16 folds it into the q rows of the QKV weight).
 // QS: 16-query sub-blocks per wave (2 or 4).  Round 5, second step: with 32 queries per wave the kernel is co-limited by LDS bandwidth - a
@@ -76,7 +79,7 @@ __device__ __forceinline__ void a3_lds_wait(bf16x4& lo, bf16x4& hi) {   // (the 
 // HOLD (round 6): -m_ref moved in place and the ones operand / V addresses held in registers (false: round 5's form, A/B runs).
 template <int NW, int KT, int OCC, int QS = 2, bool ASMV = true, bool HOLD = true>
 __global__ __launch_bounds__(64 * NW, OCC) void attention_bf16_v3_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                                         int T, int nqblk, const int* __restrict__ tpref) {
+                                                                         int T, int nqblk, const int* __restrict__ tpref, int virt0) {
     extern __shared__ __attribute__((aligned(16))) char a3_lds[];
     constexpr int NT = 64 * NW;       // threads
     constexpr int QW = 16 * QS;       // queries per wave
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void attention_bf16_v3_kernel(const b
     // XCD-aware placement: the query blocks of one head run on one XCD (their K / V re-reads are L2 hits)
     const int nwg = gridDim.x, id = blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = id & 7;
-    const int virt = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
+    const int virt = virt0 + (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
     const int bh = virt / nqblk, qb = virt - bh * nqblk;
     const int b = bh / 12, hd = bh - b * 12;
     long long row0 = (long long)b * T;
@@ -337,15 +340,26 @@ __global__ __launch_bounds__(64 * NW, OCC) void attention_bf16_v3_kernel(const b
     }
 }
 
+// Items item0 .. item0 + nitems - 1 of a batch cut into query blocks of 16 QS NW queries, nqblk per clip-head (nqblk may exceed
+// ceil(T / (16 QS NW)): blocks past the clip's end return at once).
 template <int NW, int KT, int OCC, int QS = 2, bool ASMV = true, bool HOLD = true>
-inline hipError_t launch_attention_bf16_v3(const bf16_t* qkv, bf16_t* out, int B, int T, const int* tpref, hipStream_t s) {
+inline hipError_t launch_attention_bf16_v3_items(const bf16_t* qkv, bf16_t* out, int T, int nqblk, const int* tpref, hipStream_t s, int item0,
+                                                 int nitems) {
     static LdsAttrOnce configured;
     auto kern = attention_bf16_v3_kernel<NW, KT, OCC, QS, ASMV, HOLD>;
     constexpr int lds = attn_bf16_v2_lds(KT);
     if (hipError_t e = configured.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
-    const int nqblk = (T + 16 * QS * NW - 1) / (16 * QS * NW);
-    hipLaunchKernelGGL(kern, dim3(nqblk * B * 12), dim3(64 * NW), lds, s, qkv, out, T, nqblk, tpref);
+    if (nitems <= 0) return hipSuccess;
+    hipLaunchKernelGGL(kern, dim3(nitems), dim3(64 * NW), lds, s, qkv, out, T, nqblk, tpref, item0);
     return hipGetLastError();
+}
+
+template <int NW, int KT, int OCC, int QS = 2, bool ASMV = true, bool HOLD = true>
+inline hipError_t launch_attention_bf16_v3(const bf16_t* qkv, bf16_t* out, int B, int T, const int* tpref, hipStream_t s, int item0 = 0,
+                                           int nitems = -1) {
+    const int nqblk = (T + 16 * QS * NW - 1) / (16 * QS * NW);
+    if (nitems < 0) nitems = nqblk * B * 12 - item0;
+    return launch_attention_bf16_v3_items<NW, KT, OCC, QS, ASMV, HOLD>(qkv, out, T, nqblk, tpref, s, item0, nitems);
 }
 
 }  // namespace nomad

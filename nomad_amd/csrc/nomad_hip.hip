@@ -1142,8 +1142,22 @@ static hipError_t run_attention_bf16(const nomad_ctx* c, const bf16_t* qkv, bf16
     // round 5: the 16-wide matrix shape (attention_bf16_v3.hip.h) for every batch size - a clip's bits do not depend on its batch
     // (the wave composition - 32 consecutive queries - is the same in both workgroup shapes, so the deferred-rescale decisions and
     // every bit are too)
-    if (log2e && c->tune.bf16_attn_v3 == 2)
+    if (log2e && c->tune.bf16_attn_v3 == 2) {
+#ifdef NOMAD_DIAG
+        // Round 6 probe, measured slower and kept out of the product (profiles/NOTEBOOK.md "the last round of the bf16 attention"): two
+        // 256-query workgroups fit a CU, so the launch runs in rounds of 2 x CUs items (configs[4]: 2304 items = 4.5 rounds of 512); here
+        // the items of a last round at most `bf16_attn_tail` / 8 full run as twice as many 128-query workgroups in a second launch (the
+        // same 32-query waves and 32-key blocks: every bit the same).  227 -> 240 us: a CU with ONE 256-query workgroup in the last round
+        // already runs it faster (2 waves per SIMD), and the 128-query workgroups stage 64-key tiles.
+        const int nq = (T + 255) / 256, items = nq * B * 12, slots = 2 * c->num_cus, tail = items % slots;
+        if (big && tail != 0 && tail * 8 <= slots * c->tune.bf16_attn_tail) {
+            if (hipError_t e = launch_attention_bf16_v3<8, 128, 4>(qkv, out, B, T, tpref, s, 0, items - tail); e != hipSuccess) return e;
+            // (128-query items: clip-head bh, query block 2 qb + {0, 1} - item numbers double; a second half past the clip's end returns at once)
+            return launch_attention_bf16_v3_items<4, 64, 4>(qkv, out, T, 2 * nq, tpref, s, 2 * (items - tail), 2 * tail);
+        }
+#endif
         return big ? launch_attention_bf16_v3<8, 128, 4>(qkv, out, B, T, tpref, s) : launch_attention_bf16_v3<4, 64, 4>(qkv, out, B, T, tpref, s);
+    }
 #ifdef NOMAD_DIAG
     // the V reads through the compiler's builtin (it waits for the next tile's LDS-DMA in front of them: attention_bf16_v3.hip.h): A/B
     if (log2e && c->tune.bf16_attn_v3 == 3)

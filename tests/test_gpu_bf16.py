@@ -143,6 +143,37 @@ def test_gemm_bf16_persistent_kernel_whole_line_stores_are_bit_identical(built_l
 LOG2E = 1.4426950408889634
 
 
+@pytest.mark.parametrize("B,T", [(32, 1499), (16, 1499), (19, 1030), (21, 1281), (23, 999)])
+def test_bf16_attention_tail_round_as_half_size_workgroups_is_bit_identical(built_lib, sd0, monkeypatch, B, T):
+    """Round 6 probe (diag library only; measured slower, so the product keeps one launch): the work items of a sparsely filled last round of
+    256-query workgroups run as 128-query workgroups in a second launch (run_attention_bf16, NOMAD_BF16_ATTN_TAIL eighths; 0 = one launch):
+    the same 32-query waves over the same 32-key blocks - every bit the same, which is also what makes a clip's bits independent of its batch.  Shapes: configs[4]'s (4.5 rounds) and its two-stream half (2.25); clips whose last 128-query block lies past their end
+    (T = 1030: 9 blocks of 10; T = 1281: 11 of 12, and a last round 0.95 full, which only the flag 8 splits); a tail of 0.16 round (T = 999)."""
+    from nomad_amd.engine import Engine
+    g = torch.Generator().manual_seed(B * T)
+    qkv = torch.randn(B * T, 2304, generator=g)
+    qkv[:, :1536] *= 0.35
+    qkv[:, :768] *= LOG2E
+    x = qkv.bfloat16().cuda()
+    outs = []
+    for flag in ("0", "4", "8"):
+        monkeypatch.setenv("NOMAD_BF16_ATTN_TAIL", flag)
+        eng = Engine(sd0, 0, diag=True)
+        out = eng.diag_attention_bf16(x, B, T, q_has_log2e=True)
+        torch.cuda.synchronize()
+        outs.append(out.clone())
+        eng.close()
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    # (and the 128-query kernel alone, which small batches take, gives a single clip of the batch the same bits)
+    monkeypatch.delenv("NOMAD_BF16_ATTN_TAIL")
+    eng = Engine(sd0, 0, diag=True)
+    one = eng.diag_attention_bf16(x[(B - 1) * T:].contiguous(), 1, T, q_has_log2e=True)
+    torch.cuda.synchronize()
+    eng.close()
+    assert torch.equal(one, outs[1][(B - 1) * T:])
+
+
 def _attention_case(engine, qkv32, B, T, log2e):
     """qkv32 fp32 (B*T, 2304) -> (kernel output, float64 reference from the bf16 values the kernel actually saw)."""
     x = qkv32.clone()

@@ -39,7 +39,7 @@ def main():
     ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(a.iters))
     med = ms[len(ms) // 2]
     fl = 4.0 * B * 12 * T * T * 64
-    print(json.dumps({"kernel": {"0": "v2 32x32x16, 32 queries / wave", "2": "v3 16x16x32, 32 queries / wave", "3": "v3 16x16x32, 32 queries / wave, builtin V reads", "4": "v3 16x16x32, 64 queries / wave, 4 waves", "8": "v3 16x16x32, 64 queries / wave, 8 waves", "16": "v3 16x16x32, 32 queries / wave, 16 waves", "5": "v3 16x16x32, 32 queries / wave, round 5 register use"}.get(os.environ.get("NOMAD_BF16_ATTN_V3", "4"), "?"), "B": B, "T": T,
+    print(json.dumps({"kernel": {"0": "v2 32x32x16, 32 queries / wave", "2": "v3 16x16x32, 32 queries / wave", "3": "v3 16x16x32, 32 queries / wave, builtin V reads", "4": "v3 16x16x32, 64 queries / wave, 4 waves", "8": "v3 16x16x32, 64 queries / wave, 8 waves", "16": "v3 16x16x32, 32 queries / wave, 16 waves", "5": "v3 16x16x32, 32 queries / wave, round 5 register use"}.get(os.environ.get("NOMAD_BF16_ATTN_V3", "2"), "?"), "B": B, "T": T,
                       "us_median": round(med * 1e3, 1), "us_min": round(ms[0] * 1e3, 1), "tflops": round(fl / med / 1e9, 1),
                       "max_abs_err_clip0": err}), flush=True)
 
