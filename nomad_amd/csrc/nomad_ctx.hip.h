@@ -88,6 +88,7 @@ struct Tuning {
                                    // 3: its V reads through the builtin; 5: round 5's register use; 4 / 8: 64 queries per wave, 4 / 8 waves per workgroup (A/B: no faster); 0: the 32x32x16 kernel
     int bf16_attn_tail = 0;        // NOMAD_BF16_ATTN_TAIL (diag): a last round of 256-query workgroups that is at most this many eighths full runs
                                    // as 128-query workgroups in a second launch (0: never; run_attention_bf16 - measured slower, A/B only)
+    int bf16_ln_rows = 4;          // NOMAD_BF16_LN_ROWS: rows per wave of the bf16 forward's LayerNorm (4: one gamma / beta fetch per 4 rows; 1: A/B)
     bool bf16_conv0_mfma = true;   // NOMAD_BF16_CONV0_MFMA
     bool bf16_conv0_gelu_erf = false;   // NOMAD_BF16_CONV0_GELU_ERF (diag): the matrix-core conv0 with the erf GELU instead of the bf16-output one (A/B)
     int p8_min_tiles = 256;        // NOMAD_BF16_8PHASE_MIN_TILES: smallest grid (256 x 256 tiles) for the deep-pipelined bf16 kernels
@@ -140,6 +141,7 @@ static void tuning_from_env(Tuning& t) {
     t.bf16_posconv_slab = geti("NOMAD_BF16_POSCONV_SLAB", t.bf16_posconv_slab) != 0;
     t.bf16_attn_v3 = geti("NOMAD_BF16_ATTN_V3", t.bf16_attn_v3);
     t.bf16_attn_tail = geti("NOMAD_BF16_ATTN_TAIL", t.bf16_attn_tail);
+    t.bf16_ln_rows = geti("NOMAD_BF16_LN_ROWS", t.bf16_ln_rows);
     t.bf16_conv0_mfma = getb("NOMAD_BF16_CONV0_MFMA", t.bf16_conv0_mfma);
     t.p8_min_tiles = geti("NOMAD_BF16_8PHASE_MIN_TILES", t.p8_min_tiles);
     t.p8_nt_stores = getb("NOMAD_BF16_NT_STORES", t.p8_nt_stores);

@@ -1276,9 +1276,13 @@ struct CkSum {
 #endif
 
 template <int VPT>
-static void launch_ln_bf16(const bf16_t* in, const float* g, const float* b, bf16_t* out, int M, hipStream_t s) {
-    hipLaunchKernelGGL((layernorm_kernel<VPT, bf16_t, bf16_t>), dim3((M + 3) / 4), dim3(256), 0, s, in, g, b, out,
-                       static_cast<float*>(nullptr), M);
+static void launch_ln_bf16(const bf16_t* in, const float* g, const float* b, bf16_t* out, int M, hipStream_t s, int rows) {
+    if (rows == 4)
+        hipLaunchKernelGGL((layernorm_kernel<VPT, bf16_t, bf16_t, 4>), dim3((M + 15) / 16), dim3(256), 0, s, in, g, b, out,
+                           static_cast<float*>(nullptr), M);
+    else
+        hipLaunchKernelGGL((layernorm_kernel<VPT, bf16_t, bf16_t, 1>), dim3((M + 3) / 4), dim3(256), 0, s, in, g, b, out,
+                           static_cast<float*>(nullptr), M);
 }
 
 struct Bf16Layout {
@@ -1368,7 +1372,7 @@ static int forward_bf16(nomad_ctx* c, const float* wav, int B, int n_samples, fl
     bf16_t* featln = cb[1];
     {
         Scope sc(c, s, NOMAD_K_ROW, 0.0);
-        launch_ln_bf16<2>(conv6, c->fln_w, c->fln_b, featln, M, s);
+        launch_ln_bf16<2>(conv6, c->fln_w, c->fln_b, featln, M, s, c->tune.bf16_ln_rows);
     }
     CK(featln, B, sizeof(bf16_t) * 512 * (size_t)T);
     bf16_t* xpad = H(lay.xpad);
@@ -1417,7 +1421,7 @@ static int forward_bf16(nomad_ctx* c, const float* wav, int B, int n_samples, fl
     CK(y, B, clip768);
     {
         Scope sc(c, s, NOMAD_K_ROW, 0.0);
-        launch_ln_bf16<3>(y, c->eln_w, c->eln_b, x, M, s);
+        launch_ln_bf16<3>(y, c->eln_w, c->eln_b, x, M, s, c->tune.bf16_ln_rows);
     }
     CK(x, B, clip768);
     for (int l = 0; l < NOMAD_NUM_LAYERS; ++l) {
@@ -1435,7 +1439,7 @@ static int forward_bf16(nomad_ctx* c, const float* wav, int B, int n_samples, fl
         CK(y, B, clip768);
         {
             Scope sc(c, s, NOMAD_K_ROW, 0.0);
-            launch_ln_bf16<3>(y, d.ln1_w, d.ln1_b, x2, M, s);
+            launch_ln_bf16<3>(y, d.ln1_w, d.ln1_b, x2, M, s, c->tune.bf16_ln_rows);
         }
         CK(x2, B, clip768);
         if ((rc = run_gemm_bf16(c, dense(asf(x2), 768, asf(c->fc1_w16[l]), d.fc1_b, nullptr, asfm(hb), M, 3072, 768, 1), 1, s)))
@@ -1446,7 +1450,7 @@ static int forward_bf16(nomad_ctx* c, const float* wav, int B, int n_samples, fl
         CK(y, B, clip768);
         {
             Scope sc(c, s, NOMAD_K_ROW, 0.0);
-            launch_ln_bf16<3>(y, d.ln2_w, d.ln2_b, x, M, s);
+            launch_ln_bf16<3>(y, d.ln2_w, d.ln2_b, x, M, s, c->tune.bf16_ln_rows);
         }
         CK(x, B, clip768);
     }
@@ -1863,7 +1867,7 @@ static int forward_ragged_bf16(nomad_ctx* c, const float* wav, int B, int stride
     bf16_t* featln = cb[1];
     {
         Scope sc(c, s, NOMAD_K_ROW, 0.0);
-        launch_ln_bf16<2>(cb[0], c->fln_w, c->fln_b, featln, M, s);
+        launch_ln_bf16<2>(cb[0], c->fln_w, c->fln_b, featln, M, s, c->tune.bf16_ln_rows);
     }
     bf16_t* xpad = H(lay.xpad);
     const long long grp_stride = rs.P * 48;
@@ -1908,7 +1912,7 @@ static int forward_ragged_bf16(nomad_ctx* c, const float* wav, int B, int stride
     }
     {
         Scope sc(c, s, NOMAD_K_ROW, 0.0);
-        launch_ln_bf16<3>(y, c->eln_w, c->eln_b, x, M, s);
+        launch_ln_bf16<3>(y, c->eln_w, c->eln_b, x, M, s, c->tune.bf16_ln_rows);
     }
     double attn_flops = 0.0;
     for (int i = 0; i < B; ++i) {
@@ -1927,7 +1931,7 @@ static int forward_ragged_bf16(nomad_ctx* c, const float* wav, int B, int stride
             return rc;
         {
             Scope sc(c, s, NOMAD_K_ROW, 0.0);
-            launch_ln_bf16<3>(y, d.ln1_w, d.ln1_b, x2, M, s);
+            launch_ln_bf16<3>(y, d.ln1_w, d.ln1_b, x2, M, s, c->tune.bf16_ln_rows);
         }
         if ((rc = run_gemm_bf16(c, dense(asf(x2), 768, asf(c->fc1_w16[l]), d.fc1_b, nullptr, asfm(hb), M, 3072, 768, 1), 1, s)))
             return rc;
@@ -1935,7 +1939,7 @@ static int forward_ragged_bf16(nomad_ctx* c, const float* wav, int B, int stride
             return rc;
         {
             Scope sc(c, s, NOMAD_K_ROW, 0.0);
-            launch_ln_bf16<3>(y, d.ln2_w, d.ln2_b, x, M, s);
+            launch_ln_bf16<3>(y, d.ln2_w, d.ln2_b, x, M, s, c->tune.bf16_ln_rows);
         }
     }
     return run_head<bf16_t>(c, x, B, rs.max_t, c->emb_w, c->emb_b, emb, tpref, reinterpret_cast<float*>(hb), s);

@@ -51,25 +51,37 @@ __device__ __forceinline__ void ln_row_finish(const float4 (&v)[VPT], const floa
 }
 
 // out[m][:] = (in[m][:] - mean) * rstd * gamma + beta; optional second copy out2 (layer_results).
-// VPT float4 per lane: N = 256 * VPT (512 -> 2, 768 -> 3).  grid: ceil(M/4) blocks of 256 threads.
-template <int VPT, typename TIn = float, typename TOut = float>
+// VPT float4 per lane: N = 256 * VPT (512 -> 2, 768 -> 3).  grid: ceil(M / (4 ROWS)) blocks of 256 threads; a wave normalises ROWS
+// consecutive rows with one fetch of gamma / beta (round 6: at one bf16 row per wave the 6 KB of gamma and beta a wave pulls through the
+// vector cache are twice the 3 KB of the row it reads and writes; the bf16 forward takes 4 rows per wave, all their loads in flight at once).
+// A row's arithmetic is ln_row_finish whatever ROWS is.
+template <int VPT, typename TIn = float, typename TOut = float, int ROWS = 1>
 __global__ __launch_bounds__(256) void layernorm_kernel(const TIn* __restrict__ in, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, TOut* __restrict__ out,
                                                         float* __restrict__ out2, int M, long long in_plane = 0,
                                                         long long out_plane = 0) {
     constexpr int N = 256 * VPT;
     const int lane = threadIdx.x & 63;
-    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (m >= M) return;
-    const TIn* row = in + (long long)m * N;
-    float4 v[VPT], g[VPT], bb[VPT];
+    const int m0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
+    if (m0 >= M) return;
+    float4 v[ROWS][VPT], g[VPT], bb[VPT];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const TIn* row = in + (long long)min(m0 + r, M - 1) * N;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) v[r][i] = load4p<TIn>(row + 4 * (lane + 64 * i), in_plane);
+    }
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
-        v[i] = load4p<TIn>(row + 4 * (lane + 64 * i), in_plane);
         g[i] = reinterpret_cast<const float4*>(gamma)[lane + 64 * i];
         bb[i] = reinterpret_cast<const float4*>(beta)[lane + 64 * i];
     }
-    ln_row_finish<VPT, TOut>(v, g, bb, out + (long long)m * N, out_plane, out2 ? reinterpret_cast<float4*>(out2 + (long long)m * N) : nullptr, lane);
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int m = m0 + r;
+        if (m < M)
+            ln_row_finish<VPT, TOut>(v[r], g, bb, out + (long long)m * N, out_plane, out2 ? reinterpret_cast<float4*>(out2 + (long long)m * N) : nullptr, lane);
+    }
 }
 
 // ---- head: mean over time -> ReLU -> Linear(768, 256) -> L2 normalise (nomad.py:228-230) ---------------------------

@@ -293,6 +293,23 @@ def test_ragged_bf16_bit_identical_to_single_clips(engine):
         engine.embed_ragged(waves, head=(torch.zeros(256, 768).cuda(), torch.zeros(256).cuda()), bf16=True)
 
 
+def test_bf16_layernorm_rows_per_wave_do_not_change_a_bit(built_lib, sd0, monkeypatch):
+    """Round 6: the bf16 forward's LayerNorm takes 4 consecutive rows per wave (one gamma / beta fetch for the four); a row's arithmetic is the
+    one-row kernel's.  Batches whose row count is not a multiple of 16 (the last workgroup's waves have 1-3 rows, or none)."""
+    from nomad_amd.engine import Engine
+    g = torch.Generator().manual_seed(77)
+    cases = [(0.1 * torch.randn(b, n, generator=g)).clamp(-1, 1).cuda() for b, n in ((3, 16384), (1, 400), (5, 27225), (2, 9001))]
+    outs = []
+    for flag in ("1", "4"):
+        monkeypatch.setenv("NOMAD_BF16_LN_ROWS", flag)
+        eng = Engine(sd0, 0, diag=True)
+        outs.append([eng.embed_bf16(w).clone() for w in cases])
+        torch.cuda.synchronize()
+        eng.close()
+    for a, b in zip(*outs):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
 def test_ragged_bf16_with_a_long_clip_in_the_batch(engine):
     """A 30 s clip (T = 1499) next to short ones: the batch's longest clip picks the pos-conv's frames per workgroup (512 here, 256 / 128 in
     the single-clip calls of the short files) - every clip still bit-equal to its own nomad_embed_bf16 call."""
