@@ -73,25 +73,35 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     const float4* gm4 = reinterpret_cast<const float4*>(gamma);
     float xv[VPT][4], gv[VPT][4];
     float s = 0.f;
+    // every load of the row first (round 6: behind run-time branches and a run-time slice loop they went out one memory round trip at a time)
+    float4 t[SPLITK ? VPT : 1][kSliceBurst];   // (SPLITK: the slices of the whole row in flight at once, rowops.hip.h sum_slices4)
+    float4 xa[VPT], ga[VPT], ra[VPT], g2a[VPT], gma[VPT];
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
-        const float4 a = xr[lane + 64 * i];
-        float4 b = gr[lane + 64 * i];
+        if (SPLITK) load_slices4(t[i], gr + lane + 64 * i, (long long)M * (N / 4), S);
+        else ga[i] = gr[lane + 64 * i];
+        xa[i] = xr[lane + 64 * i];
+        gma[i] = gm4[lane + 64 * i];
+        if (rr) ra[i] = rr[lane + 64 * i];
+        if (g2r) g2a[i] = g2r[lane + 64 * i];
+    }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const float4 a = xa[i];
+        float4 b;
+        if (!SPLITK) b = ga[i];
         if (SPLITK) {
-            for (int sl = 1; sl < S; ++sl) {
-                const float4 c = reinterpret_cast<const float4*>(g + ((long long)sl * M + m) * N)[lane + 64 * i];
-                b.x += c.x; b.y += c.y; b.z += c.z; b.w += c.w;
-            }
+            b = add_slices4(t[i], gr + lane + 64 * i, (long long)M * (N / 4), S);
             if (rr) {
-                const float4 c = rr[lane + 64 * i];
+                const float4 c = ra[i];
                 b.x += c.x; b.y += c.y; b.z += c.z; b.w += c.w;
             }
         }
         if (g2r) {
-            const float4 c = g2r[lane + 64 * i];
+            const float4 c = g2a[i];
             b.x += c.x; b.y += c.y; b.z += c.z; b.w += c.w;
         }
-        const float4 gm = gm4[lane + 64 * i];
+        const float4 gm = gma[i];
         xv[i][0] = a.x; xv[i][1] = a.y; xv[i][2] = a.z; xv[i][3] = a.w;
         gv[i][0] = b.x * gm.x; gv[i][1] = b.y * gm.y; gv[i][2] = b.z * gm.z; gv[i][3] = b.w * gm.w;
         s += (a.x + a.y) + (a.z + a.w);

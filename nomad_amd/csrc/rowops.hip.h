@@ -20,6 +20,35 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// Sum over the S slices of a split-K GEMM's partial products for one float4: ((p[0] + p[stride4]) + p[2 stride4]) + ... in slice order,
+// with the loads of the first kSliceBurst slices issued BEFORE the first add.  Round 6: written as `for (s = 1; s < S; ++s) a += p[s * stride4]`
+// with a run-time S hipcc emits load - s_waitcnt vmcnt(0) - add per slice, and the epilogue kernels of configs[3] (1632 rows: one wave of
+// work per CU, nothing else to hide a round trip behind) spent 6 dependent memory round trips per column chunk.  S is wave-uniform.
+constexpr int kSliceBurst = 8;
+__device__ __forceinline__ void load_slices4(float4 (&t)[kSliceBurst], const float4* __restrict__ p, long long stride4, int S) {
+#pragma unroll
+    for (int s = 0; s < kSliceBurst; ++s)
+        if (s < S) t[s] = p[s * stride4];
+}
+__device__ __forceinline__ float4 add_slices4(const float4 (&t)[kSliceBurst], const float4* __restrict__ p, long long stride4, int S) {
+    float4 a = t[0];
+#pragma unroll
+    for (int s = 1; s < kSliceBurst; ++s)
+        if (s < S) {
+            a.x += t[s].x; a.y += t[s].y; a.z += t[s].z; a.w += t[s].w;
+        }
+    for (int s = kSliceBurst; s < S; ++s) {
+        const float4 b = p[s * stride4];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    return a;
+}
+__device__ __forceinline__ float4 sum_slices4(const float4* __restrict__ p, long long stride4, int S) {
+    float4 t[kSliceBurst];
+    load_slices4(t, p, stride4, S);
+    return add_slices4(t, p, stride4, S);
+}
+
 // One row of LayerNorm by one wave: lane l holds elements 4 (l + 64 i) .. + 3 of the row, i < VPT (N = 256 VPT).  layernorm_kernel below
 // and the split-K epilogue that normalises its own rows (splitk_epilogue_ln_kernel, train.hip.h) run exactly this code - one summation
 // order, so a row's result does not depend on which kernel normalised it.

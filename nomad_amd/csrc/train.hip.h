@@ -54,12 +54,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float4* __rest
                                                             long long count4, float4* __restrict__ out, float scale) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= count4) return;
-    float4 a = partial[i];
-    for (int s = 1; s < S; ++s) {
-        const float4 b = partial[(long long)s * stride4 + i];
-        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-    }
     float4 o = out[i];
+    const float4 a = sum_slices4(partial + i, stride4, S);
     o.x = fmaf(scale, a.x, o.x); o.y = fmaf(scale, a.y, o.y); o.z = fmaf(scale, a.z, o.z); o.w = fmaf(scale, a.w, o.w);
     out[i] = o;
 }
@@ -71,21 +67,19 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float4* __re
                                                               float4* __restrict__ C, int gelu) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= count4) return;
-    float4 a = partial[i];
-    for (int s = 1; s < S; ++s) {
-        const float4 b = partial[(long long)s * count4 + i];
-        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-    }
+    // (bias and residual fetched beside the slices, not behind them)
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), rv = bv;
+    if (bias) bv = bias[i % n4];
+    if (R) rv = R[i];
+    float4 a = sum_slices4(partial + i, count4, S);
     if (bias) {
-        const float4 b = bias[i % n4];
-        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        a.x += bv.x; a.y += bv.y; a.z += bv.z; a.w += bv.w;
     }
     if (gelu) {
         a.x = gelu_erf(a.x); a.y = gelu_erf(a.y); a.z = gelu_erf(a.z); a.w = gelu_erf(a.w);
     }
     if (R) {
-        const float4 r = R[i];
-        a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
+        a.x += rv.x; a.y += rv.y; a.z += rv.z; a.w += rv.w;
     }
     C[i] = a;
 }
@@ -103,27 +97,31 @@ __global__ __launch_bounds__(256) void splitk_epilogue_ln_kernel(const float* __
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
     const long long row = (long long)m * 768, plane = (long long)M * 768;
-    float4 v[3], g[3], bb[3];
+    float4 v[3], g[3], bb[3], bv[3], rv[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {   // everything that does not depend on the slices first: one memory round trip for the row, not 2 + S per chunk
+        const int c = 4 * (lane + 64 * i);
+        bv[i] = rv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias) bv[i] = *reinterpret_cast<const float4*>(bias + c);
+        if (R) rv[i] = *reinterpret_cast<const float4*>(R + row + c);
+        g[i] = reinterpret_cast<const float4*>(gamma)[lane + 64 * i];
+        bb[i] = reinterpret_cast<const float4*>(beta)[lane + 64 * i];
+    }
+    float4 t[3][kSliceBurst];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) load_slices4(t[i], reinterpret_cast<const float4*>(partial + row + 4 * (lane + 64 * i)), plane / 4, S);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int c = 4 * (lane + 64 * i);
-        float4 a = *reinterpret_cast<const float4*>(partial + row + c);
-        for (int s = 1; s < S; ++s) {
-            const float4 b = *reinterpret_cast<const float4*>(partial + (long long)s * plane + row + c);
-            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-        }
+        float4 a = add_slices4(t[i], reinterpret_cast<const float4*>(partial + row + c), plane / 4, S);
         if (bias) {
-            const float4 b = *reinterpret_cast<const float4*>(bias + c);
-            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            a.x += bv[i].x; a.y += bv[i].y; a.z += bv[i].z; a.w += bv[i].w;
         }
         if (R) {
-            const float4 r = *reinterpret_cast<const float4*>(R + row + c);
-            a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
+            a.x += rv[i].x; a.y += rv[i].y; a.z += rv[i].z; a.w += rv[i].w;
         }
         *reinterpret_cast<float4*>(y + row + c) = a;
         v[i] = a;
-        g[i] = reinterpret_cast<const float4*>(gamma)[lane + 64 * i];
-        bb[i] = reinterpret_cast<const float4*>(beta)[lane + 64 * i];
     }
     ln_row_finish<3, float>(v, g, bb, x + row, 0, x2 ? reinterpret_cast<float4*>(x2 + row) : nullptr, lane);
 }
@@ -136,11 +134,7 @@ __global__ __launch_bounds__(192) void posconv_splitk_epilogue_kernel(const floa
                                                                       float* __restrict__ Upre, float* __restrict__ C, int gelu) {
     const int m = blockIdx.x, c4 = threadIdx.x;          // 192 float4 per row
     const long long i = (long long)m * 768 + c4 * 4;
-    float4 a = *reinterpret_cast<const float4*>(partial + i);
-    for (int s = 1; s < S; ++s) {
-        const float4 b = *reinterpret_cast<const float4*>(partial + (long long)s * M * 768 + i);
-        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-    }
+    float4 a = sum_slices4(reinterpret_cast<const float4*>(partial + i), (long long)M * 192, S);
     if (bias) {
         const float4 b = *reinterpret_cast<const float4*>(bias + c4 * 4);
         a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
