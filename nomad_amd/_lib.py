@@ -130,8 +130,9 @@ def load(diag=None):
     if diag in _libs:
         return _libs[diag]
     path = DIAG_LIB_PATH if diag else LIB_PATH
-    if os.environ.get("NOMAD_LIB_VARIANT") == "pk":   # A/B build WITH packed-FP32 instructions (python -m nomad_amd.build --pk):
-        path = path[:-3] + "_pk.so"                    # measurement tools and the hazard's reproducer only
+    variant = os.environ.get("NOMAD_LIB_VARIANT")     # A/B builds (python -m nomad_amd.build --pk / --variant <name>): measurement tools
+    if variant and variant != "main":                 # and the packed-FP32 hazard's reproducer only ("main": the library itself, for alternating runs)
+        path = path[:-3] + f"_{variant}.so"
     if not os.path.isfile(path):
         raise RuntimeError(f"{path} is missing: build it with `python -m nomad_amd.build` "
                            "(hipcc --offload-arch=gfx950). nomad_amd has no CPU or PyTorch fallback path.")

@@ -48,8 +48,19 @@ def pk_path(lib: str) -> str:
     return lib[:-3] + "_pk.so"
 
 
+# A/B builds of one source-level choice, as <library>_<name>.so (NOMAD_LIB_VARIANT=<name> loads them: measurement tools only).
+VARIANTS = {"gelu1": ["-DNOMAD_GELU_BF16_V1"]}   # the bf16 epilogues' GELU in its first form (gemm_f32.hip.h)
+
+
+def variant_path(lib: str, name: str) -> str:
+    return lib[:-3] + f"_{name}.so"
+
+
 def _flags(lib: str, diag: bool, verbose: bool):
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-pthread"]
+    for name, defs in VARIANTS.items():
+        if lib.endswith(f"_{name}.so"):
+            flags = defs + flags
     if os.environ.get("NOMAD_PACKED_FP32", "0") != "1" and not lib.endswith("_pk.so"):
         flags = NO_PACKED_FP32 + flags
     else:
@@ -117,10 +128,18 @@ def build_pk_variants() -> dict:
     return {os.path.basename(j.lib): j.finish() for j in jobs}
 
 
+def build_variant(name: str) -> dict:
+    """libnomad_hip_<name>.so / libnomad_diag_<name>.so for one entry of VARIANTS."""
+    jobs = [_Job(variant_path(lib, name), diag) for lib, diag in ((LIB, False), (DIAG_LIB, True))]
+    return {os.path.basename(j.lib): j.finish() for j in jobs}
+
+
 if __name__ == "__main__":
     import sys
     if "--pk" in sys.argv:
         print(build_pk_variants())
+    elif "--variant" in sys.argv:
+        print(build_variant(sys.argv[sys.argv.index("--variant") + 1]))
     elif "-v" in sys.argv:
         print(build_library(force=True, verbose=True, diag="--diag" in sys.argv))
     else:

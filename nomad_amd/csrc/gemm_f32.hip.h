@@ -161,26 +161,38 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return fmaf(-ax, poly * e, fmaxf(x, 0.0f));
 }
 
-// GELU for epilogues whose OUTPUT is bf16 (the bf16 path's GEMMs, config C5; never the fp32 or bf16x3 paths): x * sigmoid(g(x)) with
-// g(x) = x (c0 + c1 x^2 + c2 x^4) fitted to logit(Phi(x)) (minimax on [-9, 9] in float64: c = 1.59501055, 7.40160400e-2, -7.03804789e-4),
-// x^2 clamped at 50 so that g stays monotone.  Maximum absolute error against the exact erf GELU 2.55e-5 over [-30, 30] (evaluated in
-// fp32) - a 150th of the bf16 rounding step of an activation of size 1, and below it for every |gelu(x)| > 0.007 - at 9 instructions
-// (2 transcendental) instead of 13: the epilogues are bound by vector-instruction issue (4 cycles per instruction, 8 per
-// transcendental), so this is 44 instead of 60 issue cycles per activation.  Every bf16 GEMM kernel uses THIS function (their results
-// stay bit-identical to each other); conv0 and every fp32 / bf16x3 epilogue keep gelu_erf.
+// GELU for epilogues whose OUTPUT is bf16 (the bf16 path's GEMMs and conv0, config C5; never the fp32 or bf16x3 paths).
+// Round 6, second form: gelu(x) = max(x, 0) - |x| T(|x|) with the tail T(a) = 1 - Phi(a) = 0.5 erfc(a / sqrt 2) evaluated as 2^q(a), q a quartic
+// fitted to log2 T (minimax on the error of the RESULT, a (2^q(a) - T(a)), Lawson iteration in float64; a clamped at 13: the fit covers [0, 6], beyond which
+// a T(a) < 6e-9 and the quartic keeps falling until it turns upward at 13.5, where 2^q = 2^-81).  Maximum absolute error against the exact erf GELU 6.2e-6 over [-12, 12] evaluated in fp32 - a
+// quarter of the first form's (x sigmoid(g(x)), 2.55e-5) and a 600th of the bf16 rounding step of an activation of size 1; relative error
+// <= 3.2e-4 wherever |gelu(x)| > 0.007 - at 8 instructions, ONE of them transcendental (v_min, 4 v_fma, v_exp, v_max, v_fma), against 9 with two
+// (v_exp + v_rcp) for the first form and 13 with two for gelu_erf: 36 issue cycles per activation instead of 44 / 60 (4 per instruction, 8 per
+// transcendental) in epilogues that are bound by vector-instruction issue.  A non-finite activation stays non-finite: NaN -> NaN (through |x|), -inf -> -inf,
+// +inf -> inf - inf = NaN (torch's fp32 GELU returns NaN for both infinities); a finite x < -13 gives x 2^-81 for the exact -0.
+// Every bf16 kernel uses THIS function (their results stay bit-identical to each other); every fp32 / bf16x3 epilogue keeps gelu_erf.
+#ifdef NOMAD_GELU_BF16_V1
+// The first form (rounds 5-6), kept for A/B builds (python -m nomad_amd.build --variant gelu1, NOMAD_LIB_VARIANT=gelu1): x * sigmoid(g(x)),
+// g(x) = x (c0 + c1 x^2 + c2 x^4) fitted to logit(Phi(x)), x^2 clamped at 50; v_mul_legacy_f32 so that -inf gives 0, not -inf * 0 = NaN.
 extern "C" __device__ float nomad_fmul_legacy(float, float) __asm("llvm.amdgcn.fmul.legacy");   // this clang has no __builtin_amdgcn_fmul_legacy
 __device__ __forceinline__ float gelu_bf16out(float x) {
     const float x2 = fminf(x * x, 50.0f);
     float p = fmaf(x2, 1.0153758e-3f, -1.0678258e-1f);     // -log2(e) * (c2 x^2 + c1)
     p = fmaf(p, x2, -2.3011138f);                            // -log2(e) * c0
     const float e = __builtin_amdgcn_exp2f(p * x);           // 2^(-g(x) log2 e) = exp(-g(x))
-    // v_mul_legacy_f32 (0 x anything = 0): the same product as v_mul_f32 for every finite x; for x = -inf (an overflowed activation)
-    // the sigmoid is exactly 0 and the IEEE product -inf x 0 would be NaN where the erf form gives -0.  Same instruction count.
-    // (through the LLVM intrinsic, not inline asm: gfx950 needs a wait state between a transcendental instruction and the first read of
-    // its result - the compiler places it, or schedules another element's work there, for instructions it knows; an asm v_mul_legacy_f32
-    // straight behind v_rcp_f32 read the register one cycle early: 0.24 of error in tests/test_gpu_abi_errors.py, round 6)
     return nomad_fmul_legacy(x, __builtin_amdgcn_rcpf(1.0f + e));
 }
+#else
+__device__ __forceinline__ float gelu_bf16out(float x) {
+    const float a = fabsf(x);
+    const float ac = fminf(a, 13.0f);
+    float q = fmaf(ac, 3.86565109e-3f, -4.40765619e-2f);
+    q = fmaf(q, ac, -4.68018711e-1f);
+    q = fmaf(q, ac, -1.14737022f);
+    q = fmaf(q, ac, -1.00047994f);
+    return fmaf(-a, __builtin_amdgcn_exp2f(q), fmaxf(x, 0.0f));
+}
+#endif
 
 // XCD-aware bijective remap of a 1-D grid: blocks b and b+8 share an XCD (round-robin dispatch),
 // so give each XCD a contiguous run of tiles; consecutive tiles share the A row panel (n fastest).

@@ -92,23 +92,27 @@ def test_gemm_bf16_persistent_kernel_is_bit_identical(engine_for, M, N, K, epi):
             assert torch.equal(out, ref), (t, rep)
 
 
-def test_bf16_gelu_of_an_overflowed_activation_is_zero_not_nan(engine_for):
-    """x * sigmoid(g(x)) evaluated the IEEE way is -inf * 0 = NaN at x = -inf, where the erf GELU gives -0; the bf16
-    epilogues' GELU multiplies with v_mul_legacy_f32 (0 * anything = 0).  +inf stays +inf, NaN stays NaN, finite values unchanged."""
+def test_bf16_gelu_keeps_a_non_finite_activation_non_finite(engine_for):
+    """the first bf16-output GELU, x * sigmoid(g(x)), turned an activation that had overflowed to -inf into NaN where the erf form
+    gives -0.  The present form, max(x, 0) - |x| 2^q(min(|x|, 13)) (gemm_f32.hip.h gelu_bf16out), keeps every non-finite activation non-finite
+    and visible: -inf stays -inf, +inf gives inf - inf = NaN (what torch.nn.functional.gelu returns for +-inf in fp32), NaN stays NaN; finite
+    values are the GELU's to 6e-6, and a hugely negative finite one gives x 2^-81 for the exact -0."""
     g = torch.Generator().manual_seed(3)
     M, N, K = 512, 256, 128
     A = torch.randn(M, K, generator=g).bfloat16().cuda()
     W = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16().cuda()
     bias = torch.randn(N, generator=g)
-    bias[3], bias[77], bias[130] = float("-inf"), float("inf"), float("nan")
+    bias[3], bias[77], bias[130], bias[200], bias[201] = float("-inf"), float("inf"), float("nan"), -1e30, -50.0
     bias = bias.cuda()
     eng = engine_for("bf16", 63)
     ref = torch.nn.functional.gelu(A.float() @ W.float().t() + bias)
     for t in (1, 60):
         out = eng.diag_gemm_bf16(A, W, bias, None, gelu=True, tile=t).float()
-        assert (out[:, 3] == 0).all() and torch.isinf(out[:, 77]).all() and (out[:, 77] > 0).all() and torch.isnan(out[:, 130]).all()
+        assert torch.isinf(out[:, 3]).all() and (out[:, 3] < 0).all()
+        assert torch.isnan(out[:, 77]).all() and torch.isnan(out[:, 130]).all()
+        assert out[:, 200].abs().max() < 1e7 and out[:, 201].abs().max() < 1e-20   # (|x| 2^q(13), q(13) = -81.4: -1e30 -> -3e5, -50 -> -1.5e-23)
         ok = torch.ones(N, dtype=torch.bool)
-        ok[[3, 77, 130]] = False
+        ok[[3, 77, 130, 200]] = False
         assert (out[:, ok.cuda()] - ref[:, ok.cuda()]).abs().max() < 0.02
 
 
