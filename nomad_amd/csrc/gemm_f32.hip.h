@@ -161,17 +161,23 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return fmaf(-ax, poly * e, fmaxf(x, 0.0f));
 }
 
-// GELU for epilogues whose OUTPUT is bf16 (the bf16 path's GEMMs and conv0, config C5; never the fp32 or bf16x3 paths).
-// Round 6, second form: gelu(x) = max(x, 0) - |x| T(|x|) with the tail T(a) = 1 - Phi(a) = 0.5 erfc(a / sqrt 2) evaluated as 2^q(a), q a quartic
-// fitted to log2 T (minimax on the error of the RESULT, a (2^q(a) - T(a)), Lawson iteration in float64; a clamped at 13: the fit covers [0, 6], beyond which
-// a T(a) < 6e-9 and the quartic keeps falling until it turns upward at 13.5, where 2^q = 2^-81).  Maximum absolute error against the exact erf GELU 6.2e-6 over [-12, 12] evaluated in fp32 - a
-// quarter of the first form's (x sigmoid(g(x)), 2.55e-5) and a 600th of the bf16 rounding step of an activation of size 1; relative error
-// <= 3.2e-4 wherever |gelu(x)| > 0.007 - at 8 instructions, ONE of them transcendental (v_min, 4 v_fma, v_exp, v_max, v_fma), against 9 with two
-// (v_exp + v_rcp) for the first form and 13 with two for gelu_erf: 36 issue cycles per activation instead of 44 / 60 (4 per instruction, 8 per
-// transcendental) in epilogues that are bound by vector-instruction issue.  A non-finite activation stays non-finite: NaN -> NaN (through |x|), -inf -> -inf,
-// +inf -> inf - inf = NaN (torch's fp32 GELU returns NaN for both infinities); a finite x < -13 gives x 2^-81 for the exact -0.
+// GELU for epilogues whose OUTPUT is bf16 (the bf16 path's GEMMs, conv0 and pos-conv, config C5; never the fp32 or bf16x3 paths).
+// Round 6: gelu(x) = max(x, 0) - |x| T(|x|) with the tail T(a) = 1 - Phi(a) = 0.5 erfc(a / sqrt 2) evaluated as 2^q(a), q a polynomial fitted to
+// log2 T (minimax on the error of the RESULT, a (2^q(a) - T(a)), Lawson iteration in float64 over [0, 6]; beyond, a T(a) < 6e-9).  The erf
+// form's structure without its division: ONE transcendental.  Maximum absolute error against the exact erf GELU, evaluated in fp32:
+//   cubic   5.5e-5  6 instructions (3 v_fma, v_exp, v_max, v_fma)          28 issue cycles (4 per instruction, 8 per transcendental)   <- shipped
+//   quartic 6.2e-6  8 (+ v_min: the quartic turns upward at 13.5)         36
+//   round 5's x sigmoid(g(x)): 2.55e-5, 9 instructions with v_exp AND v_rcp  44;   gelu_erf: 3.3e-7, 13 with two transcendentals, 60.
+// The epilogues are bound by vector-instruction issue: configs[4] 1897 -> 1911 -> 1932 clips/s for sigmoid -> quartic -> cubic on one box, and
+// the bf16 path's distance from the fp32 path does not move (embedding rms 2.95e-4, max 1.0e-3 with all three: tools/bf16_accuracy.py,
+// profiles/r06_gelu_bf16_forms.txt) - 5.5e-5 is a 70th of the bf16 rounding step of an activation of size 1, and a tenth of the error of the
+// tanh form that passes for GELU elsewhere (4.7e-4).  Non-finite activations (NaN, +inf, -inf) give NaN (inf * 0: an overflow stays visible; torch's fp32
+// GELU does the same for -inf, and on the CPU for +inf); a hugely negative finite one gives the exact -0.
 // Every bf16 kernel uses THIS function (their results stay bit-identical to each other); every fp32 / bf16x3 epilogue keeps gelu_erf.
-#ifdef NOMAD_GELU_BF16_V1
+#ifndef NOMAD_GELU_BF16_FORM
+#define NOMAD_GELU_BF16_FORM 3
+#endif
+#if NOMAD_GELU_BF16_FORM == 1
 // The first form (rounds 5-6), kept for A/B builds (python -m nomad_amd.build --variant gelu1, NOMAD_LIB_VARIANT=gelu1): x * sigmoid(g(x)),
 // g(x) = x (c0 + c1 x^2 + c2 x^4) fitted to logit(Phi(x)), x^2 clamped at 50; v_mul_legacy_f32 so that -inf gives 0, not -inf * 0 = NaN.
 extern "C" __device__ float nomad_fmul_legacy(float, float) __asm("llvm.amdgcn.fmul.legacy");   // this clang has no __builtin_amdgcn_fmul_legacy
@@ -182,7 +188,8 @@ __device__ __forceinline__ float gelu_bf16out(float x) {
     const float e = __builtin_amdgcn_exp2f(p * x);           // 2^(-g(x) log2 e) = exp(-g(x))
     return nomad_fmul_legacy(x, __builtin_amdgcn_rcpf(1.0f + e));
 }
-#else
+#elif NOMAD_GELU_BF16_FORM == 2
+// The quartic tail (variant gelu2): 6.2e-6, 8 instructions.
 __device__ __forceinline__ float gelu_bf16out(float x) {
     const float a = fabsf(x);
     const float ac = fminf(a, 13.0f);
@@ -190,6 +197,15 @@ __device__ __forceinline__ float gelu_bf16out(float x) {
     q = fmaf(q, ac, -4.68018711e-1f);
     q = fmaf(q, ac, -1.14737022f);
     q = fmaf(q, ac, -1.00047994f);
+    return fmaf(-a, __builtin_amdgcn_exp2f(q), fmaxf(x, 0.0f));
+}
+#else
+// The cubic tail (shipped): q falls monotonically for every a >= 0 (all three derivative coefficients negative), so nothing is clamped.
+__device__ __forceinline__ float gelu_bf16out(float x) {
+    const float a = fabsf(x);
+    float q = fmaf(a, -2.48856321e-2f, -4.98820007e-1f);
+    q = fmaf(q, a, -1.129246f);
+    q = fmaf(q, a, -1.00353169f);
     return fmaf(-a, __builtin_amdgcn_exp2f(q), fmaxf(x, 0.0f));
 }
 #endif

@@ -94,9 +94,9 @@ def test_gemm_bf16_persistent_kernel_is_bit_identical(engine_for, M, N, K, epi):
 
 def test_bf16_gelu_keeps_a_non_finite_activation_non_finite(engine_for):
     """the first bf16-output GELU, x * sigmoid(g(x)), turned an activation that had overflowed to -inf into NaN where the erf form
-    gives -0.  The present form, max(x, 0) - |x| 2^q(min(|x|, 13)) (gemm_f32.hip.h gelu_bf16out), keeps every non-finite activation non-finite
-    and visible: -inf stays -inf, +inf gives inf - inf = NaN (what torch.nn.functional.gelu returns for +-inf in fp32), NaN stays NaN; finite
-    values are the GELU's to 6e-6, and a hugely negative finite one gives x 2^-81 for the exact -0."""
+    gives -0.  The present form, max(x, 0) - |x| 2^q(|x|) (gemm_f32.hip.h gelu_bf16out; q a cubic that falls monotonically), turns every
+    non-finite input into NaN (inf * 0; torch.nn.functional.gelu in fp32 does the same for -inf, and on the CPU for +inf) - an overflow stays
+    visible - and gives for finite inputs the GELU to 5.5e-5: a hugely negative activation gives the exact -0 (2^q underflows to 0)."""
     g = torch.Generator().manual_seed(3)
     M, N, K = 512, 256, 128
     A = torch.randn(M, K, generator=g).bfloat16().cuda()
@@ -108,11 +108,10 @@ def test_bf16_gelu_keeps_a_non_finite_activation_non_finite(engine_for):
     ref = torch.nn.functional.gelu(A.float() @ W.float().t() + bias)
     for t in (1, 60):
         out = eng.diag_gemm_bf16(A, W, bias, None, gelu=True, tile=t).float()
-        assert torch.isinf(out[:, 3]).all() and (out[:, 3] < 0).all()
-        assert torch.isnan(out[:, 77]).all() and torch.isnan(out[:, 130]).all()
-        assert out[:, 200].abs().max() < 1e7 and out[:, 201].abs().max() < 1e-20   # (|x| 2^q(13), q(13) = -81.4: -1e30 -> -3e5, -50 -> -1.5e-23)
+        assert torch.isnan(out[:, 3]).all() and torch.isnan(out[:, 77]).all() and torch.isnan(out[:, 130]).all()
+        assert (out[:, 200] == 0).all() and (out[:, 201] == 0).all()
         ok = torch.ones(N, dtype=torch.bool)
-        ok[[3, 77, 130, 200]] = False
+        ok[[3, 77, 130]] = False
         assert (out[:, ok.cuda()] - ref[:, ok.cuda()]).abs().max() < 0.02
 
 
@@ -378,15 +377,16 @@ def test_conv0_on_the_matrix_cores(built_lib, sd0, B, N):
         assert torch.isfinite(out).all(), name
         err = (out.double() - ref).abs()
         # one bf16 rounding of the output (half an ulp is 2^-8 |x| at the bottom of a binade) + the fp32-class conv
-        # (the matrix-core kernel drops the x_lo w_lo products: 2^-16 of the tap magnitudes, an absolute 1e-5 next to O(1) values)
-        bad = err > 1.02 * 2 ** -8 * ref.abs() + (4e-5 if name.startswith("matrix") else 1e-6)
+        # (the matrix-core kernel drops the x_lo w_lo products: 2^-16 of the tap magnitudes, an absolute 1e-5 next to O(1) values, and
+        # evaluates the bf16-output GELU, gemm_f32.hip.h gelu_bf16out: 5.5e-5 from the erf GELU; the VALU kernel keeps the erf form)
+        bad = err > 1.02 * 2 ** -8 * ref.abs() + (4e-5 + 5.6e-5 if name.startswith("matrix") else 1e-6)
         if bad.any():
             i = torch.nonzero(bad)[0].tolist()
             raise AssertionError(f"{name}: {int(bad.sum())} elements off, first at {i}: out {out[tuple(i)].item()!r} ref {ref[tuple(i)].item()!r}")
     diff = (outs[0] - outs[1]).abs()
-    assert (diff <= 2 ** -7 * outs[0].abs() + 8e-5).all(), diff.max().item()      # never more than one bf16 ulp apart (outputs near zero: the absolute 2^-16 floor)
+    assert (diff <= 2 ** -7 * outs[0].abs() + 8e-5 + 5.6e-5).all(), diff.max().item()      # never more than one bf16 ulp + the GELU forms' distance apart (outputs near zero: the absolute 2^-16 floor)
     frac = (diff > 0).float().mean().item()
-    assert frac < 0.05, frac                                                        # and different in a few per cent of the elements only
+    assert frac < 0.12, frac                                                        # and different in a minority of the elements only (5.5e-5 is a bf16 ulp where |gelu| < 0.014: the negative tail)
 
 
 @pytest.mark.parametrize("B,T", [(2, 1499), (3, 199), (2, 50), (1, 1), (1, 130), (2, 513), (1, 257), (5, 199), (3, 100), (7, 128), (4, 256)])
