@@ -50,7 +50,8 @@ def pk_path(lib: str) -> str:
 
 # A/B builds of one source-level choice, as <library>_<name>.so (NOMAD_LIB_VARIANT=<name> loads them: measurement tools only).
 VARIANTS = {"gelu1": ["-DNOMAD_GELU_BF16_FORM=1"],   # the bf16 epilogues' GELU (gemm_f32.hip.h gelu_bf16out) in its first form (sigmoid, 9 instructions)
-            "gelu2": ["-DNOMAD_GELU_BF16_FORM=2"]}   # ... and with the quartic tail (8 instructions, 6.2e-6)
+            "gelu2": ["-DNOMAD_GELU_BF16_FORM=2"],   # ... and with the quartic tail (8 instructions, 6.2e-6)
+            "gelu_tail6": ["-DNOMAD_GELU_F32_FORM=2"]}  # the fp32 / bf16x3 paths' GELU (gelu_erf) as a sextic tail (10 instructions, 2.8e-7: measured, not shipped)
 
 
 def variant_path(lib: str, name: str) -> str:

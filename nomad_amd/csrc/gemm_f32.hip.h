@@ -147,6 +147,15 @@ __device__ __forceinline__ float dgelu_erf_(float u) {
 // textbook 0.5 x (1 + erff(x / sqrt 2)) evaluated in fp32 - at 13 VALU instructions instead of 38
 // (v_rcp_f32 + v_exp_f32 + 9 FMA/MUL).  This function runs once per activation in seven conv layers, the
 // pos-conv and every fc1 epilogue: 20 M times per 4 s clip.
+// Round 6 (late) built the alternative the bf16 path now uses (gelu_bf16out below) at fp32 accuracy: max(x, 0) - |x| 2^q(min(|x|, 13)) with q a
+// SEXTIC fitted to log2 of the Gaussian tail 1 - Phi - 2.8e-7 (the rounding of the result itself) at 10 instructions with one transcendental
+// instead of 13 with two.  Alternating libraries on one box: fp32 headline 2391.1 -> 2393.7 clips/s, bf16x3 6314.8 -> 6347.8 (+0.1 % / +0.5 %):
+// these paths' epilogues are not bound by vector-instruction issue the way the bf16 GEMM's are (16x / 3x the matrix time per activation), so the
+// fp32 path keeps the bits it has had since round 1; the sextic stays buildable (form 2: `python -m nomad_amd.build --variant gelu_tail6`).
+#ifndef NOMAD_GELU_F32_FORM
+#define NOMAD_GELU_F32_FORM 1
+#endif
+#if NOMAD_GELU_F32_FORM == 1
 __device__ __forceinline__ float gelu_erf(float x) {
     const float ax = fabsf(x);
     const float t = __builtin_amdgcn_rcpf(fmaf(0.23164189f, ax, 1.0f));  // p / sqrt(2), p = 0.3275911
@@ -160,6 +169,19 @@ __device__ __forceinline__ float gelu_erf(float x) {
     const float e = __builtin_amdgcn_exp2f(-0.72134752044f * x * x);  // exp(-x^2/2) = 2^(-x^2 log2(e) / 2)
     return fmaf(-ax, poly * e, fmaxf(x, 0.0f));
 }
+#else
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float a = fabsf(x);
+    const float ac = fminf(a, 13.0f);
+    float q = fmaf(ac, 3.30926559e-5f, -7.6921843e-4f);
+    q = fmaf(q, ac, 8.08071252e-3f);
+    q = fmaf(q, ac, -5.34120984e-2f);
+    q = fmaf(q, ac, -4.5877099e-1f);
+    q = fmaf(q, ac, -1.15120173f);
+    q = fmaf(q, ac, -9.99993086e-1f);
+    return fmaf(-a, __builtin_amdgcn_exp2f(q), fmaxf(x, 0.0f));
+}
+#endif
 
 // GELU for epilogues whose OUTPUT is bf16 (the bf16 path's GEMMs, conv0 and pos-conv, config C5; never the fp32 or bf16x3 paths).
 // Round 6: gelu(x) = max(x, 0) - |x| T(|x|) with the tail T(a) = 1 - Phi(a) = 0.5 erfc(a / sqrt 2) evaluated as 2^q(a), q a polynomial fitted to

@@ -7,7 +7,7 @@
 #   smoke                    __graft_entry__.smoke()
 #   p9ab:<tiles>:<shapes>    tools/p9_ab.py on diag tiles / shapes (comma lists)
 #   c5ab:<VAR>:<v1,v2,..>:<reps>[:extra bench flags]   configs[4] bench alternating over the values of one NOMAD_* switch (diag library)
-#   c2ab:<VAR>:<v1,v2,..>:<reps>                       the same for the fp32 headline
+#   c2ab:<VAR>:<v1,v2,..>:<reps>[:extra bench flags]   the same for the fp32 headline ('+' in the extra flags stands for a space: --dtype+bf16x3)
 #   c4ab:<VAR>:<v1,v2,..>:<reps>                       the same for configs[3] (tools/bench_c4.py)
 #   bench                    default bench.py (the driver's line) -> bench.json
 #   c5table:<name>[:VAR=val,..]   rocprofv3 kernel trace of the single-stream configs[4] bench -> layer_table_<name>.json + kernel_stats_<name>.csv
@@ -45,9 +45,9 @@ for step in "$@"; do
       VAR=${S[1]}; IFS=',' read -r -a VALS <<< "${S[2]}"; REPS=${S[3]:-2}
       for rep in $(seq 1 $REPS); do for v in "${VALS[@]}"; do
         f=$OUT/${S[0]}_${VAR}_${v}_$rep.json
-        if [ ${S[0]} = c5ab ]; then env NOMAD_DIAG_LIB=1 $VAR=$v timeout 600 python bench.py $C5FLAGS ${S[4]} > $f 2> ${f%.json}.err
+        if [ ${S[0]} = c5ab ]; then env NOMAD_DIAG_LIB=1 $VAR=$v timeout 600 python bench.py $C5FLAGS ${S[4]//+/ } > $f 2> ${f%.json}.err
           echo "c5 $VAR=$v rep $rep: $(val $f value ms_per_step)" | tee -a $SUM
-        elif [ ${S[0]} = c2ab ]; then env NOMAD_DIAG_LIB=1 $VAR=$v timeout 600 python bench.py --no-cpu-baseline --no-profile --no-also --live-traffic off > $f 2> ${f%.json}.err
+        elif [ ${S[0]} = c2ab ]; then env NOMAD_DIAG_LIB=1 $VAR=$v timeout 600 python bench.py --no-cpu-baseline --no-profile --no-also --live-traffic off ${S[4]//+/ } > $f 2> ${f%.json}.err
           echo "c2 $VAR=$v rep $rep: $(val $f value ms_per_step)" | tee -a $SUM
         else env NOMAD_DIAG_LIB=1 $VAR=$v timeout 600 python3 tools/bench_c4.py > $f 2> ${f%.json}.err
           echo "c4 $VAR=$v rep $rep: $(tail -n 1 $f)" | tee -a $SUM
