@@ -294,8 +294,8 @@ __global__ __launch_bounds__(256, OCC) void conv0_mfma_gn_gelu_kernel(const floa
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float z = fmaf(acc[u][j][r], sc4[j][r], sh4[j][r]);
-                        // (round 6: the bf16-output GELU of the bf16 GEMM epilogues here too - 9 instead of 13 instructions, |error| <= 2.6e-5
-                        // against the erf form, a 150th of the output's rounding step; ABL 3 = the erf form, A/B)
+                        // (round 6: the bf16-output GELU of the bf16 GEMM epilogues here too - 6 instead of 13 instructions, |error| <= 5.5e-5
+                        // against the erf form, a 70th of the rounding step of an output of size 1; ABL 3 = the erf form, A/B)
                         const float y = ABL == 2 ? z : (ABL == 3 ? gelu_erf(z) : gelu_bf16out(z));
                         if (j < 2) lo[4 * j + r] = (bf16_t)y;
                         else hi[4 * (j - 2) + r] = (bf16_t)y;
