@@ -221,7 +221,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_p9_kernel(const GemmParams p) {
     const bool has_r = p.R != nullptr, has_b = p.bias != nullptr;
     const bool inter = INTER && !has_r && ABL != 1;   // this problem's epilogues are interleaved into the next tile's first K tile
     const bool late_hook = wr == 0 && p.p9_late != 0;   // (see NOMAD_P9_EPI_HOOK_LATE)
-    const bool wl = p.p9_wl != 0;                        // whole-line output stores (NOMAD_P9_LINE_SWAP)
+    // whole-line output stores (NOMAD_P9_LINE_SWAP): measured and left off - a run-time choice in libnomad_diag.so only.  As a run-time flag of
+    // the product it cost every hook 8 v_mov per row tile (the merge of the two paths' store registers: 6 % of a GELU hook's vector
+    // instructions, 20 % of a plain one's) and a branch per row tile.
+#ifdef NOMAD_DIAG
+    const bool wl = p.p9_wl != 0;
+#else
+    constexpr bool wl = false;
+#endif
     int n_done = 0;
 
     f32x4 acc[8][4];
