@@ -590,7 +590,7 @@ def main():
                        "one_stream": c5_one,
                        "fp32_class_scores_same_batch": c5_x3,
                        "context": "STATIC notes, not measured in this run: this forward holds a shader clock of 1997-2090 MHz of the 2400 nominal "
-                                  "(profiles/r05_clock_c5.jsonl); alone on the GPU the shipped persistent bf16 GEMM does 1016-1146 TFLOP/s on QKV, "
+                                  "(profiles/r05_clock_c5.jsonl, r06_clock_c5.jsonl); alone on the GPU the shipped persistent bf16 GEMM does 1016-1146 TFLOP/s on QKV, "
                                   "903-1018 on fc1 + GELU, 985-1108 on fc2 (192-row tiles), hipBLASLt (no epilogue) 933-967 / 949-1041 / 1115-1180 "
                                   "(profiles/r05_vendor_yardstick_bf16.jsonl, r06_gemm_bf16_p9_short_ab.jsonl); per-shape times inside the forward: "
                                   "profiles/r06_c5_layer_table_*.json; what the GEMM's epilogues cost per tile: profiles/r06_gemm_bf16_p9_epilogue_cost.txt"}
